@@ -1,0 +1,392 @@
+"""CPU restatement of the StarVector-1B im2svg hot path (TEST INFRASTRUCTURE ONLY).
+
+Every function cites the reference lines it follows (paths relative to
+/root/reference).  The decoder arithmetic lives in a third-party dependency the
+reference does not vendor at run time: ``transformers==4.49.0``
+(pyproject.toml:18), classes ``GPTBigCodeForCausalLM`` + ``GenerationMixin``;
+the dead in-tree copy ``starvector/model/gpt_bigcode/modeling_gpt_bigcode.py``
+is the line-by-line source cited below.
+
+Two precision modes:
+  * ``mode="fp32"``  - the reference's CPU float32 path (BASELINE config 1).  This is the
+    mode pinned against the reference modules by ``oracle/make_golden.py``.
+  * ``mode="bf16"``  - same arithmetic in fp32, but every tensor the reference would hold
+    in bf16 (``model_precision=bfloat16``: module outputs, residual stream, softmax
+    probabilities, logits) is rounded to bf16 at that point.  GEMM / LayerNorm / softmax
+    accumulate in fp32 exactly as ATen and flash-attn do (SURVEY.md section 8a "cast points").
+
+Plain torch CPU ops only; no imports from the product package.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+# state_dict prefixes (SURVEY.md section 8b "Weight names")
+P_VIT = "model.image_encoder.visual_encoder."
+P_LNV = "model.image_encoder.ln_vision."
+P_ADP = "model.image_projection."
+P_DEC = "model.svg_transformer.transformer.transformer."
+K_LMH = "model.svg_transformer.transformer.lm_head.weight"
+
+
+@dataclass
+class OracleConfig:
+    """Shapes of the path.  Defaults = StarVector-1B (SURVEY.md section 8 header)."""
+    image_size: int = 224
+    patch_size: int = 14
+    vit_width: int = 1024
+    vit_layers: int = 23          # image_encoder.py:52-58 (ViT-L/14 minus the last block)
+    vit_heads: int = 16
+    adapter_norm: str = "layer_norm"   # starvector_arch.py:103 ; "batch_norm" also supported
+    hidden: int = 2048
+    n_layer: int = 24
+    n_head: int = 16
+    n_inner: int = 8192
+    vocab: int = 49156            # 49152 + [PAD] + 3 added tokens (llm/starcoder.py:40-53)
+    n_positions: int = 8192
+    eos_token_id: int = 0
+    pad_token_id: int = 49152
+    ln_eps: float = 1e-5
+
+    @property
+    def n_patches(self) -> int:
+        return (self.image_size // self.patch_size) ** 2
+
+    @property
+    def query_length(self) -> int:   # starvector_base.py:85-106
+        return self.n_patches + 1
+
+    @property
+    def head_dim(self) -> int:
+        return self.hidden // self.n_head
+
+    @staticmethod
+    def tiny() -> "OracleConfig":
+        """Reduced shapes for golden fixtures / CPU tests (same op graph, same head dims)."""
+        return OracleConfig(image_size=56, patch_size=14, vit_width=128, vit_layers=2, vit_heads=2,
+                            hidden=256, n_layer=2, n_head=2, n_inner=1024, vocab=516,
+                            n_positions=128, eos_token_id=0, pad_token_id=512)
+
+
+# ----------------------------------------------------------------------------------------------
+# precision model
+# ----------------------------------------------------------------------------------------------
+def _rounder(mode: str):
+    if mode == "fp32":
+        return lambda t: t
+    if mode == "bf16":
+        return lambda t: t.to(torch.bfloat16).to(torch.float32)
+    raise ValueError(f"unknown mode {mode!r}")
+
+
+def _ln(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
+    # clip_model.py:117-124 (LayerNorm subclass computing in the weight dtype) and
+    # gpt_bigcode/modeling_gpt_bigcode.py:676,680 (nn.LayerNorm, eps 1e-5); fp32 statistics.
+    return F.layer_norm(x, (x.shape[-1],), w, b, eps)
+
+
+# ----------------------------------------------------------------------------------------------
+# deterministic weights + inputs (shared by tests, smoke and bench; values are bf16-exact so the
+# fp32 oracle and the bf16 engine consume IDENTICAL numbers)
+# ----------------------------------------------------------------------------------------------
+def make_weights(cfg: OracleConfig, seed: int = 1234, init: str = "parity") -> Dict[str, Tensor]:
+    """Seeded random-init state_dict with the reference's key names and shapes.
+
+    init="parity": fan-in scaled normals so activations stay O(1) and greedy argmax has
+    non-degenerate margins.  init="std002": N(0, 0.02) everywhere
+    (throughput runs; values do not affect speed).
+    """
+    g = torch.Generator().manual_seed(seed)
+
+    def nrm(*shape, std):
+        t = torch.empty(*shape, dtype=torch.float32).normal_(0.0, std, generator=g)
+        return t.to(torch.bfloat16).to(torch.float32)
+
+    def lin(out_f, in_f, gain=1.0):
+        std = 0.02 if init == "std002" else gain / math.sqrt(in_f)
+        return nrm(out_f, in_f, std=std), nrm(out_f, std=0.02)
+
+    def ln(*shape):
+        if init == "std002":
+            return torch.ones(*shape), torch.zeros(*shape)
+        w = (1.0 + 0.1 * torch.empty(*shape).normal_(0, 1, generator=g)).to(torch.bfloat16).to(torch.float32)
+        return w, nrm(*shape, std=0.02)
+
+    w: Dict[str, Tensor] = {}
+    Dv, ps = cfg.vit_width, cfg.patch_size
+    w[P_VIT + "conv1.weight"] = nrm(Dv, 3, ps, ps, std=(0.02 if init == "std002" else 1.0 / math.sqrt(3 * ps * ps)))
+    w[P_VIT + "class_embedding"] = nrm(Dv, std=Dv ** -0.5 if init != "std002" else 0.02)
+    w[P_VIT + "positional_embedding"] = nrm(cfg.query_length, Dv, std=(0.3 if init != "std002" else 0.02))
+    w[P_VIT + "ln_pre.weight"], w[P_VIT + "ln_pre.bias"] = ln(Dv)
+    for i in range(cfg.vit_layers):
+        p = f"{P_VIT}transformer.resblocks.{i}."
+        w[p + "ln_1.weight"], w[p + "ln_1.bias"] = ln(Dv)
+        w[p + "attn.in_proj_weight"], w[p + "attn.in_proj_bias"] = lin(3 * Dv, Dv)
+        w[p + "attn.out_proj.weight"], w[p + "attn.out_proj.bias"] = lin(Dv, Dv, gain=0.5)
+        w[p + "ln_2.weight"], w[p + "ln_2.bias"] = ln(Dv)
+        w[p + "mlp.c_fc.weight"], w[p + "mlp.c_fc.bias"] = lin(4 * Dv, Dv)
+        w[p + "mlp.c_proj.weight"], w[p + "mlp.c_proj.bias"] = lin(Dv, 4 * Dv, gain=0.5)
+    w[P_LNV + "weight"], w[P_LNV + "bias"] = ln(Dv)
+
+    D = cfg.hidden
+    w[P_ADP + "c_fc.weight"], w[P_ADP + "c_fc.bias"] = lin(2 * Dv, Dv)
+    w[P_ADP + "c_proj.weight"], w[P_ADP + "c_proj.bias"] = lin(D, 2 * Dv)
+    if cfg.adapter_norm == "layer_norm":
+        w[P_ADP + "norm.weight"], w[P_ADP + "norm.bias"] = ln(cfg.query_length, D)
+    else:
+        Q = cfg.query_length
+        w[P_ADP + "norm.weight"], w[P_ADP + "norm.bias"] = ln(Q)
+        w[P_ADP + "norm.running_mean"] = nrm(Q, std=0.1)
+        w[P_ADP + "norm.running_var"] = (1.0 + 0.2 * torch.rand(Q, generator=g)).to(torch.bfloat16).to(torch.float32)
+
+    w[P_DEC + "wte.weight"] = nrm(cfg.vocab, D, std=0.02)   # small: keeps the tied-head self-logit from
+    # dominating, so random-init greedy streams are diverse instead of one repeated token
+    w[P_DEC + "wpe.weight"] = nrm(cfg.n_positions, D, std=(0.1 if init != "std002" else 0.02))
+    kv = 2 * cfg.head_dim
+    for i in range(cfg.n_layer):
+        p = f"{P_DEC}h.{i}."
+        w[p + "ln_1.weight"], w[p + "ln_1.bias"] = ln(D)
+        w[p + "attn.c_attn.weight"], w[p + "attn.c_attn.bias"] = lin(D + kv, D)
+        w[p + "attn.c_proj.weight"], w[p + "attn.c_proj.bias"] = lin(D, D, gain=0.5)
+        w[p + "ln_2.weight"], w[p + "ln_2.bias"] = ln(D)
+        w[p + "mlp.c_fc.weight"], w[p + "mlp.c_fc.bias"] = lin(cfg.n_inner, D)
+        w[p + "mlp.c_proj.weight"], w[p + "mlp.c_proj.bias"] = lin(D, cfg.n_inner, gain=0.5)
+    w[P_DEC + "ln_f.weight"], w[P_DEC + "ln_f.bias"] = ln(D)
+    w[K_LMH] = w[P_DEC + "wte.weight"]        # tied (gpt_bigcode/modeling_gpt_bigcode.py:1145)
+    return w
+
+
+_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)   # data/util.py:33-38
+_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def synthetic_images(batch: int, size: int = 224, seed: int = 0) -> Tensor:
+    """Random-pixel images through CLIP normalisation, bf16-exact fp32."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(batch, 3, size, size, generator=g)
+    mean = torch.tensor(_CLIP_MEAN).view(1, 3, 1, 1)
+    std = torch.tensor(_CLIP_STD).view(1, 3, 1, 1)
+    return ((x - mean) / std).to(torch.bfloat16).to(torch.float32)
+
+
+# ----------------------------------------------------------------------------------------------
+# a2-a5: CLIP ViT + ln_vision
+# ----------------------------------------------------------------------------------------------
+def vit_forward(w: Dict[str, Tensor], cfg: OracleConfig, image: Tensor, mode: str = "fp32") -> Tensor:
+    """clip_model.py:181-191 (VisionTransformer.forward) with blocks clip_model.py:130-155."""
+    r = _rounder(mode)
+    B = image.shape[0]
+    Dv, H = cfg.vit_width, cfg.vit_heads
+    dh = Dv // H
+    # conv1, stride = kernel = patch, no bias (clip_model.py:174,182)
+    x = F.conv2d(image, w[P_VIT + "conv1.weight"], stride=cfg.patch_size)
+    x = r(x.reshape(B, Dv, -1).permute(0, 2, 1))                       # :183-184
+    cls = r(w[P_VIT + "class_embedding"]).expand(B, 1, Dv)              # :185
+    x = torch.cat([cls, x], dim=1)
+    x = r(x + w[P_VIT + "positional_embedding"])                        # :186
+    x = r(_ln(x, w[P_VIT + "ln_pre.weight"], w[P_VIT + "ln_pre.bias"], cfg.ln_eps))   # :187
+    scale = dh ** -0.5
+    for i in range(cfg.vit_layers):
+        p = f"{P_VIT}transformer.resblocks.{i}."
+        # x = x + attn(ln_1(x))  (clip_model.py:148-153; nn.MultiheadAttention packed in_proj)
+        h = r(_ln(x, w[p + "ln_1.weight"], w[p + "ln_1.bias"], cfg.ln_eps))
+        qkv = r(h @ w[p + "attn.in_proj_weight"].T + w[p + "attn.in_proj_bias"])
+        q, k, v = qkv.split(Dv, dim=-1)
+        q = q.view(B, -1, H, dh).transpose(1, 2)
+        k = k.view(B, -1, H, dh).transpose(1, 2)
+        v = v.view(B, -1, H, dh).transpose(1, 2)
+        s = (q @ k.transpose(-1, -2)) * scale                           # no mask (attn_mask=None)
+        pr = r(torch.softmax(s, dim=-1))
+        o = r((pr @ v).transpose(1, 2).reshape(B, -1, Dv))
+        a = r(o @ w[p + "attn.out_proj.weight"].T + w[p + "attn.out_proj.bias"])
+        x = r(x + a)
+        # x = x + c_proj(QuickGELU(c_fc(ln_2(x))))  (clip_model.py:126-128,136-140,154)
+        h = r(_ln(x, w[p + "ln_2.weight"], w[p + "ln_2.bias"], cfg.ln_eps))
+        f = r(h @ w[p + "mlp.c_fc.weight"].T + w[p + "mlp.c_fc.bias"])
+        f = r(f * torch.sigmoid(1.702 * f))
+        m = r(f @ w[p + "mlp.c_proj.weight"].T + w[p + "mlp.c_proj.bias"])
+        x = r(x + m)
+    return x
+
+
+def image_encoder_forward(w, cfg: OracleConfig, image: Tensor, mode: str = "fp32") -> Tensor:
+    """image_encoder.py:91-94 (clip branch): ln_vision(visual_encoder(image)) on all tokens."""
+    r = _rounder(mode)
+    x = vit_forward(w, cfg, image, mode)
+    return r(_ln(x, w[P_LNV + "weight"], w[P_LNV + "bias"], cfg.ln_eps))
+
+
+# ----------------------------------------------------------------------------------------------
+# a6: adapter
+# ----------------------------------------------------------------------------------------------
+def adapter_forward(w, cfg: OracleConfig, x: Tensor, mode: str = "fp32") -> Tensor:
+    """adapter.py:33-39: dropout(eval: identity) -> c_fc -> Swish -> c_proj -> norm."""
+    r = _rounder(mode)
+    h = r(x @ w[P_ADP + "c_fc.weight"].T + w[P_ADP + "c_fc.bias"])
+    h = r(h * torch.sigmoid(h))                                         # adapter.py:5-10
+    h = r(h @ w[P_ADP + "c_proj.weight"].T + w[P_ADP + "c_proj.bias"])
+    if cfg.adapter_norm == "layer_norm":
+        # nn.LayerNorm([query_length, output_size]) : statistics over the joint plane, affine
+        # weight/bias of shape [Q, D] (adapter.py:25-26)
+        Q, D = h.shape[-2], h.shape[-1]
+        h = F.layer_norm(h, (Q, D), w[P_ADP + "norm.weight"], w[P_ADP + "norm.bias"], cfg.ln_eps)
+    else:
+        # nn.BatchNorm1d(query_length) in eval: per-token affine from running stats (adapter.py:27-28)
+        rm = w[P_ADP + "norm.running_mean"].view(1, -1, 1)
+        rv = w[P_ADP + "norm.running_var"].view(1, -1, 1)
+        h = (h - rm) / torch.sqrt(rv + cfg.ln_eps) * w[P_ADP + "norm.weight"].view(1, -1, 1) \
+            + w[P_ADP + "norm.bias"].view(1, -1, 1)
+    return r(h)
+
+
+# ----------------------------------------------------------------------------------------------
+# a7-a10: StarCoder (GPTBigCode, MQA) decoder
+# ----------------------------------------------------------------------------------------------
+def _gelu_tanh(x: Tensor) -> Tensor:
+    # activation_function = gelu_pytorch_tanh (configuration_gpt_bigcode.py:107)
+    return F.gelu(x, approximate="tanh")
+
+
+def _block(w, cfg: OracleConfig, p: str, h: Tensor, k_cache: Optional[Tensor], v_cache: Optional[Tensor],
+           r) -> Tuple[Tensor, Tensor, Tensor]:
+    """GPTBigCodeBlock.forward (gpt_bigcode/modeling_gpt_bigcode.py:694-755) with MQA attention
+    (:228-285, :151-226).  h: [B,S,D].  Returns (h_out, k_all [B,L,dh], v_all [B,L,dh])."""
+    B, S, D = h.shape
+    H, dh = cfg.n_head, cfg.head_dim
+    x = r(_ln(h, w[p + "ln_1.weight"], w[p + "ln_1.bias"], cfg.ln_eps))
+    qkv = r(x @ w[p + "attn.c_attn.weight"].T + w[p + "attn.c_attn.bias"])     # :138,253
+    q, k, v = qkv.split((D, dh, dh), dim=-1)                                     # MQA: one kv head
+    if k_cache is not None:                                                      # :265-269 cache append
+        k = torch.cat([k_cache, k], dim=1)
+        v = torch.cat([v_cache, v], dim=1)
+    L = k.shape[1]
+    q = q.view(B, S, H, dh).transpose(1, 2)                                      # [B,H,S,dh]
+    s = torch.einsum("bhsd,bld->bhsl", q, k) * (dh ** -0.5)                      # scale_attn_weights
+    # causal: query at absolute position L-S+i sees keys 0..L-S+i (all-ones padding mask)
+    qi = torch.arange(L - S, L).view(S, 1)
+    kj = torch.arange(L).view(1, L)
+    s = s.masked_fill(kj > qi, float("-inf"))
+    pr = r(torch.softmax(s, dim=-1))                                             # softmax in fp32 (:156-159)
+    o = r(torch.einsum("bhsl,bld->bhsd", pr, v).transpose(1, 2).reshape(B, S, D))
+    a = r(o @ w[p + "attn.c_proj.weight"].T + w[p + "attn.c_proj.bias"])
+    h = r(h + a)
+    x = r(_ln(h, w[p + "ln_2.weight"], w[p + "ln_2.bias"], cfg.ln_eps))
+    f = r(x @ w[p + "mlp.c_fc.weight"].T + w[p + "mlp.c_fc.bias"])             # :645-660
+    f = r(_gelu_tanh(f))
+    m = r(f @ w[p + "mlp.c_proj.weight"].T + w[p + "mlp.c_proj.bias"])
+    h = r(h + m)
+    return h, k, v
+
+
+def _lm_logits(w, cfg: OracleConfig, h_last: Tensor, r) -> Tensor:
+    """ln_f + tied lm_head (gpt_bigcode/modeling_gpt_bigcode.py:1114,1258); logits are produced in
+    model precision and cast to float32 before argmax/sampling (HF GenerationMixin._sample)."""
+    x = r(_ln(h_last, w[P_DEC + "ln_f.weight"], w[P_DEC + "ln_f.bias"], cfg.ln_eps))
+    return r(x @ w[K_LMH].T)
+
+
+def decoder_prefill(w, cfg: OracleConfig, inputs_embeds: Tensor, mode: str = "fp32"):
+    """GPTBigCodeModel.forward over the 257+P prompt rows (gpt_bigcode/...:930-1134): position ids
+    0..S0-1 from the all-ones mask (:980-985), hidden = inputs_embeds + wpe (:1060-1063).
+    Returns (last-row logits [B,V] fp32, kv cache list[(k,v)])."""
+    r = _rounder(mode)
+    B, S0, D = inputs_embeds.shape
+    h = r(inputs_embeds + w[P_DEC + "wpe.weight"][:S0])
+    cache = []
+    for i in range(cfg.n_layer):
+        h, k, v = _block(w, cfg, f"{P_DEC}h.{i}.", h, None, None, r)
+        cache.append((k, v))
+    return _lm_logits(w, cfg, h[:, -1, :], r), cache
+
+
+def decoder_decode_step(w, cfg: OracleConfig, tokens: Tensor, cache, mode: str = "fp32"):
+    """One autoregressive step: wte[token] + wpe[pos] -> 24 blocks against the cache -> logits."""
+    r = _rounder(mode)
+    pos = cache[0][0].shape[1]
+    h = r(w[P_DEC + "wte.weight"][tokens] + w[P_DEC + "wpe.weight"][pos]).unsqueeze(1)
+    new_cache = []
+    for i in range(cfg.n_layer):
+        h, k, v = _block(w, cfg, f"{P_DEC}h.{i}.", h, cache[i][0], cache[i][1], r)
+        new_cache.append((k, v))
+    return _lm_logits(w, cfg, h[:, -1, :], r), new_cache
+
+
+# ----------------------------------------------------------------------------------------------
+# a1, a11: generation orchestration
+# ----------------------------------------------------------------------------------------------
+def prepare_generation_inputs(w, cfg: OracleConfig, image: Tensor, prompt_ids: Tensor, mode: str = "fp32"):
+    """starvector_base.py:203-221: encoder -> adapter -> cat(visual, wte(prompt_ids)); ones mask."""
+    r = _rounder(mode)
+    vis = adapter_forward(w, cfg, image_encoder_forward(w, cfg, image, mode), mode)
+    tok = r(w[P_DEC + "wte.weight"][prompt_ids])                        # starvector_v1.py:16-18
+    return torch.cat([vis, tok], dim=1)
+
+
+def greedy_generate(w, cfg: OracleConfig, inputs_embeds: Tensor, max_length: int,
+                    stop_ids: Optional[Sequence[int]] = None, mode: str = "fp32",
+                    return_logits: bool = False):
+    """HF GenerationMixin.generate -> _sample with do_sample=False, num_beams=1, as driven by
+    starvector_base.py:228-241,255.  Semantics:
+      * with inputs_embeds the new-token budget is max_length - S0;
+      * only NEW tokens are returned;
+      * finished rows (EOS seen) emit pad_token_id;
+      * StoppingCriteriaSub (starvector_base.py:9-20) looks at ROW 0 only and stops the batch;
+      * generation ends when every row is finished, the stop fires, or the budget is spent.
+    """
+    B, S0, _ = inputs_embeds.shape
+    budget = max_length - S0
+    if budget <= 0:
+        raise ValueError("max_length must exceed the prompt length (HF raises here)")
+    logits, cache = decoder_prefill(w, cfg, inputs_embeds, mode)
+    unfinished = torch.ones(B, dtype=torch.bool)
+    out: List[Tensor] = []
+    all_logits: List[Tensor] = []
+    stop = list(stop_ids) if stop_ids else None
+    for t in range(budget):
+        if return_logits:
+            all_logits.append(logits)
+        nxt = torch.argmax(logits.float(), dim=-1)
+        nxt = torch.where(unfinished, nxt, torch.full_like(nxt, cfg.pad_token_id))
+        out.append(nxt)
+        unfinished = unfinished & (nxt != cfg.eos_token_id)
+        fired = False
+        if stop is not None:
+            row0 = [int(o[0]) for o in out[-len(stop):]]
+            fired = row0 == stop
+        if fired or not bool(unfinished.any()) or t == budget - 1:
+            break
+        logits, cache = decoder_decode_step(w, cfg, nxt, cache, mode)
+    toks = torch.stack(out, dim=1)
+    if return_logits:
+        return toks, torch.stack(all_logits, dim=1)
+    return toks
+
+
+def top_p_filtered_probs(logits: Tensor, temperature: float, top_p: float) -> Tensor:
+    """HF TemperatureLogitsWarper then TopPLogitsWarper (min_tokens_to_keep=1) then softmax:
+    the distribution torch.multinomial draws from on the do_sample=True path
+    (starvector_base.py:230-232 defaults top_p 0.9 / temperature 1)."""
+    scores = logits.float() / temperature
+    sorted_logits, sorted_idx = torch.sort(scores, descending=False, dim=-1)
+    cum = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
+    remove = cum <= (1.0 - top_p)
+    remove[..., -1:] = False
+    remove = remove.scatter(-1, sorted_idx, remove)
+    scores = scores.masked_fill(remove, float("-inf"))
+    return scores.softmax(dim=-1)
+
+
+def generate_im2svg_tokens(w, cfg: OracleConfig, image: Tensor, prompt_ids: Tensor, max_length: int,
+                           stop_ids=None, mode: str = "fp32") -> Tensor:
+    """starvector_base.py:243-257 up to (not including) tokenizer.batch_decode:
+    cat([prompt_ids, generated]) as int64 [B, P+N]."""
+    emb = prepare_generation_inputs(w, cfg, image, prompt_ids, mode)
+    new = greedy_generate(w, cfg, emb, max_length, stop_ids, mode)
+    return torch.cat([prompt_ids, new], dim=1)
