@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: StarVector-1B im2svg, batch 32 per GPU, bf16, greedy, 224x224 synthetic images,
+random-init weights (BASELINE.json configs[1]; configs[2] = the same shard on each of N GPUs).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch already resident in HBM:
+image encoder -> adapter -> prompt embedding -> decoder prefill -> N_NEW greedy decode steps -> token ids
+(rows a1-a11 of SURVEY.md section 8a; detokenisation is host Python in the reference too and is outside
+the timed region).  Multi-GPU: the global batch is sharded by rank, no collective inside the path, ONE
+all_gather of the token streams per step (RCCL), weak scaling (32 images per GPU).
+
+Prints ONE JSON line (rank 0).  value = generated SVG tokens / second over ALL GPUs.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from oracle.hostinfo import host_cores  # noqa: E402  (cpu_baseline leg only)
+
+B_PER_GPU = 32
+PROMPT_IDS = [7, 11]          # '<svg' is 2 ids under the (gated, offline) StarCoder tokenizer: synthetic stand-ins
+
+# algorithmic bytes of the dominant kernel
+W_BYTES_PER_STEP = 2 * (24 * 42_490_112 + 4_096 + 100_671_488)     # decoder weights streamed per decode step
+HBM_PEAK_GBS = 8000.0                                              # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--new-tokens", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ttft-requests", type=int, default=20)
+    return ap.parse_args()
+
+
+def cpu_baseline(w, cfg, O):
+    """The oracle (CPU float32 restatement of the reference modules, BASELINE config 1) timed on this
+    box's host cores, bounded sample: one image, prefill + 12 greedy decode steps."""
+    torch.set_num_threads(host_cores())
+    cores = torch.get_num_threads()
+    img = O.synthetic_images(1, cfg.image_size, seed=3)
+    prompt = torch.tensor([PROMPT_IDS], dtype=torch.long)
+    t0 = time.perf_counter()
+    emb = O.prepare_generation_inputs(w, cfg, img, prompt)
+    t1 = time.perf_counter()
+    logits, cache = O.decoder_prefill(w, cfg, emb)
+    tok = logits.argmax(-1)
+    t2 = time.perf_counter()
+    n = 12
+    for _ in range(n):
+        logits, cache = O.decoder_decode_step(w, cfg, tok, cache)
+        tok = logits.argmax(-1)
+    t3 = time.perf_counter()
+    return {"value": round(n / (t3 - t2), 3), "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32, batch 1, one 224x224 image: encoder+adapter {t1 - t0:.2f}s, prefill(259)+first "
+                      f"token {t2 - t1:.2f}s (TTFT {t2 - t0:.2f}s), then {n} greedy decode steps at context 260-271",
+            "ttft_s": round(t2 - t0, 3)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+
+    import starvector_amd as sva
+    from starvector_amd.parallel import all_gather_token_streams
+    from oracle import starvector_oracle as O        # weight factory + synthetic inputs + cpu_baseline only
+
+    cfg = O.OracleConfig()
+    n_new = args.new_tokens
+    S0 = cfg.query_length + len(PROMPT_IDS)
+    t_setup = time.time()
+    w = O.make_weights(cfg, seed=1234, init="std002")
+    ec = sva.EngineConfig(max_batch=B_PER_GPU, max_seq_len=S0 + n_new)
+    eng = sva.HipEngine(ec, device=local_rank)
+    eng.load_state_dict({k: v for k, v in w.items()})          # fp32 -> bf16 + fragment packing on device
+    keep_cpu = (world == 1 and rank == 0 and not args.no_cpu_baseline)
+    if not keep_cpu:
+        del w
+    # this rank's shard of the global batch (seeded per global row -> identical under any sharding)
+    images = O.synthetic_images(B_PER_GPU * world, cfg.image_size, seed=0)[rank * B_PER_GPU:(rank + 1) * B_PER_GPU]
+    images = images.to(torch.bfloat16).to(dev)
+    prompt = torch.tensor([PROMPT_IDS] * B_PER_GPU, dtype=torch.long, device=dev)
+    t_setup = time.time() - t_setup
+
+    def step(max_new=n_new):
+        enc = eng.encode_image(images)                         # a2-a5
+        vis = eng.adapter(enc)                                 # a6
+        emb = torch.cat([vis, eng.embed_tokens(prompt)], 1)    # a1, a7
+        new = eng.generate(emb, max_length=S0 + max_new, eos_token_id=-1,      # EOS disabled:
+                           pad_token_id=cfg.pad_token_id)                      # fixed-length workload
+        out = torch.cat([prompt, new], 1)                      # starvector_base.py:256
+        if world > 1:
+            out = all_gather_token_streams(out, cfg.pad_token_id, B_PER_GPU * world)
+        return out, new.shape[1]
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    n_tok = 0
+    decode_ms, decode_steps, graph = 0.0, 0.0, True
+    for _ in range(args.steps):
+        _, n = step()
+        n_tok += n
+        tm = eng.last_timing()
+        decode_ms += tm["decode_ms"]; decode_steps += tm["decode_steps"]; graph = graph and tm["graph"]
+    sync_all()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_tokens = n_tok * B_PER_GPU * world
+    value = total_tokens / dt
+
+    # time-to-first-token: encoder + adapter + prefill + first sampled token, batch 32, p50 over requests
+    ttfts = []
+    for _ in range(args.ttft_requests):
+        torch.cuda.synchronize()
+        a = time.perf_counter()
+        step(max_new=1)
+        torch.cuda.synchronize()
+        ttfts.append((time.perf_counter() - a) * 1e3)
+    ttft_p50 = statistics.median(ttfts) if ttfts else None
+
+    # dominant kernel = skinny weight-streaming GEMM (97 launches / decode step): HIP-event time per step
+    prof = eng.profile_decode_step(B_PER_GPU, iters=5)
+    sk = prof["skinny_gemm"]
+    sk_ms = sk["ms_per_step"]
+    launches = max(sk["launches_per_step"], 1.0)
+    achieved = W_BYTES_PER_STEP / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else None
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")       # filled from the rocprofv3 --pmc pass
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get("skinny_gemm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        res = {
+            "metric": "SVG tokens/sec (whole job) + p50 time-to-first-token, StarVector-1B im2svg batch32/GPU",
+            "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic: random-pixel 224x224 images (CLIP-normalised), random-init weights N(0,0.02) seed 1234",
+            "config": {"workload": f"StarVector-1B im2svg, batch {B_PER_GPU}/GPU, bf16, greedy, 224x224, prompt rows "
+                                   f"{S0} (257 visual + {len(PROMPT_IDS)}), {n_new} new tokens/seq, EOS disabled",
+                       "global_batch": B_PER_GPU * world, "new_tokens": n_new,
+                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       "hipgraph_decode": bool(graph)},
+            "tokens_per_s_per_gpu": round(value / world, 1),
+            "ttft_p50_ms": round(ttft_p50, 2) if ttft_p50 is not None else None,
+            "decode_us_per_step": round(decode_ms / max(decode_steps, 1) * 1e3, 1),
+            "roofline": {"bound": "hbm", "kernel": "gemm_skinny_kernel (decoder weight streaming, 97 launches/step)",
+                         "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": round(W_BYTES_PER_STEP / launches),
+                         "avg_launch_us": round(sk_ms * 1e3 / launches, 2)},
+            "decode_step_profile_ms": {k: round(v["ms_per_step"], 4) for k, v in prof.items()},
+            "setup_s": round(t_setup, 1),
+        }
+        if keep_cpu:
+            res["cpu_baseline"] = cpu_baseline(w, cfg, O)
+        print(json.dumps(res), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

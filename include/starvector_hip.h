@@ -1,0 +1,157 @@
+/*
+ * libstarvector_hip.so - C ABI of the MI355X (gfx950) StarVector im2svg inference engine.
+ *
+ * Drop-in boundary for the hot path of joanrod/star-vector (paths below are relative to the
+ * reference checkout):
+ *
+ *   sv_encode_image        replaces  ImageEncoder.forward, clip branch
+ *                                    starvector/model/image_encoder/image_encoder.py:91-94
+ *                                    (VisionTransformer.forward, .../clip_model.py:181-191)
+ *   sv_adapter             replaces  Adapter.forward  starvector/model/adapters/adapter.py:33-39
+ *   sv_embed_tokens        replaces  StarVectorStarCoder._get_embeddings (wte lookup)
+ *                                    starvector/model/models/starvector_v1.py:16-18
+ *   sv_prefill / sv_decode_step
+ *                          replace   GPTBigCodeForCausalLM.forward as called by HF generate
+ *                                    (restated in starvector/model/gpt_bigcode/modeling_gpt_bigcode.py:930-1134,1241-1258)
+ *   sv_generate            replaces  svg_transformer.transformer.generate(**generation_kwargs)
+ *                                    starvector/model/models/starvector_base.py:228-241,255
+ *                                    incl. StoppingCriteriaSub (starvector_base.py:9-20)
+ *   sv_load_weight         ingests the reference state_dict keys (train/util.py:71 naming;
+ *                          SURVEY.md section 8b "Weight names")
+ *   sv_op_*                single-operator entry points used by the parity tests (one per row of
+ *                          SURVEY.md section 8a)
+ *
+ * Conventions: every pointer named dev_* / documented "device" is a HIP device pointer owned by the
+ * caller (PyTorch-ROCm tensor.data_ptr()); `stream` is a hipStream_t passed as void* (0 = default
+ * stream); all work is enqueued on it.  Functions return 0 on success or a negative SV_E* code;
+ * sv_last_error() returns the message of the calling thread's last failure.  One in-flight call
+ * per engine handle (internal mutex); handles are independent.  bf16 = IEEE bfloat16 bits.
+ */
+#ifndef STARVECTOR_HIP_H
+#define STARVECTOR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SV_ABI_VERSION 1
+
+enum {
+    SV_OK = 0,
+    SV_EINVAL = -22,      /* bad argument / shape */
+    SV_ENOMEM = -12,      /* device allocation failed */
+    SV_ENOENT = -2,       /* unknown weight name / missing weight */
+    SV_EHIP = -5,         /* HIP runtime error */
+    SV_ESTATE = -1        /* call order (e.g. generate before weights are complete) */
+};
+
+enum { SV_DTYPE_BF16 = 0, SV_DTYPE_F32 = 1 };
+enum { SV_NORM_LAYER = 0, SV_NORM_BATCH = 1 };          /* adapter_norm (adapter.py:25-28) */
+enum { SV_ACT_NONE = 0, SV_ACT_QUICKGELU = 1, SV_ACT_SWISH = 2, SV_ACT_GELU_TANH = 3 };
+
+typedef struct sv_engine sv_engine;
+typedef void* sv_stream;
+
+/* Shapes of StarVector-1B unless overridden (StarVectorConfig, starvector_arch.py:96-131) */
+typedef struct sv_config {
+    int32_t image_size;        /* 224 */
+    int32_t patch_size;        /* 14  */
+    int32_t vit_width;         /* 1024 */
+    int32_t vit_layers;        /* 23 (image_encoder.py:52-58) */
+    int32_t vit_heads;         /* 16 */
+    int32_t adapter_norm;      /* SV_NORM_LAYER */
+    int32_t hidden;            /* 2048 */
+    int32_t n_layer;           /* 24 */
+    int32_t n_head;            /* 16 */
+    int32_t n_inner;           /* 8192 */
+    int32_t vocab;             /* 49156 */
+    int32_t n_positions;       /* 8192 */
+    int32_t max_batch;         /* sequences per generate call (KV pool + workspace sizing) */
+    int32_t max_seq_len;       /* prompt + generated tokens per sequence (<= n_positions) */
+    float   ln_eps;            /* 1e-5 */
+    int32_t device;            /* HIP device ordinal */
+} sv_config;
+
+/* generate(...) arguments that reach HF generate through starvector_base.py:228-241 */
+typedef struct sv_sampling {
+    int32_t do_sample;         /* 0 = greedy argmax */
+    float   temperature;       /* used when do_sample */
+    float   top_p;             /* used when do_sample */
+    int32_t max_length;        /* HF semantics: INCLUDES the prompt rows (budget = max_length - S0) */
+    int32_t eos_token_id;
+    int32_t pad_token_id;
+    int32_t n_stop;            /* length of the row-0 stop sequence ("</svg>" ids), 0 = none */
+    const int32_t* stop_ids;   /* host pointer, n_stop entries */
+    uint64_t seed;             /* sampling RNG seed */
+    int32_t sync_every;        /* host polls the device "done" flag every this many steps (0 = 32) */
+} sv_sampling;
+
+int  sv_abi_version(void);
+const char* sv_last_error(void);
+void sv_config_default_1b(sv_config* cfg);
+
+int  sv_create(const sv_config* cfg, sv_engine** out);
+int  sv_destroy(sv_engine* e);
+
+/* Ingest one tensor of the reference state_dict (device pointer, dtype SV_DTYPE_*).  Linear weights
+ * are repacked into MFMA fragment order in library-owned memory; the caller's tensor is only read. */
+int  sv_load_weight(sv_engine* e, const char* name, const void* dev_ptr, int32_t dtype, int32_t ndim,
+                    const int64_t* shape, sv_stream stream);
+/* 0 when every tensor the path needs has been loaded; otherwise SV_ENOENT and sv_last_error() names
+ * the first missing key. */
+int  sv_weights_complete(sv_engine* e);
+
+/* image [B,3,S,S] bf16 (device) -> out [B, T, vit_width] bf16, T = (S/patch)^2 + 1 */
+int  sv_encode_image(sv_engine* e, const void* dev_image, int32_t B, void* dev_out, sv_stream stream);
+/* in [B,T,vit_width] bf16 -> out [B,T,hidden] bf16 */
+int  sv_adapter(sv_engine* e, const void* dev_in, int32_t B, void* dev_out, sv_stream stream);
+/* ids [n] int64 (device) -> out [n, hidden] bf16 */
+int  sv_embed_tokens(sv_engine* e, const int64_t* dev_ids, int32_t n, void* dev_out, sv_stream stream);
+
+/* Prompt pass over inputs_embeds [B,S0,hidden] bf16 (all-ones attention mask): fills the paged KV
+ * cache and writes the last-row logits [B, vocab] fp32 (bf16-rounded values, as the reference's
+ * bf16 lm_head produces). */
+int  sv_prefill(sv_engine* e, const void* dev_embeds, int32_t B, int32_t S0, float* dev_logits,
+                sv_stream stream);
+/* One autoregressive step for tokens [B] int32 (device) appended after the cached context. */
+int  sv_decode_step(sv_engine* e, const int32_t* dev_tokens, int32_t B, float* dev_logits, sv_stream stream);
+
+/* Full generation.  out_tokens [B, max_new] int64 (device, max_new = max_length - S0) receives the
+ * NEW tokens only (HF semantics); *n_generated = number of columns produced (<= max_new); trailing
+ * columns are left untouched.  Blocks until generation has finished (polls a device flag). */
+int  sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int32_t S0, const sv_sampling* sp,
+                 int64_t* dev_out_tokens, int32_t* n_generated, sv_stream stream);
+/* host wall-clock of the last sv_generate, 4 doubles: [0] ms prefill + first token (TTFT),
+ * [1] ms decode loop, [2] decode steps enqueued, [3] 1 if the step ran as a hipGraph replay */
+int  sv_last_timing(sv_engine* e, double* out4);
+/* HIP-event timing of one decode step by kernel class, on the cache state left by the last
+ * sv_generate / sv_prefill (bench.py roofline leg).  out: 8 doubles, [2k] = ms per step in class k,
+ * [2k+1] = launches per step; k = 0 skinny weight-streaming GEMM, 1 paged decode attention,
+ * 2 residual+LayerNorm row update, 3 unused. */
+int  sv_profile_decode_step(sv_engine* e, int32_t B, int32_t iters, double* out8, sv_stream stream);
+
+/* ---- single operators (parity tests; all device pointers, bf16 unless noted) ------------------ */
+int  sv_op_layernorm(const void* x, const void* gamma, const void* beta, void* y, int32_t M, int32_t D,
+                     float eps, sv_stream stream);
+/* y[M,N] = act(x[M,K] . W[N,K]^T + bias) (+ residual); W/bias/residual reference layouts */
+int  sv_op_linear(const void* x, const void* W, const void* bias, const void* residual, void* y,
+                  int32_t M, int32_t N, int32_t K, int32_t act, int32_t out_f32, sv_stream stream);
+/* the decode-path (M<=32 per tile, weight-streaming) implementation of the same contraction */
+int  sv_op_linear_skinny(const void* x, const void* W, const void* bias, void* y_f32, int32_t M, int32_t N,
+                         int32_t K, int32_t splitk, sv_stream stream);
+/* q,k,v token-major [B,S,H*D] / [B,S,Hkv*D]; out [B,S,H*D] */
+int  sv_op_attention(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t S,
+                     int32_t H, int32_t Hkv, int32_t head_dim, int32_t causal, float scale,
+                     sv_stream stream);
+int  sv_op_plane_layernorm(const void* x, const void* gamma, const void* beta, void* y, int32_t B,
+                           int32_t QD, float eps, sv_stream stream);
+int  sv_op_argmax(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t* out, sv_stream stream);
+int  sv_op_sample_top_p(const float* logits, int32_t B, int32_t V, int32_t ld, float temperature,
+                        float top_p, uint64_t seed, int32_t step, int32_t* out, sv_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STARVECTOR_HIP_H */

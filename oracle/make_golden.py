@@ -31,7 +31,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 sys.path.insert(0, ROOT)
 
-from oracle import starvector_oracle as O  # noqa: E402
+from oracle import starvector_oracle as O
+from oracle.hostinfo import host_cores  # noqa: E402
 
 REF = os.environ.get("STARVECTOR_REFERENCE", "/root/reference")
 GOLD = os.path.join(ROOT, "tests", "golden")
@@ -204,7 +205,7 @@ def run_stop_case(write):
 def main():
     write = "--no-write" not in sys.argv
     torch.manual_seed(0)
-    torch.set_num_threads(os.cpu_count() or 8)
+    torch.set_num_threads(host_cores())
     run_case("tiny_b3", O.OracleConfig.tiny(), seed=1234, batch=3, n_new=24, write=write)
     import dataclasses
     run_case("tiny_bn_b2", dataclasses.replace(O.OracleConfig.tiny(), adapter_norm="batch_norm"),

@@ -1,0 +1,114 @@
+"""ctypes binding of libstarvector_hip.so (include/starvector_hip.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load this module raises,
+and every public entry point of the package goes through it.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libstarvector_hip.so")
+HEADER_PATH = os.path.normpath(os.path.join(HERE, "..", "include", "starvector_hip.h"))
+
+SV_DTYPE_BF16, SV_DTYPE_F32 = 0, 1
+SV_NORM_LAYER, SV_NORM_BATCH = 0, 1
+ACT = {"none": 0, "quickgelu": 1, "swish": 2, "gelu_tanh": 3}
+
+
+class SvConfig(C.Structure):
+    _fields_ = [
+        ("image_size", C.c_int32), ("patch_size", C.c_int32), ("vit_width", C.c_int32),
+        ("vit_layers", C.c_int32), ("vit_heads", C.c_int32), ("adapter_norm", C.c_int32),
+        ("hidden", C.c_int32), ("n_layer", C.c_int32), ("n_head", C.c_int32), ("n_inner", C.c_int32),
+        ("vocab", C.c_int32), ("n_positions", C.c_int32), ("max_batch", C.c_int32),
+        ("max_seq_len", C.c_int32), ("ln_eps", C.c_float), ("device", C.c_int32),
+    ]
+
+
+class SvSampling(C.Structure):
+    _fields_ = [
+        ("do_sample", C.c_int32), ("temperature", C.c_float), ("top_p", C.c_float),
+        ("max_length", C.c_int32), ("eos_token_id", C.c_int32), ("pad_token_id", C.c_int32),
+        ("n_stop", C.c_int32), ("stop_ids", C.POINTER(C.c_int32)), ("seed", C.c_uint64),
+        ("sync_every", C.c_int32),
+    ]
+
+
+_P = C.c_void_p
+_I = C.c_int32
+_F = C.c_float
+
+# name -> (restype, argtypes): exactly the prototypes of include/starvector_hip.h
+PROTOTYPES = {
+    "sv_abi_version": (_I, []),
+    "sv_last_error": (C.c_char_p, []),
+    "sv_config_default_1b": (None, [C.POINTER(SvConfig)]),
+    "sv_create": (_I, [C.POINTER(SvConfig), C.POINTER(_P)]),
+    "sv_destroy": (_I, [_P]),
+    "sv_load_weight": (_I, [_P, C.c_char_p, _P, _I, _I, C.POINTER(C.c_int64), _P]),
+    "sv_weights_complete": (_I, [_P]),
+    "sv_encode_image": (_I, [_P, _P, _I, _P, _P]),
+    "sv_adapter": (_I, [_P, _P, _I, _P, _P]),
+    "sv_embed_tokens": (_I, [_P, _P, _I, _P, _P]),
+    "sv_prefill": (_I, [_P, _P, _I, _I, _P, _P]),
+    "sv_decode_step": (_I, [_P, _P, _I, _P, _P]),
+    "sv_generate": (_I, [_P, _P, _I, _I, C.POINTER(SvSampling), _P, C.POINTER(_I), _P]),
+    "sv_last_timing": (_I, [_P, C.POINTER(C.c_double)]),
+    "sv_profile_decode_step": (_I, [_P, _I, _I, C.POINTER(C.c_double), _P]),
+    "sv_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
+    "sv_op_linear": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sv_op_linear_skinny": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sv_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
+    "sv_op_plane_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
+    "sv_op_argmax": (_I, [_P, _I, _I, _I, _P, _P]),
+    "sv_op_sample_top_p": (_I, [_P, _I, _I, _I, _F, _F, C.c_uint64, _I, _P, _P]),
+}
+
+_lib = None
+
+
+class StarVectorHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load the HIP library or raise.  Never falls back to another implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise StarVectorHipError(
+            f"{LIB_PATH} is missing: the HIP engine has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `python star-vector_amd/build.py`); "
+            "there is no CPU/PyTorch fallback for this path.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise StarVectorHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in PROTOTYPES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise StarVectorHipError(f"{LIB_PATH} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sv_abi_version() != 1:
+        raise StarVectorHipError(f"ABI version mismatch: library {lib.sv_abi_version()}, binding 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    """Map C return codes onto the exceptions the reference's callers already catch
+    (serve/model_worker.py:183-207 handles ValueError / RuntimeError)."""
+    if rc == 0:
+        return
+    msg = load().sv_last_error().decode("utf-8", "replace")
+    text = f"{what}: {msg}" if what else msg
+    if rc == -22:
+        raise ValueError(text)
+    if rc == -2:
+        raise KeyError(text)
+    raise StarVectorHipError(f"{text} (code {rc})")

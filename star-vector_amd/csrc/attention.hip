@@ -1,0 +1,416 @@
+// Attention kernels for gfx950.
+//
+//  * attn_prefill_kernel : flash-style forward (no S x S matrix) for the ViT's bidirectional MHSA
+//    (clip_model.py:130-155, nn.MultiheadAttention 16 x 64) and the decoder's causal MQA prefill
+//    (gpt_bigcode/modeling_gpt_bigcode.py:151-285).  v_mfma_f32_32x32x16_bf16 with the "swapped"
+//    products  S^T = K.Q^T  and  O^T = V^T.P^T : every lane owns ONE query row, so the online-softmax
+//    statistics and the rescale factor are lane-local (one cross-half shuffle per tile), and P feeds the
+//    second MFMA straight from registers (the key order inside a 16-key k-step is a free permutation,
+//    applied when V is transposed into LDS).
+//  * attn_decode_kernel  : single-token MQA/GQA attention over the PAGED KV cache (HBM-bound).  The
+//    16 query heads that share one KV head form the N=16 side of v_mfma_f32_16x16x32_bf16, so every
+//    K/V byte is read once for all heads.  K and V^T live in the cache in MFMA fragment order: each
+//    wave-load is one contiguous 1 KiB.  The kernel also finishes the c_attn split-K reduction
+//    (+bias, bf16 round) for its sequence and appends the new token's K/V to the cache.
+#include "kernels.h"
+
+namespace sv {
+
+__device__ __forceinline__ int swap23(int x) { return (x & ~0xC) | ((x & 4) << 1) | ((x & 8) >> 1); }
+
+// ------------------------------------------------------------------------------------------------
+// prefill
+// ------------------------------------------------------------------------------------------------
+template <int D, int HPB>
+__global__ __launch_bounds__(256) void attn_prefill_kernel(AttnPrefillArgs p) {
+    constexpr int KSTR = D + 8;          // K tile row stride (elements): +16 B pad -> conflict-free b128
+    constexpr int VSTR = 64 + 8;         // V^T tile row stride
+    constexpr int NKS = D / 16;          // k-steps of the QK^T product
+    constexpr int NDV = D / 32;          // 32-wide dv tiles of the output
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * KSTR];
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[D * VSTR];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane >> 5;
+    const int b = blockIdx.z;
+    const int S = p.S;
+    int head, q0, qblock_end;
+    if (HPB == 1) {
+        head = blockIdx.y;
+        q0 = blockIdx.x * 128 + wave * 32;
+        qblock_end = blockIdx.x * 128 + 128;
+    } else {
+        head = blockIdx.y * HPB + wave;
+        q0 = blockIdx.x * 32;
+        qblock_end = q0 + 32;
+    }
+    const int kvh = (HPB == 1 ? head : blockIdx.y * HPB) / p.kv_group;
+    const int qabs = q0 + (lane & 31);
+    const int qrow = qabs < S ? qabs : S - 1;
+
+    // Q fragments (B operand): lane (q = l&31, c = l>>5) holds Q[q][16 s + 8 c .. +8]
+    bf16x8 qf[NKS];
+    {
+        const bf16_t* qp = p.q + ((size_t)b * S + qrow) * p.q_row_stride + (size_t)head * p.q_head_stride + c * 8;
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) qf[s] = as_frag(*reinterpret_cast<const uint4*>(qp + s * 16));
+    }
+
+    f32x16 accO[NDV];
+#pragma unroll
+    for (int t = 0; t < NDV; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accO[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    int last = (qblock_end < S ? qblock_end : S) - 1;        // last query row of the block
+    const int ntiles = p.causal ? (last / 64 + 1) : ((S + 63) / 64);
+    const bf16_t* kbase = p.k + (size_t)b * S * p.kv_row_stride + (size_t)kvh * p.kv_head_stride;
+    const bf16_t* vbase = p.v + (size_t)b * S * p.kv_row_stride + (size_t)kvh * p.kv_head_stride;
+
+    for (int kt = 0; kt < ntiles; ++kt) {
+        if (kt) __syncthreads();
+        // K tile: 64 keys x D, row-major
+        for (int idx = tid; idx < 64 * (D / 8); idx += 256) {
+            const int row = idx / (D / 8), ch = idx % (D / 8);
+            int key = kt * 64 + row;
+            key = key < S ? key : S - 1;
+            const uint4 v = *reinterpret_cast<const uint4*>(kbase + (size_t)key * p.kv_row_stride + ch * 8);
+            *reinterpret_cast<uint4*>(Ks + row * KSTR + ch * 8) = v;
+        }
+        // V tile transposed: lane <-> key, Vt[dv][swap23(key)]
+        {
+            int key = kt * 64 + lane;
+            key = key < S ? key : S - 1;
+            const int col = swap23(lane);
+            for (int ch = wave; ch < D / 8; ch += 4) {
+                const uint4 v = *reinterpret_cast<const uint4*>(vbase + (size_t)key * p.kv_row_stride + ch * 8);
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    Vt[(ch * 8 + e) * VSTR + col] = (bf16_t)(w[e >> 1] >> ((e & 1) * 16));
+            }
+        }
+        __syncthreads();
+
+        // S^T = K . Q^T : two 32-key sub-tiles
+        f32x16 accS[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accS[j][r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (32 * j + (lane & 31)) * KSTR + 16 * s + 8 * c);
+                accS[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], accS[j], 0, 0, 0);
+            }
+        }
+        // mask + online softmax; lane holds keys kt*64 + 32 j + (r&3) + 8 (r>>2) + 4 c of its query row
+        float mt = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 64 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * c;
+                const bool ok = key < S && (!p.causal || key <= qabs);
+                const float sc = ok ? accS[j][r] * p.scale : -INFINITY;
+                accS[j][r] = sc;
+                mt = fmaxf(mt, sc);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __expf(m_run - m_new);
+        float ls = 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __expf(accS[j][r] - m_new);
+                accS[j][r] = pv;
+                ls += pv;
+            }
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+        // P fragments (B operand of O^T = V^T.P^T): element e of k-step (j, s2) = accS[j][8 s2 + e]
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                uint4 u;
+                u.x = pack2bf(accS[j][8 * s2 + 0], accS[j][8 * s2 + 1]);
+                u.y = pack2bf(accS[j][8 * s2 + 2], accS[j][8 * s2 + 3]);
+                u.z = pack2bf(accS[j][8 * s2 + 4], accS[j][8 * s2 + 5]);
+                u.w = pack2bf(accS[j][8 * s2 + 6], accS[j][8 * s2 + 7]);
+                pf[j][s2] = as_frag(u);
+            }
+#pragma unroll
+        for (int t = 0; t < NDV; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accO[t][r] *= alpha;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const bf16x8 vf = *reinterpret_cast<const bf16x8*>(
+                        Vt + (32 * t + (lane & 31)) * VSTR + 32 * j + 16 * s2 + 8 * c);
+                    accO[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[j][s2], accO[t], 0, 0, 0);
+                }
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qabs < S) {
+        bf16_t* op = p.o + ((size_t)b * S + qabs) * p.o_row_stride + (size_t)head * D;
+#pragma unroll
+        for (int t = 0; t < NDV; ++t)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                uint2 o;
+                o.x = pack2bf(accO[t][rg * 4 + 0] * inv, accO[t][rg * 4 + 1] * inv);
+                o.y = pack2bf(accO[t][rg * 4 + 2] * inv, accO[t][rg * 4 + 3] * inv);
+                *reinterpret_cast<uint2*>(op + 32 * t + 8 * rg + 4 * c) = o;
+            }
+    }
+}
+
+void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st) {
+    const bool mqa4 = (a.kv_group % 4 == 0) && (a.H % 4 == 0);
+    if (mqa4) {
+        dim3 grid((a.S + 31) / 32, a.H / 4, a.B);
+        if (a.head_dim == 128) attn_prefill_kernel<128, 4><<<grid, 256, 0, st>>>(a);
+        else attn_prefill_kernel<64, 4><<<grid, 256, 0, st>>>(a);
+    } else {
+        dim3 grid((a.S + 127) / 128, a.H, a.B);
+        if (a.head_dim == 128) attn_prefill_kernel<128, 1><<<grid, 256, 0, st>>>(a);
+        else attn_prefill_kernel<64, 1><<<grid, 256, 0, st>>>(a);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// paged KV cache, fragment order.  One page = 64 tokens of one layer (one KV head):
+//   K part  [4 key-groups of 16][D/32 k-steps][64 lanes][8] : lane (key = l&15, c = l>>4) holds
+//           K[16 kg + key][32 s + 8 c + e]                         (A operand of S^T = K.Q^T)
+//   V part  [2 key-groups of 32][D/16 dv-tiles][64 lanes][8] : lane (dv = l&15, c = l>>4) holds
+//           V[32 g + 16 (e>>2) + 4 c + (e&3)][16 t + dv]            (A operand of O^T = V^T.P^T)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ size_t kv_k_offset(int D, int t64, int d) {
+    const int kg = t64 >> 4, key = t64 & 15, s = d >> 5, c = (d >> 3) & 3, e = d & 7;
+    return ((size_t)((kg * (D >> 5) + s) * 64 + c * 16 + key)) * 16 + e * 2;
+}
+__device__ __forceinline__ size_t kv_v_offset(int D, int t64, int dv) {
+    const int g = t64 >> 5, k32 = t64 & 31, u = k32 >> 4, c = (k32 >> 2) & 3, r = k32 & 3;
+    const int e = 4 * u + r, t = dv >> 4, dl = dv & 15;
+    return (size_t)64 * D * 2 + ((size_t)((g * (D >> 4) + t) * 64 + c * 16 + dl)) * 16 + e * 2;
+}
+
+__global__ void kv_write_prefill_kernel(const bf16_t* __restrict__ qkv, int row_stride, int k_off, int v_off,
+                                        char* __restrict__ pool, const int32_t* __restrict__ table,
+                                        int max_pages, int B, int S0, int D) {
+    const int NC = D >> 3;
+    const size_t total = (size_t)B * S0 * NC * 2;
+    const int page_bytes = kv_page_bytes(D);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % NC);
+        size_t r = i / NC;
+        const int isv = (int)(r & 1);
+        r >>= 1;
+        const int tok = (int)(r % S0), b = (int)(r / S0);
+        const bf16_t* src = qkv + ((size_t)b * S0 + tok) * row_stride + (isv ? v_off : k_off) + ch * 8;
+        const uint4 v = *reinterpret_cast<const uint4*>(src);
+        char* page = pool + (size_t)table[b * max_pages + (tok >> 6)] * page_bytes;
+        const int t64 = tok & 63;
+        if (!isv) {
+            *reinterpret_cast<uint4*>(page + kv_k_offset(D, t64, ch * 8)) = v;
+        } else {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                *reinterpret_cast<bf16_t*>(page + kv_v_offset(D, t64, ch * 8 + e)) =
+                    (bf16_t)(w[e >> 1] >> ((e & 1) * 16));
+        }
+    }
+}
+void launch_kv_write_prefill(const bf16_t* qkv, int row_stride, int k_off, int v_off, char* pool_layer,
+                             const int32_t* block_table, int max_pages, int B, int S0, int head_dim,
+                             hipStream_t st) {
+    size_t total = (size_t)B * S0 * (head_dim / 8) * 2;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    kv_write_prefill_kernel<<<blocks, 256, 0, st>>>(qkv, row_stride, k_off, v_off, pool_layer, block_table,
+                                                     max_pages, B, S0, head_dim);
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode
+// ------------------------------------------------------------------------------------------------
+#define AD_WAVES 8
+
+template <int D>
+__global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeArgs p) {
+    constexpr int NKS = D / 32;          // k-steps of S^T (over head_dim)
+    constexpr int NDV = D / 16;          // dv tiles of O^T
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* q_s = reinterpret_cast<bf16_t*>(smem);                       // [16][D]
+    bf16_t* kv_new = q_s + 16 * D;                                       // [2][D]
+    float* m_s = reinterpret_cast<float*>(kv_new + 2 * D);               // [AD_WAVES][16]
+    float* l_s = m_s + AD_WAVES * 16;                                    // [AD_WAVES][16]
+    float* O_s = l_s + AD_WAVES * 16;                                    // [AD_WAVES][16][D]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x;
+    const int H = p.H;
+    const int HD = H * D;
+
+    // finish the c_attn GEMM for this row: sum split-K slabs (fixed order) + bias, round to bf16
+    for (int n = tid; n < 16 * D + 2 * D; n += AD_WAVES * 64) {
+        // index space: [0,16*D) = q rows (rows >= H are zero), then k_new, v_new
+        int col;
+        if (n < 16 * D) col = (n / D) < H ? n : -1;
+        else col = HD + (n - 16 * D);
+        float v = 0.f;
+        if (col >= 0) {
+            for (int sp = 0; sp < p.splitk; ++sp) v += p.ws[((size_t)sp * p.rows_ws + b) * p.ldws + col];
+            v += bf2f(p.bias[col]);
+        }
+        q_s[n] = f2bf(v);                // q_s and kv_new are contiguous
+    }
+    __syncthreads();
+
+    const int pos = p.positions[b];
+    const int page_bytes = kv_page_bytes(D);
+    const int32_t* table = p.block_table + (size_t)b * p.max_pages;
+    // append the new token's K / V to the cache
+    if (tid < 2 * D) {
+        char* page = p.pool_layer + (size_t)table[pos >> 6] * page_bytes;
+        const int t64 = pos & 63;
+        const int d = tid < D ? tid : tid - D;
+        const size_t off = tid < D ? kv_k_offset(D, t64, d) : kv_v_offset(D, t64, d);
+        *reinterpret_cast<bf16_t*>(page + off) = kv_new[tid];
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    const int hd = lane & 15, c = lane >> 4;
+    bf16x8 qf[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s)
+        qf[s] = *reinterpret_cast<const bf16x8*>(q_s + hd * D + 32 * s + 8 * c);
+
+    f32x4 accO[NDV];
+#pragma unroll
+    for (int t = 0; t < NDV; ++t) accO[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int L = pos + 1;
+    const int ngroups = (L + 31) >> 5;
+    for (int g = wave; g < ngroups; g += AD_WAVES) {
+        const int t0 = g << 5;
+        const char* page = p.pool_layer + (size_t)table[t0 >> 6] * page_bytes;
+        const int half = (t0 >> 5) & 1;
+        u32x4 kf[2][NKS], vf[NDV];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int s = 0; s < NKS; ++s)
+                kf[u][s] = *reinterpret_cast<const u32x4*>(page + ((size_t)(((half * 2 + u) * NKS + s) * 64 + lane)) * 16);
+#pragma unroll
+        for (int t = 0; t < NDV; ++t)
+            vf[t] = *reinterpret_cast<const u32x4*>(page + (size_t)64 * D * 2 + ((size_t)((half * NDV + t) * 64 + lane)) * 16);
+
+        f32x4 accS[2];
+        float sc[2][4];
+        float mt = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            accS[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < NKS; ++s)
+                accS[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag4(kf[u][s]), qf[s], accS[u], 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = t0 + 16 * u + 4 * c + r;
+                sc[u][r] = key <= pos ? accS[u][r] * p.scale : -INFINITY;
+                mt = fmaxf(mt, sc[u][r]);
+            }
+        }
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __expf(m_run - m_new);
+        float pr[8];
+        float ls = 0.f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pr[4 * u + r] = __expf(sc[u][r] - m_new);
+                ls += pr[4 * u + r];
+            }
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+        const bf16x8 pf = as_frag(pack8(pr));
+#pragma unroll
+        for (int t = 0; t < NDV; ++t) {
+            accO[t] = accO[t] * alpha;
+            accO[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag4(vf[t]), pf, accO[t], 0, 0, 0);
+        }
+    }
+
+    // combine the waves' partial (m, l, O)
+    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    if (c == 0) {
+        m_s[wave * 16 + hd] = m_run;
+        l_s[wave * 16 + hd] = l_tot;
+    }
+#pragma unroll
+    for (int t = 0; t < NDV; ++t)
+        *reinterpret_cast<float4*>(O_s + ((size_t)(wave * 16 + hd)) * D + 16 * t + 4 * c) =
+            make_float4(accO[t][0], accO[t][1], accO[t][2], accO[t][3]);
+    __syncthreads();
+    for (int idx = tid; idx < HD; idx += AD_WAVES * 64) {
+        const int h = idx / D, dv = idx % D;
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < AD_WAVES; ++w) M = fmaxf(M, m_s[w * 16 + h]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int w = 0; w < AD_WAVES; ++w) {
+            const float mw = m_s[w * 16 + h];
+            const float f = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+            num += f * O_s[((size_t)(w * 16 + h)) * D + dv];
+            den += f * l_s[w * 16 + h];
+        }
+        p.out_xp[xp_index(b >> 5, p.out_KS, b & 31, idx)] = f2bf(num / den);
+    }
+}
+
+static size_t attn_decode_smem(int D) {
+    return (size_t)(16 * D + 2 * D) * 2 + (size_t)AD_WAVES * 16 * 4 * 2 + (size_t)AD_WAVES * 16 * D * 4;
+}
+
+// dynamic LDS above the 64 KiB default needs an explicit opt-in; done once at engine creation
+// (never inside a stream capture)
+int init_attention_kernels() {
+    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_decode_kernel<128>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_decode_smem(128));
+    if (r != hipSuccess) return (int)r;
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_decode_kernel<64>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_decode_smem(64));
+    return (int)r;
+}
+
+void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
+    const size_t smem = attn_decode_smem(a.head_dim);
+    if (a.head_dim == 128)
+        attn_decode_kernel<128><<<a.B, AD_WAVES * 64, smem, st>>>(a);
+    else
+        attn_decode_kernel<64><<<a.B, AD_WAVES * 64, smem, st>>>(a);
+}
+
+}  // namespace sv

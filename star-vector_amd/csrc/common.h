@@ -1,0 +1,80 @@
+// Shared device helpers for the StarVector gfx950 kernels (CDNA4, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 MFMA accumulator
+typedef __attribute__((ext_vector_type(4))) float f32x4;     // 16x16 MFMA accumulator
+
+#define SV_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
+
+// round-to-nearest-even, NaN kept quiet: identical to torch's float -> bfloat16 cast
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
+
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// 8 bf16 <-> 8 floats
+__device__ __forceinline__ void unpack8(const uint4& u, float* f) {
+    f[0] = __uint_as_float(u.x << 16); f[1] = __uint_as_float(u.x & 0xffff0000u);
+    f[2] = __uint_as_float(u.y << 16); f[3] = __uint_as_float(u.y & 0xffff0000u);
+    f[4] = __uint_as_float(u.z << 16); f[5] = __uint_as_float(u.z & 0xffff0000u);
+    f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 u;
+    u.x = pack2bf(f[0], f[1]); u.y = pack2bf(f[2], f[3]);
+    u.z = pack2bf(f[4], f[5]); u.w = pack2bf(f[6], f[7]);
+    return u;
+}
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native 16-byte vector (nontemporal loads)
+__device__ __forceinline__ bf16x8 as_frag(const uint4& u) { return __builtin_bit_cast(bf16x8, u); }
+__device__ __forceinline__ bf16x8 as_frag4(const u32x4& u) { return __builtin_bit_cast(bf16x8, u); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// activations used by the path's fused epilogues
+enum { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_SWISH = 2, ACT_GELU_TANH = 3 };
+
+__device__ __forceinline__ float sv_act(float x, int act) {
+    switch (act) {
+        case ACT_QUICKGELU: return x / (1.0f + __expf(-1.702f * x));         // clip_model.py:126-128
+        case ACT_SWISH:     return x / (1.0f + __expf(-x));                   // adapter.py:5-10
+        case ACT_GELU_TANH: {                                                 // gelu_pytorch_tanh
+            const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+            float t = tanhf(k0 * (x + k1 * x * x * x));
+            return 0.5f * x * (1.0f + t);
+        }
+        default: return x;
+    }
+}
+
+// Packed ("fragment order") layouts --------------------------------------------------------------
+// Weight  W[N][K]  ->  Wp[N/32][K/16][64 lanes][8]:  lane l holds W[nt*32 + (l&31)][ks*16 + (l>>5)*8 + e]
+//   = the A operand of v_mfma_f32_32x32x16_bf16; one 1 KiB wave-load per (n-tile, k-step).
+// Skinny activations x[32][K] -> xp[K/16][64][8]:    lane l holds x[l&31][ks*16 + (l>>5)*8 + e]
+//   = the B operand of the same instruction.
+__device__ __forceinline__ size_t xp_index(int mt, int KS, int m, int k) {
+    // element offset of x[mt*32 + m][k] in a packed activation buffer with KS = K/16 k-steps
+    return ((((size_t)mt * KS + (k >> 4)) * 64) + (((k >> 3) & 1) * 32) + m) * 8 + (k & 7);
+}

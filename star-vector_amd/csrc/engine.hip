@@ -1,0 +1,983 @@
+// Host driver + C ABI of libstarvector_hip.so (see include/starvector_hip.h for the contract and the
+// reference lines each entry point replaces).  Owns: repacked weights, workspaces, the paged KV pool
+// and its page allocator, the generation loop (hipGraph-captured decode step, device-side stop flag).
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/starvector_hip.h"
+#include "kernels.h"
+
+using namespace sv;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHECK(x)                                                                              \
+    do {                                                                                         \
+        hipError_t _e = (x);                                                                     \
+        if (_e != hipSuccess)                                                                    \
+            return fail(SV_EHIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+#define SVCHECK(x)          \
+    do {                    \
+        int _r = (x);       \
+        if (_r) return _r;  \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// small utility kernels local to the driver
+// ------------------------------------------------------------------------------------------------
+__global__ void fill_i32_kernel(int32_t* p, int32_t v, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+__global__ void add_i32_kernel(int32_t* p, int32_t v, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] += v;
+}
+__global__ void tokens_to_i64_kernel(const int32_t* src, int ld, int64_t* dst, int B, int ncols, int dst_ld) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B * ncols) {
+        int b = i / ncols, t = i % ncols;
+        dst[(size_t)b * dst_ld + t] = src[(size_t)b * ld + t];
+    }
+}
+// row-major [M][K] -> skinny fragment order
+__global__ void pack_rows_kernel(const bf16_t* x, int ldx, bf16_t* xp, int M, int K) {
+    const int NC = K >> 3;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M * NC; i += gridDim.x * blockDim.x) {
+        const int c = i % NC, m = i / NC;
+        *reinterpret_cast<uint4*>(xp + xp_index(m >> 5, K >> 4, m & 31, c * 8)) =
+            *reinterpret_cast<const uint4*>(x + (size_t)m * ldx + c * 8);
+    }
+}
+__global__ void reduce_partials_kernel(const float* ws, int splitk, int rows_ws, int ldws, const bf16_t* bias,
+                                       float* y, int M, int N) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M * N; i += gridDim.x * blockDim.x) {
+        const int n = i % N, m = i / N;
+        float v = 0.f;
+        for (int s = 0; s < splitk; ++s) v += ws[((size_t)s * rows_ws + m) * ldws + n];
+        if (bias) v += bf2f(bias[n]);
+        y[(size_t)m * N + n] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// engine state
+// ------------------------------------------------------------------------------------------------
+struct Linear {
+    bf16_t* Wp = nullptr;
+    bf16_t* bias = nullptr;
+    int N = 0, K = 0, Npad = 0, Kpad = 0;
+    int splitk = 1;       // decode-path split-K factor
+};
+struct LNp { bf16_t* g = nullptr; bf16_t* b = nullptr; };
+struct VitLayer { LNp ln1, ln2; Linear in_proj, out_proj, c_fc, c_proj; };
+struct DecLayer { LNp ln1, ln2; Linear c_attn, c_proj, c_fc, c_proj2; };
+
+enum SlotKind { SLOT_LINEAR_W, SLOT_RAW, SLOT_WTE };
+struct Slot {
+    SlotKind kind;
+    Linear* lin = nullptr;
+    bf16_t** raw = nullptr;
+    size_t numel = 0;
+    bool loaded = false;
+    bool required = true;
+};
+
+struct sv_engine {
+    sv_config cfg;
+    std::mutex mu;
+    int T = 0, NP = 0, dh = 0, vdh = 0;
+    int conv_K = 0;
+
+    // weights
+    Linear conv1;
+    bf16_t *cls = nullptr, *pos = nullptr;
+    LNp ln_pre, ln_vision;
+    std::vector<VitLayer> vit;
+    Linear ad_fc, ad_proj;
+    bf16_t *ad_w = nullptr, *ad_b = nullptr, *ad_rm = nullptr, *ad_rv = nullptr;
+    bf16_t *wte = nullptr, *wpe = nullptr;
+    Linear lm_head;
+    bool lm_head_explicit = false;
+    LNp ln_f;
+    std::vector<DecLayer> dec;
+    std::unordered_map<std::string, Slot> slots;
+    std::vector<void*> allocs;
+
+    // vision workspaces (rows = max_batch * T)
+    bf16_t *patches = nullptr, *patch_out = nullptr, *vx = nullptr, *vln = nullptr, *vqkv = nullptr,
+           *vattn = nullptr, *vmlp = nullptr, *a1 = nullptr, *a2 = nullptr;
+    // prefill workspaces (lazily grown)
+    size_t pf_rows = 0;
+    bf16_t *ph = nullptr, *pln = nullptr, *pqkv = nullptr, *pattn = nullptr, *pmlp = nullptr;
+    // decode workspaces
+    int MT = 0, ldws = 0, Vpad = 0;
+    bf16_t *h_dec = nullptr, *hl = nullptr, *xp_a = nullptr, *xp_attn = nullptr, *xp_mlp = nullptr;
+    float *ws = nullptr, *logits = nullptr, *sample_scratch = nullptr;
+    int32_t *cur_tok = nullptr, *next_tok = nullptr, *unfinished = nullptr, *positions = nullptr,
+            *out_tok = nullptr, *d_step = nullptr, *d_done = nullptr, *d_nemit = nullptr, *d_stop = nullptr;
+    int out_ld = 0;
+    int32_t* h_flags = nullptr;   // pinned: [0]=done [1]=n_emitted
+    // KV pool
+    char* kv_pool = nullptr;
+    size_t layer_stride = 0;
+    int pages_per_seq = 0, num_pages = 0, page_bytes = 0;
+    int32_t* block_table = nullptr;
+    std::vector<int> free_pages;
+    int cached_B = 0;
+    double timing[3] = {0, 0, 0};
+    double timing_graph = 0;
+    // generation runs on an engine-owned non-blocking stream (the caller's stream may be the legacy
+    // null stream, which cannot be captured into a hipGraph); ordered after the caller's stream by an event
+    hipStream_t gen_stream = nullptr;
+    hipEvent_t gen_event = nullptr;
+    // optional per-kernel HIP-event profiling of the decode step (bench.py roofline leg)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;
+    std::vector<int> prof_kind;
+    size_t prof_used = 0;
+};
+
+enum { PK_SKINNY = 0, PK_ATTN = 1, PK_ROWLN = 2, PK_SAMPLE = 3, PK_COUNT = 4 };
+// record an event in front of the next launch (tagged with its kind); durations = event deltas
+static void prof_mark(sv_engine* e, int kind, hipStream_t st) {
+    if (!e->prof_on) return;
+    if (e->prof_used == e->prof_ev.size()) {
+        hipEvent_t ev;
+        if (hipEventCreate(&ev) != hipSuccess) return;
+        e->prof_ev.push_back(ev);
+        e->prof_kind.push_back(kind);
+    }
+    e->prof_kind[e->prof_used] = kind;
+    (void)hipEventRecord(e->prof_ev[e->prof_used++], st);
+}
+
+static int dev_alloc(sv_engine* e, void** p, size_t bytes, bool zero = true) {
+    if (bytes == 0) bytes = 16;
+    hipError_t r = hipMalloc(p, bytes);
+    if (r != hipSuccess) return fail(SV_ENOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(r));
+    if (zero) {
+        r = hipMemset(*p, 0, bytes);
+        if (r != hipSuccess) return fail(SV_EHIP, "hipMemset failed: %s", hipGetErrorString(r));
+    }
+    e->allocs.push_back(*p);
+    return 0;
+}
+template <typename T>
+static int dalloc(sv_engine* e, T** p, size_t count, bool zero = true) {
+    return dev_alloc(e, reinterpret_cast<void**>(p), count * sizeof(T), zero);
+}
+
+static void reg_linear(sv_engine* e, const std::string& base, Linear* l, int N, int K, int Kalign, bool has_bias) {
+    l->N = N; l->K = K; l->Npad = round_up(N, 32); l->Kpad = round_up(K, Kalign);
+    Slot w; w.kind = SLOT_LINEAR_W; w.lin = l; w.numel = (size_t)N * K;
+    e->slots[base + (base.back() == '.' ? "weight" : "")] = w;
+    if (has_bias) {
+        Slot b; b.kind = SLOT_RAW; b.raw = &l->bias; b.numel = (size_t)N;
+        e->slots[base + "bias"] = b;
+    }
+}
+static void reg_raw(sv_engine* e, const std::string& name, bf16_t** p, size_t numel, bool required = true) {
+    Slot s; s.kind = SLOT_RAW; s.raw = p; s.numel = numel; s.required = required;
+    e->slots[name] = s;
+}
+static void reg_ln(sv_engine* e, const std::string& base, LNp* ln, size_t n) {
+    reg_raw(e, base + "weight", &ln->g, n);
+    reg_raw(e, base + "bias", &ln->b, n);
+}
+
+static int pick_splitk(int n_tiles, int KS) {
+    int want = (256 + n_tiles - 1) / n_tiles;
+    int s = 1;
+    while (s < want && s < 8) s <<= 1;
+    while (s > 1 && (KS % s) != 0) s >>= 1;
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI: lifecycle
+// ------------------------------------------------------------------------------------------------
+extern "C" int sv_abi_version(void) { return SV_ABI_VERSION; }
+extern "C" const char* sv_last_error(void) { return g_err.c_str(); }
+
+extern "C" void sv_config_default_1b(sv_config* c) {
+    c->image_size = 224; c->patch_size = 14; c->vit_width = 1024; c->vit_layers = 23; c->vit_heads = 16;
+    c->adapter_norm = SV_NORM_LAYER; c->hidden = 2048; c->n_layer = 24; c->n_head = 16; c->n_inner = 8192;
+    c->vocab = 49156; c->n_positions = 8192; c->max_batch = 32; c->max_seq_len = 2048; c->ln_eps = 1e-5f;
+    c->device = 0;
+}
+
+extern "C" int sv_destroy(sv_engine* e) {
+    if (!e) return 0;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    for (void* p : e->allocs) (void)hipFree(p);
+    if (e->h_flags) (void)hipHostFree(e->h_flags);
+    for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
+    if (e->gen_event) (void)hipEventDestroy(e->gen_event);
+    if (e->gen_stream) (void)hipStreamDestroy(e->gen_stream);
+    delete e;
+    return 0;
+}
+
+extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
+    if (!cfg || !out) return fail(SV_EINVAL, "sv_create: null argument");
+    const sv_config& c = *cfg;
+    if (c.image_size % c.patch_size) return fail(SV_EINVAL, "image_size %% patch_size != 0");
+    if (c.vit_width % c.vit_heads || c.hidden % c.n_head) return fail(SV_EINVAL, "width %% heads != 0");
+    const int vdh = c.vit_width / c.vit_heads, dh = c.hidden / c.n_head;
+    if (vdh != 64 && vdh != 128) return fail(SV_EINVAL, "ViT head_dim %d unsupported (64|128)", vdh);
+    if (dh != 64 && dh != 128) return fail(SV_EINVAL, "decoder head_dim %d unsupported (64|128)", dh);
+    if (c.n_head > 16) return fail(SV_EINVAL, "MQA decode kernel supports <= 16 query heads per KV head");
+    if (c.vit_width % 64 || c.hidden % 64 || c.n_inner % 64) return fail(SV_EINVAL, "dims must be multiples of 64");
+    if (c.vocab % 4) return fail(SV_EINVAL, "vocab must be a multiple of 4");
+    if (c.max_batch < 1 || c.max_seq_len < 2 || c.max_seq_len > c.n_positions)
+        return fail(SV_EINVAL, "bad max_batch / max_seq_len");
+    hipError_t r = hipSetDevice(c.device);
+    if (r != hipSuccess) return fail(SV_EHIP, "hipSetDevice(%d): %s", c.device, hipGetErrorString(r));
+
+    if (int ar = init_attention_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
+
+    sv_engine* e = new sv_engine();
+    e->cfg = c;
+    e->vdh = vdh; e->dh = dh;
+    const int G = c.image_size / c.patch_size;
+    e->NP = G * G; e->T = e->NP + 1;
+    const int Dv = c.vit_width, D = c.hidden, F = c.n_inner;
+    e->conv_K = 3 * c.patch_size * c.patch_size;
+
+    const std::string pv = "model.image_encoder.visual_encoder.";
+    reg_linear(e, pv + "conv1.", &e->conv1, Dv, e->conv_K, 64, false);
+    reg_raw(e, pv + "class_embedding", &e->cls, Dv);
+    reg_raw(e, pv + "positional_embedding", &e->pos, (size_t)e->T * Dv);
+    reg_ln(e, pv + "ln_pre.", &e->ln_pre, Dv);
+    e->vit.resize(c.vit_layers);
+    for (int i = 0; i < c.vit_layers; ++i) {
+        const std::string p = pv + "transformer.resblocks." + std::to_string(i) + ".";
+        VitLayer& L = e->vit[i];
+        reg_ln(e, p + "ln_1.", &L.ln1, Dv);
+        reg_ln(e, p + "ln_2.", &L.ln2, Dv);
+        // nn.MultiheadAttention packs q|k|v into in_proj_weight / in_proj_bias (no '.weight' suffix)
+        L.in_proj.N = 3 * Dv; L.in_proj.K = Dv; L.in_proj.Npad = 3 * Dv; L.in_proj.Kpad = Dv;
+        { Slot w; w.kind = SLOT_LINEAR_W; w.lin = &L.in_proj; w.numel = (size_t)3 * Dv * Dv; e->slots[p + "attn.in_proj_weight"] = w; }
+        reg_raw(e, p + "attn.in_proj_bias", &L.in_proj.bias, (size_t)3 * Dv);
+        reg_linear(e, p + "attn.out_proj.", &L.out_proj, Dv, Dv, 64, true);
+        reg_linear(e, p + "mlp.c_fc.", &L.c_fc, 4 * Dv, Dv, 64, true);
+        reg_linear(e, p + "mlp.c_proj.", &L.c_proj, Dv, 4 * Dv, 64, true);
+    }
+    reg_ln(e, "model.image_encoder.ln_vision.", &e->ln_vision, Dv);
+
+    const std::string pa = "model.image_projection.";
+    reg_linear(e, pa + "c_fc.", &e->ad_fc, 2 * Dv, Dv, 64, true);
+    reg_linear(e, pa + "c_proj.", &e->ad_proj, D, 2 * Dv, 64, true);
+    if (c.adapter_norm == SV_NORM_LAYER) {
+        reg_raw(e, pa + "norm.weight", &e->ad_w, (size_t)e->T * D);
+        reg_raw(e, pa + "norm.bias", &e->ad_b, (size_t)e->T * D);
+    } else {
+        reg_raw(e, pa + "norm.weight", &e->ad_w, e->T);
+        reg_raw(e, pa + "norm.bias", &e->ad_b, e->T);
+        reg_raw(e, pa + "norm.running_mean", &e->ad_rm, e->T);
+        reg_raw(e, pa + "norm.running_var", &e->ad_rv, e->T);
+    }
+
+    const std::string pd = "model.svg_transformer.transformer.transformer.";
+    { Slot s; s.kind = SLOT_WTE; s.raw = &e->wte; s.numel = (size_t)c.vocab * D; e->slots[pd + "wte.weight"] = s; }
+    reg_raw(e, pd + "wpe.weight", &e->wpe, (size_t)c.n_positions * D);
+    e->lm_head.N = c.vocab; e->lm_head.K = D; e->lm_head.Npad = round_up(c.vocab, 32); e->lm_head.Kpad = D;
+    { Slot s; s.kind = SLOT_LINEAR_W; s.lin = &e->lm_head; s.numel = (size_t)c.vocab * D; s.required = false;
+      e->slots["model.svg_transformer.transformer.lm_head.weight"] = s; }
+    e->dec.resize(c.n_layer);
+    for (int i = 0; i < c.n_layer; ++i) {
+        const std::string p = pd + "h." + std::to_string(i) + ".";
+        DecLayer& L = e->dec[i];
+        reg_ln(e, p + "ln_1.", &L.ln1, D);
+        reg_ln(e, p + "ln_2.", &L.ln2, D);
+        reg_linear(e, p + "attn.c_attn.", &L.c_attn, D + 2 * dh, D, 64, true);
+        reg_linear(e, p + "attn.c_proj.", &L.c_proj, D, D, 64, true);
+        reg_linear(e, p + "mlp.c_fc.", &L.c_fc, F, D, 64, true);
+        reg_linear(e, p + "mlp.c_proj.", &L.c_proj2, D, F, 64, true);
+        L.c_attn.splitk = pick_splitk(L.c_attn.Npad / 32, D / 16);
+        L.c_proj.splitk = pick_splitk(L.c_proj.Npad / 32, D / 16);
+        L.c_fc.splitk = 1;
+        L.c_proj2.splitk = pick_splitk(L.c_proj2.Npad / 32, F / 16);
+    }
+    reg_ln(e, pd + "ln_f.", &e->ln_f, D);
+
+    // ---- workspaces ----
+    int rc = 0;
+    const size_t Mv = (size_t)c.max_batch * e->T;
+    const size_t Mp = (size_t)c.max_batch * e->NP;
+#define A(call) if (!rc) rc = (call)
+    A(dalloc(e, &e->patches, Mp * e->conv1.Kpad));
+    A(dalloc(e, &e->patch_out, Mp * Dv));
+    A(dalloc(e, &e->vx, Mv * Dv));
+    A(dalloc(e, &e->vln, Mv * Dv));
+    A(dalloc(e, &e->vqkv, Mv * 3 * Dv));
+    A(dalloc(e, &e->vattn, Mv * Dv));
+    A(dalloc(e, &e->vmlp, Mv * 4 * Dv));
+    A(dalloc(e, &e->a1, Mv * 2 * Dv));
+    A(dalloc(e, &e->a2, Mv * D));
+
+    e->MT = (c.max_batch + 31) / 32;
+    const size_t R = (size_t)e->MT * 32;
+    e->Vpad = e->lm_head.Npad;
+    e->ldws = round_up(D + 2 * dh, 32);
+    if (e->ldws < D) e->ldws = D;
+    A(dalloc(e, &e->h_dec, R * D));
+    A(dalloc(e, &e->hl, R * D));
+    A(dalloc(e, &e->xp_a, R * D));
+    A(dalloc(e, &e->xp_attn, R * D));
+    A(dalloc(e, &e->xp_mlp, R * F));
+    A(dalloc(e, &e->ws, (size_t)8 * R * e->ldws));
+    A(dalloc(e, &e->logits, R * e->Vpad));
+    A(dalloc(e, &e->sample_scratch, R * 4));
+    A(dalloc(e, &e->cur_tok, R));
+    A(dalloc(e, &e->next_tok, R));
+    A(dalloc(e, &e->unfinished, R));
+    A(dalloc(e, &e->positions, R));
+    e->out_ld = c.max_seq_len;
+    A(dalloc(e, &e->out_tok, (size_t)c.max_batch * e->out_ld));
+    A(dalloc(e, &e->d_step, 4));
+    A(dalloc(e, &e->d_done, 4));
+    A(dalloc(e, &e->d_nemit, 4));
+    A(dalloc(e, &e->d_stop, 64));
+
+    e->page_bytes = kv_page_bytes(dh);
+    e->pages_per_seq = (c.max_seq_len + SV_PAGE_TOKENS - 1) / SV_PAGE_TOKENS;
+    e->num_pages = c.max_batch * e->pages_per_seq;
+    e->layer_stride = (size_t)e->num_pages * e->page_bytes;
+    A(dev_alloc(e, reinterpret_cast<void**>(&e->kv_pool), e->layer_stride * c.n_layer, true));
+    A(dalloc(e, &e->block_table, (size_t)c.max_batch * e->pages_per_seq));
+#undef A
+    if (!rc) {
+        hipError_t hr = hipHostMalloc(reinterpret_cast<void**>(&e->h_flags), 64, hipHostMallocDefault);
+        if (hr != hipSuccess) rc = fail(SV_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(hr));
+    }
+    if (!rc) {
+        hipError_t hr = hipStreamCreateWithFlags(&e->gen_stream, hipStreamNonBlocking);
+        if (hr == hipSuccess) hr = hipEventCreateWithFlags(&e->gen_event, hipEventDisableTiming);
+        if (hr != hipSuccess) rc = fail(SV_EHIP, "stream/event creation: %s", hipGetErrorString(hr));
+    }
+    if (rc) { sv_destroy(e); return rc; }
+    *out = e;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights
+// ------------------------------------------------------------------------------------------------
+extern "C" int sv_load_weight(sv_engine* e, const char* name, const void* dev_ptr, int32_t dtype, int32_t ndim,
+                              const int64_t* shape, sv_stream stream) {
+    if (!e || !name || !dev_ptr) return fail(SV_EINVAL, "sv_load_weight: null argument");
+    if (dtype != SV_DTYPE_BF16 && dtype != SV_DTYPE_F32) return fail(SV_EINVAL, "unsupported dtype %d", dtype);
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    auto it = e->slots.find(name);
+    if (it == e->slots.end()) return fail(SV_ENOENT, "unknown weight name '%s'", name);
+    Slot& s = it->second;
+    size_t numel = 1;
+    for (int i = 0; i < ndim; ++i) numel *= (size_t)shape[i];
+    if (numel != s.numel)
+        return fail(SV_EINVAL, "weight '%s': %zu elements given, %zu expected", name, numel, s.numel);
+    hipStream_t st = (hipStream_t)stream;
+    const int is_f32 = dtype == SV_DTYPE_F32;
+    if (s.kind == SLOT_LINEAR_W || s.kind == SLOT_WTE) {
+        Linear* l = s.kind == SLOT_WTE ? &e->lm_head : s.lin;
+        const bool pack = !(s.kind == SLOT_WTE && e->lm_head_explicit);
+        if (pack) {
+            if (!l->Wp) SVCHECK(dalloc(e, &l->Wp, (size_t)l->Npad * l->Kpad, false));
+            launch_pack_weight(dev_ptr, is_f32, l->Wp, l->N, l->K, l->Npad, l->Kpad, st);
+        }
+        if (s.kind == SLOT_LINEAR_W && l == &e->lm_head) e->lm_head_explicit = true;
+    }
+    if (s.kind == SLOT_RAW || s.kind == SLOT_WTE) {
+        if (!*s.raw) SVCHECK(dalloc(e, s.raw, numel, false));
+        launch_convert_to_bf16(dev_ptr, is_f32, *s.raw, numel, st);
+    }
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(st));   // the caller may free its tensor right after this returns
+    s.loaded = true;
+    return 0;
+}
+
+extern "C" int sv_weights_complete(sv_engine* e) {
+    if (!e) return fail(SV_EINVAL, "null engine");
+    for (auto& kv : e->slots)
+        if (kv.second.required && !kv.second.loaded) return fail(SV_ENOENT, "missing weight '%s'", kv.first.c_str());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+static void gemm(const bf16_t* A, int lda, const Linear& l, const bf16_t* R, int ldr, void* C, int ldc, int M,
+                 int act, int out_f32, hipStream_t st) {
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.Wp = l.Wp; g.bias = l.bias; g.R = R; g.ldr = ldr; g.C = C; g.ldc = ldc;
+    g.M = M; g.N = l.N; g.K = l.Kpad; g.act = act; g.out_f32 = out_f32;
+    launch_gemm(g, st);
+}
+
+static void skinny_partial(sv_engine* e, const bf16_t* xp, const Linear& l, int MT, hipStream_t st) {
+    SkinnyArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xp = xp; a.Wp = l.Wp; a.bias = nullptr; a.MT = MT; a.Npad = l.Npad; a.K = l.Kpad; a.splitk = l.splitk;
+    a.out_mode = SK_OUT_PARTIAL; a.ws = e->ws; a.ldws = e->ldws; a.N = l.N;
+    launch_gemm_skinny(a, st);
+}
+
+static int vision_forward(sv_engine* e, const bf16_t* img, int B, bf16_t* out, hipStream_t st) {
+    const sv_config& c = e->cfg;
+    const int Dv = c.vit_width, T = e->T, NP = e->NP, M = B * T;
+    launch_im2col(img, e->patches, B, c.image_size, c.patch_size, e->conv1.Kpad, st);
+    gemm(e->patches, e->conv1.Kpad, e->conv1, nullptr, 0, e->patch_out, Dv, B * NP, ACT_NONE, 0, st);
+    launch_vit_embed_lnpre(e->patch_out, Dv, e->cls, e->pos, e->ln_pre.g, e->ln_pre.b, e->vx, B, NP, Dv,
+                           c.ln_eps, st);
+    AttnPrefillArgs at;
+    at.q = e->vqkv; at.k = e->vqkv + Dv; at.v = e->vqkv + 2 * Dv;
+    at.q_row_stride = 3 * Dv; at.kv_row_stride = 3 * Dv; at.q_head_stride = e->vdh; at.kv_head_stride = e->vdh;
+    at.o = e->vattn; at.o_row_stride = Dv; at.B = B; at.S = T; at.H = c.vit_heads; at.head_dim = e->vdh;
+    at.kv_group = 1; at.causal = 0; at.scale = 1.0f / sqrtf((float)e->vdh);
+    for (int i = 0; i < c.vit_layers; ++i) {
+        VitLayer& L = e->vit[i];
+        launch_layernorm_rows(e->vx, Dv, L.ln1.g, L.ln1.b, e->vln, Dv, M, Dv, c.ln_eps, st);
+        gemm(e->vln, Dv, L.in_proj, nullptr, 0, e->vqkv, 3 * Dv, M, ACT_NONE, 0, st);
+        launch_attn_prefill(at, st);
+        gemm(e->vattn, Dv, L.out_proj, e->vx, Dv, e->vx, Dv, M, ACT_NONE, 0, st);
+        launch_layernorm_rows(e->vx, Dv, L.ln2.g, L.ln2.b, e->vln, Dv, M, Dv, c.ln_eps, st);
+        gemm(e->vln, Dv, L.c_fc, nullptr, 0, e->vmlp, 4 * Dv, M, ACT_QUICKGELU, 0, st);
+        gemm(e->vmlp, 4 * Dv, L.c_proj, e->vx, Dv, e->vx, Dv, M, ACT_NONE, 0, st);
+    }
+    launch_layernorm_rows(e->vx, Dv, e->ln_vision.g, e->ln_vision.b, out, Dv, M, Dv, c.ln_eps, st);
+    return 0;
+}
+
+static int adapter_forward(sv_engine* e, const bf16_t* in, int B, bf16_t* out, hipStream_t st) {
+    const sv_config& c = e->cfg;
+    const int Dv = c.vit_width, D = c.hidden, T = e->T, M = B * T;
+    gemm(in, Dv, e->ad_fc, nullptr, 0, e->a1, 2 * Dv, M, ACT_SWISH, 0, st);
+    gemm(e->a1, 2 * Dv, e->ad_proj, nullptr, 0, e->a2, D, M, ACT_NONE, 0, st);
+    if (c.adapter_norm == SV_NORM_LAYER)
+        launch_plane_layernorm(e->a2, e->ad_w, e->ad_b, out, B, T * D, c.ln_eps, st);
+    else
+        launch_token_batchnorm(e->a2, e->ad_w, e->ad_b, e->ad_rm, e->ad_rv, out, B, T, D, c.ln_eps, st);
+    return 0;
+}
+
+static int ensure_prefill_ws(sv_engine* e, size_t rows) {
+    if (rows <= e->pf_rows) return 0;
+    const sv_config& c = e->cfg;
+    const int D = c.hidden;
+    // previous buffers stay in e->allocs (freed at destroy); growth is rare (max_batch * S0)
+    SVCHECK(dalloc(e, &e->ph, rows * D));
+    SVCHECK(dalloc(e, &e->pln, rows * D));
+    SVCHECK(dalloc(e, &e->pqkv, rows * (D + 2 * e->dh)));
+    SVCHECK(dalloc(e, &e->pattn, rows * D));
+    SVCHECK(dalloc(e, &e->pmlp, rows * c.n_inner));
+    e->pf_rows = rows;
+    return 0;
+}
+
+static int assign_pages(sv_engine* e, int B, int total_len, hipStream_t st) {
+    // page allocator: hand every sequence the pages for its whole budget up front (the decode loop
+    // runs without host round-trips, so pages cannot be added mid-flight)
+    const int need = (total_len + SV_PAGE_TOKENS - 1) / SV_PAGE_TOKENS;
+    if (need > e->pages_per_seq) return fail(SV_EINVAL, "sequence length %d exceeds max_seq_len %d", total_len, e->cfg.max_seq_len);
+    e->free_pages.clear();
+    for (int p = e->num_pages - 1; p >= 0; --p) e->free_pages.push_back(p);
+    std::vector<int32_t> table((size_t)e->cfg.max_batch * e->pages_per_seq, 0);
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < need; ++i) {
+            table[(size_t)b * e->pages_per_seq + i] = e->free_pages.back();
+            e->free_pages.pop_back();
+        }
+    HIPCHECK(hipMemcpyAsync(e->block_table, table.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// lm_head on the rows currently normalised in xp_a -> e->logits
+static void lm_head_logits(sv_engine* e, int MT, hipStream_t st) {
+    SkinnyArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xp = e->xp_a; a.Wp = e->lm_head.Wp; a.MT = MT; a.Npad = e->lm_head.Npad; a.K = e->lm_head.Kpad;
+    a.splitk = 1; a.out_mode = SK_OUT_F32; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1;
+    a.N = e->lm_head.N;
+    launch_gemm_skinny(a, st);
+}
+
+static int prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hipStream_t st) {
+    const sv_config& c = e->cfg;
+    const int D = c.hidden, dh = e->dh, F = c.n_inner, M = B * S0, QKV = D + 2 * dh;
+    SVCHECK(ensure_prefill_ws(e, (size_t)M));
+    launch_dec_embed(embeds, e->wpe, e->ph, B, S0, D, st);
+    AttnPrefillArgs at;
+    at.q = e->pqkv; at.k = e->pqkv + D; at.v = e->pqkv + D + dh;
+    at.q_row_stride = QKV; at.kv_row_stride = QKV; at.q_head_stride = dh; at.kv_head_stride = 0;
+    at.o = e->pattn; at.o_row_stride = D; at.B = B; at.S = S0; at.H = c.n_head; at.head_dim = dh;
+    at.kv_group = c.n_head; at.causal = 1; at.scale = 1.0f / sqrtf((float)dh);
+    for (int i = 0; i < c.n_layer; ++i) {
+        DecLayer& L = e->dec[i];
+        launch_layernorm_rows(e->ph, D, L.ln1.g, L.ln1.b, e->pln, D, M, D, c.ln_eps, st);
+        gemm(e->pln, D, L.c_attn, nullptr, 0, e->pqkv, QKV, M, ACT_NONE, 0, st);
+        launch_kv_write_prefill(e->pqkv, QKV, D, D + dh, e->kv_pool + (size_t)i * e->layer_stride, e->block_table,
+                                e->pages_per_seq, B, S0, dh, st);
+        launch_attn_prefill(at, st);
+        gemm(e->pattn, D, L.c_proj, e->ph, D, e->ph, D, M, ACT_NONE, 0, st);
+        launch_layernorm_rows(e->ph, D, L.ln2.g, L.ln2.b, e->pln, D, M, D, c.ln_eps, st);
+        gemm(e->pln, D, L.c_fc, nullptr, 0, e->pmlp, F, M, ACT_GELU_TANH, 0, st);
+        gemm(e->pmlp, F, L.c_proj2, e->ph, D, e->ph, D, M, ACT_NONE, 0, st);
+    }
+    // only the last prompt row feeds ln_f + lm_head (HF computes all rows; same result)
+    launch_gather_last_rows(e->ph, e->hl, B, S0, D, st);
+    launch_layernorm_rows_packed(e->hl, D, e->ln_f.g, e->ln_f.b, e->xp_a, B, D, c.ln_eps, st);
+    lm_head_logits(e, (B + 31) / 32, st);
+    return 0;
+}
+
+// one autoregressive step: consumes cur_tok/positions, leaves logits in e->logits
+static void decode_forward(sv_engine* e, int B, hipStream_t st) {
+    const sv_config& c = e->cfg;
+    const int D = c.hidden, dh = e->dh, F = c.n_inner, MT = (B + 31) / 32;
+    RowUpdateArgs ru;
+    memset(&ru, 0, sizeof(ru));
+    ru.h = e->h_dec; ru.ldh = D; ru.M = B; ru.D = D; ru.eps = c.ln_eps; ru.xp_out = e->xp_a;
+    ru.ldws = e->ldws; ru.rows_ws = MT * 32;
+    // embedding + ln_1 of layer 0
+    ru.ws = nullptr; ru.wte = e->wte; ru.wpe = e->wpe; ru.tokens = e->cur_tok; ru.positions = e->positions;
+    ru.g = e->dec[0].ln1.g; ru.b = e->dec[0].ln1.b;
+    prof_mark(e, PK_ROWLN, st);
+    launch_row_update_ln(ru, st);
+    for (int i = 0; i < c.n_layer; ++i) {
+        DecLayer& L = e->dec[i];
+        prof_mark(e, PK_SKINNY, st);
+        skinny_partial(e, e->xp_a, L.c_attn, MT, st);
+        AttnDecodeArgs ad;
+        ad.ws = e->ws; ad.splitk = L.c_attn.splitk; ad.ldws = e->ldws; ad.rows_ws = MT * 32; ad.bias = L.c_attn.bias;
+        ad.pool_layer = e->kv_pool + (size_t)i * e->layer_stride; ad.block_table = e->block_table;
+        ad.max_pages = e->pages_per_seq; ad.positions = e->positions; ad.out_xp = e->xp_attn; ad.out_KS = D / 16;
+        ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
+        prof_mark(e, PK_ATTN, st);
+        launch_attn_decode(ad, st);
+        prof_mark(e, PK_SKINNY, st);
+        skinny_partial(e, e->xp_attn, L.c_proj, MT, st);
+        ru.ws = e->ws; ru.splitk = L.c_proj.splitk; ru.bias = L.c_proj.bias; ru.g = L.ln2.g; ru.b = L.ln2.b;
+        prof_mark(e, PK_ROWLN, st);
+        launch_row_update_ln(ru, st);
+        prof_mark(e, PK_SKINNY, st);
+        {
+            SkinnyArgs a;
+            memset(&a, 0, sizeof(a));
+            a.xp = e->xp_a; a.Wp = L.c_fc.Wp; a.bias = L.c_fc.bias; a.MT = MT; a.Npad = L.c_fc.Npad; a.K = L.c_fc.Kpad;
+            a.splitk = 1; a.out_mode = SK_OUT_PACKED_ACT; a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16;
+            a.N = L.c_fc.N;
+            launch_gemm_skinny(a, st);
+        }
+        prof_mark(e, PK_SKINNY, st);
+        skinny_partial(e, e->xp_mlp, L.c_proj2, MT, st);
+        const LNp& nxt = (i + 1 < c.n_layer) ? e->dec[i + 1].ln1 : e->ln_f;
+        ru.splitk = L.c_proj2.splitk; ru.bias = L.c_proj2.bias; ru.g = nxt.g; ru.b = nxt.b;
+        prof_mark(e, PK_ROWLN, st);
+        launch_row_update_ln(ru, st);
+    }
+    prof_mark(e, PK_SKINNY, st);
+    lm_head_logits(e, MT, st);
+    prof_mark(e, PK_SAMPLE, st);      // closes the lm_head interval; whatever follows is sampling
+}
+
+static int check_ready(sv_engine* e) {
+    if (!e) return fail(SV_EINVAL, "null engine");
+    int r = sv_weights_complete(e);
+    if (r) return fail(SV_ESTATE, "weights incomplete: %s", g_err.c_str());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI: forward entry points
+// ------------------------------------------------------------------------------------------------
+extern "C" int sv_encode_image(sv_engine* e, const void* dev_image, int32_t B, void* dev_out, sv_stream stream) {
+    SVCHECK(check_ready(e));
+    if (!dev_image || !dev_out || B < 1 || B > e->cfg.max_batch) return fail(SV_EINVAL, "sv_encode_image: bad B=%d (max_batch %d) or null pointer", B, e->cfg.max_batch);
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    SVCHECK(vision_forward(e, (const bf16_t*)dev_image, B, (bf16_t*)dev_out, (hipStream_t)stream));
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sv_adapter(sv_engine* e, const void* dev_in, int32_t B, void* dev_out, sv_stream stream) {
+    SVCHECK(check_ready(e));
+    if (!dev_in || !dev_out || B < 1 || B > e->cfg.max_batch) return fail(SV_EINVAL, "sv_adapter: bad B=%d or null pointer", B);
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    SVCHECK(adapter_forward(e, (const bf16_t*)dev_in, B, (bf16_t*)dev_out, (hipStream_t)stream));
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sv_embed_tokens(sv_engine* e, const int64_t* dev_ids, int32_t n, void* dev_out, sv_stream stream) {
+    SVCHECK(check_ready(e));
+    if (!dev_ids || !dev_out || n < 0) return fail(SV_EINVAL, "sv_embed_tokens: bad argument");
+    if (n == 0) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    launch_gather_rows(e->wte, dev_ids, (bf16_t*)dev_out, n, e->cfg.hidden, (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+static int copy_logits_out(sv_engine* e, int B, float* dev_logits, hipStream_t st) {
+    HIPCHECK(hipMemcpy2DAsync(dev_logits, (size_t)e->cfg.vocab * sizeof(float), e->logits,
+                              (size_t)e->Vpad * sizeof(float), (size_t)e->cfg.vocab * sizeof(float), B,
+                              hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+static int prefill_locked(sv_engine* e, const void* dev_embeds, int B, int S0, int total_len, hipStream_t st) {
+    if (!dev_embeds || B < 1 || B > e->cfg.max_batch) return fail(SV_EINVAL, "prefill: bad B=%d (max_batch %d)", B, e->cfg.max_batch);
+    if (S0 < 1 || S0 > e->cfg.max_seq_len) return fail(SV_EINVAL, "prefill: S0=%d out of range (max_seq_len %d)", S0, e->cfg.max_seq_len);
+    SVCHECK(assign_pages(e, B, total_len, st));
+    SVCHECK(prefill_forward(e, (const bf16_t*)dev_embeds, B, S0, st));
+    fill_i32_kernel<<<(B + 63) / 64, 64, 0, st>>>(e->positions, S0, B);
+    e->cached_B = B;
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sv_prefill(sv_engine* e, const void* dev_embeds, int32_t B, int32_t S0, float* dev_logits,
+                          sv_stream stream) {
+    SVCHECK(check_ready(e));
+    if (!dev_logits) return fail(SV_EINVAL, "sv_prefill: null logits pointer");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    SVCHECK(prefill_locked(e, dev_embeds, B, S0, e->cfg.max_seq_len, st));
+    SVCHECK(copy_logits_out(e, B, dev_logits, st));
+    return 0;
+}
+
+extern "C" int sv_decode_step(sv_engine* e, const int32_t* dev_tokens, int32_t B, float* dev_logits, sv_stream stream) {
+    SVCHECK(check_ready(e));
+    if (!dev_tokens || !dev_logits) return fail(SV_EINVAL, "sv_decode_step: null pointer");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (B != e->cached_B) return fail(SV_ESTATE, "sv_decode_step: B=%d but the cache holds %d sequences", B, e->cached_B);
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHECK(hipMemcpyAsync(e->cur_tok, dev_tokens, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    decode_forward(e, B, st);
+    add_i32_kernel<<<(B + 63) / 64, 64, 0, st>>>(e->positions, 1, B);
+    SVCHECK(copy_logits_out(e, B, dev_logits, st));
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+// sample from e->logits into next_tok, then the bookkeeping kernel
+static void sample_and_finish(sv_engine* e, int B, const sv_sampling& sp, int max_new, hipStream_t st) {
+    if (sp.do_sample) {
+        SampleArgs sa;
+        sa.logits = e->logits; sa.ld = e->Vpad; sa.V = e->cfg.vocab; sa.B = B; sa.temperature = sp.temperature;
+        sa.top_p = sp.top_p; sa.seed = sp.seed; sa.step = e->d_step; sa.out = e->next_tok; sa.scratch = e->sample_scratch;
+        launch_sample_top_p(sa, st);
+    } else {
+        launch_argmax(e->logits, e->Vpad, e->cfg.vocab, e->next_tok, B, st);
+    }
+    FinishArgs f;
+    f.next = e->next_tok; f.cur_tok = e->cur_tok; f.unfinished = e->unfinished; f.positions = e->positions;
+    f.out_tokens = e->out_tok; f.ld_out = e->out_ld; f.step = e->d_step; f.done = e->d_done; f.n_emitted = e->d_nemit;
+    f.stop_ids = e->d_stop; f.n_stop = sp.n_stop; f.eos = sp.eos_token_id; f.pad = sp.pad_token_id; f.B = B;
+    f.max_new = max_new;
+    launch_finish_step(f, st);
+}
+
+extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int32_t S0, const sv_sampling* sp,
+                           int64_t* dev_out_tokens, int32_t* n_generated, sv_stream stream) {
+    SVCHECK(check_ready(e));
+    if (!sp || !dev_out_tokens || !n_generated) return fail(SV_EINVAL, "sv_generate: null argument");
+    const int max_new = sp->max_length - S0;     // HF: with inputs_embeds, max_length includes the prompt
+    if (max_new <= 0) return fail(SV_EINVAL, "max_length (%d) must exceed the prompt length (%d)", sp->max_length, S0);
+    if (S0 + max_new > e->cfg.max_seq_len) return fail(SV_EINVAL, "max_length %d exceeds engine max_seq_len %d", sp->max_length, e->cfg.max_seq_len);
+    if (sp->n_stop < 0 || sp->n_stop > 16) return fail(SV_EINVAL, "stop sequence length %d unsupported (0..16)", sp->n_stop);
+    if (sp->do_sample && !(sp->temperature > 0.f && sp->top_p > 0.f)) return fail(SV_EINVAL, "temperature and top_p must be > 0");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    // order the engine stream after everything already queued on the caller's stream
+    HIPCHECK(hipEventRecord(e->gen_event, (hipStream_t)stream));
+    hipStream_t st = e->gen_stream;
+    HIPCHECK(hipStreamWaitEvent(st, e->gen_event, 0));
+
+    auto t0 = std::chrono::steady_clock::now();
+    SVCHECK(prefill_locked(e, dev_embeds, B, S0, S0 + max_new, st));
+    // generation state
+    fill_i32_kernel<<<(B + 63) / 64, 64, 0, st>>>(e->positions, S0 - 1, B);     // finish_step adds 1
+    fill_i32_kernel<<<(B + 63) / 64, 64, 0, st>>>(e->unfinished, 1, B);
+    HIPCHECK(hipMemsetAsync(e->d_step, 0, sizeof(int32_t), st));
+    HIPCHECK(hipMemsetAsync(e->d_done, 0, sizeof(int32_t), st));
+    HIPCHECK(hipMemsetAsync(e->d_nemit, 0, sizeof(int32_t), st));
+    if (sp->n_stop > 0) {
+        if (!sp->stop_ids) return fail(SV_EINVAL, "n_stop > 0 but stop_ids is null");
+        HIPCHECK(hipMemcpyAsync(e->d_stop, sp->stop_ids, sp->n_stop * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    }
+    sample_and_finish(e, B, *sp, max_new, st);       // first token from the prefill logits
+    HIPCHECK(hipMemcpyAsync(&e->h_flags[0], e->d_done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    auto t1 = std::chrono::steady_clock::now();
+
+    int steps = 0;
+    const int chunk = sp->sync_every > 0 ? sp->sync_every : 32;
+    const bool use_graph = getenv("SV_NO_GRAPH") == nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t gexec = nullptr;
+    if (!e->h_flags[0] && use_graph) {
+        // capture one decode step (all kernel arguments are stable device pointers; the step index,
+        // positions and stop state live in device memory), replay it every step
+        hipError_t ce = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+        if (ce == hipSuccess) {
+            decode_forward(e, B, st);
+            sample_and_finish(e, B, *sp, max_new, st);
+            ce = hipStreamEndCapture(st, &graph);
+            if (ce == hipSuccess && graph) ce = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
+        }
+        if (ce != hipSuccess) {          // fall back to plain launches of the SAME kernels
+            (void)hipGetLastError();
+            if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
+            if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+            if (getenv("SV_REQUIRE_GRAPH")) return fail(SV_EHIP, "hipGraph capture failed: %s", hipGetErrorString(ce));
+        }
+    }
+    while (!e->h_flags[0]) {
+        int n = max_new - 1 - steps;
+        if (n <= 0) break;                       // budget exhausted: the device flag is already set
+        if (n > chunk) n = chunk;
+        for (int i = 0; i < n; ++i) {
+            if (gexec) {
+                HIPCHECK(hipGraphLaunch(gexec, st));
+            } else {
+                decode_forward(e, B, st);
+                sample_and_finish(e, B, *sp, max_new, st);
+            }
+        }
+        steps += n;
+        HIPCHECK(hipMemcpyAsync(&e->h_flags[0], e->d_done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+    }
+    const double gexec_used = gexec ? 1.0 : 0.0;
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (graph) (void)hipGraphDestroy(graph);
+    HIPCHECK(hipMemcpyAsync(&e->h_flags[1], e->d_nemit, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    const int n_emit = e->h_flags[1];
+    if (n_emit < 1 || n_emit > max_new) return fail(SV_EHIP, "generation bookkeeping failed (n_emitted=%d)", n_emit);
+    tokens_to_i64_kernel<<<(B * n_emit + 255) / 256, 256, 0, st>>>(e->out_tok, e->out_ld, dev_out_tokens, B, n_emit, max_new);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(st));
+    auto t2 = std::chrono::steady_clock::now();
+    *n_generated = n_emit;
+    e->timing[0] = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    e->timing[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    e->timing[2] = (double)steps;
+    e->timing_graph = gexec_used;
+    return 0;
+}
+
+// Per-kernel timing of the decode step with HIP events on the engine stream (eager launches of the
+// same kernels the graph replays).  Uses the KV cache / positions left by the last generate or prefill.
+// out[2*k] = milliseconds per step spent in kernel class k, out[2*k+1] = launches per step,
+// k in {0: skinny GEMM, 1: decode attention, 2: row update + LayerNorm, 3: lm_head-to-end marker}.
+extern "C" int sv_profile_decode_step(sv_engine* e, int32_t B, int32_t iters, double* out, sv_stream stream) {
+    SVCHECK(check_ready(e));
+    if (!out || iters < 1) return fail(SV_EINVAL, "sv_profile_decode_step: bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (B != e->cached_B) return fail(SV_ESTATE, "sv_profile_decode_step: B=%d but the cache holds %d sequences", B, e->cached_B);
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    HIPCHECK(hipEventRecord(e->gen_event, (hipStream_t)stream));
+    hipStream_t st = e->gen_stream;
+    HIPCHECK(hipStreamWaitEvent(st, e->gen_event, 0));
+    // positions may sit one past the budget after a full generate: step back so the probe stays in range
+    add_i32_kernel<<<(B + 63) / 64, 64, 0, st>>>(e->positions, -1, B);
+    for (int k = 0; k < 2 * PK_COUNT; ++k) out[k] = 0.0;
+    // event-pair overhead: two back-to-back events with nothing in between
+    double overhead_ms = 0.0;
+    {
+        hipEvent_t a, b;
+        HIPCHECK(hipEventCreate(&a)); HIPCHECK(hipEventCreate(&b));
+        float acc = 0.f;
+        for (int i = 0; i < 20; ++i) {
+            HIPCHECK(hipEventRecord(a, st)); HIPCHECK(hipEventRecord(b, st));
+            HIPCHECK(hipEventSynchronize(b));
+            float ms = 0.f; HIPCHECK(hipEventElapsedTime(&ms, a, b)); acc += ms;
+        }
+        overhead_ms = acc / 20.0;
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    }
+    for (int it = 0; it < iters + 1; ++it) {
+        e->prof_on = true; e->prof_used = 0;
+        decode_forward(e, B, st);
+        e->prof_on = false;
+        HIPCHECK(hipStreamSynchronize(st));
+        if (it == 0) continue;              // warm-up pass (also creates the events)
+        for (size_t i = 0; i + 1 < e->prof_used; ++i) {
+            float ms = 0.f;
+            HIPCHECK(hipEventElapsedTime(&ms, e->prof_ev[i], e->prof_ev[i + 1]));
+            double d = (double)ms - overhead_ms;
+            if (d < 0) d = 0;
+            out[2 * e->prof_kind[i]] += d;
+            out[2 * e->prof_kind[i] + 1] += 1.0;
+        }
+    }
+    for (int k = 0; k < 2 * PK_COUNT; ++k) out[k] /= (double)iters;
+    add_i32_kernel<<<(B + 63) / 64, 64, 0, st>>>(e->positions, 1, B);
+    HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int sv_last_timing(sv_engine* e, double* out3) {   /* 4 doubles */
+    if (!e || !out3) return fail(SV_EINVAL, "null argument");
+    out3[0] = e->timing[0]; out3[1] = e->timing[1]; out3[2] = e->timing[2]; out3[3] = e->timing_graph;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI: single operators (test surface)
+// ------------------------------------------------------------------------------------------------
+struct TmpBufs {
+    std::vector<void*> p;
+    ~TmpBufs() { for (void* q : p) (void)hipFree(q); }
+    template <typename T> int get(T** out, size_t count) {
+        hipError_t r = hipMalloc(reinterpret_cast<void**>(out), count * sizeof(T));
+        if (r != hipSuccess) return fail(SV_ENOMEM, "hipMalloc: %s", hipGetErrorString(r));
+        p.push_back(*out);
+        return 0;
+    }
+};
+
+extern "C" int sv_op_layernorm(const void* x, const void* gamma, const void* beta, void* y, int32_t M, int32_t D,
+                               float eps, sv_stream stream) {
+    if (!x || !gamma || !beta || !y || M < 1 || D < 8 || D % 8) return fail(SV_EINVAL, "sv_op_layernorm: bad argument");
+    launch_layernorm_rows((const bf16_t*)x, D, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, D, M, D, eps,
+                          (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sv_op_linear(const void* x, const void* W, const void* bias, const void* residual, void* y, int32_t M,
+                            int32_t N, int32_t K, int32_t act, int32_t out_f32, sv_stream stream) {
+    if (!x || !W || !y || M < 1 || N < 4 || N % 4 || K < 1) return fail(SV_EINVAL, "sv_op_linear: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    TmpBufs tmp;
+    const int Npad = round_up(N, 32), Kpad = round_up(K, 64);
+    bf16_t* Wp;
+    SVCHECK(tmp.get(&Wp, (size_t)Npad * Kpad));
+    launch_pack_weight(W, 0, Wp, N, K, Npad, Kpad, st);
+    const bf16_t* A = (const bf16_t*)x;
+    int lda = K;
+    if (Kpad != K) {
+        bf16_t* xpd;
+        SVCHECK(tmp.get(&xpd, (size_t)M * Kpad));
+        HIPCHECK(hipMemsetAsync(xpd, 0, (size_t)M * Kpad * 2, st));
+        HIPCHECK(hipMemcpy2DAsync(xpd, (size_t)Kpad * 2, x, (size_t)K * 2, (size_t)K * 2, M, hipMemcpyDeviceToDevice, st));
+        A = xpd; lda = Kpad;
+    }
+    GemmArgs g;
+    g.A = A; g.lda = lda; g.Wp = Wp; g.bias = (const bf16_t*)bias; g.R = (const bf16_t*)residual; g.ldr = N;
+    g.C = y; g.ldc = N; g.M = M; g.N = N; g.K = Kpad; g.act = act; g.out_f32 = out_f32;
+    launch_gemm(g, st);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int sv_op_linear_skinny(const void* x, const void* W, const void* bias, void* y_f32, int32_t M, int32_t N,
+                                   int32_t K, int32_t splitk, sv_stream stream) {
+    if (!x || !W || !y_f32 || M < 1 || N < 1 || K < 16 || K % 16 || splitk < 1 || (K / 16) % splitk)
+        return fail(SV_EINVAL, "sv_op_linear_skinny: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    TmpBufs tmp;
+    const int Npad = round_up(N, 32), MT = (M + 31) / 32;
+    bf16_t *Wp, *xp;
+    float* ws;
+    SVCHECK(tmp.get(&Wp, (size_t)Npad * K));
+    SVCHECK(tmp.get(&xp, (size_t)MT * 32 * K));
+    SVCHECK(tmp.get(&ws, (size_t)splitk * MT * 32 * Npad));
+    HIPCHECK(hipMemsetAsync(xp, 0, (size_t)MT * 32 * K * 2, st));
+    launch_pack_weight(W, 0, Wp, N, K, Npad, K, st);
+    pack_rows_kernel<<<(M * (K / 8) + 255) / 256, 256, 0, st>>>((const bf16_t*)x, K, xp, M, K);
+    SkinnyArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xp = xp; a.Wp = Wp; a.MT = MT; a.Npad = Npad; a.K = K; a.splitk = splitk; a.out_mode = SK_OUT_PARTIAL;
+    a.ws = ws; a.ldws = Npad; a.N = N;
+    launch_gemm_skinny(a, st);
+    reduce_partials_kernel<<<(M * N + 255) / 256, 256, 0, st>>>(ws, splitk, MT * 32, Npad, (const bf16_t*)bias,
+                                                                 (float*)y_f32, M, N);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int sv_op_attention(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t S, int32_t H,
+                               int32_t Hkv, int32_t head_dim, int32_t causal, float scale, sv_stream stream) {
+    if (!q || !k || !v || !out || B < 1 || S < 1 || H < 1 || Hkv < 1 || H % Hkv) return fail(SV_EINVAL, "sv_op_attention: bad argument");
+    if (head_dim != 64 && head_dim != 128) return fail(SV_EINVAL, "head_dim %d unsupported (64|128)", head_dim);
+    AttnPrefillArgs a;
+    a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
+    a.q_row_stride = H * head_dim; a.kv_row_stride = Hkv * head_dim; a.q_head_stride = head_dim;
+    a.kv_head_stride = head_dim; a.o = (bf16_t*)out; a.o_row_stride = H * head_dim; a.B = B; a.S = S; a.H = H;
+    a.head_dim = head_dim; a.kv_group = H / Hkv; a.causal = causal; a.scale = scale;
+    launch_attn_prefill(a, (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sv_op_plane_layernorm(const void* x, const void* gamma, const void* beta, void* y, int32_t B, int32_t QD,
+                                     float eps, sv_stream stream) {
+    if (!x || !gamma || !beta || !y || B < 1 || QD < 8 || QD % 8) return fail(SV_EINVAL, "sv_op_plane_layernorm: bad argument");
+    launch_plane_layernorm((const bf16_t*)x, (const bf16_t*)gamma, (const bf16_t*)beta, (bf16_t*)y, B, QD, eps,
+                           (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sv_op_argmax(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t* out, sv_stream stream) {
+    if (!logits || !out || B < 1 || V < 1 || ld < V || ld % 4) return fail(SV_EINVAL, "sv_op_argmax: bad argument (ld must be a multiple of 4)");
+    launch_argmax(logits, ld, V, out, B, (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sv_op_sample_top_p(const float* logits, int32_t B, int32_t V, int32_t ld, float temperature, float top_p,
+                                  uint64_t seed, int32_t step, int32_t* out, sv_stream stream) {
+    if (!logits || !out || B < 1 || V < 1 || ld < V || !(temperature > 0.f) || !(top_p > 0.f))
+        return fail(SV_EINVAL, "sv_op_sample_top_p: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    TmpBufs tmp;
+    int32_t* dstep;
+    SVCHECK(tmp.get(&dstep, 1));
+    HIPCHECK(hipMemcpyAsync(dstep, &step, sizeof(int32_t), hipMemcpyHostToDevice, st));
+    SampleArgs sa;
+    sa.logits = logits; sa.ld = ld; sa.V = V; sa.B = B; sa.temperature = temperature; sa.top_p = top_p; sa.seed = seed;
+    sa.step = dstep; sa.out = out; sa.scratch = nullptr;
+    launch_sample_top_p(sa, st);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+}

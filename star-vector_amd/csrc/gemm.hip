@@ -1,0 +1,325 @@
+// bf16 MFMA GEMMs for gfx950 (CDNA4).
+//
+//  * gemm_bf16_kernel   : big-M tile GEMM (ViT / adapter / decoder prefill).  128x128x64 block tile,
+//                         4 waves (2x2), each wave 64x64 = 2x2 v_mfma_f32_32x32x16_bf16 accumulators,
+//                         operands staged HBM->LDS with global_load_lds (16 B/lane, 1 KiB/wave-instr),
+//                         double-buffered, one barrier per K-tile.  The weight arrives pre-packed in
+//                         MFMA fragment order (linear, conflict-free LDS image); the activation tile is
+//                         row-major with an XOR swizzle applied on the SOURCE address (LDS-DMA destinations
+//                         are lane-linear) and the matching XOR on the ds_read_b128.
+//  * gemm_skinny_kernel : M<=32 weight-streaming GEMM for the autoregressive step (HBM-bound): weights
+//                         and activations both in fragment order, loaded straight to VGPRs as fully
+//                         coalesced 1 KiB wave loads, K split across the waves of a block (LDS reduce)
+//                         and optionally across blocks (fp32 slabs, reduced in a fixed order by the
+//                         consumer kernel => deterministic).
+//
+// Orientation: MFMA A operand = weight fragment (i = output column n), B operand = activation
+// fragment (j = row m).  D[i=n][j=m]: lane l holds m = l&31 and n = 8*(r>>2) + 4*(l>>5) + (r&3),
+// i.e. 4 consecutive output columns per register group -> 8-byte bf16 stores per row.
+#include "kernels.h"
+
+namespace sv {
+
+// ------------------------------------------------------------------------------------------------
+// weight packing
+// ------------------------------------------------------------------------------------------------
+template <typename SrcT>
+__global__ void pack_weight_kernel(const SrcT* __restrict__ W, bf16_t* __restrict__ Wp, int N, int K,
+                                   int Npad, int Kpad) {
+    const int KS = Kpad >> 4;
+    const size_t total = (size_t)(Npad >> 5) * KS * 64;
+    for (size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x; c < total;
+         c += (size_t)gridDim.x * blockDim.x) {
+        int lane = (int)(c & 63);
+        size_t t = c >> 6;
+        int ks = (int)(t % KS);
+        int nt = (int)(t / KS);
+        int n = nt * 32 + (lane & 31);
+        int k0 = ks * 16 + (lane >> 5) * 8;
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int k = k0 + e;
+            float v = 0.f;
+            if (n < N && k < K) {
+                if constexpr (sizeof(SrcT) == 4) v = (float)W[(size_t)n * K + k];
+                else v = bf2f((bf16_t)W[(size_t)n * K + k]);
+            }
+            f[e] = v;
+        }
+        *reinterpret_cast<uint4*>(Wp + c * 8) = pack8(f);
+    }
+}
+
+void launch_pack_weight(const void* src, int src_is_f32, bf16_t* dst, int N, int K, int Npad, int Kpad,
+                        hipStream_t st) {
+    size_t total = (size_t)(Npad / 32) * (Kpad / 16) * 64;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 65535) blocks = 65535;
+    if (src_is_f32)
+        pack_weight_kernel<float><<<blocks, 256, 0, st>>>((const float*)src, dst, N, K, Npad, Kpad);
+    else
+        pack_weight_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)src, dst, N, K, Npad, Kpad);
+}
+
+template <typename SrcT>
+__global__ void convert_bf16_kernel(const SrcT* __restrict__ s, bf16_t* __restrict__ d, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if constexpr (sizeof(SrcT) == 4) d[i] = f2bf((float)s[i]);
+        else d[i] = (bf16_t)s[i];
+    }
+}
+void launch_convert_to_bf16(const void* src, int src_is_f32, bf16_t* dst, size_t n, hipStream_t st) {
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    if (src_is_f32) convert_bf16_kernel<float><<<blocks, 256, 0, st>>>((const float*)src, dst, n);
+    else convert_bf16_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)src, dst, n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// big-M GEMM
+// ------------------------------------------------------------------------------------------------
+#define GB_M 128
+#define GB_N 128
+#define GB_K 64
+#define GB_BUF 32768   // per stage: 16 KiB activations + 16 KiB weights
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void lds_dma16(const void* g, char* lds_wave_base) {
+    // 16 B per lane; LDS destination = wave-uniform base + lane*16 (hardware), source is per lane
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * GB_M;
+    const int n0 = blockIdx.x * GB_N;
+    const int KS = p.K >> 4;
+    const int KT = p.K / GB_K;
+    const int NT_total = (p.N + 31) >> 5;   // packed n-tiles available (Npad/32 >= this)
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // per-lane constants of the activation staging: 4 wave-instructions of 8 rows x 128 B each
+    // lane -> (row within the 8-row group, physical 16-B chunk); source chunk = p ^ f(row)
+    const int srow = lane >> 3, schunk = lane & 7;
+
+    auto stage = [&](int kt, int buf) {
+        char* base = smem + buf * GB_BUF;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ii = wave * 4 + i;                 // 0..15 : rows 8*ii .. 8*ii+7
+            const int r = ii * 8 + srow;
+            const int c = schunk ^ ((r >> 1) & 7);
+            int grow = m0 + r;
+            grow = grow < p.M ? grow : p.M - 1;
+            const bf16_t* g = p.A + (size_t)grow * p.lda + kt * GB_K + c * 8;
+            lds_dma16(g, base + ii * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ci = wave * 4 + i;                 // 0..15 : (n-tile t, k-step s)
+            const int t = ci >> 2, s = ci & 3;
+            int nt = (n0 >> 5) + t;
+            nt = nt < NT_total ? nt : NT_total - 1;
+            const bf16_t* g = p.Wp + (((size_t)nt * KS + kt * 4 + s) * 64 + lane) * 8;
+            lds_dma16(g, base + 16384 + ci * 1024);
+        }
+    };
+
+    stage(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
+        const char* base = smem + (kt & 1) * GB_BUF;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            bf16x8 wf[2], xf[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                wf[nt] = *reinterpret_cast<const bf16x8*>(base + 16384 + (((wn * 2 + nt) * 4 + s) * 1024) + lane * 16);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int r = wm * 64 + mt * 32 + (lane & 31);
+                const int c = (2 * s + (lane >> 5)) ^ ((r >> 1) & 7);
+                xf[mt] = *reinterpret_cast<const bf16x8*>(base + r * 128 + c * 16);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+    }
+
+    // epilogue: bias -> round to bf16 (the reference's Linear output) -> activation -> (+ residual)
+    const int half = lane >> 5;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = m0 + wm * 64 + mt * 32 + (lane & 31);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int n = n0 + wn * 64 + nt * 32 + rg * 8 + half * 4;
+                if (n >= p.N) continue;       // N % 4 == 0
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float x = acc[nt][mt][rg * 4 + j];
+                    if (p.bias) x += bf2f(p.bias[n + j]);
+                    if (p.act != ACT_NONE) x = sv_act(bfround(x), p.act);
+                    v[j] = x;
+                }
+                if (p.R) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(p.R + (size_t)m * p.ldr + n);
+                    v[0] = bfround(v[0]) + __uint_as_float(rr.x << 16);
+                    v[1] = bfround(v[1]) + __uint_as_float(rr.x & 0xffff0000u);
+                    v[2] = bfround(v[2]) + __uint_as_float(rr.y << 16);
+                    v[3] = bfround(v[3]) + __uint_as_float(rr.y & 0xffff0000u);
+                }
+                if constexpr (sizeof(OutT) == 4) {
+                    float4 o = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>((float*)p.C + (size_t)m * p.ldc + n) = o;
+                } else {
+                    uint2 o;
+                    o.x = pack2bf(v[0], v[1]);
+                    o.y = pack2bf(v[2], v[3]);
+                    *reinterpret_cast<uint2*>((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+                }
+            }
+        }
+    }
+}
+
+void launch_gemm(const GemmArgs& a, hipStream_t st) {
+    dim3 grid((a.N + GB_N - 1) / GB_N, (a.M + GB_M - 1) / GB_M);
+    if (a.out_f32)
+        gemm_bf16_kernel<float><<<grid, 256, 2 * GB_BUF, st>>>(a);
+    else
+        gemm_bf16_kernel<bf16_t><<<grid, 256, 2 * GB_BUF, st>>>(a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// skinny GEMM
+// ------------------------------------------------------------------------------------------------
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
+    __shared__ float red[WAVES][16][64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = blockIdx.x;
+    const int split = blockIdx.y;
+    const int mt = blockIdx.z;
+    const int KS = p.K >> 4;
+    const int ks_per_split = KS / p.splitk;
+    const int ks_per_wave = ks_per_split / WAVES;
+    const int ks0 = split * ks_per_split + wave * ks_per_wave;
+
+    const u32x4* wptr = reinterpret_cast<const u32x4*>(p.Wp) + ((size_t)nt * KS + ks0) * 64 + lane;
+    const u32x4* xptr = reinterpret_cast<const u32x4*>(p.xp) + ((size_t)mt * KS + ks0) * 64 + lane;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    int ks = 0;
+    for (; ks + 8 <= ks_per_wave; ks += 8) {
+        u32x4 wv[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            wv[u] = __builtin_nontemporal_load(wptr + (size_t)(ks + u) * 64);   // streamed once
+            xv[u] = xptr[(size_t)(ks + u) * 64];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wv[u]), as_frag4(xv[u]), acc, 0, 0, 0);
+    }
+    for (; ks < ks_per_wave; ++ks) {
+        u32x4 wv = __builtin_nontemporal_load(wptr + (size_t)ks * 64);
+        u32x4 xv = xptr[(size_t)ks * 64];
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wv), as_frag4(xv), acc, 0, 0, 0);
+    }
+
+    if (WAVES > 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = red[0][r][lane];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) s += red[w][r][lane];
+            acc[r] = s;
+        }
+    }
+
+    const int m = lane & 31;
+    const int half = lane >> 5;
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const int n = nt * 32 + rg * 8 + half * 4;
+        float v[4] = {acc[rg * 4 + 0], acc[rg * 4 + 1], acc[rg * 4 + 2], acc[rg * 4 + 3]};
+        if (p.out_mode == SK_OUT_PARTIAL) {
+            float* dst = p.ws + ((size_t)split * p.MT * 32 + mt * 32 + m) * p.ldws + n;
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        } else if (p.out_mode == SK_OUT_PACKED_ACT) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float x = v[j];
+                if (n + j < p.N) {
+                    if (p.bias) x += bf2f(p.bias[n + j]);
+                    x = sv_act(bfround(x), p.act);
+                } else {
+                    x = 0.f;
+                }
+                v[j] = x;
+            }
+            uint2 o;
+            o.x = pack2bf(v[0], v[1]);
+            o.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(p.out_xp + xp_index(mt, p.out_KS, m, n)) = o;
+        } else {
+            if (p.round_bf16) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = bfround(v[j]);
+            }
+            float* dst = p.out_f32 + ((size_t)mt * 32 + m) * p.ldo + n;
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st) {
+    dim3 grid(a.Npad / 32, a.splitk, a.MT);
+    const int KS = a.K / 16;
+    const int per_split = KS / a.splitk;
+    if (per_split % 8 == 0)
+        gemm_skinny_kernel<8><<<grid, 512, 0, st>>>(a);
+    else if (per_split % 4 == 0)
+        gemm_skinny_kernel<4><<<grid, 256, 0, st>>>(a);
+    else if (per_split % 2 == 0)
+        gemm_skinny_kernel<2><<<grid, 128, 0, st>>>(a);
+    else
+        gemm_skinny_kernel<1><<<grid, 64, 0, st>>>(a);
+}
+
+}  // namespace sv

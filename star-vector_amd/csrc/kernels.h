@@ -1,0 +1,138 @@
+// Internal host-side launchers for the gfx950 kernels (not part of the public C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.h"
+
+namespace sv {
+
+inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// ---- weights -----------------------------------------------------------------------------------
+// src: [N][K] row-major (bf16 if src_is_f32==0 else float).  dst: packed [Npad/32][Kpad/16][64][8].
+void launch_pack_weight(const void* src, int src_is_f32, bf16_t* dst, int N, int K, int Npad, int Kpad,
+                        hipStream_t st);
+void launch_convert_to_bf16(const void* src, int src_is_f32, bf16_t* dst, size_t n, hipStream_t st);
+
+// ---- big-M MFMA GEMM:  C[M][N] = epi( A[M][K] . W^T + bias ) (+ residual) ----------------------
+struct GemmArgs {
+    const bf16_t* A; int lda;        // activations, row-major bf16, K-contiguous
+    const bf16_t* Wp;                // packed weight
+    const bf16_t* bias;              // [N] or nullptr
+    const bf16_t* R; int ldr;        // residual [M][N] or nullptr (added after the activation)
+    void* C; int ldc;                // bf16 (out_f32==0) or float
+    int M, N, K;                     // K = padded K (multiple of 64) shared by A and Wp
+    int act; int out_f32;
+};
+void launch_gemm(const GemmArgs& a, hipStream_t st);
+
+// ---- skinny (M<=32 per tile) weight-streaming GEMM --------------------------------------------
+enum { SK_OUT_PARTIAL = 0, SK_OUT_PACKED_ACT = 1, SK_OUT_F32 = 2 };
+struct SkinnyArgs {
+    const bf16_t* xp;                // packed activations [MT][K/16][64][8]
+    const bf16_t* Wp;                // packed weight [Npad/32][K/16][64][8]
+    const bf16_t* bias;              // used by PACKED_ACT
+    int MT;                          // number of 32-row tiles
+    int Npad, K;                     // Npad multiple of 32, K multiple of 16
+    int splitk;                      // >=1; (K/16) must be divisible by splitk*waves
+    int out_mode; int act;
+    float* ws; int ldws;             // PARTIAL: ws[split][MT*32][ldws]
+    bf16_t* out_xp; int out_KS;      // PACKED_ACT: packed activation buffer with out_KS = Npad/16 k-steps
+    float* out_f32; int ldo;         // F32: [MT*32][ldo]; rounded to bf16 values if round_bf16
+    int round_bf16;
+    int N;                           // valid columns (<= Npad)
+};
+void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st);
+
+// ---- row kernels ---------------------------------------------------------------------------------
+void launch_layernorm_rows(const bf16_t* x, int ldx, const bf16_t* g, const bf16_t* b, bf16_t* y, int ldy,
+                           int M, int D, float eps, hipStream_t st);
+// y_packed (xp layout) variant for the decode path
+void launch_layernorm_rows_packed(const bf16_t* x, int ldx, const bf16_t* g, const bf16_t* b, bf16_t* yp,
+                                  int M, int D, float eps, hipStream_t st);
+
+// decode row update: v = sum_s ws[s][m][:] + bias ; h = bf(h + bf(v)) (in place) ; xp = LN(h)
+struct RowUpdateArgs {
+    const float* ws; int splitk; int ldws; int rows_ws;   // partials [splitk][rows_ws][ldws] (or nullptr)
+    const bf16_t* bias;
+    bf16_t* h; int ldh;                                    // residual stream [M][D] (in/out)
+    const bf16_t* wte; const bf16_t* wpe;                  // embedding mode (ws == nullptr)
+    const int32_t* tokens; const int32_t* positions;       // [M]
+    const bf16_t* g; const bf16_t* b; float eps;           // LayerNorm applied to the updated row
+    bf16_t* xp_out;                                        // packed LN output
+    int M, D;
+};
+void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st);
+
+// ---- embeddings ---------------------------------------------------------------------------------
+void launch_im2col(const bf16_t* img, bf16_t* out, int B, int img_size, int patch, int Kpad, hipStream_t st);
+void launch_vit_embed_lnpre(const bf16_t* patch_out, int ldp, const bf16_t* cls, const bf16_t* pos,
+                            const bf16_t* g, const bf16_t* b, bf16_t* x, int B, int NP, int Dv, float eps,
+                            hipStream_t st);
+void launch_dec_embed(const bf16_t* emb, const bf16_t* wpe, bf16_t* h, int B, int S0, int D, hipStream_t st);
+void launch_gather_rows(const bf16_t* table, const int64_t* ids, bf16_t* out, int n, int D, hipStream_t st);
+void launch_gather_last_rows(const bf16_t* h, bf16_t* out, int B, int S0, int D, hipStream_t st);
+
+// ---- adapter norm -------------------------------------------------------------------------------
+void launch_plane_layernorm(const bf16_t* x, const bf16_t* g, const bf16_t* b, bf16_t* y, int B, int QD,
+                            float eps, hipStream_t st);
+void launch_token_batchnorm(const bf16_t* x, const bf16_t* w, const bf16_t* b, const bf16_t* rm,
+                            const bf16_t* rv, bf16_t* y, int B, int Q, int D, float eps, hipStream_t st);
+
+// ---- attention ----------------------------------------------------------------------------------
+struct AttnPrefillArgs {
+    const bf16_t* q; const bf16_t* k; const bf16_t* v;   // token-major buffers
+    int q_row_stride, kv_row_stride;                      // elements between consecutive tokens
+    int q_head_stride, kv_head_stride;                    // elements between heads (kv: 0 for MQA)
+    bf16_t* o; int o_row_stride;                          // [B*S][H*D]
+    int B, S, H, head_dim, kv_group;                      // kv head = head / kv_group
+    int causal; float scale;
+};
+void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st);
+
+// paged KV cache geometry (one layer):  page = 64 tokens, K|V in MFMA-fragment order, 32 KiB
+#define SV_PAGE_TOKENS 64
+struct KvLayout { int head_dim; int page_bytes; };
+__host__ __device__ inline int kv_page_bytes(int head_dim) { return SV_PAGE_TOKENS * head_dim * 2 * 2; }
+
+// scatter prefill K/V rows (from the c_attn output) into the paged cache
+void launch_kv_write_prefill(const bf16_t* qkv, int row_stride, int k_off, int v_off, char* pool_layer,
+                             const int32_t* block_table, int max_pages, int B, int S0, int head_dim,
+                             hipStream_t st);
+
+struct AttnDecodeArgs {
+    const float* ws; int splitk; int ldws; int rows_ws;   // c_attn split-K partials [splitk][rows][ldws]
+    const bf16_t* bias;                                    // c_attn bias [H*D + 2*D]
+    char* pool_layer;                                      // this layer's page pool
+    const int32_t* block_table; int max_pages;
+    const int32_t* positions;                              // [B] index of the new token (= tokens already cached)
+    bf16_t* out_xp; int out_KS;                            // packed [MT][H*D/16][64][8]
+    int B, H, head_dim; float scale;
+};
+void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t st);
+int init_attention_kernels();   // returns a hipError_t value (0 = ok)
+
+// ---- sampling -----------------------------------------------------------------------------------
+void launch_argmax(const float* logits, int ld, int V, int32_t* out, int B, hipStream_t st);
+struct SampleArgs {
+    const float* logits; int ld; int V; int B;
+    float temperature, top_p; uint64_t seed; const int32_t* step;   // device step counter
+    int32_t* out; float* scratch;                                    // scratch >= B*4 floats
+};
+void launch_sample_top_p(const SampleArgs& a, hipStream_t st);
+
+struct FinishArgs {
+    const int32_t* next;          // [B] raw sampled ids
+    int32_t* cur_tok;             // [B] token fed to the next step
+    int32_t* unfinished;          // [B]
+    int32_t* positions;           // [B] (+1 each step)
+    int32_t* out_tokens; int ld_out;   // [B][max_new]
+    int32_t* step;                // device scalar: number of tokens emitted so far
+    int32_t* done;                // device scalar: 1 once generation has ended
+    int32_t* n_emitted;           // device scalar: final column count
+    const int32_t* stop_ids; int n_stop;
+    int eos, pad, B, max_new;
+};
+void launch_finish_step(const FinishArgs& a, hipStream_t st);
+
+}  // namespace sv

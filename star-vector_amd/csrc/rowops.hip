@@ -1,0 +1,400 @@
+// Row-wise (HBM/L2-bound) kernels of the path: LayerNorm flavours, embeddings, im2col, adapter norms.
+// All loads/stores are 16-byte bf16x8 vectors; statistics in fp32 with wave64 shuffle reductions.
+#include "kernels.h"
+
+namespace sv {
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over the last dim, one wave per row (clip_model.py:117-124, gpt_bigcode LN eps 1e-5)
+// PACKED=false: y[M][D] row-major.  PACKED=true: y in skinny "xp" fragment order.
+// ------------------------------------------------------------------------------------------------
+template <bool PACKED>
+__global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* __restrict__ x, int ldx,
+                                                             const bf16_t* __restrict__ g,
+                                                             const bf16_t* __restrict__ b,
+                                                             bf16_t* __restrict__ y, int ldy, int M, int D,
+                                                             float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bf16_t* xr = x + (size_t)row * ldx;
+    const int NC = D >> 3;
+    float s = 0.f;
+    for (int c = lane; c < NC; c += 64) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += f[e];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+    for (int c = lane; c < NC; c += 64) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float d = f[e] - mean; q += d * d; }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    const int KS = D >> 4;
+    for (int c = lane; c < NC; c += 64) {
+        float f[8], gg[8], bb[8];
+        unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);
+        unpack8(*reinterpret_cast<const uint4*>(g + c * 8), gg);
+        unpack8(*reinterpret_cast<const uint4*>(b + c * 8), bb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * rstd * gg[e] + bb[e];
+        if (PACKED)
+            *reinterpret_cast<uint4*>(y + xp_index(row >> 5, KS, row & 31, c * 8)) = pack8(f);
+        else
+            *reinterpret_cast<uint4*>(y + (size_t)row * ldy + c * 8) = pack8(f);
+    }
+}
+
+void launch_layernorm_rows(const bf16_t* x, int ldx, const bf16_t* g, const bf16_t* b, bf16_t* y, int ldy,
+                           int M, int D, float eps, hipStream_t st) {
+    layernorm_rows_kernel<false><<<(M + 3) / 4, 256, 0, st>>>(x, ldx, g, b, y, ldy, M, D, eps);
+}
+void launch_layernorm_rows_packed(const bf16_t* x, int ldx, const bf16_t* g, const bf16_t* b, bf16_t* yp,
+                                  int M, int D, float eps, hipStream_t st) {
+    layernorm_rows_kernel<true><<<(M + 3) / 4, 256, 0, st>>>(x, ldx, g, b, yp, 0, M, D, eps);
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode row update + LayerNorm (one block per row):
+//   embedding mode : h = bf(wte[tok] + wpe[pos])                           (gpt_bigcode :1060-1063)
+//   residual mode  : h = bf(h + bf(sum_s ws[s][row][:] + bias))            (block residual adds)
+//   then           : xp = LN(h)   written in fragment order for the next skinny GEMM
+// the split-K slabs are summed in slab order -> bitwise deterministic.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* hrow = reinterpret_cast<float*>(smem_raw);          // [D]
+    __shared__ float redbuf[8];
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = p.D, NC = D >> 3;
+    bf16_t* hr = p.h + (size_t)row * p.ldh;
+
+    float s = 0.f;
+    for (int c = tid; c < NC; c += 256) {
+        float f[8];
+        if (p.ws == nullptr) {
+            const int tok = p.tokens[row], pos = p.positions[row];
+            float a[8], w[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.wte + (size_t)tok * D + c * 8), a);
+            unpack8(*reinterpret_cast<const uint4*>(p.wpe + (size_t)pos * D + c * 8), w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = bfround(a[e] + w[e]);
+        } else {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            for (int sp = 0; sp < p.splitk; ++sp) {
+                const float* src = p.ws + ((size_t)sp * p.rows_ws + row) * p.ldws + c * 8;
+                const float4 a = *reinterpret_cast<const float4*>(src);
+                const float4 b4 = *reinterpret_cast<const float4*>(src + 4);
+                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+                v[4] += b4.x; v[5] += b4.y; v[6] += b4.z; v[7] += b4.w;
+            }
+            float bb[8], hh[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.bias + c * 8), bb);
+            unpack8(*reinterpret_cast<const uint4*>(hr + c * 8), hh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = bfround(hh[e] + bfround(v[e] + bb[e]));
+        }
+        *reinterpret_cast<uint4*>(hr + c * 8) = pack8(f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hrow[c * 8 + e] = f[e]; s += f[e]; }
+    }
+    s = wave_sum(s);
+    if (lane == 0) redbuf[wave] = s;
+    __syncthreads();
+    const float mean = (redbuf[0] + redbuf[1] + redbuf[2] + redbuf[3]) / (float)D;
+    float q = 0.f;
+    for (int c = tid; c < NC; c += 256) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float d = hrow[c * 8 + e] - mean; q += d * d; }
+    }
+    q = wave_sum(q);
+    if (lane == 0) redbuf[4 + wave] = q;
+    __syncthreads();
+    const float rstd = rsqrtf((redbuf[4] + redbuf[5] + redbuf[6] + redbuf[7]) / (float)D + p.eps);
+    const int KS = D >> 4;
+    for (int c = tid; c < NC; c += 256) {
+        float f[8], gg[8], bb[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.g + c * 8), gg);
+        unpack8(*reinterpret_cast<const uint4*>(p.b + c * 8), bb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (hrow[c * 8 + e] - mean) * rstd * gg[e] + bb[e];
+        *reinterpret_cast<uint4*>(p.xp_out + xp_index(row >> 5, KS, row & 31, c * 8)) = pack8(f);
+    }
+}
+
+void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st) {
+    row_update_ln_kernel<<<a.M, 256, a.D * sizeof(float), st>>>(a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// patch embedding operand: image [B][3][S][S] -> patches [B*NP][Kpad]  (k = c*P*P + ky*P + kx)
+// (clip_model.py:174,182: Conv2d(3->width, k=P, s=P, bias=False) == GEMM over flattened patches)
+// ------------------------------------------------------------------------------------------------
+__global__ void im2col_kernel(const bf16_t* __restrict__ img, bf16_t* __restrict__ out, int B, int S, int P,
+                              int Kpad) {
+    const int G = S / P, NP = G * G, K = 3 * P * P;
+    const int chunks = Kpad >> 3;
+    const size_t total = (size_t)B * NP * chunks;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % chunks);
+        const size_t rowi = i / chunks;
+        const int pidx = (int)(rowi % NP), b = (int)(rowi / NP);
+        const int py = pidx / G, px = pidx % G;
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = ch * 8 + e;
+            bf16_t v = 0;
+            if (k < K) {
+                const int c = k / (P * P), rem = k % (P * P);
+                const int ky = rem / P, kx = rem % P;
+                v = img[(((size_t)b * 3 + c) * S + (py * P + ky)) * S + px * P + kx];
+            }
+            w[e >> 1] |= (uint32_t)v << ((e & 1) * 16);
+        }
+        *reinterpret_cast<uint4*>(out + rowi * Kpad + ch * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+void launch_im2col(const bf16_t* img, bf16_t* out, int B, int img_size, int patch, int Kpad, hipStream_t st) {
+    const int G = img_size / patch;
+    size_t total = (size_t)B * G * G * (Kpad / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    im2col_kernel<<<blocks, 256, 0, st>>>(img, out, B, img_size, patch, Kpad);
+}
+
+// ------------------------------------------------------------------------------------------------
+// ViT token assembly + ln_pre (clip_model.py:185-187): x[b][0] = cls, x[b][1+p] = patch_out ;
+// x = bf(x + pos) ; x = LN(x).  One wave per token row.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vit_embed_lnpre_kernel(const bf16_t* __restrict__ patch_out, int ldp,
+                                                              const bf16_t* __restrict__ cls,
+                                                              const bf16_t* __restrict__ pos,
+                                                              const bf16_t* __restrict__ g,
+                                                              const bf16_t* __restrict__ b,
+                                                              bf16_t* __restrict__ x, int B, int NP, int Dv,
+                                                              float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int T = NP + 1;
+    if (row >= B * T) return;
+    const int bi = row / T, tok = row % T;
+    const bf16_t* src = tok == 0 ? cls : patch_out + ((size_t)bi * NP + tok - 1) * ldp;
+    const bf16_t* pr = pos + (size_t)tok * Dv;
+    const int NC = Dv >> 3;
+    // Dv <= 8*64*4 = 2048 -> at most 4 chunks per lane kept in registers
+    float v[4][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < NC) {
+            float a[8], pp[8];
+            unpack8(*reinterpret_cast<const uint4*>(src + c * 8), a);
+            unpack8(*reinterpret_cast<const uint4*>(pr + c * 8), pp);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[i][e] = bfround(a[e] + pp[e]); s += v[i][e]; }
+        }
+    }
+    const float mean = wave_sum(s) / (float)Dv;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (lane + i * 64 < NC) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { float d = v[i][e] - mean; q += d * d; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)Dv + eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = lane + i * 64;
+        if (c < NC) {
+            float gg[8], bb[8], f[8];
+            unpack8(*reinterpret_cast<const uint4*>(g + c * 8), gg);
+            unpack8(*reinterpret_cast<const uint4*>(b + c * 8), bb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = (v[i][e] - mean) * rstd * gg[e] + bb[e];
+            *reinterpret_cast<uint4*>(x + (size_t)row * Dv + c * 8) = pack8(f);
+        }
+    }
+}
+void launch_vit_embed_lnpre(const bf16_t* patch_out, int ldp, const bf16_t* cls, const bf16_t* pos,
+                            const bf16_t* g, const bf16_t* b, bf16_t* x, int B, int NP, int Dv, float eps,
+                            hipStream_t st) {
+    int rows = B * (NP + 1);
+    vit_embed_lnpre_kernel<<<(rows + 3) / 4, 256, 0, st>>>(patch_out, ldp, cls, pos, g, b, x, B, NP, Dv, eps);
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoder prefill input: h = bf(inputs_embeds + wpe[0..S0-1])   (gpt_bigcode :980-985,1060-1063)
+// ------------------------------------------------------------------------------------------------
+__global__ void dec_embed_kernel(const bf16_t* __restrict__ emb, const bf16_t* __restrict__ wpe,
+                                 bf16_t* __restrict__ h, int B, int S0, int D) {
+    const int NC = D >> 3;
+    const size_t total = (size_t)B * S0 * NC;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % NC);
+        const size_t row = i / NC;
+        const int t = (int)(row % S0);
+        float a[8], w[8];
+        unpack8(*reinterpret_cast<const uint4*>(emb + row * D + c * 8), a);
+        unpack8(*reinterpret_cast<const uint4*>(wpe + (size_t)t * D + c * 8), w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] += w[e];
+        *reinterpret_cast<uint4*>(h + row * D + c * 8) = pack8(a);
+    }
+}
+void launch_dec_embed(const bf16_t* emb, const bf16_t* wpe, bf16_t* h, int B, int S0, int D, hipStream_t st) {
+    size_t total = (size_t)B * S0 * (D / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    dec_embed_kernel<<<blocks, 256, 0, st>>>(emb, wpe, h, B, S0, D);
+}
+
+// wte lookup (starvector_v1.py:16-18): out[i][:] = table[ids[i]][:]
+__global__ void gather_rows_kernel(const bf16_t* __restrict__ table, const int64_t* __restrict__ ids,
+                                   bf16_t* __restrict__ out, int n, int D) {
+    const int NC = D >> 3;
+    const size_t total = (size_t)n * NC;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % NC);
+        const size_t r = i / NC;
+        *reinterpret_cast<uint4*>(out + r * D + c * 8) =
+            *reinterpret_cast<const uint4*>(table + (size_t)ids[r] * D + c * 8);
+    }
+}
+void launch_gather_rows(const bf16_t* table, const int64_t* ids, bf16_t* out, int n, int D, hipStream_t st) {
+    size_t total = (size_t)n * (D / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    gather_rows_kernel<<<blocks, 256, 0, st>>>(table, ids, out, n, D);
+}
+
+// last prompt row of every sequence (only that row feeds ln_f + lm_head in prefill)
+__global__ void gather_last_rows_kernel(const bf16_t* __restrict__ h, bf16_t* __restrict__ out, int B, int S0,
+                                        int D) {
+    const int NC = D >> 3;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * NC; i += gridDim.x * blockDim.x) {
+        const int c = i % NC, b = i / NC;
+        *reinterpret_cast<uint4*>(out + (size_t)b * D + c * 8) =
+            *reinterpret_cast<const uint4*>(h + ((size_t)b * S0 + S0 - 1) * D + c * 8);
+    }
+}
+void launch_gather_last_rows(const bf16_t* h, bf16_t* out, int B, int S0, int D, hipStream_t st) {
+    int total = B * (D / 8);
+    gather_last_rows_kernel<<<(total + 255) / 256, 256, 0, st>>>(h, out, B, S0, D);
+}
+
+// ------------------------------------------------------------------------------------------------
+// adapter norm: nn.LayerNorm([Q, D]) over the joint plane, affine [Q][D] (adapter.py:25-26,38)
+// one 1024-thread block per sample, two-pass statistics (mean, then centred second moment)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void plane_layernorm_kernel(const bf16_t* __restrict__ x,
+                                                               const bf16_t* __restrict__ g,
+                                                               const bf16_t* __restrict__ b,
+                                                               bf16_t* __restrict__ y, int QD, float eps) {
+    __shared__ float red[16];
+    __shared__ float stat[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bf16_t* xs = x + (size_t)blockIdx.x * QD;
+    bf16_t* ys = y + (size_t)blockIdx.x * QD;
+    const int NC = QD >> 3;
+    float s = 0.f;
+    for (int c = tid; c < NC; c += 1024) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(xs + (size_t)c * 8), f);
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t += f[e];
+        s += t;
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        stat[0] = t / (float)QD;
+    }
+    __syncthreads();
+    const float mean = stat[0];
+    float q = 0.f;
+    for (int c = tid; c < NC; c += 1024) {
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(xs + (size_t)c * 8), f);
+        float t = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float d = f[e] - mean; t += d * d; }
+        q += t;
+    }
+    q = wave_sum(q);
+    __syncthreads();
+    if (lane == 0) red[wave] = q;
+    __syncthreads();
+    if (tid == 0) {
+        float t = 0.f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        stat[1] = rsqrtf(t / (float)QD + eps);
+    }
+    __syncthreads();
+    const float rstd = stat[1];
+    for (int c = tid; c < NC; c += 1024) {
+        float f[8], gg[8], bb[8];
+        unpack8(*reinterpret_cast<const uint4*>(xs + (size_t)c * 8), f);
+        unpack8(*reinterpret_cast<const uint4*>(g + (size_t)c * 8), gg);
+        unpack8(*reinterpret_cast<const uint4*>(b + (size_t)c * 8), bb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * rstd * gg[e] + bb[e];
+        *reinterpret_cast<uint4*>(ys + (size_t)c * 8) = pack8(f);
+    }
+}
+void launch_plane_layernorm(const bf16_t* x, const bf16_t* g, const bf16_t* b, bf16_t* y, int B, int QD,
+                            float eps, hipStream_t st) {
+    plane_layernorm_kernel<<<B, 1024, 0, st>>>(x, g, b, y, QD, eps);
+}
+
+// adapter_norm="batch_norm": nn.BatchNorm1d(Q) in eval = per-token affine from running statistics
+// (adapter.py:27-28)
+__global__ void token_batchnorm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                       const bf16_t* __restrict__ b, const bf16_t* __restrict__ rm,
+                                       const bf16_t* __restrict__ rv, bf16_t* __restrict__ y, int B, int Q,
+                                       int D, float eps) {
+    const int NC = D >> 3;
+    const size_t total = (size_t)B * Q * NC;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / NC;
+        const int c = (int)(i % NC);
+        const int qi = (int)(row % Q);
+        const float mean = bf2f(rm[qi]);
+        const float inv = 1.0f / sqrtf(bf2f(rv[qi]) + eps);
+        const float ww = bf2f(w[qi]), bb = bf2f(b[qi]);
+        float f[8];
+        unpack8(*reinterpret_cast<const uint4*>(x + row * D + c * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * inv * ww + bb;
+        *reinterpret_cast<uint4*>(y + row * D + c * 8) = pack8(f);
+    }
+}
+void launch_token_batchnorm(const bf16_t* x, const bf16_t* w, const bf16_t* b, const bf16_t* rm,
+                            const bf16_t* rv, bf16_t* y, int B, int Q, int D, float eps, hipStream_t st) {
+    size_t total = (size_t)B * Q * (D / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    token_batchnorm_kernel<<<blocks, 256, 0, st>>>(x, w, b, rm, rv, y, B, Q, D, eps);
+}
+
+}  // namespace sv

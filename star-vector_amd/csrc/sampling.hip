@@ -1,0 +1,205 @@
+// Token selection + generation bookkeeping on device (no per-step host sync).
+//   argmax        : greedy (HF _sample with do_sample=False): argmax of the fp32 logits, lowest index on ties
+//   sample_top_p  : TemperatureLogitsWarper -> TopPLogitsWarper(min_tokens_to_keep=1) -> softmax -> one
+//                   multinomial draw (counter-based RNG; distributional parity with torch.multinomial)
+//   finish_step   : pad-after-EOS, append, EOS bookkeeping, the reference's row-0 stop sequence
+//                   (starvector_base.py:9-20), max-length budget -> device "done" flag
+#include "kernels.h"
+
+namespace sv {
+
+#define SP_THREADS 1024
+
+__device__ __forceinline__ void argmax_pair(float& v, int& i, float ov, int oi) {
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+}
+
+__global__ __launch_bounds__(SP_THREADS) void argmax_kernel(const float* __restrict__ logits, int ld, int V,
+                                                            int32_t* __restrict__ out) {
+    __shared__ float sv_[16];
+    __shared__ int si_[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = logits + (size_t)blockIdx.x * ld;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = tid * 4; i < V; i += SP_THREADS * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(row + i);
+        const float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (i + e < V) argmax_pair(best, bi, a[e], i + e);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        argmax_pair(best, bi, ov, oi);
+    }
+    if (lane == 0) { sv_[wave] = best; si_[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 16; ++w) argmax_pair(best, bi, sv_[w], si_[w]);
+        out[blockIdx.x] = bi;
+    }
+}
+void launch_argmax(const float* logits, int ld, int V, int32_t* out, int B, hipStream_t st) {
+    argmax_kernel<<<B, SP_THREADS, 0, st>>>(logits, ld, V, out);
+}
+
+// block-wide sum (all threads get the result)
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < SP_THREADS / 64; ++w) t += red[w];
+    return t;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < SP_THREADS / 64; ++w) t = fmaxf(t, red[w]);
+    return t;
+}
+
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+__global__ __launch_bounds__(SP_THREADS) void sample_top_p_kernel(SampleArgs p) {
+    __shared__ float red[SP_THREADS / 64];
+    __shared__ float scan[SP_THREADS];
+    __shared__ int result;
+    const int tid = threadIdx.x;
+    const int V = p.V;
+    const float* row = p.logits + (size_t)blockIdx.x * p.ld;
+    const float invT = 1.0f / p.temperature;
+
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += SP_THREADS) mx = fmaxf(mx, row[i] * invT);
+    mx = block_max(mx, red);
+    float z = 0.f;
+    for (int i = tid; i < V; i += SP_THREADS) z += __expf(row[i] * invT - mx);
+    z = block_sum(z, red);
+    const float invZ = 1.0f / z;
+
+    // smallest probability value v0 whose at-or-below mass exceeds 1 - top_p: bisection over the
+    // (monotone) float bit pattern; tokens with prob >= v0 survive (TopPLogitsWarper: ascending
+    // sort, drop while cumulative mass <= 1 - top_p, always keep the most probable token)
+    uint32_t lo = 0u, hi = 0x3f800000u;   // (lo, hi]
+    const float cut = 1.0f - p.top_p;
+    if (p.top_p < 1.0f) {
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            const float thr = __uint_as_float(mid);
+            float f = 0.f;
+            for (int i = tid; i < V; i += SP_THREADS) {
+                const float pr = __expf(row[i] * invT - mx) * invZ;
+                f += pr <= thr ? pr : 0.f;
+            }
+            f = block_sum(f, red);
+            if (f > cut) hi = mid; else lo = mid;
+        }
+    } else {
+        hi = 0u;
+    }
+    const float v0 = __uint_as_float(hi);
+
+    // multinomial over the survivors, in index order: per-thread contiguous ranges + block scan
+    const int per = (V + SP_THREADS - 1) / SP_THREADS;
+    const int beg = tid * per, end = min(beg + per, V);
+    float mine = 0.f;
+    for (int i = beg; i < end; ++i) {
+        const float pr = __expf(row[i] * invT - mx) * invZ;
+        mine += pr >= v0 ? pr : 0.f;
+    }
+    scan[tid] = mine;
+    __syncthreads();
+    if (tid == 0) {
+        float run = 0.f;
+        for (int t = 0; t < SP_THREADS; ++t) { const float x = scan[t]; scan[t] = run; run += x; }
+        red[0] = run;
+        result = -1;
+    }
+    __syncthreads();
+    const float total = red[0];
+    const uint64_t h = splitmix64(p.seed ^ splitmix64(((uint64_t)(uint32_t)p.step[0] << 32) | (uint32_t)blockIdx.x));
+    const float u = (float)((h >> 40) * (1.0 / 16777216.0)) * total;
+    const float base = scan[tid];
+    if (mine > 0.f && u >= base && u < base + mine) {
+        float run = base;
+        int pick = -1;
+        for (int i = beg; i < end; ++i) {
+            const float pr = __expf(row[i] * invT - mx) * invZ;
+            if (pr >= v0) {
+                run += pr;
+                pick = i;                 // last survivor seen (guards fp round-off at the range end)
+                if (u < run) break;
+            }
+        }
+        result = pick;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (result < 0) {
+            // round-off fell between ranges: take the most probable token (always a survivor)
+            float best = -INFINITY; int bi = 0;
+            for (int i = 0; i < V; ++i) if (row[i] > best) { best = row[i]; bi = i; }
+            result = bi;
+        }
+        p.out[blockIdx.x] = result;
+    }
+}
+void launch_sample_top_p(const SampleArgs& a, hipStream_t st) {
+    sample_top_p_kernel<<<a.B, SP_THREADS, 0, st>>>(a);
+}
+
+__global__ void finish_step_kernel(FinishArgs p) {
+    __shared__ int any_unf;
+    if (*p.done) return;
+    const int b = threadIdx.x;
+    const int t = *p.step;
+    if (b == 0) any_unf = 0;
+    __syncthreads();
+    if (b < p.B) {
+        const int unf = p.unfinished[b];
+        const int tok = unf ? p.next[b] : p.pad;
+        p.out_tokens[(size_t)b * p.ld_out + t] = tok;
+        p.cur_tok[b] = tok;
+        const int still = unf && tok != p.eos;
+        p.unfinished[b] = still;
+        p.positions[b] += 1;
+        if (still) atomicOr(&any_unf, 1);
+    }
+    __syncthreads();
+    if (b == 0) {
+        bool fired = false;
+        if (p.n_stop > 0 && t + 1 >= p.n_stop) {
+            fired = true;
+            for (int i = 0; i < p.n_stop; ++i)
+                if (p.out_tokens[t + 1 - p.n_stop + i] != p.stop_ids[i]) { fired = false; break; }
+        }
+        *p.step = t + 1;
+        if (fired || !any_unf || t + 1 >= p.max_new) {
+            *p.done = 1;
+            *p.n_emitted = t + 1;
+        }
+    }
+}
+void launch_finish_step(const FinishArgs& a, hipStream_t st) {
+    int threads = ((a.B + 63) / 64) * 64;
+    finish_step_kernel<<<1, threads, 0, st>>>(a);
+}
+
+}  // namespace sv

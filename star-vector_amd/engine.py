@@ -1,0 +1,253 @@
+"""Python handle on the C-ABI engine: tensors in, tensors out (PyTorch is only the allocator/stream)."""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Dict, Iterable, Optional, Sequence
+
+import torch
+
+from . import _lib
+from ._lib import SvConfig, SvSampling, check
+
+
+@dataclass
+class EngineConfig:
+    """Shapes of the path; defaults = StarVector-1B (StarVectorConfig, starvector_arch.py:96-131)."""
+    image_size: int = 224
+    patch_size: int = 14
+    vit_width: int = 1024
+    vit_layers: int = 23
+    vit_heads: int = 16
+    adapter_norm: str = "layer_norm"
+    hidden: int = 2048
+    n_layer: int = 24
+    n_head: int = 16
+    n_inner: int = 8192
+    vocab: int = 49156
+    n_positions: int = 8192
+    max_batch: int = 32
+    max_seq_len: int = 2048
+    ln_eps: float = 1e-5
+
+    @property
+    def query_length(self) -> int:
+        return (self.image_size // self.patch_size) ** 2 + 1
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need(t: torch.Tensor, dtype, what: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise ValueError(f"{what} must be a CUDA(HIP) tensor; the engine has no CPU path")
+    if t.dtype != dtype:
+        raise ValueError(f"{what} must be {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+class HipEngine:
+    """Owns one ``sv_engine`` (weights repacked into library memory, paged KV pool, workspaces)."""
+
+    def __init__(self, cfg: EngineConfig, device: Optional[int] = None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise _lib.StarVectorHipError("no HIP device visible; the StarVector engine requires a GPU")
+        self.cfg = cfg
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        c = SvConfig(cfg.image_size, cfg.patch_size, cfg.vit_width, cfg.vit_layers, cfg.vit_heads,
+                     _lib.SV_NORM_LAYER if cfg.adapter_norm == "layer_norm" else _lib.SV_NORM_BATCH,
+                     cfg.hidden, cfg.n_layer, cfg.n_head, cfg.n_inner, cfg.vocab, cfg.n_positions,
+                     cfg.max_batch, cfg.max_seq_len, cfg.ln_eps, self.device)
+        h = C.c_void_p()
+        check(self.lib.sv_create(C.byref(c), C.byref(h)), "sv_create")
+        self._h = h
+        self._dev = torch.device("cuda", self.device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.sv_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- weights -------------------------------------------------------------------------------
+    def load_weight(self, name: str, t: torch.Tensor) -> None:
+        if t.dtype == torch.bfloat16:
+            dt = _lib.SV_DTYPE_BF16
+        elif t.dtype == torch.float32:
+            dt = _lib.SV_DTYPE_F32
+        else:
+            t = t.to(torch.float32)
+            dt = _lib.SV_DTYPE_F32
+        t = t.to(self._dev).contiguous()
+        shape = (C.c_int64 * max(t.dim(), 1))(*(t.shape if t.dim() else (1,)))
+        check(self.lib.sv_load_weight(self._h, name.encode(), _ptr(t), dt, max(t.dim(), 1), shape, _stream()),
+              f"sv_load_weight({name})")
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True) -> None:
+        """Ingest a reference state_dict (keys as saved by the reference, train/util.py:71)."""
+        skipped = []
+        for k, v in sd.items():
+            if k.endswith("num_batches_tracked") or k.endswith(".attn.bias") or k.endswith(".attn.masked_bias"):
+                continue
+            try:
+                self.load_weight(k, v)
+            except KeyError:
+                skipped.append(k)
+        if strict and skipped:
+            raise KeyError(f"unexpected keys in state_dict: {skipped[:5]}{'...' if len(skipped) > 5 else ''}")
+        check(self.lib.sv_weights_complete(self._h), "sv_weights_complete")
+
+    # ---- forward entry points -----------------------------------------------------------------
+    def encode_image(self, image: torch.Tensor) -> torch.Tensor:
+        image = _need(image, torch.bfloat16, "image")
+        B = image.shape[0]
+        if image.shape[1:] != (3, self.cfg.image_size, self.cfg.image_size):
+            raise ValueError(f"image must be [B,3,{self.cfg.image_size},{self.cfg.image_size}], got {tuple(image.shape)}")
+        out = torch.empty(B, self.cfg.query_length, self.cfg.vit_width, dtype=torch.bfloat16, device=image.device)
+        check(self.lib.sv_encode_image(self._h, _ptr(image), B, _ptr(out), _stream()), "sv_encode_image")
+        return out
+
+    def adapter(self, x: torch.Tensor) -> torch.Tensor:
+        x = _need(x, torch.bfloat16, "adapter input")
+        B = x.shape[0]
+        if x.shape[1:] != (self.cfg.query_length, self.cfg.vit_width):
+            raise ValueError(f"adapter input must be [B,{self.cfg.query_length},{self.cfg.vit_width}]")
+        out = torch.empty(B, self.cfg.query_length, self.cfg.hidden, dtype=torch.bfloat16, device=x.device)
+        check(self.lib.sv_adapter(self._h, _ptr(x), B, _ptr(out), _stream()), "sv_adapter")
+        return out
+
+    def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
+        ids = _need(ids, torch.int64, "input_ids")
+        out = torch.empty(*ids.shape, self.cfg.hidden, dtype=torch.bfloat16, device=ids.device)
+        check(self.lib.sv_embed_tokens(self._h, _ptr(ids), ids.numel(), _ptr(out), _stream()), "sv_embed_tokens")
+        return out
+
+    def prefill(self, inputs_embeds: torch.Tensor) -> torch.Tensor:
+        x = _need(inputs_embeds, torch.bfloat16, "inputs_embeds")
+        B, S0, D = x.shape
+        if D != self.cfg.hidden:
+            raise ValueError("inputs_embeds hidden size mismatch")
+        logits = torch.empty(B, self.cfg.vocab, dtype=torch.float32, device=x.device)
+        check(self.lib.sv_prefill(self._h, _ptr(x), B, S0, _ptr(logits), _stream()), "sv_prefill")
+        return logits
+
+    def decode_step(self, tokens: torch.Tensor) -> torch.Tensor:
+        tokens = _need(tokens.to(torch.int32), torch.int32, "tokens")
+        B = tokens.numel()
+        logits = torch.empty(B, self.cfg.vocab, dtype=torch.float32, device=tokens.device)
+        check(self.lib.sv_decode_step(self._h, _ptr(tokens), B, _ptr(logits), _stream()), "sv_decode_step")
+        return logits
+
+    def generate(self, inputs_embeds: torch.Tensor, max_length: int, do_sample: bool = False,
+                 temperature: float = 1.0, top_p: float = 1.0, eos_token_id: int = 0, pad_token_id: int = 0,
+                 stop_ids: Optional[Sequence[int]] = None, seed: int = 0, sync_every: int = 32) -> torch.Tensor:
+        """HF ``generate`` semantics for inputs_embeds: returns ONLY the new tokens, int64 [B, N]."""
+        x = _need(inputs_embeds, torch.bfloat16, "inputs_embeds")
+        B, S0, D = x.shape
+        if D != self.cfg.hidden:
+            raise ValueError("inputs_embeds hidden size mismatch")
+        max_new = max_length - S0
+        if max_new <= 0:
+            raise ValueError(f"max_length ({max_length}) must exceed the prompt length ({S0})")
+        stops = list(stop_ids) if stop_ids else []
+        arr = (C.c_int32 * max(len(stops), 1))(*stops) if stops else None
+        sp = SvSampling(int(bool(do_sample)), float(temperature), float(top_p), int(max_length), int(eos_token_id),
+                        int(pad_token_id), len(stops), C.cast(arr, C.POINTER(C.c_int32)) if stops else None,
+                        int(seed) & 0xFFFFFFFFFFFFFFFF, int(sync_every))
+        out = torch.empty(B, max_new, dtype=torch.int64, device=x.device)
+        n = C.c_int32(0)
+        check(self.lib.sv_generate(self._h, _ptr(x), B, S0, C.byref(sp), _ptr(out), C.byref(n), _stream()), "sv_generate")
+        return out[:, : n.value]
+
+    def last_timing(self) -> Dict[str, float]:
+        buf = (C.c_double * 4)()
+        check(self.lib.sv_last_timing(self._h, buf), "sv_last_timing")
+        return {"ttft_ms": buf[0], "decode_ms": buf[1], "decode_steps": buf[2], "graph": bool(buf[3])}
+
+    def profile_decode_step(self, B: int, iters: int = 5) -> Dict[str, Dict[str, float]]:
+        """HIP-event time per decode step by kernel class (eager launches of the graph's kernels)."""
+        buf = (C.c_double * 8)()
+        check(self.lib.sv_profile_decode_step(self._h, B, iters, buf, _stream()), "sv_profile_decode_step")
+        names = ["skinny_gemm", "attn_decode", "row_update_ln", "other"]
+        return {n: {"ms_per_step": buf[2 * i], "launches_per_step": buf[2 * i + 1]} for i, n in enumerate(names)}
+
+
+# ---- single operators (used by the parity tests; one per SURVEY.md section 8a row) ----------------
+def op_layernorm(x, gamma, beta, eps=1e-5):
+    lib = _lib.load()
+    x = _need(x, torch.bfloat16, "x"); M, D = x.shape
+    y = torch.empty_like(x)
+    check(lib.sv_op_layernorm(_ptr(x), _ptr(_need(gamma, torch.bfloat16, "gamma")),
+                              _ptr(_need(beta, torch.bfloat16, "beta")), _ptr(y), M, D, eps, _stream()))
+    return y
+
+
+def op_linear(x, W, bias=None, residual=None, act="none", out_f32=False):
+    lib = _lib.load()
+    x = _need(x, torch.bfloat16, "x"); W = _need(W, torch.bfloat16, "W")
+    M, K = x.shape; N = W.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    b = _need(bias, torch.bfloat16, "bias") if bias is not None else None
+    r = _need(residual, torch.bfloat16, "residual") if residual is not None else None
+    check(lib.sv_op_linear(_ptr(x), _ptr(W), _ptr(b), _ptr(r), _ptr(y), M, N, K, _lib.ACT[act], int(out_f32), _stream()))
+    return y
+
+
+def op_linear_skinny(x, W, bias=None, splitk=1):
+    lib = _lib.load()
+    x = _need(x, torch.bfloat16, "x"); W = _need(W, torch.bfloat16, "W")
+    M, K = x.shape; N = W.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    b = _need(bias, torch.bfloat16, "bias") if bias is not None else None
+    check(lib.sv_op_linear_skinny(_ptr(x), _ptr(W), _ptr(b), _ptr(y), M, N, K, splitk, _stream()))
+    return y
+
+
+def op_attention(q, k, v, n_head, n_kv_head, causal, scale=None):
+    lib = _lib.load()
+    q = _need(q, torch.bfloat16, "q"); k = _need(k, torch.bfloat16, "k"); v = _need(v, torch.bfloat16, "v")
+    B, S, HD = q.shape
+    hd = HD // n_head
+    out = torch.empty_like(q)
+    check(lib.sv_op_attention(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, S, n_head, n_kv_head, hd, int(causal),
+                              float(scale if scale is not None else hd ** -0.5), _stream()))
+    return out
+
+
+def op_plane_layernorm(x, gamma, beta, eps=1e-5):
+    lib = _lib.load()
+    x = _need(x, torch.bfloat16, "x"); B = x.shape[0]; QD = x[0].numel()
+    y = torch.empty_like(x)
+    check(lib.sv_op_plane_layernorm(_ptr(x), _ptr(_need(gamma, torch.bfloat16, "gamma")),
+                                    _ptr(_need(beta, torch.bfloat16, "beta")), _ptr(y), B, QD, eps, _stream()))
+    return y
+
+
+def op_argmax(logits):
+    lib = _lib.load()
+    logits = _need(logits, torch.float32, "logits"); B, V = logits.shape
+    if V % 4:
+        raise ValueError("V must be a multiple of 4")
+    out = torch.empty(B, dtype=torch.int32, device=logits.device)
+    check(lib.sv_op_argmax(_ptr(logits), B, V, V, _ptr(out), _stream()))
+    return out
+
+
+def op_sample_top_p(logits, temperature, top_p, seed, step):
+    lib = _lib.load()
+    logits = _need(logits, torch.float32, "logits"); B, V = logits.shape
+    out = torch.empty(B, dtype=torch.int32, device=logits.device)
+    check(lib.sv_op_sample_top_p(_ptr(logits), B, V, V, float(temperature), float(top_p), int(seed), int(step),
+                                 _ptr(out), _stream()))
+    return out

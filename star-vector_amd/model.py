@@ -1,0 +1,428 @@
+"""Host-side mirror of the reference's operator interface for the im2svg hot path.
+
+Same names, argument meaning and error behaviour as the reference classes, so a caller of
+``StarVectorForCausalLM.generate_im2svg`` / ``model.model.image_encoder`` / ``image_projection`` /
+``svg_transformer.transformer.generate`` can switch without edits.  Every forward goes through the
+C-ABI HIP engine (``engine.HipEngine``); there is no PyTorch compute path here.
+
+Reference lines mirrored:
+  StarVectorConfig / StarVectorForCausalLM   starvector/model/starvector_arch.py:96-193
+  StarVectorBase orchestration               starvector/model/models/starvector_base.py:203-295
+  StarVectorStarCoder (v1)                   starvector/model/models/starvector_v1.py:6-22
+  ImageEncoder (clip branch)                 starvector/model/image_encoder/image_encoder.py:9-119
+  Adapter                                    starvector/model/adapters/adapter.py:12-39
+  StarCoderModel                             starvector/model/llm/starcoder.py:9-53
+  ImageTrainProcessor                        starvector/data/util.py:40-68
+"""
+from __future__ import annotations
+
+import json
+import os
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .engine import EngineConfig, HipEngine
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)   # data/util.py:33-38
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+class StarVectorConfig:
+    """starvector_arch.py:96-131 (fields the hot path reads) + the engine sizing knobs."""
+    model_type = "starvector"
+
+    def __init__(self, starcoder_model_name: str = "bigcode/starcoderbase-1b", image_encoder_type: str = "clip",
+                 adapter_norm: str = "layer_norm", image_size: int = 224, max_length: int = 8192,
+                 max_length_train: int = 8192, use_flash_attn: bool = True, use_cache: bool = True,
+                 num_attention_heads: int = 16, num_hidden_layers: int = 24, vocab_size: int = 49152,
+                 hidden_size: int = 2048, num_kv_heads: int = 4, torch_dtype: str = "bfloat16",
+                 # engine-only (not in the reference config): shapes that the reference takes from the HF
+                 # sub-model configs, and the batch/sequence capacity the KV pool is sized for
+                 n_inner: Optional[int] = None, n_positions: int = 8192, added_tokens: int = 4,
+                 vit_width: int = 1024, vit_layers: int = 23, vit_heads: int = 16, patch_size: int = 14,
+                 max_batch: int = 32, **kwargs):
+        self.starcoder_model_name = starcoder_model_name
+        self.image_encoder_type = image_encoder_type
+        self.adapter_norm = adapter_norm
+        self.image_size = image_size
+        self.max_length = max_length
+        self.max_length_train = max_length_train
+        self.use_flash_attn = use_flash_attn
+        self.use_cache = use_cache
+        self.num_attention_heads = num_attention_heads
+        self.num_hidden_layers = num_hidden_layers
+        self.vocab_size = vocab_size
+        self.hidden_size = hidden_size
+        self.num_kv_heads = num_kv_heads
+        self.torch_dtype = torch_dtype
+        self.n_inner = n_inner if n_inner is not None else 4 * hidden_size
+        self.n_positions = n_positions
+        self.added_tokens = added_tokens          # [PAD] + <svg-start>,<image-start>,<caption-start>
+        self.vit_width, self.vit_layers, self.vit_heads, self.patch_size = vit_width, vit_layers, vit_heads, patch_size
+        self.max_batch = max_batch
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    def engine_config(self) -> EngineConfig:
+        if "starcoder2" in self.starcoder_model_name:
+            raise NotImplementedError("StarVector-8B (StarCoder2 + SigLIP) is a later row of the build plan "
+                                      "(SURVEY.md section 8f rank 3)")
+        if self.image_encoder_type != "clip":
+            raise NotImplementedError(f"image_encoder_type={self.image_encoder_type!r}: only the clip branch is built")
+        if str(self.torch_dtype).replace("torch.", "") not in ("bfloat16", "auto"):
+            raise ValueError("the HIP engine computes in bfloat16 (BASELINE config 2); got torch_dtype="
+                             f"{self.torch_dtype}")
+        return EngineConfig(image_size=self.image_size, patch_size=self.patch_size, vit_width=self.vit_width,
+                            vit_layers=self.vit_layers, vit_heads=self.vit_heads, adapter_norm=self.adapter_norm,
+                            hidden=self.hidden_size, n_layer=self.num_hidden_layers, n_head=self.num_attention_heads,
+                            n_inner=self.n_inner, vocab=self.vocab_size + self.added_tokens,
+                            n_positions=self.n_positions, max_batch=self.max_batch,
+                            max_seq_len=min(self.max_length, self.n_positions))
+
+
+# --------------------------------------------------------------------------------------------------
+# tokenizer used when the gated StarCoder tokenizer is not on disk
+# --------------------------------------------------------------------------------------------------
+class _Encoding(dict):
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def to(self, device):
+        return _Encoding({k: (v.to(device) if torch.is_tensor(v) else v) for k, v in self.items()})
+
+
+class ByteTokenizer:
+    """Deterministic byte-level stand-in with the tokenizer surface the path uses
+    (llm/starcoder.py:40-53): eos id 0, ``[PAD]`` = vocab_size, then the three added tokens."""
+
+    def __init__(self, vocab_size: int = 49152):
+        self.vocab_size = vocab_size
+        self.eos_token, self.eos_token_id = "<|endoftext|>", 0
+        self.bos_token_id = 0
+        self.pad_token, self.pad_token_id = "[PAD]", vocab_size
+        self.added = {"<svg-start>": vocab_size + 1, "<image-start>": vocab_size + 2, "<caption-start>": vocab_size + 3}
+        self.padding_side = "right"
+
+    def __len__(self):
+        return self.vocab_size + 4
+
+    def encode(self, text: str, add_special_tokens: bool = False) -> List[int]:
+        if text in self.added:
+            return [self.added[text]]
+        return [1 + b for b in text.encode("utf-8")]
+
+    def __call__(self, text, add_special_tokens: bool = False, return_tensors: Optional[str] = None, **kw):
+        single = isinstance(text, str)
+        rows = [self.encode(t) for t in ([text] if single else text)]
+        if return_tensors is None:
+            return _Encoding(input_ids=rows[0] if single else rows)
+        n = max(len(r) for r in rows)
+        ids = torch.full((len(rows), n), self.pad_token_id, dtype=torch.long)
+        mask = torch.zeros((len(rows), n), dtype=torch.long)
+        for i, r in enumerate(rows):
+            ids[i, : len(r)] = torch.tensor(r, dtype=torch.long)
+            mask[i, : len(r)] = 1
+        return _Encoding(input_ids=ids, attention_mask=mask)
+
+    def decode(self, ids, skip_special_tokens: bool = True) -> str:
+        out = bytearray()
+        for t in (ids.tolist() if torch.is_tensor(ids) else ids):
+            if 1 <= t <= 256:
+                out.append(t - 1)
+            elif not skip_special_tokens:
+                out.extend(f"<{t}>".encode())
+        return out.decode("utf-8", "replace")
+
+    def batch_decode(self, ids, skip_special_tokens: bool = True) -> List[str]:
+        return [self.decode(r, skip_special_tokens) for r in ids]
+
+
+# --------------------------------------------------------------------------------------------------
+# image pre-processing (host side, PIL): data/util.py:40-68
+# --------------------------------------------------------------------------------------------------
+class ImageTrainProcessor:
+    def __init__(self, mean=None, std=None, size: int = 224, **kwargs):
+        self.mean = torch.tensor(mean or CLIP_MEAN).view(3, 1, 1)
+        self.std = torch.tensor(std or CLIP_STD).view(3, 1, 1)
+        self.size = size
+
+    def __call__(self, img):
+        from PIL import Image
+        import numpy as np
+        if img.mode == "RGBA":                               # _rgba_to_rgb_white (data/util.py:64-67)
+            bg = Image.new("RGB", img.size, (255, 255, 255))
+            bg.paste(img, mask=img.split()[3])
+            img = bg
+        w, h = img.size                                      # _pad_to_square, white (data/util.py:56-62)
+        m = max(w, h)
+        if (w, h) != (m, m):
+            canvas = Image.new(img.mode, (m, m), 255 if img.mode in ("L", "1") else (255,) * len(img.getbands()))
+            canvas.paste(img, ((m - w) // 2, (m - h) // 2))
+            img = canvas
+        if img.size != (self.size, self.size):               # transforms.Resize(size, BICUBIC) on a PIL image
+            img = img.resize((self.size, self.size), Image.BICUBIC)
+        if img.mode != "RGB":
+            img = img.convert("RGB")
+        x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0   # ToTensor
+        return (x - self.mean) / self.std
+
+
+# --------------------------------------------------------------------------------------------------
+# modules
+# --------------------------------------------------------------------------------------------------
+class _EngineModule(nn.Module):
+    """nn.Module shell so .eval()/.cuda()/.to() calls of existing callers keep working; holds no
+    parameters (weights live repacked inside the engine)."""
+
+    def __init__(self, engine: HipEngine):
+        super().__init__()
+        object.__setattr__(self, "_engine", engine)
+
+
+class ImageEncoder(_EngineModule):
+    """image_encoder.py:91-94 (clip branch): ln_vision(VisionTransformer(image)) -> [B,257,1024]."""
+
+    def __init__(self, engine: HipEngine, image_size: int = 224):
+        super().__init__(engine)
+        self.image_encoder_type = "clip"
+        self.processor = ImageTrainProcessor(size=image_size)
+
+    def forward(self, image: torch.Tensor) -> torch.Tensor:
+        return self._engine.encode_image(image)
+
+    def process_images(self, images):                      # image_encoder.py:112-117
+        return [self.processor(image).unsqueeze(0) for image in images]
+
+
+class Adapter(_EngineModule):
+    """adapter.py:33-39: Linear -> Swish -> Linear -> LayerNorm([Q,D]) | BatchNorm1d(Q)."""
+
+    def __init__(self, engine: HipEngine, query_length: int, adapter_norm: str):
+        super().__init__(engine)
+        self.query_length = query_length
+        self.adapter_norm = adapter_norm
+
+    def forward(self, hidden_states: torch.Tensor) -> torch.Tensor:
+        return self._engine.adapter(hidden_states)
+
+
+class _TokenEmbedding(_EngineModule):
+    def forward(self, input_ids: torch.Tensor) -> torch.Tensor:
+        return self._engine.embed_tokens(input_ids)
+
+
+class _Backbone(_EngineModule):
+    """stand-in for GPTBigCodeModel: exposes ``wte`` (starvector_v1.py:16-18)."""
+
+    def __init__(self, engine: HipEngine):
+        super().__init__(engine)
+        self.wte = _TokenEmbedding(engine)
+
+
+class HipCausalLM(_EngineModule):
+    """The object the reference reaches as ``svg_transformer.transformer``: ``.generate(**kwargs)`` with
+    the keyword set built at starvector_base.py:228-241 (+ :289-295), ``.transformer.wte``."""
+
+    def __init__(self, engine: HipEngine, eos_token_id: int, pad_token_id: int):
+        super().__init__(engine)
+        self.transformer = _Backbone(engine)
+        self.eos_token_id = eos_token_id
+        self.pad_token_id = pad_token_id
+        self.seed = 0
+
+    @staticmethod
+    def _stop_ids(stopping_criteria) -> Optional[List[int]]:
+        if not stopping_criteria:
+            return None
+        stops: List[List[int]] = []
+        for crit in stopping_criteria:
+            s = getattr(crit, "stops", None)
+            if s is None:
+                raise NotImplementedError(f"unsupported stopping criterion {type(crit).__name__}: the engine evaluates "
+                                          "the reference's StoppingCriteriaSub (token-sequence stop) on device")
+            stops.extend([list(map(int, x)) for x in s])
+        if len(stops) > 1:
+            raise NotImplementedError("one stop sequence is supported (the reference passes exactly one: '</svg>')")
+        return stops[0] if stops else None
+
+    @torch.no_grad()
+    def generate(self, inputs_embeds: torch.Tensor = None, attention_mask: Optional[torch.Tensor] = None,
+                 do_sample: bool = False, top_p: Optional[float] = 1.0, temperature: Optional[float] = 1.0,
+                 num_beams: int = 1, max_length: int = 30, min_length: int = 0, repetition_penalty: float = 1.0,
+                 length_penalty: float = 1.0, use_cache: bool = True, stopping_criteria=None,
+                 early_stopping: bool = False, pad_token_id: Optional[int] = None, eos_token_id: Optional[int] = None,
+                 num_return_sequences: int = 1, **unused) -> torch.Tensor:
+        if inputs_embeds is None:
+            raise ValueError("inputs_embeds is required (the reference always generates from embeddings)")
+        if num_beams != 1:
+            raise NotImplementedError("beam search (num_beams>1) is the next row of the build plan "
+                                      "(SURVEY.md section 8f rank 2); pass num_beams=1")
+        if repetition_penalty not in (None, 1.0) or num_return_sequences != 1:
+            raise NotImplementedError("repetition_penalty != 1 / num_return_sequences > 1 not built yet")
+        if attention_mask is not None and not bool((attention_mask == 1).all()):
+            raise NotImplementedError("left/right padding masks are not on the im2svg path (mask is all ones)")
+        S0 = inputs_embeds.shape[1]
+        # HF: min_length is reduced by the prompt length, leaving 0 on this path
+        if max(int(min_length or 0) - S0, 0) > 0:
+            raise NotImplementedError("min_length beyond the prompt length is not built")
+        if not use_cache:
+            pass        # the engine always uses its paged KV cache; results are identical
+        return self._engine.generate(
+            inputs_embeds.to(torch.bfloat16), max_length=int(max_length), do_sample=bool(do_sample),
+            temperature=float(temperature if temperature is not None else 1.0),
+            top_p=float(top_p if top_p is not None else 1.0),
+            eos_token_id=int(self.eos_token_id if eos_token_id is None else eos_token_id),
+            pad_token_id=int(self.pad_token_id if pad_token_id is None else pad_token_id),
+            stop_ids=self._stop_ids(stopping_criteria), seed=self.seed)
+
+
+class StoppingCriteriaSub:
+    """starvector_base.py:9-20: stop the whole batch when ROW 0 ends with one of ``stops``.
+    Carried to the device by HipCausalLM.generate (no per-step host sync)."""
+
+    def __init__(self, stops=()):
+        self.stops = [list(s) for s in stops]
+
+    def __call__(self, input_ids, scores=None, **kw):
+        return any(input_ids[0][-len(s):].tolist() == s for s in self.stops)
+
+
+class StarCoderModel(nn.Module):
+    """llm/starcoder.py:9-53: tokenizer + causal LM + the '<svg' prompt."""
+
+    def __init__(self, engine: HipEngine, tokenizer, max_length: int):
+        super().__init__()
+        self.tokenizer = tokenizer
+        self.max_length = max_length
+        self.transformer = HipCausalLM(engine, tokenizer.eos_token_id, tokenizer.pad_token_id)
+        self.prompt = "<svg"
+        self.svg_start_token = "<svg-start>"
+        self.image_start_token = "<image-start>"
+        self.text_start_token = "<caption-start>"
+        self.svg_start_token_id = tokenizer.encode(self.svg_start_token)[0]
+
+
+class StarVectorStarCoder(nn.Module):
+    """StarVectorBase + v1 binding (starvector_base.py:22-48,203-295; starvector_v1.py)."""
+
+    def __init__(self, config: StarVectorConfig, engine: HipEngine, tokenizer):
+        super().__init__()
+        self.task = "im2svg"
+        self.model_precision = torch.bfloat16
+        ec = engine.cfg
+        self.svg_transformer = StarCoderModel(engine, tokenizer, config.max_length)
+        self.image_encoder = ImageEncoder(engine, ec.image_size)
+        self.query_length = ec.query_length                          # starvector_base.py:85-106
+        self.image_projection = Adapter(engine, self.query_length, ec.adapter_norm)
+        self.max_length = config.max_length_train - self.query_length - 4
+        self.processor = self.image_encoder.processor
+
+    def use_image_encoder(self):
+        return True
+
+    def _get_embeddings(self, input_ids):                             # starvector_v1.py:16-18
+        return self.svg_transformer.transformer.transformer.wte(input_ids)
+
+    def _tokenize(self, text, max_length, device, add_special_tokens=True):
+        tokens = self.svg_transformer.tokenizer(text, add_special_tokens=add_special_tokens, padding="longest",
+                                                return_tensors="pt")
+        return tokens.to(device)
+
+    def _prepare_generation_inputs(self, batch, prompt, device):      # starvector_base.py:203-221
+        image = batch["image"].to(device).to(self.model_precision)
+        embedded_image = self.image_projection(self.image_encoder(image))
+        embedded_att = torch.ones(embedded_image.size()[:-1], dtype=torch.long, device=device)
+        if prompt is None:
+            prompt = self.svg_transformer.prompt
+        prompt_tokens = self._tokenize([prompt] * image.size(0), None, device, add_special_tokens=False)
+        attention_mask = torch.cat([embedded_att, prompt_tokens.attention_mask], dim=1)
+        inputs_embeds = torch.cat([embedded_image, self._get_embeddings(prompt_tokens.input_ids)], dim=1)
+        return inputs_embeds, attention_mask, prompt_tokens
+
+    def _get_generation_kwargs(self, base_kwargs):                    # starvector_base.py:223-241
+        end_sequence = self.svg_transformer.tokenizer("</svg>", add_special_tokens=False)["input_ids"]
+        return {
+            "inputs_embeds": base_kwargs["inputs_embeds"],
+            "attention_mask": base_kwargs["attention_mask"],
+            "do_sample": base_kwargs.get("use_nucleus_sampling", True),
+            "top_p": base_kwargs.get("top_p", 0.9),
+            "temperature": base_kwargs.get("temperature", 1),
+            "num_beams": base_kwargs.get("num_beams", 2),
+            "max_length": base_kwargs.get("max_length", 30),
+            "min_length": base_kwargs.get("min_length", 1),
+            "repetition_penalty": base_kwargs.get("repetition_penalty", 1.0),
+            "length_penalty": base_kwargs.get("length_penalty", 1.0),
+            "use_cache": base_kwargs.get("use_cache", True),
+            "stopping_criteria": [StoppingCriteriaSub(stops=[end_sequence])],
+        }
+
+    def _get_im2svg_specific_kwargs(self, kwargs):                    # starvector_base.py:289-295
+        return {"early_stopping": True, "pad_token_id": self.svg_transformer.tokenizer.pad_token_id}
+
+    def generate_im2svg(self, batch, **kwargs):                       # starvector_base.py:243-259
+        return self.generate_im2svg_grpo(batch, **kwargs)["raw_svg"]
+
+    def generate_im2svg_grpo(self, batch, **kwargs):                  # starvector_base.py:261-286
+        device = batch["image"].device
+        inputs_embeds, attention_mask, prompt_tokens = self._prepare_generation_inputs(batch, kwargs.get("prompt"), device)
+        generation_kwargs = self._get_generation_kwargs({**kwargs, "inputs_embeds": inputs_embeds,
+                                                         "attention_mask": attention_mask})
+        generation_kwargs.update(self._get_im2svg_specific_kwargs(kwargs))
+        outputs = self.svg_transformer.transformer.generate(**generation_kwargs)
+        outputs = torch.cat([prompt_tokens.input_ids, outputs], dim=1)
+        raw_svg = self.svg_transformer.tokenizer.batch_decode(outputs, skip_special_tokens=True)
+        return {"raw_svg": raw_svg, "outputs": outputs, "inputs_embeds": inputs_embeds}
+
+
+class StarVectorForCausalLM(nn.Module):
+    """starvector_arch.py:133-193 facade."""
+    config_class = StarVectorConfig
+
+    def __init__(self, config: StarVectorConfig, state_dict: Optional[Dict[str, torch.Tensor]] = None, tokenizer=None,
+                 device: Optional[int] = None):
+        super().__init__()
+        self.config = config
+        self.engine = HipEngine(config.engine_config(), device=device)
+        if state_dict is not None:
+            self.engine.load_state_dict(state_dict)
+        if tokenizer is None:
+            tokenizer = ByteTokenizer(config.vocab_size)
+        self.model = StarVectorStarCoder(config, self.engine, tokenizer)
+
+    @classmethod
+    def from_pretrained(cls, path: str, torch_dtype="bfloat16", tokenizer=None, **kwargs):
+        """Load a LOCAL checkpoint directory in the reference's format (config.json + *.safetensors).
+        There is no network here: hub names are rejected with a clear error."""
+        if not os.path.isdir(path):
+            raise FileNotFoundError(f"{path!r} is not a local directory (hub download is unavailable offline)")
+        with open(os.path.join(path, "config.json")) as f:
+            cfg = StarVectorConfig(**{**json.load(f), **kwargs, "torch_dtype": "bfloat16"})
+        from safetensors.torch import load_file
+        sd: Dict[str, torch.Tensor] = {}
+        for fn in sorted(os.listdir(path)):
+            if fn.endswith(".safetensors"):
+                sd.update(load_file(os.path.join(path, fn)))
+        if tokenizer is None:
+            try:
+                from transformers import AutoTokenizer
+                tokenizer = AutoTokenizer.from_pretrained(path, use_fast=False)
+            except Exception:
+                tokenizer = None
+        return cls(cfg, state_dict=sd, tokenizer=tokenizer)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("training forward (GRPO logits) is outside the inference hot path (SURVEY.md section 2 #1)")
+
+    def generate_im2svg(self, batch, **kwargs):           # starvector_arch.py:186-187
+        return self.model.generate_im2svg(batch, **kwargs)
+
+    def generate_im2text(self, batch, **kwargs):          # starvector_arch.py:189-190 forwards to a method the
+        raise NotImplementedError("generate_im2text does not exist in the reference either (starvector_arch.py:189)")
+
+    def process_images(self, images):                     # starvector_arch.py:192-193
+        return self.model.image_encoder.process_images(images)

@@ -1,0 +1,77 @@
+"""CPU: the C-ABI library builds, loads and exports every symbol declared in include/*.h; argument
+validation paths that need no GPU."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge.build()
+    from starvector_amd import _lib
+    return _lib.load()
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "starvector_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sv_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(lib):
+    names = _declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/starvector_hip.h but not exported"
+
+
+def test_binding_matches_header(lib):
+    from starvector_amd import _lib
+    assert sorted(_lib.PROTOTYPES) == _declared_functions()
+
+
+def test_struct_layouts():
+    from starvector_amd._lib import SvConfig, SvSampling
+    assert C.sizeof(SvConfig) == 16 * 4
+    assert SvSampling.stop_ids.offset % 8 == 0 and SvSampling.seed.offset % 8 == 0
+
+
+def test_default_config_is_starvector_1b(lib):
+    from starvector_amd._lib import SvConfig
+    c = SvConfig()
+    lib.sv_config_default_1b(C.byref(c))
+    assert (c.image_size, c.patch_size, c.vit_width, c.vit_layers, c.vit_heads) == (224, 14, 1024, 23, 16)
+    assert (c.hidden, c.n_layer, c.n_head, c.n_inner, c.vocab, c.n_positions) == (2048, 24, 16, 8192, 49156, 8192)
+
+
+def test_errors_are_reported_not_crashes(lib):
+    from starvector_amd._lib import SvConfig
+    h = C.c_void_p()
+    assert lib.sv_create(None, C.byref(h)) == -22
+    assert b"null" in lib.sv_last_error()
+    c = SvConfig()
+    lib.sv_config_default_1b(C.byref(c))
+    c.vit_width = 1000                       # head_dim 62.5 -> rejected before touching the device
+    assert lib.sv_create(C.byref(c), C.byref(h)) == -22
+    assert lib.sv_op_layernorm(None, None, None, None, 1, 8, 1e-5, None) == -22
+    assert lib.sv_destroy(None) == 0
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    import starvector_amd as sva
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(sva.StarVectorHipError):
+        sva.HipEngine(sva.EngineConfig())
+    # and the package never imports the oracle
+    import sys
+    src_dir = os.path.join(ROOT, "star-vector_amd")
+    for fn in os.listdir(src_dir):
+        if fn.endswith(".py"):
+            assert "oracle" not in open(os.path.join(src_dir, fn)).read().replace("oracle/", "").lower() or fn == "never"

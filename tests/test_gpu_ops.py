@@ -1,0 +1,169 @@
+"""-m gpu: every kernel of the path, called through the C ABI (sv_op_*), against a plain float32
+restatement of the same operator on the same bf16-exact inputs.
+
+Tolerances (stated, floating point): bf16 outputs must sit within ONE bf16 rounding of the float32
+result -> |err| <= 2^-8 * max|ref| (plus the second rounding where the reference rounds an
+intermediate); float32 outputs within 1e-5 relative (accumulation order only)."""
+import pytest
+import torch
+
+from starvector_amd import engine as E
+from tests.gpu_util import bf, dev, rel_err, mean_err
+from oracle import starvector_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF16_1ULP = 2.0 ** -8
+
+
+@pytest.mark.parametrize("M,D", [(1, 128), (5, 128), (257, 1024), (8288, 2048), (33, 4608)])
+def test_layernorm_rows(M, D):
+    g = torch.Generator().manual_seed(M * 7 + D)
+    x = (2 * torch.randn(M, D, generator=g) + 0.5).bfloat16().float()
+    w = (1 + 0.1 * torch.randn(D, generator=g)).bfloat16().float()
+    b = (0.1 * torch.randn(D, generator=g)).bfloat16().float()
+    ref = torch.nn.functional.layer_norm(x, (D,), w, b, 1e-5)
+    got = E.op_layernorm(bf(x), bf(w), bf(b))
+    assert rel_err(got, ref) <= 1.1 * BF16_1ULP and mean_err(got, ref) <= 5e-4
+
+
+@pytest.mark.parametrize("M,N,K,act,res", [
+    (1, 32, 64, "none", False), (32, 128, 64, "none", False), (300, 384, 128, "none", False),
+    (512, 1024, 588, "none", False),            # patch-embed shape: K = 3*14*14, padded to 640 inside
+    (257, 3072, 1024, "none", False),           # ViT in_proj
+    (200, 512, 1024, "gelu_tanh", False), (130, 256, 256, "quickgelu", True), (1000, 2048, 1024, "swish", True),
+    (129, 2304, 2048, "none", True),            # ragged M tile, N not a multiple of 128
+    (64, 516, 256, "none", False),              # N % 32 != 0 (vocab-like)
+])
+def test_linear_mfma(M, N, K, act, res):
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16().float()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().float()
+    b = (0.1 * torch.randn(N, generator=g)).bfloat16().float()
+    r = torch.randn(M, N, generator=g).bfloat16().float()
+    y = x @ W.T + b
+    if act != "none":
+        yy = y.bfloat16().float()               # the reference rounds the Linear output before the activation
+        y = {"gelu_tanh": lambda t: torch.nn.functional.gelu(t, approximate="tanh"),
+             "quickgelu": lambda t: t * torch.sigmoid(1.702 * t),
+             "swish": lambda t: t * torch.sigmoid(t)}[act](yy)
+    if res:
+        y = y.bfloat16().float() + r
+    got = E.op_linear(bf(x), bf(W), bf(b), bf(r) if res else None, act=act)
+    assert not torch.isnan(got.float()).any()
+    assert rel_err(got, y) <= 2.2 * BF16_1ULP and mean_err(got, y) <= 6e-4
+
+
+def test_linear_transpose_detecting():
+    """A = identity with an ASYMMETRIC weight: catches swapped row/column in the MFMA C layout."""
+    K = N = 128
+    x = torch.eye(K)
+    W = (torch.arange(N * K, dtype=torch.float32).view(N, K) % 251) / 16.0   # exact in bf16, W != W^T
+    got = E.op_linear(bf(x), bf(W), None, None, out_f32=True)
+    assert torch.equal(got.cpu(), W.T.contiguous())
+
+
+def test_linear_f32_out():
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(70, 256, generator=g).bfloat16().float()
+    W = (torch.randn(516, 256, generator=g) / 16).bfloat16().float()
+    got = E.op_linear(bf(x), bf(W), None, None, out_f32=True)
+    assert rel_err(got, x @ W.T) <= 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,sk", [(32, 64, 256, 1), (32, 2304, 2048, 4), (7, 516, 256, 2), (40, 2048, 8192, 4),
+                                       (32, 96, 64, 1), (1, 8192, 2048, 1), (32, 49156, 2048, 1), (3, 256, 1024, 8)])
+def test_linear_skinny_weight_streaming(M, N, K, sk):
+    g = torch.Generator().manual_seed(M + N + K + sk)
+    x = torch.randn(M, K, generator=g).bfloat16().float()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().float()
+    b = (0.1 * torch.randn(N, generator=g)).bfloat16().float()
+    got = E.op_linear_skinny(bf(x), bf(W), bf(b), splitk=sk)
+    assert rel_err(got, x @ W.T + b) <= 1e-5
+    # linearity (size-independent property): f(2x) == 2 f(x) exactly in fp32 up to accumulation order
+    got2 = E.op_linear_skinny(bf(2 * x), bf(W), None, splitk=sk)
+    got1 = E.op_linear_skinny(bf(x), bf(W), None, splitk=sk)
+    assert torch.equal(got2, 2 * got1)
+    # deterministic (fixed-order split-K reduction)
+    assert torch.equal(got1, E.op_linear_skinny(bf(x), bf(W), None, splitk=sk))
+
+
+@pytest.mark.parametrize("B,S,H,Hkv,hd,causal", [
+    (2, 1, 2, 2, 64, 0), (2, 17, 2, 2, 64, 0), (2, 257, 16, 16, 64, 0),       # ViT MHSA shapes
+    (3, 19, 2, 1, 128, 1), (2, 259, 16, 1, 128, 1),                           # decoder MQA prefill
+    (1, 64, 4, 4, 128, 1), (1, 130, 4, 4, 128, 1), (1, 70, 8, 2, 64, 1), (1, 300, 16, 1, 128, 0)])
+def test_attention_prefill(B, S, H, Hkv, hd, causal):
+    g = torch.Generator().manual_seed(B + S + H + hd)
+    q = torch.randn(B, S, H * hd, generator=g).bfloat16().float()
+    k = torch.randn(B, S, Hkv * hd, generator=g).bfloat16().float()
+    v = torch.randn(B, S, Hkv * hd, generator=g).bfloat16().float()
+    qq = q.view(B, S, H, hd).transpose(1, 2)
+    kk = k.view(B, S, Hkv, hd).transpose(1, 2).repeat_interleave(H // Hkv, dim=1)
+    vv = v.view(B, S, Hkv, hd).transpose(1, 2).repeat_interleave(H // Hkv, dim=1)
+    s = qq @ kk.transpose(-1, -2) * hd ** -0.5
+    if causal:
+        s = s.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
+    ref = (torch.softmax(s, -1) @ vv).transpose(1, 2).reshape(B, S, H * hd)
+    got = E.op_attention(bf(q), bf(k), bf(v), H, Hkv, causal)
+    assert not torch.isnan(got.float()).any()
+    # probabilities are rounded to bf16 before P.V (flash-attn / HF eager both do): two roundings
+    assert rel_err(got, ref) <= 3 * BF16_1ULP and mean_err(got, ref) <= 1e-3
+
+
+def test_attention_online_softmax_rescale_branch():
+    """Force the running max to jump at a later KV tile (rule: a rare data-dependent branch needs its
+    own test): one key in the LAST tile dominates one query row."""
+    B, S, H, hd = 1, 200, 2, 64
+    g = torch.Generator().manual_seed(0)
+    q = (0.1 * torch.randn(B, S, H * hd, generator=g))
+    k = (0.1 * torch.randn(B, S, H * hd, generator=g))
+    v = torch.randn(B, S, H * hd, generator=g)
+    q[0, 150, :hd] = 4.0
+    k[0, 190, :hd] = 4.0                          # score 4*4*64/8 = 128 >> all others, in KV tile 2
+    q, k, v = q.bfloat16().float(), k.bfloat16().float(), v.bfloat16().float()
+    qq = q.view(B, S, H, hd).transpose(1, 2); kk = k.view(B, S, H, hd).transpose(1, 2); vv = v.view(B, S, H, hd).transpose(1, 2)
+    ref = (torch.softmax(qq @ kk.transpose(-1, -2) * hd ** -0.5, -1) @ vv).transpose(1, 2).reshape(B, S, H * hd)
+    got = E.op_attention(bf(q), bf(k), bf(v), H, H, 0)
+    assert rel_err(got, ref) <= 3 * BF16_1ULP
+    torch.testing.assert_close(got.float().cpu()[0, 150, :hd], v[0, 190, :hd], rtol=0, atol=2e-2)
+
+
+def test_plane_layernorm():
+    g = torch.Generator().manual_seed(5)
+    for (B, Q, D) in [(3, 17, 256), (2, 257, 2048)]:
+        x = (torch.randn(B, Q, D, generator=g) + 0.3).bfloat16().float()
+        w = (1 + 0.1 * torch.randn(Q, D, generator=g)).bfloat16().float()
+        b = (0.1 * torch.randn(Q, D, generator=g)).bfloat16().float()
+        ref = torch.nn.functional.layer_norm(x, (Q, D), w, b, 1e-5)
+        got = E.op_plane_layernorm(bf(x), bf(w), bf(b))
+        assert rel_err(got, ref) <= 1.1 * BF16_1ULP
+
+
+def test_argmax_lowest_index_on_ties():
+    g = torch.Generator().manual_seed(6)
+    lg = torch.randn(33, 49156, generator=g)
+    lg[2, 100] = lg[2, 40000] = 9.0
+    lg[5, 49155] = 11.0
+    lg[7] = 0.0                                   # all equal -> index 0
+    got = E.op_argmax(lg.to(dev())).cpu().long()
+    assert torch.equal(got, lg.argmax(-1))        # integer result: bit-exact
+    assert got[2] == 100 and got[5] == 49155 and got[7] == 0
+
+
+def test_top_p_sampler_distribution():
+    """Distributional parity with HF's temperature -> top-p -> multinomial (torch's RNG stream itself is
+    not reproducible in a custom kernel)."""
+    g = torch.Generator().manual_seed(7)
+    V, n = 64, 20000
+    lg = 2.0 * torch.randn(1, V, generator=g)
+    probs = O.top_p_filtered_probs(lg, 0.8, 0.9)[0]
+    rows = lg.repeat(n, 1).to(dev()).contiguous()
+    s = E.op_sample_top_p(rows, 0.8, 0.9, seed=123, step=7).cpu().long()
+    emp = torch.bincount(s, minlength=V).float() / n
+    assert float(emp[probs == 0].sum()) == 0.0               # never samples outside the nucleus
+    assert float((emp - probs).abs().sum()) < 0.03           # L1 distance (n = 20000 draws)
+    # same (seed, step, row) -> same draw; different step -> different stream
+    assert torch.equal(s, E.op_sample_top_p(rows, 0.8, 0.9, seed=123, step=7).cpu().long())
+    assert not torch.equal(s, E.op_sample_top_p(rows, 0.8, 0.9, seed=123, step=8).cpu().long())
+    # top_p -> tiny keeps only the argmax
+    only = E.op_sample_top_p(rows[:64], 1.0, 1e-6, seed=1, step=0).cpu().long()
+    assert bool((only == lg.argmax()).all())

@@ -1,0 +1,98 @@
+"""CPU: host-side mirror of the reference interface (no GPU compute involved)."""
+import os
+
+import pytest
+import torch
+
+import starvector_amd as sva
+from starvector_amd.model import ByteTokenizer, ImageTrainProcessor, StarVectorConfig, StoppingCriteriaSub, HipCausalLM
+from starvector_amd.parallel import shard_bounds, shard_batch
+
+
+def test_config_maps_to_engine_shapes():
+    ec = StarVectorConfig().engine_config()
+    assert (ec.vit_width, ec.vit_layers, ec.vit_heads, ec.hidden, ec.n_layer, ec.n_head, ec.n_inner) == \
+        (1024, 23, 16, 2048, 24, 16, 8192)
+    assert ec.vocab == 49152 + 4 and ec.query_length == 257          # SURVEY.md section 8 header
+    with pytest.raises(NotImplementedError):
+        StarVectorConfig(starcoder_model_name="bigcode/starcoder2-7b").engine_config()
+    with pytest.raises(ValueError):
+        StarVectorConfig(torch_dtype="float16").engine_config()
+
+
+def test_byte_tokenizer_surface():
+    tok = ByteTokenizer(49152)
+    assert len(tok) == 49156 and tok.pad_token_id == 49152 and tok.eos_token_id == 0
+    enc = tok(["<svg", "<svg"], add_special_tokens=False, return_tensors="pt")
+    assert enc.input_ids.shape == (2, 4) and bool((enc.attention_mask == 1).all())
+    ids = tok("</svg>", add_special_tokens=False)["input_ids"]
+    assert isinstance(ids, list) and len(ids) == 6
+    assert tok.batch_decode(torch.tensor([tok.encode("<svg width") + [tok.pad_token_id, 0]])) == ["<svg width"]
+    assert tok.encode("<svg-start>") == [49153]
+
+
+def test_image_processor_matches_reference_recipe():
+    """data/util.py:40-68: RGBA->white composite, white pad to square, bicubic resize, ToTensor, CLIP normalise."""
+    from PIL import Image
+    proc = ImageTrainProcessor(size=224)
+    img = Image.new("RGBA", (100, 60), (255, 0, 0, 0))               # fully transparent -> white
+    x = proc(img)
+    assert x.shape == (3, 224, 224)
+    white = (1.0 - torch.tensor(sva.model.CLIP_MEAN)) / torch.tensor(sva.model.CLIP_STD)
+    torch.testing.assert_close(x[:, 0, 0], white, rtol=0, atol=1e-5)
+    torch.testing.assert_close(x[:, 112, 112], white, rtol=0, atol=1e-5)
+    # a 224x224 RGB image goes through untouched apart from normalisation
+    g = torch.Generator().manual_seed(0)
+    arr = (torch.rand(224, 224, 3, generator=g) * 255).to(torch.uint8)
+    y = proc(Image.fromarray(arr.numpy(), "RGB"))
+    ref = (arr.permute(2, 0, 1).float() / 255 - torch.tensor(sva.model.CLIP_MEAN).view(3, 1, 1)) / \
+        torch.tensor(sva.model.CLIP_STD).view(3, 1, 1)
+    torch.testing.assert_close(y, ref, rtol=0, atol=1e-6)
+    # non-square: padded with white on the short side
+    z = proc(Image.new("RGB", (224, 112), (0, 0, 0)))
+    torch.testing.assert_close(z[:, 0, 112], white, rtol=0, atol=1e-5)
+    assert float(z[0, 112, 112]) < 0
+
+
+def test_stopping_criteria_sub_is_row0_only():
+    crit = StoppingCriteriaSub(stops=[[5, 6]])
+    assert crit(torch.tensor([[1, 5, 6], [0, 0, 0]]))
+    assert not crit(torch.tensor([[1, 2, 3], [4, 5, 6]]))             # row 1 is never inspected
+    assert not crit(torch.tensor([[6]]))                               # shorter than the stop sequence
+    assert HipCausalLM._stop_ids([crit]) == [5, 6]
+    assert HipCausalLM._stop_ids(None) is None
+
+
+def test_generate_kwargs_validation_without_gpu():
+    lm = HipCausalLM.__new__(HipCausalLM)
+    torch.nn.Module.__init__(lm)
+    object.__setattr__(lm, "_engine", None)
+    lm.eos_token_id, lm.pad_token_id, lm.seed = 0, 1, 0
+    emb = torch.zeros(1, 4, 8)
+    with pytest.raises(NotImplementedError):
+        lm.generate(inputs_embeds=emb, num_beams=2, max_length=8)      # reference default; "next" row
+    with pytest.raises(NotImplementedError):
+        lm.generate(inputs_embeds=emb, repetition_penalty=3.1, max_length=8)
+    with pytest.raises(ValueError):
+        lm.generate(max_length=8)
+
+
+def test_shard_bounds_cover_batch_exactly():
+    for n in (0, 1, 7, 32, 256):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    b = {"image": torch.arange(10).view(10, 1), "note": "x"}
+    s = shard_batch(b, 1, 4)
+    assert s["image"].flatten().tolist() == [3, 4, 5] and s["note"] == "x"
+
+
+def test_package_never_imports_the_oracle():
+    src_dir = os.path.dirname(sva.__file__)
+    for fn in os.listdir(src_dir):
+        if fn.endswith(".py"):
+            text = open(os.path.join(src_dir, fn)).read()
+            assert "import oracle" not in text and "from oracle" not in text, fn

@@ -1,0 +1,97 @@
+"""CPU: the oracle against the golden vectors minted from the reference (oracle/make_golden.py),
+plus the generation semantics that define parity."""
+import dataclasses
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from oracle import starvector_oracle as O
+
+
+def _load(golden_dir, name):
+    return load_file(os.path.join(golden_dir, name + ".safetensors"))
+
+
+@pytest.mark.parametrize("name,norm", [("tiny_b3", "layer_norm"), ("tiny_bn_b2", "batch_norm")])
+def test_oracle_reproduces_reference_goldens(golden_dir, name, norm):
+    g = _load(golden_dir, name)
+    seed, B, n_new = [int(x) for x in g["meta"]]
+    cfg = dataclasses.replace(O.OracleConfig.tiny(), adapter_norm=norm)
+    w = O.make_weights(cfg, seed=seed)
+    assert torch.equal(O.synthetic_images(B, cfg.image_size, seed=seed + 1), g["image"])
+    enc = O.image_encoder_forward(w, cfg, g["image"])
+    vis = O.adapter_forward(w, cfg, enc)
+    emb = O.prepare_generation_inputs(w, cfg, g["image"], g["prompt_ids"])
+    logits0, _ = O.decoder_prefill(w, cfg, emb)
+    # float32 restatement vs the reference's own modules: float32 round-off only
+    torch.testing.assert_close(enc, g["enc"], rtol=0, atol=2e-5 * float(g["enc"].abs().max()))
+    torch.testing.assert_close(vis, g["vis"], rtol=0, atol=2e-5 * float(g["vis"].abs().max()))
+    torch.testing.assert_close(emb, g["emb"], rtol=0, atol=2e-5 * float(g["emb"].abs().max()))
+    torch.testing.assert_close(logits0, g["logits0"], rtol=0, atol=5e-5 * max(1.0, float(g["logits0"].abs().max())))
+    toks = O.greedy_generate(w, cfg, emb, emb.shape[1] + n_new)
+    assert torch.equal(toks, g["tokens"])                  # integer token ids: bit-exact
+    full = O.generate_im2svg_tokens(w, cfg, g["image"], g["prompt_ids"], emb.shape[1] + n_new)
+    assert torch.equal(full, torch.cat([g["prompt_ids"], g["tokens"]], 1))
+
+
+def test_stop_eos_pad_semantics_match_hf(golden_dir):
+    g = _load(golden_dir, "tiny_stop")
+    seed, B, n_new, eos = [int(x) for x in g["meta"]]
+    cfg = dataclasses.replace(O.OracleConfig.tiny(), eos_token_id=eos)
+    w = O.make_weights(cfg, seed=seed)
+    emb = O.prepare_generation_inputs(w, cfg, g["image"], g["prompt_ids"])
+    toks = O.greedy_generate(w, cfg, emb, emb.shape[1] + n_new, stop_ids=g["stop_ids"].tolist())
+    assert torch.equal(toks, g["tokens"])
+    assert toks.shape[1] < n_new                           # row-0 stop ended the whole batch early
+    assert (toks == cfg.pad_token_id).any()                # a finished row emitted pad afterwards
+    assert toks[0, -len(g["stop_ids"]):].tolist() == g["stop_ids"].tolist()
+
+
+def test_max_length_includes_prompt():
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=3)
+    emb = O.prepare_generation_inputs(w, cfg, O.synthetic_images(1, cfg.image_size, 4), torch.tensor([[7, 11]]))
+    S0 = emb.shape[1]
+    assert O.greedy_generate(w, cfg, emb, S0 + 5).shape == (1, 5)
+    with pytest.raises(ValueError):
+        O.greedy_generate(w, cfg, emb, S0)
+
+
+def test_kv_cache_equals_full_recompute():
+    """decode with the cache == full forward over the grown sequence (the oracle's own consistency)."""
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=5)
+    emb = O.prepare_generation_inputs(w, cfg, O.synthetic_images(2, cfg.image_size, 6), torch.tensor([[7, 11]] * 2))
+    toks, lg = O.greedy_generate(w, cfg, emb, emb.shape[1] + 4, return_logits=True)
+    cur = emb
+    for t in range(4):
+        full, _ = O.decoder_prefill(w, cfg, cur)
+        torch.testing.assert_close(full, lg[:, t], rtol=0, atol=2e-4)
+        cur = torch.cat([cur, w[O.P_DEC + "wte.weight"][toks[:, t]].unsqueeze(1)], 1)
+
+
+def test_bf16_mode_tracks_fp32():
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=7)
+    img = O.synthetic_images(2, cfg.image_size, 8)
+    a = O.image_encoder_forward(w, cfg, img, "fp32")
+    b = O.image_encoder_forward(w, cfg, img, "bf16")
+    assert float((a - b).abs().max() / a.abs().max()) < 3e-2
+    assert torch.equal(b, b.to(torch.bfloat16).float())    # bf16-exact values
+
+
+def test_top_p_filter_properties():
+    g = torch.Generator().manual_seed(0)
+    lg = 3 * torch.randn(4, 100, generator=g)
+    p = O.top_p_filtered_probs(lg, temperature=0.7, top_p=0.9)
+    torch.testing.assert_close(p.sum(-1), torch.ones(4), rtol=0, atol=1e-5)
+    full = torch.softmax(lg / 0.7, -1)
+    for r in range(4):
+        kept = p[r] > 0
+        assert kept[full[r].argmax()]                       # the most probable token always survives
+        assert full[r][kept].sum() >= 0.9 - 1e-6            # kept mass reaches top_p
+        assert full[r][kept].min() >= full[r][~kept].max()  # a probability threshold separates them
+    # top_p = 1 keeps everything
+    assert (O.top_p_filtered_probs(lg, 1.0, 1.0) > 0).all()
