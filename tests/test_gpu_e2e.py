@@ -204,7 +204,7 @@ def test_starvector_1b_shapes_against_oracle():
     torch.set_num_threads(host_cores())
     cfg = O.OracleConfig()
     w = O.make_weights(cfg, seed=1234)
-    B, n_new = 2, 4
+    B, n_new = 2, 3
     eng = build_engine(cfg, w, max_batch=2, max_seq_len=300)
     img = O.synthetic_images(B, 224, seed=1235)
     prompt = torch.tensor([[7, 11]] * B)
