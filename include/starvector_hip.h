@@ -141,6 +141,15 @@ int  sv_op_linear(const void* x, const void* W, const void* bias, const void* re
 /* the decode-path (M<=32 per tile, weight-streaming) implementation of the same contraction */
 int  sv_op_linear_skinny(const void* x, const void* W, const void* bias, void* y_f32, int32_t M, int32_t N,
                          int32_t K, int32_t splitk, sv_stream stream);
+/* The fused decode-step GEMM: y[M,N] = act( LN_opt(h)[M,K] . W^T + bias ) (+ residual), with the LayerNorm
+ * applied in the GEMM prologue from per-tile partial statistics, the split-K reduction done by the last
+ * arriving block (ticket), and (residual mode) the new rows' LayerNorm statistics row_stats[M][2] =
+ * (sum, sum of squares).  gamma/beta/residual/row_stats may be NULL. */
+int  sv_op_decode_linear(const void* h, const void* gamma, const void* beta, float eps, const void* W,
+                         const void* bias, const void* residual, void* y, float* row_stats, int32_t M, int32_t N,
+                         int32_t K, int32_t splitk, int32_t act, sv_stream stream);
+/* f32 -> bf16 through the hardware convert used inside the kernels (rounding-mode check) */
+int  sv_op_cvt_bf16_hw(const float* x, void* y, int64_t n, sv_stream stream);
 /* q,k,v token-major [B,S,H*D] / [B,S,Hkv*D]; out [B,S,H*D] */
 int  sv_op_attention(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t S,
                      int32_t H, int32_t Hkv, int32_t head_dim, int32_t causal, float scale,

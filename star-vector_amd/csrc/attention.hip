@@ -245,55 +245,99 @@ void launch_kv_write_prefill(const bf16_t* qkv, int row_stride, int k_off, int v
 }
 
 // ------------------------------------------------------------------------------------------------
-// decode
+// decode: one block of 8 waves per (sequence, context split).  The grid is (B, AD_SPLIT) so the captured
+// hipGraph is static, but only `act = clamp(ceil(groups/16), 1, AD_SPLIT)` splits are ACTIVE for the
+// current context (the rest exit at once): short contexts run one block per sequence with no
+// inter-block hand-off at all; long contexts split flash-decoding style.  Active blocks own the 32-key
+// groups g = split + act*(wave + 8*i), prefetch the next group's fragments while the MFMAs of the
+// current one run, and (act > 1) leave a partial (m, l, O) in HBM; an arrival ticket elects the last
+// block, which merges the partials in split order (bitwise deterministic).  Hand-off = agent-scope
+// release (writers) / acquire (merger): placement independent.
 // ------------------------------------------------------------------------------------------------
 #define AD_WAVES 8
+#define AD_SPLIT 8
+#define AD_GROUPS_PER_BLOCK 16
+
+template <int D>
+struct KvFrags {
+    u32x4 k[2][D / 32];
+    u32x4 v[D / 16];
+};
+
+template <int D>
+__device__ __forceinline__ void load_group(KvFrags<D>& f, const char* pool, const int32_t* table, int page_bytes,
+                                           int g, int lane) {
+    constexpr int NKS = D / 32, NDV = D / 16;
+    const int t0 = g << 5;
+    const char* page = pool + (size_t)table[t0 >> 6] * page_bytes;
+    const int half = (t0 >> 5) & 1;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int s = 0; s < NKS; ++s)
+            f.k[u][s] = *reinterpret_cast<const u32x4*>(page + ((size_t)(((half * 2 + u) * NKS + s) * 64 + lane)) * 16);
+#pragma unroll
+    for (int t = 0; t < NDV; ++t)
+        f.v[t] = *reinterpret_cast<const u32x4*>(page + (size_t)64 * D * 2 + ((size_t)((half * NDV + t) * 64 + lane)) * 16);
+}
 
 template <int D>
 __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeArgs p) {
     constexpr int NKS = D / 32;          // k-steps of S^T (over head_dim)
     constexpr int NDV = D / 16;          // dv tiles of O^T
+    constexpr int PART = 32 + 16 * D;    // floats per partial: m[16], l[16], O[16][D]
+    const int b = blockIdx.x;
+    const int split = blockIdx.y;
+    const int pos = p.positions[b];
+    const int L = pos + 1;
+    const int ngroups = (L + 31) >> 5;
+    int act = (ngroups + AD_GROUPS_PER_BLOCK - 1) / AD_GROUPS_PER_BLOCK;
+    act = act < 1 ? 1 : (act > AD_SPLIT ? AD_SPLIT : act);
+    if (split >= act) return;
+
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* q_s = reinterpret_cast<bf16_t*>(smem);                       // [16][D]
     bf16_t* kv_new = q_s + 16 * D;                                       // [2][D]
     float* m_s = reinterpret_cast<float*>(kv_new + 2 * D);               // [AD_WAVES][16]
     float* l_s = m_s + AD_WAVES * 16;                                    // [AD_WAVES][16]
     float* O_s = l_s + AD_WAVES * 16;                                    // [AD_WAVES][16][D]
+    int* flag_s = reinterpret_cast<int*>(O_s + AD_WAVES * 16 * D);       // [4]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x;
     const int H = p.H;
     const int HD = H * D;
 
-    // finish the c_attn GEMM for this row: sum split-K slabs (fixed order) + bias, round to bf16
+    // q / k_new / v_new of this sequence (c_attn output, bias already added, bf16)
     for (int n = tid; n < 16 * D + 2 * D; n += AD_WAVES * 64) {
-        // index space: [0,16*D) = q rows (rows >= H are zero), then k_new, v_new
-        int col;
+        int col;                         // [0,16*D) = q rows (rows >= H are zero), then k_new, v_new
         if (n < 16 * D) col = (n / D) < H ? n : -1;
         else col = HD + (n - 16 * D);
-        float v = 0.f;
+        bf16_t v = 0;
         if (col >= 0) {
-            for (int sp = 0; sp < p.splitk; ++sp) v += p.ws[((size_t)sp * p.rows_ws + b) * p.ldws + col];
-            v += bf2f(p.bias[col]);
+            if (p.qkv) {
+                v = p.qkv[(size_t)b * p.ld_qkv + col];
+            } else {                     // legacy input: fp32 split-K slabs of the c_attn GEMM
+                float a = 0.f;
+                for (int sp = 0; sp < p.splitk; ++sp) a += p.ws[((size_t)sp * p.rows_ws + b) * p.ldws + col];
+                v = f2bf(a + bf2f(p.bias[col]));
+            }
         }
-        q_s[n] = f2bf(v);                // q_s and kv_new are contiguous
+        q_s[n] = v;                      // q_s and kv_new are contiguous
     }
     __syncthreads();
 
-    const int pos = p.positions[b];
     const int page_bytes = kv_page_bytes(D);
     const int32_t* table = p.block_table + (size_t)b * p.max_pages;
-    // append the new token's K / V to the cache
-    if (tid < 2 * D) {
+    // split 0 appends the new token's K / V to the cache (for FUTURE steps; in this launch every block
+    // patches the new token into its fragments from LDS, so no block depends on another block's store)
+    if (split == 0 && tid < 2 * D) {
         char* page = p.pool_layer + (size_t)table[pos >> 6] * page_bytes;
         const int t64 = pos & 63;
         const int d = tid < D ? tid : tid - D;
         const size_t off = tid < D ? kv_k_offset(D, t64, d) : kv_v_offset(D, t64, d);
         *reinterpret_cast<bf16_t*>(page + off) = kv_new[tid];
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
 
     const int hd = lane & 15, c = lane >> 4;
     bf16x8 qf[NKS];
@@ -306,22 +350,31 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     for (int t = 0; t < NDV; ++t) accO[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
-    const int L = pos + 1;
-    const int ngroups = (L + 31) >> 5;
-    for (int g = wave; g < ngroups; g += AD_WAVES) {
+    auto process = [&](KvFrags<D>& f, int g) {
         const int t0 = g << 5;
-        const char* page = p.pool_layer + (size_t)table[t0 >> 6] * page_bytes;
-        const int half = (t0 >> 5) & 1;
-        u32x4 kf[2][NKS], vf[NDV];
+        if (pos >= t0 && pos < t0 + 32) {
+            // this group holds the new token: take its K row / V column from LDS (wave-uniform branch)
+            const int k32 = pos - t0;
+            const int us = k32 >> 4, key_lo = k32 & 15, cs = (k32 >> 2) & 3, es = 4 * us + (k32 & 3);
+            const bool klane = hd == key_lo;
 #pragma unroll
-        for (int u = 0; u < 2; ++u)
+            for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int s = 0; s < NKS; ++s)
-                kf[u][s] = *reinterpret_cast<const u32x4*>(page + ((size_t)(((half * 2 + u) * NKS + s) * 64 + lane)) * 16);
+                for (int s = 0; s < NKS; ++s) {
+                    const u32x4 nk = *reinterpret_cast<const u32x4*>(kv_new + 32 * s + 8 * c);
+                    if (klane && u == us) f.k[u][s] = nk;
+                }
+            const bool vlane = c == cs;
+            const int ws = es >> 1, sh = (es & 1) * 16;
 #pragma unroll
-        for (int t = 0; t < NDV; ++t)
-            vf[t] = *reinterpret_cast<const u32x4*>(page + (size_t)64 * D * 2 + ((size_t)((half * NDV + t) * 64 + lane)) * 16);
-
+            for (int t = 0; t < NDV; ++t) {
+                const uint32_t nv = (uint32_t)kv_new[D + 16 * t + hd] << sh;
+                const uint32_t keep = ~(0xffffu << sh);
+#pragma unroll
+                for (int w = 0; w < 4; ++w)
+                    if (vlane && w == ws) f.v[t][w] = (f.v[t][w] & keep) | nv;
+            }
+        }
         f32x4 accS[2];
         float sc[2][4];
         float mt = -INFINITY;
@@ -330,7 +383,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
             accS[u] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < NKS; ++s)
-                accS[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag4(kf[u][s]), qf[s], accS[u], 0, 0, 0);
+                accS[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag4(f.k[u][s]), qf[s], accS[u], 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = t0 + 16 * u + 4 * c + r;
@@ -357,11 +410,27 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
 #pragma unroll
         for (int t = 0; t < NDV; ++t) {
             accO[t] = accO[t] * alpha;
-            accO[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag4(vf[t]), pf, accO[t], 0, 0, 0);
+            accO[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag4(f.v[t]), pf, accO[t], 0, 0, 0);
         }
+    };
+
+    // two register buffers: the loads of group i+1 are in flight while group i is processed
+    const int stride = act * AD_WAVES;
+    int g = split + act * wave;
+    KvFrags<D> fa, fb;
+    if (g < ngroups) load_group<D>(fa, p.pool_layer, table, page_bytes, g, lane);
+    while (g < ngroups) {
+        const int g1 = g + stride;
+        if (g1 < ngroups) load_group<D>(fb, p.pool_layer, table, page_bytes, g1, lane);
+        process(fa, g);
+        if (g1 >= ngroups) break;
+        const int g2 = g1 + stride;
+        if (g2 < ngroups) load_group<D>(fa, p.pool_layer, table, page_bytes, g2, lane);
+        process(fb, g1);
+        g = g2;
     }
 
-    // combine the waves' partial (m, l, O)
+    // merge the waves of this block (LDS), in wave order
     float l_tot = l_run + __shfl_xor(l_run, 16, 64);
     l_tot += __shfl_xor(l_tot, 32, 64);
     if (c == 0) {
@@ -373,6 +442,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
         *reinterpret_cast<float4*>(O_s + ((size_t)(wave * 16 + hd)) * D + 16 * t + 4 * c) =
             make_float4(accO[t][0], accO[t][1], accO[t][2], accO[t][3]);
     __syncthreads();
+    float* mypart = p.part + ((size_t)b * AD_SPLIT + split) * PART;
     for (int idx = tid; idx < HD; idx += AD_WAVES * 64) {
         const int h = idx / D, dv = idx % D;
         float M = -INFINITY;
@@ -386,16 +456,75 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
             num += f * O_s[((size_t)(w * 16 + h)) * D + dv];
             den += f * l_s[w * 16 + h];
         }
+        if (act == 1) {
+            p.out_xp[xp_index(b >> 5, p.out_KS, b & 31, idx)] = f2bf(num / den);
+        } else {
+            mypart[32 + idx] = num;
+            if (dv == 0) { mypart[h] = M; mypart[16 + h] = den; }
+        }
+    }
+    if (act == 1) return;
+
+    // publish the partial, draw a ticket (release at agent scope; the counted wait keeps the ticket
+    // behind the write-back)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(p.counters + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag_s[0] = (t == (unsigned)(act - 1)) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!flag_s[0]) return;
+    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    const float* parts = p.part + (size_t)b * AD_SPLIT * PART;
+    // all loads of the merge are issued in two batches (statistics, then O), never one per dependent step
+    float* ml = m_s;                                  // reuse LDS: [AD_SPLIT][32]
+    if (tid < AD_SPLIT * 32) {
+        const int s = tid >> 5;
+        ml[tid] = s < act ? parts[(size_t)s * PART + (tid & 31)] : -INFINITY;
+    }
+    __syncthreads();
+    constexpr int PER = (16 * D) / (AD_WAVES * 64);   // outputs per thread
+    float ov[PER][AD_SPLIT];
+#pragma unroll
+    for (int j = 0; j < PER; ++j)
+#pragma unroll
+        for (int s = 0; s < AD_SPLIT; ++s) {
+            const int idx = tid + j * AD_WAVES * 64;
+            ov[j][s] = (s < act && idx < HD) ? parts[(size_t)s * PART + 32 + idx] : 0.f;
+        }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int idx = tid + j * AD_WAVES * 64;
+        if (idx >= HD) continue;
+        const int h = idx / D;
+        float M = -INFINITY;
+#pragma unroll
+        for (int s = 0; s < AD_SPLIT; ++s) M = fmaxf(M, ml[s * 32 + h]);
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int s = 0; s < AD_SPLIT; ++s) {
+            const float ms = ml[s * 32 + h];
+            const float f = (s < act && ms != -INFINITY) ? __expf(ms - M) : 0.f;
+            num += f * ov[j][s];
+            den += f * (s < act ? ml[s * 32 + 16 + h] : 0.f);
+        }
         p.out_xp[xp_index(b >> 5, p.out_KS, b & 31, idx)] = f2bf(num / den);
     }
+    if (tid == 0) __hip_atomic_store(p.counters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
 }
+
+size_t attn_decode_part_floats(int head_dim) { return (size_t)AD_SPLIT * (32 + 16 * (size_t)head_dim); }
 
 static size_t attn_decode_smem(int D) {
-    return (size_t)(16 * D + 2 * D) * 2 + (size_t)AD_WAVES * 16 * 4 * 2 + (size_t)AD_WAVES * 16 * D * 4;
+    return (size_t)(16 * D + 2 * D) * 2 + (size_t)AD_WAVES * 16 * 4 * 2 + (size_t)AD_WAVES * 16 * D * 4 + 16;
 }
 
-// dynamic LDS above the 64 KiB default needs an explicit opt-in; done once at engine creation
-// (never inside a stream capture)
+// dynamic LDS above the 64 KiB default needs an explicit opt-in.  Done once at engine creation (never
+// inside a stream capture)
 int init_attention_kernels() {
     hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_decode_kernel<128>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_decode_smem(128));
@@ -407,10 +536,11 @@ int init_attention_kernels() {
 
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
     const size_t smem = attn_decode_smem(a.head_dim);
+    dim3 grid(a.B, AD_SPLIT);
     if (a.head_dim == 128)
-        attn_decode_kernel<128><<<a.B, AD_WAVES * 64, smem, st>>>(a);
+        attn_decode_kernel<128><<<grid, AD_WAVES * 64, smem, st>>>(a);
     else
-        attn_decode_kernel<64><<<a.B, AD_WAVES * 64, smem, st>>>(a);
+        attn_decode_kernel<64><<<grid, AD_WAVES * 64, smem, st>>>(a);
 }
 
 }  // namespace sv

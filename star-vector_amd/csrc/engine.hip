@@ -70,6 +70,26 @@ __global__ void pack_rows_kernel(const bf16_t* x, int ldx, bf16_t* xp, int M, in
             *reinterpret_cast<const uint4*>(x + (size_t)m * ldx + c * 8);
     }
 }
+// fragment order -> row-major [M][K]
+__global__ void unpack_rows_kernel(const bf16_t* xp, bf16_t* x, int ldx, int M, int K) {
+    const int NC = K >> 3;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M * NC; i += gridDim.x * blockDim.x) {
+        const int c = i % NC, m = i / NC;
+        *reinterpret_cast<uint4*>(x + (size_t)m * ldx + c * 8) =
+            *reinterpret_cast<const uint4*>(xp + xp_index(m >> 5, K >> 4, m & 31, c * 8));
+    }
+}
+// per-row totals of the per-tile LayerNorm partials (tile order)
+__global__ void sum_stats_kernel(const float2* st, int tiles, float* out, int M) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    float a = 0.f, b = 0.f;
+    for (int t = 0; t < tiles; ++t) {
+        const float2 v = st[((size_t)(m >> 5) * tiles + t) * 32 + (m & 31)];
+        a += v.x; b += v.y;
+    }
+    out[2 * m] = a; out[2 * m + 1] = b;
+}
 __global__ void reduce_partials_kernel(const float* ws, int splitk, int rows_ws, int ldws, const bf16_t* bias,
                                        float* y, int M, int N) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M * N; i += gridDim.x * blockDim.x) {
@@ -133,8 +153,12 @@ struct sv_engine {
     bf16_t *ph = nullptr, *pln = nullptr, *pqkv = nullptr, *pattn = nullptr, *pmlp = nullptr;
     // decode workspaces
     int MT = 0, ldws = 0, Vpad = 0;
-    bf16_t *h_dec = nullptr, *hl = nullptr, *xp_a = nullptr, *xp_attn = nullptr, *xp_mlp = nullptr;
-    float *ws = nullptr, *logits = nullptr, *sample_scratch = nullptr;
+    bf16_t *h_xp = nullptr, *hl = nullptr, *xp_a = nullptr, *xp_attn = nullptr, *xp_mlp = nullptr, *qkv_rm = nullptr;
+    float2* ln_stats = nullptr;
+    unsigned* sk_cnt = nullptr;
+    int ldq = 0;
+    float *ws = nullptr, *logits = nullptr, *sample_scratch = nullptr, *attn_part = nullptr;
+    unsigned* attn_cnt = nullptr;
     int32_t *cur_tok = nullptr, *next_tok = nullptr, *unfinished = nullptr, *positions = nullptr,
             *out_tok = nullptr, *d_step = nullptr, *d_done = nullptr, *d_nemit = nullptr, *d_stop = nullptr;
     int out_ld = 0;
@@ -344,7 +368,11 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     e->Vpad = e->lm_head.Npad;
     e->ldws = round_up(D + 2 * dh, 32);
     if (e->ldws < D) e->ldws = D;
-    A(dalloc(e, &e->h_dec, R * D));
+    A(dalloc(e, &e->h_xp, R * D));
+    e->ldq = D + 2 * dh;
+    A(dalloc(e, &e->qkv_rm, R * e->ldq));
+    A(dalloc(e, &e->ln_stats, R * (D / 32)));
+    A(dalloc(e, &e->sk_cnt, (size_t)e->MT * 4096));
     A(dalloc(e, &e->hl, R * D));
     A(dalloc(e, &e->xp_a, R * D));
     A(dalloc(e, &e->xp_attn, R * D));
@@ -352,6 +380,8 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     A(dalloc(e, &e->ws, (size_t)8 * R * e->ldws));
     A(dalloc(e, &e->logits, R * e->Vpad));
     A(dalloc(e, &e->sample_scratch, R * 4));
+    A(dalloc(e, &e->attn_part, R * attn_decode_part_floats(dh)));
+    A(dalloc(e, &e->attn_cnt, R));
     A(dalloc(e, &e->cur_tok, R));
     A(dalloc(e, &e->next_tok, R));
     A(dalloc(e, &e->unfinished, R));
@@ -439,11 +469,22 @@ static void gemm(const bf16_t* A, int lda, const Linear& l, const bf16_t* R, int
     launch_gemm(g, st);
 }
 
-static void skinny_partial(sv_engine* e, const bf16_t* xp, const Linear& l, int MT, hipStream_t st) {
+// decode-path GEMM on the engine's buffers
+static void decode_gemm(sv_engine* e, const bf16_t* xp, const Linear& l, const LNp* ln, int MT, int out_mode, int act,
+                        hipStream_t st) {
     SkinnyArgs a;
     memset(&a, 0, sizeof(a));
-    a.xp = xp; a.Wp = l.Wp; a.bias = nullptr; a.MT = MT; a.Npad = l.Npad; a.K = l.Kpad; a.splitk = l.splitk;
-    a.out_mode = SK_OUT_PARTIAL; a.ws = e->ws; a.ldws = e->ldws; a.N = l.N;
+    a.xp = xp; a.Wp = l.Wp; a.bias = l.bias; a.MT = MT; a.Npad = l.Npad; a.K = l.Kpad; a.splitk = l.splitk;
+    a.out_mode = out_mode; a.act = act; a.N = l.N;
+    if (ln) { a.ln_stats = e->ln_stats; a.ln_tiles = l.Kpad / 32; a.ln_g = ln->g; a.ln_b = ln->b; a.ln_eps = e->cfg.ln_eps; }
+    a.ws = e->ws; a.ldws = e->ldws; a.counters = e->sk_cnt;
+    if (out_mode == SK_OUT_RESID) {
+        a.out_xp = e->h_xp; a.resid_xp = e->h_xp; a.out_KS = l.Npad / 16; a.stats_out = e->ln_stats;
+    } else if (out_mode == SK_OUT_PACKED_ACT) {
+        a.out_xp = e->xp_mlp; a.out_KS = l.Npad / 16;
+    } else if (out_mode == SK_OUT_ROWMAJOR) {
+        a.out_rm = e->qkv_rm; a.ld_rm = e->ldq;
+    }
     launch_gemm_skinny(a, st);
 }
 
@@ -517,13 +558,14 @@ static int assign_pages(sv_engine* e, int B, int total_len, hipStream_t st) {
     return 0;
 }
 
-// lm_head on the rows currently normalised in xp_a -> e->logits
-static void lm_head_logits(sv_engine* e, int MT, hipStream_t st) {
+// lm_head -> e->logits.  ln == nullptr: xp already holds ln_f(h); else xp = raw h and ln_f is applied in the prologue
+static void lm_head_logits(sv_engine* e, int MT, const bf16_t* xp, const LNp* ln, hipStream_t st) {
     SkinnyArgs a;
     memset(&a, 0, sizeof(a));
-    a.xp = e->xp_a; a.Wp = e->lm_head.Wp; a.MT = MT; a.Npad = e->lm_head.Npad; a.K = e->lm_head.Kpad;
+    a.xp = xp; a.Wp = e->lm_head.Wp; a.MT = MT; a.Npad = e->lm_head.Npad; a.K = e->lm_head.Kpad;
     a.splitk = 1; a.out_mode = SK_OUT_F32; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1;
     a.N = e->lm_head.N;
+    if (ln) { a.ln_stats = e->ln_stats; a.ln_tiles = e->lm_head.Kpad / 32; a.ln_g = ln->g; a.ln_b = ln->b; a.ln_eps = e->cfg.ln_eps; }
     launch_gemm_skinny(a, st);
 }
 
@@ -552,57 +594,43 @@ static int prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hi
     // only the last prompt row feeds ln_f + lm_head (HF computes all rows; same result)
     launch_gather_last_rows(e->ph, e->hl, B, S0, D, st);
     launch_layernorm_rows_packed(e->hl, D, e->ln_f.g, e->ln_f.b, e->xp_a, B, D, c.ln_eps, st);
-    lm_head_logits(e, (B + 31) / 32, st);
+    lm_head_logits(e, (B + 31) / 32, e->xp_a, nullptr, st);
     return 0;
 }
 
-// one autoregressive step: consumes cur_tok/positions, leaves logits in e->logits
+// one autoregressive step: consumes cur_tok/positions, leaves logits in e->logits.
+// 1 + 5 per layer + 1 launches: embed | c_attn(LN1) . attention . c_proj(+res) . c_fc(LN2,GELU) . c_proj(+res) | lm_head(ln_f)
 static void decode_forward(sv_engine* e, int B, hipStream_t st) {
     const sv_config& c = e->cfg;
-    const int D = c.hidden, dh = e->dh, F = c.n_inner, MT = (B + 31) / 32;
-    RowUpdateArgs ru;
-    memset(&ru, 0, sizeof(ru));
-    ru.h = e->h_dec; ru.ldh = D; ru.M = B; ru.D = D; ru.eps = c.ln_eps; ru.xp_out = e->xp_a;
-    ru.ldws = e->ldws; ru.rows_ws = MT * 32;
-    // embedding + ln_1 of layer 0
-    ru.ws = nullptr; ru.wte = e->wte; ru.wpe = e->wpe; ru.tokens = e->cur_tok; ru.positions = e->positions;
-    ru.g = e->dec[0].ln1.g; ru.b = e->dec[0].ln1.b;
+    const int D = c.hidden, dh = e->dh, MT = (B + 31) / 32;
+    EmbedRowsArgs er;
+    memset(&er, 0, sizeof(er));
+    er.wte = e->wte; er.wpe = e->wpe; er.tokens = e->cur_tok; er.positions = e->positions;
+    er.h_xp = e->h_xp; er.stats = e->ln_stats; er.M = B; er.D = D;
     prof_mark(e, PK_ROWLN, st);
-    launch_row_update_ln(ru, st);
+    launch_embed_rows(er, st);
     for (int i = 0; i < c.n_layer; ++i) {
         DecLayer& L = e->dec[i];
         prof_mark(e, PK_SKINNY, st);
-        skinny_partial(e, e->xp_a, L.c_attn, MT, st);
+        decode_gemm(e, e->h_xp, L.c_attn, &L.ln1, MT, SK_OUT_ROWMAJOR, ACT_NONE, st);
         AttnDecodeArgs ad;
-        ad.ws = e->ws; ad.splitk = L.c_attn.splitk; ad.ldws = e->ldws; ad.rows_ws = MT * 32; ad.bias = L.c_attn.bias;
+        memset(&ad, 0, sizeof(ad));
+        ad.qkv = e->qkv_rm; ad.ld_qkv = e->ldq;
         ad.pool_layer = e->kv_pool + (size_t)i * e->layer_stride; ad.block_table = e->block_table;
         ad.max_pages = e->pages_per_seq; ad.positions = e->positions; ad.out_xp = e->xp_attn; ad.out_KS = D / 16;
         ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
+        ad.part = e->attn_part; ad.counters = e->attn_cnt;
         prof_mark(e, PK_ATTN, st);
         launch_attn_decode(ad, st);
         prof_mark(e, PK_SKINNY, st);
-        skinny_partial(e, e->xp_attn, L.c_proj, MT, st);
-        ru.ws = e->ws; ru.splitk = L.c_proj.splitk; ru.bias = L.c_proj.bias; ru.g = L.ln2.g; ru.b = L.ln2.b;
-        prof_mark(e, PK_ROWLN, st);
-        launch_row_update_ln(ru, st);
+        decode_gemm(e, e->xp_attn, L.c_proj, nullptr, MT, SK_OUT_RESID, ACT_NONE, st);
         prof_mark(e, PK_SKINNY, st);
-        {
-            SkinnyArgs a;
-            memset(&a, 0, sizeof(a));
-            a.xp = e->xp_a; a.Wp = L.c_fc.Wp; a.bias = L.c_fc.bias; a.MT = MT; a.Npad = L.c_fc.Npad; a.K = L.c_fc.Kpad;
-            a.splitk = 1; a.out_mode = SK_OUT_PACKED_ACT; a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16;
-            a.N = L.c_fc.N;
-            launch_gemm_skinny(a, st);
-        }
+        decode_gemm(e, e->h_xp, L.c_fc, &L.ln2, MT, SK_OUT_PACKED_ACT, ACT_GELU_TANH, st);
         prof_mark(e, PK_SKINNY, st);
-        skinny_partial(e, e->xp_mlp, L.c_proj2, MT, st);
-        const LNp& nxt = (i + 1 < c.n_layer) ? e->dec[i + 1].ln1 : e->ln_f;
-        ru.splitk = L.c_proj2.splitk; ru.bias = L.c_proj2.bias; ru.g = nxt.g; ru.b = nxt.b;
-        prof_mark(e, PK_ROWLN, st);
-        launch_row_update_ln(ru, st);
+        decode_gemm(e, e->xp_mlp, L.c_proj2, nullptr, MT, SK_OUT_RESID, ACT_NONE, st);
     }
     prof_mark(e, PK_SKINNY, st);
-    lm_head_logits(e, MT, st);
+    lm_head_logits(e, MT, e->h_xp, &e->ln_f, st);
     prof_mark(e, PK_SAMPLE, st);      // closes the lm_head interval; whatever follows is sampling
 }
 
@@ -931,6 +959,65 @@ extern "C" int sv_op_linear_skinny(const void* x, const void* W, const void* bia
                                                                  (float*)y_f32, M, N);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int sv_op_decode_linear(const void* h, const void* gamma, const void* beta, float eps, const void* W,
+                                   const void* bias, const void* residual, void* y, float* row_stats, int32_t M,
+                                   int32_t N, int32_t K, int32_t splitk, int32_t act, sv_stream stream) {
+    if (!h || !W || !y || M < 1 || N < 4 || N % 4 || K < 32 || K % 32 || splitk < 1 || (K / 16) % splitk)
+        return fail(SV_EINVAL, "sv_op_decode_linear: bad argument");
+    if ((gamma == nullptr) != (beta == nullptr)) return fail(SV_EINVAL, "gamma and beta go together");
+    if (residual && N % 32) return fail(SV_EINVAL, "residual mode needs N %% 32 == 0");
+    hipStream_t st = (hipStream_t)stream;
+    TmpBufs tmp;
+    const int Npad = round_up(N, 32), MT = (M + 31) / 32, R = MT * 32;
+    bf16_t *Wp, *hxp, *oxp, *orm;
+    float* ws; float2 *st_in, *st_out; unsigned* cnt;
+    SVCHECK(tmp.get(&Wp, (size_t)Npad * K));
+    SVCHECK(tmp.get(&hxp, (size_t)R * K));
+    SVCHECK(tmp.get(&oxp, (size_t)R * Npad));
+    SVCHECK(tmp.get(&orm, (size_t)R * Npad));
+    SVCHECK(tmp.get(&ws, (size_t)splitk * R * Npad));
+    SVCHECK(tmp.get(&st_in, (size_t)R * (K / 32)));
+    SVCHECK(tmp.get(&st_out, (size_t)R * (Npad / 32)));
+    SVCHECK(tmp.get(&cnt, (size_t)MT * (Npad / 32)));
+    HIPCHECK(hipMemsetAsync(hxp, 0, (size_t)R * K * 2, st));
+    HIPCHECK(hipMemsetAsync(oxp, 0, (size_t)R * Npad * 2, st));
+    HIPCHECK(hipMemsetAsync(cnt, 0, (size_t)MT * (Npad / 32) * sizeof(unsigned), st));
+    HIPCHECK(hipMemsetAsync(st_in, 0, (size_t)R * (K / 32) * sizeof(float2), st));
+    launch_pack_weight(W, 0, Wp, N, K, Npad, K, st);
+    EmbedRowsArgs er;
+    memset(&er, 0, sizeof(er));
+    er.rows = (const bf16_t*)h; er.ld_rows = K; er.h_xp = hxp; er.stats = st_in; er.M = M; er.D = K;
+    launch_embed_rows(er, st);
+    SkinnyArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xp = hxp; a.Wp = Wp; a.bias = (const bf16_t*)bias; a.MT = MT; a.Npad = Npad; a.K = K; a.splitk = splitk;
+    a.act = act; a.N = N; a.ws = ws; a.ldws = Npad; a.counters = cnt;
+    if (gamma) { a.ln_stats = st_in; a.ln_tiles = K / 32; a.ln_g = (const bf16_t*)gamma; a.ln_b = (const bf16_t*)beta; a.ln_eps = eps; }
+    if (residual) {
+        pack_rows_kernel<<<(M * (N / 8) + 255) / 256, 256, 0, st>>>((const bf16_t*)residual, N, oxp, M, N);
+        a.out_mode = SK_OUT_RESID; a.out_xp = oxp; a.resid_xp = oxp; a.out_KS = Npad / 16; a.stats_out = st_out;
+    } else {
+        a.out_mode = SK_OUT_ROWMAJOR; a.out_rm = orm; a.ld_rm = Npad;
+    }
+    launch_gemm_skinny(a, st);
+    if (residual) {
+        unpack_rows_kernel<<<(M * (N / 8) + 255) / 256, 256, 0, st>>>(oxp, (bf16_t*)y, N, M, N);
+        if (row_stats) sum_stats_kernel<<<(M + 63) / 64, 64, 0, st>>>(st_out, Npad / 32, row_stats, M);
+    } else {
+        HIPCHECK(hipMemcpy2DAsync(y, (size_t)N * 2, orm, (size_t)Npad * 2, (size_t)N * 2, M, hipMemcpyDeviceToDevice, st));
+    }
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int sv_op_cvt_bf16_hw(const float* x, void* y, int64_t n, sv_stream stream) {
+    if (!x || !y || n < 1) return fail(SV_EINVAL, "sv_op_cvt_bf16_hw: bad argument");
+    launch_cvt_bf16_hw(x, (bf16_t*)y, (size_t)n, (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
     return 0;
 }
 

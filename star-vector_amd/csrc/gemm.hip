@@ -217,11 +217,32 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// skinny GEMM
+// skinny GEMM (decode step)
+//   out[m][n] = epi( sum_k x[m][k] W[n][k] ),  M <= 32 rows per tile, HBM-bound weight streaming.
+//   * optional LayerNorm PROLOGUE: the activation operand is the raw residual stream h (fragment order)
+//     and x = LN(h) is formed in registers on the way to the MFMA; the per-row mean / rstd come from
+//     per-32-column partial sums (sum, sum of squares) that the PRODUCER of h left in `ln_stats`,
+//     combined here in tile order (deterministic).
+//   * K split across the 8 waves of a block (LDS reduce) and, for narrow outputs, across `splitk`
+//     blocks: each block writes an fp32 slab, draws an arrival ticket, and the LAST block of a tile sums
+//     the slabs in slab order and runs the epilogue (agent-scope release / acquire hand-off; no separate
+//     reduce kernel, bitwise deterministic).
+//   * epilogues: bias+activation -> fragment-order bf16 (c_fc); bias -> row-major bf16 (c_attn: q|k|v);
+//     bias + residual -> new residual stream in fragment order + its LayerNorm partial statistics
+//     (both c_proj); fp32 logits rounded to bf16 values (lm_head); raw fp32 slabs (test surface).
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    // v_cvt_pk_bf16_f32: two f32 -> packed bf16, round-to-nearest-even (checked bit-exactly against
+    // torch's cast by tests/test_gpu_ops.py::test_bf16_rounding_is_rne)
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     __shared__ float red[WAVES][16][64];
+    __shared__ float lnp[32][2];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -232,6 +253,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     const int ks_per_split = KS / p.splitk;
     const int ks_per_wave = ks_per_split / WAVES;
     const int ks0 = split * ks_per_split + wave * ks_per_wave;
+    const int m = lane & 31;
+    const int half = lane >> 5;
 
     const u32x4* wptr = reinterpret_cast<const u32x4*>(p.Wp) + ((size_t)nt * KS + ks0) * 64 + lane;
     const u32x4* xptr = reinterpret_cast<const u32x4*>(p.xp) + ((size_t)mt * KS + ks0) * 64 + lane;
@@ -240,24 +263,93 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    int ks = 0;
-    for (; ks + 8 <= ks_per_wave; ks += 8) {
-        u32x4 wv[8], xv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            wv[u] = __builtin_nontemporal_load(wptr + (size_t)(ks + u) * 64);   // streamed once
-            xv[u] = xptr[(size_t)(ks + u) * 64];
+    if (p.ln_stats) {
+        // ---- LayerNorm prologue: row statistics from the producer's per-tile partial sums ----------
+        float* part = &red[0][0][0];                      // [parts][32][2] scratch (before the k-loop)
+        constexpr int PARTS = WAVES * 2;
+        const int prt = tid >> 5;
+        float s1 = 0.f, s2 = 0.f;
+        for (int t = prt; t < p.ln_tiles; t += PARTS) {
+            const float2 v = p.ln_stats[((size_t)mt * p.ln_tiles + t) * 32 + m];
+            s1 += v.x; s2 += v.y;
         }
+        part[(prt * 32 + m) * 2 + 0] = s1;
+        part[(prt * 32 + m) * 2 + 1] = s2;
+        __syncthreads();
+        if (tid < 32) {
+            float a = 0.f, b = 0.f;
+            for (int q = 0; q < PARTS; ++q) { a += part[(q * 32 + tid) * 2]; b += part[(q * 32 + tid) * 2 + 1]; }
+            const float invD = 1.0f / (float)(p.ln_tiles * 32);
+            const float mean = a * invD;
+            float var = b * invD - mean * mean;
+            var = var > 0.f ? var : 0.f;
+            const float rstd = rsqrtf(var + p.ln_eps);
+            lnp[tid][0] = rstd;
+            lnp[tid][1] = -mean * rstd;
+        }
+        __syncthreads();
+        const float ra = lnp[m][0], rb = lnp[m][1];
+        __syncthreads();                                   // `red` is reused by the wave reduction below
+        const u32x4* gptr = reinterpret_cast<const u32x4*>(p.ln_g) + (size_t)ks0 * 2 + half;
+        const u32x4* bptr = reinterpret_cast<const u32x4*>(p.ln_b) + (size_t)ks0 * 2 + half;
+        int ks = 0;
+        for (; ks + 4 <= ks_per_wave; ks += 4) {
+            u32x4 wv[4], hv[4], gv[4], bv[4];
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wv[u]), as_frag4(xv[u]), acc, 0, 0, 0);
-    }
-    for (; ks < ks_per_wave; ++ks) {
-        u32x4 wv = __builtin_nontemporal_load(wptr + (size_t)ks * 64);
-        u32x4 xv = xptr[(size_t)ks * 64];
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wv), as_frag4(xv), acc, 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+                wv[u] = __builtin_nontemporal_load(wptr + (size_t)(ks + u) * 64);
+                hv[u] = xptr[(size_t)(ks + u) * 64];
+                gv[u] = gptr[(size_t)(ks + u) * 2];
+                bv[u] = bptr[(size_t)(ks + u) * 2];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                u32x4 xv;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    const float h0 = __uint_as_float(hv[u][w] << 16), h1 = __uint_as_float(hv[u][w] & 0xffff0000u);
+                    const float g0 = __uint_as_float(gv[u][w] << 16), g1 = __uint_as_float(gv[u][w] & 0xffff0000u);
+                    const float b0 = __uint_as_float(bv[u][w] << 16), b1 = __uint_as_float(bv[u][w] & 0xffff0000u);
+                    xv[w] = cvt_pk_bf16(fmaf(fmaf(h0, ra, rb), g0, b0), fmaf(fmaf(h1, ra, rb), g1, b1));
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wv[u]), as_frag4(xv), acc, 0, 0, 0);
+            }
+        }
+        for (; ks < ks_per_wave; ++ks) {
+            const u32x4 wv = __builtin_nontemporal_load(wptr + (size_t)ks * 64);
+            const u32x4 hv = xptr[(size_t)ks * 64];
+            const u32x4 gv = gptr[(size_t)ks * 2], bv = bptr[(size_t)ks * 2];
+            u32x4 xv;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const float h0 = __uint_as_float(hv[w] << 16), h1 = __uint_as_float(hv[w] & 0xffff0000u);
+                const float g0 = __uint_as_float(gv[w] << 16), g1 = __uint_as_float(gv[w] & 0xffff0000u);
+                const float b0 = __uint_as_float(bv[w] << 16), b1 = __uint_as_float(bv[w] & 0xffff0000u);
+                xv[w] = cvt_pk_bf16(fmaf(fmaf(h0, ra, rb), g0, b0), fmaf(fmaf(h1, ra, rb), g1, b1));
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wv), as_frag4(xv), acc, 0, 0, 0);
+        }
+    } else {
+        int ks = 0;
+        for (; ks + 8 <= ks_per_wave; ks += 8) {
+            u32x4 wv[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                wv[u] = __builtin_nontemporal_load(wptr + (size_t)(ks + u) * 64);   // streamed once
+                xv[u] = xptr[(size_t)(ks + u) * 64];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wv[u]), as_frag4(xv[u]), acc, 0, 0, 0);
+        }
+        for (; ks < ks_per_wave; ++ks) {
+            const u32x4 wv = __builtin_nontemporal_load(wptr + (size_t)ks * 64);
+            const u32x4 xv = xptr[(size_t)ks * 64];
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wv), as_frag4(xv), acc, 0, 0, 0);
+        }
     }
 
+    // ---- K reduction across the waves of the block (wave order) ---------------------------------
     if (WAVES > 1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
@@ -271,40 +363,104 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
             acc[r] = s;
         }
     }
+    // only wave 0 continues: lane (m = l&31, half) owns columns n = nt*32 + 8*rg + 4*half + j
 
-    const int m = lane & 31;
-    const int half = lane >> 5;
+    if (p.out_mode == SK_OUT_PARTIAL) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            float* dst = p.ws + ((size_t)split * p.MT * 32 + mt * 32 + m) * p.ldws + nt * 32 + rg * 8 + half * 4;
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[rg * 4], acc[rg * 4 + 1], acc[rg * 4 + 2], acc[rg * 4 + 3]);
+        }
+        return;
+    }
+
+    if (p.splitk > 1) {
+        // ---- cross-block K reduction: slab -> ticket -> the last block of this tile sums all slabs ----
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            float* dst = p.ws + ((size_t)split * p.MT * 32 + mt * 32 + m) * p.ldws + nt * 32 + rg * 8 + half * 4;
+            *reinterpret_cast<float4*>(dst) = make_float4(acc[rg * 4], acc[rg * 4 + 1], acc[rg * 4 + 2], acc[rg * 4 + 3]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned* cnt = p.counters + (size_t)mt * gridDim.x + nt;
+        unsigned t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t != (unsigned)(p.splitk - 1)) return;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int sp = 0; sp < p.splitk; ++sp) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float* src = p.ws + ((size_t)sp * p.MT * 32 + mt * 32 + m) * p.ldws + nt * 32 + rg * 8 + half * 4;
+                const float4 v = *reinterpret_cast<const float4*>(src);
+                acc[rg * 4] += v.x; acc[rg * 4 + 1] += v.y; acc[rg * 4 + 2] += v.z; acc[rg * 4 + 3] += v.w;
+            }
+        }
+        if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    }
+
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
         const int n = nt * 32 + rg * 8 + half * 4;
         float v[4] = {acc[rg * 4 + 0], acc[rg * 4 + 1], acc[rg * 4 + 2], acc[rg * 4 + 3]};
-        if (p.out_mode == SK_OUT_PARTIAL) {
-            float* dst = p.ws + ((size_t)split * p.MT * 32 + mt * 32 + m) * p.ldws + n;
-            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-        } else if (p.out_mode == SK_OUT_PACKED_ACT) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float x = v[j];
-                if (n + j < p.N) {
-                    if (p.bias) x += bf2f(p.bias[n + j]);
-                    x = sv_act(bfround(x), p.act);
-                } else {
-                    x = 0.f;
-                }
-                v[j] = x;
-            }
-            uint2 o;
-            o.x = pack2bf(v[0], v[1]);
-            o.y = pack2bf(v[2], v[3]);
-            *reinterpret_cast<uint2*>(p.out_xp + xp_index(mt, p.out_KS, m, n)) = o;
-        } else {
+        if (p.out_mode == SK_OUT_F32) {
             if (p.round_bf16) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) v[j] = bfround(v[j]);
             }
             float* dst = p.out_f32 + ((size_t)mt * 32 + m) * p.ldo + n;
             *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            continue;
         }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float x = v[j];
+            if (n + j < p.N) {
+                if (p.bias) x += bf2f(p.bias[n + j]);
+                x = bfround(x);
+                if (p.act != ACT_NONE) x = sv_act(x, p.act);
+            } else {
+                x = 0.f;
+            }
+            v[j] = x;
+        }
+        if (p.out_mode == SK_OUT_RESID) {
+            const size_t off = xp_index(mt, p.out_KS, m, n);
+            const uint2 rr = *reinterpret_cast<const uint2*>(p.resid_xp + off);
+            v[0] = bfround(v[0] + __uint_as_float(rr.x << 16));
+            v[1] = bfround(v[1] + __uint_as_float(rr.x & 0xffff0000u));
+            v[2] = bfround(v[2] + __uint_as_float(rr.y << 16));
+            v[3] = bfround(v[3] + __uint_as_float(rr.y & 0xffff0000u));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (n + j < p.N) { s1 += v[j]; s2 += v[j] * v[j]; }
+            uint2 o;
+            o.x = pack2bf(v[0], v[1]);
+            o.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(p.out_xp + off) = o;
+        } else if (p.out_mode == SK_OUT_PACKED_ACT) {
+            uint2 o;
+            o.x = pack2bf(v[0], v[1]);
+            o.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(p.out_xp + xp_index(mt, p.out_KS, m, n)) = o;
+        } else {   // SK_OUT_ROWMAJOR
+            if (n < p.N) {
+                uint2 o;
+                o.x = pack2bf(v[0], v[1]);
+                o.y = pack2bf(v[2], v[3]);
+                *reinterpret_cast<uint2*>(p.out_rm + ((size_t)mt * 32 + m) * p.ld_rm + n) = o;
+            }
+        }
+    }
+    if (p.out_mode == SK_OUT_RESID && p.stats_out) {
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (half == 0) p.stats_out[((size_t)mt * gridDim.x + nt) * 32 + m] = make_float2(s1, s2);
     }
 }
 
@@ -320,6 +476,52 @@ void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st) {
         gemm_skinny_kernel<2><<<grid, 128, 0, st>>>(a);
     else
         gemm_skinny_kernel<1><<<grid, 64, 0, st>>>(a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// decode-step entry: h = bf(wte[tok] + wpe[pos]) in fragment order + its LayerNorm partial statistics
+// (gpt_bigcode :1060-1063).  One block per sequence.  Also used (generic form) to turn row-major rows
+// into the (h, stats) pair the LN-prologue GEMM consumes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_rows_kernel(EmbedRowsArgs p) {
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int D = p.D, NC = D >> 3, KS = D >> 4, NT = D >> 5;
+    for (int c = tid; c < NC; c += 256) {                 // chunk c = 8 features; 4 chunks per 32-col tile
+        float f[8];
+        if (p.rows) {
+            unpack8(*reinterpret_cast<const uint4*>(p.rows + (size_t)row * p.ld_rows + c * 8), f);
+        } else {
+            const int tok = p.tokens[row], pos = p.positions[row];
+            float a[8], w[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.wte + (size_t)tok * D + c * 8), a);
+            unpack8(*reinterpret_cast<const uint4*>(p.wpe + (size_t)pos * D + c * 8), w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = bfround(a[e] + w[e]);
+        }
+        *reinterpret_cast<uint4*>(p.h_xp + xp_index(row >> 5, KS, row & 31, c * 8)) = pack8(f);
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1 += f[e]; s2 += f[e] * f[e]; }
+        // the 4 chunks of one tile sit in 4 consecutive lanes (NC % 4 == 0, 256 % 4 == 0)
+        s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
+        s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
+        if ((c & 3) == 0) p.stats[((size_t)(row >> 5) * NT + (c >> 2)) * 32 + (row & 31)] = make_float2(s1, s2);
+    }
+}
+void launch_embed_rows(const EmbedRowsArgs& a, hipStream_t st) { embed_rows_kernel<<<a.M, 256, 0, st>>>(a); }
+
+// f32 -> bf16 through the hardware convert used by the LN prologue (test surface)
+__global__ void cvt_bf16_hw_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    if (i + 1 < n) {
+        *reinterpret_cast<uint32_t*>(y + i) = cvt_pk_bf16(x[i], x[i + 1]);
+    } else if (i < n) {
+        y[i] = (bf16_t)(cvt_pk_bf16(x[i], 0.f) & 0xffffu);
+    }
+}
+void launch_cvt_bf16_hw(const float* x, bf16_t* y, size_t n, hipStream_t st) {
+    cvt_bf16_hw_kernel<<<(unsigned)((n / 2 + 256) / 256), 256, 0, st>>>(x, y, n);
 }
 
 }  // namespace sv

@@ -27,22 +27,41 @@ struct GemmArgs {
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 
 // ---- skinny (M<=32 per tile) weight-streaming GEMM --------------------------------------------
-enum { SK_OUT_PARTIAL = 0, SK_OUT_PACKED_ACT = 1, SK_OUT_F32 = 2 };
+enum { SK_OUT_PARTIAL = 0, SK_OUT_PACKED_ACT = 1, SK_OUT_F32 = 2, SK_OUT_RESID = 3, SK_OUT_ROWMAJOR = 4 };
 struct SkinnyArgs {
-    const bf16_t* xp;                // packed activations [MT][K/16][64][8]
+    const bf16_t* xp;                // packed activations [MT][K/16][64][8] (the raw residual stream h when ln_stats)
     const bf16_t* Wp;                // packed weight [Npad/32][K/16][64][8]
-    const bf16_t* bias;              // used by PACKED_ACT
+    const bf16_t* bias;              // [N] or nullptr
     int MT;                          // number of 32-row tiles
     int Npad, K;                     // Npad multiple of 32, K multiple of 16
     int splitk;                      // >=1; (K/16) must be divisible by splitk*waves
     int out_mode; int act;
-    float* ws; int ldws;             // PARTIAL: ws[split][MT*32][ldws]
-    bf16_t* out_xp; int out_KS;      // PACKED_ACT: packed activation buffer with out_KS = Npad/16 k-steps
+    int N;                           // valid columns (<= Npad)
+    // LayerNorm prologue (optional): x = LN(h); statistics from per-32-column partial (sum, sumsq)
+    const float2* ln_stats; int ln_tiles;     // [MT][ln_tiles][32], ln_tiles = K/32
+    const bf16_t* ln_g; const bf16_t* ln_b; float ln_eps;
+    // split-K hand-off
+    float* ws; int ldws;             // fp32 slabs ws[split][MT*32][ldws]
+    unsigned* counters;              // [MT][Npad/32] arrival tickets, zero between launches
+    // outputs
+    bf16_t* out_xp; int out_KS;      // PACKED_ACT / RESID: fragment-order buffer with out_KS = Npad/16 k-steps
+    const bf16_t* resid_xp;          // RESID: residual stream (same layout; may alias out_xp)
+    float2* stats_out;               // RESID: [MT][Npad/32][32] LayerNorm partials of the new rows
+    bf16_t* out_rm; int ld_rm;       // ROWMAJOR: [MT*32][ld_rm]
     float* out_f32; int ldo;         // F32: [MT*32][ldo]; rounded to bf16 values if round_bf16
     int round_bf16;
-    int N;                           // valid columns (<= Npad)
 };
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st);
+
+struct EmbedRowsArgs {
+    const bf16_t* rows; int ld_rows;                       // generic: row-major input rows; or nullptr:
+    const bf16_t* wte; const bf16_t* wpe;                  //   wte[tokens[row]] + wpe[positions[row]]
+    const int32_t* tokens; const int32_t* positions;
+    bf16_t* h_xp; float2* stats;                           // fragment-order rows + [MT][D/32][32] partials
+    int M, D;
+};
+void launch_embed_rows(const EmbedRowsArgs& a, hipStream_t st);
+void launch_cvt_bf16_hw(const float* x, bf16_t* y, size_t n, hipStream_t st);
 
 // ---- row kernels ---------------------------------------------------------------------------------
 void launch_layernorm_rows(const bf16_t* x, int ldx, const bf16_t* g, const bf16_t* b, bf16_t* y, int ldy,
@@ -50,19 +69,6 @@ void launch_layernorm_rows(const bf16_t* x, int ldx, const bf16_t* g, const bf16
 // y_packed (xp layout) variant for the decode path
 void launch_layernorm_rows_packed(const bf16_t* x, int ldx, const bf16_t* g, const bf16_t* b, bf16_t* yp,
                                   int M, int D, float eps, hipStream_t st);
-
-// decode row update: v = sum_s ws[s][m][:] + bias ; h = bf(h + bf(v)) (in place) ; xp = LN(h)
-struct RowUpdateArgs {
-    const float* ws; int splitk; int ldws; int rows_ws;   // partials [splitk][rows_ws][ldws] (or nullptr)
-    const bf16_t* bias;
-    bf16_t* h; int ldh;                                    // residual stream [M][D] (in/out)
-    const bf16_t* wte; const bf16_t* wpe;                  // embedding mode (ws == nullptr)
-    const int32_t* tokens; const int32_t* positions;       // [M]
-    const bf16_t* g; const bf16_t* b; float eps;           // LayerNorm applied to the updated row
-    bf16_t* xp_out;                                        // packed LN output
-    int M, D;
-};
-void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st);
 
 // ---- embeddings ---------------------------------------------------------------------------------
 void launch_im2col(const bf16_t* img, bf16_t* out, int B, int img_size, int patch, int Kpad, hipStream_t st);
@@ -101,15 +107,19 @@ void launch_kv_write_prefill(const bf16_t* qkv, int row_stride, int k_off, int v
                              hipStream_t st);
 
 struct AttnDecodeArgs {
-    const float* ws; int splitk; int ldws; int rows_ws;   // c_attn split-K partials [splitk][rows][ldws]
-    const bf16_t* bias;                                    // c_attn bias [H*D + 2*D]
+    const bf16_t* qkv; int ld_qkv;                         // c_attn output rows [B][ld] bf16 (bias added); or nullptr:
+    const float* ws; int splitk; int ldws; int rows_ws;   //   legacy fp32 split-K slabs [splitk][rows][ldws]
+    const bf16_t* bias;                                    //   + c_attn bias [H*D + 2*D]
     char* pool_layer;                                      // this layer's page pool
     const int32_t* block_table; int max_pages;
     const int32_t* positions;                              // [B] index of the new token (= tokens already cached)
     bf16_t* out_xp; int out_KS;                            // packed [MT][H*D/16][64][8]
     int B, H, head_dim; float scale;
+    float* part;                                           // [B][splits][32 + 16*D] partial (m, l, O)
+    unsigned* counters;                                    // [B] arrival tickets, zero between launches
 };
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t st);
+size_t attn_decode_part_floats(int head_dim);            // floats of `part` per sequence
 int init_attention_kernels();   // returns a hipError_t value (0 = ok)
 
 // ---- sampling -----------------------------------------------------------------------------------

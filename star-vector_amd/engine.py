@@ -214,6 +214,28 @@ def op_linear_skinny(x, W, bias=None, splitk=1):
     return y
 
 
+def op_decode_linear(h, W, bias=None, gamma=None, beta=None, residual=None, act="none", splitk=1, eps=1e-5):
+    """Returns (y bf16 [M,N], row_stats f32 [M,2] or None)."""
+    lib = _lib.load()
+    h = _need(h, torch.bfloat16, "h"); W = _need(W, torch.bfloat16, "W")
+    M, K = h.shape; N = W.shape[0]
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=h.device)
+    opt = lambda t, n: _need(t, torch.bfloat16, n) if t is not None else None
+    b, g, be, r = opt(bias, "bias"), opt(gamma, "gamma"), opt(beta, "beta"), opt(residual, "residual")
+    stats = torch.empty(M, 2, dtype=torch.float32, device=h.device) if residual is not None else None
+    check(lib.sv_op_decode_linear(_ptr(h), _ptr(g), _ptr(be), float(eps), _ptr(W), _ptr(b), _ptr(r), _ptr(y), _ptr(stats),
+                                  M, N, K, splitk, _lib.ACT[act], _stream()))
+    return y, stats
+
+
+def op_cvt_bf16_hw(x):
+    lib = _lib.load()
+    x = _need(x, torch.float32, "x")
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(lib.sv_op_cvt_bf16_hw(_ptr(x), _ptr(y), x.numel(), _stream()))
+    return y
+
+
 def op_attention(q, k, v, n_head, n_kv_head, causal, scale=None):
     lib = _lib.load()
     q = _need(q, torch.bfloat16, "q"); k = _need(k, torch.bfloat16, "k"); v = _need(v, torch.bfloat16, "v")

@@ -167,3 +167,62 @@ def test_top_p_sampler_distribution():
     # top_p -> tiny keeps only the argmax
     only = E.op_sample_top_p(rows[:64], 1.0, 1e-6, seed=1, step=0).cpu().long()
     assert bool((only == lg.argmax()).all())
+
+
+def test_bf16_rounding_is_rne():
+    """Both float->bf16 conversions used by the kernels (software f2bf in the epilogues, hardware
+    v_cvt_pk_bf16_f32 in the LayerNorm prologue) must be round-to-nearest-EVEN like torch's cast:
+    exact halfway cases decide it."""
+    g = torch.Generator().manual_seed(11)
+    x = torch.cat([torch.randn(4096, generator=g) * 3,
+                   torch.tensor([1.0 + 2 ** -9, 1.0 + 2 ** -8 + 2 ** -9, -(1.0 + 2 ** -9), 2.0 + 2 ** -8, 0.0, 65280.0 * 2,
+                                 1.0 + 2 ** -9 + 2 ** -20, 1.0 + 2 ** -9 - 2 ** -20, 3.0e-39])])
+    ref = x.to(torch.bfloat16)
+    got = E.op_cvt_bf16_hw(x.to(dev())).cpu()
+    assert torch.equal(got.view(torch.int16), ref.view(torch.int16))
+    # software path: y = 1 * w + bias hits the halfway cases inside the GEMM epilogue
+    w = torch.tensor([[1.0], [1.0 + 2 ** -7], [-1.0], [2.0]]).repeat(8, 1)          # N=32, K=1 (padded inside)
+    W = torch.zeros(32, 64); W[:, :1] = w
+    xx = torch.zeros(4, 64); xx[:, 0] = 1.0
+    b = torch.full((32,), 2.0 ** -9)
+    y = E.op_linear(bf(xx), bf(W), bf(b), None).float().cpu()
+    expect = (xx @ W.T + b).to(torch.bfloat16).float()
+    assert torch.equal(y, expect)
+
+
+@pytest.mark.parametrize("M,N,K,sk,ln,res,act", [
+    (32, 2304, 2048, 4, True, False, "none"),      # c_attn: LN1 prologue, split-K ticket, row-major q|k|v
+    (32, 2048, 2048, 4, False, True, "none"),      # attn c_proj: ticket + residual + LN statistics
+    (32, 8192, 2048, 1, True, False, "gelu_tanh"), # c_fc: LN2 prologue + GELU
+    (32, 2048, 8192, 4, False, True, "none"),      # mlp c_proj
+    (5, 512, 256, 8, True, False, "none"), (40, 256, 1024, 2, False, True, "none"), (3, 96, 64, 1, True, False, "swish"),
+])
+def test_decode_linear_fused(M, N, K, sk, ln, res, act):
+    g = torch.Generator().manual_seed(M + N + K + sk)
+    h = (torch.randn(M, K, generator=g) * 1.5 + 0.2).bfloat16().float()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().float()
+    b = (0.1 * torch.randn(N, generator=g)).bfloat16().float()
+    gam = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().float()
+    bet = (0.1 * torch.randn(K, generator=g)).bfloat16().float()
+    r = torch.randn(M, N, generator=g).bfloat16().float()
+    x = torch.nn.functional.layer_norm(h, (K,), gam, bet, 1e-5).bfloat16().float() if ln else h
+    y = (x @ W.T + b).bfloat16().float()
+    if act == "gelu_tanh":
+        y = torch.nn.functional.gelu(y, approximate="tanh")
+    elif act == "swish":
+        y = y * torch.sigmoid(y)
+    if res:
+        y = y.bfloat16().float() + r
+    got, stats = E.op_decode_linear(bf(h), bf(W), bf(b), bf(gam) if ln else None, bf(bet) if ln else None,
+                                    bf(r) if res else None, act=act, splitk=sk)
+    assert not torch.isnan(got.float()).any()
+    # LN-prologue inputs are bf16-rounded before the GEMM, so a 1-ulp flip of x moves y by ~|W| * ulp
+    assert rel_err(got, y) <= (4 if ln else 2.2) * BF16_1ULP and mean_err(got, y) <= 1.5e-3
+    if res:
+        gg = got.float().cpu()
+        torch.testing.assert_close(stats.cpu()[:, 0], gg.sum(-1), rtol=1e-5, atol=1e-3)
+        torch.testing.assert_close(stats.cpu()[:, 1], (gg * gg).sum(-1), rtol=1e-5, atol=1e-3)
+    # ticket-elected reducer sums slabs in slab order: bitwise repeatable
+    got2, _ = E.op_decode_linear(bf(h), bf(W), bf(b), bf(gam) if ln else None, bf(bet) if ln else None,
+                                 bf(r) if res else None, act=act, splitk=sk)
+    assert torch.equal(got, got2)
