@@ -251,8 +251,8 @@ void launch_kv_write_prefill(const bf16_t* qkv, int row_stride, int k_off, int v
 // inter-block hand-off at all; long contexts split flash-decoding style.  Active blocks own the 32-key
 // groups g = split + act*(wave + 8*i), prefetch the next group's fragments while the MFMAs of the
 // current one run, and (act > 1) leave a partial (m, l, O) in HBM; an arrival ticket elects the last
-// block, which merges the partials in split order (bitwise deterministic).  Hand-off = agent-scope
-// release (writers) / acquire (merger): placement independent.
+// block, which merges the partials in split order (bitwise deterministic).  Hand-off = write-through
+// (sc1) partial stores + drained ticket + sc1 loads in the merger: no fences, placement independent.
 // ------------------------------------------------------------------------------------------------
 #define AD_WAVES 8
 #define AD_SPLIT 8
@@ -442,77 +442,110 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
         *reinterpret_cast<float4*>(O_s + ((size_t)(wave * 16 + hd)) * D + 16 * t + 4 * c) =
             make_float4(accO[t][0], accO[t][1], accO[t][2], accO[t][3]);
     __syncthreads();
-    float* mypart = p.part + ((size_t)b * AD_SPLIT + split) * PART;
-    for (int idx = tid; idx < HD; idx += AD_WAVES * 64) {
+    // each thread owns 4 consecutive outputs (same head): 16-byte stores for the partial / 8-byte for the result
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        p.part, 0, (unsigned)((size_t)p.B * AD_SPLIT * PART * sizeof(float)), 0x00020000);
+    const int my_off = (int)(((size_t)b * AD_SPLIT + split) * PART * 4);            // bytes
+    for (int idx = tid * 4; idx < 16 * D; idx += AD_WAVES * 64 * 4) {
         const int h = idx / D, dv = idx % D;
         float M = -INFINITY;
 #pragma unroll
         for (int w = 0; w < AD_WAVES; ++w) M = fmaxf(M, m_s[w * 16 + h]);
-        float num = 0.f, den = 0.f;
+        float num[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int w = 0; w < AD_WAVES; ++w) {
             const float mw = m_s[w * 16 + h];
             const float f = (mw == -INFINITY) ? 0.f : __expf(mw - M);
-            num += f * O_s[((size_t)(w * 16 + h)) * D + dv];
-            den += f * l_s[w * 16 + h];
+            const float4 o = *reinterpret_cast<const float4*>(O_s + ((size_t)(w * 16 + h)) * D + dv);
+            num[0] += f * o.x; num[1] += f * o.y; num[2] += f * o.z; num[3] += f * o.w;
         }
         if (act == 1) {
-            p.out_xp[xp_index(b >> 5, p.out_KS, b & 31, idx)] = f2bf(num / den);
+            if (idx < HD) {
+                float den = 0.f;
+#pragma unroll
+                for (int w = 0; w < AD_WAVES; ++w) {
+                    const float mw = m_s[w * 16 + h];
+                    den += ((mw == -INFINITY) ? 0.f : __expf(mw - M)) * l_s[w * 16 + h];
+                }
+                const float inv = 1.0f / den;
+                uint2 o;
+                o.x = pack2bf(num[0] * inv, num[1] * inv);
+                o.y = pack2bf(num[2] * inv, num[3] * inv);
+                *reinterpret_cast<uint2*>(p.out_xp + xp_index(b >> 5, p.out_KS, b & 31, idx)) = o;
+            }
         } else {
-            mypart[32 + idx] = num;
-            if (dv == 0) { mypart[h] = M; mypart[16 + h] = den; }
+            u32x4 v;
+            v[0] = __float_as_uint(num[0]); v[1] = __float_as_uint(num[1]);
+            v[2] = __float_as_uint(num[2]); v[3] = __float_as_uint(num[3]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, my_off + (32 + idx) * 4, 0, 16);   // write-through
         }
     }
     if (act == 1) return;
+    if (tid < 8) {
+        // m[16] | l[16] of this block's partial: 8 x 16 bytes
+        const bool is_l = tid >= 4;
+        u32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int h = (tid & 3) * 4 + j;
+            float M = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < AD_WAVES; ++w) M = fmaxf(M, m_s[w * 16 + h]);
+            float den = 0.f;
+#pragma unroll
+            for (int w = 0; w < AD_WAVES; ++w) {
+                const float mw = m_s[w * 16 + h];
+                den += ((mw == -INFINITY) ? 0.f : __expf(mw - M)) * l_s[w * 16 + h];
+            }
+            v[j] = __float_as_uint(is_l ? den : M);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, my_off + tid * 16, 0, 16);
+    }
 
-    // publish the partial, draw a ticket (release at agent scope; the counted wait keeps the ticket
-    // behind the write-back)
+    // hand-off without fences: write-through (sc1) partial, every storing wave drains, one relaxed
+    // agent-scope ticket; the last arriver reads the partials with sc1 loads (L1 bypass)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         const unsigned t = __hip_atomic_fetch_add(p.counters + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         flag_s[0] = (t == (unsigned)(act - 1)) ? 1 : 0;
     }
     __syncthreads();
     if (!flag_s[0]) return;
-    if (tid == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __syncthreads();
-    const float* parts = p.part + (size_t)b * AD_SPLIT * PART;
-    // all loads of the merge are issued in two batches (statistics, then O), never one per dependent step
+    const int seq_off = (int)((size_t)b * AD_SPLIT * PART * 4);
     float* ml = m_s;                                  // reuse LDS: [AD_SPLIT][32]
     if (tid < AD_SPLIT * 32) {
         const int s = tid >> 5;
-        ml[tid] = s < act ? parts[(size_t)s * PART + (tid & 31)] : -INFINITY;
+        float v = -INFINITY;
+        if (s < act) v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, seq_off + (s * PART + (tid & 31)) * 4, 0, 16));
+        ml[tid] = v;
     }
     __syncthreads();
-    constexpr int PER = (16 * D) / (AD_WAVES * 64);   // outputs per thread
-    float ov[PER][AD_SPLIT];
-#pragma unroll
-    for (int j = 0; j < PER; ++j)
+    for (int idx = tid * 4; idx < HD; idx += AD_WAVES * 64 * 4) {
+        const int h = idx / D;
+        u32x4 ov[AD_SPLIT];
 #pragma unroll
         for (int s = 0; s < AD_SPLIT; ++s) {
-            const int idx = tid + j * AD_WAVES * 64;
-            ov[j][s] = (s < act && idx < HD) ? parts[(size_t)s * PART + 32 + idx] : 0.f;
+            ov[s] = u32x4{0u, 0u, 0u, 0u};
+            if (s < act) ov[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, seq_off + (s * PART + 32 + idx) * 4, 0, 16);
         }
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int idx = tid + j * AD_WAVES * 64;
-        if (idx >= HD) continue;
-        const int h = idx / D;
         float M = -INFINITY;
 #pragma unroll
         for (int s = 0; s < AD_SPLIT; ++s) M = fmaxf(M, ml[s * 32 + h]);
-        float num = 0.f, den = 0.f;
+        float num[4] = {0.f, 0.f, 0.f, 0.f}, den = 0.f;
 #pragma unroll
         for (int s = 0; s < AD_SPLIT; ++s) {
             const float ms = ml[s * 32 + h];
             const float f = (s < act && ms != -INFINITY) ? __expf(ms - M) : 0.f;
-            num += f * ov[j][s];
+            num[0] += f * __uint_as_float(ov[s][0]); num[1] += f * __uint_as_float(ov[s][1]);
+            num[2] += f * __uint_as_float(ov[s][2]); num[3] += f * __uint_as_float(ov[s][3]);
             den += f * (s < act ? ml[s * 32 + 16 + h] : 0.f);
         }
-        p.out_xp[xp_index(b >> 5, p.out_KS, b & 31, idx)] = f2bf(num / den);
+        const float inv = 1.0f / den;
+        uint2 o;
+        o.x = pack2bf(num[0] * inv, num[1] * inv);
+        o.y = pack2bf(num[2] * inv, num[3] * inv);
+        *reinterpret_cast<uint2*>(p.out_xp + xp_index(b >> 5, p.out_KS, b & 31, idx)) = o;
     }
     if (tid == 0) __hip_atomic_store(p.counters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
 }

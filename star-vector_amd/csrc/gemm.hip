@@ -224,9 +224,9 @@ void launch_gemm(const GemmArgs& a, hipStream_t st) {
 //     per-32-column partial sums (sum, sum of squares) that the PRODUCER of h left in `ln_stats`,
 //     combined here in tile order (deterministic).
 //   * K split across the 8 waves of a block (LDS reduce) and, for narrow outputs, across `splitk`
-//     blocks: each block writes an fp32 slab, draws an arrival ticket, and the LAST block of a tile sums
-//     the slabs in slab order and runs the epilogue (agent-scope release / acquire hand-off; no separate
-//     reduce kernel, bitwise deterministic).
+//     blocks: each block writes an fp32 slab (write-through), draws an arrival ticket, and the LAST block
+//     of a tile sums the slabs in slab order and runs the epilogue (no separate reduce kernel, no fences,
+//     bitwise deterministic).
 //   * epilogues: bias+activation -> fragment-order bf16 (c_fc); bias -> row-major bf16 (c_attn: q|k|v);
 //     bias + residual -> new residual stream in fragment order + its LayerNorm partial statistics
 //     (both c_proj); fp32 logits rounded to bf16 values (lm_head); raw fp32 slabs (test surface).
@@ -376,28 +376,34 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
 
     if (p.splitk > 1) {
         // ---- cross-block K reduction: slab -> ticket -> the last block of this tile sums all slabs ----
+        // Hand-off without fences: the slab is stored WRITE-THROUGH (sc1, 16 B per lane), every storing
+        // lane drains (vmcnt 0), one lane draws a relaxed agent-scope ticket; the last arriver reads all
+        // slabs with sc1 loads (L1 bypass).  Placement independent; slabs are summed in slab order.
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            p.ws, 0, (unsigned)((size_t)p.splitk * p.MT * 32 * p.ldws * sizeof(float)), 0x00020000);
+        const int row_off = ((mt * 32 + m) * p.ldws + nt * 32 + half * 4) * 4;     // bytes inside one slab
+        const int slab_bytes = p.MT * 32 * p.ldws * 4;
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-            float* dst = p.ws + ((size_t)split * p.MT * 32 + mt * 32 + m) * p.ldws + nt * 32 + rg * 8 + half * 4;
-            *reinterpret_cast<float4*>(dst) = make_float4(acc[rg * 4], acc[rg * 4 + 1], acc[rg * 4 + 2], acc[rg * 4 + 3]);
+            u32x4 v;
+            v[0] = __float_as_uint(acc[rg * 4]); v[1] = __float_as_uint(acc[rg * 4 + 1]);
+            v[2] = __float_as_uint(acc[rg * 4 + 2]); v[3] = __float_as_uint(acc[rg * 4 + 3]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, split * slab_bytes + row_off + rg * 32, 0, 16);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned* cnt = p.counters + (size_t)mt * gridDim.x + nt;
         unsigned t = 0;
         if (lane == 0) t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         t = __builtin_amdgcn_readfirstlane(t);
         if (t != (unsigned)(p.splitk - 1)) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         for (int sp = 0; sp < p.splitk; ++sp) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
-                const float* src = p.ws + ((size_t)sp * p.MT * 32 + mt * 32 + m) * p.ldws + nt * 32 + rg * 8 + half * 4;
-                const float4 v = *reinterpret_cast<const float4*>(src);
-                acc[rg * 4] += v.x; acc[rg * 4 + 1] += v.y; acc[rg * 4 + 2] += v.z; acc[rg * 4 + 3] += v.w;
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, sp * slab_bytes + row_off + rg * 32, 0, 16);
+                acc[rg * 4] += __uint_as_float(v[0]); acc[rg * 4 + 1] += __uint_as_float(v[1]);
+                acc[rg * 4 + 2] += __uint_as_float(v[2]); acc[rg * 4 + 3] += __uint_as_float(v[3]);
             }
         }
         if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
