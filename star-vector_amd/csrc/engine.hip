@@ -282,6 +282,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     if (r != hipSuccess) return fail(SV_EHIP, "hipSetDevice(%d): %s", c.device, hipGetErrorString(r));
 
     if (int ar = init_attention_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
+    if (int ar = init_gemm_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
 
     sv_engine* e = new sv_engine();
     e->cfg = c;
@@ -341,10 +342,8 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         reg_linear(e, p + "attn.c_proj.", &L.c_proj, D, D, 64, true);
         reg_linear(e, p + "mlp.c_fc.", &L.c_fc, F, D, 64, true);
         reg_linear(e, p + "mlp.c_proj.", &L.c_proj2, D, F, 64, true);
-        L.c_attn.splitk = pick_splitk(L.c_attn.Npad / 32, D / 16);
-        L.c_proj.splitk = pick_splitk(L.c_proj.Npad / 32, D / 16);
-        L.c_fc.splitk = 1;
-        L.c_proj2.splitk = pick_splitk(L.c_proj2.Npad / 32, F / 16);
+        // decode path: K is split across the 16 waves of a block, never across blocks (no hand-off)
+        L.c_attn.splitk = L.c_proj.splitk = L.c_fc.splitk = L.c_proj2.splitk = 1;
     }
     reg_ln(e, pd + "ln_f.", &e->ln_f, D);
 

@@ -239,10 +239,32 @@ __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
     return r;
 }
 
+// one chunk of the weight / activation stream held in registers
+template <int CH>
+struct SkChunk {
+    u32x4 w[CH];
+    u32x4 x[CH];
+};
+
+template <int CH>
+__device__ __forceinline__ void sk_load(SkChunk<CH>& c, const u32x4* wptr, const u32x4* xptr, int ks, int ks_end) {
+#pragma unroll
+    for (int u = 0; u < CH; ++u) {
+        if (ks + u < ks_end) {                                                  // wave-uniform
+            c.w[u] = __builtin_nontemporal_load(wptr + (size_t)(ks + u) * 64);  // streamed once
+            c.x[u] = xptr[(size_t)(ks + u) * 64];
+        }
+    }
+}
+
 template <int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
-    __shared__ float red[WAVES][16][64];
-    __shared__ float lnp[32][2];
+    constexpr int CH = WAVES >= 16 ? 4 : 8;          // k-steps per register chunk (two chunks in flight)
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(sk_smem);          // [WAVES][16][64]
+    float* lnp = reinterpret_cast<float*>(sk_smem + (size_t)WAVES * 16 * 64 * 4);  // [32][2]
+    float* lpart = lnp + 64;                                                        // [2*WAVES][32][2]
+    bf16_t* gb_s = reinterpret_cast<bf16_t*>(lpart + 2 * WAVES * 64);               // gamma[K] | beta[K]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -263,9 +285,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    if (p.ln_stats) {
-        // ---- LayerNorm prologue: row statistics from the producer's per-tile partial sums ----------
-        float* part = &red[0][0][0];                      // [parts][32][2] scratch (before the k-loop)
+    // start the weight stream before anything else: neither W nor h depends on the LayerNorm statistics
+    SkChunk<CH> ca, cb;
+    sk_load<CH>(ca, wptr, xptr, 0, ks_per_wave);
+    if (CH < ks_per_wave) sk_load<CH>(cb, wptr, xptr, CH, ks_per_wave);
+
+    float ra = 1.f, rb = 0.f;
+    const bool ln = p.ln_stats != nullptr;
+    if (ln) {
+        // ---- LayerNorm prologue: gamma/beta -> LDS; row statistics from the producer's per-tile partials
+        for (int c = tid; c < (p.K >> 3); c += WAVES * 64) {
+            *reinterpret_cast<uint4*>(gb_s + c * 8) = *reinterpret_cast<const uint4*>(p.ln_g + c * 8);
+            *reinterpret_cast<uint4*>(gb_s + p.K + c * 8) = *reinterpret_cast<const uint4*>(p.ln_b + c * 8);
+        }
         constexpr int PARTS = WAVES * 2;
         const int prt = tid >> 5;
         float s1 = 0.f, s2 = 0.f;
@@ -273,80 +305,51 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
             const float2 v = p.ln_stats[((size_t)mt * p.ln_tiles + t) * 32 + m];
             s1 += v.x; s2 += v.y;
         }
-        part[(prt * 32 + m) * 2 + 0] = s1;
-        part[(prt * 32 + m) * 2 + 1] = s2;
+        lpart[(prt * 32 + m) * 2 + 0] = s1;
+        lpart[(prt * 32 + m) * 2 + 1] = s2;
         __syncthreads();
         if (tid < 32) {
             float a = 0.f, b = 0.f;
-            for (int q = 0; q < PARTS; ++q) { a += part[(q * 32 + tid) * 2]; b += part[(q * 32 + tid) * 2 + 1]; }
+            for (int q = 0; q < PARTS; ++q) { a += lpart[(q * 32 + tid) * 2]; b += lpart[(q * 32 + tid) * 2 + 1]; }
             const float invD = 1.0f / (float)(p.ln_tiles * 32);
             const float mean = a * invD;
             float var = b * invD - mean * mean;
             var = var > 0.f ? var : 0.f;
             const float rstd = rsqrtf(var + p.ln_eps);
-            lnp[tid][0] = rstd;
-            lnp[tid][1] = -mean * rstd;
+            lnp[tid * 2] = rstd;
+            lnp[tid * 2 + 1] = -mean * rstd;
         }
         __syncthreads();
-        const float ra = lnp[m][0], rb = lnp[m][1];
-        __syncthreads();                                   // `red` is reused by the wave reduction below
-        const u32x4* gptr = reinterpret_cast<const u32x4*>(p.ln_g) + (size_t)ks0 * 2 + half;
-        const u32x4* bptr = reinterpret_cast<const u32x4*>(p.ln_b) + (size_t)ks0 * 2 + half;
-        int ks = 0;
-        for (; ks + 4 <= ks_per_wave; ks += 4) {
-            u32x4 wv[4], hv[4], gv[4], bv[4];
+        ra = lnp[m * 2]; rb = lnp[m * 2 + 1];
+    }
+
+    auto compute = [&](SkChunk<CH>& c, int ks) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                wv[u] = __builtin_nontemporal_load(wptr + (size_t)(ks + u) * 64);
-                hv[u] = xptr[(size_t)(ks + u) * 64];
-                gv[u] = gptr[(size_t)(ks + u) * 2];
-                bv[u] = bptr[(size_t)(ks + u) * 2];
-            }
+        for (int u = 0; u < CH; ++u) {
+            if (ks + u < ks_per_wave) {
+                u32x4 xv = c.x[u];
+                if (ln) {
+                    const int k0 = (ks0 + ks + u) * 16 + half * 8;
+                    const u32x4 gv = *reinterpret_cast<const u32x4*>(gb_s + k0);
+                    const u32x4 bv = *reinterpret_cast<const u32x4*>(gb_s + p.K + k0);
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                u32x4 xv;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const float h0 = __uint_as_float(hv[u][w] << 16), h1 = __uint_as_float(hv[u][w] & 0xffff0000u);
-                    const float g0 = __uint_as_float(gv[u][w] << 16), g1 = __uint_as_float(gv[u][w] & 0xffff0000u);
-                    const float b0 = __uint_as_float(bv[u][w] << 16), b1 = __uint_as_float(bv[u][w] & 0xffff0000u);
-                    xv[w] = cvt_pk_bf16(fmaf(fmaf(h0, ra, rb), g0, b0), fmaf(fmaf(h1, ra, rb), g1, b1));
+                    for (int w = 0; w < 4; ++w) {
+                        const float h0 = __uint_as_float(xv[w] << 16), h1 = __uint_as_float(xv[w] & 0xffff0000u);
+                        const float g0 = __uint_as_float(gv[w] << 16), g1 = __uint_as_float(gv[w] & 0xffff0000u);
+                        const float b0 = __uint_as_float(bv[w] << 16), b1 = __uint_as_float(bv[w] & 0xffff0000u);
+                        xv[w] = cvt_pk_bf16(fmaf(fmaf(h0, ra, rb), g0, b0), fmaf(fmaf(h1, ra, rb), g1, b1));
+                    }
                 }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wv[u]), as_frag4(xv), acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(c.w[u]), as_frag4(xv), acc, 0, 0, 0);
             }
         }
-        for (; ks < ks_per_wave; ++ks) {
-            const u32x4 wv = __builtin_nontemporal_load(wptr + (size_t)ks * 64);
-            const u32x4 hv = xptr[(size_t)ks * 64];
-            const u32x4 gv = gptr[(size_t)ks * 2], bv = bptr[(size_t)ks * 2];
-            u32x4 xv;
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const float h0 = __uint_as_float(hv[w] << 16), h1 = __uint_as_float(hv[w] & 0xffff0000u);
-                const float g0 = __uint_as_float(gv[w] << 16), g1 = __uint_as_float(gv[w] & 0xffff0000u);
-                const float b0 = __uint_as_float(bv[w] << 16), b1 = __uint_as_float(bv[w] & 0xffff0000u);
-                xv[w] = cvt_pk_bf16(fmaf(fmaf(h0, ra, rb), g0, b0), fmaf(fmaf(h1, ra, rb), g1, b1));
-            }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wv), as_frag4(xv), acc, 0, 0, 0);
-        }
-    } else {
-        int ks = 0;
-        for (; ks + 8 <= ks_per_wave; ks += 8) {
-            u32x4 wv[8], xv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                wv[u] = __builtin_nontemporal_load(wptr + (size_t)(ks + u) * 64);   // streamed once
-                xv[u] = xptr[(size_t)(ks + u) * 64];
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wv[u]), as_frag4(xv[u]), acc, 0, 0, 0);
-        }
-        for (; ks < ks_per_wave; ++ks) {
-            const u32x4 wv = __builtin_nontemporal_load(wptr + (size_t)ks * 64);
-            const u32x4 xv = xptr[(size_t)ks * 64];
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wv), as_frag4(xv), acc, 0, 0, 0);
-        }
+    };
+
+    for (int ks = 0; ks < ks_per_wave; ks += 2 * CH) {
+        compute(ca, ks);
+        if (ks + 2 * CH < ks_per_wave) sk_load<CH>(ca, wptr, xptr, ks + 2 * CH, ks_per_wave);
+        if (ks + CH < ks_per_wave) compute(cb, ks + CH);
+        if (ks + 3 * CH < ks_per_wave) sk_load<CH>(cb, wptr, xptr, ks + 3 * CH, ks_per_wave);
     }
 
     // ---- K reduction across the waves of the block (wave order) ---------------------------------
@@ -470,18 +473,37 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     }
 }
 
+static size_t skinny_smem(int waves, int K, bool ln) {
+    return (size_t)waves * 16 * 64 * 4 + 64 * 4 + (size_t)2 * waves * 64 * 4 + (ln ? (size_t)K * 4 : 0) + 16;
+}
+
+int init_gemm_kernels() {
+    // 16-wave blocks reduce through 64 KiB of LDS (+ gamma/beta): above the default dynamic-LDS limit
+    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<16>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (r != hipSuccess) return (int)r;
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    return (int)r;
+}
+
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st) {
     dim3 grid(a.Npad / 32, a.splitk, a.MT);
     const int KS = a.K / 16;
     const int per_split = KS / a.splitk;
-    if (per_split % 8 == 0)
-        gemm_skinny_kernel<8><<<grid, 512, 0, st>>>(a);
+    const bool ln = a.ln_stats != nullptr;
+    // narrow outputs (few column tiles) get 16 waves per block so that no cross-block split-K is needed
+    const bool narrow = (a.Npad / 32) * a.splitk * a.MT < 160;
+    if (per_split % 16 == 0 && narrow)
+        gemm_skinny_kernel<16><<<grid, 1024, skinny_smem(16, a.K, ln), st>>>(a);
+    else if (per_split % 8 == 0)
+        gemm_skinny_kernel<8><<<grid, 512, skinny_smem(8, a.K, ln), st>>>(a);
     else if (per_split % 4 == 0)
-        gemm_skinny_kernel<4><<<grid, 256, 0, st>>>(a);
+        gemm_skinny_kernel<4><<<grid, 256, skinny_smem(4, a.K, ln), st>>>(a);
     else if (per_split % 2 == 0)
-        gemm_skinny_kernel<2><<<grid, 128, 0, st>>>(a);
+        gemm_skinny_kernel<2><<<grid, 128, skinny_smem(2, a.K, ln), st>>>(a);
     else
-        gemm_skinny_kernel<1><<<grid, 64, 0, st>>>(a);
+        gemm_skinny_kernel<1><<<grid, 64, skinny_smem(1, a.K, ln), st>>>(a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -52,6 +52,7 @@ struct SkinnyArgs {
     int round_bf16;
 };
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st);
+int init_gemm_kernels();        // hipFuncSetAttribute for the large-LDS variants (0 = ok)
 
 struct EmbedRowsArgs {
     const bf16_t* rows; int ld_rows;                       // generic: row-major input rows; or nullptr:
