@@ -148,6 +148,11 @@ int  sv_op_linear_skinny(const void* x, const void* W, const void* bias, void* y
 int  sv_op_decode_linear(const void* h, const void* gamma, const void* beta, float eps, const void* W,
                          const void* bias, const void* residual, void* y, float* row_stats, int32_t M, int32_t N,
                          int32_t K, int32_t splitk, int32_t act, sv_stream stream);
+/* micro-benchmark of the decode GEMM kernel alone: average microseconds per launch over `iters`
+ * back-to-back launches (HIP events); ln = LayerNorm prologue on/off; mode = epilogue (0 fp32 slabs,
+ * 1 bias+GELU fragment order, 3 bias+residual+statistics, 4 bias row-major) */
+int  sv_bench_decode_linear(int32_t M, int32_t N, int32_t K, int32_t splitk, int32_t ln, int32_t mode,
+                            int32_t iters, double* avg_us, sv_stream stream);
 /* f32 -> bf16 through the hardware convert used inside the kernels (rounding-mode check) */
 int  sv_op_cvt_bf16_hw(const float* x, void* y, int64_t n, sv_stream stream);
 /* q,k,v token-major [B,S,H*D] / [B,S,Hkv*D]; out [B,S,H*D] */

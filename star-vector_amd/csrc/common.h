@@ -61,9 +61,10 @@ __device__ __forceinline__ float sv_act(float x, int act) {
         case ACT_QUICKGELU: return x / (1.0f + __expf(-1.702f * x));         // clip_model.py:126-128
         case ACT_SWISH:     return x / (1.0f + __expf(-x));                   // adapter.py:5-10
         case ACT_GELU_TANH: {                                                 // gelu_pytorch_tanh
+            // 0.5 x (1 + tanh(u)) = x / (1 + exp(-2u)),  u = sqrt(2/pi) (x + 0.044715 x^3)
             const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-            float t = tanhf(k0 * (x + k1 * x * x * x));
-            return 0.5f * x * (1.0f + t);
+            const float u = k0 * (x + k1 * x * x * x);
+            return x / (1.0f + __expf(-2.0f * u));
         }
         default: return x;
     }

@@ -344,6 +344,9 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         reg_linear(e, p + "mlp.c_proj.", &L.c_proj2, D, F, 64, true);
         // decode path: K is split across the 16 waves of a block, never across blocks (no hand-off)
         L.c_attn.splitk = L.c_proj.splitk = L.c_fc.splitk = L.c_proj2.splitk = 1;
+        // ... except the long-K down projection: one CU streams only ~25 GB/s, so 64 column tiles cannot
+        // carry 33 MB; its K is split 4-way across blocks and merged by the last arriver (ticket)
+        if (L.c_proj2.Npad / 32 < 128 && (F / 16) % 32 == 0 && F >= 4096) L.c_proj2.splitk = 4;
     }
     reg_ln(e, pd + "ln_f.", &e->ln_f, D);
 
@@ -628,8 +631,11 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
         prof_mark(e, PK_SKINNY, st);
         decode_gemm(e, e->xp_mlp, L.c_proj2, nullptr, MT, SK_OUT_RESID, ACT_NONE, st);
     }
+    // ln_f is applied ONCE (all 1537 lm_head blocks would otherwise repeat the prologue)
+    prof_mark(e, PK_ROWLN, st);
+    launch_ln_apply_packed(e->h_xp, e->ln_stats, e->ln_f.g, e->ln_f.b, e->xp_a, B, D, c.ln_eps, st);
     prof_mark(e, PK_SKINNY, st);
-    lm_head_logits(e, MT, e->h_xp, &e->ln_f, st);
+    lm_head_logits(e, MT, e->xp_a, nullptr, st);
     prof_mark(e, PK_SAMPLE, st);      // closes the lm_head interval; whatever follows is sampling
 }
 
@@ -1010,6 +1016,57 @@ extern "C" int sv_op_decode_linear(const void* h, const void* gamma, const void*
     }
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// Micro-benchmark of the decode GEMM kernel alone (HIP events, `iters` back-to-back launches on one
+// stream): mode 0 = fp32 slabs (no epilogue), 1 = bias+act -> fragment order, 3 = bias+residual+stats,
+// 4 = bias -> row-major.  Weights / activations are zero-filled device buffers (bandwidth only).
+extern "C" int sv_bench_decode_linear(int32_t M, int32_t N, int32_t K, int32_t splitk, int32_t ln, int32_t mode,
+                                      int32_t iters, double* avg_us, sv_stream stream) {
+    if (!avg_us || M < 1 || N < 32 || K < 32 || K % 32 || splitk < 1 || (K / 16) % splitk || iters < 1)
+        return fail(SV_EINVAL, "sv_bench_decode_linear: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    TmpBufs tmp;
+    const int Npad = round_up(N, 32), MT = (M + 31) / 32, R = MT * 32;
+    bf16_t *Wp, *hxp, *oxp, *orm, *gb, *bias;
+    float* ws; float2 *st_in, *st_out; unsigned* cnt;
+    SVCHECK(tmp.get(&Wp, (size_t)Npad * K));
+    SVCHECK(tmp.get(&hxp, (size_t)R * K));
+    SVCHECK(tmp.get(&oxp, (size_t)R * Npad));
+    SVCHECK(tmp.get(&orm, (size_t)R * Npad));
+    SVCHECK(tmp.get(&gb, (size_t)2 * K));
+    SVCHECK(tmp.get(&bias, (size_t)Npad));
+    SVCHECK(tmp.get(&ws, (size_t)splitk * R * Npad));
+    SVCHECK(tmp.get(&st_in, (size_t)R * (K / 32)));
+    SVCHECK(tmp.get(&st_out, (size_t)R * (Npad / 32)));
+    SVCHECK(tmp.get(&cnt, (size_t)MT * (Npad / 32)));
+    HIPCHECK(hipMemsetAsync(Wp, 0, (size_t)Npad * K * 2, st));
+    HIPCHECK(hipMemsetAsync(hxp, 0, (size_t)R * K * 2, st));
+    HIPCHECK(hipMemsetAsync(oxp, 0, (size_t)R * Npad * 2, st));
+    HIPCHECK(hipMemsetAsync(gb, 0, (size_t)2 * K * 2, st));
+    HIPCHECK(hipMemsetAsync(bias, 0, (size_t)Npad * 2, st));
+    HIPCHECK(hipMemsetAsync(cnt, 0, (size_t)MT * (Npad / 32) * sizeof(unsigned), st));
+    HIPCHECK(hipMemsetAsync(st_in, 0, (size_t)R * (K / 32) * sizeof(float2), st));
+    SkinnyArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xp = hxp; a.Wp = Wp; a.bias = bias; a.MT = MT; a.Npad = Npad; a.K = K; a.splitk = splitk;
+    a.act = mode == 1 ? ACT_GELU_TANH : ACT_NONE; a.N = N; a.ws = ws; a.ldws = Npad; a.counters = cnt; a.out_mode = mode;
+    if (ln) { a.ln_stats = st_in; a.ln_tiles = K / 32; a.ln_g = gb; a.ln_b = gb + K; a.ln_eps = 1e-5f; }
+    a.out_xp = oxp; a.resid_xp = oxp; a.out_KS = Npad / 16; a.stats_out = st_out; a.out_rm = orm; a.ld_rm = Npad;
+    a.out_f32 = ws; a.ldo = Npad;
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) launch_gemm_skinny(a, st);
+    HIPCHECK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) launch_gemm_skinny(a, st);
+    HIPCHECK(hipEventRecord(e1, st));
+    HIPCHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = (double)ms * 1e3 / iters;
+    HIPCHECK(hipGetLastError());
     return 0;
 }
 

@@ -257,9 +257,9 @@ __device__ __forceinline__ void sk_load(SkChunk<CH>& c, const u32x4* wptr, const
     }
 }
 
-template <int WAVES>
+template <int WAVES, bool LN>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
-    constexpr int CH = WAVES >= 16 ? 4 : 8;          // k-steps per register chunk (two chunks in flight)
+    constexpr int CH = 4;                            // k-steps per register chunk (two chunks = 8 KiB of W in flight per wave)
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(sk_smem);          // [WAVES][16][64]
     float* lnp = reinterpret_cast<float*>(sk_smem + (size_t)WAVES * 16 * 64 * 4);  // [32][2]
@@ -285,42 +285,66 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    // start the weight stream before anything else: neither W nor h depends on the LayerNorm statistics
+    // ---- everything the kernel will need from memory is requested up front, smallest first: LayerNorm
+    // partials + gamma/beta (LDS), the epilogue's bias / residual (wave 0), then the weight stream ----
+    constexpr int PARTS = WAVES * 2;
+    float s1p = 0.f, s2p = 0.f;
+    uint4 gq[2], bq[2];
+    if (LN) {
+        const int prt = tid >> 5;
+        for (int t = prt; t < p.ln_tiles; t += PARTS) {
+            const float2 v = p.ln_stats[((size_t)mt * p.ln_tiles + t) * 32 + m];
+            s1p += v.x; s2p += v.y;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                     // K <= 2 * 8 * WAVES*64 elements
+            const int c = tid + i * WAVES * 64;
+            if (c < (p.K >> 3)) {
+                gq[i] = *reinterpret_cast<const uint4*>(p.ln_g + c * 8);
+                bq[i] = *reinterpret_cast<const uint4*>(p.ln_b + c * 8);
+            }
+        }
+    }
+    uint2 bias_q[4], res_q[4];
+    const bool epi_wave = wave == 0 && p.out_mode != SK_OUT_PARTIAL && p.out_mode != SK_OUT_F32;
+    if (epi_wave) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int n = nt * 32 + rg * 8 + half * 4;
+            bias_q[rg] = make_uint2(0u, 0u);
+            if (p.bias && n < p.N) bias_q[rg] = *reinterpret_cast<const uint2*>(p.bias + n);
+            if (p.out_mode == SK_OUT_RESID)
+                res_q[rg] = *reinterpret_cast<const uint2*>(p.resid_xp + xp_index(mt, p.out_KS, m, n));
+        }
+    }
     SkChunk<CH> ca, cb;
     sk_load<CH>(ca, wptr, xptr, 0, ks_per_wave);
     if (CH < ks_per_wave) sk_load<CH>(cb, wptr, xptr, CH, ks_per_wave);
 
     float ra = 1.f, rb = 0.f;
-    const bool ln = p.ln_stats != nullptr;
-    if (ln) {
+    if (LN) {
         // ---- LayerNorm prologue: gamma/beta -> LDS; row statistics from the producer's per-tile partials
-        for (int c = tid; c < (p.K >> 3); c += WAVES * 64) {
-            *reinterpret_cast<uint4*>(gb_s + c * 8) = *reinterpret_cast<const uint4*>(p.ln_g + c * 8);
-            *reinterpret_cast<uint4*>(gb_s + p.K + c * 8) = *reinterpret_cast<const uint4*>(p.ln_b + c * 8);
-        }
-        constexpr int PARTS = WAVES * 2;
         const int prt = tid >> 5;
-        float s1 = 0.f, s2 = 0.f;
-        for (int t = prt; t < p.ln_tiles; t += PARTS) {
-            const float2 v = p.ln_stats[((size_t)mt * p.ln_tiles + t) * 32 + m];
-            s1 += v.x; s2 += v.y;
-        }
-        lpart[(prt * 32 + m) * 2 + 0] = s1;
-        lpart[(prt * 32 + m) * 2 + 1] = s2;
-        __syncthreads();
-        if (tid < 32) {
-            float a = 0.f, b = 0.f;
-            for (int q = 0; q < PARTS; ++q) { a += lpart[(q * 32 + tid) * 2]; b += lpart[(q * 32 + tid) * 2 + 1]; }
-            const float invD = 1.0f / (float)(p.ln_tiles * 32);
-            const float mean = a * invD;
-            float var = b * invD - mean * mean;
-            var = var > 0.f ? var : 0.f;
-            const float rstd = rsqrtf(var + p.ln_eps);
-            lnp[tid * 2] = rstd;
-            lnp[tid * 2 + 1] = -mean * rstd;
+        lpart[(prt * 32 + m) * 2 + 0] = s1p;
+        lpart[(prt * 32 + m) * 2 + 1] = s2p;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + i * WAVES * 64;
+            if (c < (p.K >> 3)) {
+                *reinterpret_cast<uint4*>(gb_s + c * 8) = gq[i];
+                *reinterpret_cast<uint4*>(gb_s + p.K + c * 8) = bq[i];
+            }
         }
         __syncthreads();
-        ra = lnp[m * 2]; rb = lnp[m * 2 + 1];
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int q = 0; q < PARTS; ++q) { a += lpart[(q * 32 + m) * 2]; b += lpart[(q * 32 + m) * 2 + 1]; }
+        const float invD = 1.0f / (float)(p.ln_tiles * 32);
+        const float mean = a * invD;
+        float var = b * invD - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        ra = rsqrtf(var + p.ln_eps);
+        rb = -mean * ra;
     }
 
     auto compute = [&](SkChunk<CH>& c, int ks) {
@@ -328,7 +352,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
         for (int u = 0; u < CH; ++u) {
             if (ks + u < ks_per_wave) {
                 u32x4 xv = c.x[u];
-                if (ln) {
+                if (LN) {
                     const int k0 = (ks0 + ks + u) * 16 + half * 8;
                     const u32x4 gv = *reinterpret_cast<const u32x4*>(gb_s + k0);
                     const u32x4 bv = *reinterpret_cast<const u32x4*>(gb_s + p.K + k0);
@@ -426,12 +450,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
             *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
             continue;
         }
+        const float bj[4] = {__uint_as_float(bias_q[rg].x << 16), __uint_as_float(bias_q[rg].x & 0xffff0000u),
+                             __uint_as_float(bias_q[rg].y << 16), __uint_as_float(bias_q[rg].y & 0xffff0000u)};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float x = v[j];
             if (n + j < p.N) {
-                if (p.bias) x += bf2f(p.bias[n + j]);
-                x = bfround(x);
+                x = bfround(x + bj[j]);
                 if (p.act != ACT_NONE) x = sv_act(x, p.act);
             } else {
                 x = 0.f;
@@ -440,7 +465,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
         }
         if (p.out_mode == SK_OUT_RESID) {
             const size_t off = xp_index(mt, p.out_KS, m, n);
-            const uint2 rr = *reinterpret_cast<const uint2*>(p.resid_xp + off);
+            const uint2 rr = res_q[rg];
             v[0] = bfround(v[0] + __uint_as_float(rr.x << 16));
             v[1] = bfround(v[1] + __uint_as_float(rr.x & 0xffff0000u));
             v[2] = bfround(v[2] + __uint_as_float(rr.y << 16));
@@ -477,33 +502,38 @@ static size_t skinny_smem(int waves, int K, bool ln) {
     return (size_t)waves * 16 * 64 * 4 + 64 * 4 + (size_t)2 * waves * 64 * 4 + (ln ? (size_t)K * 4 : 0) + 16;
 }
 
+template <int W, bool LN>
+static int set_attr(int bytes) {
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<W, LN>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
 int init_gemm_kernels() {
     // 16-wave blocks reduce through 64 KiB of LDS (+ gamma/beta): above the default dynamic-LDS limit
-    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<16>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (r != hipSuccess) return (int)r;
-    r = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<8>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    return (int)r;
+    int r = set_attr<16, true>(160 * 1024);
+    if (!r) r = set_attr<16, false>(160 * 1024);
+    if (!r) r = set_attr<8, true>(128 * 1024);
+    if (!r) r = set_attr<8, false>(128 * 1024);
+    return r;
+}
+
+template <int W>
+static void launch_sk(const SkinnyArgs& a, dim3 grid, hipStream_t st) {
+    const bool ln = a.ln_stats != nullptr;
+    if (ln) gemm_skinny_kernel<W, true><<<grid, W * 64, skinny_smem(W, a.K, true), st>>>(a);
+    else gemm_skinny_kernel<W, false><<<grid, W * 64, skinny_smem(W, a.K, false), st>>>(a);
 }
 
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st) {
     dim3 grid(a.Npad / 32, a.splitk, a.MT);
     const int KS = a.K / 16;
     const int per_split = KS / a.splitk;
-    const bool ln = a.ln_stats != nullptr;
     // narrow outputs (few column tiles) get 16 waves per block so that no cross-block split-K is needed
     const bool narrow = (a.Npad / 32) * a.splitk * a.MT < 160;
-    if (per_split % 16 == 0 && narrow)
-        gemm_skinny_kernel<16><<<grid, 1024, skinny_smem(16, a.K, ln), st>>>(a);
-    else if (per_split % 8 == 0)
-        gemm_skinny_kernel<8><<<grid, 512, skinny_smem(8, a.K, ln), st>>>(a);
-    else if (per_split % 4 == 0)
-        gemm_skinny_kernel<4><<<grid, 256, skinny_smem(4, a.K, ln), st>>>(a);
-    else if (per_split % 2 == 0)
-        gemm_skinny_kernel<2><<<grid, 128, skinny_smem(2, a.K, ln), st>>>(a);
-    else
-        gemm_skinny_kernel<1><<<grid, 64, skinny_smem(1, a.K, ln), st>>>(a);
+    if (per_split % 16 == 0 && narrow) launch_sk<16>(a, grid, st);
+    else if (per_split % 8 == 0) launch_sk<8>(a, grid, st);
+    else if (per_split % 4 == 0) launch_sk<4>(a, grid, st);
+    else if (per_split % 2 == 0) launch_sk<2>(a, grid, st);
+    else launch_sk<1>(a, grid, st);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -71,6 +71,9 @@ void launch_layernorm_rows(const bf16_t* x, int ldx, const bf16_t* g, const bf16
 void launch_layernorm_rows_packed(const bf16_t* x, int ldx, const bf16_t* g, const bf16_t* b, bf16_t* yp,
                                   int M, int D, float eps, hipStream_t st);
 
+void launch_ln_apply_packed(const bf16_t* hxp, const float2* stats, const bf16_t* g, const bf16_t* b, bf16_t* yxp,
+                            int M, int D, float eps, hipStream_t st);
+
 // ---- embeddings ---------------------------------------------------------------------------------
 void launch_im2col(const bf16_t* img, bf16_t* out, int B, int img_size, int patch, int Kpad, hipStream_t st);
 void launch_vit_embed_lnpre(const bf16_t* patch_out, int ldp, const bf16_t* cls, const bf16_t* pos,
