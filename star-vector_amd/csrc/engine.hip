@@ -108,7 +108,8 @@ struct Linear {
     bf16_t* Wp = nullptr;
     bf16_t* bias = nullptr;
     int N = 0, K = 0, Npad = 0, Kpad = 0;
-    int splitk = 1;       // decode-path split-K factor
+    int splitk = 1;       // decode-path split-K factor (slab pipeline)
+    int splitk_fused = 1; // decode-path split-K factor (fused pipeline: ticket merge)
 };
 struct LNp { bf16_t* g = nullptr; bf16_t* b = nullptr; };
 struct VitLayer { LNp ln1, ln2; Linear in_proj, out_proj, c_fc, c_proj; };
@@ -153,7 +154,7 @@ struct sv_engine {
     bf16_t *ph = nullptr, *pln = nullptr, *pqkv = nullptr, *pattn = nullptr, *pmlp = nullptr;
     // decode workspaces
     int MT = 0, ldws = 0, Vpad = 0;
-    bf16_t *h_xp = nullptr, *hl = nullptr, *xp_a = nullptr, *xp_attn = nullptr, *xp_mlp = nullptr, *qkv_rm = nullptr;
+    bf16_t *h_dec = nullptr, *h_xp = nullptr, *hl = nullptr, *xp_a = nullptr, *xp_attn = nullptr, *xp_mlp = nullptr, *qkv_rm = nullptr;
     float2* ln_stats = nullptr;
     unsigned* sk_cnt = nullptr;
     int ldq = 0;
@@ -170,6 +171,7 @@ struct sv_engine {
     int32_t* block_table = nullptr;
     std::vector<int> free_pages;
     int cached_B = 0;
+    bool fused_decode = false;   // SV_DECODE_FUSED=1: LN-prologue / ticket pipeline (5 launches per layer)
     double timing[3] = {0, 0, 0};
     double timing_graph = 0;
     // generation runs on an engine-owned non-blocking stream (the caller's stream may be the legacy
@@ -342,11 +344,16 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         reg_linear(e, p + "attn.c_proj.", &L.c_proj, D, D, 64, true);
         reg_linear(e, p + "mlp.c_fc.", &L.c_fc, F, D, 64, true);
         reg_linear(e, p + "mlp.c_proj.", &L.c_proj2, D, F, 64, true);
-        // decode path: K is split across the 16 waves of a block, never across blocks (no hand-off)
-        L.c_attn.splitk = L.c_proj.splitk = L.c_fc.splitk = L.c_proj2.splitk = 1;
-        // ... except the long-K down projection: one CU streams only ~25 GB/s, so 64 column tiles cannot
-        // carry 33 MB; its K is split 4-way across blocks and merged by the last arriver (ticket)
-        if (L.c_proj2.Npad / 32 < 128 && (F / 16) % 32 == 0 && F >= 4096) L.c_proj2.splitk = 4;
+        // slab pipeline (default): narrow outputs split K across blocks into fp32 slabs that the next
+        // kernel (attention / row update) sums in slab order
+        L.c_attn.splitk = pick_splitk(L.c_attn.Npad / 32, D / 16);
+        L.c_proj.splitk = pick_splitk(L.c_proj.Npad / 32, D / 16);
+        L.c_fc.splitk = 1;
+        L.c_proj2.splitk = pick_splitk(L.c_proj2.Npad / 32, F / 16);
+        // fused pipeline: K is split across the 16 waves of a block; only the long-K down projection is
+        // split across blocks (one CU streams ~25 GB/s) and merged by the last arriver (ticket)
+        L.c_attn.splitk_fused = L.c_proj.splitk_fused = L.c_fc.splitk_fused = L.c_proj2.splitk_fused = 1;
+        if (L.c_proj2.Npad / 32 < 128 && (F / 16) % 32 == 0 && F >= 4096) L.c_proj2.splitk_fused = 4;
     }
     reg_ln(e, pd + "ln_f.", &e->ln_f, D);
 
@@ -370,6 +377,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     e->Vpad = e->lm_head.Npad;
     e->ldws = round_up(D + 2 * dh, 32);
     if (e->ldws < D) e->ldws = D;
+    A(dalloc(e, &e->h_dec, R * D));
     A(dalloc(e, &e->h_xp, R * D));
     e->ldq = D + 2 * dh;
     A(dalloc(e, &e->qkv_rm, R * e->ldq));
@@ -411,6 +419,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         if (hr == hipSuccess) hr = hipEventCreateWithFlags(&e->gen_event, hipEventDisableTiming);
         if (hr != hipSuccess) rc = fail(SV_EHIP, "stream/event creation: %s", hipGetErrorString(hr));
     }
+    e->fused_decode = getenv("SV_DECODE_FUSED") != nullptr && atoi(getenv("SV_DECODE_FUSED")) != 0;
     if (rc) { sv_destroy(e); return rc; }
     *out = e;
     return 0;
@@ -476,7 +485,7 @@ static void decode_gemm(sv_engine* e, const bf16_t* xp, const Linear& l, const L
                         hipStream_t st) {
     SkinnyArgs a;
     memset(&a, 0, sizeof(a));
-    a.xp = xp; a.Wp = l.Wp; a.bias = l.bias; a.MT = MT; a.Npad = l.Npad; a.K = l.Kpad; a.splitk = l.splitk;
+    a.xp = xp; a.Wp = l.Wp; a.bias = l.bias; a.MT = MT; a.Npad = l.Npad; a.K = l.Kpad; a.splitk = l.splitk_fused;
     a.out_mode = out_mode; a.act = act; a.N = l.N;
     if (ln) { a.ln_stats = e->ln_stats; a.ln_tiles = l.Kpad / 32; a.ln_g = ln->g; a.ln_b = ln->b; a.ln_eps = e->cfg.ln_eps; }
     a.ws = e->ws; a.ldws = e->ldws; a.counters = e->sk_cnt;
@@ -602,7 +611,7 @@ static int prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hi
 
 // one autoregressive step: consumes cur_tok/positions, leaves logits in e->logits.
 // 1 + 5 per layer + 1 launches: embed | c_attn(LN1) . attention . c_proj(+res) . c_fc(LN2,GELU) . c_proj(+res) | lm_head(ln_f)
-static void decode_forward(sv_engine* e, int B, hipStream_t st) {
+static void decode_forward_fused(sv_engine* e, int B, hipStream_t st) {
     const sv_config& c = e->cfg;
     const int D = c.hidden, dh = e->dh, MT = (B + 31) / 32;
     EmbedRowsArgs er;
@@ -637,6 +646,72 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
     prof_mark(e, PK_SKINNY, st);
     lm_head_logits(e, MT, e->xp_a, nullptr, st);
     prof_mark(e, PK_SAMPLE, st);      // closes the lm_head interval; whatever follows is sampling
+}
+
+// slab pipeline (default; measured faster in situ, profiles/): 7 launches per layer
+//   c_attn -> fp32 slabs | attention (sums the slabs, +bias) | c_proj -> slabs | row update (+bias, +residual, LN2)
+//   | c_fc (bias+GELU epilogue) | c_proj -> slabs | row update (+residual, LN1 of the next layer / ln_f)
+static void skinny_slabs(sv_engine* e, const bf16_t* xp, const Linear& l, int MT, hipStream_t st) {
+    SkinnyArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xp = xp; a.Wp = l.Wp; a.MT = MT; a.Npad = l.Npad; a.K = l.Kpad; a.splitk = l.splitk;
+    a.out_mode = SK_OUT_PARTIAL; a.ws = e->ws; a.ldws = e->ldws; a.N = l.N;
+    launch_gemm_skinny(a, st);
+}
+
+static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
+    const sv_config& c = e->cfg;
+    const int D = c.hidden, dh = e->dh, F = c.n_inner, MT = (B + 31) / 32;
+    RowUpdateArgs ru;
+    memset(&ru, 0, sizeof(ru));
+    ru.h = e->h_dec; ru.ldh = D; ru.M = B; ru.D = D; ru.eps = c.ln_eps; ru.xp_out = e->xp_a;
+    ru.ldws = e->ldws; ru.rows_ws = MT * 32;
+    ru.ws = nullptr; ru.wte = e->wte; ru.wpe = e->wpe; ru.tokens = e->cur_tok; ru.positions = e->positions;
+    ru.g = e->dec[0].ln1.g; ru.b = e->dec[0].ln1.b;
+    prof_mark(e, PK_ROWLN, st);
+    launch_row_update_ln(ru, st);                       // embedding + ln_1 of layer 0
+    for (int i = 0; i < c.n_layer; ++i) {
+        DecLayer& L = e->dec[i];
+        prof_mark(e, PK_SKINNY, st);
+        skinny_slabs(e, e->xp_a, L.c_attn, MT, st);
+        AttnDecodeArgs ad;
+        memset(&ad, 0, sizeof(ad));
+        ad.ws = e->ws; ad.splitk = L.c_attn.splitk; ad.ldws = e->ldws; ad.rows_ws = MT * 32; ad.bias = L.c_attn.bias;
+        ad.pool_layer = e->kv_pool + (size_t)i * e->layer_stride; ad.block_table = e->block_table;
+        ad.max_pages = e->pages_per_seq; ad.positions = e->positions; ad.out_xp = e->xp_attn; ad.out_KS = D / 16;
+        ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
+        ad.part = e->attn_part; ad.counters = e->attn_cnt;
+        prof_mark(e, PK_ATTN, st);
+        launch_attn_decode(ad, st);
+        prof_mark(e, PK_SKINNY, st);
+        skinny_slabs(e, e->xp_attn, L.c_proj, MT, st);
+        ru.ws = e->ws; ru.splitk = L.c_proj.splitk; ru.bias = L.c_proj.bias; ru.g = L.ln2.g; ru.b = L.ln2.b;
+        prof_mark(e, PK_ROWLN, st);
+        launch_row_update_ln(ru, st);
+        prof_mark(e, PK_SKINNY, st);
+        {
+            SkinnyArgs a;
+            memset(&a, 0, sizeof(a));
+            a.xp = e->xp_a; a.Wp = L.c_fc.Wp; a.bias = L.c_fc.bias; a.MT = MT; a.Npad = L.c_fc.Npad; a.K = L.c_fc.Kpad;
+            a.splitk = 1; a.out_mode = SK_OUT_PACKED_ACT; a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16;
+            a.N = L.c_fc.N;
+            launch_gemm_skinny(a, st);
+        }
+        prof_mark(e, PK_SKINNY, st);
+        skinny_slabs(e, e->xp_mlp, L.c_proj2, MT, st);
+        const LNp& nxt = (i + 1 < c.n_layer) ? e->dec[i + 1].ln1 : e->ln_f;
+        ru.splitk = L.c_proj2.splitk; ru.bias = L.c_proj2.bias; ru.g = nxt.g; ru.b = nxt.b;
+        prof_mark(e, PK_ROWLN, st);
+        launch_row_update_ln(ru, st);
+    }
+    prof_mark(e, PK_SKINNY, st);
+    lm_head_logits(e, MT, e->xp_a, nullptr, st);
+    prof_mark(e, PK_SAMPLE, st);      // closes the lm_head interval; whatever follows is sampling
+}
+
+static void decode_forward(sv_engine* e, int B, hipStream_t st) {
+    if (e->fused_decode) decode_forward_fused(e, B, st);
+    else decode_forward_slabs(e, B, st);
 }
 
 static int check_ready(sv_engine* e) {

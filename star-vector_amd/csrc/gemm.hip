@@ -317,6 +317,22 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
                 res_q[rg] = *reinterpret_cast<const uint2*>(p.resid_xp + xp_index(mt, p.out_KS, m, n));
         }
     }
+    // distributed epilogue (no cross-block hand-off, no row statistics): every wave finishes RPW of the 16
+    // accumulator rows, so the tail of the kernel is WAVES times shorter than a wave-0 epilogue
+    constexpr int RPW = WAVES >= 16 ? 1 : 16 / WAVES;
+    const bool dist = WAVES > 1 && WAVES <= 16 &&
+                      (p.out_mode == SK_OUT_PARTIAL ||
+                       (p.splitk == 1 && (p.out_mode == SK_OUT_PACKED_ACT || p.out_mode == SK_OUT_F32)));
+    float bias_d[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        bias_d[i] = 0.f;
+        if (dist && p.out_mode == SK_OUT_PACKED_ACT && p.bias) {
+            const int r = wave * RPW + i;
+            const int n = nt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+            if (n < p.N) bias_d[i] = bf2f(p.bias[n]);
+        }
+    }
     SkChunk<CH> ca, cb;
     sk_load<CH>(ca, wptr, xptr, 0, ks_per_wave);
     if (CH < ks_per_wave) sk_load<CH>(cb, wptr, xptr, CH, ks_per_wave);
@@ -381,6 +397,56 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
         __syncthreads();
+        if (dist) {
+            float v[RPW];
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const int r = wave * RPW + i;
+                float t = red[0][r][lane];
+#pragma unroll
+                for (int w = 1; w < WAVES; ++w) t += red[w][r][lane];
+                v[i] = t;
+            }
+            const int r0 = wave * RPW;
+            const int n0 = nt * 32 + 8 * (r0 >> 2) + 4 * half + (r0 & 3);       // RPW consecutive columns (RPW <= 4)
+            if (p.out_mode == SK_OUT_PARTIAL || p.out_mode == SK_OUT_F32) {
+                float* dst = p.out_mode == SK_OUT_PARTIAL
+                                 ? p.ws + ((size_t)split * p.MT * 32 + mt * 32 + m) * p.ldws + n0
+                                 : p.out_f32 + ((size_t)mt * 32 + m) * p.ldo + n0;
+                if (p.out_mode == SK_OUT_F32 && p.round_bf16) {
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i) v[i] = bfround(v[i]);
+                }
+                if constexpr (RPW == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                else if constexpr (RPW == 2) *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
+                else {
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i) dst[i + (i >> 2) * 4] = v[i];      // RPW 1 (or 8: two groups of 4)
+                }
+            } else {   // SK_OUT_PACKED_ACT
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) {
+                    float x = 0.f;
+                    if (n0 + i + (i >> 2) * 4 < p.N) {
+                        x = bfround(v[i] + bias_d[i]);
+                        if (p.act != ACT_NONE) x = sv_act(x, p.act);
+                    }
+                    v[i] = x;
+                }
+                bf16_t* dst = p.out_xp + xp_index(mt, p.out_KS, m, n0);
+                if constexpr (RPW == 4) {
+                    uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(dst) = o;
+                } else if constexpr (RPW == 2) {
+                    *reinterpret_cast<uint32_t*>(dst) = pack2bf(v[0], v[1]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < RPW; ++i)        // RPW 1, or 8 = two groups of 4 columns 8 apart
+                        p.out_xp[xp_index(mt, p.out_KS, m, n0 + i + (i >> 2) * 4)] = f2bf(v[i]);
+                }
+            }
+            return;
+        }
         if (wave != 0) return;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {

@@ -71,6 +71,19 @@ void launch_layernorm_rows(const bf16_t* x, int ldx, const bf16_t* g, const bf16
 void launch_layernorm_rows_packed(const bf16_t* x, int ldx, const bf16_t* g, const bf16_t* b, bf16_t* yp,
                                   int M, int D, float eps, hipStream_t st);
 
+// decode row update: v = sum_s ws[s][m][:] + bias ; h = bf(h + bf(v)) (in place) ; xp = LN(h)
+struct RowUpdateArgs {
+    const float* ws; int splitk; int ldws; int rows_ws;   // partials [splitk][rows_ws][ldws] (or nullptr)
+    const bf16_t* bias;
+    bf16_t* h; int ldh;                                    // residual stream [M][D] (in/out)
+    const bf16_t* wte; const bf16_t* wpe;                  // embedding mode (ws == nullptr)
+    const int32_t* tokens; const int32_t* positions;       // [M]
+    const bf16_t* g; const bf16_t* b; float eps;           // LayerNorm applied to the updated row
+    bf16_t* xp_out;                                        // packed LN output
+    int M, D;
+};
+void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st);
+
 void launch_ln_apply_packed(const bf16_t* hxp, const float2* stats, const bf16_t* g, const bf16_t* b, bf16_t* yxp,
                             int M, int D, float eps, hipStream_t st);
 

@@ -60,6 +60,81 @@ void launch_layernorm_rows_packed(const bf16_t* x, int ldx, const bf16_t* g, con
 }
 
 // ------------------------------------------------------------------------------------------------
+// decode row update + LayerNorm (one block per row):
+//   embedding mode : h = bf(wte[tok] + wpe[pos])                           (gpt_bigcode :1060-1063)
+//   residual mode  : h = bf(h + bf(sum_s ws[s][row][:] + bias))            (block residual adds)
+//   then           : xp = LN(h)   written in fragment order for the next skinny GEMM
+// the split-K slabs are summed in slab order -> bitwise deterministic.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* hrow = reinterpret_cast<float*>(smem_raw);          // [D]
+    __shared__ float redbuf[8];
+    const int row = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int D = p.D, NC = D >> 3;
+    bf16_t* hr = p.h + (size_t)row * p.ldh;
+
+    float s = 0.f;
+    for (int c = tid; c < NC; c += 256) {
+        float f[8];
+        if (p.ws == nullptr) {
+            const int tok = p.tokens[row], pos = p.positions[row];
+            float a[8], w[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.wte + (size_t)tok * D + c * 8), a);
+            unpack8(*reinterpret_cast<const uint4*>(p.wpe + (size_t)pos * D + c * 8), w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = bfround(a[e] + w[e]);
+        } else {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            for (int sp = 0; sp < p.splitk; ++sp) {
+                const float* src = p.ws + ((size_t)sp * p.rows_ws + row) * p.ldws + c * 8;
+                const float4 a = *reinterpret_cast<const float4*>(src);
+                const float4 b4 = *reinterpret_cast<const float4*>(src + 4);
+                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+                v[4] += b4.x; v[5] += b4.y; v[6] += b4.z; v[7] += b4.w;
+            }
+            float bb[8], hh[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.bias + c * 8), bb);
+            unpack8(*reinterpret_cast<const uint4*>(hr + c * 8), hh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = bfround(hh[e] + bfround(v[e] + bb[e]));
+        }
+        *reinterpret_cast<uint4*>(hr + c * 8) = pack8(f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hrow[c * 8 + e] = f[e]; s += f[e]; }
+    }
+    s = wave_sum(s);
+    if (lane == 0) redbuf[wave] = s;
+    __syncthreads();
+    const float mean = (redbuf[0] + redbuf[1] + redbuf[2] + redbuf[3]) / (float)D;
+    float q = 0.f;
+    for (int c = tid; c < NC; c += 256) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { float d = hrow[c * 8 + e] - mean; q += d * d; }
+    }
+    q = wave_sum(q);
+    if (lane == 0) redbuf[4 + wave] = q;
+    __syncthreads();
+    const float rstd = rsqrtf((redbuf[4] + redbuf[5] + redbuf[6] + redbuf[7]) / (float)D + p.eps);
+    const int KS = D >> 4;
+    for (int c = tid; c < NC; c += 256) {
+        float f[8], gg[8], bb[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.g + c * 8), gg);
+        unpack8(*reinterpret_cast<const uint4*>(p.b + c * 8), bb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (hrow[c * 8 + e] - mean) * rstd * gg[e] + bb[e];
+        *reinterpret_cast<uint4*>(p.xp_out + xp_index(row >> 5, KS, row & 31, c * 8)) = pack8(f);
+    }
+}
+
+void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st) {
+    row_update_ln_kernel<<<a.M, 256, a.D * sizeof(float), st>>>(a);
+}
+
+// ------------------------------------------------------------------------------------------------
 // decode: y = LN(h) for rows held in fragment order, statistics from the per-32-column partials left by
 // the producer GEMM (summed in tile order).  One block per row.  Used once per step for ln_f.
 // ------------------------------------------------------------------------------------------------
