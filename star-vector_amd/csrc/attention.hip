@@ -245,18 +245,18 @@ void launch_kv_write_prefill(const bf16_t* qkv, int row_stride, int k_off, int v
 }
 
 // ------------------------------------------------------------------------------------------------
-// decode: one block of 8 waves per (sequence, context split).  The grid is (B, AD_SPLIT) so the captured
-// hipGraph is static, but only `act = clamp(ceil(groups/16), 1, AD_SPLIT)` splits are ACTIVE for the
-// current context (the rest exit at once): short contexts run one block per sequence with no
-// inter-block hand-off at all; long contexts split flash-decoding style.  Active blocks own the 32-key
+// decode: one block of 8 waves per (sequence, context split).  A single CU streams only ~25 GB/s from
+// HBM, so the KV pages of one sequence are spread over `act = clamp(ceil(groups/4), 1, AD_SPLIT)` blocks
+// (<= 64 KiB of KV each); the grid is (B, AD_SPLIT) so the captured hipGraph is static and the inactive
+// splits exit at once.  Active blocks own the 32-key
 // groups g = split + act*(wave + 8*i), prefetch the next group's fragments while the MFMAs of the
 // current one run, and (act > 1) leave a partial (m, l, O) in HBM; an arrival ticket elects the last
 // block, which merges the partials in split order (bitwise deterministic).  Hand-off = write-through
 // (sc1) partial stores + drained ticket + sc1 loads in the merger: no fences, placement independent.
 // ------------------------------------------------------------------------------------------------
 #define AD_WAVES 8
-#define AD_SPLIT 8
-#define AD_GROUPS_PER_BLOCK 16
+#define AD_SPLIT 16
+#define AD_GROUPS_PER_BLOCK 4
 
 template <int D>
 struct KvFrags {
@@ -308,27 +308,43 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     const int H = p.H;
     const int HD = H * D;
 
-    // q / k_new / v_new of this sequence (c_attn output, bias already added, bf16)
-    for (int n = tid; n < 16 * D + 2 * D; n += AD_WAVES * 64) {
-        int col;                         // [0,16*D) = q rows (rows >= H are zero), then k_new, v_new
-        if (n < 16 * D) col = (n / D) < H ? n : -1;
-        else col = HD + (n - 16 * D);
-        bf16_t v = 0;
-        if (col >= 0) {
-            if (p.qkv) {
-                v = p.qkv[(size_t)b * p.ld_qkv + col];
-            } else {                     // legacy input: fp32 split-K slabs of the c_attn GEMM
-                float a = 0.f;
-                for (int sp = 0; sp < p.splitk; ++sp) a += p.ws[((size_t)sp * p.rows_ws + b) * p.ldws + col];
-                v = f2bf(a + bf2f(p.bias[col]));
-            }
+    const int page_bytes = kv_page_bytes(D);
+    const int32_t* table = p.block_table + (size_t)b * p.max_pages;
+    // the KV stream does not depend on q: request the first group before anything else
+    const int stride = act * AD_WAVES;
+    int g = split + act * wave;
+    KvFrags<D> fa, fb;
+    if (g < ngroups) load_group<D>(fa, p.pool_layer, table, page_bytes, g, lane);
+
+    // q / k_new / v_new of this sequence -> LDS (bf16).  Input: the c_attn output rows (bf16, bias added)
+    // or, slab pipeline, the fp32 split-K slabs of the c_attn GEMM, summed here in slab order + bias.
+    // 4 columns per thread and every load issued before the first add: one memory round trip.
+    if (H < 16)
+        for (int n = HD + tid; n < 16 * D; n += AD_WAVES * 64) q_s[n] = 0;
+    for (int c4 = tid; c4 < (HD + 2 * D) / 4; c4 += AD_WAVES * 64) {
+        const int col = c4 * 4;
+        uint2 o;
+        if (p.qkv) {
+            o = *reinterpret_cast<const uint2*>(p.qkv + (size_t)b * p.ld_qkv + col);
+        } else {
+            float4 acc4[8];
+            const uint2 bb = *reinterpret_cast<const uint2*>(p.bias + col);
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp)
+                if (sp < p.splitk)
+                    acc4[sp] = *reinterpret_cast<const float4*>(p.ws + ((size_t)sp * p.rows_ws + b) * p.ldws + col);
+            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int sp = 0; sp < 8; ++sp)
+                if (sp < p.splitk) { a.x += acc4[sp].x; a.y += acc4[sp].y; a.z += acc4[sp].z; a.w += acc4[sp].w; }
+            o.x = pack2bf(a.x + __uint_as_float(bb.x << 16), a.y + __uint_as_float(bb.x & 0xffff0000u));
+            o.y = pack2bf(a.z + __uint_as_float(bb.y << 16), a.w + __uint_as_float(bb.y & 0xffff0000u));
         }
-        q_s[n] = v;                      // q_s and kv_new are contiguous
+        const int dst = col < HD ? col : 16 * D + (col - HD);      // q rows, then k_new | v_new
+        *reinterpret_cast<uint2*>(q_s + dst) = o;
     }
     __syncthreads();
 
-    const int page_bytes = kv_page_bytes(D);
-    const int32_t* table = p.block_table + (size_t)b * p.max_pages;
     // split 0 appends the new token's K / V to the cache (for FUTURE steps; in this launch every block
     // patches the new token into its fragments from LDS, so no block depends on another block's store)
     if (split == 0 && tid < 2 * D) {
@@ -415,10 +431,6 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     };
 
     // two register buffers: the loads of group i+1 are in flight while group i is processed
-    const int stride = act * AD_WAVES;
-    int g = split + act * wave;
-    KvFrags<D> fa, fb;
-    if (g < ngroups) load_group<D>(fa, p.pool_layer, table, page_bytes, g, lane);
     while (g < ngroups) {
         const int g1 = g + stride;
         if (g1 < ngroups) load_group<D>(fb, p.pool_layer, table, page_bytes, g1, lane);
@@ -513,33 +525,32 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     __syncthreads();
     if (!flag_s[0]) return;
     const int seq_off = (int)((size_t)b * AD_SPLIT * PART * 4);
-    float* ml = m_s;                                  // reuse LDS: [AD_SPLIT][32]
-    if (tid < AD_SPLIT * 32) {
-        const int s = tid >> 5;
-        float v = -INFINITY;
-        if (s < act) v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, seq_off + (s * PART + (tid & 31)) * 4, 0, 16));
-        ml[tid] = v;
-    }
-    __syncthreads();
+    // merge: every load (statistics of all splits for this thread's head + its O columns) is issued before
+    // the first use -> one memory round trip
     for (int idx = tid * 4; idx < HD; idx += AD_WAVES * 64 * 4) {
         const int h = idx / D;
         u32x4 ov[AD_SPLIT];
+        float ms[AD_SPLIT], ls[AD_SPLIT];
 #pragma unroll
-        for (int s = 0; s < AD_SPLIT; ++s) {
-            ov[s] = u32x4{0u, 0u, 0u, 0u};
-            if (s < act) ov[s] = __builtin_amdgcn_raw_buffer_load_b128(rs, seq_off + (s * PART + 32 + idx) * 4, 0, 16);
+        for (int s2 = 0; s2 < AD_SPLIT; ++s2) {
+            ov[s2] = u32x4{0u, 0u, 0u, 0u};
+            ms[s2] = -INFINITY; ls[s2] = 0.f;
+            if (s2 < act) {
+                ms[s2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, seq_off + (s2 * PART + h) * 4, 0, 16));
+                ls[s2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, seq_off + (s2 * PART + 16 + h) * 4, 0, 16));
+                ov[s2] = __builtin_amdgcn_raw_buffer_load_b128(rs, seq_off + (s2 * PART + 32 + idx) * 4, 0, 16);
+            }
         }
         float M = -INFINITY;
 #pragma unroll
-        for (int s = 0; s < AD_SPLIT; ++s) M = fmaxf(M, ml[s * 32 + h]);
+        for (int s2 = 0; s2 < AD_SPLIT; ++s2) M = fmaxf(M, ms[s2]);
         float num[4] = {0.f, 0.f, 0.f, 0.f}, den = 0.f;
 #pragma unroll
-        for (int s = 0; s < AD_SPLIT; ++s) {
-            const float ms = ml[s * 32 + h];
-            const float f = (s < act && ms != -INFINITY) ? __expf(ms - M) : 0.f;
-            num[0] += f * __uint_as_float(ov[s][0]); num[1] += f * __uint_as_float(ov[s][1]);
-            num[2] += f * __uint_as_float(ov[s][2]); num[3] += f * __uint_as_float(ov[s][3]);
-            den += f * (s < act ? ml[s * 32 + 16 + h] : 0.f);
+        for (int s2 = 0; s2 < AD_SPLIT; ++s2) {
+            const float f = (s2 < act && ms[s2] != -INFINITY) ? __expf(ms[s2] - M) : 0.f;
+            num[0] += f * __uint_as_float(ov[s2][0]); num[1] += f * __uint_as_float(ov[s2][1]);
+            num[2] += f * __uint_as_float(ov[s2][2]); num[3] += f * __uint_as_float(ov[s2][3]);
+            den += f * ls[s2];
         }
         const float inv = 1.0f / den;
         uint2 o;
