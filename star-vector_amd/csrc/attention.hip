@@ -292,7 +292,8 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     const int L = pos + 1;
     const int ngroups = (L + 31) >> 5;
     int act = (ngroups + AD_GROUPS_PER_BLOCK - 1) / AD_GROUPS_PER_BLOCK;
-    act = act < 1 ? 1 : (act > AD_SPLIT ? AD_SPLIT : act);
+    act = act > p.max_splits ? p.max_splits : act;      // host cap: B * act <= #CUs (one block per CU) and <= AD_SPLIT
+    act = act < 1 ? 1 : act;
     if (split >= act) return;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];

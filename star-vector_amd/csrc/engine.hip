@@ -160,6 +160,7 @@ struct sv_engine {
     int ldq = 0;
     float *ws = nullptr, *logits = nullptr, *sample_scratch = nullptr, *attn_part = nullptr;
     unsigned* attn_cnt = nullptr;
+    float* am_val = nullptr; int32_t* am_idx = nullptr;
     int32_t *cur_tok = nullptr, *next_tok = nullptr, *unfinished = nullptr, *positions = nullptr,
             *out_tok = nullptr, *d_step = nullptr, *d_done = nullptr, *d_nemit = nullptr, *d_stop = nullptr;
     int out_ld = 0;
@@ -171,6 +172,7 @@ struct sv_engine {
     int32_t* block_table = nullptr;
     std::vector<int> free_pages;
     int cached_B = 0;
+    int num_cus = 256;
     bool fused_decode = false;   // SV_DECODE_FUSED=1: LN-prologue / ticket pipeline (5 launches per layer)
     double timing[3] = {0, 0, 0};
     double timing_graph = 0;
@@ -392,6 +394,8 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     A(dalloc(e, &e->sample_scratch, R * 4));
     A(dalloc(e, &e->attn_part, R * attn_decode_part_floats(dh)));
     A(dalloc(e, &e->attn_cnt, R));
+    A(dalloc(e, &e->am_val, R * 8));
+    A(dalloc(e, &e->am_idx, R * 8));
     A(dalloc(e, &e->cur_tok, R));
     A(dalloc(e, &e->next_tok, R));
     A(dalloc(e, &e->unfinished, R));
@@ -418,6 +422,11 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         hipError_t hr = hipStreamCreateWithFlags(&e->gen_stream, hipStreamNonBlocking);
         if (hr == hipSuccess) hr = hipEventCreateWithFlags(&e->gen_event, hipEventDisableTiming);
         if (hr != hipSuccess) rc = fail(SV_EHIP, "stream/event creation: %s", hipGetErrorString(hr));
+    }
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c.device) == hipSuccess && prop.multiProcessorCount > 0)
+            e->num_cus = prop.multiProcessorCount;
     }
     e->fused_decode = getenv("SV_DECODE_FUSED") != nullptr && atoi(getenv("SV_DECODE_FUSED")) != 0;
     if (rc) { sv_destroy(e); return rc; }
@@ -631,6 +640,7 @@ static void decode_forward_fused(sv_engine* e, int B, hipStream_t st) {
         ad.max_pages = e->pages_per_seq; ad.positions = e->positions; ad.out_xp = e->xp_attn; ad.out_KS = D / 16;
         ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
         ad.part = e->attn_part; ad.counters = e->attn_cnt;
+        ad.max_splits = e->num_cus / B < 1 ? 1 : (e->num_cus / B > 16 ? 16 : e->num_cus / B);
         prof_mark(e, PK_ATTN, st);
         launch_attn_decode(ad, st);
         prof_mark(e, PK_SKINNY, st);
@@ -681,6 +691,7 @@ static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
         ad.max_pages = e->pages_per_seq; ad.positions = e->positions; ad.out_xp = e->xp_attn; ad.out_KS = D / 16;
         ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
         ad.part = e->attn_part; ad.counters = e->attn_cnt;
+        ad.max_splits = e->num_cus / B < 1 ? 1 : (e->num_cus / B > 16 ? 16 : e->num_cus / B);
         prof_mark(e, PK_ATTN, st);
         launch_attn_decode(ad, st);
         prof_mark(e, PK_SKINNY, st);
@@ -808,9 +819,10 @@ static void sample_and_finish(sv_engine* e, int B, const sv_sampling& sp, int ma
         sa.top_p = sp.top_p; sa.seed = sp.seed; sa.step = e->d_step; sa.out = e->next_tok; sa.scratch = e->sample_scratch;
         launch_sample_top_p(sa, st);
     } else {
-        launch_argmax(e->logits, e->Vpad, e->cfg.vocab, e->next_tok, B, st);
+        launch_argmax_partial(e->logits, e->Vpad, e->cfg.vocab, e->am_val, e->am_idx, B, st);
     }
     FinishArgs f;
+    f.pval = sp.do_sample ? nullptr : e->am_val; f.pidx = sp.do_sample ? nullptr : e->am_idx;
     f.next = e->next_tok; f.cur_tok = e->cur_tok; f.unfinished = e->unfinished; f.positions = e->positions;
     f.out_tokens = e->out_tok; f.ld_out = e->out_ld; f.step = e->d_step; f.done = e->d_done; f.n_emitted = e->d_nemit;
     f.stop_ids = e->d_stop; f.n_stop = sp.n_stop; f.eos = sp.eos_token_id; f.pad = sp.pad_token_id; f.B = B;
@@ -1177,8 +1189,13 @@ extern "C" int sv_op_plane_layernorm(const void* x, const void* gamma, const voi
 
 extern "C" int sv_op_argmax(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t* out, sv_stream stream) {
     if (!logits || !out || B < 1 || V < 1 || ld < V || ld % 4) return fail(SV_EINVAL, "sv_op_argmax: bad argument (ld must be a multiple of 4)");
-    launch_argmax(logits, ld, V, out, B, (hipStream_t)stream);
+    TmpBufs tmp;
+    float* pv; int32_t* pi;
+    SVCHECK(tmp.get(&pv, (size_t)B * 8));
+    SVCHECK(tmp.get(&pi, (size_t)B * 8));
+    launch_argmax(logits, ld, V, out, pv, pi, B, (hipStream_t)stream);
     HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize((hipStream_t)stream));
     return 0;
 }
 

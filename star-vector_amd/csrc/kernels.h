@@ -134,13 +134,16 @@ struct AttnDecodeArgs {
     int B, H, head_dim; float scale;
     float* part;                                           // [B][splits][32 + 16*D] partial (m, l, O)
     unsigned* counters;                                    // [B] arrival tickets, zero between launches
+    int max_splits;                                        // cap on active context splits (#CUs / B, <= 16)
 };
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t st);
 size_t attn_decode_part_floats(int head_dim);            // floats of `part` per sequence
 int init_attention_kernels();   // returns a hipError_t value (0 = ok)
 
 // ---- sampling -----------------------------------------------------------------------------------
-void launch_argmax(const float* logits, int ld, int V, int32_t* out, int B, hipStream_t st);
+// greedy selection: per-slice winners (pval/pidx: [B][8]) then a merge (standalone, or inside finish_step)
+void launch_argmax_partial(const float* logits, int ld, int V, float* pval, int32_t* pidx, int B, hipStream_t st);
+void launch_argmax(const float* logits, int ld, int V, int32_t* out, float* pval, int32_t* pidx, int B, hipStream_t st);
 struct SampleArgs {
     const float* logits; int ld; int V; int B;
     float temperature, top_p; uint64_t seed; const int32_t* step;   // device step counter
@@ -149,7 +152,8 @@ struct SampleArgs {
 void launch_sample_top_p(const SampleArgs& a, hipStream_t st);
 
 struct FinishArgs {
-    const int32_t* next;          // [B] raw sampled ids
+    const int32_t* next;          // [B] raw sampled ids (sampling path)
+    const float* pval; const int32_t* pidx;   // greedy path: [B][8] slice winners merged here (or nullptr)
     int32_t* cur_tok;             // [B] token fed to the next step
     int32_t* unfinished;          // [B]
     int32_t* positions;           // [B] (+1 each step)

@@ -14,20 +14,25 @@ __device__ __forceinline__ void argmax_pair(float& v, int& i, float ov, int oi) 
     if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
 
-__global__ __launch_bounds__(SP_THREADS) void argmax_kernel(const float* __restrict__ logits, int ld, int V,
-                                                            int32_t* __restrict__ out) {
-    __shared__ float sv_[16];
-    __shared__ int si_[16];
+// grid (B, AM_SPLIT): one CU streams ~25 GB/s, so a 196 KB logits row is scanned by AM_SPLIT blocks; each
+// leaves (max, index) of its slice and finish_step_kernel merges them (lowest index wins ties)
+#define AM_SPLIT 8
+__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int ld, int V,
+                                                     float* __restrict__ pval, int32_t* __restrict__ pidx) {
+    __shared__ float sv_[4];
+    __shared__ int si_[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* row = logits + (size_t)blockIdx.x * ld;
+    const int per = (((V + AM_SPLIT - 1) / AM_SPLIT) + 3) & ~3;
+    const int beg = blockIdx.y * per, end = min(beg + per, V);
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = tid * 4; i < V; i += SP_THREADS * 4) {
+    for (int i = beg + tid * 4; i < end; i += 256 * 4) {
         const float4 v = *reinterpret_cast<const float4*>(row + i);
         const float a[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (i + e < V) argmax_pair(best, bi, a[e], i + e);
+            if (i + e < end) argmax_pair(best, bi, a[e], i + e);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -38,12 +43,26 @@ __global__ __launch_bounds__(SP_THREADS) void argmax_kernel(const float* __restr
     if (lane == 0) { sv_[wave] = best; si_[wave] = bi; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 16; ++w) argmax_pair(best, bi, sv_[w], si_[w]);
-        out[blockIdx.x] = bi;
+        for (int w = 1; w < 4; ++w) argmax_pair(best, bi, sv_[w], si_[w]);
+        pval[blockIdx.x * AM_SPLIT + blockIdx.y] = best;
+        pidx[blockIdx.x * AM_SPLIT + blockIdx.y] = bi;
     }
 }
-void launch_argmax(const float* logits, int ld, int V, int32_t* out, int B, hipStream_t st) {
-    argmax_kernel<<<B, SP_THREADS, 0, st>>>(logits, ld, V, out);
+__global__ void argmax_merge_kernel(const float* __restrict__ pval, const int32_t* __restrict__ pidx,
+                                    int32_t* __restrict__ out, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int s = 0; s < AM_SPLIT; ++s) argmax_pair(best, bi, pval[b * AM_SPLIT + s], pidx[b * AM_SPLIT + s]);
+    out[b] = bi;
+}
+void launch_argmax_partial(const float* logits, int ld, int V, float* pval, int32_t* pidx, int B, hipStream_t st) {
+    argmax_kernel<<<dim3(B, AM_SPLIT), 256, 0, st>>>(logits, ld, V, pval, pidx);
+}
+void launch_argmax(const float* logits, int ld, int V, int32_t* out, float* pval, int32_t* pidx, int B, hipStream_t st) {
+    launch_argmax_partial(logits, ld, V, pval, pidx, B, st);
+    argmax_merge_kernel<<<(B + 63) / 64, 64, 0, st>>>(pval, pidx, out, B);
 }
 
 // block-wide sum (all threads get the result)
@@ -174,7 +193,15 @@ __global__ void finish_step_kernel(FinishArgs p) {
     __syncthreads();
     if (b < p.B) {
         const int unf = p.unfinished[b];
-        const int tok = unf ? p.next[b] : p.pad;
+        int nxt;
+        if (p.pval) {                       // greedy: merge the AM_SPLIT slice winners of this row
+            float best = -INFINITY;
+            nxt = 0x7fffffff;
+            for (int s = 0; s < AM_SPLIT; ++s) argmax_pair(best, nxt, p.pval[b * AM_SPLIT + s], p.pidx[b * AM_SPLIT + s]);
+        } else {
+            nxt = p.next[b];
+        }
+        const int tok = unf ? nxt : p.pad;
         p.out_tokens[(size_t)b * p.ld_out + t] = tok;
         p.cur_tok[b] = tok;
         const int still = unf && tok != p.eos;
