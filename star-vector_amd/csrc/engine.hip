@@ -959,13 +959,14 @@ extern "C" int sv_profile_decode_step(sv_engine* e, int32_t B, int32_t iters, do
         for (size_t i = 0; i + 1 < e->prof_used; ++i) {
             float ms = 0.f;
             HIPCHECK(hipEventElapsedTime(&ms, e->prof_ev[i], e->prof_ev[i + 1]));
-            double d = (double)ms - overhead_ms;
-            if (d < 0) d = 0;
-            out[2 * e->prof_kind[i]] += d;
+            // raw event-to-event time: execution + the launch boundary, i.e. what rocprofv3's kernel trace
+            // reports as the dispatch duration (the empty event-pair time is returned separately)
+            out[2 * e->prof_kind[i]] += (double)ms;
             out[2 * e->prof_kind[i] + 1] += 1.0;
         }
     }
     for (int k = 0; k < 2 * PK_COUNT; ++k) out[k] /= (double)iters;
+    out[2 * PK_SAMPLE] = overhead_ms;         // slot 6: time between two back-to-back events with no kernel
     add_i32_kernel<<<(B + 63) / 64, 64, 0, st>>>(e->positions, 1, B);
     HIPCHECK(hipStreamSynchronize(st));
     return 0;

@@ -179,8 +179,10 @@ class HipEngine:
         """HIP-event time per decode step by kernel class (eager launches of the graph's kernels)."""
         buf = (C.c_double * 8)()
         check(self.lib.sv_profile_decode_step(self._h, B, iters, buf, _stream()), "sv_profile_decode_step")
-        names = ["skinny_gemm", "attn_decode", "row_update_ln", "other"]
-        return {n: {"ms_per_step": buf[2 * i], "launches_per_step": buf[2 * i + 1]} for i, n in enumerate(names)}
+        names = ["skinny_gemm", "attn_decode", "row_update_ln"]
+        res = {n: {"ms_per_step": buf[2 * i], "launches_per_step": buf[2 * i + 1]} for i, n in enumerate(names)}
+        res["event_pair_overhead_ms"] = buf[6]
+        return res
 
 
 # ---- single operators (used by the parity tests; one per SURVEY.md section 8a row) ----------------

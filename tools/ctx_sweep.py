@@ -29,4 +29,4 @@ for n_new in (2, 128, 512, 1024, 2048):
     prof = eng.profile_decode_step(B, iters=5)
     print(json.dumps({"ctx_end": S0 + n_new, "avg_us_per_step": round(tm["decode_ms"] / max(tm["decode_steps"], 1) * 1e3, 1),
                       "ttft_ms": round(tm["ttft_ms"], 2),
-                      "at_ctx_end_ms": {k: round(v["ms_per_step"], 4) for k, v in prof.items()}}), flush=True)
+                      "at_ctx_end_ms": {k: round(v["ms_per_step"], 4) for k, v in prof.items() if isinstance(v, dict)}}), flush=True)
