@@ -95,13 +95,17 @@ def main():
     n_new = args.new_tokens
     S0 = cfg.query_length + len(PROMPT_IDS)
     t_setup = time.time()
-    w = O.make_weights(cfg, seed=1234, init="std002")
     ec = sva.EngineConfig(max_batch=B_PER_GPU, max_seq_len=S0 + n_new)
     eng = sva.HipEngine(ec, device=local_rank)
-    eng.load_state_dict({k: v for k, v in w.items()})          # fp32 -> bf16 + fragment packing on device
     keep_cpu = (world == 1 and rank == 0 and not args.no_cpu_baseline)
-    if not keep_cpu:
-        del w
+    w = {}
+    for name, t in O.iter_weights(cfg, seed=1234, init="std002"):      # streamed: fp32 -> bf16 + fragment
+        eng.load_weight(name, t)                                       # packing on device, one tensor at a time
+        if keep_cpu:
+            w[name] = t
+    eng.load_state_dict({})                                            # completeness check
+    if keep_cpu:
+        w[O.K_LMH] = w[O.P_DEC + "wte.weight"]
     # this rank's shard of the global batch (seeded per global row -> identical under any sharding)
     images = O.synthetic_images(B_PER_GPU * world, cfg.image_size, seed=0)[rank * B_PER_GPU:(rank + 1) * B_PER_GPU]
     images = images.to(torch.bfloat16).to(dev)

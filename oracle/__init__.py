@@ -18,6 +18,7 @@ the fixtures under ``tests/golden/``.
 from .starvector_oracle import (  # noqa: F401
     OracleConfig,
     make_weights,
+    iter_weights,
     vit_forward,
     image_encoder_forward,
     adapter_forward,

@@ -96,12 +96,13 @@ def _ln(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
 # deterministic weights + inputs (shared by tests, smoke and bench; values are bf16-exact so the
 # fp32 oracle and the bf16 engine consume IDENTICAL numbers)
 # ----------------------------------------------------------------------------------------------
-def make_weights(cfg: OracleConfig, seed: int = 1234, init: str = "parity") -> Dict[str, Tensor]:
-    """Seeded random-init state_dict with the reference's key names and shapes.
+def iter_weights(cfg: OracleConfig, seed: int = 1234, init: str = "parity"):
+    """Seeded random-init state_dict with the reference's key names and shapes, streamed as
+    (name, float32 tensor) pairs so a loader never has to hold all 1.4 B parameters at once.
 
     init="parity": fan-in scaled normals so activations stay O(1) and greedy argmax has
     non-degenerate margins.  init="std002": N(0, 0.02) everywhere
-    (throughput runs; values do not affect speed).
+    (throughput runs; values do not affect speed).  Values are bf16-exact.
     """
     g = torch.Generator().manual_seed(seed)
 
@@ -109,57 +110,67 @@ def make_weights(cfg: OracleConfig, seed: int = 1234, init: str = "parity") -> D
         t = torch.empty(*shape, dtype=torch.float32).normal_(0.0, std, generator=g)
         return t.to(torch.bfloat16).to(torch.float32)
 
-    def lin(out_f, in_f, gain=1.0):
+    def lin(name, out_f, in_f, gain=1.0):
         std = 0.02 if init == "std002" else gain / math.sqrt(in_f)
-        return nrm(out_f, in_f, std=std), nrm(out_f, std=0.02)
+        yield name + ".weight", nrm(out_f, in_f, std=std)
+        yield name + ".bias", nrm(out_f, std=0.02)
 
-    def ln(*shape):
+    def ln(name, *shape):
         if init == "std002":
-            return torch.ones(*shape), torch.zeros(*shape)
-        w = (1.0 + 0.1 * torch.empty(*shape).normal_(0, 1, generator=g)).to(torch.bfloat16).to(torch.float32)
-        return w, nrm(*shape, std=0.02)
+            yield name + ".weight", torch.ones(*shape)
+            yield name + ".bias", torch.zeros(*shape)
+            return
+        yield name + ".weight", (1.0 + 0.1 * torch.empty(*shape).normal_(0, 1, generator=g)).to(torch.bfloat16).to(torch.float32)
+        yield name + ".bias", nrm(*shape, std=0.02)
 
-    w: Dict[str, Tensor] = {}
     Dv, ps = cfg.vit_width, cfg.patch_size
-    w[P_VIT + "conv1.weight"] = nrm(Dv, 3, ps, ps, std=(0.02 if init == "std002" else 1.0 / math.sqrt(3 * ps * ps)))
-    w[P_VIT + "class_embedding"] = nrm(Dv, std=Dv ** -0.5 if init != "std002" else 0.02)
-    w[P_VIT + "positional_embedding"] = nrm(cfg.query_length, Dv, std=(0.3 if init != "std002" else 0.02))
-    w[P_VIT + "ln_pre.weight"], w[P_VIT + "ln_pre.bias"] = ln(Dv)
+    yield P_VIT + "conv1.weight", nrm(Dv, 3, ps, ps, std=(0.02 if init == "std002" else 1.0 / math.sqrt(3 * ps * ps)))
+    yield P_VIT + "class_embedding", nrm(Dv, std=Dv ** -0.5 if init != "std002" else 0.02)
+    yield P_VIT + "positional_embedding", nrm(cfg.query_length, Dv, std=(0.3 if init != "std002" else 0.02))
+    yield from ln(P_VIT + "ln_pre", Dv)
     for i in range(cfg.vit_layers):
         p = f"{P_VIT}transformer.resblocks.{i}."
-        w[p + "ln_1.weight"], w[p + "ln_1.bias"] = ln(Dv)
-        w[p + "attn.in_proj_weight"], w[p + "attn.in_proj_bias"] = lin(3 * Dv, Dv)
-        w[p + "attn.out_proj.weight"], w[p + "attn.out_proj.bias"] = lin(Dv, Dv, gain=0.5)
-        w[p + "ln_2.weight"], w[p + "ln_2.bias"] = ln(Dv)
-        w[p + "mlp.c_fc.weight"], w[p + "mlp.c_fc.bias"] = lin(4 * Dv, Dv)
-        w[p + "mlp.c_proj.weight"], w[p + "mlp.c_proj.bias"] = lin(Dv, 4 * Dv, gain=0.5)
-    w[P_LNV + "weight"], w[P_LNV + "bias"] = ln(Dv)
+        yield from ln(p + "ln_1", Dv)
+        for (nm, t) in lin(p + "attn.in_proj", 3 * Dv, Dv):
+            yield nm.replace("in_proj.weight", "in_proj_weight").replace("in_proj.bias", "in_proj_bias"), t
+        yield from lin(p + "attn.out_proj", Dv, Dv, gain=0.5)
+        yield from ln(p + "ln_2", Dv)
+        yield from lin(p + "mlp.c_fc", 4 * Dv, Dv)
+        yield from lin(p + "mlp.c_proj", Dv, 4 * Dv, gain=0.5)
+    yield from ln(P_LNV[:-1], Dv)
 
     D = cfg.hidden
-    w[P_ADP + "c_fc.weight"], w[P_ADP + "c_fc.bias"] = lin(2 * Dv, Dv)
-    w[P_ADP + "c_proj.weight"], w[P_ADP + "c_proj.bias"] = lin(D, 2 * Dv)
+    yield from lin(P_ADP + "c_fc", 2 * Dv, Dv)
+    yield from lin(P_ADP + "c_proj", D, 2 * Dv)
     if cfg.adapter_norm == "layer_norm":
-        w[P_ADP + "norm.weight"], w[P_ADP + "norm.bias"] = ln(cfg.query_length, D)
+        yield from ln(P_ADP + "norm", cfg.query_length, D)
     else:
         Q = cfg.query_length
-        w[P_ADP + "norm.weight"], w[P_ADP + "norm.bias"] = ln(Q)
-        w[P_ADP + "norm.running_mean"] = nrm(Q, std=0.1)
-        w[P_ADP + "norm.running_var"] = (1.0 + 0.2 * torch.rand(Q, generator=g)).to(torch.bfloat16).to(torch.float32)
+        yield from ln(P_ADP + "norm", Q)
+        yield P_ADP + "norm.running_mean", nrm(Q, std=0.1)
+        yield P_ADP + "norm.running_var", (1.0 + 0.2 * torch.rand(Q, generator=g)).to(torch.bfloat16).to(torch.float32)
 
-    w[P_DEC + "wte.weight"] = nrm(cfg.vocab, D, std=0.02)   # small: keeps the tied-head self-logit from
-    # dominating, so random-init greedy streams are diverse instead of one repeated token
-    w[P_DEC + "wpe.weight"] = nrm(cfg.n_positions, D, std=(0.1 if init != "std002" else 0.02))
+    # wte is small (std 0.02): keeps the tied-head self-logit from dominating, so random-init greedy streams
+    # are diverse instead of one repeated token
+    yield P_DEC + "wte.weight", nrm(cfg.vocab, D, std=0.02)
+    yield P_DEC + "wpe.weight", nrm(cfg.n_positions, D, std=(0.1 if init != "std002" else 0.02))
     kv = 2 * cfg.head_dim
     for i in range(cfg.n_layer):
         p = f"{P_DEC}h.{i}."
-        w[p + "ln_1.weight"], w[p + "ln_1.bias"] = ln(D)
-        w[p + "attn.c_attn.weight"], w[p + "attn.c_attn.bias"] = lin(D + kv, D)
-        w[p + "attn.c_proj.weight"], w[p + "attn.c_proj.bias"] = lin(D, D, gain=0.5)
-        w[p + "ln_2.weight"], w[p + "ln_2.bias"] = ln(D)
-        w[p + "mlp.c_fc.weight"], w[p + "mlp.c_fc.bias"] = lin(cfg.n_inner, D)
-        w[p + "mlp.c_proj.weight"], w[p + "mlp.c_proj.bias"] = lin(D, cfg.n_inner, gain=0.5)
-    w[P_DEC + "ln_f.weight"], w[P_DEC + "ln_f.bias"] = ln(D)
-    w[K_LMH] = w[P_DEC + "wte.weight"]        # tied (gpt_bigcode/modeling_gpt_bigcode.py:1145)
+        yield from ln(p + "ln_1", D)
+        yield from lin(p + "attn.c_attn", D + kv, D)
+        yield from lin(p + "attn.c_proj", D, D, gain=0.5)
+        yield from ln(p + "ln_2", D)
+        yield from lin(p + "mlp.c_fc", cfg.n_inner, D)
+        yield from lin(p + "mlp.c_proj", D, cfg.n_inner, gain=0.5)
+    yield from ln(P_DEC + "ln_f", D)
+
+
+def make_weights(cfg: OracleConfig, seed: int = 1234, init: str = "parity") -> Dict[str, Tensor]:
+    """The whole state_dict of iter_weights, plus the tied lm_head alias
+    (gpt_bigcode/modeling_gpt_bigcode.py:1145)."""
+    w = dict(iter_weights(cfg, seed, init))
+    w[K_LMH] = w[P_DEC + "wte.weight"]
     return w
 
 

@@ -157,8 +157,11 @@ struct sv_engine {
     bf16_t *h_dec = nullptr, *h_xp = nullptr, *hl = nullptr, *xp_a = nullptr, *xp_attn = nullptr, *xp_mlp = nullptr, *qkv_rm = nullptr;
     float2* ln_stats = nullptr;
     unsigned* sk_cnt = nullptr;
+    unsigned* ru_ready = nullptr;   // one arrival counter per overlapped launch site, zeroed at the start of a step
+    int* ru_err = nullptr;
+    int overlap = 1;                // row updates run inside the consumer GEMM's launch (SV_DECODE_OVERLAP=0: separate kernels)
     int ldq = 0;
-    float *ws = nullptr, *logits = nullptr, *sample_scratch = nullptr, *attn_part = nullptr;
+    float *ws = nullptr, *ws2 = nullptr, *logits = nullptr, *sample_scratch = nullptr, *attn_part = nullptr;
     unsigned* attn_cnt = nullptr;
     float* am_val = nullptr; int32_t* am_idx = nullptr;
     int32_t *cur_tok = nullptr, *next_tok = nullptr, *unfinished = nullptr, *positions = nullptr,
@@ -390,6 +393,9 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     A(dalloc(e, &e->xp_attn, R * D));
     A(dalloc(e, &e->xp_mlp, R * F));
     A(dalloc(e, &e->ws, (size_t)8 * R * e->ldws));
+    A(dalloc(e, &e->ws2, (size_t)8 * R * e->ldws));
+    A(dalloc(e, &e->ru_ready, 64));
+    A(dalloc(e, &e->ru_err, 4));
     A(dalloc(e, &e->logits, R * e->Vpad));
     A(dalloc(e, &e->sample_scratch, R * 4));
     A(dalloc(e, &e->attn_part, R * attn_decode_part_floats(dh)));
@@ -428,6 +434,8 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         if (hipGetDeviceProperties(&prop, c.device) == hipSuccess && prop.multiProcessorCount > 0)
             e->num_cus = prop.multiProcessorCount;
     }
+    if (getenv("SV_DECODE_OVERLAP")) e->overlap = atoi(getenv("SV_DECODE_OVERLAP")) != 0;
+    if (2 * c.n_layer + 1 > 64) e->overlap = 0;
     e->fused_decode = getenv("SV_DECODE_FUSED") != nullptr && atoi(getenv("SV_DECODE_FUSED")) != 0;
     if (rc) { sv_destroy(e); return rc; }
     *out = e;
@@ -672,21 +680,39 @@ static void skinny_slabs(sv_engine* e, const bf16_t* xp, const Linear& l, int MT
 static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
     const sv_config& c = e->cfg;
     const int D = c.hidden, dh = e->dh, F = c.n_inner, MT = (B + 31) / 32;
+    // slab double buffer: A = c_attn slabs (read by attention); B = c_proj / down-proj slabs (read by the row update)
+    float* wsA = e->ws;
+    float* wsB = e->overlap ? e->ws2 : e->ws;
     RowUpdateArgs ru;
     memset(&ru, 0, sizeof(ru));
     ru.h = e->h_dec; ru.ldh = D; ru.M = B; ru.D = D; ru.eps = c.ln_eps; ru.xp_out = e->xp_a;
     ru.ldws = e->ldws; ru.rows_ws = MT * 32;
     ru.ws = nullptr; ru.wte = e->wte; ru.wpe = e->wpe; ru.tokens = e->cur_tok; ru.positions = e->positions;
     ru.g = e->dec[0].ln1.g; ru.b = e->dec[0].ln1.b;
-    prof_mark(e, PK_ROWLN, st);
-    launch_row_update_ln(ru, st);                       // embedding + ln_1 of layer 0
+    int site = 0;
+    if (e->overlap) (void)hipMemsetAsync(e->ru_ready, 0, 64 * sizeof(unsigned), st);
+    // the pending row update either runs as its own launch or rides inside the next GEMM's launch
+    auto attach = [&](SkinnyArgs& a) {
+        if (!e->overlap) { prof_mark(e, PK_ROWLN, st); launch_row_update_ln(ru, st); return; }
+        a.ru_M = B; a.ru_ws = ru.ws; a.ru_splitk = ru.splitk; a.ru_ldws = ru.ldws; a.ru_rows_ws = ru.rows_ws;
+        a.ru_bias = ru.bias; a.ru_h = ru.h; a.ru_ldh = ru.ldh; a.ru_wte = ru.wte; a.ru_wpe = ru.wpe;
+        a.ru_tokens = ru.tokens; a.ru_positions = ru.positions; a.ru_g = ru.g; a.ru_b = ru.b; a.ru_eps = ru.eps;
+        a.ru_ready = e->ru_ready + (site++); a.ru_err = e->ru_err;
+    };
     for (int i = 0; i < c.n_layer; ++i) {
         DecLayer& L = e->dec[i];
-        prof_mark(e, PK_SKINNY, st);
-        skinny_slabs(e, e->xp_a, L.c_attn, MT, st);
+        {   // c_attn (+ the row update that produces its input: embedding or previous layer's down-proj)
+            SkinnyArgs a;
+            memset(&a, 0, sizeof(a));
+            a.xp = e->xp_a; a.Wp = L.c_attn.Wp; a.MT = MT; a.Npad = L.c_attn.Npad; a.K = L.c_attn.Kpad;
+            a.splitk = L.c_attn.splitk; a.out_mode = SK_OUT_PARTIAL; a.ws = wsA; a.ldws = e->ldws; a.N = L.c_attn.N;
+            attach(a);
+            prof_mark(e, PK_SKINNY, st);
+            launch_gemm_skinny(a, st);
+        }
         AttnDecodeArgs ad;
         memset(&ad, 0, sizeof(ad));
-        ad.ws = e->ws; ad.splitk = L.c_attn.splitk; ad.ldws = e->ldws; ad.rows_ws = MT * 32; ad.bias = L.c_attn.bias;
+        ad.ws = wsA; ad.splitk = L.c_attn.splitk; ad.ldws = e->ldws; ad.rows_ws = MT * 32; ad.bias = L.c_attn.bias;
         ad.pool_layer = e->kv_pool + (size_t)i * e->layer_stride; ad.block_table = e->block_table;
         ad.max_pages = e->pages_per_seq; ad.positions = e->positions; ad.out_xp = e->xp_attn; ad.out_KS = D / 16;
         ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
@@ -694,29 +720,46 @@ static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
         ad.max_splits = e->num_cus / B < 1 ? 1 : (e->num_cus / B > 16 ? 16 : e->num_cus / B);
         prof_mark(e, PK_ATTN, st);
         launch_attn_decode(ad, st);
-        prof_mark(e, PK_SKINNY, st);
-        skinny_slabs(e, e->xp_attn, L.c_proj, MT, st);
-        ru.ws = e->ws; ru.splitk = L.c_proj.splitk; ru.bias = L.c_proj.bias; ru.g = L.ln2.g; ru.b = L.ln2.b;
-        prof_mark(e, PK_ROWLN, st);
-        launch_row_update_ln(ru, st);
-        prof_mark(e, PK_SKINNY, st);
-        {
+        {   // attention output projection -> slabs
+            SkinnyArgs a;
+            memset(&a, 0, sizeof(a));
+            a.xp = e->xp_attn; a.Wp = L.c_proj.Wp; a.MT = MT; a.Npad = L.c_proj.Npad; a.K = L.c_proj.Kpad;
+            a.splitk = L.c_proj.splitk; a.out_mode = SK_OUT_PARTIAL; a.ws = wsB; a.ldws = e->ldws; a.N = L.c_proj.N;
+            prof_mark(e, PK_SKINNY, st);
+            launch_gemm_skinny(a, st);
+        }
+        ru.ws = wsB; ru.splitk = L.c_proj.splitk; ru.bias = L.c_proj.bias; ru.g = L.ln2.g; ru.b = L.ln2.b;
+        {   // c_fc (+ row update: bias, residual, LN2), GELU epilogue
             SkinnyArgs a;
             memset(&a, 0, sizeof(a));
             a.xp = e->xp_a; a.Wp = L.c_fc.Wp; a.bias = L.c_fc.bias; a.MT = MT; a.Npad = L.c_fc.Npad; a.K = L.c_fc.Kpad;
             a.splitk = 1; a.out_mode = SK_OUT_PACKED_ACT; a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16;
             a.N = L.c_fc.N;
+            attach(a);
+            prof_mark(e, PK_SKINNY, st);
             launch_gemm_skinny(a, st);
         }
-        prof_mark(e, PK_SKINNY, st);
-        skinny_slabs(e, e->xp_mlp, L.c_proj2, MT, st);
+        {   // down projection -> slabs
+            SkinnyArgs a;
+            memset(&a, 0, sizeof(a));
+            a.xp = e->xp_mlp; a.Wp = L.c_proj2.Wp; a.MT = MT; a.Npad = L.c_proj2.Npad; a.K = L.c_proj2.Kpad;
+            a.splitk = L.c_proj2.splitk; a.out_mode = SK_OUT_PARTIAL; a.ws = wsB; a.ldws = e->ldws; a.N = L.c_proj2.N;
+            prof_mark(e, PK_SKINNY, st);
+            launch_gemm_skinny(a, st);
+        }
         const LNp& nxt = (i + 1 < c.n_layer) ? e->dec[i + 1].ln1 : e->ln_f;
-        ru.splitk = L.c_proj2.splitk; ru.bias = L.c_proj2.bias; ru.g = nxt.g; ru.b = nxt.b;
-        prof_mark(e, PK_ROWLN, st);
-        launch_row_update_ln(ru, st);
+        ru.ws = wsB; ru.splitk = L.c_proj2.splitk; ru.bias = L.c_proj2.bias; ru.g = nxt.g; ru.b = nxt.b;
     }
-    prof_mark(e, PK_SKINNY, st);
-    lm_head_logits(e, MT, e->xp_a, nullptr, st);
+    {   // lm_head (+ the last row update: bias, residual, ln_f)
+        SkinnyArgs a;
+        memset(&a, 0, sizeof(a));
+        a.xp = e->xp_a; a.Wp = e->lm_head.Wp; a.MT = MT; a.Npad = e->lm_head.Npad; a.K = e->lm_head.Kpad;
+        a.splitk = 1; a.out_mode = SK_OUT_F32; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1;
+        a.N = e->lm_head.N;
+        attach(a);
+        prof_mark(e, PK_SKINNY, st);
+        launch_gemm_skinny(a, st);
+    }
     prof_mark(e, PK_SAMPLE, st);      // closes the lm_head interval; whatever follows is sampling
 }
 
@@ -906,6 +949,14 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
     if (graph) (void)hipGraphDestroy(graph);
     HIPCHECK(hipMemcpyAsync(&e->h_flags[1], e->d_nemit, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
+    if (e->overlap && !e->fused_decode) {
+        HIPCHECK(hipMemcpyAsync(&e->h_flags[2], e->ru_err, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        if (e->h_flags[2]) {
+            HIPCHECK(hipMemsetAsync(e->ru_err, 0, sizeof(int32_t), st));
+            return fail(SV_EHIP, "in-launch row-update hand-off timed out (set SV_DECODE_OVERLAP=0)");
+        }
+    }
     const int n_emit = e->h_flags[1];
     if (n_emit < 1 || n_emit > max_new) return fail(SV_EHIP, "generation bookkeeping failed (n_emitted=%d)", n_emit);
     tokens_to_i64_kernel<<<(B * n_emit + 255) / 256, 256, 0, st>>>(e->out_tok, e->out_ld, dev_out_tokens, B, n_emit, max_new);

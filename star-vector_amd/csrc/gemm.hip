@@ -247,18 +247,120 @@ struct SkChunk {
 };
 
 template <int CH>
-__device__ __forceinline__ void sk_load(SkChunk<CH>& c, const u32x4* wptr, const u32x4* xptr, int ks, int ks_end) {
+__device__ __forceinline__ void sk_load_w(SkChunk<CH>& c, const u32x4* wptr, int ks, int ks_end) {
+#pragma unroll
+    for (int u = 0; u < CH; ++u)
+        if (ks + u < ks_end) c.w[u] = __builtin_nontemporal_load(wptr + (size_t)(ks + u) * 64);   // streamed once
+}
+// SC1: the activation rows were produced by other workgroups of THIS launch (write-through stores) ->
+// read them past the L1 (sc1); otherwise plain loads
+template <int CH, bool SC1>
+__device__ __forceinline__ void sk_load_x(SkChunk<CH>& c, const u32x4* xptr, __amdgpu_buffer_rsrc_t rs, int xoff,
+                                          int ks, int ks_end) {
 #pragma unroll
     for (int u = 0; u < CH; ++u) {
         if (ks + u < ks_end) {                                                  // wave-uniform
-            c.w[u] = __builtin_nontemporal_load(wptr + (size_t)(ks + u) * 64);  // streamed once
-            c.x[u] = xptr[(size_t)(ks + u) * 64];
+            if (SC1) c.x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff + (ks + u) * 1024, 0, 16);
+            else c.x[u] = xptr[(size_t)(ks + u) * 64];
         }
     }
 }
+template <int CH, bool SC1>
+__device__ __forceinline__ void sk_load(SkChunk<CH>& c, const u32x4* wptr, const u32x4* xptr,
+                                        __amdgpu_buffer_rsrc_t rs, int xoff, int ks, int ks_end) {
+    sk_load_w<CH>(c, wptr, ks, ks_end);
+    sk_load_x<CH, SC1>(c, xptr, rs, xoff, ks, ks_end);
+}
 
-template <int WAVES, bool LN>
-__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
+// one row of the decode row update, executed by a whole block inside the consumer GEMM's launch:
+//   embedding mode : h = bf(wte[tok] + wpe[pos])                       (gpt_bigcode :1060-1063)
+//   residual mode  : h = bf(h + bf(sum_s slab_s[row] + bias))          (slab order -> deterministic)
+//   then           : xp = LN(h) in fragment order, stored WRITE-THROUGH (sc1) for the waiting blocks
+template <int WAVES>
+__device__ __forceinline__ void ru_row(const SkinnyArgs& p, int row, char* smem, __amdgpu_buffer_rsrc_t rs_x) {
+    constexpr int NT = WAVES * 64;
+    const int D = p.K, NC = D >> 3, KS = D >> 4;
+    float* hrow = reinterpret_cast<float*>(smem);          // [D]
+    float* redbuf = hrow + D;                              // [2][WAVES]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    bf16_t* hr = p.ru_h + (size_t)row * p.ru_ldh;
+    float s = 0.f;
+    for (int c = tid; c < NC; c += NT) {
+        float f[8];
+        if (p.ru_ws == nullptr) {
+            const int tok = p.ru_tokens[row], pos = p.ru_positions[row];
+            float a[8], w[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.ru_wte + (size_t)tok * D + c * 8), a);
+            unpack8(*reinterpret_cast<const uint4*>(p.ru_wpe + (size_t)pos * D + c * 8), w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = bfround(a[e] + w[e]);
+        } else {
+            float bb[8], hh[8], v[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.ru_bias + c * 8), bb);
+            unpack8(*reinterpret_cast<const uint4*>(hr + c * 8), hh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            for (int base = 0; base < p.ru_splitk; base += 4) {        // slab order; 4 slabs in flight at a time
+                float4 q0[4], q1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (base + j < p.ru_splitk) {
+                        const float* src = p.ru_ws + ((size_t)(base + j) * p.ru_rows_ws + row) * p.ru_ldws + c * 8;
+                        q0[j] = *reinterpret_cast<const float4*>(src);
+                        q1[j] = *reinterpret_cast<const float4*>(src + 4);
+                    }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (base + j < p.ru_splitk) {
+                        v[0] += q0[j].x; v[1] += q0[j].y; v[2] += q0[j].z; v[3] += q0[j].w;
+                        v[4] += q1[j].x; v[5] += q1[j].y; v[6] += q1[j].z; v[7] += q1[j].w;
+                    }
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = bfround(hh[e] + bfround(v[e] + bb[e]));
+        }
+        *reinterpret_cast<uint4*>(hr + c * 8) = pack8(f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hrow[c * 8 + e] = f[e]; s += f[e]; }
+    }
+    s = wave_sum(s);
+    if (lane == 0) redbuf[wave] = s;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) tot += redbuf[w];
+    const float mean = tot / (float)D;
+    float q = 0.f;
+    for (int c = tid; c < NC; c += NT) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = hrow[c * 8 + e] - mean; q += d * d; }
+    }
+    q = wave_sum(q);
+    if (lane == 0) redbuf[WAVES + wave] = q;
+    __syncthreads();
+    float qt = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) qt += redbuf[WAVES + w];
+    const float rstd = rsqrtf(qt / (float)D + p.ru_eps);
+    for (int c = tid; c < NC; c += NT) {
+        float f[8], gg[8], bb[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.ru_g + c * 8), gg);
+        unpack8(*reinterpret_cast<const uint4*>(p.ru_b + c * 8), bb);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = (hrow[c * 8 + e] - mean) * rstd * gg[e] + bb[e];
+        const uint4 o = pack8(f);
+        u32x4 v; v[0] = o.x; v[1] = o.y; v[2] = o.z; v[3] = o.w;
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs_x, (int)(xp_index(row >> 5, KS, row & 31, c * 8) * 2), 0, 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its write-through stores
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(p.ru_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int WAVES, int PRE>
+__global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && PRE == 2) ? 4 : 1) void gemm_skinny_kernel(SkinnyArgs p) {
+    constexpr bool LN = PRE == 1;
+    constexpr bool RU = PRE == 2;
     constexpr int CH = 4;                            // k-steps per register chunk (two chunks = 8 KiB of W in flight per wave)
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(sk_smem);          // [WAVES][16][64]
@@ -333,9 +435,27 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
             if (n < p.N) bias_d[i] = bf2f(p.bias[n]);
         }
     }
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(p.xp), 0, (unsigned)((size_t)p.MT * 32 * p.K * 2), 0x00020000);
+    const int xoff = (int)((((size_t)mt * KS + ks0) * 64 + lane) * 16);
     SkChunk<CH> ca, cb;
-    sk_load<CH>(ca, wptr, xptr, 0, ks_per_wave);
-    if (CH < ks_per_wave) sk_load<CH>(cb, wptr, xptr, CH, ks_per_wave);
+    sk_load_w<CH>(ca, wptr, 0, ks_per_wave);
+    if (CH < ks_per_wave) sk_load_w<CH>(cb, wptr, CH, ks_per_wave);
+    if (RU) {
+        // the weight stream is in flight; now produce / wait for this GEMM's activation rows
+        const int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        if (bid < p.ru_M) ru_row<WAVES>(p, bid, sk_smem, rs_x);
+        if (tid == 0) {
+            unsigned spins = 0;
+            while (__hip_atomic_load(p.ru_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.ru_M) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 22)) { *p.ru_err = 1; break; }       // bounded: never hang the GPU
+            }
+        }
+        __syncthreads();
+    }
+    sk_load_x<CH, RU>(ca, xptr, rs_x, xoff, 0, ks_per_wave);
+    if (CH < ks_per_wave) sk_load_x<CH, RU>(cb, xptr, rs_x, xoff, CH, ks_per_wave);
 
     float ra = 1.f, rb = 0.f;
     if (LN) {
@@ -387,9 +507,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
 
     for (int ks = 0; ks < ks_per_wave; ks += 2 * CH) {
         compute(ca, ks);
-        if (ks + 2 * CH < ks_per_wave) sk_load<CH>(ca, wptr, xptr, ks + 2 * CH, ks_per_wave);
+        if (ks + 2 * CH < ks_per_wave) sk_load<CH, RU>(ca, wptr, xptr, rs_x, xoff, ks + 2 * CH, ks_per_wave);
         if (ks + CH < ks_per_wave) compute(cb, ks + CH);
-        if (ks + 3 * CH < ks_per_wave) sk_load<CH>(cb, wptr, xptr, ks + 3 * CH, ks_per_wave);
+        if (ks + 3 * CH < ks_per_wave) sk_load<CH, RU>(cb, wptr, xptr, rs_x, xoff, ks + 3 * CH, ks_per_wave);
     }
 
     // ---- K reduction across the waves of the block (wave order) ---------------------------------
@@ -568,25 +688,35 @@ static size_t skinny_smem(int waves, int K, bool ln) {
     return (size_t)waves * 16 * 64 * 4 + 64 * 4 + (size_t)2 * waves * 64 * 4 + (ln ? (size_t)K * 4 : 0) + 16;
 }
 
-template <int W, bool LN>
+template <int W, int PRE>
 static int set_attr(int bytes) {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<W, LN>),
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<W, PRE>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 int init_gemm_kernels() {
     // 16-wave blocks reduce through 64 KiB of LDS (+ gamma/beta): above the default dynamic-LDS limit
-    int r = set_attr<16, true>(160 * 1024);
-    if (!r) r = set_attr<16, false>(160 * 1024);
-    if (!r) r = set_attr<8, true>(128 * 1024);
-    if (!r) r = set_attr<8, false>(128 * 1024);
+    int r = set_attr<16, 1>(160 * 1024);
+    if (!r) r = set_attr<16, 0>(160 * 1024);
+    if (!r) r = set_attr<16, 2>(160 * 1024);
+    if (!r) r = set_attr<8, 1>(128 * 1024);
+    if (!r) r = set_attr<8, 0>(128 * 1024);
+    if (!r) r = set_attr<8, 2>(128 * 1024);
     return r;
 }
 
 template <int W>
 static void launch_sk(const SkinnyArgs& a, dim3 grid, hipStream_t st) {
     const bool ln = a.ln_stats != nullptr;
-    if (ln) gemm_skinny_kernel<W, true><<<grid, W * 64, skinny_smem(W, a.K, true), st>>>(a);
-    else gemm_skinny_kernel<W, false><<<grid, W * 64, skinny_smem(W, a.K, false), st>>>(a);
+    size_t smem = skinny_smem(W, a.K, ln);
+    if (a.ru_M > 0) {
+        const size_t need = (size_t)a.K * 4 + 2 * W * 4 + 64;       // row buffer of the overlapped row update
+        if (smem < need) smem = need;
+        gemm_skinny_kernel<W, 2><<<grid, W * 64, smem, st>>>(a);
+    } else if (ln) {
+        gemm_skinny_kernel<W, 1><<<grid, W * 64, smem, st>>>(a);
+    } else {
+        gemm_skinny_kernel<W, 0><<<grid, W * 64, smem, st>>>(a);
+    }
 }
 
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st) {

@@ -50,6 +50,17 @@ struct SkinnyArgs {
     bf16_t* out_rm; int ld_rm;       // ROWMAJOR: [MT*32][ld_rm]
     float* out_f32; int ldo;         // F32: [MT*32][ldo]; rounded to bf16 values if round_bf16
     int round_bf16;
+    // overlapped row update (optional): the first ru_M blocks of the grid first produce one row each of THIS
+    // GEMM's activation operand (split-K slab sum + bias + residual + LayerNorm, or token embedding + LayerNorm)
+    // while every block's weight stream is already in flight; the others wait on `ru_ready`
+    int ru_M;                        // 0 = off
+    const float* ru_ws; int ru_splitk, ru_ldws, ru_rows_ws;      // slabs of the PREVIOUS GEMM (nullptr: embedding mode)
+    const bf16_t* ru_bias;
+    bf16_t* ru_h; int ru_ldh;        // residual stream rows [M][D] (row-major, in/out)
+    const bf16_t* ru_wte; const bf16_t* ru_wpe; const int32_t* ru_tokens; const int32_t* ru_positions;
+    const bf16_t* ru_g; const bf16_t* ru_b; float ru_eps;
+    unsigned* ru_ready;              // arrival counter of this launch site (zeroed at the start of the step)
+    int* ru_err;                     // set if the bounded wait gives up
 };
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st);
 int init_gemm_kernels();        // hipFuncSetAttribute for the large-LDS variants (0 = ok)
