@@ -128,9 +128,10 @@ int  sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int32_t S0, co
 int  sv_last_timing(sv_engine* e, double* out4);
 /* HIP-event timing of one decode step by kernel class, on the cache state left by the last
  * sv_generate / sv_prefill (bench.py roofline leg).  out: 8 doubles, [2k] = ms per step in class k
- * (event to event: execution + launch boundary, comparable to a rocprofv3 dispatch duration),
- * [2k+1] = launches per step; k = 0 skinny weight-streaming GEMM, 1 paged decode attention,
- * 2 residual+LayerNorm row update; [6] = ms between two back-to-back events with no kernel. */
+ * (event deltas minus the empty event-pair time), [2k+1] = launches per step; k = 0 skinny
+ * weight-streaming GEMM, 1 paged decode attention, 2 residual+LayerNorm row update;
+ * [6] = ms between two back-to-back events with no kernel; [7] = ms per step of the step's GEMM launches
+ * enqueued back to back between ONE event pair (dispatch-to-dispatch, as rocprofv3 reports it). */
 int  sv_profile_decode_step(sv_engine* e, int32_t B, int32_t iters, double* out8, sv_stream stream);
 
 /* ---- single operators (parity tests; all device pointers, bf16 unless noted) ------------------ */

@@ -159,7 +159,8 @@ struct sv_engine {
     unsigned* sk_cnt = nullptr;
     unsigned* ru_ready = nullptr;   // one arrival counter per overlapped launch site, zeroed at the start of a step
     int* ru_err = nullptr;
-    int overlap = 1;                // row updates run inside the consumer GEMM's launch (SV_DECODE_OVERLAP=0: separate kernels)
+    int overlap = 0;                // SV_DECODE_OVERLAP=1: row updates ride inside the consumer GEMM's launch (measured slower)
+    bool only_skinny = false;       // profiling: enqueue only the weight-streaming GEMMs of a step
     int ldq = 0;
     float *ws = nullptr, *ws2 = nullptr, *logits = nullptr, *sample_scratch = nullptr, *attn_part = nullptr;
     unsigned* attn_cnt = nullptr;
@@ -669,14 +670,6 @@ static void decode_forward_fused(sv_engine* e, int B, hipStream_t st) {
 // slab pipeline (default; measured faster in situ, profiles/): 7 launches per layer
 //   c_attn -> fp32 slabs | attention (sums the slabs, +bias) | c_proj -> slabs | row update (+bias, +residual, LN2)
 //   | c_fc (bias+GELU epilogue) | c_proj -> slabs | row update (+residual, LN1 of the next layer / ln_f)
-static void skinny_slabs(sv_engine* e, const bf16_t* xp, const Linear& l, int MT, hipStream_t st) {
-    SkinnyArgs a;
-    memset(&a, 0, sizeof(a));
-    a.xp = xp; a.Wp = l.Wp; a.MT = MT; a.Npad = l.Npad; a.K = l.Kpad; a.splitk = l.splitk;
-    a.out_mode = SK_OUT_PARTIAL; a.ws = e->ws; a.ldws = e->ldws; a.N = l.N;
-    launch_gemm_skinny(a, st);
-}
-
 static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
     const sv_config& c = e->cfg;
     const int D = c.hidden, dh = e->dh, F = c.n_inner, MT = (B + 31) / 32;
@@ -693,7 +686,7 @@ static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
     if (e->overlap) (void)hipMemsetAsync(e->ru_ready, 0, 64 * sizeof(unsigned), st);
     // the pending row update either runs as its own launch or rides inside the next GEMM's launch
     auto attach = [&](SkinnyArgs& a) {
-        if (!e->overlap) { prof_mark(e, PK_ROWLN, st); launch_row_update_ln(ru, st); return; }
+        if (!e->overlap) { if (!e->only_skinny) { prof_mark(e, PK_ROWLN, st); launch_row_update_ln(ru, st); } return; }
         a.ru_M = B; a.ru_ws = ru.ws; a.ru_splitk = ru.splitk; a.ru_ldws = ru.ldws; a.ru_rows_ws = ru.rows_ws;
         a.ru_bias = ru.bias; a.ru_h = ru.h; a.ru_ldh = ru.ldh; a.ru_wte = ru.wte; a.ru_wpe = ru.wpe;
         a.ru_tokens = ru.tokens; a.ru_positions = ru.positions; a.ru_g = ru.g; a.ru_b = ru.b; a.ru_eps = ru.eps;
@@ -718,8 +711,7 @@ static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
         ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
         ad.part = e->attn_part; ad.counters = e->attn_cnt;
         ad.max_splits = e->num_cus / B < 1 ? 1 : (e->num_cus / B > 16 ? 16 : e->num_cus / B);
-        prof_mark(e, PK_ATTN, st);
-        launch_attn_decode(ad, st);
+        if (!e->only_skinny) { prof_mark(e, PK_ATTN, st); launch_attn_decode(ad, st); }
         {   // attention output projection -> slabs
             SkinnyArgs a;
             memset(&a, 0, sizeof(a));
@@ -1010,14 +1002,30 @@ extern "C" int sv_profile_decode_step(sv_engine* e, int32_t B, int32_t iters, do
         for (size_t i = 0; i + 1 < e->prof_used; ++i) {
             float ms = 0.f;
             HIPCHECK(hipEventElapsedTime(&ms, e->prof_ev[i], e->prof_ev[i + 1]));
-            // raw event-to-event time: execution + the launch boundary, i.e. what rocprofv3's kernel trace
-            // reports as the dispatch duration (the empty event-pair time is returned separately)
-            out[2 * e->prof_kind[i]] += (double)ms;
+            double d = (double)ms - overhead_ms;      // an event pair with nothing in between costs ~4 us
+            if (d < 0) d = 0;
+            out[2 * e->prof_kind[i]] += d;
             out[2 * e->prof_kind[i] + 1] += 1.0;
         }
     }
     for (int k = 0; k < 2 * PK_COUNT; ++k) out[k] /= (double)iters;
     out[2 * PK_SAMPLE] = overhead_ms;         // slot 6: time between two back-to-back events with no kernel
+    // slot 7: the step's weight-streaming GEMMs alone, back to back between ONE event pair: average
+    // dispatch-to-dispatch time per launch (what rocprofv3's kernel trace calls the kernel duration)
+    if (!e->fused_decode && !e->overlap) {
+        hipEvent_t a, b;
+        HIPCHECK(hipEventCreate(&a)); HIPCHECK(hipEventCreate(&b));
+        e->only_skinny = true;
+        decode_forward(e, B, st);
+        HIPCHECK(hipEventRecord(a, st));
+        for (int it = 0; it < iters; ++it) decode_forward(e, B, st);
+        HIPCHECK(hipEventRecord(b, st));
+        e->only_skinny = false;
+        HIPCHECK(hipEventSynchronize(b));
+        float ms = 0.f; HIPCHECK(hipEventElapsedTime(&ms, a, b));
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        out[2 * PK_SAMPLE + 1] = (double)ms / iters;       // ms per step for the GEMM chain
+    }
     add_i32_kernel<<<(B + 63) / 64, 64, 0, st>>>(e->positions, 1, B);
     HIPCHECK(hipStreamSynchronize(st));
     return 0;

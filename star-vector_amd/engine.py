@@ -182,6 +182,7 @@ class HipEngine:
         names = ["skinny_gemm", "attn_decode", "row_update_ln"]
         res = {n: {"ms_per_step": buf[2 * i], "launches_per_step": buf[2 * i + 1]} for i, n in enumerate(names)}
         res["event_pair_overhead_ms"] = buf[6]
+        res["skinny_chain_ms_per_step"] = buf[7]
         return res
 
 

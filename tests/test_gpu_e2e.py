@@ -244,3 +244,34 @@ def test_full_size_properties_batch32():
         os.environ.pop("SV_NO_GRAPH", None)
     assert torch.equal(a[17], eng.generate(emb[17:18].contiguous(), **kw).cpu()[0])
     eng.close()
+
+
+def test_more_than_one_row_tile_and_short_prompts():
+    """B > 32 exercises the second 32-row tile of every decode kernel (BASELINE configs 3/5 use up to 64 rows per
+    GPU); a text-only prompt (no visual rows) exercises S0 much smaller than a KV page."""
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=51)
+    B = 40
+    eng = build_engine(cfg, w, max_batch=B, max_seq_len=96)
+    img = bf(O.synthetic_images(B, cfg.image_size, seed=52))
+    prompt = torch.tensor([[7, 11]] * B, device=dev())
+    emb = torch.cat([eng.adapter(eng.encode_image(img)), eng.embed_tokens(prompt)], 1)
+    S0 = emb.shape[1]
+    kw = dict(max_length=S0 + 20, eos_token_id=-1, pad_token_id=cfg.pad_token_id)
+    full = eng.generate(emb, **kw).cpu()
+    assert full.shape == (B, 20)
+    for b in (0, 31, 32, 39):                                   # rows of both tiles equal their solo runs
+        assert torch.equal(full[b], eng.generate(emb[b:b + 1].contiguous(), **kw).cpu()[0]), b
+    # teacher-forced logits of row 35 (second tile) against the oracle
+    o_toks, o_lg = O.greedy_generate(w, cfg, emb[35:36].float().cpu(), S0 + 6, mode="bf16", return_logits=True)
+    lg0 = eng.prefill(emb)[35].float().cpu()
+    assert float((lg0 - o_lg[0, 0]).abs().max()) <= LOGIT_TOL * float(o_lg.abs().max())
+    # short prompt: 3 token embeddings only (generate_text2svg-style input)
+    ids = torch.tensor([[5, 9, 13]] * 2, device=dev())
+    e3 = eng.embed_tokens(ids)
+    t3 = eng.generate(e3, max_length=3 + 70, eos_token_id=-1, pad_token_id=0).cpu()     # crosses a 64-token page
+    assert t3.shape == (2, 70) and torch.equal(t3[0], t3[1])
+    o3 = O.greedy_generate(w, cfg, e3[:1].float().cpu(), 3 + 4, mode="bf16", return_logits=True)[1]
+    l3 = eng.prefill(e3)[0].float().cpu()
+    assert float((l3 - o3[0, 0]).abs().max()) <= LOGIT_TOL * float(o3.abs().max())
+    eng.close()
