@@ -275,3 +275,40 @@ def test_more_than_one_row_tile_and_short_prompts():
     l3 = eng.prefill(e3)[0].float().cpu()
     assert float((l3 - o3[0, 0]).abs().max()) <= LOGIT_TOL * float(o3.abs().max())
     eng.close()
+
+
+def _gen_with_env(env, cfg, w, emb_cpu, n_new):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        eng = build_engine(cfg, w, max_batch=4, max_seq_len=96)       # the pipeline is chosen at sv_create
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    emb = emb_cpu.to(dev())
+    toks = eng.generate(emb, max_length=emb.shape[1] + n_new, eos_token_id=-1, pad_token_id=cfg.pad_token_id).cpu()
+    return eng, emb, toks
+
+
+def test_alternative_decode_pipelines_stay_correct():
+    """The two in-launch-fusion pipelines kept behind env switches are slower but must stay
+    right: the overlapped row update performs the same arithmetic in the same order -> bit-identical tokens; the
+    LayerNorm-prologue / ticket pipeline uses single-pass row statistics -> logits within the stated tolerance."""
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=61)
+    base = build_engine(cfg, w, max_batch=4, max_seq_len=96)
+    img = bf(O.synthetic_images(3, cfg.image_size, seed=62))
+    prompt = torch.tensor([[7, 11]] * 3, device=dev())
+    emb = torch.cat([base.adapter(base.encode_image(img)), base.embed_tokens(prompt)], 1)
+    ref = base.generate(emb, max_length=emb.shape[1] + 24, eos_token_id=-1, pad_token_id=cfg.pad_token_id).cpu()
+    base.close()
+    eng, _, toks = _gen_with_env({"SV_DECODE_OVERLAP": "1"}, cfg, w, emb.cpu(), 24)
+    assert torch.equal(toks, ref)
+    eng.close()
+    eng, e2, _ = _gen_with_env({"SV_DECODE_FUSED": "1"}, cfg, w, emb.cpu(), 24)
+    worst, scale, checked, near, _, _ = _teacher_forced_check(eng, e2, w, cfg, 12)
+    assert checked > 0
+    eng.close()
