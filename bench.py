@@ -176,6 +176,12 @@ def main():
         except Exception:
             traffic = None
 
+    # secondary, MFMA-bound kernel (TTFT path): the prefill c_fc GEMM [B*S0, 8192] x [8192, 2048]^T, live
+    from starvector_amd.engine import bench_linear
+    Mp = B_PER_GPU * S0
+    us_fc = bench_linear(Mp, cfg.n_inner, cfg.hidden, act="gelu_tanh", iters=10)
+    tf_fc = 2.0 * Mp * cfg.n_inner * cfg.hidden / us_fc / 1e6
+
     if rank == 0:
         res = {
             "metric": "SVG tokens/sec (whole job) + p50 time-to-first-token, StarVector-1B im2svg batch32/GPU",
@@ -197,6 +203,9 @@ def main():
                          "algorithmic_bytes_per_launch": round(W_BYTES_PER_STEP / launches),
                          "avg_launch_us": round(sk_ms * 1e3 / launches, 2),
                          "avg_exec_us_event_deltas": round(sk_exec_ms * 1e3 / launches, 2)},
+            "roofline_prefill_gemm": {"bound": "mfma", "kernel": "gemm_bf16_kernel (prefill c_fc + GELU epilogue)",
+                                      "achieved": round(tf_fc, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                                      "frac": round(tf_fc / 2500.0, 4), "shape": [Mp, cfg.n_inner, cfg.hidden]},
             "decode_step_profile_ms": {k: round(v["ms_per_step"], 4) for k, v in prof.items() if isinstance(v, dict)},
             "setup_s": round(t_setup, 1),
         }

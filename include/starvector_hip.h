@@ -150,6 +150,9 @@ int  sv_op_linear_skinny(const void* x, const void* W, const void* bias, void* y
 int  sv_op_decode_linear(const void* h, const void* gamma, const void* beta, float eps, const void* W,
                          const void* bias, const void* residual, void* y, float* row_stats, int32_t M, int32_t N,
                          int32_t K, int32_t splitk, int32_t act, sv_stream stream);
+/* micro-benchmark of the big-M MFMA GEMM alone (pseudo-random operands): average microseconds per launch */
+int  sv_bench_linear(int32_t M, int32_t N, int32_t K, int32_t act, int32_t residual, int32_t iters, double* avg_us,
+                     sv_stream stream);
 /* micro-benchmark of the decode GEMM kernel alone: average microseconds per launch over `iters`
  * back-to-back launches (HIP events); ln = LayerNorm prologue on/off; mode = epilogue (0 fp32 slabs,
  * 1 bias+GELU fragment order, 3 bias+residual+statistics, 4 bias row-major) */

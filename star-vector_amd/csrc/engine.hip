@@ -61,6 +61,13 @@ __global__ void tokens_to_i64_kernel(const int32_t* src, int ld, int64_t* dst, i
         dst[(size_t)b * dst_ld + t] = src[(size_t)b * ld + t];
     }
 }
+__global__ void fill_random_bf16_kernel(bf16_t* p, size_t n, unsigned seed) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        unsigned x = (unsigned)i * 2654435761u ^ (seed * 0x9E3779B9u);
+        x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+        p[i] = f2bf(((float)(x >> 8) * (1.0f / 8388608.0f)) - 1.0f);
+    }
+}
 // row-major [M][K] -> skinny fragment order
 __global__ void pack_rows_kernel(const bf16_t* x, int ldx, bf16_t* xp, int M, int K) {
     const int NC = K >> 3;
@@ -1084,6 +1091,43 @@ extern "C" int sv_op_linear(const void* x, const void* W, const void* bias, cons
     launch_gemm(g, st);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// Micro-benchmark of the big-M MFMA GEMM alone (zero-filled... no: uniform random bf16 operands, HIP events)
+extern "C" int sv_bench_linear(int32_t M, int32_t N, int32_t K, int32_t act, int32_t residual, int32_t iters,
+                               double* avg_us, sv_stream stream) {
+    if (!avg_us || M < 1 || N < 32 || N % 4 || K < 64 || K % 64 || iters < 1) return fail(SV_EINVAL, "sv_bench_linear: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    TmpBufs tmp;
+    const int Npad = round_up(N, 32);
+    bf16_t *Wp, *A, *C, *bias, *Wsrc;
+    SVCHECK(tmp.get(&Wp, (size_t)Npad * K));
+    SVCHECK(tmp.get(&Wsrc, (size_t)N * K));
+    SVCHECK(tmp.get(&A, (size_t)M * K));
+    SVCHECK(tmp.get(&C, (size_t)M * N));
+    SVCHECK(tmp.get(&bias, (size_t)N));
+    // pseudo-random operands in [-1, 1): zero-filled data would clock ~20 % higher (cdna guide, rule 25)
+    fill_random_bf16_kernel<<<4096, 256, 0, st>>>(A, (size_t)M * K, 1u);
+    fill_random_bf16_kernel<<<4096, 256, 0, st>>>(Wsrc, (size_t)N * K, 2u);
+    fill_random_bf16_kernel<<<64, 256, 0, st>>>(bias, (size_t)N, 3u);
+    fill_random_bf16_kernel<<<4096, 256, 0, st>>>(C, (size_t)M * N, 4u);
+    launch_pack_weight(Wsrc, 0, Wp, N, K, Npad, K, st);
+    GemmArgs g;
+    g.A = A; g.lda = K; g.Wp = Wp; g.bias = bias; g.R = residual ? C : nullptr; g.ldr = N; g.C = C; g.ldc = N;
+    g.M = M; g.N = N; g.K = K; g.act = act; g.out_f32 = 0;
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 2; ++i) launch_gemm(g, st);
+    HIPCHECK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) launch_gemm(g, st);
+    HIPCHECK(hipEventRecord(e1, st));
+    HIPCHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = (double)ms * 1e3 / iters;
+    HIPCHECK(hipGetLastError());
     return 0;
 }
 

@@ -16,6 +16,7 @@
 // Orientation: MFMA A operand = weight fragment (i = output column n), B operand = activation
 // fragment (j = row m).  D[i=n][j=m]: lane l holds m = l&31 and n = 8*(r>>2) + 4*(l>>5) + (r&3),
 // i.e. 4 consecutive output columns per register group -> 8-byte bf16 stores per row.
+#include <cstdlib>
 #include "kernels.h"
 
 namespace sv {
@@ -93,7 +94,7 @@ __device__ __forceinline__ void lds_dma16(const void* g, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-template <typename OutT>
+template <typename OutT, int VAR>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -147,24 +148,29 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         __syncthreads();
         if (kt + 1 < KT) stage(kt + 1, (kt + 1) & 1);
         const char* base = smem + (kt & 1) * GB_BUF;
+        // all 16 fragments of the K-tile are requested before the first MFMA (64 VGPRs): the LDS latency of
+        // k-step s+1 hides behind the MFMAs of k-step s instead of stalling every second instruction
+        bf16x8 wf[4][2], xf[4][2];
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            bf16x8 wf[2], xf[2];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
-                wf[nt] = *reinterpret_cast<const bf16x8*>(base + 16384 + (((wn * 2 + nt) * 4 + s) * 1024) + lane * 16);
+                wf[s][nt] = *reinterpret_cast<const bf16x8*>(base + 16384 + (((wn * 2 + nt) * 4 + s) * 1024) + lane * 16);
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int r = wm * 64 + mt * 32 + (lane & 31);
                 const int c = (2 * s + (lane >> 5)) ^ ((r >> 1) & 7);
-                xf[mt] = *reinterpret_cast<const bf16x8*>(base + r * 128 + c * 16);
+                xf[s][mt] = *reinterpret_cast<const bf16x8*>(base + r * 128 + c * 16);
             }
+        }
+        if (VAR == 1) __builtin_amdgcn_sched_barrier(0);      // keep the 16 ds_reads ahead of the MFMAs
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
-        }
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][nt], xf[s][mt], acc[nt][mt], 0, 0, 0);
     }
 
     // epilogue: bias -> round to bf16 (the reference's Linear output) -> activation -> (+ residual)
@@ -210,10 +216,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 
 void launch_gemm(const GemmArgs& a, hipStream_t st) {
     dim3 grid((a.N + GB_N - 1) / GB_N, (a.M + GB_M - 1) / GB_M);
+    static const int variant = getenv("SV_GEMM_VARIANT") ? atoi(getenv("SV_GEMM_VARIANT")) : 0;
     if (a.out_f32)
-        gemm_bf16_kernel<float><<<grid, 256, 2 * GB_BUF, st>>>(a);
+        gemm_bf16_kernel<float, 0><<<grid, 256, 2 * GB_BUF, st>>>(a);
+    else if (variant == 1)
+        gemm_bf16_kernel<bf16_t, 1><<<grid, 256, 2 * GB_BUF, st>>>(a);
     else
-        gemm_bf16_kernel<bf16_t><<<grid, 256, 2 * GB_BUF, st>>>(a);
+        gemm_bf16_kernel<bf16_t, 0><<<grid, 256, 2 * GB_BUF, st>>>(a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -186,6 +186,14 @@ class HipEngine:
         return res
 
 
+def bench_linear(M: int, N: int, K: int, act: str = "none", residual: bool = False, iters: int = 10) -> float:
+    """Average microseconds of one big-M MFMA GEMM launch on pseudo-random operands (HIP events)."""
+    lib = _lib.load()
+    us = C.c_double(0.0)
+    check(lib.sv_bench_linear(M, N, K, _lib.ACT[act], int(residual), iters, C.byref(us), _stream()), "sv_bench_linear")
+    return us.value
+
+
 # ---- single operators (used by the parity tests; one per SURVEY.md section 8a row) ----------------
 def op_layernorm(x, gamma, beta, eps=1e-5):
     lib = _lib.load()
