@@ -29,4 +29,6 @@ from .starvector_oracle import (  # noqa: F401
     top_p_filtered_probs,
     generate_im2svg_tokens,
     synthetic_images,
+    siglip_forward,
+    embed_key,
 )

@@ -112,6 +112,74 @@ def reference_outputs(cfg, w, image, prompt_ids, n_new, stop_ids=None):
     return dict(enc=enc, vis=vis, emb=emb, logits0=logits0, tokens=toks, tokens_nocache=nocache)
 
 
+def build_reference_v2(cfg, w):
+    """v2: the reference builds HF SigLIP (image_encoder.py:32-48, keeps .vision_model) and HF
+    Starcoder2ForCausalLM (llm/starcoder2.py:22-27); both un-vendored transformers classes."""
+    from transformers import SiglipVisionConfig, SiglipVisionModel, Starcoder2Config, Starcoder2ForCausalLM
+    sys.path.insert(0, REF)
+    for n in ("fairscale", "fairscale.nn", "fairscale.nn.checkpoint"):
+        sys.modules.setdefault(n, types.ModuleType(n))
+    from starvector.model.adapters.adapter import Adapter
+    vc = SiglipVisionConfig(hidden_size=cfg.vit_width, intermediate_size=cfg.vit_mlp, num_hidden_layers=cfg.vit_layers,
+                            num_attention_heads=cfg.vit_heads, image_size=cfg.image_size, patch_size=cfg.patch_size,
+                            layer_norm_eps=cfg.vit_eps, hidden_act="gelu_pytorch_tanh")
+    vm = SiglipVisionModel(vc)
+    vm = getattr(vm, "vision_model", vm)
+    miss = vm.load_state_dict({k[len(O.P_VIT):]: v for k, v in w.items() if k.startswith(O.P_VIT)}, strict=False)
+    assert not [k for k in miss.missing_keys if not k.startswith("head.")], miss
+    adp = Adapter(cfg.vit_width, cfg.hidden, adapter_norm=cfg.adapter_norm, query_length=cfg.query_length)
+    adp.load_state_dict({k[len(O.P_ADP):]: v for k, v in w.items() if k.startswith(O.P_ADP)}, strict=True)
+    sc = Starcoder2Config(vocab_size=cfg.vocab, hidden_size=cfg.hidden, intermediate_size=cfg.n_inner,
+                          num_hidden_layers=cfg.n_layer, num_attention_heads=cfg.n_head,
+                          num_key_value_heads=cfg.n_kv_head, hidden_act="gelu_pytorch_tanh",
+                          max_position_embeddings=cfg.n_positions, norm_epsilon=cfg.ln_eps, rope_theta=cfg.rope_theta,
+                          sliding_window=4096, use_bias=True, tie_word_embeddings=True, residual_dropout=0.0,
+                          embedding_dropout=0.0, attention_dropout=0.0, bos_token_id=cfg.eos_token_id,
+                          eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id)
+    lm = Starcoder2ForCausalLM(sc)
+    pre = "model.svg_transformer.transformer."
+    lm.load_state_dict({k[len(pre):]: v for k, v in w.items() if k.startswith(pre)}, strict=True)
+    for m in (vm, adp, lm):
+        m.eval()
+    return vm, adp, lm
+
+
+@torch.no_grad()
+def run_case_v2(tag, cfg, seed, batch, n_new, write):
+    print(f"[{tag}] cfg={cfg}")
+    w = O.make_weights(cfg, seed=seed)
+    image = O.synthetic_images(batch, cfg.image_size, seed=seed + 1)
+    prompt_ids = torch.tensor([[7, 11]] * batch, dtype=torch.long)
+    vm, adp, lm = build_reference_v2(cfg, w)
+    r_enc = vm(image)["last_hidden_state"]                       # image_encoder.py:108-109
+    r_vis = adp(r_enc)
+    r_emb = torch.cat([r_vis, lm.model.embed_tokens(prompt_ids)], dim=1)      # starvector_v2.py:45-47
+    mask = torch.ones(r_emb.shape[:2], dtype=torch.long)
+    r_logits0 = lm(inputs_embeds=r_emb, attention_mask=mask).logits[:, -1].float()
+    r_toks = lm.generate(inputs_embeds=r_emb, attention_mask=mask, do_sample=False, num_beams=1, top_p=None,
+                         temperature=None, max_length=r_emb.shape[1] + n_new, use_cache=True,
+                         pad_token_id=cfg.pad_token_id)
+    enc = O.image_encoder_forward(w, cfg, image)
+    vis = O.adapter_forward(w, cfg, enc)
+    emb = O.prepare_generation_inputs(w, cfg, image, prompt_ids)
+    logits0, _ = O.decoder_prefill(w, cfg, emb)
+    toks = O.greedy_generate(w, cfg, emb, emb.shape[1] + n_new)
+    check("siglip tower (a13)", enc, r_enc, 2e-5)
+    check("adapter (a6)", vis, r_vis, 2e-5)
+    check("inputs_embeds", emb, r_emb, 2e-5)
+    check("starcoder2 prefill logits (a13)", logits0, r_logits0, 5e-5)
+    n = r_toks.shape[1]
+    print(f"  greedy tokens == HF generate: {torch.equal(toks[:, :n], r_toks)}; N={n}")
+    assert torch.equal(toks[:, :n], r_toks) and toks.shape[1] == n
+    if write:
+        from safetensors.torch import save_file
+        save_file({"image": image, "prompt_ids": prompt_ids, "enc": r_enc.contiguous(), "vis": r_vis.contiguous(),
+                   "emb": r_emb.contiguous(), "logits0": r_logits0.contiguous(), "tokens": r_toks.contiguous(),
+                   "meta": torch.tensor([seed, batch, n_new], dtype=torch.long)},
+                  os.path.join(GOLD, f"{tag}.safetensors"))
+        print(f"  wrote tests/golden/{tag}.safetensors")
+
+
 def check(name, a, b, tol):
     err = (a - b).abs().max().item()
     ref = b.abs().max().item()
@@ -211,6 +279,7 @@ def main():
     run_case("tiny_bn_b2", dataclasses.replace(O.OracleConfig.tiny(), adapter_norm="batch_norm"),
              seed=4321, batch=2, n_new=8, write=write)
     run_stop_case(write)
+    run_case_v2("tiny_v2_b2", O.OracleConfig.tiny_v2(), seed=2024, batch=2, n_new=12, write=write)
     if "--full" in sys.argv:
         # StarVector-1B shapes, 1 image, a few tokens: validates the restatement at BASELINE
         # config 1 (too large to commit; run on demand)

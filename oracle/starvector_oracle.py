@@ -54,18 +54,39 @@ class OracleConfig:
     eos_token_id: int = 0
     pad_token_id: int = 49152
     ln_eps: float = 1e-5
+    # StarVector-8B (v2): SigLIP vision tower + StarCoder2 decoder
+    arch: str = "v1"              # "v1": CLIP + GPTBigCode (MQA, learned positions); "v2": SigLIP + StarCoder2
+    n_kv_head: int = 1            # v2: GQA key/value heads
+    rope_theta: float = 1e6       # v2: rotary base (bigcode/starcoder2-7b config)
+    vit_mlp: int = 4096           # v2: SigLIP intermediate size
+    vit_eps: float = 1e-6         # v2: SigLIP layer_norm_eps
 
     @property
     def n_patches(self) -> int:
         return (self.image_size // self.patch_size) ** 2
 
     @property
-    def query_length(self) -> int:   # starvector_base.py:85-106
-        return self.n_patches + 1
+    def query_length(self) -> int:   # starvector_base.py:85-106 (clip: 256 patches + cls; siglip_384: 576)
+        return self.n_patches + (1 if self.arch == "v1" else 0)
 
     @property
     def head_dim(self) -> int:
         return self.hidden // self.n_head
+
+    @staticmethod
+    def starvector_8b() -> "OracleConfig":
+        """StarVector-8B: siglip_384 (google/siglip-large-patch16-384) + bigcode/starcoder2-7b
+        (configs/models/starvector-8b/im2svg-stack.yaml:7-11; llm/starcoder2.py:47 adds 4 tokens + [PAD])."""
+        return OracleConfig(image_size=384, patch_size=16, vit_width=1024, vit_layers=24, vit_heads=16, vit_mlp=4096,
+                            hidden=4608, n_layer=32, n_head=36, n_kv_head=4, n_inner=18432, vocab=49152 + 5,
+                            n_positions=16384, eos_token_id=0, pad_token_id=0, arch="v2")
+
+    @staticmethod
+    def tiny_v2() -> "OracleConfig":
+        """Reduced v2 shapes (same op graph: SigLIP tower, RoPE, GQA with 3 query heads per KV head)."""
+        return OracleConfig(image_size=64, patch_size=16, vit_width=128, vit_layers=2, vit_heads=2, vit_mlp=512,
+                            hidden=768, n_layer=2, n_head=6, n_kv_head=2, n_inner=1024, vocab=517,
+                            n_positions=256, eos_token_id=0, pad_token_id=0, arch="v2")
 
     @staticmethod
     def tiny() -> "OracleConfig":
@@ -123,6 +144,9 @@ def iter_weights(cfg: OracleConfig, seed: int = 1234, init: str = "parity"):
         yield name + ".weight", (1.0 + 0.1 * torch.empty(*shape).normal_(0, 1, generator=g)).to(torch.bfloat16).to(torch.float32)
         yield name + ".bias", nrm(*shape, std=0.02)
 
+    if cfg.arch == "v2":
+        yield from _iter_weights_v2(cfg, init, nrm, lin, ln)
+        return
     Dv, ps = cfg.vit_width, cfg.patch_size
     yield P_VIT + "conv1.weight", nrm(Dv, 3, ps, ps, std=(0.02 if init == "std002" else 1.0 / math.sqrt(3 * ps * ps)))
     yield P_VIT + "class_embedding", nrm(Dv, std=Dv ** -0.5 if init != "std002" else 0.02)
@@ -166,11 +190,59 @@ def iter_weights(cfg: OracleConfig, seed: int = 1234, init: str = "parity"):
     yield from ln(P_DEC + "ln_f", D)
 
 
+P_DEC2 = "model.svg_transformer.transformer.model."      # Starcoder2ForCausalLM.model
+
+
+def _iter_weights_v2(cfg: OracleConfig, init, nrm, lin, ln):
+    """State-dict keys of the v2 model: HF SiglipVisionTransformer (image_encoder.py:41-43 keeps `.vision_model`)
+    and HF Starcoder2ForCausalLM (llm/starcoder2.py:22-27)."""
+    Dv, ps = cfg.vit_width, cfg.patch_size
+    pe = P_VIT + "embeddings."
+    yield pe + "patch_embedding.weight", nrm(Dv, 3, ps, ps, std=(0.02 if init == "std002" else 1.0 / math.sqrt(3 * ps * ps)))
+    yield pe + "patch_embedding.bias", nrm(Dv, std=0.02)
+    yield pe + "position_embedding.weight", nrm(cfg.n_patches, Dv, std=(0.3 if init != "std002" else 0.02))
+    for i in range(cfg.vit_layers):
+        p = f"{P_VIT}encoder.layers.{i}."
+        yield from ln(p + "layer_norm1", Dv)
+        yield from lin(p + "self_attn.q_proj", Dv, Dv)
+        yield from lin(p + "self_attn.k_proj", Dv, Dv)
+        yield from lin(p + "self_attn.v_proj", Dv, Dv)
+        yield from lin(p + "self_attn.out_proj", Dv, Dv, gain=0.5)
+        yield from ln(p + "layer_norm2", Dv)
+        yield from lin(p + "mlp.fc1", cfg.vit_mlp, Dv)
+        yield from lin(p + "mlp.fc2", Dv, cfg.vit_mlp, gain=0.5)
+    yield from ln(P_VIT + "post_layernorm", Dv)
+    D = cfg.hidden
+    yield from lin(P_ADP + "c_fc", 2 * Dv, Dv)
+    yield from lin(P_ADP + "c_proj", D, 2 * Dv)
+    if cfg.adapter_norm == "layer_norm":
+        yield from ln(P_ADP + "norm", cfg.query_length, D)
+    else:
+        raise NotImplementedError("v2 oracle weights: layer_norm adapter only (configs/models/starvector-8b)")
+    yield P_DEC2 + "embed_tokens.weight", nrm(cfg.vocab, D, std=0.02)
+    dh, kvd = cfg.head_dim, cfg.n_kv_head * cfg.head_dim
+    for i in range(cfg.n_layer):
+        p = f"{P_DEC2}layers.{i}."
+        yield from ln(p + "input_layernorm", D)
+        yield from lin(p + "self_attn.q_proj", cfg.n_head * dh, D)
+        yield from lin(p + "self_attn.k_proj", kvd, D)
+        yield from lin(p + "self_attn.v_proj", kvd, D)
+        yield from lin(p + "self_attn.o_proj", D, cfg.n_head * dh, gain=0.5)
+        yield from ln(p + "post_attention_layernorm", D)
+        yield from lin(p + "mlp.c_fc", cfg.n_inner, D)
+        yield from lin(p + "mlp.c_proj", D, cfg.n_inner, gain=0.5)
+    yield from ln(P_DEC2 + "norm", D)
+
+
+def embed_key(cfg: OracleConfig) -> str:
+    return (P_DEC + "wte.weight") if cfg.arch == "v1" else (P_DEC2 + "embed_tokens.weight")
+
+
 def make_weights(cfg: OracleConfig, seed: int = 1234, init: str = "parity") -> Dict[str, Tensor]:
     """The whole state_dict of iter_weights, plus the tied lm_head alias
-    (gpt_bigcode/modeling_gpt_bigcode.py:1145)."""
+    (gpt_bigcode/modeling_gpt_bigcode.py:1145; StarCoder2 ties embeddings too)."""
     w = dict(iter_weights(cfg, seed, init))
-    w[K_LMH] = w[P_DEC + "wte.weight"]
+    w[K_LMH] = w[embed_key(cfg)]
     return w
 
 
@@ -227,8 +299,38 @@ def vit_forward(w: Dict[str, Tensor], cfg: OracleConfig, image: Tensor, mode: st
     return x
 
 
+def siglip_forward(w: Dict[str, Tensor], cfg: OracleConfig, image: Tensor, mode: str = "fp32") -> Tensor:
+    """image_encoder.py:108-109 (siglip branch): HF SiglipVisionTransformer(...)["last_hidden_state"], i.e.
+    patch conv (with bias) + learned positions, N pre-LN layers (MHA, GELU-tanh MLP), post_layernorm.
+    Third-party arithmetic (transformers SiglipVisionTransformer; the reference pins transformers==4.49.0)."""
+    r = _rounder(mode)
+    B = image.shape[0]
+    Dv, H = cfg.vit_width, cfg.vit_heads
+    dh = Dv // H
+    pe = P_VIT + "embeddings."
+    x = F.conv2d(image, w[pe + "patch_embedding.weight"], w[pe + "patch_embedding.bias"], stride=cfg.patch_size)
+    x = r(x.flatten(2).transpose(1, 2))
+    x = r(x + w[pe + "position_embedding.weight"])
+    for i in range(cfg.vit_layers):
+        p = f"{P_VIT}encoder.layers.{i}."
+        h = r(_ln(x, w[p + "layer_norm1.weight"], w[p + "layer_norm1.bias"], cfg.vit_eps))
+        q = r(h @ w[p + "self_attn.q_proj.weight"].T + w[p + "self_attn.q_proj.bias"]).view(B, -1, H, dh).transpose(1, 2)
+        k = r(h @ w[p + "self_attn.k_proj.weight"].T + w[p + "self_attn.k_proj.bias"]).view(B, -1, H, dh).transpose(1, 2)
+        v = r(h @ w[p + "self_attn.v_proj.weight"].T + w[p + "self_attn.v_proj.bias"]).view(B, -1, H, dh).transpose(1, 2)
+        pr = r(torch.softmax((q @ k.transpose(-1, -2)) * dh ** -0.5, dim=-1))
+        o = r((pr @ v).transpose(1, 2).reshape(B, -1, Dv))
+        x = r(x + r(o @ w[p + "self_attn.out_proj.weight"].T + w[p + "self_attn.out_proj.bias"]))
+        h = r(_ln(x, w[p + "layer_norm2.weight"], w[p + "layer_norm2.bias"], cfg.vit_eps))
+        f = r(_gelu_tanh(r(h @ w[p + "mlp.fc1.weight"].T + w[p + "mlp.fc1.bias"])))
+        x = r(x + r(f @ w[p + "mlp.fc2.weight"].T + w[p + "mlp.fc2.bias"]))
+    return r(_ln(x, w[P_VIT + "post_layernorm.weight"], w[P_VIT + "post_layernorm.bias"], cfg.vit_eps))
+
+
 def image_encoder_forward(w, cfg: OracleConfig, image: Tensor, mode: str = "fp32") -> Tensor:
-    """image_encoder.py:91-94 (clip branch): ln_vision(visual_encoder(image)) on all tokens."""
+    """image_encoder.py:91-94 (clip branch): ln_vision(visual_encoder(image)) on all tokens;
+    image_encoder.py:108-109 (siglip branch) for v2."""
+    if cfg.arch == "v2":
+        return siglip_forward(w, cfg, image, mode)
     r = _rounder(mode)
     x = vit_forward(w, cfg, image, mode)
     return r(_ln(x, w[P_LNV + "weight"], w[P_LNV + "bias"], cfg.ln_eps))
@@ -303,11 +405,70 @@ def _lm_logits(w, cfg: OracleConfig, h_last: Tensor, r) -> Tensor:
     return r(x @ w[K_LMH].T)
 
 
+def _rope(cfg: OracleConfig, positions: Tensor, r):
+    """Starcoder2RotaryEmbedding: inv_freq = theta^(-2i/d); cos/sin over cat(freqs, freqs), cast to the model dtype."""
+    dh = cfg.head_dim
+    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, dh, 2, dtype=torch.float32) / dh))
+    fr = positions.to(torch.float32)[:, None] * inv[None, :]
+    emb = torch.cat([fr, fr], dim=-1)
+    return r(emb.cos()), r(emb.sin())
+
+
+def _rot_half(x: Tensor) -> Tensor:
+    h = x.shape[-1] // 2
+    return torch.cat([-x[..., h:], x[..., :h]], dim=-1)
+
+
+def _block_v2(w, cfg: OracleConfig, p: str, h: Tensor, k_cache, v_cache, r):
+    """Starcoder2DecoderLayer (transformers modeling_starcoder2): pre-LN, q/k/v/o projections with bias,
+    rotary embedding (rotate_half convention), GQA, GELU-tanh MLP.  Sliding window (4096) is not reached on this
+    path's contexts and is not modelled.  Returns (h, k_all [B,Hkv,L,dh], v_all)."""
+    B, S, D = h.shape
+    H, Hkv, dh = cfg.n_head, cfg.n_kv_head, cfg.head_dim
+    x = r(_ln(h, w[p + "input_layernorm.weight"], w[p + "input_layernorm.bias"], cfg.ln_eps))
+    q = r(x @ w[p + "self_attn.q_proj.weight"].T + w[p + "self_attn.q_proj.bias"]).view(B, S, H, dh).transpose(1, 2)
+    k = r(x @ w[p + "self_attn.k_proj.weight"].T + w[p + "self_attn.k_proj.bias"]).view(B, S, Hkv, dh).transpose(1, 2)
+    v = r(x @ w[p + "self_attn.v_proj.weight"].T + w[p + "self_attn.v_proj.bias"]).view(B, S, Hkv, dh).transpose(1, 2)
+    past = 0 if k_cache is None else k_cache.shape[2]
+    cos, sin = _rope(cfg, torch.arange(past, past + S), r)
+    q = r(r(q * cos) + r(_rot_half(q) * sin))          # apply_rotary_pos_emb in model precision
+    k = r(r(k * cos) + r(_rot_half(k) * sin))
+    if k_cache is not None:
+        k = torch.cat([k_cache, k], dim=2)
+        v = torch.cat([v_cache, v], dim=2)
+    L = k.shape[2]
+    kk = k.repeat_interleave(H // Hkv, dim=1)
+    vv = v.repeat_interleave(H // Hkv, dim=1)
+    s = (q @ kk.transpose(-1, -2)) * dh ** -0.5
+    qi = torch.arange(L - S, L).view(S, 1)
+    kj = torch.arange(L).view(1, L)
+    s = s.masked_fill(kj > qi, float("-inf"))
+    pr = r(torch.softmax(s, dim=-1))
+    o = r((pr @ vv).transpose(1, 2).reshape(B, S, H * dh))
+    h = r(h + r(o @ w[p + "self_attn.o_proj.weight"].T + w[p + "self_attn.o_proj.bias"]))
+    x = r(_ln(h, w[p + "post_attention_layernorm.weight"], w[p + "post_attention_layernorm.bias"], cfg.ln_eps))
+    f = r(_gelu_tanh(r(x @ w[p + "mlp.c_fc.weight"].T + w[p + "mlp.c_fc.bias"])))
+    h = r(h + r(f @ w[p + "mlp.c_proj.weight"].T + w[p + "mlp.c_proj.bias"]))
+    return h, k, v
+
+
+def _forward_v2(w, cfg: OracleConfig, h: Tensor, cache, r):
+    new_cache = []
+    for i in range(cfg.n_layer):
+        kc, vc = (None, None) if cache is None else cache[i]
+        h, k, v = _block_v2(w, cfg, f"{P_DEC2}layers.{i}.", h, kc, vc, r)
+        new_cache.append((k, v))
+    x = r(_ln(h[:, -1, :], w[P_DEC2 + "norm.weight"], w[P_DEC2 + "norm.bias"], cfg.ln_eps))
+    return r(x @ w[K_LMH].T), new_cache
+
+
 def decoder_prefill(w, cfg: OracleConfig, inputs_embeds: Tensor, mode: str = "fp32"):
     """GPTBigCodeModel.forward over the 257+P prompt rows (gpt_bigcode/...:930-1134): position ids
     0..S0-1 from the all-ones mask (:980-985), hidden = inputs_embeds + wpe (:1060-1063).
     Returns (last-row logits [B,V] fp32, kv cache list[(k,v)])."""
     r = _rounder(mode)
+    if cfg.arch == "v2":
+        return _forward_v2(w, cfg, r(inputs_embeds), None, r)
     B, S0, D = inputs_embeds.shape
     h = r(inputs_embeds + w[P_DEC + "wpe.weight"][:S0])
     cache = []
@@ -320,6 +481,8 @@ def decoder_prefill(w, cfg: OracleConfig, inputs_embeds: Tensor, mode: str = "fp
 def decoder_decode_step(w, cfg: OracleConfig, tokens: Tensor, cache, mode: str = "fp32"):
     """One autoregressive step: wte[token] + wpe[pos] -> 24 blocks against the cache -> logits."""
     r = _rounder(mode)
+    if cfg.arch == "v2":
+        return _forward_v2(w, cfg, r(w[embed_key(cfg)][tokens]).unsqueeze(1), cache, r)
     pos = cache[0][0].shape[1]
     h = r(w[P_DEC + "wte.weight"][tokens] + w[P_DEC + "wpe.weight"][pos]).unsqueeze(1)
     new_cache = []
@@ -336,7 +499,7 @@ def prepare_generation_inputs(w, cfg: OracleConfig, image: Tensor, prompt_ids: T
     """starvector_base.py:203-221: encoder -> adapter -> cat(visual, wte(prompt_ids)); ones mask."""
     r = _rounder(mode)
     vis = adapter_forward(w, cfg, image_encoder_forward(w, cfg, image, mode), mode)
-    tok = r(w[P_DEC + "wte.weight"][prompt_ids])                        # starvector_v1.py:16-18
+    tok = r(w[embed_key(cfg)][prompt_ids])                               # starvector_v1.py:16-18 / starvector_v2.py:45-47
     return torch.cat([vis, tok], dim=1)
 
 

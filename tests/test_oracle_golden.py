@@ -95,3 +95,20 @@ def test_top_p_filter_properties():
         assert full[r][kept].min() >= full[r][~kept].max()  # a probability threshold separates them
     # top_p = 1 keeps everything
     assert (O.top_p_filtered_probs(lg, 1.0, 1.0) > 0).all()
+
+
+def test_v2_oracle_reproduces_reference_goldens(golden_dir):
+    """StarVector-8B op graph (SigLIP tower, StarCoder2: RoPE, GQA) at reduced shapes vs HF's own classes."""
+    g = _load(golden_dir, "tiny_v2_b2")
+    seed, B, n_new = [int(x) for x in g["meta"]]
+    cfg = O.OracleConfig.tiny_v2()
+    w = O.make_weights(cfg, seed=seed)
+    enc = O.image_encoder_forward(w, cfg, g["image"])
+    vis = O.adapter_forward(w, cfg, enc)
+    emb = O.prepare_generation_inputs(w, cfg, g["image"], g["prompt_ids"])
+    logits0, _ = O.decoder_prefill(w, cfg, emb)
+    torch.testing.assert_close(enc, g["enc"], rtol=0, atol=2e-5 * float(g["enc"].abs().max()))
+    torch.testing.assert_close(vis, g["vis"], rtol=0, atol=2e-5 * float(g["vis"].abs().max()))
+    torch.testing.assert_close(logits0, g["logits0"], rtol=0, atol=5e-5 * max(1.0, float(g["logits0"].abs().max())))
+    assert torch.equal(O.greedy_generate(w, cfg, emb, emb.shape[1] + n_new), g["tokens"])
+    assert enc.shape == (B, cfg.query_length, cfg.vit_width) and cfg.query_length == cfg.n_patches     # no cls token
