@@ -48,6 +48,7 @@ enum {
 };
 
 enum { SV_DTYPE_BF16 = 0, SV_DTYPE_F32 = 1 };
+enum { SV_ARCH_V1 = 0, SV_ARCH_V2 = 1 };
 enum { SV_NORM_LAYER = 0, SV_NORM_BATCH = 1 };          /* adapter_norm (adapter.py:25-28) */
 enum { SV_ACT_NONE = 0, SV_ACT_QUICKGELU = 1, SV_ACT_SWISH = 2, SV_ACT_GELU_TANH = 3 };
 
@@ -72,6 +73,13 @@ typedef struct sv_config {
     int32_t max_seq_len;       /* prompt + generated tokens per sequence (<= n_positions) */
     float   ln_eps;            /* 1e-5 */
     int32_t device;            /* HIP device ordinal */
+    /* StarVector-8B; sv_config_default_1b() zeroes / defaults them */
+    int32_t arch;              /* SV_ARCH_V1: CLIP + GPTBigCode (MQA, learned positions)
+                                  SV_ARCH_V2: SigLIP tower + StarCoder2 (RoPE, GQA)   */
+    int32_t n_kv_head;         /* v2: key/value heads (v1: 1) */
+    float   rope_theta;        /* v2: rotary base (1e6 for bigcode/starcoder2-7b) */
+    int32_t vit_mlp;           /* v2: SigLIP intermediate size (v1: 4 * vit_width) */
+    float   vit_eps;           /* v2: SigLIP layer_norm_eps 1e-6 (v1: ln_eps) */
 } sv_config;
 
 /* generate(...) arguments that reach HF generate through starvector_base.py:228-241 */
@@ -91,6 +99,7 @@ typedef struct sv_sampling {
 int  sv_abi_version(void);
 const char* sv_last_error(void);
 void sv_config_default_1b(sv_config* cfg);
+void sv_config_default_8b(sv_config* cfg);    /* siglip_384 + starcoder2-7b shapes, max_batch 16 */
 
 int  sv_create(const sv_config* cfg, sv_engine** out);
 int  sv_destroy(sv_engine* e);

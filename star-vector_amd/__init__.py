@@ -6,11 +6,11 @@ sibling shim package maps the importable name onto this directory).
 from ._lib import StarVectorHipError, LIB_PATH, HEADER_PATH  # noqa: F401
 from .engine import EngineConfig, HipEngine  # noqa: F401
 from .model import (  # noqa: F401
-    StarVectorConfig, StarVectorForCausalLM, StarVectorStarCoder, StarCoderModel, ImageEncoder, Adapter,
+    StarVectorConfig, StarVectorForCausalLM, StarVectorStarCoder, StarVectorStarCoder2, StarCoderModel, ImageEncoder, Adapter,
     HipCausalLM, StoppingCriteriaSub, ImageTrainProcessor, ByteTokenizer,
 )
 from . import parallel  # noqa: F401
 
-__all__ = ["EngineConfig", "HipEngine", "StarVectorConfig", "StarVectorForCausalLM", "StarVectorStarCoder",
+__all__ = ["EngineConfig", "HipEngine", "StarVectorConfig", "StarVectorForCausalLM", "StarVectorStarCoder", "StarVectorStarCoder2",
            "StarCoderModel", "ImageEncoder", "Adapter", "HipCausalLM", "StoppingCriteriaSub",
            "ImageTrainProcessor", "ByteTokenizer", "StarVectorHipError", "parallel"]

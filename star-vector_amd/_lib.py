@@ -14,6 +14,7 @@ HEADER_PATH = os.path.normpath(os.path.join(HERE, "..", "include", "starvector_h
 
 SV_DTYPE_BF16, SV_DTYPE_F32 = 0, 1
 SV_NORM_LAYER, SV_NORM_BATCH = 0, 1
+SV_ARCH_V1, SV_ARCH_V2 = 0, 1
 ACT = {"none": 0, "quickgelu": 1, "swish": 2, "gelu_tanh": 3}
 
 
@@ -24,6 +25,8 @@ class SvConfig(C.Structure):
         ("hidden", C.c_int32), ("n_layer", C.c_int32), ("n_head", C.c_int32), ("n_inner", C.c_int32),
         ("vocab", C.c_int32), ("n_positions", C.c_int32), ("max_batch", C.c_int32),
         ("max_seq_len", C.c_int32), ("ln_eps", C.c_float), ("device", C.c_int32),
+        ("arch", C.c_int32), ("n_kv_head", C.c_int32), ("rope_theta", C.c_float), ("vit_mlp", C.c_int32),
+        ("vit_eps", C.c_float),
     ]
 
 
@@ -45,6 +48,7 @@ PROTOTYPES = {
     "sv_abi_version": (_I, []),
     "sv_last_error": (C.c_char_p, []),
     "sv_config_default_1b": (None, [C.POINTER(SvConfig)]),
+    "sv_config_default_8b": (None, [C.POINTER(SvConfig)]),
     "sv_create": (_I, [C.POINTER(SvConfig), C.POINTER(_P)]),
     "sv_destroy": (_I, [_P]),
     "sv_load_weight": (_I, [_P, C.c_char_p, _P, _I, _I, C.POINTER(C.c_int64), _P]),

@@ -234,6 +234,32 @@ __global__ void kv_write_prefill_kernel(const bf16_t* __restrict__ qkv, int row_
         }
     }
 }
+// rotary embedding over the prompt rows (Starcoder2: apply_rotary_pos_emb on q and k before the cache / attention)
+__global__ void rope_prefill_kernel(bf16_t* __restrict__ qkv, int row_stride, int rows, int S0, int n_heads, int D,
+                                    const float* __restrict__ cos_t, const float* __restrict__ sin_t) {
+    const int half = D >> 1;
+    const size_t total = (size_t)rows * n_heads * half;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(i % half);
+        const size_t t = i / half;
+        const int hd = (int)(t % n_heads);
+        const size_t row = t / n_heads;
+        const int pos = (int)(row % S0);
+        bf16_t* pnt = qkv + row * row_stride + (size_t)hd * D;
+        const float x1 = bf2f(pnt[d]), x2 = bf2f(pnt[d + half]);
+        const float cs = cos_t[(size_t)pos * half + d], sn = sin_t[(size_t)pos * half + d];
+        pnt[d] = f2bf(bfround(x1 * cs) + bfround(-x2 * sn));
+        pnt[d + half] = f2bf(bfround(x2 * cs) + bfround(x1 * sn));
+    }
+}
+void launch_rope_prefill(bf16_t* qkv, int row_stride, int rows, int S0, int n_heads, int head_dim, const float* cos_t,
+                         const float* sin_t, hipStream_t st) {
+    size_t total = (size_t)rows * n_heads * (head_dim / 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    rope_prefill_kernel<<<blocks, 256, 0, st>>>(qkv, row_stride, rows, S0, n_heads, head_dim, cos_t, sin_t);
+}
+
 void launch_kv_write_prefill(const bf16_t* qkv, int row_stride, int k_off, int v_off, char* pool_layer,
                              const int32_t* block_table, int max_pages, int B, int S0, int head_dim,
                              hipStream_t st) {
@@ -286,7 +312,9 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     constexpr int NKS = D / 32;          // k-steps of S^T (over head_dim)
     constexpr int NDV = D / 16;          // dv tiles of O^T
     constexpr int PART = 32 + 16 * D;    // floats per partial: m[16], l[16], O[16][D]
-    const int b = blockIdx.x;
+    const int bx = blockIdx.x;               // (sequence, KV head)
+    const int b = bx / p.n_kv;
+    const int kvh = bx % p.n_kv;
     const int split = blockIdx.y;
     const int pos = p.positions[b];
     const int L = pos + 1;
@@ -306,8 +334,10 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int H = p.H;
-    const int HD = H * D;
+    const int H = p.H;                       // all query heads of the model
+    const int G = H / p.n_kv;                // query heads sharing this KV head (<= 16): the MFMA N side
+    const int HD = G * D;                    // output columns owned by this block
+    char* const pool = p.pool_layer + (size_t)kvh * p.kv_head_stride;
 
     const int page_bytes = kv_page_bytes(D);
     const int32_t* table = p.block_table + (size_t)b * p.max_pages;
@@ -315,41 +345,59 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     const int stride = act * AD_WAVES;
     int g = split + act * wave;
     KvFrags<D> fa, fb;
-    if (g < ngroups) load_group<D>(fa, p.pool_layer, table, page_bytes, g, lane);
+    if (g < ngroups) load_group<D>(fa, pool, table, page_bytes, g, lane);
 
     // q / k_new / v_new of this sequence -> LDS (bf16).  Input: the c_attn output rows (bf16, bias added)
     // or, slab pipeline, the fp32 split-K slabs of the c_attn GEMM, summed here in slab order + bias.
     // 4 columns per thread and every load issued before the first add: one memory round trip.
-    if (H < 16)
-        for (int n = HD + tid; n < 16 * D; n += AD_WAVES * 64) q_s[n] = 0;
-    for (int c4 = tid; c4 < (HD + 2 * D) / 4; c4 += AD_WAVES * 64) {
-        const int col = c4 * 4;
-        uint2 o;
-        if (p.qkv) {
-            o = *reinterpret_cast<const uint2*>(p.qkv + (size_t)b * p.ld_qkv + col);
-        } else {
-            float4 acc4[8];
-            const uint2 bb = *reinterpret_cast<const uint2*>(p.bias + col);
+    for (int c4 = tid; c4 < (16 * D + 2 * D) / 4; c4 += AD_WAVES * 64) {
+        const int n = c4 * 4;                    // LDS slot: q rows [0,16*D) (rows >= G are zero), k_new, v_new
+        int col;                                 // column of the c_attn output: q heads | k heads | v heads
+        if (n < 16 * D) col = (n / D) < G ? (kvh * G + n / D) * D + n % D : -1;
+        else if (n < 17 * D) col = H * D + kvh * D + (n - 16 * D);
+        else col = H * D + p.n_kv * D + kvh * D + (n - 17 * D);
+        uint2 o = make_uint2(0u, 0u);
+        if (col >= 0) {
+            if (p.qkv) {
+                o = *reinterpret_cast<const uint2*>(p.qkv + (size_t)b * p.ld_qkv + col);
+            } else {
+                float4 acc4[8];
+                const uint2 bb = *reinterpret_cast<const uint2*>(p.bias + col);
 #pragma unroll
-            for (int sp = 0; sp < 8; ++sp)
-                if (sp < p.splitk)
-                    acc4[sp] = *reinterpret_cast<const float4*>(p.ws + ((size_t)sp * p.rows_ws + b) * p.ldws + col);
-            float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int sp = 0; sp < 8; ++sp)
+                    if (sp < p.splitk)
+                        acc4[sp] = *reinterpret_cast<const float4*>(p.ws + ((size_t)sp * p.rows_ws + b) * p.ldws + col);
+                float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int sp = 0; sp < 8; ++sp)
-                if (sp < p.splitk) { a.x += acc4[sp].x; a.y += acc4[sp].y; a.z += acc4[sp].z; a.w += acc4[sp].w; }
-            o.x = pack2bf(a.x + __uint_as_float(bb.x << 16), a.y + __uint_as_float(bb.x & 0xffff0000u));
-            o.y = pack2bf(a.z + __uint_as_float(bb.y << 16), a.w + __uint_as_float(bb.y & 0xffff0000u));
+                for (int sp = 0; sp < 8; ++sp)
+                    if (sp < p.splitk) { a.x += acc4[sp].x; a.y += acc4[sp].y; a.z += acc4[sp].z; a.w += acc4[sp].w; }
+                o.x = pack2bf(a.x + __uint_as_float(bb.x << 16), a.y + __uint_as_float(bb.x & 0xffff0000u));
+                o.y = pack2bf(a.z + __uint_as_float(bb.y << 16), a.w + __uint_as_float(bb.y & 0xffff0000u));
+            }
         }
-        const int dst = col < HD ? col : 16 * D + (col - HD);      // q rows, then k_new | v_new
-        *reinterpret_cast<uint2*>(q_s + dst) = o;
+        *reinterpret_cast<uint2*>(q_s + n) = o;
     }
     __syncthreads();
+    if (p.rope_cos) {
+        // rotary embedding of the G query rows and of k_new at position `pos` (rotate_half convention; the
+        // products and the sum are rounded to bf16 one by one, as the reference's bf16 tensors are)
+        const float* ct = p.rope_cos + (size_t)pos * (D / 2);
+        const float* st_ = p.rope_sin + (size_t)pos * (D / 2);
+        for (int i = tid; i < (G + 1) * (D / 2); i += AD_WAVES * 64) {
+            const int r = i / (D / 2), d = i % (D / 2);
+            bf16_t* row = r < G ? q_s + r * D : kv_new;
+            const float x1 = bf2f(row[d]), x2 = bf2f(row[d + D / 2]);
+            const float cs = ct[d], sn = st_[d];
+            row[d] = f2bf(bfround(x1 * cs) + bfround(-x2 * sn));
+            row[d + D / 2] = f2bf(bfround(x2 * cs) + bfround(x1 * sn));
+        }
+        __syncthreads();
+    }
 
     // split 0 appends the new token's K / V to the cache (for FUTURE steps; in this launch every block
     // patches the new token into its fragments from LDS, so no block depends on another block's store)
     if (split == 0 && tid < 2 * D) {
-        char* page = p.pool_layer + (size_t)table[pos >> 6] * page_bytes;
+        char* page = pool + (size_t)table[pos >> 6] * page_bytes;
         const int t64 = pos & 63;
         const int d = tid < D ? tid : tid - D;
         const size_t off = tid < D ? kv_k_offset(D, t64, d) : kv_v_offset(D, t64, d);
@@ -434,11 +482,11 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     // two register buffers: the loads of group i+1 are in flight while group i is processed
     while (g < ngroups) {
         const int g1 = g + stride;
-        if (g1 < ngroups) load_group<D>(fb, p.pool_layer, table, page_bytes, g1, lane);
+        if (g1 < ngroups) load_group<D>(fb, pool, table, page_bytes, g1, lane);
         process(fa, g);
         if (g1 >= ngroups) break;
         const int g2 = g1 + stride;
-        if (g2 < ngroups) load_group<D>(fa, p.pool_layer, table, page_bytes, g2, lane);
+        if (g2 < ngroups) load_group<D>(fa, pool, table, page_bytes, g2, lane);
         process(fb, g1);
         g = g2;
     }
@@ -457,8 +505,9 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     __syncthreads();
     // each thread owns 4 consecutive outputs (same head): 16-byte stores for the partial / 8-byte for the result
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        p.part, 0, (unsigned)((size_t)p.B * AD_SPLIT * PART * sizeof(float)), 0x00020000);
-    const int my_off = (int)(((size_t)b * AD_SPLIT + split) * PART * 4);            // bytes
+        p.part, 0, (unsigned)((size_t)p.B * p.n_kv * AD_SPLIT * PART * sizeof(float)), 0x00020000);
+    const int my_off = (int)(((size_t)bx * AD_SPLIT + split) * PART * 4);            // bytes
+    const int col0 = kvh * G * D;            // this block's first output column ((kvh*G + h)*D + dv = col0 + idx)
     for (int idx = tid * 4; idx < 16 * D; idx += AD_WAVES * 64 * 4) {
         const int h = idx / D, dv = idx % D;
         float M = -INFINITY;
@@ -484,7 +533,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
                 uint2 o;
                 o.x = pack2bf(num[0] * inv, num[1] * inv);
                 o.y = pack2bf(num[2] * inv, num[3] * inv);
-                *reinterpret_cast<uint2*>(p.out_xp + xp_index(b >> 5, p.out_KS, b & 31, idx)) = o;
+                *reinterpret_cast<uint2*>(p.out_xp + xp_index(b >> 5, p.out_KS, b & 31, col0 + idx)) = o;
             }
         } else {
             u32x4 v;
@@ -520,12 +569,12 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
-        const unsigned t = __hip_atomic_fetch_add(p.counters + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned t = __hip_atomic_fetch_add(p.counters + bx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         flag_s[0] = (t == (unsigned)(act - 1)) ? 1 : 0;
     }
     __syncthreads();
     if (!flag_s[0]) return;
-    const int seq_off = (int)((size_t)b * AD_SPLIT * PART * 4);
+    const int seq_off = (int)((size_t)bx * AD_SPLIT * PART * 4);
     // merge: every load (statistics of all splits for this thread's head + its O columns) is issued before
     // the first use -> one memory round trip
     for (int idx = tid * 4; idx < HD; idx += AD_WAVES * 64 * 4) {
@@ -557,9 +606,9 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
         uint2 o;
         o.x = pack2bf(num[0] * inv, num[1] * inv);
         o.y = pack2bf(num[2] * inv, num[3] * inv);
-        *reinterpret_cast<uint2*>(p.out_xp + xp_index(b >> 5, p.out_KS, b & 31, idx)) = o;
+        *reinterpret_cast<uint2*>(p.out_xp + xp_index(b >> 5, p.out_KS, b & 31, col0 + idx)) = o;
     }
-    if (tid == 0) __hip_atomic_store(p.counters + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    if (tid == 0) __hip_atomic_store(p.counters + bx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
 }
 
 size_t attn_decode_part_floats(int head_dim) { return (size_t)AD_SPLIT * (32 + 16 * (size_t)head_dim); }
@@ -581,7 +630,7 @@ int init_attention_kernels() {
 
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
     const size_t smem = attn_decode_smem(a.head_dim);
-    dim3 grid(a.B, AD_SPLIT);
+    dim3 grid(a.B * a.n_kv, AD_SPLIT);
     if (a.head_dim == 128)
         attn_decode_kernel<128><<<grid, AD_WAVES * 64, smem, st>>>(a);
     else

@@ -130,12 +130,18 @@ struct Slot {
     size_t numel = 0;
     bool loaded = false;
     bool required = true;
+    int row_off = 0;          // fused projections (q|k|v): first output row of this part inside the Linear
+    int part_rows = 0;        // rows of this part (0 = the whole tensor)
 };
 
 struct sv_engine {
     sv_config cfg;
     std::mutex mu;
     int T = 0, NP = 0, dh = 0, vdh = 0;
+    int nkv = 1, QKV = 0, vit_F = 0;      // KV heads, width of the fused q|k|v projection, ViT MLP width
+    bool v2 = false;
+    float *rope_cos = nullptr, *rope_sin = nullptr;
+    size_t kv_head_stride = 0;
     int conv_K = 0;
 
     // weights
@@ -237,6 +243,13 @@ static void reg_linear(sv_engine* e, const std::string& base, Linear* l, int N, 
         e->slots[base + "bias"] = b;
     }
 }
+// one part of a fused projection: rows [row_off, row_off + rows) of `l` (weight) and of its bias
+static void reg_linear_part(sv_engine* e, const std::string& base, Linear* l, int row_off, int rows, int K) {
+    Slot w; w.kind = SLOT_LINEAR_W; w.lin = l; w.numel = (size_t)rows * K; w.row_off = row_off; w.part_rows = rows;
+    e->slots[base + "weight"] = w;
+    Slot b; b.kind = SLOT_RAW; b.raw = &l->bias; b.numel = (size_t)rows; b.row_off = row_off; b.part_rows = rows;
+    e->slots[base + "bias"] = b;
+}
 static void reg_raw(sv_engine* e, const std::string& name, bf16_t** p, size_t numel, bool required = true) {
     Slot s; s.kind = SLOT_RAW; s.raw = p; s.numel = numel; s.required = required;
     e->slots[name] = s;
@@ -254,6 +267,76 @@ static int pick_splitk(int n_tiles, int KS) {
     return s;
 }
 
+// StarVector-8B key names: HF SiglipVisionTransformer under model.image_encoder.visual_encoder.*
+// (image_encoder.py:41-43) and HF Starcoder2ForCausalLM under model.svg_transformer.transformer.*
+// (llm/starcoder2.py:22-27).  q|k|v projections are separate tensors there; they are packed side by side into
+// ONE fused projection here (parts with a row offset), so the kernels are the same as for v1.
+static void register_v2(sv_engine* e) {
+    const sv_config& c = e->cfg;
+    const int Dv = c.vit_width, D = c.hidden, F = c.n_inner, dh = e->dh, nkv = e->nkv;
+    const std::string pv = "model.image_encoder.visual_encoder.";
+    e->conv1.N = Dv; e->conv1.K = e->conv_K; e->conv1.Npad = round_up(Dv, 32); e->conv1.Kpad = round_up(e->conv_K, 64);
+    { Slot w; w.kind = SLOT_LINEAR_W; w.lin = &e->conv1; w.numel = (size_t)Dv * e->conv_K;
+      e->slots[pv + "embeddings.patch_embedding.weight"] = w; }
+    reg_raw(e, pv + "embeddings.patch_embedding.bias", &e->conv1.bias, Dv);
+    reg_raw(e, pv + "embeddings.position_embedding.weight", &e->pos, (size_t)e->NP * Dv);
+    e->vit.resize(c.vit_layers);
+    for (int i = 0; i < c.vit_layers; ++i) {
+        const std::string p = pv + "encoder.layers." + std::to_string(i) + ".";
+        VitLayer& L = e->vit[i];
+        reg_ln(e, p + "layer_norm1.", &L.ln1, Dv);
+        reg_ln(e, p + "layer_norm2.", &L.ln2, Dv);
+        L.in_proj.N = 3 * Dv; L.in_proj.K = Dv; L.in_proj.Npad = 3 * Dv; L.in_proj.Kpad = Dv;
+        reg_linear_part(e, p + "self_attn.q_proj.", &L.in_proj, 0, Dv, Dv);
+        reg_linear_part(e, p + "self_attn.k_proj.", &L.in_proj, Dv, Dv, Dv);
+        reg_linear_part(e, p + "self_attn.v_proj.", &L.in_proj, 2 * Dv, Dv, Dv);
+        reg_linear(e, p + "self_attn.out_proj.", &L.out_proj, Dv, Dv, 64, true);
+        reg_linear(e, p + "mlp.fc1.", &L.c_fc, e->vit_F, Dv, 64, true);
+        reg_linear(e, p + "mlp.fc2.", &L.c_proj, Dv, e->vit_F, 64, true);
+    }
+    reg_ln(e, pv + "post_layernorm.", &e->ln_vision, Dv);
+
+    const std::string pa = "model.image_projection.";
+    reg_linear(e, pa + "c_fc.", &e->ad_fc, 2 * Dv, Dv, 64, true);
+    reg_linear(e, pa + "c_proj.", &e->ad_proj, D, 2 * Dv, 64, true);
+    if (c.adapter_norm == SV_NORM_LAYER) {
+        reg_raw(e, pa + "norm.weight", &e->ad_w, (size_t)e->T * D);
+        reg_raw(e, pa + "norm.bias", &e->ad_b, (size_t)e->T * D);
+    } else {
+        reg_raw(e, pa + "norm.weight", &e->ad_w, e->T);
+        reg_raw(e, pa + "norm.bias", &e->ad_b, e->T);
+        reg_raw(e, pa + "norm.running_mean", &e->ad_rm, e->T);
+        reg_raw(e, pa + "norm.running_var", &e->ad_rv, e->T);
+    }
+
+    const std::string pd = "model.svg_transformer.transformer.model.";
+    { Slot s; s.kind = SLOT_WTE; s.raw = &e->wte; s.numel = (size_t)c.vocab * D; e->slots[pd + "embed_tokens.weight"] = s; }
+    e->lm_head.N = c.vocab; e->lm_head.K = D; e->lm_head.Npad = round_up(c.vocab, 32); e->lm_head.Kpad = D;
+    { Slot s; s.kind = SLOT_LINEAR_W; s.lin = &e->lm_head; s.numel = (size_t)c.vocab * D; s.required = false;
+      e->slots["model.svg_transformer.transformer.lm_head.weight"] = s; }
+    e->dec.resize(c.n_layer);
+    const int QD = c.n_head * dh, KD = nkv * dh;
+    for (int i = 0; i < c.n_layer; ++i) {
+        const std::string p = pd + "layers." + std::to_string(i) + ".";
+        DecLayer& L = e->dec[i];
+        reg_ln(e, p + "input_layernorm.", &L.ln1, D);
+        reg_ln(e, p + "post_attention_layernorm.", &L.ln2, D);
+        L.c_attn.N = e->QKV; L.c_attn.K = D; L.c_attn.Npad = round_up(e->QKV, 32); L.c_attn.Kpad = D;
+        reg_linear_part(e, p + "self_attn.q_proj.", &L.c_attn, 0, QD, D);
+        reg_linear_part(e, p + "self_attn.k_proj.", &L.c_attn, QD, KD, D);
+        reg_linear_part(e, p + "self_attn.v_proj.", &L.c_attn, QD + KD, KD, D);
+        reg_linear(e, p + "self_attn.o_proj.", &L.c_proj, D, QD, 64, true);
+        reg_linear(e, p + "mlp.c_fc.", &L.c_fc, F, D, 64, true);
+        reg_linear(e, p + "mlp.c_proj.", &L.c_proj2, D, F, 64, true);
+        L.c_attn.splitk = pick_splitk(L.c_attn.Npad / 32, D / 16);
+        L.c_proj.splitk = pick_splitk(L.c_proj.Npad / 32, QD / 16);
+        L.c_fc.splitk = 1;
+        L.c_proj2.splitk = pick_splitk(L.c_proj2.Npad / 32, F / 16);
+        L.c_attn.splitk_fused = L.c_proj.splitk_fused = L.c_fc.splitk_fused = L.c_proj2.splitk_fused = 1;
+    }
+    reg_ln(e, pd + "norm.", &e->ln_f, D);
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI: lifecycle
 // ------------------------------------------------------------------------------------------------
@@ -265,6 +348,16 @@ extern "C" void sv_config_default_1b(sv_config* c) {
     c->adapter_norm = SV_NORM_LAYER; c->hidden = 2048; c->n_layer = 24; c->n_head = 16; c->n_inner = 8192;
     c->vocab = 49156; c->n_positions = 8192; c->max_batch = 32; c->max_seq_len = 2048; c->ln_eps = 1e-5f;
     c->device = 0;
+    c->arch = SV_ARCH_V1; c->n_kv_head = 1; c->rope_theta = 0.f; c->vit_mlp = 4096; c->vit_eps = 1e-5f;
+}
+
+extern "C" void sv_config_default_8b(sv_config* c) {
+    // siglip_384 = google/siglip-large-patch16-384 (image_encoder.py:35-36), bigcode/starcoder2-7b (llm/starcoder2.py:22)
+    c->image_size = 384; c->patch_size = 16; c->vit_width = 1024; c->vit_layers = 24; c->vit_heads = 16;
+    c->adapter_norm = SV_NORM_LAYER; c->hidden = 4608; c->n_layer = 32; c->n_head = 36; c->n_inner = 18432;
+    c->vocab = 49152 + 5; c->n_positions = 16384; c->max_batch = 16; c->max_seq_len = 4096; c->ln_eps = 1e-5f;
+    c->device = 0;
+    c->arch = SV_ARCH_V2; c->n_kv_head = 4; c->rope_theta = 1e6f; c->vit_mlp = 4096; c->vit_eps = 1e-6f;
 }
 
 extern "C" int sv_destroy(sv_engine* e) {
@@ -288,9 +381,15 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     const int vdh = c.vit_width / c.vit_heads, dh = c.hidden / c.n_head;
     if (vdh != 64 && vdh != 128) return fail(SV_EINVAL, "ViT head_dim %d unsupported (64|128)", vdh);
     if (dh != 64 && dh != 128) return fail(SV_EINVAL, "decoder head_dim %d unsupported (64|128)", dh);
-    if (c.n_head > 16) return fail(SV_EINVAL, "MQA decode kernel supports <= 16 query heads per KV head");
+    const bool v2 = c.arch == SV_ARCH_V2;
+    const int nkv = v2 ? c.n_kv_head : 1;
+    if (c.arch != SV_ARCH_V1 && c.arch != SV_ARCH_V2) return fail(SV_EINVAL, "unknown arch %d", c.arch);
+    if (nkv < 1 || c.n_head % nkv) return fail(SV_EINVAL, "n_head %% n_kv_head != 0");
+    if (c.n_head / nkv > 16) return fail(SV_EINVAL, "decode attention supports <= 16 query heads per KV head");
     if (c.vit_width % 64 || c.hidden % 64 || c.n_inner % 64) return fail(SV_EINVAL, "dims must be multiples of 64");
-    if (c.vocab % 4) return fail(SV_EINVAL, "vocab must be a multiple of 4");
+    if (v2 && (c.vit_mlp < 64 || c.vit_mlp % 64 || !(c.rope_theta > 1.f))) return fail(SV_EINVAL, "bad vit_mlp / rope_theta");
+    if (v2 && c.max_seq_len > 4096)
+        return fail(SV_EINVAL, "StarCoder2's 4096-token sliding window is not built: max_seq_len must be <= 4096");
     if (c.max_batch < 1 || c.max_seq_len < 2 || c.max_seq_len > c.n_positions)
         return fail(SV_EINVAL, "bad max_batch / max_seq_len");
     hipError_t r = hipSetDevice(c.device);
@@ -301,11 +400,15 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
 
     sv_engine* e = new sv_engine();
     e->cfg = c;
-    e->vdh = vdh; e->dh = dh;
+    e->vdh = vdh; e->dh = dh; e->v2 = v2; e->nkv = nkv;
     const int G = c.image_size / c.patch_size;
-    e->NP = G * G; e->T = e->NP + 1;
+    e->NP = G * G; e->T = e->NP + (v2 ? 0 : 1);
     const int Dv = c.vit_width, D = c.hidden, F = c.n_inner;
     e->conv_K = 3 * c.patch_size * c.patch_size;
+    e->QKV = c.n_head * dh + 2 * nkv * dh;
+    e->vit_F = v2 ? c.vit_mlp : 4 * Dv;
+    if (v2) register_v2(e);
+    else {
 
     const std::string pv = "model.image_encoder.visual_encoder.";
     reg_linear(e, pv + "conv1.", &e->conv1, Dv, e->conv_K, 64, false);
@@ -369,6 +472,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         if (L.c_proj2.Npad / 32 < 128 && (F / 16) % 32 == 0 && F >= 4096) L.c_proj2.splitk_fused = 4;
     }
     reg_ln(e, pd + "ln_f.", &e->ln_f, D);
+    }   // v1 registration
 
     // ---- workspaces ----
     int rc = 0;
@@ -381,18 +485,18 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     A(dalloc(e, &e->vln, Mv * Dv));
     A(dalloc(e, &e->vqkv, Mv * 3 * Dv));
     A(dalloc(e, &e->vattn, Mv * Dv));
-    A(dalloc(e, &e->vmlp, Mv * 4 * Dv));
+    A(dalloc(e, &e->vmlp, Mv * e->vit_F));
     A(dalloc(e, &e->a1, Mv * 2 * Dv));
     A(dalloc(e, &e->a2, Mv * D));
 
     e->MT = (c.max_batch + 31) / 32;
     const size_t R = (size_t)e->MT * 32;
     e->Vpad = e->lm_head.Npad;
-    e->ldws = round_up(D + 2 * dh, 32);
+    e->ldws = round_up(e->QKV, 32);
     if (e->ldws < D) e->ldws = D;
     A(dalloc(e, &e->h_dec, R * D));
     A(dalloc(e, &e->h_xp, R * D));
-    e->ldq = D + 2 * dh;
+    e->ldq = e->QKV;
     A(dalloc(e, &e->qkv_rm, R * e->ldq));
     A(dalloc(e, &e->ln_stats, R * (D / 32)));
     A(dalloc(e, &e->sk_cnt, (size_t)e->MT * 4096));
@@ -406,8 +510,8 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     A(dalloc(e, &e->ru_err, 4));
     A(dalloc(e, &e->logits, R * e->Vpad));
     A(dalloc(e, &e->sample_scratch, R * 4));
-    A(dalloc(e, &e->attn_part, R * attn_decode_part_floats(dh)));
-    A(dalloc(e, &e->attn_cnt, R));
+    A(dalloc(e, &e->attn_part, R * nkv * attn_decode_part_floats(dh)));
+    A(dalloc(e, &e->attn_cnt, R * nkv));
     A(dalloc(e, &e->am_val, R * 8));
     A(dalloc(e, &e->am_idx, R * 8));
     A(dalloc(e, &e->cur_tok, R));
@@ -424,7 +528,8 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     e->page_bytes = kv_page_bytes(dh);
     e->pages_per_seq = (c.max_seq_len + SV_PAGE_TOKENS - 1) / SV_PAGE_TOKENS;
     e->num_pages = c.max_batch * e->pages_per_seq;
-    e->layer_stride = (size_t)e->num_pages * e->page_bytes;
+    e->kv_head_stride = (size_t)e->num_pages * e->page_bytes;
+    e->layer_stride = e->kv_head_stride * nkv;
     A(dev_alloc(e, reinterpret_cast<void**>(&e->kv_pool), e->layer_stride * c.n_layer, true));
     A(dalloc(e, &e->block_table, (size_t)c.max_batch * e->pages_per_seq));
 #undef A
@@ -442,9 +547,30 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         if (hipGetDeviceProperties(&prop, c.device) == hipSuccess && prop.multiProcessorCount > 0)
             e->num_cus = prop.multiProcessorCount;
     }
+    if (!rc && v2) {
+        // rotary tables, computed in float like the reference's Starcoder2RotaryEmbedding and rounded to bf16
+        // like its `cos.to(dtype=x.dtype)` (values kept in fp32 storage)
+        const int half = dh / 2, npos = c.max_seq_len;
+        std::vector<float> hc((size_t)npos * half), hs((size_t)npos * half);
+        for (int i = 0; i < half; ++i) {
+            const float inv = 1.0f / powf(c.rope_theta, (float)(2 * i) / (float)dh);
+            for (int p_ = 0; p_ < npos; ++p_) {
+                const float fr = (float)p_ * inv;
+                auto bfr = [](float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); u &= 0xffff0000u; float r; memcpy(&r, &u, 4); return r; };
+                hc[(size_t)p_ * half + i] = bfr(cosf(fr));
+                hs[(size_t)p_ * half + i] = bfr(sinf(fr));
+            }
+        }
+        rc = dalloc(e, &e->rope_cos, hc.size(), false);
+        if (!rc) rc = dalloc(e, &e->rope_sin, hs.size(), false);
+        if (!rc && (hipMemcpy(e->rope_cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(e->rope_sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice) != hipSuccess))
+            rc = fail(SV_EHIP, "rope table upload failed");
+    }
     if (getenv("SV_DECODE_OVERLAP")) e->overlap = atoi(getenv("SV_DECODE_OVERLAP")) != 0;
     if (2 * c.n_layer + 1 > 64) e->overlap = 0;
     e->fused_decode = getenv("SV_DECODE_FUSED") != nullptr && atoi(getenv("SV_DECODE_FUSED")) != 0;
+    if (v2) e->fused_decode = false;       // the alternative pipelines are v1-only experiments
     if (rc) { sv_destroy(e); return rc; }
     *out = e;
     return 0;
@@ -459,6 +585,7 @@ extern "C" int sv_load_weight(sv_engine* e, const char* name, const void* dev_pt
     if (dtype != SV_DTYPE_BF16 && dtype != SV_DTYPE_F32) return fail(SV_EINVAL, "unsupported dtype %d", dtype);
     std::lock_guard<std::mutex> lk(e->mu);
     HIPCHECK(hipSetDevice(e->cfg.device));
+    if (strstr(name, ".visual_encoder.head.")) return 0;     // SigLIP pooling head: not on the path (image_encoder.py:109)
     auto it = e->slots.find(name);
     if (it == e->slots.end()) return fail(SV_ENOENT, "unknown weight name '%s'", name);
     Slot& s = it->second;
@@ -472,14 +599,29 @@ extern "C" int sv_load_weight(sv_engine* e, const char* name, const void* dev_pt
         Linear* l = s.kind == SLOT_WTE ? &e->lm_head : s.lin;
         const bool pack = !(s.kind == SLOT_WTE && e->lm_head_explicit);
         if (pack) {
-            if (!l->Wp) SVCHECK(dalloc(e, &l->Wp, (size_t)l->Npad * l->Kpad, false));
-            launch_pack_weight(dev_ptr, is_f32, l->Wp, l->N, l->K, l->Npad, l->Kpad, st);
+            if (!l->Wp) SVCHECK(dalloc(e, &l->Wp, (size_t)l->Npad * l->Kpad, s.part_rows != 0));
+            if (s.part_rows) {
+                // one part of a fused projection: rows [row_off, row_off + part_rows), tile aligned
+                if (s.row_off % 32) return fail(SV_EINVAL, "weight '%s': part offset %d is not a multiple of 32", name, s.row_off);
+                bf16_t* dst = l->Wp + (size_t)(s.row_off / 32) * (l->Kpad / 16) * 512;
+                launch_pack_weight(dev_ptr, is_f32, dst, s.part_rows, l->K, round_up(s.part_rows, 32), l->Kpad, st);
+            } else {
+                launch_pack_weight(dev_ptr, is_f32, l->Wp, l->N, l->K, l->Npad, l->Kpad, st);
+            }
         }
         if (s.kind == SLOT_LINEAR_W && l == &e->lm_head) e->lm_head_explicit = true;
     }
     if (s.kind == SLOT_RAW || s.kind == SLOT_WTE) {
-        if (!*s.raw) SVCHECK(dalloc(e, s.raw, numel, false));
-        launch_convert_to_bf16(dev_ptr, is_f32, *s.raw, numel, st);
+        if (s.part_rows) {          // bias of one part of a fused projection
+            Linear* l = nullptr;
+            for (auto& kv : e->slots) if (kv.second.kind == SLOT_LINEAR_W && kv.second.lin && &kv.second.lin->bias == s.raw) { l = kv.second.lin; break; }
+            const size_t total = l ? (size_t)l->Npad : (size_t)s.row_off + numel;
+            if (!*s.raw) SVCHECK(dalloc(e, s.raw, total, true));
+            launch_convert_to_bf16(dev_ptr, is_f32, *s.raw + s.row_off, numel, st);
+        } else {
+            if (!*s.raw) SVCHECK(dalloc(e, s.raw, numel, false));
+            launch_convert_to_bf16(dev_ptr, is_f32, *s.raw, numel, st);
+        }
     }
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(st));   // the caller may free its tensor right after this returns
@@ -526,11 +668,16 @@ static void decode_gemm(sv_engine* e, const bf16_t* xp, const Linear& l, const L
 
 static int vision_forward(sv_engine* e, const bf16_t* img, int B, bf16_t* out, hipStream_t st) {
     const sv_config& c = e->cfg;
-    const int Dv = c.vit_width, T = e->T, NP = e->NP, M = B * T;
+    const int Dv = c.vit_width, T = e->T, NP = e->NP, M = B * T, Fv = e->vit_F;
+    const float eps = e->v2 ? c.vit_eps : c.ln_eps;
+    const int act = e->v2 ? ACT_GELU_TANH : ACT_QUICKGELU;       // SigLIP gelu_pytorch_tanh | CLIP QuickGELU
     launch_im2col(img, e->patches, B, c.image_size, c.patch_size, e->conv1.Kpad, st);
     gemm(e->patches, e->conv1.Kpad, e->conv1, nullptr, 0, e->patch_out, Dv, B * NP, ACT_NONE, 0, st);
-    launch_vit_embed_lnpre(e->patch_out, Dv, e->cls, e->pos, e->ln_pre.g, e->ln_pre.b, e->vx, B, NP, Dv,
-                           c.ln_eps, st);
+    if (e->v2)      // SigLIP: patches (+conv bias) + learned positions, no class token, no ln_pre
+        launch_dec_embed(e->patch_out, e->pos, e->vx, B, NP, Dv, st);
+    else
+        launch_vit_embed_lnpre(e->patch_out, Dv, e->cls, e->pos, e->ln_pre.g, e->ln_pre.b, e->vx, B, NP, Dv,
+                               c.ln_eps, st);
     AttnPrefillArgs at;
     at.q = e->vqkv; at.k = e->vqkv + Dv; at.v = e->vqkv + 2 * Dv;
     at.q_row_stride = 3 * Dv; at.kv_row_stride = 3 * Dv; at.q_head_stride = e->vdh; at.kv_head_stride = e->vdh;
@@ -538,15 +685,15 @@ static int vision_forward(sv_engine* e, const bf16_t* img, int B, bf16_t* out, h
     at.kv_group = 1; at.causal = 0; at.scale = 1.0f / sqrtf((float)e->vdh);
     for (int i = 0; i < c.vit_layers; ++i) {
         VitLayer& L = e->vit[i];
-        launch_layernorm_rows(e->vx, Dv, L.ln1.g, L.ln1.b, e->vln, Dv, M, Dv, c.ln_eps, st);
+        launch_layernorm_rows(e->vx, Dv, L.ln1.g, L.ln1.b, e->vln, Dv, M, Dv, eps, st);
         gemm(e->vln, Dv, L.in_proj, nullptr, 0, e->vqkv, 3 * Dv, M, ACT_NONE, 0, st);
         launch_attn_prefill(at, st);
         gemm(e->vattn, Dv, L.out_proj, e->vx, Dv, e->vx, Dv, M, ACT_NONE, 0, st);
-        launch_layernorm_rows(e->vx, Dv, L.ln2.g, L.ln2.b, e->vln, Dv, M, Dv, c.ln_eps, st);
-        gemm(e->vln, Dv, L.c_fc, nullptr, 0, e->vmlp, 4 * Dv, M, ACT_QUICKGELU, 0, st);
-        gemm(e->vmlp, 4 * Dv, L.c_proj, e->vx, Dv, e->vx, Dv, M, ACT_NONE, 0, st);
+        launch_layernorm_rows(e->vx, Dv, L.ln2.g, L.ln2.b, e->vln, Dv, M, Dv, eps, st);
+        gemm(e->vln, Dv, L.c_fc, nullptr, 0, e->vmlp, Fv, M, act, 0, st);
+        gemm(e->vmlp, Fv, L.c_proj, e->vx, Dv, e->vx, Dv, M, ACT_NONE, 0, st);
     }
-    launch_layernorm_rows(e->vx, Dv, e->ln_vision.g, e->ln_vision.b, out, Dv, M, Dv, c.ln_eps, st);
+    launch_layernorm_rows(e->vx, Dv, e->ln_vision.g, e->ln_vision.b, out, Dv, M, Dv, eps, st);
     return 0;
 }
 
@@ -569,7 +716,7 @@ static int ensure_prefill_ws(sv_engine* e, size_t rows) {
     // previous buffers stay in e->allocs (freed at destroy); growth is rare (max_batch * S0)
     SVCHECK(dalloc(e, &e->ph, rows * D));
     SVCHECK(dalloc(e, &e->pln, rows * D));
-    SVCHECK(dalloc(e, &e->pqkv, rows * (D + 2 * e->dh)));
+    SVCHECK(dalloc(e, &e->pqkv, rows * (size_t)e->QKV));
     SVCHECK(dalloc(e, &e->pattn, rows * D));
     SVCHECK(dalloc(e, &e->pmlp, rows * c.n_inner));
     e->pf_rows = rows;
@@ -607,22 +754,29 @@ static void lm_head_logits(sv_engine* e, int MT, const bf16_t* xp, const LNp* ln
 
 static int prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hipStream_t st) {
     const sv_config& c = e->cfg;
-    const int D = c.hidden, dh = e->dh, F = c.n_inner, M = B * S0, QKV = D + 2 * dh;
+    const int D = c.hidden, dh = e->dh, F = c.n_inner, M = B * S0, QKV = e->QKV, nkv = e->nkv;
+    const int QD = c.n_head * dh;                      // width of the query block (= D for both model families)
     SVCHECK(ensure_prefill_ws(e, (size_t)M));
-    launch_dec_embed(embeds, e->wpe, e->ph, B, S0, D, st);
+    if (e->v2)      // StarCoder2: no learned positions (rotary), hidden = inputs_embeds
+        HIPCHECK(hipMemcpyAsync(e->ph, embeds, (size_t)M * D * sizeof(bf16_t), hipMemcpyDeviceToDevice, st));
+    else
+        launch_dec_embed(embeds, e->wpe, e->ph, B, S0, D, st);
     AttnPrefillArgs at;
-    at.q = e->pqkv; at.k = e->pqkv + D; at.v = e->pqkv + D + dh;
-    at.q_row_stride = QKV; at.kv_row_stride = QKV; at.q_head_stride = dh; at.kv_head_stride = 0;
-    at.o = e->pattn; at.o_row_stride = D; at.B = B; at.S = S0; at.H = c.n_head; at.head_dim = dh;
-    at.kv_group = c.n_head; at.causal = 1; at.scale = 1.0f / sqrtf((float)dh);
+    at.q = e->pqkv; at.k = e->pqkv + QD; at.v = e->pqkv + QD + nkv * dh;
+    at.q_row_stride = QKV; at.kv_row_stride = QKV; at.q_head_stride = dh; at.kv_head_stride = nkv > 1 ? dh : 0;
+    at.o = e->pattn; at.o_row_stride = QD; at.B = B; at.S = S0; at.H = c.n_head; at.head_dim = dh;
+    at.kv_group = c.n_head / nkv; at.causal = 1; at.scale = 1.0f / sqrtf((float)dh);
     for (int i = 0; i < c.n_layer; ++i) {
         DecLayer& L = e->dec[i];
         launch_layernorm_rows(e->ph, D, L.ln1.g, L.ln1.b, e->pln, D, M, D, c.ln_eps, st);
         gemm(e->pln, D, L.c_attn, nullptr, 0, e->pqkv, QKV, M, ACT_NONE, 0, st);
-        launch_kv_write_prefill(e->pqkv, QKV, D, D + dh, e->kv_pool + (size_t)i * e->layer_stride, e->block_table,
-                                e->pages_per_seq, B, S0, dh, st);
+        if (e->v2) launch_rope_prefill(e->pqkv, QKV, M, S0, c.n_head + nkv, dh, e->rope_cos, e->rope_sin, st);
+        for (int kh = 0; kh < nkv; ++kh)
+            launch_kv_write_prefill(e->pqkv, QKV, QD + kh * dh, QD + nkv * dh + kh * dh,
+                                    e->kv_pool + (size_t)i * e->layer_stride + (size_t)kh * e->kv_head_stride,
+                                    e->block_table, e->pages_per_seq, B, S0, dh, st);
         launch_attn_prefill(at, st);
-        gemm(e->pattn, D, L.c_proj, e->ph, D, e->ph, D, M, ACT_NONE, 0, st);
+        gemm(e->pattn, QD, L.c_proj, e->ph, D, e->ph, D, M, ACT_NONE, 0, st);
         launch_layernorm_rows(e->ph, D, L.ln2.g, L.ln2.b, e->pln, D, M, D, c.ln_eps, st);
         gemm(e->pln, D, L.c_fc, nullptr, 0, e->pmlp, F, M, ACT_GELU_TANH, 0, st);
         gemm(e->pmlp, F, L.c_proj2, e->ph, D, e->ph, D, M, ACT_NONE, 0, st);
@@ -656,7 +810,8 @@ static void decode_forward_fused(sv_engine* e, int B, hipStream_t st) {
         ad.max_pages = e->pages_per_seq; ad.positions = e->positions; ad.out_xp = e->xp_attn; ad.out_KS = D / 16;
         ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
         ad.part = e->attn_part; ad.counters = e->attn_cnt;
-        ad.max_splits = e->num_cus / B < 1 ? 1 : (e->num_cus / B > 16 ? 16 : e->num_cus / B);
+        { const int ms = e->num_cus / (B * e->nkv); ad.max_splits = ms < 1 ? 1 : (ms > 16 ? 16 : ms); }
+        ad.n_kv = e->nkv; ad.kv_head_stride = e->kv_head_stride; ad.rope_cos = e->rope_cos; ad.rope_sin = e->rope_sin;
         prof_mark(e, PK_ATTN, st);
         launch_attn_decode(ad, st);
         prof_mark(e, PK_SKINNY, st);
@@ -717,7 +872,8 @@ static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
         ad.max_pages = e->pages_per_seq; ad.positions = e->positions; ad.out_xp = e->xp_attn; ad.out_KS = D / 16;
         ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
         ad.part = e->attn_part; ad.counters = e->attn_cnt;
-        ad.max_splits = e->num_cus / B < 1 ? 1 : (e->num_cus / B > 16 ? 16 : e->num_cus / B);
+        { const int ms = e->num_cus / (B * e->nkv); ad.max_splits = ms < 1 ? 1 : (ms > 16 ? 16 : ms); }
+        ad.n_kv = e->nkv; ad.kv_head_stride = e->kv_head_stride; ad.rope_cos = e->rope_cos; ad.rope_sin = e->rope_sin;
         if (!e->only_skinny) { prof_mark(e, PK_ATTN, st); launch_attn_decode(ad, st); }
         {   // attention output projection -> slabs
             SkinnyArgs a;

@@ -300,9 +300,14 @@ __device__ __forceinline__ void ru_row(const SkinnyArgs& p, int row, char* smem,
             const int tok = p.ru_tokens[row], pos = p.ru_positions[row];
             float a[8], w[8];
             unpack8(*reinterpret_cast<const uint4*>(p.ru_wte + (size_t)tok * D + c * 8), a);
-            unpack8(*reinterpret_cast<const uint4*>(p.ru_wpe + (size_t)pos * D + c * 8), w);
+            if (p.ru_wpe) {
+                unpack8(*reinterpret_cast<const uint4*>(p.ru_wpe + (size_t)pos * D + c * 8), w);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = bfround(a[e] + w[e]);
+                for (int e = 0; e < 8; ++e) f[e] = bfround(a[e] + w[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = a[e];
+            }
         } else {
             float bb[8], hh[8], v[8];
             unpack8(*reinterpret_cast<const uint4*>(p.ru_bias + c * 8), bb);
@@ -758,9 +763,14 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(EmbedRowsArgs p) {
             const int tok = p.tokens[row], pos = p.positions[row];
             float a[8], w[8];
             unpack8(*reinterpret_cast<const uint4*>(p.wte + (size_t)tok * D + c * 8), a);
-            unpack8(*reinterpret_cast<const uint4*>(p.wpe + (size_t)pos * D + c * 8), w);
+            if (p.wpe) {
+                unpack8(*reinterpret_cast<const uint4*>(p.wpe + (size_t)pos * D + c * 8), w);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = bfround(a[e] + w[e]);
+                for (int e = 0; e < 8; ++e) f[e] = bfround(a[e] + w[e]);
+            } else {                    // rotary models: no learned position table
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = a[e];
+            }
         }
         *reinterpret_cast<uint4*>(p.h_xp + xp_index(row >> 5, KS, row & 31, c * 8)) = pack8(f);
         float s1 = 0.f, s2 = 0.f;

@@ -145,8 +145,14 @@ struct AttnDecodeArgs {
     int B, H, head_dim; float scale;
     float* part;                                           // [B][splits][32 + 16*D] partial (m, l, O)
     unsigned* counters;                                    // [B] arrival tickets, zero between launches
-    int max_splits;                                        // cap on active context splits (#CUs / B, <= 16)
+    int max_splits;                                        // cap on active context splits (#CUs / (B*n_kv), <= 16)
+    int n_kv;                                              // key/value heads (1 = MQA); grid.x = B * n_kv
+    size_t kv_head_stride;                                 // bytes between the page pools of consecutive KV heads
+    const float* rope_cos; const float* rope_sin;          // [positions][D/2] rotary tables (nullptr: no RoPE)
 };
+// in-place rotary embedding of the q and k heads of a prefill c_attn output (rotate_half convention)
+void launch_rope_prefill(bf16_t* qkv, int row_stride, int rows, int S0, int n_heads, int head_dim,
+                         const float* cos_t, const float* sin_t, hipStream_t st);
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t st);
 size_t attn_decode_part_floats(int head_dim);            // floats of `part` per sequence
 int init_attention_kernels();   // returns a hipError_t value (0 = ok)

@@ -82,9 +82,14 @@ __global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
             const int tok = p.tokens[row], pos = p.positions[row];
             float a[8], w[8];
             unpack8(*reinterpret_cast<const uint4*>(p.wte + (size_t)tok * D + c * 8), a);
-            unpack8(*reinterpret_cast<const uint4*>(p.wpe + (size_t)pos * D + c * 8), w);
+            if (p.wpe) {
+                unpack8(*reinterpret_cast<const uint4*>(p.wpe + (size_t)pos * D + c * 8), w);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = bfround(a[e] + w[e]);
+                for (int e = 0; e < 8; ++e) f[e] = bfround(a[e] + w[e]);
+            } else {                    // rotary models: no learned position table
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = a[e];
+            }
         } else {
             float v[8];
 #pragma unroll

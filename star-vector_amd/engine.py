@@ -29,10 +29,24 @@ class EngineConfig:
     max_batch: int = 32
     max_seq_len: int = 2048
     ln_eps: float = 1e-5
+    # StarVector-8B: SigLIP tower + StarCoder2 (RoPE, GQA); defaults describe v1
+    arch: str = "v1"
+    n_kv_head: int = 1
+    rope_theta: float = 1e6
+    vit_mlp: int = 4096
+    vit_eps: float = 1e-6
 
     @property
     def query_length(self) -> int:
-        return (self.image_size // self.patch_size) ** 2 + 1
+        return (self.image_size // self.patch_size) ** 2 + (1 if self.arch == "v1" else 0)
+
+    @staticmethod
+    def starvector_8b(max_batch: int = 16, max_seq_len: int = 4096) -> "EngineConfig":
+        """siglip_384 (google/siglip-large-patch16-384) + bigcode/starcoder2-7b shapes."""
+        return EngineConfig(image_size=384, patch_size=16, vit_width=1024, vit_layers=24, vit_heads=16, hidden=4608,
+                            n_layer=32, n_head=36, n_inner=18432, vocab=49152 + 5, n_positions=16384,
+                            max_batch=max_batch, max_seq_len=max_seq_len, arch="v2", n_kv_head=4, rope_theta=1e6,
+                            vit_mlp=4096, vit_eps=1e-6)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -63,7 +77,9 @@ class HipEngine:
         c = SvConfig(cfg.image_size, cfg.patch_size, cfg.vit_width, cfg.vit_layers, cfg.vit_heads,
                      _lib.SV_NORM_LAYER if cfg.adapter_norm == "layer_norm" else _lib.SV_NORM_BATCH,
                      cfg.hidden, cfg.n_layer, cfg.n_head, cfg.n_inner, cfg.vocab, cfg.n_positions,
-                     cfg.max_batch, cfg.max_seq_len, cfg.ln_eps, self.device)
+                     cfg.max_batch, cfg.max_seq_len, cfg.ln_eps, self.device,
+                     _lib.SV_ARCH_V2 if cfg.arch == "v2" else _lib.SV_ARCH_V1, cfg.n_kv_head, cfg.rope_theta,
+                     cfg.vit_mlp, cfg.vit_eps if cfg.arch == "v2" else cfg.ln_eps)
         h = C.c_void_p()
         check(self.lib.sv_create(C.byref(c), C.byref(h)), "sv_create")
         self._h = h
@@ -98,7 +114,8 @@ class HipEngine:
         """Ingest a reference state_dict (keys as saved by the reference, train/util.py:71)."""
         skipped = []
         for k, v in sd.items():
-            if k.endswith("num_batches_tracked") or k.endswith(".attn.bias") or k.endswith(".attn.masked_bias"):
+            if k.endswith("num_batches_tracked") or k.endswith(".attn.bias") or k.endswith(".attn.masked_bias") \
+                    or ".visual_encoder.head." in k or k.endswith("rotary_emb.inv_freq"):
                 continue
             try:
                 self.load_weight(k, v)

@@ -65,15 +65,29 @@ class StarVectorConfig:
         for k, v in kwargs.items():
             setattr(self, k, v)
 
+    @property
+    def is_v2(self) -> bool:                      # starvector_arch.py:139-144 picks the class the same way
+        return "starcoder2" in self.starcoder_model_name
+
     def engine_config(self) -> EngineConfig:
-        if "starcoder2" in self.starcoder_model_name:
-            raise NotImplementedError("StarVector-8B (StarCoder2 + SigLIP) is a later row of the build plan "
-                                      "(SURVEY.md section 8f rank 3)")
-        if self.image_encoder_type != "clip":
-            raise NotImplementedError(f"image_encoder_type={self.image_encoder_type!r}: only the clip branch is built")
         if str(self.torch_dtype).replace("torch.", "") not in ("bfloat16", "auto"):
             raise ValueError("the HIP engine computes in bfloat16 (BASELINE config 2); got torch_dtype="
                              f"{self.torch_dtype}")
+        if self.is_v2:
+            # StarVector-8B: siglip_384 tower + StarCoder2 decoder (configs/models/starvector-8b/im2svg-stack.yaml)
+            if self.image_encoder_type != "siglip_384":
+                raise NotImplementedError(f"image_encoder_type={self.image_encoder_type!r}: v2 is built for siglip_384")
+            g = lambda k, d: getattr(self, k, d)
+            return EngineConfig(image_size=g("siglip_image_size", 384), patch_size=g("siglip_patch_size", 16),
+                                vit_width=self.vit_width, vit_layers=g("siglip_layers", 24), vit_heads=self.vit_heads,
+                                adapter_norm=self.adapter_norm, hidden=self.hidden_size, n_layer=self.num_hidden_layers,
+                                n_head=self.num_attention_heads, n_inner=self.n_inner,
+                                vocab=self.vocab_size + self.added_tokens, n_positions=self.n_positions,
+                                max_batch=self.max_batch, max_seq_len=min(self.max_length, 4096), arch="v2",
+                                n_kv_head=self.num_kv_heads, rope_theta=g("rope_theta", 1e6),
+                                vit_mlp=g("siglip_mlp", 4096), vit_eps=1e-6)
+        if self.image_encoder_type != "clip":
+            raise NotImplementedError(f"image_encoder_type={self.image_encoder_type!r}: v1 is built for the clip branch")
         return EngineConfig(image_size=self.image_size, patch_size=self.patch_size, vit_width=self.vit_width,
                             vit_layers=self.vit_layers, vit_heads=self.vit_heads, adapter_norm=self.adapter_norm,
                             hidden=self.hidden_size, n_layer=self.num_hidden_layers, n_head=self.num_attention_heads,
@@ -100,16 +114,18 @@ class ByteTokenizer:
     """Deterministic byte-level stand-in with the tokenizer surface the path uses
     (llm/starcoder.py:40-53): eos id 0, ``[PAD]`` = vocab_size, then the three added tokens."""
 
-    def __init__(self, vocab_size: int = 49152):
+    def __init__(self, vocab_size: int = 49152, v2: bool = False):
         self.vocab_size = vocab_size
         self.eos_token, self.eos_token_id = "<|endoftext|>", 0
         self.bos_token_id = 0
         self.pad_token, self.pad_token_id = "[PAD]", vocab_size
         self.added = {"<svg-start>": vocab_size + 1, "<image-start>": vocab_size + 2, "<caption-start>": vocab_size + 3}
-        self.padding_side = "right"
+        if v2:                                    # llm/starcoder2.py:47 adds <svg-end> too, pads on the left (:53)
+            self.added["<svg-end>"] = vocab_size + 4
+        self.padding_side = "left" if v2 else "right"
 
     def __len__(self):
-        return self.vocab_size + 4
+        return self.vocab_size + 1 + len(self.added)
 
     def encode(self, text: str, add_special_tokens: bool = False) -> List[int]:
         if text in self.added:
@@ -217,11 +233,13 @@ class _TokenEmbedding(_EngineModule):
 
 
 class _Backbone(_EngineModule):
-    """stand-in for GPTBigCodeModel: exposes ``wte`` (starvector_v1.py:16-18)."""
+    """stand-in for GPTBigCodeModel / Starcoder2Model: exposes ``wte`` (starvector_v1.py:16-18) and
+    ``embed_tokens`` (starvector_v2.py:45-47)."""
 
     def __init__(self, engine: HipEngine):
         super().__init__(engine)
         self.wte = _TokenEmbedding(engine)
+        self.embed_tokens = self.wte
 
 
 class HipCausalLM(_EngineModule):
@@ -230,7 +248,8 @@ class HipCausalLM(_EngineModule):
 
     def __init__(self, engine: HipEngine, eos_token_id: int, pad_token_id: int):
         super().__init__(engine)
-        self.transformer = _Backbone(engine)
+        self.transformer = _Backbone(engine)          # GPTBigCodeForCausalLM.transformer
+        self.model = self.transformer                 # Starcoder2ForCausalLM.model
         self.eos_token_id = eos_token_id
         self.pad_token_id = pad_token_id
         self.seed = 0
@@ -295,27 +314,33 @@ class StoppingCriteriaSub:
 class StarCoderModel(nn.Module):
     """llm/starcoder.py:9-53: tokenizer + causal LM + the '<svg' prompt."""
 
-    def __init__(self, engine: HipEngine, tokenizer, max_length: int):
+    def __init__(self, engine: HipEngine, tokenizer, max_length: int, v2: bool = False):
         super().__init__()
         self.tokenizer = tokenizer
         self.max_length = max_length
-        self.transformer = HipCausalLM(engine, tokenizer.eos_token_id, tokenizer.pad_token_id)
+        # v1 passes pad_token_id=[PAD] explicitly (starvector_base.py:289-295); v2 passes nothing
+        # (starvector_v2.py:53-57), so HF falls back to pad_token_id = eos_token_id
+        self.transformer = HipCausalLM(engine, tokenizer.eos_token_id,
+                                       tokenizer.eos_token_id if v2 else tokenizer.pad_token_id)
         self.prompt = "<svg"
         self.svg_start_token = "<svg-start>"
         self.image_start_token = "<image-start>"
         self.text_start_token = "<caption-start>"
         self.svg_start_token_id = tokenizer.encode(self.svg_start_token)[0]
+        if v2:
+            self.svg_end_token = "<svg-end>"
+            self.svg_end_token_id = tokenizer.encode(self.svg_end_token)[0]
 
 
 class StarVectorStarCoder(nn.Module):
     """StarVectorBase + v1 binding (starvector_base.py:22-48,203-295; starvector_v1.py)."""
 
-    def __init__(self, config: StarVectorConfig, engine: HipEngine, tokenizer):
+    def __init__(self, config: StarVectorConfig, engine: HipEngine, tokenizer, v2: bool = False):
         super().__init__()
         self.task = "im2svg"
         self.model_precision = torch.bfloat16
         ec = engine.cfg
-        self.svg_transformer = StarCoderModel(engine, tokenizer, config.max_length)
+        self.svg_transformer = StarCoderModel(engine, tokenizer, config.max_length, v2=v2)
         self.image_encoder = ImageEncoder(engine, ec.image_size)
         self.query_length = ec.query_length                          # starvector_base.py:85-106
         self.image_projection = Adapter(engine, self.query_length, ec.adapter_norm)
@@ -379,6 +404,19 @@ class StarVectorStarCoder(nn.Module):
         return {"raw_svg": raw_svg, "outputs": outputs, "inputs_embeds": inputs_embeds}
 
 
+class StarVectorStarCoder2(StarVectorStarCoder):
+    """v2 binding (starvector_v2.py:8-63): StarCoder2 decoder, SigLIP tower, `embed_tokens`, no im2svg kwargs."""
+
+    def __init__(self, config: StarVectorConfig, engine: HipEngine, tokenizer):
+        super().__init__(config, engine, tokenizer, v2=True)
+
+    def _get_embeddings(self, input_ids):                             # starvector_v2.py:45-47
+        return self.svg_transformer.transformer.model.embed_tokens(input_ids)
+
+    def _get_im2svg_specific_kwargs(self, kwargs):                    # starvector_v2.py:53-57
+        return {}
+
+
 class StarVectorForCausalLM(nn.Module):
     """starvector_arch.py:133-193 facade."""
     config_class = StarVectorConfig
@@ -391,8 +429,9 @@ class StarVectorForCausalLM(nn.Module):
         if state_dict is not None:
             self.engine.load_state_dict(state_dict)
         if tokenizer is None:
-            tokenizer = ByteTokenizer(config.vocab_size)
-        self.model = StarVectorStarCoder(config, self.engine, tokenizer)
+            tokenizer = ByteTokenizer(config.vocab_size, v2=config.is_v2)
+        cls = StarVectorStarCoder2 if config.is_v2 else StarVectorStarCoder       # starvector_arch.py:139-144
+        self.model = cls(config, self.engine, tokenizer)
 
     @classmethod
     def from_pretrained(cls, path: str, torch_dtype="bfloat16", tokenizer=None, **kwargs):

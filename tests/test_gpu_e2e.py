@@ -312,3 +312,34 @@ def test_alternative_decode_pipelines_stay_correct():
     worst, scale, checked, near, _, _ = _teacher_forced_check(eng, e2, w, cfg, 12)
     assert checked > 0
     eng.close()
+
+
+def test_starvector_8b_op_graph_against_reference_golden():
+    """SURVEY.md section 8a row a13 at reduced shapes: SigLIP tower (conv bias, no class token, GELU-tanh, post LN) +
+    StarCoder2 decoder (fused q|k|v from three tensors, RoPE, GQA with 3 query heads per KV head, no position
+    table).  Golden = HF SiglipVisionModel + Starcoder2ForCausalLM.generate (tests/golden/tiny_v2_b2)."""
+    g = _golden("tiny_v2_b2")
+    seed, B, n_new = [int(x) for x in g["meta"]]
+    cfg = O.OracleConfig.tiny_v2()
+    w = O.make_weights(cfg, seed=seed)
+    eng = build_engine(cfg, w, max_batch=4, max_seq_len=96)
+    enc = eng.encode_image(bf(g["image"]))
+    vis = eng.adapter(enc)
+    emb = torch.cat([vis, eng.embed_tokens(g["prompt_ids"].to(dev()))], 1)
+    assert enc.shape == (B, cfg.query_length, cfg.vit_width) and cfg.query_length == 16
+    assert rel_err(enc, g["enc"]) <= 3e-2 and rel_err(vis, g["vis"]) <= 3e-2 and rel_err(emb, g["emb"]) <= 3e-2
+    assert rel_err(eng.prefill(emb), g["logits0"]) <= 5e-2
+    worst, scale, checked, near, o_toks, margin = _teacher_forced_check(eng, emb, w, cfg, n_new)
+    assert checked > 0
+    print(f"[tiny_v2] logits max|err| {worst:.3e} (scale {scale:.3e}); {checked} token positions checked exactly, {near} near-tie flips")
+    # determinism + graph == eager + a longer decode crossing a KV page with RoPE positions
+    kw = dict(max_length=emb.shape[1] + 70, eos_token_id=-1, pad_token_id=0)
+    a = eng.generate(emb, **kw).cpu()
+    os.environ["SV_NO_GRAPH"] = "1"
+    try:
+        b2 = eng.generate(emb, **kw).cpu()
+    finally:
+        os.environ.pop("SV_NO_GRAPH", None)
+    assert a.shape == (B, 70) and torch.equal(a, b2)
+    assert torch.equal(a[1], eng.generate(emb[1:2].contiguous(), **kw).cpu()[0])
+    eng.close()

@@ -14,8 +14,13 @@ def test_config_maps_to_engine_shapes():
     assert (ec.vit_width, ec.vit_layers, ec.vit_heads, ec.hidden, ec.n_layer, ec.n_head, ec.n_inner) == \
         (1024, 23, 16, 2048, 24, 16, 8192)
     assert ec.vocab == 49152 + 4 and ec.query_length == 257          # SURVEY.md section 8 header
+    v2 = StarVectorConfig(starcoder_model_name="bigcode/starcoder2-7b", image_encoder_type="siglip_384", hidden_size=4608,
+                          num_hidden_layers=32, num_attention_heads=36, num_kv_heads=4, n_inner=18432, added_tokens=5,
+                          n_positions=16384, max_length=16000, max_batch=16).engine_config()
+    assert (v2.arch, v2.n_kv_head, v2.hidden, v2.n_head, v2.n_inner, v2.vocab) == ("v2", 4, 4608, 36, 18432, 49157)
+    assert v2.query_length == 576 and v2.max_seq_len == 4096            # siglip_384: 24x24 patches, no class token
     with pytest.raises(NotImplementedError):
-        StarVectorConfig(starcoder_model_name="bigcode/starcoder2-7b").engine_config()
+        StarVectorConfig(starcoder_model_name="bigcode/starcoder2-7b", image_encoder_type="clip").engine_config()
     with pytest.raises(ValueError):
         StarVectorConfig(torch_dtype="float16").engine_config()
 
