@@ -30,12 +30,16 @@ sys.path.insert(0, ROOT)
 
 from oracle.hostinfo import host_cores  # noqa: E402  (cpu_baseline leg only)
 
-B_PER_GPU = 32
 PROMPT_IDS = [7, 11]          # '<svg' is 2 ids under the (gated, offline) StarCoder tokenizer: synthetic stand-ins
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 
-# algorithmic bytes of the dominant kernel
-W_BYTES_PER_STEP = 2 * (24 * 42_490_112 + 4_096 + 100_671_488)     # decoder weights streamed per decode step
-HBM_PEAK_GBS = 8000.0                                              # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+def decoder_weight_bytes(cfg) -> int:
+    """Algorithmic bytes of the dominant kernel per decode step: every decoder Linear weight + the tied lm_head,
+    bf16, streamed once (2,240,876,544 B for StarVector-1B)."""
+    qkv = cfg.n_head * cfg.head_dim + 2 * cfg.n_kv_head * cfg.head_dim
+    per_layer = cfg.hidden * (qkv + cfg.n_head * cfg.head_dim + 2 * cfg.n_inner)
+    return 2 * (cfg.n_layer * per_layer + cfg.vocab * cfg.hidden)
 
 
 def parse():
@@ -44,6 +48,8 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--new-tokens", type=int, default=1024)
+    ap.add_argument("--model", choices=["1b", "8b"], default="1b",
+                    help="1b: BASELINE config 2 (batch 32, greedy); 8b: config 4 (StarVector-8B, batch 16, top-p 0.95)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ttft-requests", type=int, default=20)
     return ap.parse_args()
@@ -91,13 +97,17 @@ def main():
     from starvector_amd.parallel import all_gather_token_streams
     from oracle import starvector_oracle as O        # weight factory + synthetic inputs + cpu_baseline only
 
-    cfg = O.OracleConfig()
+    is8b = args.model == "8b"
+    cfg = O.OracleConfig.starvector_8b() if is8b else O.OracleConfig()
+    B_PER_GPU = 16 if is8b else 32
+    W_BYTES_PER_STEP = decoder_weight_bytes(cfg)
     n_new = args.new_tokens
     S0 = cfg.query_length + len(PROMPT_IDS)
     t_setup = time.time()
-    ec = sva.EngineConfig(max_batch=B_PER_GPU, max_seq_len=S0 + n_new)
+    ec = (sva.EngineConfig.starvector_8b(max_batch=B_PER_GPU, max_seq_len=S0 + n_new) if is8b
+          else sva.EngineConfig(max_batch=B_PER_GPU, max_seq_len=S0 + n_new))
     eng = sva.HipEngine(ec, device=local_rank)
-    keep_cpu = (world == 1 and rank == 0 and not args.no_cpu_baseline)
+    keep_cpu = (world == 1 and rank == 0 and not args.no_cpu_baseline and not is8b)   # 8B fp32 on CPU: 29 GB, skipped
     w = {}
     for name, t in O.iter_weights(cfg, seed=1234, init="std002"):      # streamed: fp32 -> bf16 + fragment
         eng.load_weight(name, t)                                       # packing on device, one tensor at a time
@@ -117,7 +127,8 @@ def main():
         vis = eng.adapter(enc)                                 # a6
         emb = torch.cat([vis, eng.embed_tokens(prompt)], 1)    # a1, a7
         new = eng.generate(emb, max_length=S0 + max_new, eos_token_id=-1,      # EOS disabled:
-                           pad_token_id=cfg.pad_token_id)                      # fixed-length workload
+                           pad_token_id=cfg.pad_token_id,                      # fixed-length workload
+                           do_sample=is8b, temperature=1.0, top_p=0.95, seed=1)    # config 4 samples (top-p 0.95)
         out = torch.cat([prompt, new], 1)                      # starvector_base.py:256
         if world > 1:
             out = all_gather_token_streams(out, cfg.pad_token_id, B_PER_GPU * world)
@@ -179,25 +190,27 @@ def main():
     # secondary, MFMA-bound kernel (TTFT path): the prefill c_fc GEMM [B*S0, 8192] x [8192, 2048]^T, live
     from starvector_amd.engine import bench_linear
     Mp = B_PER_GPU * S0
-    us_fc = bench_linear(Mp, cfg.n_inner, cfg.hidden, act="gelu_tanh", iters=10)
+    us_fc = bench_linear(Mp, cfg.n_inner, cfg.hidden, act="gelu_tanh", iters=5 if is8b else 10)
     tf_fc = 2.0 * Mp * cfg.n_inner * cfg.hidden / us_fc / 1e6
 
     if rank == 0:
         res = {
-            "metric": "SVG tokens/sec (whole job) + p50 time-to-first-token, StarVector-1B im2svg batch32/GPU",
+            "metric": f"SVG tokens/sec (whole job) + p50 time-to-first-token, StarVector-{args.model.upper()} im2svg batch{B_PER_GPU}/GPU",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": "synthetic: random-pixel 224x224 images (CLIP-normalised), random-init weights N(0,0.02) seed 1234",
-            "config": {"workload": f"StarVector-1B im2svg, batch {B_PER_GPU}/GPU, bf16, greedy, 224x224, prompt rows "
-                                   f"{S0} (257 visual + {len(PROMPT_IDS)}), {n_new} new tokens/seq, EOS disabled",
+            "config": {"workload": (f"StarVector-8B im2svg, batch {B_PER_GPU}/GPU, bf16, top-p 0.95, 384x384, prompt rows "
+                                    f"{S0} (576 visual + {len(PROMPT_IDS)}), {n_new} new tokens/seq, EOS disabled") if is8b else
+                                   (f"StarVector-1B im2svg, batch {B_PER_GPU}/GPU, bf16, greedy, 224x224, prompt rows "
+                                    f"{S0} (257 visual + {len(PROMPT_IDS)}), {n_new} new tokens/seq, EOS disabled"),
                        "global_batch": B_PER_GPU * world, "new_tokens": n_new,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "hipgraph_decode": bool(graph)},
             "tokens_per_s_per_gpu": round(value / world, 1),
             "ttft_p50_ms": round(ttft_p50, 2) if ttft_p50 is not None else None,
             "decode_us_per_step": round(decode_ms / max(decode_steps, 1) * 1e3, 1),
-            "roofline": {"bound": "hbm", "kernel": "gemm_skinny_kernel (decoder weight streaming, 97 launches/step)",
+            "roofline": {"bound": "hbm", "kernel": f"gemm_skinny_kernel (decoder weight streaming, {int(launches)} launches/step)",
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
                          "algorithmic_bytes_per_launch": round(W_BYTES_PER_STEP / launches),

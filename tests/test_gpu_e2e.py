@@ -343,3 +343,34 @@ def test_starvector_8b_op_graph_against_reference_golden():
     assert a.shape == (B, 70) and torch.equal(a, b2)
     assert torch.equal(a[1], eng.generate(emb[1:2].contiguous(), **kw).cpu()[0])
     eng.close()
+
+
+def test_starvector_8b_full_size_properties():
+    """BASELINE config 4 shapes (siglip_384 + starcoder2-7b: 7.2 B parameters, 36 query / 4 KV heads, D 4608):
+    the CPU oracle cannot run this size in test time, so the full size is covered by size-independent properties -
+    bit-exact determinism, graph == eager, batch invariance of a row, token range, and the top-p sampling path."""
+    import starvector_amd as sva
+    cfg = O.OracleConfig.starvector_8b()
+    eng = sva.HipEngine(sva.EngineConfig.starvector_8b(max_batch=4, max_seq_len=640))
+    for name, tns in O.iter_weights(cfg, seed=3, init="std002"):          # streamed: never 29 GB of fp32 at once
+        eng.load_weight(name, tns)
+    eng.load_state_dict({})
+    img = bf(O.synthetic_images(3, 384, seed=4))
+    prompt = torch.tensor([[7, 11]] * 3, device=dev())
+    enc = eng.encode_image(img)
+    emb = torch.cat([eng.adapter(enc), eng.embed_tokens(prompt)], 1)
+    assert enc.shape == (3, 576, 1024) and emb.shape == (3, 578, 4608) and not torch.isnan(emb.float()).any()
+    kw = dict(max_length=578 + 24, eos_token_id=-1, pad_token_id=0)
+    a = eng.generate(emb, **kw).cpu()
+    assert a.shape == (3, 24) and int(a.min()) >= 0 and int(a.max()) < cfg.vocab
+    assert torch.equal(a, eng.generate(emb, **kw).cpu())
+    os.environ["SV_NO_GRAPH"] = "1"
+    try:
+        assert torch.equal(a, eng.generate(emb, **kw).cpu())
+    finally:
+        os.environ.pop("SV_NO_GRAPH", None)
+    assert torch.equal(a[2], eng.generate(emb[2:3].contiguous(), **kw).cpu()[0])
+    s = eng.generate(emb, do_sample=True, temperature=1.0, top_p=0.95, seed=9, **kw).cpu()
+    assert s.shape == (3, 24) and torch.equal(s, eng.generate(emb, do_sample=True, temperature=1.0, top_p=0.95, seed=9, **kw).cpu())
+    print(f"[8b] timing {eng.last_timing()}")
+    eng.close()
