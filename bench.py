@@ -181,7 +181,7 @@ def main():
     achieved = W_BYTES_PER_STEP / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else None
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")       # filled from the rocprofv3 --pmc pass
-    if os.path.exists(tfile):
+    if os.path.exists(tfile) and not is8b:
         try:
             traffic = json.load(open(tfile)).get("skinny_gemm_bytes_per_launch")
         except Exception:
@@ -199,7 +199,7 @@ def main():
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic: random-pixel 224x224 images (CLIP-normalised), random-init weights N(0,0.02) seed 1234",
+            "data": f"synthetic: random-pixel {cfg.image_size}x{cfg.image_size} images (CLIP-normalised), random-init weights N(0,0.02) seed 1234",
             "config": {"workload": (f"StarVector-8B im2svg, batch {B_PER_GPU}/GPU, bf16, top-p 0.95, 384x384, prompt rows "
                                     f"{S0} (576 visual + {len(PROMPT_IDS)}), {n_new} new tokens/seq, EOS disabled") if is8b else
                                    (f"StarVector-1B im2svg, batch {B_PER_GPU}/GPU, bf16, greedy, 224x224, prompt rows "
