@@ -389,6 +389,30 @@ class StarVectorStarCoder(nn.Module):
     def _get_im2svg_specific_kwargs(self, kwargs):                    # starvector_base.py:289-295
         return {"early_stopping": True, "pad_token_id": self.svg_transformer.tokenizer.pad_token_id}
 
+    def _get_text2svg_specific_kwargs(self, kwargs):                  # starvector_base.py:332-339
+        return {"eos_token_id": self.svg_transformer.tokenizer.eos_token_id, "early_stopping": True,
+                "length_penalty": kwargs.get("length_penalty", 1.0)}
+
+    def generate_text2svg(self, batch, **kwargs):
+        """starvector_base.py:297-330, restated by intent: embed(caption ids + <svg-start>) -> generate -> new token ids.
+        The snapshot's version cannot run (it passes two positional arguments to _get_generation_kwargs, :321-324, and
+        subtracts the prompt length from max_length twice); here `max_length` counts the prompt once, as in im2svg.
+        Captions must tokenise to the same length (the engine takes an all-ones mask; padded batches are not built)."""
+        device = batch["image"].device if "image" in batch else torch.device("cuda", self._engine_device())
+        prompt_tokens = self._tokenize(list(batch["caption"]), kwargs.get("max_length", 30), device, add_special_tokens=False)
+        trigger = self._tokenize([self.svg_transformer.svg_start_token] * len(batch["caption"]), None, device,
+                                 add_special_tokens=False)
+        input_tokens = torch.cat([prompt_tokens.input_ids, trigger.input_ids], dim=1)
+        attention_mask = torch.cat([prompt_tokens.attention_mask, trigger.attention_mask], dim=1)
+        inputs_embeds = self._get_embeddings(input_tokens)
+        generation_kwargs = self._get_generation_kwargs({**kwargs, "inputs_embeds": inputs_embeds,
+                                                         "attention_mask": attention_mask})
+        generation_kwargs.update(self._get_text2svg_specific_kwargs(kwargs))
+        return self.svg_transformer.transformer.generate(**generation_kwargs)
+
+    def _engine_device(self):
+        return self.svg_transformer.transformer._engine.device
+
     def generate_im2svg(self, batch, **kwargs):                       # starvector_base.py:243-259
         return self.generate_im2svg_grpo(batch, **kwargs)["raw_svg"]
 
@@ -415,6 +439,9 @@ class StarVectorStarCoder2(StarVectorStarCoder):
 
     def _get_im2svg_specific_kwargs(self, kwargs):                    # starvector_v2.py:53-57
         return {}
+
+    def _get_text2svg_specific_kwargs(self, kwargs):                  # starvector_v2.py:59-63
+        return {"eos_token_id": self.svg_transformer.tokenizer.eos_token_id}
 
 
 class StarVectorForCausalLM(nn.Module):

@@ -189,6 +189,13 @@ def test_drop_in_api_generate_im2svg():
     assert res["outputs"].shape == (2, 4 + 10) and res["inputs_embeds"].shape == (2, S0, cfg.hidden)
     with pytest.raises(NotImplementedError):
         model.generate_im2svg(batch, max_length=S0 + 10)               # reference default num_beams=2: next row
+    # text2svg (starvector_base.py:297-330 by intent): caption ids + <svg-start> -> new token ids, budget = max_length - prompt
+    cap = {"caption": ["a red square", "a red square"], "image": batch["image"]}
+    t2s = model.model.generate_text2svg(cap, max_length=13 + 9, num_beams=1, use_nucleus_sampling=False)
+    assert t2s.shape[0] == 2 and 1 <= t2s.shape[1] <= 9 and torch.equal(t2s[0], t2s[1])
+    with pytest.raises(NotImplementedError):
+        model.model.generate_text2svg({"caption": ["short", "a much longer caption"], "image": batch["image"]},
+                                      max_length=64, num_beams=1, use_nucleus_sampling=False)     # padded batch
     # module-level operator signatures
     enc = model.model.image_encoder(batch["image"].to(torch.bfloat16))
     assert enc.shape == (2, model.model.query_length, cfg.vit_width)
