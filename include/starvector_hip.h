@@ -94,6 +94,7 @@ typedef struct sv_sampling {
     const int32_t* stop_ids;   /* host pointer, n_stop entries */
     uint64_t seed;             /* sampling RNG seed */
     int32_t sync_every;        /* host polls the device "done" flag every this many steps (0 = 32) */
+    float   repetition_penalty;/* HF RepetitionPenaltyLogitsProcessor over the generated ids; 0 or 1 = off */
 } sv_sampling;
 
 int  sv_abi_version(void);

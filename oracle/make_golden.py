@@ -80,7 +80,7 @@ def build_reference(cfg: O.OracleConfig, w):
 
 
 @torch.no_grad()
-def reference_outputs(cfg, w, image, prompt_ids, n_new, stop_ids=None):
+def reference_outputs(cfg, w, image, prompt_ids, n_new, stop_ids=None, repetition_penalty=1.0):
     vit, lnv, adp, lm = build_reference(cfg, w)
     enc = lnv(vit(image))                                   # image_encoder.py:92-94
     vis = adp(enc)                                          # starvector_base.py:209
@@ -88,7 +88,7 @@ def reference_outputs(cfg, w, image, prompt_ids, n_new, stop_ids=None):
     mask = torch.ones(emb.shape[:2], dtype=torch.long)
     S0 = emb.shape[1]
     kw = dict(inputs_embeds=emb, attention_mask=mask, do_sample=False, num_beams=1, top_p=None,
-              temperature=None, max_length=S0 + n_new, min_length=1, repetition_penalty=1.0,
+              temperature=None, max_length=S0 + n_new, min_length=1, repetition_penalty=repetition_penalty,
               length_penalty=1.0, use_cache=True, pad_token_id=cfg.pad_token_id)
     if stop_ids:
         from transformers.generation.stopping_criteria import StoppingCriteria, StoppingCriteriaList
@@ -270,6 +270,27 @@ def run_stop_case(write):
         print("  wrote tests/golden/tiny_stop.safetensors")
 
 
+def run_reppen_case(write):
+    """repetition_penalty (starvector_base.py:237; quickstart uses 3.1) through HF's RepetitionPenaltyLogitsProcessor."""
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=88)
+    B, n_new, pen = 2, 20, 1.7
+    image = O.synthetic_images(B, cfg.image_size, seed=89)
+    prompt_ids = torch.tensor([[7, 11]] * B, dtype=torch.long)
+    ref = reference_outputs(cfg, w, image, prompt_ids, n_new, repetition_penalty=pen)
+    emb = O.prepare_generation_inputs(w, cfg, image, prompt_ids)
+    mine = O.greedy_generate(w, cfg, emb, emb.shape[1] + n_new, repetition_penalty=pen)
+    free = O.greedy_generate(w, cfg, emb, emb.shape[1] + n_new)
+    print(f"[tiny_reppen] tokens == HF: {torch.equal(mine, ref['tokens'])}; differs from penalty-free run: {not torch.equal(mine, free)}")
+    assert torch.equal(mine, ref["tokens"]) and not torch.equal(mine, free)
+    if write:
+        from safetensors.torch import save_file
+        save_file({"image": image, "prompt_ids": prompt_ids, "tokens": ref["tokens"].contiguous(),
+                   "meta": torch.tensor([88, B, n_new]), "penalty": torch.tensor([pen])},
+                  os.path.join(GOLD, "tiny_reppen.safetensors"))
+        print("  wrote tests/golden/tiny_reppen.safetensors")
+
+
 def main():
     write = "--no-write" not in sys.argv
     torch.manual_seed(0)
@@ -279,6 +300,7 @@ def main():
     run_case("tiny_bn_b2", dataclasses.replace(O.OracleConfig.tiny(), adapter_norm="batch_norm"),
              seed=4321, batch=2, n_new=8, write=write)
     run_stop_case(write)
+    run_reppen_case(write)
     run_case_v2("tiny_v2_b2", O.OracleConfig.tiny_v2(), seed=2024, batch=2, n_new=12, write=write)
     if "--full" in sys.argv:
         # StarVector-1B shapes, 1 image, a few tokens: validates the restatement at BASELINE

@@ -505,14 +505,16 @@ def prepare_generation_inputs(w, cfg: OracleConfig, image: Tensor, prompt_ids: T
 
 def greedy_generate(w, cfg: OracleConfig, inputs_embeds: Tensor, max_length: int,
                     stop_ids: Optional[Sequence[int]] = None, mode: str = "fp32",
-                    return_logits: bool = False):
+                    return_logits: bool = False, repetition_penalty: float = 1.0):
     """HF GenerationMixin.generate -> _sample with do_sample=False, num_beams=1, as driven by
     starvector_base.py:228-241,255.  Semantics:
       * with inputs_embeds the new-token budget is max_length - S0;
       * only NEW tokens are returned;
       * finished rows (EOS seen) emit pad_token_id;
       * StoppingCriteriaSub (starvector_base.py:9-20) looks at ROW 0 only and stops the batch;
-      * generation ends when every row is finished, the stop fires, or the budget is spent.
+      * generation ends when every row is finished, the stop fires, or the budget is spent;
+      * repetition_penalty (starvector_base.py:237): HF RepetitionPenaltyLogitsProcessor over the ids generated
+        so far (with inputs_embeds the prompt has no ids): score < 0 ? score * p : score / p.
     """
     B, S0, _ = inputs_embeds.shape
     budget = max_length - S0
@@ -524,9 +526,15 @@ def greedy_generate(w, cfg: OracleConfig, inputs_embeds: Tensor, max_length: int
     all_logits: List[Tensor] = []
     stop = list(stop_ids) if stop_ids else None
     for t in range(budget):
+        scores = logits.float()
+        if repetition_penalty != 1.0 and out:
+            prev = torch.stack(out, dim=1)
+            g = torch.gather(scores, 1, prev)
+            g = torch.where(g < 0, g * repetition_penalty, g / repetition_penalty)
+            scores = scores.scatter(1, prev, g)
         if return_logits:
-            all_logits.append(logits)
-        nxt = torch.argmax(logits.float(), dim=-1)
+            all_logits.append(scores)
+        nxt = torch.argmax(scores, dim=-1)
         nxt = torch.where(unfinished, nxt, torch.full_like(nxt, cfg.pad_token_id))
         out.append(nxt)
         unfinished = unfinished & (nxt != cfg.eos_token_id)

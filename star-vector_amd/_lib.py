@@ -35,7 +35,7 @@ class SvSampling(C.Structure):
         ("do_sample", C.c_int32), ("temperature", C.c_float), ("top_p", C.c_float),
         ("max_length", C.c_int32), ("eos_token_id", C.c_int32), ("pad_token_id", C.c_int32),
         ("n_stop", C.c_int32), ("stop_ids", C.POINTER(C.c_int32)), ("seed", C.c_uint64),
-        ("sync_every", C.c_int32),
+        ("sync_every", C.c_int32), ("repetition_penalty", C.c_float),
     ]
 
 

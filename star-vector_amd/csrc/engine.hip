@@ -178,6 +178,7 @@ struct sv_engine {
     float *ws = nullptr, *ws2 = nullptr, *logits = nullptr, *sample_scratch = nullptr, *attn_part = nullptr;
     unsigned* attn_cnt = nullptr;
     float* am_val = nullptr; int32_t* am_idx = nullptr;
+    uint32_t* seen = nullptr; int seen_words = 0;      // repetition-penalty bitmap [rows][Vpad/32]
     int32_t *cur_tok = nullptr, *next_tok = nullptr, *unfinished = nullptr, *positions = nullptr,
             *out_tok = nullptr, *d_step = nullptr, *d_done = nullptr, *d_nemit = nullptr, *d_stop = nullptr;
     int out_ld = 0;
@@ -512,6 +513,8 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     A(dalloc(e, &e->sample_scratch, R * 4));
     A(dalloc(e, &e->attn_part, R * nkv * attn_decode_part_floats(dh)));
     A(dalloc(e, &e->attn_cnt, R * nkv));
+    e->seen_words = e->Vpad / 32;
+    A(dalloc(e, &e->seen, R * (size_t)e->seen_words));
     A(dalloc(e, &e->am_val, R * 8));
     A(dalloc(e, &e->am_idx, R * 8));
     A(dalloc(e, &e->cur_tok, R));
@@ -1011,13 +1014,17 @@ extern "C" int sv_decode_step(sv_engine* e, const int32_t* dev_tokens, int32_t B
 
 // sample from e->logits into next_tok, then the bookkeeping kernel
 static void sample_and_finish(sv_engine* e, int B, const sv_sampling& sp, int max_new, hipStream_t st) {
+    const bool pen = sp.repetition_penalty > 0.f && sp.repetition_penalty != 1.0f;
+    const uint32_t* seen = pen ? e->seen : nullptr;
     if (sp.do_sample) {
         SampleArgs sa;
         sa.logits = e->logits; sa.ld = e->Vpad; sa.V = e->cfg.vocab; sa.B = B; sa.temperature = sp.temperature;
         sa.top_p = sp.top_p; sa.seed = sp.seed; sa.step = e->d_step; sa.out = e->next_tok; sa.scratch = e->sample_scratch;
+        sa.seen = seen; sa.seen_words = e->seen_words; sa.penalty = sp.repetition_penalty;
         launch_sample_top_p(sa, st);
     } else {
-        launch_argmax_partial(e->logits, e->Vpad, e->cfg.vocab, e->am_val, e->am_idx, B, st);
+        launch_argmax_partial(e->logits, e->Vpad, e->cfg.vocab, e->am_val, e->am_idx, B, seen, e->seen_words,
+                              sp.repetition_penalty, st);
     }
     FinishArgs f;
     f.pval = sp.do_sample ? nullptr : e->am_val; f.pidx = sp.do_sample ? nullptr : e->am_idx;
@@ -1025,6 +1032,7 @@ static void sample_and_finish(sv_engine* e, int B, const sv_sampling& sp, int ma
     f.out_tokens = e->out_tok; f.ld_out = e->out_ld; f.step = e->d_step; f.done = e->d_done; f.n_emitted = e->d_nemit;
     f.stop_ids = e->d_stop; f.n_stop = sp.n_stop; f.eos = sp.eos_token_id; f.pad = sp.pad_token_id; f.B = B;
     f.max_new = max_new;
+    f.seen = pen ? e->seen : nullptr; f.seen_words = e->seen_words;
     launch_finish_step(f, st);
 }
 
@@ -1052,6 +1060,8 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
     HIPCHECK(hipMemsetAsync(e->d_step, 0, sizeof(int32_t), st));
     HIPCHECK(hipMemsetAsync(e->d_done, 0, sizeof(int32_t), st));
     HIPCHECK(hipMemsetAsync(e->d_nemit, 0, sizeof(int32_t), st));
+    if (sp->repetition_penalty > 0.f && sp->repetition_penalty != 1.0f)
+        HIPCHECK(hipMemsetAsync(e->seen, 0, (size_t)((B + 31) / 32) * 32 * e->seen_words * sizeof(uint32_t), st));
     if (sp->n_stop > 0) {
         if (!sp->stop_ids) return fail(SV_EINVAL, "n_stop > 0 but stop_ids is null");
         HIPCHECK(hipMemcpyAsync(e->d_stop, sp->stop_ids, sp->n_stop * sizeof(int32_t), hipMemcpyHostToDevice, st));
@@ -1470,7 +1480,7 @@ extern "C" int sv_op_sample_top_p(const float* logits, int32_t B, int32_t V, int
     HIPCHECK(hipMemcpyAsync(dstep, &step, sizeof(int32_t), hipMemcpyHostToDevice, st));
     SampleArgs sa;
     sa.logits = logits; sa.ld = ld; sa.V = V; sa.B = B; sa.temperature = temperature; sa.top_p = top_p; sa.seed = seed;
-    sa.step = dstep; sa.out = out; sa.scratch = nullptr;
+    sa.step = dstep; sa.out = out; sa.scratch = nullptr; sa.seen = nullptr; sa.seen_words = 0; sa.penalty = 1.f;
     launch_sample_top_p(sa, st);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(st));

@@ -159,12 +159,15 @@ int init_attention_kernels();   // returns a hipError_t value (0 = ok)
 
 // ---- sampling -----------------------------------------------------------------------------------
 // greedy selection: per-slice winners (pval/pidx: [B][8]) then a merge (standalone, or inside finish_step)
-void launch_argmax_partial(const float* logits, int ld, int V, float* pval, int32_t* pidx, int B, hipStream_t st);
+// seen / penalty: HF RepetitionPenaltyLogitsProcessor (bitmap of generated ids per row, [B][seen_words]); nullptr = off
+void launch_argmax_partial(const float* logits, int ld, int V, float* pval, int32_t* pidx, int B, const uint32_t* seen,
+                           int seen_words, float penalty, hipStream_t st);
 void launch_argmax(const float* logits, int ld, int V, int32_t* out, float* pval, int32_t* pidx, int B, hipStream_t st);
 struct SampleArgs {
     const float* logits; int ld; int V; int B;
     float temperature, top_p; uint64_t seed; const int32_t* step;   // device step counter
     int32_t* out; float* scratch;                                    // scratch >= B*4 floats
+    const uint32_t* seen; int seen_words; float penalty;             // repetition penalty (nullptr = off)
 };
 void launch_sample_top_p(const SampleArgs& a, hipStream_t st);
 
@@ -180,6 +183,7 @@ struct FinishArgs {
     int32_t* n_emitted;           // device scalar: final column count
     const int32_t* stop_ids; int n_stop;
     int eos, pad, B, max_new;
+    uint32_t* seen; int seen_words;   // repetition-penalty bitmap to update with the emitted ids (nullptr = off)
 };
 void launch_finish_step(const FinishArgs& a, hipStream_t st);
 

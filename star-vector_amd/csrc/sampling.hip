@@ -13,16 +13,23 @@ namespace sv {
 __device__ __forceinline__ void argmax_pair(float& v, int& i, float ov, int oi) {
     if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
 }
+// RepetitionPenaltyLogitsProcessor: score < 0 ? score * penalty : score / penalty for ids already generated
+__device__ __forceinline__ float rep_penalty(float l, int i, const uint32_t* seen_row, float penalty) {
+    if (seen_row && ((seen_row[i >> 5] >> (i & 31)) & 1u)) return l < 0.f ? l * penalty : l / penalty;
+    return l;
+}
 
 // grid (B, AM_SPLIT): one CU streams ~25 GB/s, so a 196 KB logits row is scanned by AM_SPLIT blocks; each
 // leaves (max, index) of its slice and finish_step_kernel merges them (lowest index wins ties)
 #define AM_SPLIT 8
 __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int ld, int V,
-                                                     float* __restrict__ pval, int32_t* __restrict__ pidx) {
+                                                     float* __restrict__ pval, int32_t* __restrict__ pidx,
+                                                     const uint32_t* __restrict__ seen, int seen_words, float penalty) {
     __shared__ float sv_[4];
     __shared__ int si_[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* row = logits + (size_t)blockIdx.x * ld;
+    const uint32_t* srow = seen ? seen + (size_t)blockIdx.x * seen_words : nullptr;
     const int per = (((V + AM_SPLIT - 1) / AM_SPLIT) + 3) & ~3;
     const int beg = blockIdx.y * per, end = min(beg + per, V);
     float best = -INFINITY;
@@ -32,7 +39,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ l
         const float a[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (i + e < end) argmax_pair(best, bi, a[e], i + e);
+            if (i + e < end) argmax_pair(best, bi, rep_penalty(a[e], i + e, srow, penalty), i + e);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -57,11 +64,12 @@ __global__ void argmax_merge_kernel(const float* __restrict__ pval, const int32_
     for (int s = 0; s < AM_SPLIT; ++s) argmax_pair(best, bi, pval[b * AM_SPLIT + s], pidx[b * AM_SPLIT + s]);
     out[b] = bi;
 }
-void launch_argmax_partial(const float* logits, int ld, int V, float* pval, int32_t* pidx, int B, hipStream_t st) {
-    argmax_kernel<<<dim3(B, AM_SPLIT), 256, 0, st>>>(logits, ld, V, pval, pidx);
+void launch_argmax_partial(const float* logits, int ld, int V, float* pval, int32_t* pidx, int B, const uint32_t* seen,
+                           int seen_words, float penalty, hipStream_t st) {
+    argmax_kernel<<<dim3(B, AM_SPLIT), 256, 0, st>>>(logits, ld, V, pval, pidx, seen, seen_words, penalty);
 }
 void launch_argmax(const float* logits, int ld, int V, int32_t* out, float* pval, int32_t* pidx, int B, hipStream_t st) {
-    launch_argmax_partial(logits, ld, V, pval, pidx, B, st);
+    launch_argmax_partial(logits, ld, V, pval, pidx, B, nullptr, 0, 1.f, st);
     argmax_merge_kernel<<<(B + 63) / 64, 64, 0, st>>>(pval, pidx, out, B);
 }
 
@@ -103,13 +111,15 @@ __global__ __launch_bounds__(SP_THREADS) void sample_top_p_kernel(SampleArgs p) 
     const int tid = threadIdx.x;
     const int V = p.V;
     const float* row = p.logits + (size_t)blockIdx.x * p.ld;
+    const uint32_t* srow = p.seen ? p.seen + (size_t)blockIdx.x * p.seen_words : nullptr;
     const float invT = 1.0f / p.temperature;
+    auto lg = [&](int i) { return rep_penalty(row[i], i, srow, p.penalty) * invT; };     // processors, then temperature
 
     float mx = -INFINITY;
-    for (int i = tid; i < V; i += SP_THREADS) mx = fmaxf(mx, row[i] * invT);
+    for (int i = tid; i < V; i += SP_THREADS) mx = fmaxf(mx, lg(i));
     mx = block_max(mx, red);
     float z = 0.f;
-    for (int i = tid; i < V; i += SP_THREADS) z += __expf(row[i] * invT - mx);
+    for (int i = tid; i < V; i += SP_THREADS) z += __expf(lg(i) - mx);
     z = block_sum(z, red);
     const float invZ = 1.0f / z;
 
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(SP_THREADS) void sample_top_p_kernel(SampleArgs p) 
             const float thr = __uint_as_float(mid);
             float f = 0.f;
             for (int i = tid; i < V; i += SP_THREADS) {
-                const float pr = __expf(row[i] * invT - mx) * invZ;
+                const float pr = __expf(lg(i) - mx) * invZ;
                 f += pr <= thr ? pr : 0.f;
             }
             f = block_sum(f, red);
@@ -140,7 +150,7 @@ __global__ __launch_bounds__(SP_THREADS) void sample_top_p_kernel(SampleArgs p) 
     const int beg = tid * per, end = min(beg + per, V);
     float mine = 0.f;
     for (int i = beg; i < end; ++i) {
-        const float pr = __expf(row[i] * invT - mx) * invZ;
+        const float pr = __expf(lg(i) - mx) * invZ;
         mine += pr >= v0 ? pr : 0.f;
     }
     scan[tid] = mine;
@@ -160,7 +170,7 @@ __global__ __launch_bounds__(SP_THREADS) void sample_top_p_kernel(SampleArgs p) 
         float run = base;
         int pick = -1;
         for (int i = beg; i < end; ++i) {
-            const float pr = __expf(row[i] * invT - mx) * invZ;
+            const float pr = __expf(lg(i) - mx) * invZ;
             if (pr >= v0) {
                 run += pr;
                 pick = i;                 // last survivor seen (guards fp round-off at the range end)
@@ -174,7 +184,7 @@ __global__ __launch_bounds__(SP_THREADS) void sample_top_p_kernel(SampleArgs p) 
         if (result < 0) {
             // round-off fell between ranges: take the most probable token (always a survivor)
             float best = -INFINITY; int bi = 0;
-            for (int i = 0; i < V; ++i) if (row[i] > best) { best = row[i]; bi = i; }
+            for (int i = 0; i < V; ++i) if (lg(i) > best) { best = lg(i); bi = i; }
             result = bi;
         }
         p.out[blockIdx.x] = result;
@@ -204,6 +214,7 @@ __global__ void finish_step_kernel(FinishArgs p) {
         const int tok = unf ? nxt : p.pad;
         p.out_tokens[(size_t)b * p.ld_out + t] = tok;
         p.cur_tok[b] = tok;
+        if (p.seen && tok >= 0) atomicOr(p.seen + (size_t)b * p.seen_words + (tok >> 5), 1u << (tok & 31));
         const int still = unf && tok != p.eos;
         p.unfinished[b] = still;
         p.positions[b] += 1;

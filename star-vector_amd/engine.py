@@ -168,7 +168,8 @@ class HipEngine:
 
     def generate(self, inputs_embeds: torch.Tensor, max_length: int, do_sample: bool = False,
                  temperature: float = 1.0, top_p: float = 1.0, eos_token_id: int = 0, pad_token_id: int = 0,
-                 stop_ids: Optional[Sequence[int]] = None, seed: int = 0, sync_every: int = 32) -> torch.Tensor:
+                 stop_ids: Optional[Sequence[int]] = None, seed: int = 0, sync_every: int = 32,
+                 repetition_penalty: float = 1.0) -> torch.Tensor:
         """HF ``generate`` semantics for inputs_embeds: returns ONLY the new tokens, int64 [B, N]."""
         x = _need(inputs_embeds, torch.bfloat16, "inputs_embeds")
         B, S0, D = x.shape
@@ -181,7 +182,7 @@ class HipEngine:
         arr = (C.c_int32 * max(len(stops), 1))(*stops) if stops else None
         sp = SvSampling(int(bool(do_sample)), float(temperature), float(top_p), int(max_length), int(eos_token_id),
                         int(pad_token_id), len(stops), C.cast(arr, C.POINTER(C.c_int32)) if stops else None,
-                        int(seed) & 0xFFFFFFFFFFFFFFFF, int(sync_every))
+                        int(seed) & 0xFFFFFFFFFFFFFFFF, int(sync_every), float(repetition_penalty))
         out = torch.empty(B, max_new, dtype=torch.int64, device=x.device)
         n = C.c_int32(0)
         check(self.lib.sv_generate(self._h, _ptr(x), B, S0, C.byref(sp), _ptr(out), C.byref(n), _stream()), "sv_generate")

@@ -281,8 +281,10 @@ class HipCausalLM(_EngineModule):
         if num_beams != 1:
             raise NotImplementedError("beam search (num_beams>1) is the next row of the build plan "
                                       "(SURVEY.md section 8f rank 2); pass num_beams=1")
-        if repetition_penalty not in (None, 1.0) or num_return_sequences != 1:
-            raise NotImplementedError("repetition_penalty != 1 / num_return_sequences > 1 not built yet")
+        if num_return_sequences != 1:
+            raise NotImplementedError("num_return_sequences > 1 not built yet")
+        if repetition_penalty is not None and not repetition_penalty > 0:
+            raise ValueError("`repetition_penalty` has to be a strictly positive float")   # HF's own check
         if attention_mask is not None and not bool((attention_mask == 1).all()):
             raise NotImplementedError("left/right padding masks are not on the im2svg path (mask is all ones)")
         S0 = inputs_embeds.shape[1]
@@ -297,7 +299,8 @@ class HipCausalLM(_EngineModule):
             top_p=float(top_p if top_p is not None else 1.0),
             eos_token_id=int(self.eos_token_id if eos_token_id is None else eos_token_id),
             pad_token_id=int(self.pad_token_id if pad_token_id is None else pad_token_id),
-            stop_ids=self._stop_ids(stopping_criteria), seed=self.seed)
+            stop_ids=self._stop_ids(stopping_criteria), seed=self.seed,
+            repetition_penalty=float(repetition_penalty if repetition_penalty is not None else 1.0))
 
 
 class StoppingCriteriaSub:

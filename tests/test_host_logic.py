@@ -76,8 +76,8 @@ def test_generate_kwargs_validation_without_gpu():
     emb = torch.zeros(1, 4, 8)
     with pytest.raises(NotImplementedError):
         lm.generate(inputs_embeds=emb, num_beams=2, max_length=8)      # reference default; "next" row
-    with pytest.raises(NotImplementedError):
-        lm.generate(inputs_embeds=emb, repetition_penalty=3.1, max_length=8)
+    with pytest.raises(ValueError):
+        lm.generate(inputs_embeds=emb, repetition_penalty=0.0, max_length=8)
     with pytest.raises(ValueError):
         lm.generate(max_length=8)
 

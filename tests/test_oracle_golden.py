@@ -112,3 +112,13 @@ def test_v2_oracle_reproduces_reference_goldens(golden_dir):
     torch.testing.assert_close(logits0, g["logits0"], rtol=0, atol=5e-5 * max(1.0, float(g["logits0"].abs().max())))
     assert torch.equal(O.greedy_generate(w, cfg, emb, emb.shape[1] + n_new), g["tokens"])
     assert enc.shape == (B, cfg.query_length, cfg.vit_width) and cfg.query_length == cfg.n_patches     # no cls token
+
+
+def test_repetition_penalty_matches_hf(golden_dir):
+    g = _load(golden_dir, "tiny_reppen")
+    seed, B, n_new = [int(x) for x in g["meta"]]
+    pen = float(g["penalty"])
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=seed)
+    emb = O.prepare_generation_inputs(w, cfg, g["image"], g["prompt_ids"])
+    assert torch.equal(O.greedy_generate(w, cfg, emb, emb.shape[1] + n_new, repetition_penalty=pen), g["tokens"])
