@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SV_ABI_VERSION 1
+#define SV_ABI_VERSION 2
 
 enum {
     SV_OK = 0,
@@ -44,7 +44,8 @@ enum {
     SV_ENOMEM = -12,      /* device allocation failed */
     SV_ENOENT = -2,       /* unknown weight name / missing weight */
     SV_EHIP = -5,         /* HIP runtime error */
-    SV_ESTATE = -1        /* call order (e.g. generate before weights are complete) */
+    SV_ESTATE = -1,       /* call order (e.g. generate before weights are complete) */
+    SV_ENOTSUP = -95      /* a combination the engine does not implement (says which) */
 };
 
 enum { SV_DTYPE_BF16 = 0, SV_DTYPE_F32 = 1 };
@@ -95,7 +96,25 @@ typedef struct sv_sampling {
     uint64_t seed;             /* sampling RNG seed */
     int32_t sync_every;        /* host polls the device "done" flag every this many steps (0 = 32) */
     float   repetition_penalty;/* HF RepetitionPenaltyLogitsProcessor over the generated ids; 0 or 1 = off */
+    int32_t num_beams;         /* 0 or 1 = greedy / sampling; 2..8 = HF beam search (the reference's default is 2,
+                                  starvector_base.py:234); batch * num_beams <= max_batch; do_sample must be 0 */
+    float   length_penalty;    /* beam search: hypothesis score = sum log-probs / len ** length_penalty (:238) */
+    int32_t early_stopping;    /* beam search: 0 False (HF default), 1 True (:293), 2 "never" */
 } sv_sampling;
+
+/* HF beam search bookkeeping as a standalone device-side scorer (what transformers' _beam_search does between two
+ * forward passes): feed it the [batch * num_beams][vocab] fp32 logits of each step.  sv_generate drives the same
+ * object internally; this handle exists so the parity tests can check it against the oracle on synthetic logits. */
+typedef struct sv_beam sv_beam;
+typedef struct sv_beam_config {
+    int32_t batch, num_beams, vocab, max_new;
+    int32_t eos_token_id, pad_token_id;
+    int32_t early_stopping;    /* 0 False, 1 True, 2 "never" */
+    float   length_penalty;
+    float   repetition_penalty;
+    int32_t n_stop;            /* the reference's row-0 stop sequence (starvector_base.py:9-20) */
+    const int32_t* stop_ids;   /* host pointer */
+} sv_beam_config;
 
 int  sv_abi_version(void);
 const char* sv_last_error(void);
@@ -133,6 +152,22 @@ int  sv_decode_step(sv_engine* e, const int32_t* dev_tokens, int32_t B, float* d
  * columns are left untouched.  Blocks until generation has finished (polls a device flag). */
 int  sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int32_t S0, const sv_sampling* sp,
                  int64_t* dev_out_tokens, int32_t* n_generated, sv_stream stream);
+/* beam scorer: one step consumes dev_logits [batch * num_beams][ld] (row r = request r / num_beams, beam r % num_beams)
+ * and reports (host arrays, each batch * num_beams long, may be NULL) the flat parent row, the token and the running
+ * score of every beam that continues; *done = 1 once HF's loop would stop.  sv_beam_finalize returns the best
+ * hypothesis per request: host_tokens [batch][max_new] (filled with pad-or-eos), *n_generated = common length. */
+int  sv_beam_create(const sv_beam_config* cfg, sv_beam** out);
+int  sv_beam_destroy(sv_beam* b);
+int  sv_beam_step(sv_beam* b, const float* dev_logits, int32_t ld, int32_t* done, int32_t* host_parent,
+                  int32_t* host_tokens, float* host_scores, sv_stream stream);
+int  sv_beam_finalize(sv_beam* b, int64_t* host_tokens, int32_t* n_generated, float* host_scores, sv_stream stream);
+
+/* Search trace of the last beam-search sv_generate on this engine (parity tests replay it through the oracle):
+ * host_parent / host_tok [n_steps][rows], rows = batch * num_beams; entry (t, r) = the beam (index inside its request)
+ * that running beam r descended from at step t, and the token it took.  NULL arrays: only *n_steps / *rows. */
+int  sv_beam_history(sv_engine* e, int32_t* host_parent, int32_t* host_tok, int32_t capacity_steps, int32_t* n_steps,
+                     int32_t* rows);
+
 /* host wall-clock of the last sv_generate, 4 doubles: [0] ms prefill + first token (TTFT),
  * [1] ms decode loop, [2] decode steps enqueued, [3] 1 if the step ran as a hipGraph replay */
 int  sv_last_timing(sv_engine* e, double* out4);

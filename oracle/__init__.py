@@ -26,6 +26,8 @@ from .starvector_oracle import (  # noqa: F401
     decoder_decode_step,
     prepare_generation_inputs,
     greedy_generate,
+    beam_search_generate,
+    BeamSearchState,
     top_p_filtered_probs,
     generate_im2svg_tokens,
     synthetic_images,

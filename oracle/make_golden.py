@@ -80,16 +80,19 @@ def build_reference(cfg: O.OracleConfig, w):
 
 
 @torch.no_grad()
-def reference_outputs(cfg, w, image, prompt_ids, n_new, stop_ids=None, repetition_penalty=1.0):
+def reference_outputs(cfg, w, image, prompt_ids, n_new, stop_ids=None, repetition_penalty=1.0, num_beams=1,
+                      length_penalty=1.0, early_stopping=None):
     vit, lnv, adp, lm = build_reference(cfg, w)
     enc = lnv(vit(image))                                   # image_encoder.py:92-94
     vis = adp(enc)                                          # starvector_base.py:209
     emb = torch.cat([vis, lm.transformer.wte(prompt_ids)], dim=1)   # :217-218
     mask = torch.ones(emb.shape[:2], dtype=torch.long)
     S0 = emb.shape[1]
-    kw = dict(inputs_embeds=emb, attention_mask=mask, do_sample=False, num_beams=1, top_p=None,
+    kw = dict(inputs_embeds=emb, attention_mask=mask, do_sample=False, num_beams=num_beams, top_p=None,
               temperature=None, max_length=S0 + n_new, min_length=1, repetition_penalty=repetition_penalty,
-              length_penalty=1.0, use_cache=True, pad_token_id=cfg.pad_token_id)
+              length_penalty=length_penalty, use_cache=True, pad_token_id=cfg.pad_token_id)
+    if early_stopping is not None:
+        kw["early_stopping"] = early_stopping
     if stop_ids:
         from transformers.generation.stopping_criteria import StoppingCriteria, StoppingCriteriaList
 
@@ -99,6 +102,8 @@ def reference_outputs(cfg, w, image, prompt_ids, n_new, stop_ids=None, repetitio
 
         kw["stopping_criteria"] = StoppingCriteriaList([StoppingCriteriaSub()])
     toks = lm.generate(**kw)
+    if num_beams > 1:
+        return dict(tokens=toks, emb=emb)
     # independent no-cache loop: full forward each step + argmax (checks HF 5.x == 4.49 semantics)
     cur = emb
     nocache = []
@@ -291,6 +296,51 @@ def run_reppen_case(write):
         print("  wrote tests/golden/tiny_reppen.safetensors")
 
 
+def run_beam_cases(write):
+    """num_beams > 1 (the reference's default is 2, starvector_base.py:234) through HF's beam search: early_stopping
+    True (v1 im2svg, :293) and False (v2), length penalties, an EOS some hypotheses reach, the row-0 stop sequence and
+    the repetition penalty on log-probs."""
+    import dataclasses
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=99)
+    B, n_new = 3, 16
+    image = O.synthetic_images(B, cfg.image_size, seed=98)
+    prompt_ids = torch.tensor([[7, 11]] * B, dtype=torch.long)
+    emb = O.prepare_generation_inputs(w, cfg, image, prompt_ids)
+    free = O.greedy_generate(w, cfg, emb, emb.shape[1] + n_new)
+    eos = int(free[1, 5])                                  # a token the greedy path of request 1 reaches
+    r0 = free[0].tolist()
+    cases = [
+        dict(tag="nb2_es", nb=2, lp=1.0, es=True, eos=eos, stop=None, pen=1.0),
+        dict(tag="nb3_noes", nb=3, lp=0.6, es=False, eos=eos, stop=None, pen=1.0),
+        dict(tag="nb2_stop", nb=2, lp=1.0, es=True, eos=cfg.eos_token_id, stop=None, pen=1.0),   # stop filled below
+        dict(tag="nb4_pen", nb=4, lp=1.3, es=True, eos=eos, stop=None, pen=1.5),
+        dict(tag="nb2_never", nb=2, lp=1.0, es="never", eos=eos, stop=None, pen=1.0),
+    ]
+    out = {"image": image, "prompt_ids": prompt_ids, "meta": torch.tensor([99, B, n_new])}
+    for c in cases:
+        cfg2 = dataclasses.replace(cfg, eos_token_id=c["eos"])
+        if c["tag"] == "nb2_stop":
+            base = O.beam_search_generate(w, cfg2, emb, emb.shape[1] + n_new, 2)
+            c["stop"] = base[0, 6:8].tolist()              # a pair the best beam of request 0 emits
+        ref = reference_outputs(cfg2, w, image, prompt_ids, n_new, stop_ids=c["stop"], repetition_penalty=c["pen"],
+                                num_beams=c["nb"], length_penalty=c["lp"], early_stopping=c["es"])["tokens"]
+        mine = O.beam_search_generate(w, cfg2, emb, emb.shape[1] + n_new, c["nb"], length_penalty=c["lp"],
+                                      early_stopping=c["es"], stop_ids=c["stop"], repetition_penalty=c["pen"])
+        same = mine.shape == ref.shape and torch.equal(mine, ref)
+        print(f"[tiny_beam/{c['tag']}] HF {tuple(ref.shape)} mine {tuple(mine.shape)} equal: {same}; "
+              f"differs from greedy: {not torch.equal(mine[:, :n_new], free[:, :mine.shape[1]])}")
+        assert same, (mine, ref)
+        es_code = {True: 1, False: 0, "never": 2}[c["es"]]
+        out[c["tag"] + ".tokens"] = ref.contiguous()
+        out[c["tag"] + ".params"] = torch.tensor([c["nb"], c["lp"], es_code, c["eos"], c["pen"]], dtype=torch.float64)
+        out[c["tag"] + ".stop"] = torch.tensor(c["stop"] if c["stop"] else [], dtype=torch.long)
+    if write:
+        from safetensors.torch import save_file
+        save_file(out, os.path.join(GOLD, "tiny_beam.safetensors"))
+        print("  wrote tests/golden/tiny_beam.safetensors")
+
+
 def main():
     write = "--no-write" not in sys.argv
     torch.manual_seed(0)
@@ -301,6 +351,7 @@ def main():
              seed=4321, batch=2, n_new=8, write=write)
     run_stop_case(write)
     run_reppen_case(write)
+    run_beam_cases(write)
     run_case_v2("tiny_v2_b2", O.OracleConfig.tiny_v2(), seed=2024, batch=2, n_new=12, write=write)
     if "--full" in sys.argv:
         # StarVector-1B shapes, 1 image, a few tokens: validates the restatement at BASELINE

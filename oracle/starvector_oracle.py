@@ -551,6 +551,126 @@ def greedy_generate(w, cfg: OracleConfig, inputs_embeds: Tensor, max_length: int
     return toks
 
 
+class BeamSearchState:
+    """HF GenerationMixin._beam_search (do_sample=False) as the reference drives it with its default num_beams=2
+    (starvector_base.py:234,238,293): the bookkeeping between two forward passes, restated from the algorithm.
+    Per request b (rows b*num_beams .. of the expanded batch):
+      * running scores start [0, -1e9, ...];
+      * each step: log_softmax (fp32) -> repetition penalty on the LOG-PROBS of each beam's own ids -> add the beam's
+        running score -> the K = 2*num_beams best (beam, token) continuations over num_beams*V, best first;
+      * a continuation "hits" when its token is EOS, when it reaches the budget, or when the reference's row-0
+        StoppingCriteriaSub fires (it looks at the best continuation of request 0 only and returns a plain bool, which
+        HF ORs into every row of every request);
+      * the num_beams best non-hitting continuations run on (hitting ones get -1e9 added);
+      * hitting continuations ranked inside the first num_beams compete, with score / len**length_penalty, for the
+        num_beams finished slots (blocked once the request is full under early_stopping=True, or once its heuristic said
+        no improvement is possible);
+      * the loop ends when no request can improve, when (early_stopping=True) all finished slots of all requests are
+        full, or when every continuation hit;
+      * result(): the best finished hypothesis per request, cropped to the longest, filled with pad (or eos when pad is
+        0 / unset -- HF's `pad or eos`)."""
+
+    def __init__(self, batch: int, num_beams: int, vocab: int, budget: int, eos_token_id: int, pad_token_id: int,
+                 length_penalty: float = 1.0, early_stopping=True, stop_ids: Optional[Sequence[int]] = None,
+                 repetition_penalty: float = 1.0):
+        self.B, self.nb, self.V, self.budget = batch, int(num_beams), vocab, budget
+        self.K = 2 * self.nb
+        self.eos, self.lp, self.es, self.pen = eos_token_id, length_penalty, early_stopping, repetition_penalty
+        self.fill = pad_token_id if pad_token_id else eos_token_id
+        self.stop = list(stop_ids) if stop_ids else None
+        B, nb = self.B, self.nb
+        self.run_seq = torch.full((B, nb, budget), self.fill, dtype=torch.long)
+        self.run_score = torch.zeros(B, nb, dtype=torch.float32)
+        self.run_score[:, 1:] = -1.0e9
+        self.fin_seq = self.run_seq.clone()
+        self.fin_len = torch.zeros(B, nb, dtype=torch.long)
+        self.fin_score = torch.full((B, nb), -1.0e9, dtype=torch.float32)
+        self.fin_done = torch.zeros(B, nb, dtype=torch.bool)
+        self.can_improve = torch.ones(B, dtype=torch.bool)
+        self.cur = 0
+
+    def step(self, logits: Tensor):
+        """logits [B*nb, V] of the current running beams -> (go_on, flat parent rows [B*nb], tokens [B*nb])."""
+        B, nb, V, K, cur = self.B, self.nb, self.V, self.K, self.cur
+        NEG = torch.tensor(-1.0e9, dtype=torch.float32)
+        ar_b = torch.arange(B)[:, None]
+        lp = torch.log_softmax(logits.float(), dim=-1)
+        if self.pen != 1.0 and cur > 0:
+            prev = self.run_seq[:, :, :cur].reshape(B * nb, cur)
+            g = torch.gather(lp, 1, prev)
+            g = torch.where(g < 0, g * self.pen, g / self.pen)
+            lp = lp.scatter(1, prev, g)
+        acc = (lp.view(B, nb, V) + self.run_score[:, :, None]).reshape(B, nb * V)
+        c_score, c_idx = torch.topk(acc, K, dim=1)                       # best first
+        c_beam, c_tok = c_idx // V, c_idx % V
+        c_seq = self.run_seq[ar_b, c_beam]                                # [B, K, budget]
+        c_seq[:, :, cur] = c_tok
+        hits = (c_tok == self.eos) | (cur + 1 >= self.budget)
+        st = self.stop
+        if st is not None and cur + 1 >= len(st) and c_seq[0, 0, cur + 1 - len(st):cur + 1].tolist() == st:
+            hits = torch.ones_like(hits)
+        # running beams for the next step
+        r_score = c_score + hits.float() * NEG
+        sel = torch.topk(r_score, nb, dim=1)[1]
+        self.run_seq = c_seq[ar_b, sel]
+        self.run_score = r_score[ar_b, sel]
+        parent = c_beam[ar_b, sel]
+        # finished slots
+        just = hits & (torch.arange(K) < nb)[None, :]
+        f = c_score / float((cur + 1) ** self.lp)
+        full = self.fin_done.all(dim=1, keepdim=True) & (self.es is True)
+        f = f + full.float() * NEG
+        f = f + (~self.can_improve)[:, None].float() * NEG
+        f = f + (~just).float() * NEG
+        m_score = torch.cat([self.fin_score, f], dim=1)
+        m_sel = torch.topk(m_score, nb, dim=1)[1]
+        self.fin_score = m_score[ar_b, m_sel]
+        self.fin_seq = torch.cat([self.fin_seq, c_seq], dim=1)[ar_b, m_sel]
+        self.fin_len = torch.cat([self.fin_len, torch.full((B, K), cur + 1)], dim=1)[ar_b, m_sel]
+        self.fin_done = torch.cat([self.fin_done, just], dim=1)[ar_b, m_sel]
+        self.cur = cur = cur + 1
+        # can the running beams still beat the worst finished hypothesis?
+        hyp_len = self.budget if (self.es == "never" and self.lp > 0.0) else cur
+        best_run = self.run_score[:, :1] / float(hyp_len ** self.lp)
+        worst = torch.where(self.fin_done, self.fin_score.min(dim=1, keepdim=True)[0], NEG)
+        self.can_improve = self.can_improve & (best_run > worst).any(dim=1)
+        go_on = bool(self.can_improve.any()) and not (bool(self.fin_done.all()) and self.es is True) \
+            and not bool(hits.all())
+        return go_on, (parent + ar_b * nb).reshape(-1), self.run_seq[:, :, cur - 1].reshape(-1)
+
+    def result(self):
+        L = int(self.fin_len[:, 0].max())
+        out = self.fin_seq[:, 0, :L].clone()
+        for b in range(self.B):
+            out[b, int(self.fin_len[b, 0]):] = self.fill
+        return out, self.fin_score[:, 0].clone()
+
+
+def beam_search_generate(w, cfg: OracleConfig, inputs_embeds: Tensor, max_length: int, num_beams: int,
+                         length_penalty: float = 1.0, early_stopping=True,
+                         stop_ids: Optional[Sequence[int]] = None, mode: str = "fp32",
+                         repetition_penalty: float = 1.0, return_scores: bool = False):
+    """generate(num_beams > 1): the prompt expanded to num_beams rows (repeat_interleave), BeamSearchState between the
+    forward passes, the KV cache re-indexed by the surviving beams' parents.  Returns new tokens [B, L]
+    (and the best scores [B] with return_scores)."""
+    B, S0, _ = inputs_embeds.shape
+    budget = max_length - S0
+    if budget <= 0:
+        raise ValueError("max_length must exceed the prompt length (HF raises here)")
+    nb = int(num_beams)
+    state = BeamSearchState(B, nb, cfg.vocab, budget, cfg.eos_token_id, cfg.pad_token_id, length_penalty,
+                            early_stopping, stop_ids, repetition_penalty)
+    logits, cache = decoder_prefill(w, cfg, inputs_embeds.repeat_interleave(nb, dim=0), mode)
+    while True:
+        go_on, flat_parent, tokens = state.step(logits)
+        if not go_on:
+            break
+        cache = [(k.index_select(0, flat_parent), v.index_select(0, flat_parent)) for k, v in cache]
+        logits, cache = decoder_decode_step(w, cfg, tokens, cache, mode)
+    out, scores = state.result()
+    return (out, scores) if return_scores else out
+
+
 def top_p_filtered_probs(logits: Tensor, temperature: float, top_p: float) -> Tensor:
     """HF TemperatureLogitsWarper then TopPLogitsWarper (min_tokens_to_keep=1) then softmax:
     the distribution torch.multinomial draws from on the do_sample=True path

@@ -12,6 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libstarvector_hip.so")
 HEADER_PATH = os.path.normpath(os.path.join(HERE, "..", "include", "starvector_hip.h"))
 
+ABI_VERSION = 2
 SV_DTYPE_BF16, SV_DTYPE_F32 = 0, 1
 SV_NORM_LAYER, SV_NORM_BATCH = 0, 1
 SV_ARCH_V1, SV_ARCH_V2 = 0, 1
@@ -36,6 +37,16 @@ class SvSampling(C.Structure):
         ("max_length", C.c_int32), ("eos_token_id", C.c_int32), ("pad_token_id", C.c_int32),
         ("n_stop", C.c_int32), ("stop_ids", C.POINTER(C.c_int32)), ("seed", C.c_uint64),
         ("sync_every", C.c_int32), ("repetition_penalty", C.c_float),
+        ("num_beams", C.c_int32), ("length_penalty", C.c_float), ("early_stopping", C.c_int32),
+    ]
+
+
+class SvBeamConfig(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("num_beams", C.c_int32), ("vocab", C.c_int32), ("max_new", C.c_int32),
+        ("eos_token_id", C.c_int32), ("pad_token_id", C.c_int32), ("early_stopping", C.c_int32),
+        ("length_penalty", C.c_float), ("repetition_penalty", C.c_float), ("n_stop", C.c_int32),
+        ("stop_ids", C.POINTER(C.c_int32)),
     ]
 
 
@@ -59,6 +70,11 @@ PROTOTYPES = {
     "sv_prefill": (_I, [_P, _P, _I, _I, _P, _P]),
     "sv_decode_step": (_I, [_P, _P, _I, _P, _P]),
     "sv_generate": (_I, [_P, _P, _I, _I, C.POINTER(SvSampling), _P, C.POINTER(_I), _P]),
+    "sv_beam_create": (_I, [C.POINTER(SvBeamConfig), C.POINTER(_P)]),
+    "sv_beam_destroy": (_I, [_P]),
+    "sv_beam_step": (_I, [_P, _P, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _P]),
+    "sv_beam_finalize": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(_F), _P]),
+    "sv_beam_history": (_I, [_P, C.POINTER(_I), C.POINTER(_I), _I, C.POINTER(_I), C.POINTER(_I)]),
     "sv_last_timing": (_I, [_P, C.POINTER(C.c_double)]),
     "sv_profile_decode_step": (_I, [_P, _I, _I, C.POINTER(C.c_double), _P]),
     "sv_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
@@ -102,8 +118,8 @@ def load() -> C.CDLL:
             raise StarVectorHipError(f"{LIB_PATH} does not export {name}") from e
         fn.restype = res
         fn.argtypes = args
-    if lib.sv_abi_version() != 1:
-        raise StarVectorHipError(f"ABI version mismatch: library {lib.sv_abi_version()}, binding 1")
+    if lib.sv_abi_version() != ABI_VERSION:
+        raise StarVectorHipError(f"ABI version mismatch: library {lib.sv_abi_version()}, binding {ABI_VERSION}")
     _lib = lib
     return lib
 
@@ -119,4 +135,6 @@ def check(rc: int, what: str = "") -> None:
         raise ValueError(text)
     if rc == -2:
         raise KeyError(text)
+    if rc == -95:
+        raise NotImplementedError(text)
     raise StarVectorHipError(f"{text} (code {rc})")

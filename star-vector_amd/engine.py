@@ -169,8 +169,10 @@ class HipEngine:
     def generate(self, inputs_embeds: torch.Tensor, max_length: int, do_sample: bool = False,
                  temperature: float = 1.0, top_p: float = 1.0, eos_token_id: int = 0, pad_token_id: int = 0,
                  stop_ids: Optional[Sequence[int]] = None, seed: int = 0, sync_every: int = 32,
-                 repetition_penalty: float = 1.0) -> torch.Tensor:
-        """HF ``generate`` semantics for inputs_embeds: returns ONLY the new tokens, int64 [B, N]."""
+                 repetition_penalty: float = 1.0, num_beams: int = 1, length_penalty: float = 1.0,
+                 early_stopping=False) -> torch.Tensor:
+        """HF ``generate`` semantics for inputs_embeds: returns ONLY the new tokens, int64 [B, N].
+        ``num_beams`` > 1 runs HF's beam search on device (``early_stopping``: False, True or "never")."""
         x = _need(inputs_embeds, torch.bfloat16, "inputs_embeds")
         B, S0, D = x.shape
         if D != self.cfg.hidden:
@@ -182,11 +184,21 @@ class HipEngine:
         arr = (C.c_int32 * max(len(stops), 1))(*stops) if stops else None
         sp = SvSampling(int(bool(do_sample)), float(temperature), float(top_p), int(max_length), int(eos_token_id),
                         int(pad_token_id), len(stops), C.cast(arr, C.POINTER(C.c_int32)) if stops else None,
-                        int(seed) & 0xFFFFFFFFFFFFFFFF, int(sync_every), float(repetition_penalty))
+                        int(seed) & 0xFFFFFFFFFFFFFFFF, int(sync_every), float(repetition_penalty),
+                        int(num_beams), float(length_penalty), _early_code(early_stopping))
         out = torch.empty(B, max_new, dtype=torch.int64, device=x.device)
         n = C.c_int32(0)
         check(self.lib.sv_generate(self._h, _ptr(x), B, S0, C.byref(sp), _ptr(out), C.byref(n), _stream()), "sv_generate")
         return out[:, : n.value]
+
+    def beam_history(self):
+        """(parent beams, tokens), each int32 [n_steps, batch * num_beams], of the last beam-search ``generate``."""
+        n, rows = C.c_int32(0), C.c_int32(0)
+        check(self.lib.sv_beam_history(self._h, None, None, 0, C.byref(n), C.byref(rows)), "sv_beam_history")
+        par, tok = (C.c_int32 * (n.value * rows.value))(), (C.c_int32 * (n.value * rows.value))()
+        check(self.lib.sv_beam_history(self._h, par, tok, n.value, C.byref(n), C.byref(rows)), "sv_beam_history")
+        shape = (n.value, rows.value)
+        return torch.tensor(list(par), dtype=torch.int32).view(shape), torch.tensor(list(tok), dtype=torch.int32).view(shape)
 
     def last_timing(self) -> Dict[str, float]:
         buf = (C.c_double * 4)()
@@ -202,6 +214,63 @@ class HipEngine:
         res["event_pair_overhead_ms"] = buf[6]
         res["skinny_chain_ms_per_step"] = buf[7]
         return res
+
+
+def _early_code(early_stopping) -> int:
+    """HF's early_stopping: False | True | "never"  ->  0 | 1 | 2."""
+    if early_stopping is True or early_stopping is False or early_stopping is None:
+        return int(bool(early_stopping))
+    if early_stopping == "never":
+        return 2
+    raise ValueError("`early_stopping` must be a boolean or 'never'")   # HF's own check
+
+
+class HipBeamScorer:
+    """The device-side beam-search bookkeeping on its own (what HF's ``_beam_search`` does between two forward passes).
+    ``step(logits)`` consumes the [batch * num_beams, vocab] fp32 logits of one step and returns
+    (done, parent_rows, tokens, running_scores); ``finalize()`` returns (tokens [batch, L], scores [batch])."""
+
+    def __init__(self, batch: int, num_beams: int, vocab: int, max_new: int, eos_token_id: int, pad_token_id: int,
+                 length_penalty: float = 1.0, early_stopping=False, repetition_penalty: float = 1.0,
+                 stop_ids: Optional[Sequence[int]] = None):
+        self.lib = _lib.load()
+        stops = list(stop_ids) if stop_ids else []
+        arr = (C.c_int32 * max(len(stops), 1))(*stops) if stops else None
+        cfg = _lib.SvBeamConfig(int(batch), int(num_beams), int(vocab), int(max_new), int(eos_token_id),
+                                int(pad_token_id), _early_code(early_stopping), float(length_penalty),
+                                float(repetition_penalty), len(stops),
+                                C.cast(arr, C.POINTER(C.c_int32)) if stops else None)
+        self._h = C.c_void_p()
+        self.rows, self.batch, self.vocab, self.max_new = batch * num_beams, batch, vocab, max_new
+        check(self.lib.sv_beam_create(C.byref(cfg), C.byref(self._h)), "sv_beam_create")
+
+    def step(self, logits: torch.Tensor):
+        x = _need(logits, torch.float32, "logits")
+        if x.shape != (self.rows, self.vocab):
+            raise ValueError(f"logits must be [{self.rows}, {self.vocab}]")
+        done = C.c_int32(0)
+        par, tok, sc = (C.c_int32 * self.rows)(), (C.c_int32 * self.rows)(), (C.c_float * self.rows)()
+        check(self.lib.sv_beam_step(self._h, _ptr(x), x.stride(0), C.byref(done), par, tok, sc, _stream()), "sv_beam_step")
+        return bool(done.value), torch.tensor(list(par)), torch.tensor(list(tok)), torch.tensor(list(sc))
+
+    def finalize(self):
+        toks = (C.c_int64 * (self.batch * self.max_new))()
+        sc = (C.c_float * self.batch)()
+        n = C.c_int32(0)
+        check(self.lib.sv_beam_finalize(self._h, toks, C.byref(n), sc, _stream()), "sv_beam_finalize")
+        t = torch.tensor(list(toks), dtype=torch.int64).view(self.batch, self.max_new)[:, : n.value].contiguous()
+        return t, torch.tensor(list(sc))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.sv_beam_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def bench_linear(M: int, N: int, K: int, act: str = "none", residual: bool = False, iters: int = 10) -> float:

@@ -278,9 +278,14 @@ class HipCausalLM(_EngineModule):
                  num_return_sequences: int = 1, **unused) -> torch.Tensor:
         if inputs_embeds is None:
             raise ValueError("inputs_embeds is required (the reference always generates from embeddings)")
-        if num_beams != 1:
-            raise NotImplementedError("beam search (num_beams>1) is the next row of the build plan "
-                                      "(SURVEY.md section 8f rank 2); pass num_beams=1")
+        num_beams = int(num_beams)
+        if num_beams < 1:
+            raise ValueError("`num_beams` has to be an integer strictly greater than 0")     # HF's own check
+        if num_beams > 1 and do_sample:
+            raise NotImplementedError("beam-sample (num_beams > 1 with do_sample / use_nucleus_sampling=True) is not "
+                                      "built; pass use_nucleus_sampling=False for beam search or num_beams=1 to sample")
+        if num_beams > 8:
+            raise NotImplementedError("num_beams > 8 is not built")
         if num_return_sequences != 1:
             raise NotImplementedError("num_return_sequences > 1 not built yet")
         if repetition_penalty is not None and not repetition_penalty > 0:
@@ -300,7 +305,9 @@ class HipCausalLM(_EngineModule):
             eos_token_id=int(self.eos_token_id if eos_token_id is None else eos_token_id),
             pad_token_id=int(self.pad_token_id if pad_token_id is None else pad_token_id),
             stop_ids=self._stop_ids(stopping_criteria), seed=self.seed,
-            repetition_penalty=float(repetition_penalty if repetition_penalty is not None else 1.0))
+            repetition_penalty=float(repetition_penalty if repetition_penalty is not None else 1.0),
+            num_beams=num_beams, length_penalty=float(length_penalty if length_penalty is not None else 1.0),
+            early_stopping=early_stopping)
 
 
 class StoppingCriteriaSub:

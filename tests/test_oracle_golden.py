@@ -122,3 +122,37 @@ def test_repetition_penalty_matches_hf(golden_dir):
     w = O.make_weights(cfg, seed=seed)
     emb = O.prepare_generation_inputs(w, cfg, g["image"], g["prompt_ids"])
     assert torch.equal(O.greedy_generate(w, cfg, emb, emb.shape[1] + n_new, repetition_penalty=pen), g["tokens"])
+
+
+def test_beam_search_matches_hf(golden_dir):
+    """num_beams > 1 (the reference's default is 2): the restated _beam_search against HF generate on every case of
+    tests/golden/tiny_beam (early_stopping True / False / "never", length penalties, EOS, the row-0 stop, the
+    repetition penalty on log-probs)."""
+    import dataclasses
+    g = _load(golden_dir, "tiny_beam")
+    seed, B, n_new = [int(x) for x in g["meta"]]
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=seed)
+    emb = O.prepare_generation_inputs(w, cfg, g["image"], g["prompt_ids"])
+    tags = sorted(k[:-len(".tokens")] for k in g if k.endswith(".tokens"))
+    assert len(tags) == 5
+    for tag in tags:
+        nb, lp, es, eos, pen = g[tag + ".params"].tolist()
+        stop = g[tag + ".stop"].tolist() or None
+        cfg2 = dataclasses.replace(cfg, eos_token_id=int(eos))
+        got = O.beam_search_generate(w, cfg2, emb, emb.shape[1] + n_new, int(nb), length_penalty=lp,
+                                     early_stopping={0: False, 1: True, 2: "never"}[int(es)], stop_ids=stop,
+                                     repetition_penalty=pen)
+        assert got.shape == g[tag + ".tokens"].shape and torch.equal(got, g[tag + ".tokens"]), tag
+
+
+def test_beam_search_single_beam_is_greedy():
+    """num_beams = 1 through the beam bookkeeping degenerates to greedy decoding (no EOS in play)."""
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=5)
+    emb = O.prepare_generation_inputs(w, cfg, O.synthetic_images(2, cfg.image_size, seed=6), torch.tensor([[7, 11]] * 2))
+    import dataclasses
+    cfg2 = dataclasses.replace(cfg, eos_token_id=-1)
+    a = O.beam_search_generate(w, cfg2, emb, emb.shape[1] + 10, 1)
+    b = O.greedy_generate(w, cfg2, emb, emb.shape[1] + 10)
+    assert torch.equal(a, b)
