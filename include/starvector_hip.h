@@ -97,9 +97,11 @@ typedef struct sv_sampling {
     int32_t sync_every;        /* host polls the device "done" flag every this many steps (0 = 32) */
     float   repetition_penalty;/* HF RepetitionPenaltyLogitsProcessor over the generated ids; 0 or 1 = off */
     int32_t num_beams;         /* 0 or 1 = greedy / sampling; 2..8 = HF beam search (the reference's default is 2,
-                                  starvector_base.py:234); batch * num_beams <= max_batch; do_sample must be 0 */
+                                  starvector_base.py:234); batch * num_beams <= max_batch; with do_sample: beam-sample */
     float   length_penalty;    /* beam search: hypothesis score = sum log-probs / len ** length_penalty (:238) */
     int32_t early_stopping;    /* beam search: 0 False (HF default), 1 True (:293), 2 "never" */
+    int32_t top_k;             /* used when do_sample: HF TopKLogitsWarper before top-p; 0 = off.  The reference never
+                                  passes it, but its pinned transformers==4.49.0 defaults GenerationConfig.top_k to 50 */
 } sv_sampling;
 
 /* HF beam search bookkeeping as a standalone device-side scorer (what transformers' _beam_search does between two
@@ -114,6 +116,11 @@ typedef struct sv_beam_config {
     float   repetition_penalty;
     int32_t n_stop;            /* the reference's row-0 stop sequence (starvector_base.py:9-20) */
     const int32_t* stop_ids;   /* host pointer */
+    int32_t do_sample;         /* beam-sample: warpers (temperature, top_k, top_p; min_tokens_to_keep 2) on the log-probs,
+                                  then 2*num_beams draws without replacement from softmax(accumulated scores) */
+    float   temperature, top_p;
+    int32_t top_k;
+    uint64_t seed;
 } sv_beam_config;
 
 int  sv_abi_version(void);
@@ -214,6 +221,9 @@ int  sv_op_plane_layernorm(const void* x, const void* gamma, const void* beta, v
 int  sv_op_argmax(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t* out, sv_stream stream);
 int  sv_op_sample_top_p(const float* logits, int32_t B, int32_t V, int32_t ld, float temperature,
                         float top_p, uint64_t seed, int32_t step, int32_t* out, sv_stream stream);
+/* temperature -> top-k (0 = off) -> top-p -> one multinomial draw per row */
+int  sv_op_sample(const float* logits, int32_t B, int32_t V, int32_t ld, float temperature, int32_t top_k,
+                  float top_p, uint64_t seed, int32_t step, int32_t* out, sv_stream stream);
 
 #ifdef __cplusplus
 }

@@ -29,6 +29,7 @@ from .starvector_oracle import (  # noqa: F401
     beam_search_generate,
     BeamSearchState,
     top_p_filtered_probs,
+    warp_scores,
     generate_im2svg_tokens,
     synthetic_images,
     siglip_forward,

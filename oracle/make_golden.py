@@ -341,6 +341,55 @@ def run_beam_cases(write):
         print("  wrote tests/golden/tiny_beam.safetensors")
 
 
+def run_sampling_cases(write):
+    """do_sample paths.  (1) The warpers: temperature -> top-k -> top-p against HF's own warper classes (the reference
+    never passes top_k, but its pinned transformers==4.49.0 defaults it to 50).  (2) beam-sample (the reference's
+    validation-time generation: num_beams 3 + nucleus sampling, configs/models/starvector-8b/im2svg-stack.yaml:75-81):
+    with the same torch seed the restated loop draws exactly what HF generate draws."""
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    g = torch.Generator().manual_seed(0)
+    for (T, tp, tk, mk) in [(0.7, 0.9, 50, 1), (1.0, 0.9, 50, 2), (1.3, 0.5, 5, 2), (1.0, 1.0, 50, 1), (0.8, 0.95, 0, 1),
+                            (1.0, 0.01, 50, 2)]:
+        lg = 3 * torch.randn(6, 300, generator=g)
+        ref = lg.clone()
+        if T != 1.0:
+            ref = TemperatureLogitsWarper(T)(None, ref)
+        if tk:
+            ref = TopKLogitsWarper(top_k=tk, min_tokens_to_keep=mk)(None, ref)
+        if tp < 1:
+            ref = TopPLogitsWarper(top_p=tp, min_tokens_to_keep=mk)(None, ref)
+        assert torch.equal(O.warp_scores(lg, T, tp, tk, mk), ref), (T, tp, tk, mk)
+    print("[warpers] temperature/top-k/top-p == HF warper classes on 6 settings")
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=99)
+    B, n_new = 3, 12
+    image = O.synthetic_images(B, cfg.image_size, seed=98)
+    prompt_ids = torch.tensor([[7, 11]] * B, dtype=torch.long)
+    emb = O.prepare_generation_inputs(w, cfg, image, prompt_ids)
+    _, _, _, lm = build_reference(cfg, w)
+    out = {"image": image, "prompt_ids": prompt_ids, "meta": torch.tensor([99, B, n_new, 1234])}
+    for i, (nb, T, tp, tk, es, lp) in enumerate([(3, 1.0, 0.9, 50, False, 0.5), (2, 0.7, 0.95, 50, True, 1.0),
+                                                 (3, 1.0, 1.0, 0, True, 1.0)]):
+        kw = dict(inputs_embeds=emb, attention_mask=torch.ones(emb.shape[:2], dtype=torch.long), do_sample=True,
+                  num_beams=nb, top_p=tp, temperature=T, top_k=tk if tk else None, max_length=emb.shape[1] + n_new,
+                  min_length=1, repetition_penalty=1.0, length_penalty=lp, use_cache=True,
+                  pad_token_id=cfg.pad_token_id, early_stopping=es)
+        torch.manual_seed(1234)
+        ref = lm.generate(**kw)
+        torch.manual_seed(1234)
+        mine = O.beam_search_generate(w, cfg, emb, emb.shape[1] + n_new, nb, length_penalty=lp, early_stopping=es,
+                                      do_sample=True, temperature=T, top_p=tp, top_k=tk)
+        same = ref.shape == mine.shape and torch.equal(ref, mine)
+        print(f"[tiny_beam_sample/{i}] nb={nb} T={T} top_p={tp} top_k={tk}: HF {tuple(ref.shape)} equal: {same}")
+        assert same
+        out[f"case{i}.tokens"] = ref.contiguous()
+        out[f"case{i}.params"] = torch.tensor([nb, T, tp, tk, {True: 1, False: 0}[es], lp], dtype=torch.float64)
+    if write:
+        from safetensors.torch import save_file
+        save_file(out, os.path.join(GOLD, "tiny_beam_sample.safetensors"))
+        print("  wrote tests/golden/tiny_beam_sample.safetensors")
+
+
 def main():
     write = "--no-write" not in sys.argv
     torch.manual_seed(0)
@@ -352,6 +401,7 @@ def main():
     run_stop_case(write)
     run_reppen_case(write)
     run_beam_cases(write)
+    run_sampling_cases(write)
     run_case_v2("tiny_v2_b2", O.OracleConfig.tiny_v2(), seed=2024, batch=2, n_new=12, write=write)
     if "--full" in sys.argv:
         # StarVector-1B shapes, 1 image, a few tokens: validates the restatement at BASELINE

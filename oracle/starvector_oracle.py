@@ -558,6 +558,9 @@ class BeamSearchState:
       * running scores start [0, -1e9, ...];
       * each step: log_softmax (fp32) -> repetition penalty on the LOG-PROBS of each beam's own ids -> add the beam's
         running score -> the K = 2*num_beams best (beam, token) continuations over num_beams*V, best first;
+        with do_sample (the reference's training-time validation uses num_beams 3 + nucleus sampling,
+        configs/models/starvector-8b/im2svg-stack.yaml:75-81) the log-probs first go through the warpers and the K
+        continuations are DRAWN without replacement from softmax(accumulated scores), kept in draw order;
       * a continuation "hits" when its token is EOS, when it reaches the budget, or when the reference's row-0
         StoppingCriteriaSub fires (it looks at the best continuation of request 0 only and returns a plain bool, which
         HF ORs into every row of every request);
@@ -572,7 +575,9 @@ class BeamSearchState:
 
     def __init__(self, batch: int, num_beams: int, vocab: int, budget: int, eos_token_id: int, pad_token_id: int,
                  length_penalty: float = 1.0, early_stopping=True, stop_ids: Optional[Sequence[int]] = None,
-                 repetition_penalty: float = 1.0):
+                 repetition_penalty: float = 1.0, do_sample: bool = False, temperature: float = 1.0,
+                 top_p: float = 1.0, top_k: int = 0):
+        self.sample = (bool(do_sample), temperature, top_p, top_k)
         self.B, self.nb, self.V, self.budget = batch, int(num_beams), vocab, budget
         self.K = 2 * self.nb
         self.eos, self.lp, self.es, self.pen = eos_token_id, length_penalty, early_stopping, repetition_penalty
@@ -600,8 +605,14 @@ class BeamSearchState:
             g = torch.gather(lp, 1, prev)
             g = torch.where(g < 0, g * self.pen, g / self.pen)
             lp = lp.scatter(1, prev, g)
+        if self.sample[0]:                                                # beam-sample: warpers act on the log-probs
+            lp = warp_scores(lp, self.sample[1], self.sample[2], self.sample[3], min_tokens_to_keep=2)
         acc = (lp.view(B, nb, V) + self.run_score[:, :, None]).reshape(B, nb * V)
-        c_score, c_idx = torch.topk(acc, K, dim=1)                       # best first
+        if self.sample[0]:                                                # K draws without replacement, in draw order
+            c_idx = torch.multinomial(torch.softmax(acc, dim=-1), num_samples=K)
+            c_score = torch.gather(acc, 1, c_idx)
+        else:
+            c_score, c_idx = torch.topk(acc, K, dim=1)                   # best first
         c_beam, c_tok = c_idx // V, c_idx % V
         c_seq = self.run_seq[ar_b, c_beam]                                # [B, K, budget]
         c_seq[:, :, cur] = c_tok
@@ -649,7 +660,8 @@ class BeamSearchState:
 def beam_search_generate(w, cfg: OracleConfig, inputs_embeds: Tensor, max_length: int, num_beams: int,
                          length_penalty: float = 1.0, early_stopping=True,
                          stop_ids: Optional[Sequence[int]] = None, mode: str = "fp32",
-                         repetition_penalty: float = 1.0, return_scores: bool = False):
+                         repetition_penalty: float = 1.0, return_scores: bool = False, do_sample: bool = False,
+                         temperature: float = 1.0, top_p: float = 1.0, top_k: int = 0):
     """generate(num_beams > 1): the prompt expanded to num_beams rows (repeat_interleave), BeamSearchState between the
     forward passes, the KV cache re-indexed by the surviving beams' parents.  Returns new tokens [B, L]
     (and the best scores [B] with return_scores)."""
@@ -659,7 +671,7 @@ def beam_search_generate(w, cfg: OracleConfig, inputs_embeds: Tensor, max_length
         raise ValueError("max_length must exceed the prompt length (HF raises here)")
     nb = int(num_beams)
     state = BeamSearchState(B, nb, cfg.vocab, budget, cfg.eos_token_id, cfg.pad_token_id, length_penalty,
-                            early_stopping, stop_ids, repetition_penalty)
+                            early_stopping, stop_ids, repetition_penalty, do_sample, temperature, top_p, top_k)
     logits, cache = decoder_prefill(w, cfg, inputs_embeds.repeat_interleave(nb, dim=0), mode)
     while True:
         go_on, flat_parent, tokens = state.step(logits)
@@ -671,18 +683,34 @@ def beam_search_generate(w, cfg: OracleConfig, inputs_embeds: Tensor, max_length
     return (out, scores) if return_scores else out
 
 
-def top_p_filtered_probs(logits: Tensor, temperature: float, top_p: float) -> Tensor:
-    """HF TemperatureLogitsWarper then TopPLogitsWarper (min_tokens_to_keep=1) then softmax:
-    the distribution torch.multinomial draws from on the do_sample=True path
-    (starvector_base.py:230-232 defaults top_p 0.9 / temperature 1)."""
-    scores = logits.float() / temperature
-    sorted_logits, sorted_idx = torch.sort(scores, descending=False, dim=-1)
-    cum = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
-    remove = cum <= (1.0 - top_p)
-    remove[..., -1:] = False
-    remove = remove.scatter(-1, sorted_idx, remove)
-    scores = scores.masked_fill(remove, float("-inf"))
-    return scores.softmax(dim=-1)
+def warp_scores(scores: Tensor, temperature: float = 1.0, top_p: float = 1.0, top_k: int = 0,
+                min_tokens_to_keep: int = 1) -> Tensor:
+    """HF TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper (generation/logits_process.py), the order
+    GenerationMixin._get_logits_processor builds them in for do_sample=True.  The reference never passes top_k, but its
+    pinned transformers==4.49.0 (pyproject.toml:18) defaults GenerationConfig.top_k to 50, so its sampling is top-k 50
+    then top-p (starvector_base.py:230-232).  Under beam search HF sets min_tokens_to_keep = 2 (one EOS id + 1).
+    Returns the warped scores (filtered entries -inf)."""
+    scores = scores.float()
+    if temperature != 1.0:
+        scores = scores / temperature
+    if top_k and top_k > 0:
+        k = min(max(int(top_k), min_tokens_to_keep), scores.shape[-1])
+        kth = torch.topk(scores, k, dim=-1).values[..., -1:]
+        scores = scores.masked_fill(scores < kth, float("-inf"))
+    if top_p is not None and top_p < 1.0:
+        sorted_logits, sorted_idx = torch.sort(scores, descending=False, dim=-1)
+        cum = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
+        remove = cum <= (1.0 - top_p)
+        remove[..., -min_tokens_to_keep:] = False
+        remove = remove.scatter(-1, sorted_idx, remove)
+        scores = scores.masked_fill(remove, float("-inf"))
+    return scores
+
+
+def top_p_filtered_probs(logits: Tensor, temperature: float, top_p: float, top_k: int = 0) -> Tensor:
+    """The distribution torch.multinomial draws from on the do_sample=True, num_beams=1 path: softmax of the warped
+    scores (starvector_base.py:230-232 defaults top_p 0.9 / temperature 1; top_k: see warp_scores)."""
+    return warp_scores(logits, temperature, top_p, top_k, 1).softmax(dim=-1)
 
 
 def generate_im2svg_tokens(w, cfg: OracleConfig, image: Tensor, prompt_ids: Tensor, max_length: int,

@@ -38,6 +38,7 @@ class SvSampling(C.Structure):
         ("n_stop", C.c_int32), ("stop_ids", C.POINTER(C.c_int32)), ("seed", C.c_uint64),
         ("sync_every", C.c_int32), ("repetition_penalty", C.c_float),
         ("num_beams", C.c_int32), ("length_penalty", C.c_float), ("early_stopping", C.c_int32),
+        ("top_k", C.c_int32),
     ]
 
 
@@ -46,7 +47,8 @@ class SvBeamConfig(C.Structure):
         ("batch", C.c_int32), ("num_beams", C.c_int32), ("vocab", C.c_int32), ("max_new", C.c_int32),
         ("eos_token_id", C.c_int32), ("pad_token_id", C.c_int32), ("early_stopping", C.c_int32),
         ("length_penalty", C.c_float), ("repetition_penalty", C.c_float), ("n_stop", C.c_int32),
-        ("stop_ids", C.POINTER(C.c_int32)),
+        ("stop_ids", C.POINTER(C.c_int32)), ("do_sample", C.c_int32), ("temperature", C.c_float),
+        ("top_p", C.c_float), ("top_k", C.c_int32), ("seed", C.c_uint64),
     ]
 
 
@@ -88,6 +90,7 @@ PROTOTYPES = {
     "sv_op_plane_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "sv_op_argmax": (_I, [_P, _I, _I, _I, _P, _P]),
     "sv_op_sample_top_p": (_I, [_P, _I, _I, _I, _F, _F, C.c_uint64, _I, _P, _P]),
+    "sv_op_sample": (_I, [_P, _I, _I, _I, _F, _I, _F, C.c_uint64, _I, _P, _P]),
 }
 
 _lib = None

@@ -24,6 +24,11 @@ struct BeamConfig {
     float penalty = 1.f;            // repetition penalty (on the log-probs, as HF's beam search applies processors)
     int n_stop = 0;
     int32_t stop[BM_MAXSTOP] = {0};
+    // beam-sample (do_sample with num_beams > 1): warpers on the log-probs, K draws without replacement
+    int do_sample = 0;
+    float temperature = 1.f, top_p = 1.f;
+    int top_k = 0;
+    uint64_t seed = 0;
 };
 
 // everything the kernels need, passed by value
@@ -38,13 +43,15 @@ struct BeamDev {
     float* fin_score; int32_t* fin_done; int32_t* fin_step; int32_t* fin_parent; int32_t* fin_tok;   // [B][nb]
     int32_t* can_improve;                              // [B]
     float* stats;                                      // [R][BM_SPLIT][2] slice (max, sum exp)
-    float* cand_val; int32_t* cand_idx;                // [R][BM_SPLIT][K] slice winners
+    float* cand_val; float* cand_key; int32_t* cand_idx;   // [R][BM_SPLIT][K] slice winners (key = ranking value)
     float* top_val; int32_t* top_beam; int32_t* top_tok;   // [B][K] best first
     const float* lenpow;                               // [max_new + 1]  t ** length_penalty
     const int32_t* stop_ids;
     uint32_t* seen; int seen_words;                    // [R][seen_words] ids each running beam has generated (or null)
     int32_t* step; int32_t* done;                      // device scalars
     int32_t* positions;                                // [R] engine position counters (+1 per step) or null
+    int do_sample; float inv_temp, top_p; int top_k; uint64_t seed;
+    float* warp;                                       // [R][8] per-row warper thresholds (WarpStats)
 };
 
 struct BeamScorer {

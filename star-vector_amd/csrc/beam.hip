@@ -2,7 +2,11 @@
 //
 // Per step (R = B * num_beams rows, K = 2 * num_beams):
 //   beam_row_stats   grid (R, 8)   slice max / sum-exp of the raw logits           (log_softmax, fp32)
+//   beam_row_warp    grid R        (beam-sample only) temperature / top-k / top-p thresholds of each row's log-probs
 //   beam_row_topk    grid (R, 8)   slice -> LDS as penalty(log_softmax) + running score; K rounds of block argmax
+//                                  (beam-sample: + Gumbel noise, so the K winners are K draws without replacement
+//                                  from softmax(accumulated scores), in draw order -- Gumbel-top-k == sequential
+//                                  sampling without replacement, which is what torch.multinomial does)
 //   beam_merge       grid B        num_beams * 8 * K slice winners -> the request's K best (beam, token), best first
 //   beam_update      1 block       HF's bookkeeping for every request: hits (EOS / budget / the reference's row-0 stop),
 //                                  next running beams, finished slots with the length penalty, early-stop heuristic,
@@ -10,6 +14,7 @@
 //   beam_seen_gather grid B        repetition-penalty bitmaps follow their beams (only when the penalty is on)
 #include "beam.h"
 #include "kernels.h"
+#include "warp.h"
 
 #include <math.h>
 #include <string.h>
@@ -50,8 +55,42 @@ __global__ __launch_bounds__(256) void beam_row_stats_kernel(BeamDev p) {
     }
 }
 
+// log_softmax row constants from the slice statistics: x -> (x - M) - logS
+__device__ __forceinline__ void bm_row_lse(const BeamDev& p, int row, float& M, float& logS) {
+    const float* st = p.stats + (size_t)row * BM_SPLIT * 2;
+    M = -INFINITY;
+#pragma unroll
+    for (int s = 0; s < BM_SPLIT; ++s) M = fmaxf(M, st[2 * s]);
+    float S = 0.f;
+#pragma unroll
+    for (int s = 0; s < BM_SPLIT; ++s) S += st[2 * s + 1] > 0.f ? st[2 * s + 1] * expf(st[2 * s] - M) : 0.f;
+    logS = logf(S);
+}
+__device__ __forceinline__ float bm_logprob(const BeamDev& p, const float* x, const uint32_t* seen, float M, float logS, int id) {
+    float lp = (x[id] - M) - logS;
+    if (seen && ((seen[id >> 5] >> (id & 31)) & 1u)) lp = lp < 0.f ? lp * p.penalty : lp / p.penalty;
+    return lp;
+}
+
+// beam-sample: HF applies the warpers to the (penalised) log-probs of every running beam
+__global__ __launch_bounds__(WP_THREADS) void beam_row_warp_kernel(BeamDev p) {
+    __shared__ float red[WP_THREADS / 64];
+    if (*p.done) return;
+    const int row = blockIdx.x;
+    const float* x = p.logits + (size_t)(row / p.logit_div) * p.ld;
+    const uint32_t* seen = p.seen ? p.seen + (size_t)row * p.seen_words : nullptr;
+    float M, logS;
+    bm_row_lse(p, row, M, logS);
+    auto sc = [&](int i) { return bm_logprob(p, x, seen, M, logS, i) * p.inv_temp; };
+    const WarpStats w = row_warp_stats(sc, p.V, p.top_k, p.top_p, 2, red);      // min_tokens_to_keep = 2 under beams
+    if (threadIdx.x == 0) {
+        float* o = p.warp + (size_t)row * 8;
+        o[0] = w.kth; o[1] = w.mx; o[2] = w.invZ; o[3] = w.v0; o[4] = w.smin;
+    }
+}
+
 __global__ __launch_bounds__(256) void beam_row_topk_kernel(BeamDev p) {
-    extern __shared__ float sl[];                  // the slice's accumulated scores
+    extern __shared__ float sl[];                  // the slice's ranking keys
     __shared__ float rv[4];
     __shared__ int ri[4];
     if (*p.done) return;
@@ -61,26 +100,36 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(BeamDev p) {
     const int per = bm_slice(p.V);
     const int beg = blockIdx.y * per, end = min(beg + per, p.V);
     const int n = max(end - beg, 0);
-    // log_softmax = (x - max) - log(sum exp(x - max))
-    const float* st = p.stats + (size_t)row * BM_SPLIT * 2;
-    float M = -INFINITY;
-#pragma unroll
-    for (int s = 0; s < BM_SPLIT; ++s) M = fmaxf(M, st[2 * s]);
-    float S = 0.f;
-#pragma unroll
-    for (int s = 0; s < BM_SPLIT; ++s) S += st[2 * s + 1] > 0.f ? st[2 * s + 1] * expf(st[2 * s] - M) : 0.f;
-    const float logS = logf(S);
+    float M, logS;
+    bm_row_lse(p, row, M, logS);
     const float base = p.run_score[row];
     const uint32_t* seen = p.seen ? p.seen + (size_t)row * p.seen_words : nullptr;
+    WarpStats w;
+    if (p.do_sample) {
+        const float* o = p.warp + (size_t)row * 8;
+        w.kth = o[0]; w.mx = o[1]; w.invZ = o[2]; w.v0 = o[3]; w.smin = o[4];
+    }
+    const uint64_t noise_seed = p.do_sample ? wp_splitmix64(p.seed ^ wp_splitmix64(((uint64_t)(uint32_t)*p.step << 32) | (uint32_t)row)) : 0ull;
+    // accumulated score of continuation `id` of this beam (what HF ranks / samples from)
+    auto acc_of = [&](int id) {
+        float s = bm_logprob(p, x, seen, M, logS, id);
+        if (p.do_sample) {
+            s *= p.inv_temp;
+            if (!wp_keep(w, s)) s = -INFINITY;
+        }
+        return s + base;
+    };
     for (int i = tid; i < n; i += 256) {
-        float lp = (x[beg + i] - M) - logS;
-        const int id = beg + i;
-        if (seen && ((seen[id >> 5] >> (id & 31)) & 1u)) lp = lp < 0.f ? lp * p.penalty : lp / p.penalty;
-        sl[i] = lp + base;
+        float key = acc_of(beg + i);
+        if (p.do_sample) {
+            const uint64_t h = wp_splitmix64(noise_seed + (uint64_t)(beg + i));
+            const float u = ((float)(h >> 40) + 0.5f) * (1.0f / 16777216.0f);          // (0, 1)
+            key += -logf(-logf(u));                                                    // Gumbel(0, 1)
+        }
+        sl[i] = key;
     }
     __syncthreads();
-    float* cv = p.cand_val + ((size_t)row * BM_SPLIT + blockIdx.y) * p.K;
-    int32_t* ci = p.cand_idx + ((size_t)row * BM_SPLIT + blockIdx.y) * p.K;
+    const size_t slot = ((size_t)row * BM_SPLIT + blockIdx.y) * p.K;
     for (int k = 0; k < p.K; ++k) {
         float best = -INFINITY;
         int bi = 0x7fffffff;
@@ -94,10 +143,11 @@ __global__ __launch_bounds__(256) void beam_row_topk_kernel(BeamDev p) {
         if (lane == 0) { rv[wave] = best; ri[wave] = bi; }
         __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < 4; ++w) bm_pair(best, bi, rv[w], ri[w]);
+            for (int w2 = 1; w2 < 4; ++w2) bm_pair(best, bi, rv[w2], ri[w2]);
             const bool ok = bi != 0x7fffffff;
-            cv[k] = ok ? best : -INFINITY;
-            ci[k] = ok ? beg + bi : -1;
+            p.cand_key[slot + k] = ok ? best : -INFINITY;
+            p.cand_val[slot + k] = ok ? (p.do_sample ? acc_of(beg + bi) : best) : -INFINITY;
+            p.cand_idx[slot + k] = ok ? beg + bi : -1;
             if (ok) sl[bi] = -INFINITY;            // taken
         }
         __syncthreads();
@@ -111,18 +161,19 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(BeamDev p) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int per_row = BM_SPLIT * p.K;
     const int n = p.nb * per_row;                  // <= 8 * 8 * 16 = 1024
-    float v[16];
+    float v[16], val[16];
     int f[16];
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int i = lane + 64 * j;
         v[j] = -INFINITY;
+        val[j] = -INFINITY;
         f[j] = 0x7fffffff;
         if (i < n) {
             const int beam = i / per_row;
             const size_t src = (size_t)(b * p.nb + beam) * per_row + (i % per_row);
             const int tok = p.cand_idx[src];
-            if (tok >= 0) { v[j] = p.cand_val[src]; f[j] = beam * p.V + tok; }
+            if (tok >= 0) { v[j] = p.cand_key[src]; val[j] = p.cand_val[src]; f[j] = beam * p.V + tok; }
         }
     }
     for (int k = 0; k < p.K; ++k) {
@@ -136,12 +187,14 @@ __global__ __launch_bounds__(64) void beam_merge_kernel(BeamDev p) {
             const int of = __shfl_xor(bf, o, 64);
             bm_pair(best, bf, ov, of);
         }
+        float mine = -INFINITY;                     // the winner's unperturbed score lives in one lane
 #pragma unroll
         for (int j = 0; j < 16; ++j)
-            if (f[j] == bf && bf != 0x7fffffff) { v[j] = -INFINITY; f[j] = 0x7fffffff; }
+            if (f[j] == bf && bf != 0x7fffffff) { mine = val[j]; v[j] = -INFINITY; f[j] = 0x7fffffff; }
+        mine = wave_max(mine);
         if (lane == 0) {
             const bool ok = bf != 0x7fffffff;
-            p.top_val[b * p.K + k] = ok ? best : -INFINITY;
+            p.top_val[b * p.K + k] = ok ? mine : -INFINITY;
             p.top_beam[b * p.K + k] = ok ? bf / p.V : 0;
             p.top_tok[b * p.K + k] = ok ? bf % p.V : 0;
         }
@@ -337,7 +390,9 @@ int BeamScorer::init(const BeamConfig& cfg, int32_t* ext_cur_tok, int32_t* ext_p
     A(bm_alloc(this, &d.can_improve, c.B));
     A(bm_alloc(this, &d.stats, (size_t)R * BM_SPLIT * 2));
     A(bm_alloc(this, &d.cand_val, (size_t)R * BM_SPLIT * K));
+    A(bm_alloc(this, &d.cand_key, (size_t)R * BM_SPLIT * K));
     A(bm_alloc(this, &d.cand_idx, (size_t)R * BM_SPLIT * K));
+    A(bm_alloc(this, &d.warp, (size_t)R * 8));
     A(bm_alloc(this, &d.top_val, (size_t)c.B * K));
     A(bm_alloc(this, &d.top_beam, (size_t)c.B * K));
     A(bm_alloc(this, &d.top_tok, (size_t)c.B * K));
@@ -360,6 +415,7 @@ int BeamScorer::init(const BeamConfig& cfg, int32_t* ext_cur_tok, int32_t* ext_p
 int BeamScorer::reset(hipStream_t st) {
     // per-call parameters (shape-independent: the device buffers are reused across calls of the same shape)
     d.eos = c.eos; d.early = c.early; d.n_stop = c.n_stop; d.length_penalty = c.length_penalty; d.penalty = c.penalty;
+    d.do_sample = c.do_sample; d.inv_temp = 1.0f / c.temperature; d.top_p = c.top_p; d.top_k = c.top_k; d.seed = c.seed;
     std::vector<float> lp((size_t)c.max_new + 1);
     // HF divides by the Python float (cur_len + 1) ** length_penalty: computed in double, used as an fp32 scalar
     for (int t = 0; t <= c.max_new; ++t) lp[t] = (float)pow((double)t, (double)c.length_penalty);
@@ -378,6 +434,7 @@ void BeamScorer::enqueue_step(const float* logits, int ld, int logit_div, hipStr
     if (!pen) a.seen = nullptr;
     const int per = (((c.V + BM_SPLIT - 1) / BM_SPLIT) + 3) & ~3;
     beam_row_stats_kernel<<<dim3(R, BM_SPLIT), 256, 0, st>>>(a);
+    if (c.do_sample) beam_row_warp_kernel<<<R, WP_THREADS, 0, st>>>(a);
     beam_row_topk_kernel<<<dim3(R, BM_SPLIT), 256, (size_t)per * sizeof(float), st>>>(a);
     beam_merge_kernel<<<c.B, 64, 0, st>>>(a);
     beam_update_kernel<<<1, ((c.B + 63) / 64) * 64, 0, st>>>(a);

@@ -1026,7 +1026,7 @@ static void sample_and_finish(sv_engine* e, int B, const sv_sampling& sp, int ma
     if (sp.do_sample) {
         SampleArgs sa;
         sa.logits = e->logits; sa.ld = e->Vpad; sa.V = e->cfg.vocab; sa.B = B; sa.temperature = sp.temperature;
-        sa.top_p = sp.top_p; sa.seed = sp.seed; sa.step = e->d_step; sa.out = e->next_tok; sa.scratch = e->sample_scratch;
+        sa.top_p = sp.top_p; sa.top_k = sp.top_k; sa.seed = sp.seed; sa.step = e->d_step; sa.out = e->next_tok; sa.scratch = e->sample_scratch;
         sa.seen = seen; sa.seen_words = e->seen_words; sa.penalty = sp.repetition_penalty;
         launch_sample_top_p(sa, st);
     } else {
@@ -1074,7 +1074,6 @@ static int generate_beam(sv_engine* e, const void* dev_embeds, int B, int S0, co
     const sv_config& c = e->cfg;
     const int nb = sp->num_beams, R = B * nb;
     if (nb > BM_MAXNB) return fail(SV_EINVAL, "num_beams %d unsupported (2..%d)", nb, BM_MAXNB);
-    if (sp->do_sample) return fail(SV_ENOTSUP, "beam search with do_sample (beam-sample) is not built");
     if (R > c.max_batch) return fail(SV_EINVAL, "batch %d x num_beams %d exceeds engine max_batch %d", B, nb, c.max_batch);
     if (sp->early_stopping < 0 || sp->early_stopping > 2) return fail(SV_EINVAL, "early_stopping must be 0 (False), 1 (True) or 2 (\"never\")");
     if (!dev_embeds || B < 1) return fail(SV_EINVAL, "generate: bad batch %d", B);
@@ -1089,6 +1088,8 @@ static int generate_beam(sv_engine* e, const void* dev_embeds, int B, int S0, co
     bc.penalty = sp->repetition_penalty > 0.f ? sp->repetition_penalty : 1.f;
     bc.n_stop = sp->n_stop;
     for (int i = 0; i < sp->n_stop; ++i) bc.stop[i] = sp->stop_ids[i];
+    bc.do_sample = sp->do_sample ? 1 : 0; bc.temperature = sp->temperature; bc.top_p = sp->top_p; bc.top_k = sp->top_k;
+    bc.seed = sp->seed;
     if (!e->beam.matches(bc)) {
         int r = e->beam.init(bc, e->cur_tok, e->positions, e->d_step, e->d_done);
         if (r) return fail(SV_ENOMEM, "beam scorer allocation failed (hip error %d)", r);
@@ -1305,6 +1306,9 @@ extern "C" int sv_beam_create(const sv_beam_config* cfg, sv_beam** out) {
     bc.pad = cfg->pad_token_id; bc.early = cfg->early_stopping; bc.length_penalty = cfg->length_penalty;
     bc.penalty = cfg->repetition_penalty > 0.f ? cfg->repetition_penalty : 1.f; bc.n_stop = cfg->n_stop;
     for (int i = 0; i < cfg->n_stop; ++i) bc.stop[i] = cfg->stop_ids[i];
+    if (cfg->do_sample && !(cfg->temperature > 0.f && cfg->top_p > 0.f)) return fail(SV_EINVAL, "sv_beam_create: temperature and top_p must be > 0");
+    bc.do_sample = cfg->do_sample ? 1 : 0; bc.temperature = cfg->do_sample ? cfg->temperature : 1.f;
+    bc.top_p = cfg->do_sample ? cfg->top_p : 1.f; bc.top_k = cfg->top_k; bc.seed = cfg->seed;
     sv_beam* h = new sv_beam();
     int r = h->s.init(bc, nullptr, nullptr, nullptr, nullptr);
     if (!r) r = h->s.reset(nullptr);
@@ -1697,17 +1701,23 @@ extern "C" int sv_op_argmax(const float* logits, int32_t B, int32_t V, int32_t l
     return 0;
 }
 
+extern "C" int sv_op_sample(const float* logits, int32_t B, int32_t V, int32_t ld, float temperature, int32_t top_k,
+                            float top_p, uint64_t seed, int32_t step, int32_t* out, sv_stream stream);
 extern "C" int sv_op_sample_top_p(const float* logits, int32_t B, int32_t V, int32_t ld, float temperature, float top_p,
                                   uint64_t seed, int32_t step, int32_t* out, sv_stream stream) {
+    return sv_op_sample(logits, B, V, ld, temperature, 0, top_p, seed, step, out, stream);
+}
+extern "C" int sv_op_sample(const float* logits, int32_t B, int32_t V, int32_t ld, float temperature, int32_t top_k,
+                            float top_p, uint64_t seed, int32_t step, int32_t* out, sv_stream stream) {
     if (!logits || !out || B < 1 || V < 1 || ld < V || !(temperature > 0.f) || !(top_p > 0.f))
-        return fail(SV_EINVAL, "sv_op_sample_top_p: bad argument");
+        return fail(SV_EINVAL, "sv_op_sample: bad argument");
     hipStream_t st = (hipStream_t)stream;
     TmpBufs tmp;
     int32_t* dstep;
     SVCHECK(tmp.get(&dstep, 1));
     HIPCHECK(hipMemcpyAsync(dstep, &step, sizeof(int32_t), hipMemcpyHostToDevice, st));
     SampleArgs sa;
-    sa.logits = logits; sa.ld = ld; sa.V = V; sa.B = B; sa.temperature = temperature; sa.top_p = top_p; sa.seed = seed;
+    sa.logits = logits; sa.ld = ld; sa.V = V; sa.B = B; sa.temperature = temperature; sa.top_p = top_p; sa.top_k = top_k; sa.seed = seed;
     sa.step = dstep; sa.out = out; sa.scratch = nullptr; sa.seen = nullptr; sa.seen_words = 0; sa.penalty = 1.f;
     launch_sample_top_p(sa, st);
     HIPCHECK(hipGetLastError());

@@ -165,7 +165,8 @@ void launch_argmax_partial(const float* logits, int ld, int V, float* pval, int3
 void launch_argmax(const float* logits, int ld, int V, int32_t* out, float* pval, int32_t* pidx, int B, hipStream_t st);
 struct SampleArgs {
     const float* logits; int ld; int V; int B;
-    float temperature, top_p; uint64_t seed; const int32_t* step;   // device step counter
+    float temperature, top_p; int top_k;                             // top_k <= 0: off
+    uint64_t seed; const int32_t* step;                              // device step counter
     int32_t* out; float* scratch;                                    // scratch >= B*4 floats
     const uint32_t* seen; int seen_words; float penalty;             // repetition penalty (nullptr = off)
 };

@@ -1,14 +1,15 @@
 // Token selection + generation bookkeeping on device (no per-step host sync).
 //   argmax        : greedy (HF _sample with do_sample=False): argmax of the fp32 logits, lowest index on ties
-//   sample_top_p  : TemperatureLogitsWarper -> TopPLogitsWarper(min_tokens_to_keep=1) -> softmax -> one
+//   sample_top_p  : TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper (warp.h) -> softmax -> one
 //                   multinomial draw (counter-based RNG; distributional parity with torch.multinomial)
 //   finish_step   : pad-after-EOS, append, EOS bookkeeping, the reference's row-0 stop sequence
 //                   (starvector_base.py:9-20), max-length budget -> device "done" flag
 #include "kernels.h"
+#include "warp.h"
 
 namespace sv {
 
-#define SP_THREADS 1024
+#define SP_THREADS WP_THREADS
 
 __device__ __forceinline__ void argmax_pair(float& v, int& i, float ov, int oi) {
     if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
@@ -73,37 +74,6 @@ void launch_argmax(const float* logits, int ld, int V, int32_t* out, float* pval
     argmax_merge_kernel<<<(B + 63) / 64, 64, 0, st>>>(pval, pidx, out, B);
 }
 
-// block-wide sum (all threads get the result)
-__device__ __forceinline__ float block_sum(float v, float* red) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    v = wave_sum(v);
-    __syncthreads();
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < SP_THREADS / 64; ++w) t += red[w];
-    return t;
-}
-__device__ __forceinline__ float block_max(float v, float* red) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    v = wave_max(v);
-    __syncthreads();
-    if (lane == 0) red[wave] = v;
-    __syncthreads();
-    float t = -INFINITY;
-#pragma unroll
-    for (int w = 0; w < SP_THREADS / 64; ++w) t = fmaxf(t, red[w]);
-    return t;
-}
-
-__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
-    x += 0x9E3779B97F4A7C15ull;
-    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-    return x ^ (x >> 31);
-}
-
 __global__ __launch_bounds__(SP_THREADS) void sample_top_p_kernel(SampleArgs p) {
     __shared__ float red[SP_THREADS / 64];
     __shared__ float scan[SP_THREADS];
@@ -114,44 +84,15 @@ __global__ __launch_bounds__(SP_THREADS) void sample_top_p_kernel(SampleArgs p) 
     const uint32_t* srow = p.seen ? p.seen + (size_t)blockIdx.x * p.seen_words : nullptr;
     const float invT = 1.0f / p.temperature;
     auto lg = [&](int i) { return rep_penalty(row[i], i, srow, p.penalty) * invT; };     // processors, then temperature
-
-    float mx = -INFINITY;
-    for (int i = tid; i < V; i += SP_THREADS) mx = fmaxf(mx, lg(i));
-    mx = block_max(mx, red);
-    float z = 0.f;
-    for (int i = tid; i < V; i += SP_THREADS) z += __expf(lg(i) - mx);
-    z = block_sum(z, red);
-    const float invZ = 1.0f / z;
-
-    // smallest probability value v0 whose at-or-below mass exceeds 1 - top_p: bisection over the
-    // (monotone) float bit pattern; tokens with prob >= v0 survive (TopPLogitsWarper: ascending
-    // sort, drop while cumulative mass <= 1 - top_p, always keep the most probable token)
-    uint32_t lo = 0u, hi = 0x3f800000u;   // (lo, hi]
-    const float cut = 1.0f - p.top_p;
-    if (p.top_p < 1.0f) {
-        while (hi - lo > 1u) {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            const float thr = __uint_as_float(mid);
-            float f = 0.f;
-            for (int i = tid; i < V; i += SP_THREADS) {
-                const float pr = __expf(lg(i) - mx) * invZ;
-                f += pr <= thr ? pr : 0.f;
-            }
-            f = block_sum(f, red);
-            if (f > cut) hi = mid; else lo = mid;
-        }
-    } else {
-        hi = 0u;
-    }
-    const float v0 = __uint_as_float(hi);
+    const WarpStats w = row_warp_stats(lg, V, p.top_k, p.top_p, 1, red);                 // TopK -> TopP thresholds
 
     // multinomial over the survivors, in index order: per-thread contiguous ranges + block scan
     const int per = (V + SP_THREADS - 1) / SP_THREADS;
     const int beg = tid * per, end = min(beg + per, V);
     float mine = 0.f;
     for (int i = beg; i < end; ++i) {
-        const float pr = __expf(lg(i) - mx) * invZ;
-        mine += pr >= v0 ? pr : 0.f;
+        const float s = lg(i);
+        mine += wp_keep(w, s) ? wp_prob(w, s) : 0.f;
     }
     scan[tid] = mine;
     __syncthreads();
@@ -163,16 +104,16 @@ __global__ __launch_bounds__(SP_THREADS) void sample_top_p_kernel(SampleArgs p) 
     }
     __syncthreads();
     const float total = red[0];
-    const uint64_t h = splitmix64(p.seed ^ splitmix64(((uint64_t)(uint32_t)p.step[0] << 32) | (uint32_t)blockIdx.x));
+    const uint64_t h = wp_splitmix64(p.seed ^ wp_splitmix64(((uint64_t)(uint32_t)p.step[0] << 32) | (uint32_t)blockIdx.x));
     const float u = (float)((h >> 40) * (1.0 / 16777216.0)) * total;
     const float base = scan[tid];
     if (mine > 0.f && u >= base && u < base + mine) {
         float run = base;
         int pick = -1;
         for (int i = beg; i < end; ++i) {
-            const float pr = __expf(lg(i) - mx) * invZ;
-            if (pr >= v0) {
-                run += pr;
+            const float s = lg(i);
+            if (wp_keep(w, s)) {
+                run += wp_prob(w, s);
                 pick = i;                 // last survivor seen (guards fp round-off at the range end)
                 if (u < run) break;
             }

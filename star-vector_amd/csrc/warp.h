@@ -1,0 +1,128 @@
+// HF logits warpers on device, shared by the sampler (sampling.hip) and beam-sample (beam.hip):
+//   TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper   (generation/logits_process.py, the order
+//   GenerationMixin._get_logits_processor builds them in), as reached from starvector_base.py:230-232.
+// transformers==4.49.0 (the reference's pin, pyproject.toml:18) defaults GenerationConfig.top_k to 50, so the
+// reference's sampling is top-k 50 THEN top-p even though it never passes top_k.
+//
+// One 1024-thread block per row.  `sc(i)` is the row's score after processors and temperature.  The filters are
+// thresholds, found by bisection over monotone float bit patterns (no sort):
+//   kth  : the top_k-th largest score        -> TopK keeps sc >= kth (ties kept, like HF's `scores < kth` removal)
+//   v0   : smallest probability whose at-or-below mass exceeds 1 - top_p, probabilities renormalised over the top-k
+//          survivors                          -> TopP keeps p >= v0
+//   smin : the min_tokens_to_keep-th largest score (1 for sampling, 2 under beam search) -> always kept
+#pragma once
+#include "common.h"
+
+namespace sv {
+
+#define WP_THREADS 1024
+
+struct WarpStats { float kth, mx, invZ, v0, smin; };
+
+__device__ __forceinline__ uint32_t wp_key(float f) {          // order-preserving float -> uint
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float wp_unkey(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// block-wide reductions over WP_THREADS threads (every thread gets the result); red: >= 16 words of LDS
+__device__ __forceinline__ float wp_block_sum(float v, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < WP_THREADS / 64; ++w) t += red[w];
+    return t;
+}
+__device__ __forceinline__ float wp_block_max(float v, float* red) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_max(v);
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float t = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < WP_THREADS / 64; ++w) t = fmaxf(t, red[w]);
+    return t;
+}
+
+__device__ __forceinline__ bool wp_keep(const WarpStats& w, float s) {
+    if (!(s >= w.kth)) return false;
+    return __expf(s - w.mx) * w.invZ >= w.v0 || s >= w.smin;
+}
+__device__ __forceinline__ float wp_prob(const WarpStats& w, float s) { return __expf(s - w.mx) * w.invZ; }
+
+template <class F>
+__device__ WarpStats row_warp_stats(F sc, int V, int top_k, float top_p, int min_keep, float* red) {
+    const int tid = threadIdx.x;
+    WarpStats w;
+    float mx = -INFINITY;
+    for (int i = tid; i < V; i += WP_THREADS) mx = fmaxf(mx, sc(i));
+    w.mx = mx = wp_block_max(mx, red);
+
+    // TopK: kth = the k-th largest score, k = max(top_k, min_keep); off when top_k <= 0 or k >= V
+    w.kth = -INFINITY;
+    const int k = top_k > 0 ? (top_k > min_keep ? top_k : min_keep) : 0;
+    if (k > 0 && k < V) {
+        uint32_t lo = 0u, hi = wp_key(mx) + 1u;          // count(key >= lo) >= k > count(key >= hi)
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            float c = 0.f;
+            for (int i = tid; i < V; i += WP_THREADS) c += wp_key(sc(i)) >= mid ? 1.f : 0.f;
+            c = wp_block_sum(c, red);                     // exact: counts < 2^24
+            if (c >= (float)k) lo = mid; else hi = mid;
+        }
+        w.kth = wp_unkey(lo);
+    }
+    float z = 0.f;
+    for (int i = tid; i < V; i += WP_THREADS) { const float s = sc(i); z += s >= w.kth ? __expf(s - mx) : 0.f; }
+    z = wp_block_sum(z, red);
+    w.invZ = 1.0f / z;
+
+    // TopP: ascending sort, drop while cumulative mass <= 1 - top_p  ==  keep p >= v0
+    w.v0 = 0.f;
+    if (top_p < 1.0f) {
+        uint32_t lo = 0u, hi = 0x3f800000u;               // (lo, hi]
+        const float cut = 1.0f - top_p;
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            const float thr = __uint_as_float(mid);
+            float f = 0.f;
+            for (int i = tid; i < V; i += WP_THREADS) {
+                const float s = sc(i);
+                const float pr = s >= w.kth ? __expf(s - mx) * w.invZ : 0.f;
+                f += pr <= thr ? pr : 0.f;
+            }
+            f = wp_block_sum(f, red);
+            if (f > cut) hi = mid; else lo = mid;
+        }
+        w.v0 = __uint_as_float(hi);
+    }
+    // min_tokens_to_keep: 1 -> the maximum; 2 -> the second largest (== the maximum if it occurs twice)
+    w.smin = mx;
+    if (min_keep >= 2) {
+        float cnt = 0.f, below = -INFINITY;
+        for (int i = tid; i < V; i += WP_THREADS) {
+            const float s = sc(i);
+            if (s == mx) cnt += 1.f; else below = fmaxf(below, s);
+        }
+        cnt = wp_block_sum(cnt, red);
+        below = wp_block_max(below, red);
+        if (cnt < 2.f) w.smin = below;
+    }
+    return w;
+}
+
+__device__ __forceinline__ uint64_t wp_splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+
+}  // namespace sv

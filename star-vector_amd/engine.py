@@ -170,9 +170,10 @@ class HipEngine:
                  temperature: float = 1.0, top_p: float = 1.0, eos_token_id: int = 0, pad_token_id: int = 0,
                  stop_ids: Optional[Sequence[int]] = None, seed: int = 0, sync_every: int = 32,
                  repetition_penalty: float = 1.0, num_beams: int = 1, length_penalty: float = 1.0,
-                 early_stopping=False) -> torch.Tensor:
+                 early_stopping=False, top_k: int = 0) -> torch.Tensor:
         """HF ``generate`` semantics for inputs_embeds: returns ONLY the new tokens, int64 [B, N].
-        ``num_beams`` > 1 runs HF's beam search on device (``early_stopping``: False, True or "never")."""
+        ``num_beams`` > 1 runs HF's beam search on device (``early_stopping``: False, True or "never"); with
+        ``do_sample`` it is HF's beam-sample.  ``top_k`` (0 = off) is HF's TopKLogitsWarper, applied before top-p."""
         x = _need(inputs_embeds, torch.bfloat16, "inputs_embeds")
         B, S0, D = x.shape
         if D != self.cfg.hidden:
@@ -185,7 +186,7 @@ class HipEngine:
         sp = SvSampling(int(bool(do_sample)), float(temperature), float(top_p), int(max_length), int(eos_token_id),
                         int(pad_token_id), len(stops), C.cast(arr, C.POINTER(C.c_int32)) if stops else None,
                         int(seed) & 0xFFFFFFFFFFFFFFFF, int(sync_every), float(repetition_penalty),
-                        int(num_beams), float(length_penalty), _early_code(early_stopping))
+                        int(num_beams), float(length_penalty), _early_code(early_stopping), int(top_k or 0))
         out = torch.empty(B, max_new, dtype=torch.int64, device=x.device)
         n = C.c_int32(0)
         check(self.lib.sv_generate(self._h, _ptr(x), B, S0, C.byref(sp), _ptr(out), C.byref(n), _stream()), "sv_generate")
@@ -232,14 +233,16 @@ class HipBeamScorer:
 
     def __init__(self, batch: int, num_beams: int, vocab: int, max_new: int, eos_token_id: int, pad_token_id: int,
                  length_penalty: float = 1.0, early_stopping=False, repetition_penalty: float = 1.0,
-                 stop_ids: Optional[Sequence[int]] = None):
+                 stop_ids: Optional[Sequence[int]] = None, do_sample: bool = False, temperature: float = 1.0,
+                 top_p: float = 1.0, top_k: int = 0, seed: int = 0):
         self.lib = _lib.load()
         stops = list(stop_ids) if stop_ids else []
         arr = (C.c_int32 * max(len(stops), 1))(*stops) if stops else None
         cfg = _lib.SvBeamConfig(int(batch), int(num_beams), int(vocab), int(max_new), int(eos_token_id),
                                 int(pad_token_id), _early_code(early_stopping), float(length_penalty),
                                 float(repetition_penalty), len(stops),
-                                C.cast(arr, C.POINTER(C.c_int32)) if stops else None)
+                                C.cast(arr, C.POINTER(C.c_int32)) if stops else None, int(bool(do_sample)),
+                                float(temperature), float(top_p), int(top_k or 0), int(seed) & 0xFFFFFFFFFFFFFFFF)
         self._h = C.c_void_p()
         self.rows, self.batch, self.vocab, self.max_new = batch * num_beams, batch, vocab, max_new
         check(self.lib.sv_beam_create(C.byref(cfg), C.byref(self._h)), "sv_beam_create")
@@ -364,10 +367,10 @@ def op_argmax(logits):
     return out
 
 
-def op_sample_top_p(logits, temperature, top_p, seed, step):
+def op_sample_top_p(logits, temperature, top_p, seed, step, top_k=0):
     lib = _lib.load()
     logits = _need(logits, torch.float32, "logits"); B, V = logits.shape
     out = torch.empty(B, dtype=torch.int32, device=logits.device)
-    check(lib.sv_op_sample_top_p(_ptr(logits), B, V, V, float(temperature), float(top_p), int(seed), int(step),
-                                 _ptr(out), _stream()))
+    check(lib.sv_op_sample(_ptr(logits), B, V, V, float(temperature), int(top_k), float(top_p), int(seed), int(step),
+                           _ptr(out), _stream()))
     return out

@@ -275,15 +275,14 @@ class HipCausalLM(_EngineModule):
                  num_beams: int = 1, max_length: int = 30, min_length: int = 0, repetition_penalty: float = 1.0,
                  length_penalty: float = 1.0, use_cache: bool = True, stopping_criteria=None,
                  early_stopping: bool = False, pad_token_id: Optional[int] = None, eos_token_id: Optional[int] = None,
-                 num_return_sequences: int = 1, **unused) -> torch.Tensor:
+                 num_return_sequences: int = 1, top_k: Optional[int] = 50, **unused) -> torch.Tensor:
+        # top_k: the reference never passes it; its pinned transformers==4.49.0 (pyproject.toml:18) defaults
+        # GenerationConfig.top_k to 50, so every do_sample call there is top-k 50 followed by top-p.  Same default here.
         if inputs_embeds is None:
             raise ValueError("inputs_embeds is required (the reference always generates from embeddings)")
         num_beams = int(num_beams)
         if num_beams < 1:
             raise ValueError("`num_beams` has to be an integer strictly greater than 0")     # HF's own check
-        if num_beams > 1 and do_sample:
-            raise NotImplementedError("beam-sample (num_beams > 1 with do_sample / use_nucleus_sampling=True) is not "
-                                      "built; pass use_nucleus_sampling=False for beam search or num_beams=1 to sample")
         if num_beams > 8:
             raise NotImplementedError("num_beams > 8 is not built")
         if num_return_sequences != 1:
@@ -307,7 +306,7 @@ class HipCausalLM(_EngineModule):
             stop_ids=self._stop_ids(stopping_criteria), seed=self.seed,
             repetition_penalty=float(repetition_penalty if repetition_penalty is not None else 1.0),
             num_beams=num_beams, length_penalty=float(length_penalty if length_penalty is not None else 1.0),
-            early_stopping=early_stopping)
+            early_stopping=early_stopping, top_k=int(top_k or 0))
 
 
 class StoppingCriteriaSub:

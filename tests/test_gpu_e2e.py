@@ -187,8 +187,10 @@ def test_drop_in_api_generate_im2svg():
     assert out[0] == out[1]                                            # identical images -> identical streams
     res = model.model.generate_im2svg_grpo(batch, max_length=S0 + 10, num_beams=1, use_nucleus_sampling=False)
     assert res["outputs"].shape == (2, 4 + 10) and res["inputs_embeds"].shape == (2, S0, cfg.hidden)
-    with pytest.raises(NotImplementedError):
-        model.generate_im2svg(batch, max_length=S0 + 10)               # reference default num_beams=2: next row
+    dflt = model.generate_im2svg(batch, max_length=S0 + 10)            # the reference's defaults: num_beams=2 + nucleus sampling
+    assert len(dflt) == 2 and all(s.startswith("<svg") for s in dflt)
+    beams = model.generate_im2svg(batch, max_length=S0 + 10, num_beams=2, use_nucleus_sampling=False)
+    assert len(beams) == 2 and beams[0] == beams[1] and beams[0].startswith("<svg")
     # text2svg (starvector_base.py:297-330 by intent): caption ids + <svg-start> -> new token ids, budget = max_length - prompt
     cap = {"caption": ["a red square", "a red square"], "image": batch["image"]}
     t2s = model.model.generate_text2svg(cap, max_length=13 + 9, num_beams=1, use_nucleus_sampling=False)

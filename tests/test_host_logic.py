@@ -75,8 +75,6 @@ def test_generate_kwargs_validation_without_gpu():
     lm.eos_token_id, lm.pad_token_id, lm.seed = 0, 1, 0
     emb = torch.zeros(1, 4, 8)
     with pytest.raises(NotImplementedError):
-        lm.generate(inputs_embeds=emb, num_beams=2, do_sample=True, max_length=8)     # beam-sample: not built, says so
-    with pytest.raises(NotImplementedError):
         lm.generate(inputs_embeds=emb, num_beams=9, max_length=8)
     with pytest.raises(ValueError):
         lm.generate(inputs_embeds=emb, num_beams=0, max_length=8)

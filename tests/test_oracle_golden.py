@@ -156,3 +156,38 @@ def test_beam_search_single_beam_is_greedy():
     a = O.beam_search_generate(w, cfg2, emb, emb.shape[1] + 10, 1)
     b = O.greedy_generate(w, cfg2, emb, emb.shape[1] + 10)
     assert torch.equal(a, b)
+
+
+def test_warpers_match_hf_classes():
+    """temperature -> top-k -> top-p restated == HF's warper classes (transformers is importable on both boxes)."""
+    lp = pytest.importorskip("transformers.generation.logits_process")
+    g = torch.Generator().manual_seed(3)
+    for (T, tp, tk, mk) in [(0.7, 0.9, 50, 1), (1.0, 0.9, 50, 2), (1.3, 0.5, 5, 2), (1.0, 1.0, 50, 1), (0.8, 0.95, 0, 1)]:
+        lg = 3 * torch.randn(5, 257, generator=g)
+        ref = lg.clone()
+        if T != 1.0:
+            ref = lp.TemperatureLogitsWarper(T)(None, ref)
+        if tk:
+            ref = lp.TopKLogitsWarper(top_k=tk, min_tokens_to_keep=mk)(None, ref)
+        if tp < 1:
+            ref = lp.TopPLogitsWarper(top_p=tp, min_tokens_to_keep=mk)(None, ref)
+        assert torch.equal(O.warp_scores(lg, T, tp, tk, mk), ref)
+    # top-k keeps ties with the k-th value; top_k = 0 is off
+    tie = torch.tensor([[1.0, 3.0, 3.0, 2.0, 0.0]])
+    assert (O.warp_scores(tie, top_k=1) > float("-inf")).sum() == 2
+    assert torch.equal(O.warp_scores(tie, top_k=0), tie)
+
+
+def test_beam_sample_matches_hf(golden_dir):
+    """Beam-sample: with torch's RNG seeded as at minting time the restated loop reproduces HF generate's draws."""
+    g = _load(golden_dir, "tiny_beam_sample")
+    seed, B, n_new, rng = [int(x) for x in g["meta"]]
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=seed)
+    emb = O.prepare_generation_inputs(w, cfg, g["image"], g["prompt_ids"])
+    for i in range(3):
+        nb, T, tp, tk, es, lp = g[f"case{i}.params"].tolist()
+        torch.manual_seed(rng)
+        got = O.beam_search_generate(w, cfg, emb, emb.shape[1] + n_new, int(nb), length_penalty=lp, early_stopping=bool(es),
+                                     do_sample=True, temperature=T, top_p=tp, top_k=int(tk))
+        assert got.shape == g[f"case{i}.tokens"].shape and torch.equal(got, g[f"case{i}.tokens"]), i
