@@ -81,6 +81,9 @@ typedef struct sv_config {
     float   rope_theta;        /* v2: rotary base (1e6 for bigcode/starcoder2-7b) */
     int32_t vit_mlp;           /* v2: SigLIP intermediate size (v1: 4 * vit_width) */
     float   vit_eps;           /* v2: SigLIP layer_norm_eps 1e-6 (v1: ln_eps) */
+    int32_t sliding_window;    /* v2: a query sees the last `sliding_window` keys, itself included (4096 for
+                                  bigcode/starcoder2-7b; HF's eager/sdpa mask `kv > q - W`); 0 = full attention.
+                                  The prompt must fit inside the window. */
 } sv_config;
 
 /* generate(...) arguments that reach HF generate through starvector_base.py:228-241 */

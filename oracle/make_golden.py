@@ -138,7 +138,7 @@ def build_reference_v2(cfg, w):
                           num_hidden_layers=cfg.n_layer, num_attention_heads=cfg.n_head,
                           num_key_value_heads=cfg.n_kv_head, hidden_act="gelu_pytorch_tanh",
                           max_position_embeddings=cfg.n_positions, norm_epsilon=cfg.ln_eps, rope_theta=cfg.rope_theta,
-                          sliding_window=4096, use_bias=True, tie_word_embeddings=True, residual_dropout=0.0,
+                          sliding_window=cfg.sliding_window or 4096, use_bias=True, tie_word_embeddings=True, residual_dropout=0.0,
                           embedding_dropout=0.0, attention_dropout=0.0, bos_token_id=cfg.eos_token_id,
                           eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id)
     lm = Starcoder2ForCausalLM(sc)
@@ -390,6 +390,33 @@ def run_sampling_cases(write):
         print("  wrote tests/golden/tiny_beam_sample.safetensors")
 
 
+def run_window_case(write):
+    """StarCoder2 sliding window (bigcode/starcoder2-7b: 4096; here 24 so that 40 new tokens leave it): HF's mask
+    `kv > q - W` on the un-cropped cache."""
+    import dataclasses
+    cfg = dataclasses.replace(O.OracleConfig.tiny_v2(), sliding_window=24)
+    w = O.make_weights(cfg, seed=2024)
+    _, _, lm = build_reference_v2(cfg, w)
+    B, n_new = 2, 40
+    image = O.synthetic_images(B, cfg.image_size, seed=5)
+    prompt_ids = torch.tensor([[7, 11]] * B, dtype=torch.long)
+    emb = O.prepare_generation_inputs(w, cfg, image, prompt_ids)
+    ref = lm.generate(inputs_embeds=emb, attention_mask=torch.ones(emb.shape[:2], dtype=torch.long), do_sample=False,
+                      num_beams=1, max_length=emb.shape[1] + n_new, use_cache=True, pad_token_id=cfg.pad_token_id,
+                      eos_token_id=None)
+    free = dataclasses.replace(cfg, eos_token_id=-1)
+    mine = O.greedy_generate(w, free, emb, emb.shape[1] + n_new)
+    nowin = O.greedy_generate(w, dataclasses.replace(free, sliding_window=0), emb, emb.shape[1] + n_new)
+    print(f"[tiny_v2_window] W=24, S0={emb.shape[1]}, {n_new} new tokens: tokens == HF {torch.equal(ref, mine)}; "
+          f"differs from full attention: {not torch.equal(mine, nowin)}")
+    assert torch.equal(ref, mine) and not torch.equal(mine, nowin)
+    if write:
+        from safetensors.torch import save_file
+        save_file({"image": image, "prompt_ids": prompt_ids, "tokens": ref.contiguous(),
+                   "meta": torch.tensor([2024, B, n_new, 24])}, os.path.join(GOLD, "tiny_v2_window.safetensors"))
+        print("  wrote tests/golden/tiny_v2_window.safetensors")
+
+
 def main():
     write = "--no-write" not in sys.argv
     torch.manual_seed(0)
@@ -403,6 +430,7 @@ def main():
     run_beam_cases(write)
     run_sampling_cases(write)
     run_case_v2("tiny_v2_b2", O.OracleConfig.tiny_v2(), seed=2024, batch=2, n_new=12, write=write)
+    run_window_case(write)
     if "--full" in sys.argv:
         # StarVector-1B shapes, 1 image, a few tokens: validates the restatement at BASELINE
         # config 1 (too large to commit; run on demand)

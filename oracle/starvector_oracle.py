@@ -60,6 +60,7 @@ class OracleConfig:
     rope_theta: float = 1e6       # v2: rotary base (bigcode/starcoder2-7b config)
     vit_mlp: int = 4096           # v2: SigLIP intermediate size
     vit_eps: float = 1e-6         # v2: SigLIP layer_norm_eps
+    sliding_window: int = 0       # v2: StarCoder2 attends to the last `sliding_window` keys (bigcode/starcoder2-7b: 4096); 0 = off
 
     @property
     def n_patches(self) -> int:
@@ -79,7 +80,7 @@ class OracleConfig:
         (configs/models/starvector-8b/im2svg-stack.yaml:7-11; llm/starcoder2.py:47 adds 4 tokens + [PAD])."""
         return OracleConfig(image_size=384, patch_size=16, vit_width=1024, vit_layers=24, vit_heads=16, vit_mlp=4096,
                             hidden=4608, n_layer=32, n_head=36, n_kv_head=4, n_inner=18432, vocab=49152 + 5,
-                            n_positions=16384, eos_token_id=0, pad_token_id=0, arch="v2")
+                            n_positions=16384, eos_token_id=0, pad_token_id=0, arch="v2", sliding_window=4096)
 
     @staticmethod
     def tiny_v2() -> "OracleConfig":
@@ -421,8 +422,12 @@ def _rot_half(x: Tensor) -> Tensor:
 
 def _block_v2(w, cfg: OracleConfig, p: str, h: Tensor, k_cache, v_cache, r):
     """Starcoder2DecoderLayer (transformers modeling_starcoder2): pre-LN, q/k/v/o projections with bias,
-    rotary embedding (rotate_half convention), GQA, GELU-tanh MLP.  Sliding window (4096) is not reached on this
-    path's contexts and is not modelled.  Returns (h, k_all [B,Hkv,L,dh], v_all)."""
+    rotary embedding (rotate_half convention), GQA, GELU-tanh MLP.  Sliding window: query i sees keys
+    i - sliding_window < j <= i (HF's eager/sdpa mask and masking_utils.sliding_window_overlay; the KV cache itself is
+    never cropped).  NOTE transformers 4.49's flash_attention_2 path -- the one the reference selects,
+    llm/starcoder2.py:25 -- passes window_size=(W, W) to flash-attn, i.e. W + 1 keys; later releases pass W - 1
+    ("we look at a max of `sliding_window` tokens back"), matching the mask used here.
+    Returns (h, k_all [B,Hkv,L,dh], v_all)."""
     B, S, D = h.shape
     H, Hkv, dh = cfg.n_head, cfg.n_kv_head, cfg.head_dim
     x = r(_ln(h, w[p + "input_layernorm.weight"], w[p + "input_layernorm.bias"], cfg.ln_eps))
@@ -443,6 +448,8 @@ def _block_v2(w, cfg: OracleConfig, p: str, h: Tensor, k_cache, v_cache, r):
     qi = torch.arange(L - S, L).view(S, 1)
     kj = torch.arange(L).view(1, L)
     s = s.masked_fill(kj > qi, float("-inf"))
+    if cfg.sliding_window:
+        s = s.masked_fill(kj <= qi - cfg.sliding_window, float("-inf"))
     pr = r(torch.softmax(s, dim=-1))
     o = r((pr @ vv).transpose(1, 2).reshape(B, S, H * dh))
     h = r(h + r(o @ w[p + "self_attn.o_proj.weight"].T + w[p + "self_attn.o_proj.bias"]))

@@ -319,7 +319,10 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     const int pos = p.positions[b];
     const int L = pos + 1;
     const int ngroups = (L + 31) >> 5;
-    int act = (ngroups + AD_GROUPS_PER_BLOCK - 1) / AD_GROUPS_PER_BLOCK;
+    // StarCoder2 sliding window: only keys win0 <= j <= pos are visible; whole groups (and pages) below are skipped
+    const int win0 = (p.window > 0 && L > p.window) ? L - p.window : 0;
+    const int g0 = win0 >> 5;
+    int act = (ngroups - g0 + AD_GROUPS_PER_BLOCK - 1) / AD_GROUPS_PER_BLOCK;
     act = act > p.max_splits ? p.max_splits : act;      // host cap: B * act <= #CUs (one block per CU) and <= AD_SPLIT
     act = act < 1 ? 1 : act;
     if (split >= act) return;
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     const int32_t* table = p.block_table + (size_t)b * p.max_pages;
     // the KV stream does not depend on q: request the first group before anything else
     const int stride = act * AD_WAVES;
-    int g = split + act * wave;
+    int g = g0 + split + act * wave;
     KvFrags<D> fa, fb;
     if (g < ngroups) load_group<D>(fa, pool, table, page_bytes, g, lane);
 
@@ -452,7 +455,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = t0 + 16 * u + 4 * c + r;
-                sc[u][r] = key <= pos ? accS[u][r] * p.scale : -INFINITY;
+                sc[u][r] = (key <= pos && key >= win0) ? accS[u][r] * p.scale : -INFINITY;
                 mt = fmaxf(mt, sc[u][r]);
             }
         }

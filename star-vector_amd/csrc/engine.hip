@@ -355,6 +355,7 @@ extern "C" void sv_config_default_1b(sv_config* c) {
     c->vocab = 49156; c->n_positions = 8192; c->max_batch = 32; c->max_seq_len = 2048; c->ln_eps = 1e-5f;
     c->device = 0;
     c->arch = SV_ARCH_V1; c->n_kv_head = 1; c->rope_theta = 0.f; c->vit_mlp = 4096; c->vit_eps = 1e-5f;
+    c->sliding_window = 0;
 }
 
 extern "C" void sv_config_default_8b(sv_config* c) {
@@ -364,6 +365,7 @@ extern "C" void sv_config_default_8b(sv_config* c) {
     c->vocab = 49152 + 5; c->n_positions = 16384; c->max_batch = 16; c->max_seq_len = 4096; c->ln_eps = 1e-5f;
     c->device = 0;
     c->arch = SV_ARCH_V2; c->n_kv_head = 4; c->rope_theta = 1e6f; c->vit_mlp = 4096; c->vit_eps = 1e-6f;
+    c->sliding_window = 4096;
 }
 
 extern "C" int sv_destroy(sv_engine* e) {
@@ -396,8 +398,8 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     if (c.n_head / nkv > 16) return fail(SV_EINVAL, "decode attention supports <= 16 query heads per KV head");
     if (c.vit_width % 64 || c.hidden % 64 || c.n_inner % 64) return fail(SV_EINVAL, "dims must be multiples of 64");
     if (v2 && (c.vit_mlp < 64 || c.vit_mlp % 64 || !(c.rope_theta > 1.f))) return fail(SV_EINVAL, "bad vit_mlp / rope_theta");
-    if (v2 && c.max_seq_len > 4096)
-        return fail(SV_EINVAL, "StarCoder2's 4096-token sliding window is not built: max_seq_len must be <= 4096");
+    if (c.sliding_window < 0 || (!v2 && c.sliding_window != 0))
+        return fail(SV_EINVAL, "sliding_window must be >= 0 (and 0 for the GPTBigCode decoder)");
     if (c.max_batch < 1 || c.max_seq_len < 2 || c.max_seq_len > c.n_positions)
         return fail(SV_EINVAL, "bad max_batch / max_seq_len");
     hipError_t r = hipSetDevice(c.device);
@@ -766,6 +768,8 @@ static int prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hi
     const sv_config& c = e->cfg;
     const int D = c.hidden, dh = e->dh, F = c.n_inner, M = B * S0, QKV = e->QKV, nkv = e->nkv;
     const int QD = c.n_head * dh;                      // width of the query block (= D for both model families)
+    if (c.sliding_window > 0 && S0 > c.sliding_window)
+        return fail(SV_ENOTSUP, "prompt of %d rows exceeds the %d-token sliding window (windowed prefill is not built)", S0, c.sliding_window);
     SVCHECK(ensure_prefill_ws(e, (size_t)M));
     if (e->v2)      // StarCoder2: no learned positions (rotary), hidden = inputs_embeds
         HIPCHECK(hipMemcpyAsync(e->ph, embeds, (size_t)M * D * sizeof(bf16_t), hipMemcpyDeviceToDevice, st));
@@ -818,6 +822,7 @@ static void decode_forward_fused(sv_engine* e, int B, hipStream_t st) {
         ad.qkv = e->qkv_rm; ad.ld_qkv = e->ldq;
         ad.pool_layer = e->kv_pool + (size_t)i * e->layer_stride; ad.block_table = e->block_table;
         ad.max_pages = e->pages_per_seq; ad.positions = e->positions; ad.out_xp = e->xp_attn; ad.out_KS = D / 16;
+        ad.window = c.sliding_window;
         ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
         ad.part = e->attn_part; ad.counters = e->attn_cnt;
         { const int ms = e->num_cus / (B * e->nkv); ad.max_splits = ms < 1 ? 1 : (ms > 16 ? 16 : ms); }
@@ -880,6 +885,7 @@ static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
         ad.ws = wsA; ad.splitk = L.c_attn.splitk; ad.ldws = e->ldws; ad.rows_ws = MT * 32; ad.bias = L.c_attn.bias;
         ad.pool_layer = e->kv_pool + (size_t)i * e->layer_stride; ad.block_table = e->block_table;
         ad.max_pages = e->pages_per_seq; ad.positions = e->positions; ad.out_xp = e->xp_attn; ad.out_KS = D / 16;
+        ad.window = c.sliding_window;
         ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
         ad.part = e->attn_part; ad.counters = e->attn_cnt;
         { const int ms = e->num_cus / (B * e->nkv); ad.max_splits = ms < 1 ? 1 : (ms > 16 ? 16 : ms); }

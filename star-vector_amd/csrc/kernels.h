@@ -149,6 +149,7 @@ struct AttnDecodeArgs {
     int n_kv;                                              // key/value heads (1 = MQA); grid.x = B * n_kv
     size_t kv_head_stride;                                 // bytes between the page pools of consecutive KV heads
     const float* rope_cos; const float* rope_sin;          // [positions][D/2] rotary tables (nullptr: no RoPE)
+    int window;                                            // sliding window: keys pos - window < j <= pos (0 = all)
 };
 // in-place rotary embedding of the q and k heads of a prefill c_attn output (rotate_half convention)
 void launch_rope_prefill(bf16_t* qkv, int row_stride, int rows, int S0, int n_heads, int head_dim,

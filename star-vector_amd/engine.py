@@ -35,6 +35,7 @@ class EngineConfig:
     rope_theta: float = 1e6
     vit_mlp: int = 4096
     vit_eps: float = 1e-6
+    sliding_window: int = 0          # v2: keys visible to a query (4096 for bigcode/starcoder2-7b); 0 = all
 
     @property
     def query_length(self) -> int:
@@ -46,7 +47,7 @@ class EngineConfig:
         return EngineConfig(image_size=384, patch_size=16, vit_width=1024, vit_layers=24, vit_heads=16, hidden=4608,
                             n_layer=32, n_head=36, n_inner=18432, vocab=49152 + 5, n_positions=16384,
                             max_batch=max_batch, max_seq_len=max_seq_len, arch="v2", n_kv_head=4, rope_theta=1e6,
-                            vit_mlp=4096, vit_eps=1e-6)
+                            vit_mlp=4096, vit_eps=1e-6, sliding_window=4096)
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -79,7 +80,8 @@ class HipEngine:
                      cfg.hidden, cfg.n_layer, cfg.n_head, cfg.n_inner, cfg.vocab, cfg.n_positions,
                      cfg.max_batch, cfg.max_seq_len, cfg.ln_eps, self.device,
                      _lib.SV_ARCH_V2 if cfg.arch == "v2" else _lib.SV_ARCH_V1, cfg.n_kv_head, cfg.rope_theta,
-                     cfg.vit_mlp, cfg.vit_eps if cfg.arch == "v2" else cfg.ln_eps)
+                     cfg.vit_mlp, cfg.vit_eps if cfg.arch == "v2" else cfg.ln_eps,
+                     int(cfg.sliding_window) if cfg.arch == "v2" else 0)
         h = C.c_void_p()
         check(self.lib.sv_create(C.byref(c), C.byref(h)), "sv_create")
         self._h = h

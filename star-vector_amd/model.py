@@ -83,9 +83,10 @@ class StarVectorConfig:
                                 adapter_norm=self.adapter_norm, hidden=self.hidden_size, n_layer=self.num_hidden_layers,
                                 n_head=self.num_attention_heads, n_inner=self.n_inner,
                                 vocab=self.vocab_size + self.added_tokens, n_positions=self.n_positions,
-                                max_batch=self.max_batch, max_seq_len=min(self.max_length, 4096), arch="v2",
+                                max_batch=self.max_batch, max_seq_len=min(self.max_length, self.n_positions), arch="v2",
                                 n_kv_head=self.num_kv_heads, rope_theta=g("rope_theta", 1e6),
-                                vit_mlp=g("siglip_mlp", 4096), vit_eps=1e-6)
+                                vit_mlp=g("siglip_mlp", 4096), vit_eps=1e-6,
+                                sliding_window=g("sliding_window", 4096))      # bigcode/starcoder2-7b config.json
         if self.image_encoder_type != "clip":
             raise NotImplementedError(f"image_encoder_type={self.image_encoder_type!r}: v1 is built for the clip branch")
         return EngineConfig(image_size=self.image_size, patch_size=self.patch_size, vit_width=self.vit_width,
@@ -285,8 +286,17 @@ class HipCausalLM(_EngineModule):
             raise ValueError("`num_beams` has to be an integer strictly greater than 0")     # HF's own check
         if num_beams > 8:
             raise NotImplementedError("num_beams > 8 is not built")
-        if num_return_sequences != 1:
-            raise NotImplementedError("num_return_sequences > 1 not built yet")
+        num_return_sequences = int(num_return_sequences or 1)
+        if num_return_sequences < 1:
+            raise ValueError("`num_return_sequences` has to be at least 1")
+        if num_return_sequences > 1:
+            # HF expands the inputs (repeat_interleave) and samples every copy independently; the reference forces
+            # num_beams = 1 whenever it asks for several sequences (starvector_base.py:273-276)
+            if num_beams > 1:
+                raise NotImplementedError("num_return_sequences > 1 with beam search is not built "
+                                          "(the reference sets num_beams=1 on this path)")
+            inputs_embeds = inputs_embeds.repeat_interleave(num_return_sequences, dim=0)
+            attention_mask = None if attention_mask is None else attention_mask.repeat_interleave(num_return_sequences, dim=0)
         if repetition_penalty is not None and not repetition_penalty > 0:
             raise ValueError("`repetition_penalty` has to be a strictly positive float")   # HF's own check
         if attention_mask is not None and not bool((attention_mask == 1).all()):
@@ -431,8 +441,12 @@ class StarVectorStarCoder(nn.Module):
         generation_kwargs = self._get_generation_kwargs({**kwargs, "inputs_embeds": inputs_embeds,
                                                          "attention_mask": attention_mask})
         generation_kwargs.update(self._get_im2svg_specific_kwargs(kwargs))
+        num_return_sequences = kwargs.get("num_return_sequences", 1)
+        if num_return_sequences > 1:                                   # :273-276
+            generation_kwargs["num_return_sequences"] = num_return_sequences
+            generation_kwargs["num_beams"] = 1
         outputs = self.svg_transformer.transformer.generate(**generation_kwargs)
-        outputs = torch.cat([prompt_tokens.input_ids, outputs], dim=1)
+        outputs = torch.cat([prompt_tokens.input_ids.repeat(num_return_sequences, 1), outputs], dim=1)    # :279
         raw_svg = self.svg_transformer.tokenizer.batch_decode(outputs, skip_special_tokens=True)
         return {"raw_svg": raw_svg, "outputs": outputs, "inputs_embeds": inputs_embeds}
 

@@ -37,7 +37,7 @@ def test_binding_matches_header(lib):
 
 def test_struct_layouts():
     from starvector_amd._lib import SvConfig, SvSampling
-    assert C.sizeof(SvConfig) == 21 * 4
+    assert C.sizeof(SvConfig) == 22 * 4
     assert SvSampling.stop_ids.offset % 8 == 0 and SvSampling.seed.offset % 8 == 0
 
 
@@ -51,7 +51,7 @@ def test_default_config_is_starvector_1b(lib):
     lib.sv_config_default_8b(C.byref(c))                   # siglip_384 + starcoder2-7b
     assert (c.image_size, c.patch_size, c.vit_layers, c.hidden, c.n_layer, c.n_head, c.n_kv_head, c.n_inner, c.vocab) == \
         (384, 16, 24, 4608, 32, 36, 4, 18432, 49157)
-    assert c.arch == 1 and abs(c.rope_theta - 1e6) < 1 and abs(c.vit_eps - 1e-6) < 1e-9
+    assert c.arch == 1 and abs(c.rope_theta - 1e6) < 1 and abs(c.vit_eps - 1e-6) < 1e-9 and c.sliding_window == 4096
 
 
 def test_errors_are_reported_not_crashes(lib):

@@ -187,6 +187,10 @@ def test_drop_in_api_generate_im2svg():
     assert out[0] == out[1]                                            # identical images -> identical streams
     res = model.model.generate_im2svg_grpo(batch, max_length=S0 + 10, num_beams=1, use_nucleus_sampling=False)
     assert res["outputs"].shape == (2, 4 + 10) and res["inputs_embeds"].shape == (2, S0, cfg.hidden)
+    many = model.model.generate_im2svg_grpo(batch, max_length=S0 + 10, num_return_sequences=2, use_nucleus_sampling=True,
+                                            temperature=1.0, top_p=0.95)            # GRPO sampling: 2 sequences per image
+    assert many["outputs"].shape == (4, 4 + 10) and len(many["raw_svg"]) == 4
+    assert not torch.equal(many["outputs"][0], many["outputs"][1])     # copies of one image are sampled independently
     dflt = model.generate_im2svg(batch, max_length=S0 + 10)            # the reference's defaults: num_beams=2 + nucleus sampling
     assert len(dflt) == 2 and all(s.startswith("<svg") for s in dflt)
     beams = model.generate_im2svg(batch, max_length=S0 + 10, num_beams=2, use_nucleus_sampling=False)
@@ -352,6 +356,35 @@ def test_starvector_8b_op_graph_against_reference_golden():
     assert a.shape == (B, 70) and torch.equal(a, b2)
     assert torch.equal(a[1], eng.generate(emb[1:2].contiguous(), **kw).cpu()[0])
     eng.close()
+
+
+def test_starcoder2_sliding_window():
+    """StarCoder2 attends to the last `sliding_window` keys (4096 in bigcode/starcoder2-7b; 24 here).  Teacher-forced
+    logits against the windowed oracle (pinned to HF by tests/golden/tiny_v2_window) for 80 steps: the window start
+    moves through key groups and across a KV page, so skipped groups, skipped pages and the partially masked first
+    group are all exercised.  An engine without the window must NOT pass the same check."""
+    g = _golden("tiny_v2_window")
+    seed, B, n_new, W = [int(x) for x in g["meta"]]
+    cfg = dataclasses.replace(O.OracleConfig.tiny_v2(), sliding_window=W, eos_token_id=-1)
+    w = O.make_weights(cfg, seed=seed)
+    eng = build_engine(cfg, w, max_batch=4, max_seq_len=128)
+    emb = torch.cat([eng.adapter(eng.encode_image(bf(g["image"]))), eng.embed_tokens(g["prompt_ids"].to(dev()))], 1)
+    S0 = emb.shape[1]
+    worst, scale, checked, near, o_toks, margin = _teacher_forced_check(eng, emb, w, cfg, 80)
+    print(f"[v2 window] W={W} S0={S0}: logits max|err| {worst:.3e} (scale {scale:.3e}) over 80 steps; {checked} exact, {near} near-tie flips")
+    assert checked > 0
+    got = eng.generate(emb, max_length=S0 + n_new, eos_token_id=-1, pad_token_id=0).cpu()
+    same = sum(int(torch.equal(got[b], g["tokens"][b])) for b in range(B))
+    print(f"[v2 window] {same}/{B} streams identical to HF's windowed generate")
+    eng.close()
+    full = build_engine(dataclasses.replace(cfg, sliding_window=0), w, max_batch=4, max_seq_len=128)
+    with pytest.raises(AssertionError):
+        _teacher_forced_check(full, emb, w, cfg, 80)            # full attention drifts from the windowed oracle
+    full.close()
+    small = build_engine(dataclasses.replace(cfg, sliding_window=8), w, max_batch=4, max_seq_len=128)
+    with pytest.raises(NotImplementedError):
+        small.prefill(emb)                                      # prompt longer than the window: says so
+    small.close()
 
 
 def test_starvector_8b_full_size_properties():

@@ -18,7 +18,8 @@ def test_config_maps_to_engine_shapes():
                           num_hidden_layers=32, num_attention_heads=36, num_kv_heads=4, n_inner=18432, added_tokens=5,
                           n_positions=16384, max_length=16000, max_batch=16).engine_config()
     assert (v2.arch, v2.n_kv_head, v2.hidden, v2.n_head, v2.n_inner, v2.vocab) == ("v2", 4, 4608, 36, 18432, 49157)
-    assert v2.query_length == 576 and v2.max_seq_len == 4096            # siglip_384: 24x24 patches, no class token
+    assert v2.query_length == 576 and v2.max_seq_len == 16000           # siglip_384: 24x24 patches, no class token
+    assert v2.sliding_window == 4096                                    # StarCoder2 attends to the last 4096 keys
     with pytest.raises(NotImplementedError):
         StarVectorConfig(starcoder_model_name="bigcode/starcoder2-7b", image_encoder_type="clip").engine_config()
     with pytest.raises(ValueError):

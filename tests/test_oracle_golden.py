@@ -191,3 +191,15 @@ def test_beam_sample_matches_hf(golden_dir):
         got = O.beam_search_generate(w, cfg, emb, emb.shape[1] + n_new, int(nb), length_penalty=lp, early_stopping=bool(es),
                                      do_sample=True, temperature=T, top_p=tp, top_k=int(tk))
         assert got.shape == g[f"case{i}.tokens"].shape and torch.equal(got, g[f"case{i}.tokens"]), i
+
+
+def test_starcoder2_sliding_window_matches_hf(golden_dir):
+    """StarCoder2's sliding window (4096 in bigcode/starcoder2-7b; 24 here so the generation leaves it)."""
+    import dataclasses
+    g = _load(golden_dir, "tiny_v2_window")
+    seed, B, n_new, W = [int(x) for x in g["meta"]]
+    cfg = dataclasses.replace(O.OracleConfig.tiny_v2(), sliding_window=W, eos_token_id=-1)
+    w = O.make_weights(cfg, seed=seed)
+    emb = O.prepare_generation_inputs(w, cfg, g["image"], g["prompt_ids"])
+    assert emb.shape[1] < W < emb.shape[1] + n_new
+    assert torch.equal(O.greedy_generate(w, cfg, emb, emb.shape[1] + n_new), g["tokens"])
