@@ -173,36 +173,54 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][nt], xf[s][mt], acc[nt][mt], 0, 0, 0);
     }
 
-    // epilogue: bias -> round to bf16 (the reference's Linear output) -> activation -> (+ residual)
+    // epilogue: bias -> round to bf16 (the reference's Linear output) -> activation -> (+ residual).  The bias of the
+    // wave's columns is fetched once and the residual of a whole m-tile is requested before the first value is needed
     const int half = lane >> 5;
+    uint2 bq[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int n = n0 + wn * 64 + nt * 32 + rg * 8 + half * 4;
+            bq[nt][rg] = (p.bias && n < p.N) ? *reinterpret_cast<const uint2*>(p.bias + n) : make_uint2(0u, 0u);
+        }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int m = m0 + wm * 64 + mt * 32 + (lane & 31);
-        if (m >= p.M) continue;
+        const bool mok = m < p.M;
+        uint2 rq[2][4];
+        if (p.R) {
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int n = n0 + wn * 64 + nt * 32 + rg * 8 + half * 4;
+                    rq[nt][rg] = (mok && n < p.N) ? *reinterpret_cast<const uint2*>(p.R + (size_t)m * p.ldr + n) : make_uint2(0u, 0u);
+                }
+        }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
 #pragma unroll
             for (int rg = 0; rg < 4; ++rg) {
                 const int n = n0 + wn * 64 + nt * 32 + rg * 8 + half * 4;
-                if (n >= p.N) continue;       // N % 4 == 0
+                const float bj[4] = {__uint_as_float(bq[nt][rg].x << 16), __uint_as_float(bq[nt][rg].x & 0xffff0000u),
+                                     __uint_as_float(bq[nt][rg].y << 16), __uint_as_float(bq[nt][rg].y & 0xffff0000u)};
                 float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float x = acc[nt][mt][rg * 4 + j];
-                    if (p.bias) x += bf2f(p.bias[n + j]);
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[nt][mt][rg * 4 + e] + bj[e];
                     if (p.act != ACT_NONE) x = sv_act(bfround(x), p.act);
-                    v[j] = x;
+                    v[e] = x;
                 }
                 if (p.R) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(p.R + (size_t)m * p.ldr + n);
-                    v[0] = bfround(v[0]) + __uint_as_float(rr.x << 16);
-                    v[1] = bfround(v[1]) + __uint_as_float(rr.x & 0xffff0000u);
-                    v[2] = bfround(v[2]) + __uint_as_float(rr.y << 16);
-                    v[3] = bfround(v[3]) + __uint_as_float(rr.y & 0xffff0000u);
+                    v[0] = bfround(v[0]) + __uint_as_float(rq[nt][rg].x << 16);
+                    v[1] = bfround(v[1]) + __uint_as_float(rq[nt][rg].x & 0xffff0000u);
+                    v[2] = bfround(v[2]) + __uint_as_float(rq[nt][rg].y << 16);
+                    v[3] = bfround(v[3]) + __uint_as_float(rq[nt][rg].y & 0xffff0000u);
                 }
+                if (!mok || n >= p.N) continue;       // N % 4 == 0
                 if constexpr (sizeof(OutT) == 4) {
-                    float4 o = make_float4(v[0], v[1], v[2], v[3]);
-                    *reinterpret_cast<float4*>((float*)p.C + (size_t)m * p.ldc + n) = o;
+                    *reinterpret_cast<float4*>((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
                     uint2 o;
                     o.x = pack2bf(v[0], v[1]);
@@ -214,15 +232,403 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     }
 }
 
-void launch_gemm(const GemmArgs& a, hipStream_t st) {
+// ------------------------------------------------------------------------------------------------
+// big-M GEMM, 256x256x64 tile, 8 waves in two ping-pong groups (prefill / ViT when the tile count fills the chip)
+//
+//   The 128^2 kernel above parks every wave at `vmcnt(0)` + barrier once per K-tile and issues its LDS reads right
+//   in front of the MFMAs that need them.  Here a K-tile is cut into 4 PHASES (one 64x32 quadrant of the wave's
+//   128x64 output each: 8 MFMAs 32x32x16), and every phase is
+//        [ds_read this phase's fragments | LDS-DMA one half-tile of the NEXT K-tile]  barrier
+//        [8 MFMAs at raised priority]  vmcnt(2)  barrier
+//   Waves 0-3 and 4-7 (one of each per SIMD) run one barrier apart, so while one group feeds the MFMA pipe the other
+//   issues its LDS / LDS-DMA traffic.  The LDS-DMA queue is never drained in steady state: `vmcnt(2)` leaves the
+//   half-tile staged in this phase in flight across both barriers.
+//
+//   LDS (2 K-tile buffers x 64 KiB): [X0 | X1 | W0 | W1], 16 KiB each.  X-half i = rows {128*wr + 64*i + 0..63} of
+//   both wave rows (128 rows x 64 k, XOR-swizzled 16-B chunks like the 128^2 kernel); W-half j = fragment
+//   (2*wc + j) of the four wave columns (packed fragments, lane-linear).  Quadrant order (i,j) = (0,0) (0,1) (1,1)
+//   (1,0): the half-tiles are first needed in phases 0,0,1,2 and are staged in the order X0 W0 W1 X1 one K-tile ahead.
+//
+//   Hazards (s = staging phase, counted in global phases; B = the group that runs one barrier late):
+//     RAW  a half-tile read in phase Q must be retired (`vmcnt`) by every staging wave before a barrier that precedes
+//          the read; for group B that is the wait at the END of phase Q-2 -> with one half-tile (2 LDS-DMAs) issued per
+//          phase the count is vmcnt(2); the last K-tile stages nothing and waits vmcnt(0).  (X0 of the next K-tile is
+//          read one phase early, in phase 3: staged in phase 0, it is the only half-tile old enough for that.)
+//     WAR  a slot is restaged >= 4 phases after its last ds_read, and those reads were consumed by MFMAs long before.
+// ------------------------------------------------------------------------------------------------
+#define G2_T 256
+#define G2_HALF 16384
+#define G2_BUF 65536
+
+#define G2_BARRIER() asm volatile("s_barrier" ::: "memory")
+
+template <typename OutT, int SCHED>
+__global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p, int tiles_m, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    // XCD-aware tile order: blocks are dealt round-robin to the 8 XCDs; give each XCD a contiguous run of tile ids and
+    // walk the tile grid in bands of 4 m-tiles so that one XCD round (32 CUs) covers a 4 x 8 patch sharing L2 lines
+    const int T = tiles_m * tiles_n;
+    const int id = blockIdx.x;
+    const int q = T >> 3, rem = T & 7, xcd = id & 7, loc = id >> 3;
+    const int wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+    const int band = wg / (4 * tiles_n), r_in = wg - band * 4 * tiles_n;
+    const int band_rows = min(4, tiles_m - band * 4);
+    const int tm = band * 4 + r_in % band_rows, tn = r_in / band_rows;
+    const int m0 = tm * G2_T, n0 = tn * G2_T;
+    const int KS = p.K >> 4;
+    const int KT = p.K >> 6;
+    const int NT_total = (p.N + 31) >> 5;
+
+    f32x16 acc[2][4];                 // [n-tile j][m-tile 2*i + mt2]
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    // staging addresses.  X: piece g = 2*wave + q covers local rows 8g .. 8g+7 of a half (128 rows)
+    const bf16_t* xsrc[2][2];          // [half i][piece]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            const int g = wave * 2 + pc;
+            const int r = g * 8 + (lane >> 3);                   // 0..127 inside the half
+            int grow = m0 + (r >> 6) * 128 + i * 64 + (r & 63);
+            grow = grow < p.M ? grow : p.M - 1;
+            const int c = (lane & 7) ^ ((r >> 1) & 7);
+            xsrc[i][pc] = p.A + (size_t)grow * p.lda + c * 8;
+        }
+    const bf16_t* wsrc[2][2];          // [half j][piece]: fragment f = 2*wave + pc -> (wave column f>>2, k-step f&3)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int pc = 0; pc < 2; ++pc) {
+            const int f = wave * 2 + pc;
+            int nt = (n0 >> 5) + (f >> 2) * 2 + j;
+            nt = nt < NT_total ? nt : NT_total - 1;
+            wsrc[j][pc] = p.Wp + (((size_t)nt * KS + (f & 3)) * 64 + lane) * 8;
+        }
+    auto stage = [&](int h, int kt, char* buf) {          // h: 0 X0, 1 W0, 2 W1, 3 X1
+        if (h == 0 || h == 3) {
+            const int i = h == 0 ? 0 : 1;
+            char* dst = buf + i * G2_HALF + wave * 2048;
+            lds_dma16(xsrc[i][0] + kt * 64, dst);
+            lds_dma16(xsrc[i][1] + kt * 64, dst + 1024);
+        } else {
+            const int j = h - 1;
+            char* dst = buf + 2 * G2_HALF + j * G2_HALF + wave * 2048;
+            lds_dma16(wsrc[j][0] + (size_t)kt * 4 * 512, dst);
+            lds_dma16(wsrc[j][1] + (size_t)kt * 4 * 512, dst + 1024);
+        }
+    };
+    // fragment read offsets
+    int xoff[2][4];                    // [mt2][k-step] byte offset inside an X half
+#pragma unroll
+    for (int mt2 = 0; mt2 < 2; ++mt2)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int r = wr * 64 + mt2 * 32 + (lane & 31);
+            xoff[mt2][ks] = r * 128 + (((2 * ks + (lane >> 5)) ^ ((r >> 1) & 7)) << 4);
+        }
+    const int woff = wc * 4096 + lane * 16;            // + ks * 1024 inside a W half
+
+    bf16x8 x0[2][4], x1[2][4], w0[4], w1[4];
+    auto read_x = [&](bf16x8 (&x)[2][4], const char* half) {
+#pragma unroll
+        for (int mt2 = 0; mt2 < 2; ++mt2)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) x[mt2][ks] = *reinterpret_cast<const bf16x8*>(half + xoff[mt2][ks]);
+    };
+    auto read_w = [&](bf16x8 (&w)[4], const char* half) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) w[ks] = *reinterpret_cast<const bf16x8*>(half + woff + ks * 1024);
+    };
+    auto quad = [&](bf16x8 (&w)[4], bf16x8 (&x)[2][4], int j, int i) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mt2 = 0; mt2 < 2; ++mt2)
+                acc[j][2 * i + mt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], x[mt2][ks], acc[j][2 * i + mt2], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // prologue: K-tile 0 entirely
+    stage(0, 0, smem); stage(1, 0, smem); stage(2, 0, smem); stage(3, 0, smem);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    G2_BARRIER();
+    if (wr == 1) G2_BARRIER();                            // group B runs one barrier behind group A
+    read_x(x0, smem);                                     // X0 of K-tile 0 (later tiles: read in phase 3 of the tile before)
+    if constexpr (SCHED >= 3) { read_x(x1, smem + G2_HALF); read_w(w0, smem + 2 * G2_HALF); read_w(w1, smem + 3 * G2_HALF); }
+
+#define G2_WAIT(n) do { if (more) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
+    for (int t = 0; t < KT; ++t) {
+        char* buf = smem + (t & 1) * G2_BUF;
+        char* nbuf = smem + ((t + 1) & 1) * G2_BUF;
+        const bool more = t + 1 < KT;
+        // one half-tile per phase, X0 W0 W1 X1: every half-tile has ~2 phases to land.  (Staging the whole next K-tile in
+        // phases 0-1 instead, 3-4 phases of slack, measured the same: the loop is not waiting on LDS-DMA latency.)
+        // SCHED 2/3/4 are timing ablations only (wrong results): no staging / no LDS reads / neither.
+        constexpr bool ST = SCHED == 0 || SCHED == 3, RD = SCHED == 0 || SCHED == 2;
+        if (RD) read_w(w0, buf + 2 * G2_HALF);
+        if (ST && more) stage(0, t + 1, nbuf);
+        G2_BARRIER(); quad(w0, x0, 0, 0); G2_WAIT(2); G2_BARRIER();
+        if (RD) read_w(w1, buf + 3 * G2_HALF);
+        if (ST && more) stage(1, t + 1, nbuf);
+        G2_BARRIER(); quad(w1, x0, 1, 0); G2_WAIT(2); G2_BARRIER();
+        if (RD) read_x(x1, buf + G2_HALF);
+        if (ST && more) stage(2, t + 1, nbuf);
+        G2_BARRIER(); quad(w1, x1, 1, 1); G2_WAIT(2); G2_BARRIER();
+        // x0 is free again: fetch X0 of the next K-tile (staged in phase 0, retired by every wave's wait at the
+        // end of phase 1) so that no phase issues more than 8 LDS reads
+        if (more) { if (RD) read_x(x0, nbuf); if (ST) stage(3, t + 1, nbuf); }
+        G2_BARRIER(); quad(w0, x1, 0, 1); G2_WAIT(2); G2_BARRIER();
+    }
+#undef G2_WAIT
+    if (wr == 0) G2_BARRIER();                            // both groups execute the same number of barriers
+
+    // epilogue: bias -> round to bf16 (the reference's Linear output) -> activation -> (+ residual).
+    // One block per CU: nothing else hides a load here, so the bias of the wave's 64 columns is fetched once and the
+    // residual of a whole m-tile is requested before the first value is needed (a load per value, each waited for
+    // on its own, cost twice the K loop at K = 2048).
+    const int half = lane >> 5;
+    uint2 bq[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int n = n0 + wc * 64 + j * 32 + rg * 8 + half * 4;
+            bq[j][rg] = (p.bias && n < p.N) ? *reinterpret_cast<const uint2*>(p.bias + n) : make_uint2(0u, 0u);
+        }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int m = m0 + wr * 128 + (mt >> 1) * 64 + (mt & 1) * 32 + (lane & 31);
+        const bool mok = m < p.M;
+        uint2 rq[2][4];
+        if (p.R) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const int n = n0 + wc * 64 + j * 32 + rg * 8 + half * 4;
+                    rq[j][rg] = (mok && n < p.N) ? *reinterpret_cast<const uint2*>(p.R + (size_t)m * p.ldr + n) : make_uint2(0u, 0u);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int n = n0 + wc * 64 + j * 32 + rg * 8 + half * 4;
+                const float bj[4] = {__uint_as_float(bq[j][rg].x << 16), __uint_as_float(bq[j][rg].x & 0xffff0000u),
+                                     __uint_as_float(bq[j][rg].y << 16), __uint_as_float(bq[j][rg].y & 0xffff0000u)};
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float x = acc[j][mt][rg * 4 + e] + bj[e];
+                    if (p.act != ACT_NONE) x = sv_act(bfround(x), p.act);
+                    v[e] = x;
+                }
+                if (p.R) {
+                    v[0] = bfround(v[0]) + __uint_as_float(rq[j][rg].x << 16);
+                    v[1] = bfround(v[1]) + __uint_as_float(rq[j][rg].x & 0xffff0000u);
+                    v[2] = bfround(v[2]) + __uint_as_float(rq[j][rg].y << 16);
+                    v[3] = bfround(v[3]) + __uint_as_float(rq[j][rg].y & 0xffff0000u);
+                }
+                if (!mok || n >= p.N) continue;       // N % 4 == 0
+                if constexpr (sizeof(OutT) == 4) {
+                    *reinterpret_cast<float4*>((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    uint2 o;
+                    o.x = pack2bf(v[0], v[1]);
+                    o.y = pack2bf(v[2], v[3]);
+                    *reinterpret_cast<uint2*>((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+                }
+            }
+        }
+    }
+}
+
+static void launch_gemm256(const GemmArgs& a, hipStream_t st) {
+    const int tiles_m = (a.M + G2_T - 1) / G2_T, tiles_n = (a.N + G2_T - 1) / G2_T;
+    static const int sched = getenv("SV_GEMM_SCHED") ? atoi(getenv("SV_GEMM_SCHED")) : 0;
+    if (a.out_f32)
+        gemm256_kernel<float, 0><<<tiles_m * tiles_n, 512, 2 * G2_BUF, st>>>(a, tiles_m, tiles_n);
+    else if (sched == 2)
+        gemm256_kernel<bf16_t, 2><<<tiles_m * tiles_n, 512, 2 * G2_BUF, st>>>(a, tiles_m, tiles_n);
+    else if (sched == 3)
+        gemm256_kernel<bf16_t, 3><<<tiles_m * tiles_n, 512, 2 * G2_BUF, st>>>(a, tiles_m, tiles_n);
+    else if (sched == 4)
+        gemm256_kernel<bf16_t, 4><<<tiles_m * tiles_n, 512, 2 * G2_BUF, st>>>(a, tiles_m, tiles_n);
+    else
+        gemm256_kernel<bf16_t, 0><<<tiles_m * tiles_n, 512, 2 * G2_BUF, st>>>(a, tiles_m, tiles_n);
+}
+
+// ------------------------------------------------------------------------------------------------
+// tail rows of a big-M GEMM.  32 x 259 prompt rows are 32 full 256-row tiles plus 96 rows; run as a 33rd tile row
+// those 96 rows cost every GEMM one more (nearly empty) round of the chip.  They go through this kernel instead: one
+// wave per 32 x 32 output tile walking the whole K, operands straight from global memory (weight fragments are 1 KiB
+// contiguous; the activation fragment is 16 B per lane from its own row), 8 k-steps of loads in flight.
+// Same MFMA, same operand roles and the same ascending k order as the tile kernels, so a row's result does not depend
+// on which kernel computed it (bit-identical: batch composition cannot change a token).
+// ------------------------------------------------------------------------------------------------
+#define GT_D 7        // chunks of 4 k-steps in flight: 7 * 8 = 56 loads (the vmcnt counter holds 63)
+__global__ __launch_bounds__(64) void gemm_tail_kernel(GemmArgs p) {
+    const int lane = threadIdx.x;
+    const int nt = blockIdx.x, mt = blockIdx.y;
+    const int KS = p.K >> 4;
+    const int NCH = KS >> 2;                       // K % 64 == 0
+    int row = mt * 32 + (lane & 31);
+    const bool rok = row < p.M;
+    row = rok ? row : p.M - 1;
+    const bf16_t* xrow = p.A + (size_t)row * p.lda + 8 * (lane >> 5);
+    const bf16_t* wfr = p.Wp + ((size_t)nt * KS * 64 + lane) * 8;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // a ring of GT_D chunks, statically indexed (fully unrolled): chunk c lives in slot c % GT_D.  No per-element
+    // conditions: hipcc answers those with a branch and a vmcnt(0) around every load.
+    bf16x8 w[GT_D][4], x[GT_D][4];
+    auto load = [&](int d, int c) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            w[d][s] = *reinterpret_cast<const bf16x8*>(wfr + (size_t)(4 * c + s) * 512);
+            x[d][s] = *reinterpret_cast<const bf16x8*>(xrow + (4 * c + s) * 16);
+        }
+    };
+    auto mma = [&](int d) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[d][s], x[d][s], acc, 0, 0, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < GT_D; ++d)
+        if (d < NCH) load(d, d);
+    int c = 0;
+    for (; c + 2 * GT_D <= NCH; c += GT_D) {       // steady state: every slot is refilled right after it is consumed
+#pragma unroll
+        for (int d = 0; d < GT_D; ++d) { mma(d); load(d, c + GT_D + d); }
+    }
+#pragma unroll
+    for (int d = 0; d < GT_D; ++d) {               // drain (chunk-level, wave-uniform conditions only)
+        if (c + d < NCH) mma(d);
+        if (c + GT_D + d < NCH) load(d, c + GT_D + d);
+    }
+#pragma unroll
+    for (int d = 0; d < GT_D; ++d)
+        if (c + GT_D + d < NCH) mma(d);
+    if (!rok) return;
+    const int half = lane >> 5;
+    const int m = row;
+    // bias and residual of the lane's 16 outputs are requested together (one wave per CU: nothing else hides a load)
+    uint2 bq[4], rq[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const int n = nt * 32 + rg * 8 + half * 4;
+        bq[rg] = (p.bias && n < p.N) ? *reinterpret_cast<const uint2*>(p.bias + n) : make_uint2(0u, 0u);
+        rq[rg] = (p.R && n < p.N) ? *reinterpret_cast<const uint2*>(p.R + (size_t)m * p.ldr + n) : make_uint2(0u, 0u);
+    }
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        const int n = nt * 32 + rg * 8 + half * 4;
+        if (n >= p.N) continue;       // N % 4 == 0
+        const float bj[4] = {__uint_as_float(bq[rg].x << 16), __uint_as_float(bq[rg].x & 0xffff0000u),
+                             __uint_as_float(bq[rg].y << 16), __uint_as_float(bq[rg].y & 0xffff0000u)};
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = acc[rg * 4 + e] + bj[e];
+            if (p.act != ACT_NONE) x = sv_act(bfround(x), p.act);
+            v[e] = x;
+        }
+        if (p.R) {
+            v[0] = bfround(v[0]) + __uint_as_float(rq[rg].x << 16);
+            v[1] = bfround(v[1]) + __uint_as_float(rq[rg].x & 0xffff0000u);
+            v[2] = bfround(v[2]) + __uint_as_float(rq[rg].y << 16);
+            v[3] = bfround(v[3]) + __uint_as_float(rq[rg].y & 0xffff0000u);
+        }
+        if (p.out_f32) {
+            *reinterpret_cast<float4*>((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            uint2 o;
+            o.x = pack2bf(v[0], v[1]);
+            o.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+        }
+    }
+}
+
+// Pick the tile kernel, and decide whether to peel a small row remainder, by a cost model fitted to measurements at
+// the prefill / ViT shapes (tools/bench_gemm.py).  A "round" is one wave of tiles over the chip (128^2: 2 blocks per
+// CU, 256^2: 1 block per CU); the last round costs as much as a full one, which is the whole reason for peeling.
+static double tiles_us(int M, int N, int K, int act, bool* use256) {
+    const int cus = 256;
+    const double k = (double)K;
+    const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+    const long t256 = (long)((M + 255) / 256) * ((N + 255) / 256);
+    // 128^2 (2 blocks per CU smooth the schedule): between the fractional and the whole number of rounds
+    const double f128 = (double)t128 / (2 * cus), c128 = (double)((t128 + 2 * cus - 1) / (2 * cus));
+    const double r128 = f128 < 1.0 ? 1.0 : 0.5 * (f128 + c128);
+    const double r256 = (double)((t256 + cus - 1) / cus);
+    const double us128 = r128 * 0.0195 * k * (act ? 1.12 : 1.0) + 10.0;
+    const double us256 = r256 * (0.0243 * k + 33.0);
+    // the fit comes from chip-filling grids: a 256^2 grid that leaves CUs idle (few requests) measured slower than 128^2
+    const bool u = us256 < us128 && t256 >= 200;
+    if (use256) *use256 = u;
+    return u ? us256 : us128;
+}
+static double tail_us(int tail, int N, int K) {
+    return 7.0 + 4.2e-5 * (double)((N + 31) / 32) * (double)((tail + 31) / 32) * (double)K;
+}
+
+static void launch_gemm_tiles(const GemmArgs& a, hipStream_t st, bool force128 = false) {
     dim3 grid((a.N + GB_N - 1) / GB_N, (a.M + GB_M - 1) / GB_M);
-    static const int variant = getenv("SV_GEMM_VARIANT") ? atoi(getenv("SV_GEMM_VARIANT")) : 0;
+    // SV_GEMM_VARIANT: -1 (default) cost model; 0 / 1 force the 128^2 kernel (plain / sched_barrier); 2 force 256^2
+    const char* ev = getenv("SV_GEMM_VARIANT");          // read per launch: tools flip it inside one process for A/B runs
+    const int variant = ev ? atoi(ev) : -1;
+    bool use256 = false;
+    (void)tiles_us(a.M, a.N, a.K, a.act, &use256);
+    if (!force128 && (variant == 2 || (variant < 0 && use256))) { launch_gemm256(a, st); return; }
     if (a.out_f32)
         gemm_bf16_kernel<float, 0><<<grid, 256, 2 * GB_BUF, st>>>(a);
     else if (variant == 1)
         gemm_bf16_kernel<bf16_t, 1><<<grid, 256, 2 * GB_BUF, st>>>(a);
     else
         gemm_bf16_kernel<bf16_t, 0><<<grid, 256, 2 * GB_BUF, st>>>(a);
+}
+
+void launch_gemm(const GemmArgs& a, hipStream_t st) {
+    // a small remainder over a multiple of 256 rows is peeled off to the tail kernel when the model says the saved
+    // round is worth more than the tail kernel costs (SV_GEMM_TAIL: 0 never, 2 always, default 1 = model)
+    const char* et = getenv("SV_GEMM_TAIL");
+    const int tail_on = et ? atoi(et) : 1;
+    const int tail = a.M % 256, main_rows = a.M - tail;
+    bool peel = tail_on && tail > 0 && tail <= 96 && main_rows >= 2048;
+    // two ways to do the remainder: one wave per 32x32 tile (good for few column tiles / long K), or one row of 128^2
+    // tiles (LDS-shared operands: good for wide N, but a single block per 128 columns walks the whole K alone)
+    const double t_wave = tail_us(tail, a.N, a.K), t_tile = 10.0 + 0.03 * (double)a.K;   // measured: a lone K=2048 tile row ~70 us
+    const bool tail_by_tiles = t_tile < t_wave;
+    if (peel && tail_on == 1)
+        peel = tiles_us(a.M, a.N, a.K, a.act, nullptr) - tiles_us(main_rows, a.N, a.K, a.act, nullptr) > (tail_by_tiles ? t_tile : t_wave);
+    if (peel) {
+        GemmArgs m = a;
+        m.M = main_rows;
+        launch_gemm_tiles(m, st);
+        GemmArgs t = a;
+        t.A = a.A + (size_t)main_rows * a.lda;
+        t.R = a.R ? a.R + (size_t)main_rows * a.ldr : nullptr;
+        t.C = a.out_f32 ? (void*)((float*)a.C + (size_t)main_rows * a.ldc) : (void*)((bf16_t*)a.C + (size_t)main_rows * a.ldc);
+        t.M = tail;
+        if (tail_by_tiles) launch_gemm_tiles(t, st, true);
+        else gemm_tail_kernel<<<dim3((a.N + 31) / 32, (tail + 31) / 32), 64, 0, st>>>(t);
+        return;
+    }
+    launch_gemm_tiles(a, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -715,6 +1121,16 @@ int init_gemm_kernels() {
     if (!r) r = set_attr<8, 1>(128 * 1024);
     if (!r) r = set_attr<8, 0>(128 * 1024);
     if (!r) r = set_attr<8, 2>(128 * 1024);
+    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<bf16_t, 0>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
+    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<bf16_t, 2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
+    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<bf16_t, 3>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
+    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<bf16_t, 4>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
+    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<float, 0>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
     return r;
 }
 

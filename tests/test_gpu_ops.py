@@ -53,6 +53,34 @@ def test_linear_mfma(M, N, K, act, res):
     assert rel_err(got, y) <= 2.2 * BF16_1ULP and mean_err(got, y) <= 6e-4
 
 
+@pytest.mark.parametrize("M,N,K,act,res", [(2048 + 96, 512, 1024, "gelu_tanh", True),    # 128^2 tiles + tail kernel
+                                           (2048 + 96, 8192, 2048, "none", True),       # 256^2 ping-pong tiles + tail
+                                           (4096 + 32, 2048, 8192, "quickgelu", False), # long K through the tail kernel
+                                           (2048 + 7, 1024, 640, "none", False)])       # ragged tail (7 rows), K = 10 * 64
+def test_linear_big_m_kernels_agree_bitwise(M, N, K, act, res):
+    """A big-M Linear is split into full 256-row tiles (128^2 or 256^2 kernel, picked by a cost model) and a remainder
+    that goes through the one-wave-per-tile tail kernel.  All three accumulate K in the same order with the same MFMA,
+    so a row's result must not depend on where it sits: rotate the rows so the tail rows land in full tiles and
+    compare bit for bit (this is what keeps a request's tokens independent of the batch around it)."""
+    g = torch.Generator().manual_seed(N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    b = (0.1 * torch.randn(N, generator=g)).bfloat16()
+    r = torch.randn(M, N, generator=g).bfloat16() if res else None
+    tail = M % 256
+    y = E.op_linear(bf(x), bf(W), bf(b), bf(r) if res else None, act=act).cpu()
+    rot = lambda t: torch.cat([t[-tail:], t[:-tail]]).contiguous()
+    y2 = E.op_linear(bf(rot(x)), bf(W), bf(b), bf(rot(r)) if res else None, act=act).cpu()
+    assert torch.equal(y2.view(torch.int16), rot(y).view(torch.int16))
+    ref = x.float() @ W.float().T + b.float()
+    if act != "none":
+        ref = {"gelu_tanh": lambda t: torch.nn.functional.gelu(t, approximate="tanh"),
+               "quickgelu": lambda t: t * torch.sigmoid(1.702 * t)}[act](ref.bfloat16().float())
+    if res:
+        ref = ref.bfloat16().float() + r.float()
+    assert rel_err(y, ref) <= 2.2 * BF16_1ULP and mean_err(y, ref) <= 6e-4
+
+
 def test_linear_transpose_detecting():
     """A = identity with an ASYMMETRIC weight: catches swapped row/column in the MFMA C layout."""
     K = N = 128
