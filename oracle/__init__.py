@@ -13,7 +13,8 @@ outputs of the reference itself run in the build container:
 ``clip_model.VisionTransformer`` / ``adapter.Adapter`` and the un-vendored
 decoder the reference loads (``transformers.GPTBigCodeForCausalLM`` driven by
 ``GenerationMixin.generate``), checks this restatement against them and writes
-the fixtures under ``tests/golden/``.
+the fixtures under ``tests/golden/``.  The image pre-processing recipe (``oracle/image_preprocess.py``) restates
+Pillow's integer arithmetic and is pinned against Pillow itself (``image_preprocess.pin()``).
 """
 from .starvector_oracle import (  # noqa: F401
     OracleConfig,

@@ -163,14 +163,24 @@ class ByteTokenizer:
 # image pre-processing (host side, PIL): data/util.py:40-68
 # --------------------------------------------------------------------------------------------------
 class ImageTrainProcessor:
-    def __init__(self, mean=None, std=None, size: int = 224, **kwargs):
-        self.mean = torch.tensor(mean or CLIP_MEAN).view(3, 1, 1)
-        self.std = torch.tensor(std or CLIP_STD).view(3, 1, 1)
+    """starvector/data/util.py:40-68.  ``device=None`` (default): the reference's own host recipe with Pillow.
+    ``device="cuda"``: the same arithmetic on the GPU (``sv_preprocess_image``: composite, pad, Pillow-exact bicubic
+    resize, /255, normalise) -- the float32 tensor is bit-identical, it just never leaves the device."""
+
+    def __init__(self, mean=None, std=None, size: int = 224, device=None, **kwargs):
+        self._mean, self._std = tuple(mean or CLIP_MEAN), tuple(std or CLIP_STD)
+        self.mean = torch.tensor(self._mean).view(3, 1, 1)
+        self.std = torch.tensor(self._std).view(3, 1, 1)
         self.size = size
+        self.device = device
 
     def __call__(self, img):
         from PIL import Image
         import numpy as np
+        if self.device is not None and img.mode in ("RGB", "RGBA"):
+            from .engine import op_preprocess_image
+            px = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).to(self.device)
+            return op_preprocess_image(px, self.size, self._mean, self._std)
         if img.mode == "RGBA":                               # _rgba_to_rgb_white (data/util.py:64-67)
             bg = Image.new("RGB", img.size, (255, 255, 255))
             bg.paste(img, mask=img.split()[3])
@@ -186,7 +196,8 @@ class ImageTrainProcessor:
         if img.mode != "RGB":
             img = img.convert("RGB")
         x = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).permute(2, 0, 1).float() / 255.0   # ToTensor
-        return (x - self.mean) / self.std
+        x = (x - self.mean) / self.std
+        return x if self.device is None else x.to(self.device)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -207,7 +218,9 @@ class ImageEncoder(_EngineModule):
     def __init__(self, engine: HipEngine, image_size: int = 224):
         super().__init__(engine)
         self.image_encoder_type = "clip"
-        self.processor = ImageTrainProcessor(size=image_size)
+        # the engine lives on a GPU, so the images are pre-processed there as well (bit-identical to the Pillow recipe)
+        dev = torch.device("cuda", engine.device) if engine is not None and hasattr(engine, "device") else None
+        self.processor = ImageTrainProcessor(size=image_size, device=dev)
 
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         return self._engine.encode_image(image)

@@ -254,3 +254,39 @@ def test_decode_linear_fused(M, N, K, sk, ln, res, act):
     got2, _ = E.op_decode_linear(bf(h), bf(W), bf(b), bf(gam) if ln else None, bf(bet) if ln else None,
                                  bf(r) if res else None, act=act, splitk=sk)
     assert torch.equal(got, got2)
+
+
+@pytest.mark.parametrize("w,h,c", [(224, 224, 3), (300, 300, 3), (100, 60, 4), (517, 333, 3), (64, 200, 4), (1024, 768, 3),
+                                   (50, 50, 4), (223, 225, 4), (2048, 1536, 3), (1, 1, 3)])
+def test_preprocess_image_bit_exact(w, h, c):
+    """sv_preprocess_image == the reference's ImageTrainProcessor (Pillow paste / pad / BICUBIC resize + torchvision
+    ToTensor / Normalize, restated with Pillow + torch here because torchvision is not installed), bit for bit: it is
+    an integer / byte path up to the final two IEEE float operations."""
+    import numpy as np
+    from PIL import Image
+    from oracle import image_preprocess as P
+    rng = np.random.default_rng(w * 7 + h)
+    px = rng.integers(0, 256, size=(h, w, c), dtype=np.uint8)
+    if c == 4:
+        px[..., 3] = rng.choice([0, 255, 128, 7, 254], size=(h, w))
+    got = E.op_preprocess_image(torch.from_numpy(px).to(dev()), 224, P.CLIP_MEAN, P.CLIP_STD).cpu()
+    img = Image.fromarray(px, "RGBA" if c == 4 else "RGB")
+    if c == 4:
+        bg = Image.new("RGB", img.size, (255, 255, 255))
+        bg.paste(img, mask=img.split()[3])
+        img = bg
+    m = max(w, h)
+    canvas = Image.new("RGB", (m, m), (255, 255, 255))
+    canvas.paste(img, ((m - w) // 2, (m - h) // 2))
+    if m != 224:
+        canvas = canvas.resize((224, 224), Image.BICUBIC)
+    ref = torch.from_numpy(np.asarray(canvas).copy()).permute(2, 0, 1).float().div(255.0)
+    ref = (ref - torch.tensor(P.CLIP_MEAN).view(3, 1, 1)) / torch.tensor(P.CLIP_STD).view(3, 1, 1)
+    assert got.shape == (3, 224, 224) and torch.equal(got.view(torch.int32), ref.view(torch.int32))
+    assert np.array_equal(got.numpy().view(np.int32), P.preprocess(px).view(np.int32))            # and the numpy oracle
+    # the mirror's processor takes the device path for RGB / RGBA and returns the same tensor
+    from starvector_amd.model import ImageTrainProcessor
+    pil = Image.fromarray(px, "RGBA" if c == 4 else "RGB")
+    on_dev = ImageTrainProcessor(size=224, device=dev())(pil)
+    on_host = ImageTrainProcessor(size=224)(pil)
+    assert on_dev.is_cuda and torch.equal(on_dev.cpu().view(torch.int32), on_host.view(torch.int32))

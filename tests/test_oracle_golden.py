@@ -203,3 +203,15 @@ def test_starcoder2_sliding_window_matches_hf(golden_dir):
     emb = O.prepare_generation_inputs(w, cfg, g["image"], g["prompt_ids"])
     assert emb.shape[1] < W < emb.shape[1] + n_new
     assert torch.equal(O.greedy_generate(w, cfg, emb, emb.shape[1] + n_new), g["tokens"])
+
+
+def test_image_preprocess_restatement_matches_pillow():
+    """the numpy integer restatement of ImageTrainProcessor (composite on white, pad, Pillow's
+    fixed-point bicubic resize, ToTensor, Normalize) equals Pillow + torch bit for bit (Pillow is the oracle's pin)."""
+    pytest.importorskip("PIL")
+    from oracle import image_preprocess as P
+    P.pin(verbose=False)
+    b, t = P.resample_coeffs(448, 224)
+    assert t.shape[1] == 9 and int(t[100, :b[100, 1]].sum()) in range((1 << 22) - 8, (1 << 22) + 9)   # taps sum to 1.0
+    b, t = P.resample_coeffs(100, 224)                       # upscaling keeps the 2-pixel support
+    assert t.shape[1] == 5 and int(b[:, 1].max()) <= 5
