@@ -152,9 +152,12 @@ int  sv_embed_tokens(sv_engine* e, const int64_t* dev_ids, int32_t n, void* dev_
 /* Image pre-processing on device = `ImageTrainProcessor.__call__` (starvector/data/util.py:40-68):
  * dev_pixels uint8 [height][width][channels] (3 = RGB, 4 = RGBA composited on white) -> white pad to square -> Pillow's
  * antialiased BICUBIC resize to out_size -> /255 -> (x - mean) / std.  dev_out float32 [3][out_size][out_size], bit for bit
- * the tensor the reference computes with Pillow + torchvision.  Needs no engine handle. */
+ * the tensor the reference computes with Pillow + torchvision.  Needs no engine handle.
+ * recipe 0: the above (clip branch).  recipe 1: the SigLIP tower's HF image processor (image_encoder.py:45-48,116-117):
+ * alpha dropped (`convert("RGB")`), the image STRETCHED to out_size x out_size by the same resampler, rescale by 1/255 in
+ * double, then (x - mean) / std (mean = std = 0.5 for google/siglip-large-patch16-384). */
 int  sv_preprocess_image(const uint8_t* dev_pixels, int32_t width, int32_t height, int32_t channels, int32_t out_size,
-                         const float* mean3, const float* std3, float* dev_out, sv_stream stream);
+                         int32_t recipe, const float* mean3, const float* std3, float* dev_out, sv_stream stream);
 
 /* Prompt pass over inputs_embeds [B,S0,hidden] bf16 (all-ones attention mask): fills the paged KV
  * cache and writes the last-row logits [B, vocab] fp32 (bf16-rounded values, as the reference's

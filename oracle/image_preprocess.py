@@ -65,11 +65,12 @@ def _clip8(v: np.ndarray) -> np.ndarray:
 
 
 def resize_bicubic_u8(img: np.ndarray, out_size: int) -> np.ndarray:
-    """Pillow `Image.resize((out, out), BICUBIC)` on a square uint8 [H, W, C] image: horizontal pass to uint8, then
-    vertical pass (ImagingResampleHorizontal_8bpc / ImagingResampleVertical_8bpc)."""
+    """Pillow `Image.resize((out, out), BICUBIC)` on a uint8 [H, W, C] image: horizontal pass to uint8, then
+    vertical pass (ImagingResampleHorizontal_8bpc / ImagingResampleVertical_8bpc).  A pass whose input size already
+    equals the output size has identity taps (Pillow skips it)."""
     h, w, _ = img.shape
-    assert h == w
     bh, th = resample_coeffs(w, out_size)
+    bv, tv = resample_coeffs(h, out_size)
     src = img.astype(np.int64)
     tmp = np.empty((h, out_size, img.shape[2]), dtype=np.uint8)
     for xo in range(out_size):
@@ -79,8 +80,8 @@ def resize_bicubic_u8(img: np.ndarray, out_size: int) -> np.ndarray:
     out = np.empty((out_size, out_size, img.shape[2]), dtype=np.uint8)
     t64 = tmp.astype(np.int64)
     for yo in range(out_size):
-        y0, n = bh[yo]                                  # square -> same tables for both passes
-        acc = (t64[y0:y0 + n, :, :] * th[yo, :n].astype(np.int64)[:, None, None]).sum(axis=0) + (1 << (PRECISION_BITS - 1))
+        y0, n = bv[yo]
+        acc = (t64[y0:y0 + n, :, :] * tv[yo, :n].astype(np.int64)[:, None, None]).sum(axis=0) + (1 << (PRECISION_BITS - 1))
         out[yo] = _clip8(acc)
     return out
 
@@ -114,6 +115,36 @@ def preprocess(pixels: np.ndarray, size: int = 224, mean=CLIP_MEAN, std=CLIP_STD
     m = np.asarray(mean, dtype=np.float32).reshape(3, 1, 1)
     s = np.asarray(std, dtype=np.float32).reshape(3, 1, 1)
     return ((x - m) / s).astype(np.float32)                                                # Normalize
+
+
+def preprocess_siglip(pixels: np.ndarray, size: int = 384, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)) -> np.ndarray:
+    """HF SiglipImageProcessor (the `AutoProcessor` of the v2 tower, image_encoder.py:45-48,116-117): convert("RGB") drops
+    alpha, the image is STRETCHED to size x size (same resampler), rescale = float32(float64(u) * (1/255)), normalise."""
+    rgb = np.ascontiguousarray(pixels[..., :3])
+    if rgb.shape[0] != size or rgb.shape[1] != size:
+        rgb = resize_bicubic_u8(rgb, size)
+    x = (rgb.astype(np.float64) * (1 / 255)).astype(np.float32).transpose(2, 0, 1)
+    m = np.asarray(mean, dtype=np.float32).reshape(3, 1, 1)
+    s = np.asarray(std, dtype=np.float32).reshape(3, 1, 1)
+    return ((x - m) / s).astype(np.float32)
+
+
+def pin_siglip(verbose: bool = True) -> None:
+    """The SigLIP recipe against HF's own PIL image processor (when transformers is importable) and Pillow."""
+    from PIL import Image
+    rng = np.random.default_rng(1)
+    try:
+        from transformers.models.siglip.image_processing_pil_siglip import SiglipImageProcessorPil as HFP
+    except Exception:                                      # older transformers: the PIL processor is the default class
+        from transformers import SiglipImageProcessor as HFP
+    ip = HFP(size={"height": 384, "width": 384}, resample=3, do_rescale=True, rescale_factor=1 / 255, do_normalize=True,
+             image_mean=[0.5, 0.5, 0.5], image_std=[0.5, 0.5, 0.5], do_convert_rgb=True)
+    for (w, h, c) in [(517, 300, 4), (384, 384, 3), (224, 224, 3), (1000, 120, 3), (384, 100, 4)]:
+        px = rng.integers(0, 256, size=(h, w, c), dtype=np.uint8)
+        ref = ip(images=[Image.fromarray(px, "RGBA" if c == 4 else "RGB")], return_tensors="np")["pixel_values"][0]
+        assert np.array_equal(preprocess_siglip(px).view(np.int32), np.asarray(ref, dtype=np.float32).view(np.int32)), (w, h, c)
+        if verbose:
+            print(f"[image_preprocess/siglip] {w}x{h}x{c}: == HF SiglipImageProcessor (PIL), bit for bit")
 
 
 def pin(verbose: bool = True) -> None:
@@ -152,3 +183,4 @@ def pin(verbose: bool = True) -> None:
 
 if __name__ == "__main__":
     pin()
+    pin_siglip()

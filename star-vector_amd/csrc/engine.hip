@@ -1298,15 +1298,16 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
 // C ABI: image pre-processing on device (no engine handle: it depends on nothing but the pixels)
 // ------------------------------------------------------------------------------------------------
 extern "C" int sv_preprocess_image(const uint8_t* dev_pixels, int32_t width, int32_t height, int32_t channels,
-                                   int32_t out_size, const float* mean3, const float* std3, float* dev_out,
-                                   sv_stream stream) {
+                                   int32_t out_size, int32_t recipe, const float* mean3, const float* std3,
+                                   float* dev_out, sv_stream stream) {
+    if (recipe != 0 && recipe != 1) return fail(SV_EINVAL, "sv_preprocess_image: recipe must be 0 (ImageTrainProcessor) or 1 (SigLIP processor)");
     if (!dev_pixels || !dev_out || !mean3 || !std3) return fail(SV_EINVAL, "sv_preprocess_image: null argument");
     if (width < 1 || height < 1 || width > 16384 || height > 16384) return fail(SV_EINVAL, "sv_preprocess_image: bad image size %dx%d", width, height);
     if (channels != 3 && channels != 4) return fail(SV_EINVAL, "sv_preprocess_image: channels must be 3 (RGB) or 4 (RGBA), got %d", channels);
     if (out_size < 1 || out_size > 4096) return fail(SV_EINVAL, "sv_preprocess_image: bad output size %d", out_size);
     for (int c = 0; c < 3; ++c)
         if (!(std3[c] > 0.f)) return fail(SV_EINVAL, "sv_preprocess_image: std must be positive");
-    const int r = preprocess_image(dev_pixels, width, height, channels, out_size, mean3, std3, dev_out, (hipStream_t)stream);
+    const int r = preprocess_image(dev_pixels, width, height, channels, out_size, recipe, mean3, std3, dev_out, (hipStream_t)stream);
     if (r) return fail(SV_EHIP, "sv_preprocess_image: %s", hipGetErrorString((hipError_t)r));
     return 0;
 }

@@ -190,7 +190,7 @@ struct FinishArgs {
 void launch_finish_step(const FinishArgs& a, hipStream_t st);
 
 // ---- image pre-processing (preprocess.hip): uint8 HWC (3 or 4 channels) -> float32 [3][S][S], returns a hipError_t value
-int preprocess_image(const uint8_t* dev_pixels, int width, int height, int channels, int out_size, const float* mean3,
-                     const float* std3, float* dev_out, hipStream_t st);
+int preprocess_image(const uint8_t* dev_pixels, int width, int height, int channels, int out_size, int recipe,
+                     const float* mean3, const float* std3, float* dev_out, hipStream_t st);
 
 }  // namespace sv

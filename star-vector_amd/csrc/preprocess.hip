@@ -1,7 +1,8 @@
 // Image pre-processing on device (reference: starvector/data/util.py:40-68
 // `ImageTrainProcessor`): RGBA -> composite on white, white pad to square, Pillow's antialiased BICUBIC resize (what
 // torchvision `Resize` runs on a PIL image), ToTensor, Normalize.  A byte / integer path: the output equals the
-// reference's float32 tensor bit for bit.
+// reference's float32 tensor bit for bit.  Recipe 1 is the SigLIP tower's HF image processor (image_encoder.py:45-48,
+// 116-117): alpha dropped, the image stretched to S x S with the same resampler, rescale by 1/255 in double.
 //
 //   composite : Pillow Paste.c paste_mask_L on a white background, per channel
 //               DIV255(255 * (255 - a) + c * a),  DIV255(t) = ((t' >> 8) + t') >> 8, t' = t + 128
@@ -27,11 +28,13 @@ namespace sv {
 
 struct PpArgs {
     const uint8_t* px; int W, H, C;      // source pixels, HWC
-    int m, left, top;                    // padded square side and the offset of the source inside it
+    int cw, ch, left, top;               // canvas (padded square, or the image itself) and the source offset inside it
     int S;                               // output side
-    const int32_t* bounds;               // [S][2] first input index, tap count
-    const int32_t* taps; int ksize;      // [S][ksize]
-    uint8_t* tmp;                        // [m][S][3] horizontal pass output
+    int recipe;                          // 0: ImageTrainProcessor (composite on white, pad, u/255 in float32)
+                                         // 1: HF SiglipImageProcessor (alpha dropped, stretch, u * (1/255) in double)
+    const int32_t* bounds_h; const int32_t* taps_h; int ksize_h;   // [S][2], [S][ksize]: canvas width  -> S
+    const int32_t* bounds_v; const int32_t* taps_v; int ksize_v;   //                     canvas height -> S
+    uint8_t* tmp;                        // [ch][S][3] horizontal pass output
     float* out;                          // [3][S][S]
     float mean[3], stdv[3];
 };
@@ -40,7 +43,7 @@ __device__ __forceinline__ int pp_src(const PpArgs& p, int y, int x, int c) {
     const int yy = y - p.top, xx = x - p.left;
     if (yy < 0 || yy >= p.H || xx < 0 || xx >= p.W) return 255;          // white padding
     const uint8_t* q = p.px + ((size_t)yy * p.W + xx) * p.C;
-    if (p.C == 3) return q[c];
+    if (p.C == 3 || p.recipe == 1) return q[c];                         // recipe 1: image.convert("RGB") drops alpha
     const int a = q[3];
     const int t = 255 * (255 - a) + (int)q[c] * a + 128;
     return ((t >> 8) + t) >> 8;
@@ -50,15 +53,16 @@ __device__ __forceinline__ int pp_clip8(int v) {
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
 __device__ __forceinline__ float pp_norm(const PpArgs& p, int u, int c) {
-    const float x = (float)u / 255.0f;                                   // ToTensor
+    // recipe 0: ToTensor = float32 u / 255.  recipe 1: HF rescale = float32(double(u) * (1 / 255))
+    const float x = p.recipe == 1 ? (float)((double)u * 0.00392156862745098) : (float)u / 255.0f;
     return (x - p.mean[c]) / p.stdv[c];                                   // Normalize
 }
 
 __global__ __launch_bounds__(256) void pp_horizontal_kernel(PpArgs p) {
     const int xo = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
     if (xo >= p.S) return;
-    const int x0 = p.bounds[2 * xo], n = p.bounds[2 * xo + 1];
-    const int32_t* k = p.taps + (size_t)xo * p.ksize;
+    const int x0 = p.bounds_h[2 * xo], n = p.bounds_h[2 * xo + 1];
+    const int32_t* k = p.taps_h + (size_t)xo * p.ksize_h;
     int acc[3] = {1 << (PP_BITS - 1), 1 << (PP_BITS - 1), 1 << (PP_BITS - 1)};
     for (int i = 0; i < n; ++i) {
         const int w = k[i];
@@ -73,8 +77,8 @@ __global__ __launch_bounds__(256) void pp_horizontal_kernel(PpArgs p) {
 __global__ __launch_bounds__(256) void pp_vertical_kernel(PpArgs p) {
     const int xo = blockIdx.x * blockDim.x + threadIdx.x, yo = blockIdx.y;
     if (xo >= p.S) return;
-    const int y0 = p.bounds[2 * yo], n = p.bounds[2 * yo + 1];
-    const int32_t* k = p.taps + (size_t)yo * p.ksize;
+    const int y0 = p.bounds_v[2 * yo], n = p.bounds_v[2 * yo + 1];
+    const int32_t* k = p.taps_v + (size_t)yo * p.ksize_v;
     int acc[3] = {1 << (PP_BITS - 1), 1 << (PP_BITS - 1), 1 << (PP_BITS - 1)};
     for (int i = 0; i < n; ++i) {
         const int w = k[i];
@@ -140,25 +144,31 @@ static std::mutex g_pp_mu;
 static void* g_pp_buf = nullptr;
 static size_t g_pp_bytes = 0;
 
-int preprocess_image(const uint8_t* dev_pixels, int width, int height, int channels, int out_size, const float* mean3,
-                     const float* std3, float* dev_out, hipStream_t st) {
+int preprocess_image(const uint8_t* dev_pixels, int width, int height, int channels, int out_size, int recipe,
+                     const float* mean3, const float* std3, float* dev_out, hipStream_t st) {
     std::lock_guard<std::mutex> lk(g_pp_mu);
     PpArgs p;
-    p.px = dev_pixels; p.W = width; p.H = height; p.C = channels;
-    p.m = width > height ? width : height;
-    p.left = (p.m - width) / 2; p.top = (p.m - height) / 2;               // data/util.py:56-62
+    p.px = dev_pixels; p.W = width; p.H = height; p.C = channels; p.recipe = recipe;
+    if (recipe == 0) {                    // white pad to square (data/util.py:56-62)
+        p.cw = p.ch = width > height ? width : height;
+        p.left = (p.cw - width) / 2; p.top = (p.ch - height) / 2;
+    } else {                              // stretch: no padding
+        p.cw = width; p.ch = height; p.left = p.top = 0;
+    }
     p.S = out_size; p.out = dev_out;
     for (int c = 0; c < 3; ++c) { p.mean[c] = mean3[c]; p.stdv[c] = std3[c]; }
-    p.bounds = nullptr; p.taps = nullptr; p.ksize = 0; p.tmp = nullptr;
+    p.bounds_h = p.bounds_v = nullptr; p.taps_h = p.taps_v = nullptr; p.ksize_h = p.ksize_v = 0; p.tmp = nullptr;
     const dim3 blk(256), grid_out((out_size + 255) / 256, out_size);
-    if (p.m == out_size) {
+    if (p.cw == out_size && p.ch == out_size) {
         pp_copy_kernel<<<grid_out, blk, 0, st>>>(p);
         return (int)hipGetLastError();
     }
-    std::vector<int32_t> bounds, taps;
-    const int ksize = pp_coeffs(p.m, out_size, bounds, taps);
-    const size_t b_bytes = bounds.size() * 4, t_bytes = taps.size() * 4, tmp_bytes = (size_t)p.m * out_size * 3;
-    const size_t need = ((b_bytes + 255) & ~(size_t)255) + ((t_bytes + 255) & ~(size_t)255) + tmp_bytes + 256;
+    // a pass whose input size equals the output size has identity taps (bicubic(0) = 1, bicubic(+-1) = 0): Pillow skips it
+    std::vector<int32_t> bh, th, bv, tv;
+    const int kh = pp_coeffs(p.cw, out_size, bh, th), kv = pp_coeffs(p.ch, out_size, bv, tv);
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t tmp_bytes = (size_t)p.ch * out_size * 3;
+    const size_t need = al(bh.size() * 4) + al(th.size() * 4) + al(bv.size() * 4) + al(tv.size() * 4) + tmp_bytes + 256;
     if (need > g_pp_bytes) {
         if (g_pp_buf) (void)hipFree(g_pp_buf);
         g_pp_buf = nullptr; g_pp_bytes = 0;
@@ -166,16 +176,20 @@ int preprocess_image(const uint8_t* dev_pixels, int width, int height, int chann
         if (e != hipSuccess) return (int)e;
         g_pp_bytes = need;
     }
-    char* base = (char*)g_pp_buf;
-    int32_t* d_bounds = (int32_t*)base;
-    int32_t* d_taps = (int32_t*)(base + ((b_bytes + 255) & ~(size_t)255));
-    uint8_t* d_tmp = (uint8_t*)((char*)d_taps + ((t_bytes + 255) & ~(size_t)255));
-    hipError_t e = hipMemcpyAsync(d_bounds, bounds.data(), b_bytes, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_taps, taps.data(), t_bytes, hipMemcpyHostToDevice, st);
+    char* q = (char*)g_pp_buf;
+    int32_t* d_bh = (int32_t*)q; q += al(bh.size() * 4);
+    int32_t* d_th = (int32_t*)q; q += al(th.size() * 4);
+    int32_t* d_bv = (int32_t*)q; q += al(bv.size() * 4);
+    int32_t* d_tv = (int32_t*)q; q += al(tv.size() * 4);
+    uint8_t* d_tmp = (uint8_t*)q;
+    hipError_t e = hipMemcpyAsync(d_bh, bh.data(), bh.size() * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_th, th.data(), th.size() * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_bv, bv.data(), bv.size() * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_tv, tv.data(), tv.size() * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);                    // the tables are host temporaries
     if (e != hipSuccess) return (int)e;
-    p.bounds = d_bounds; p.taps = d_taps; p.ksize = ksize; p.tmp = d_tmp;
-    pp_horizontal_kernel<<<dim3((out_size + 255) / 256, p.m), blk, 0, st>>>(p);
+    p.bounds_h = d_bh; p.taps_h = d_th; p.ksize_h = kh; p.bounds_v = d_bv; p.taps_v = d_tv; p.ksize_v = kv; p.tmp = d_tmp;
+    pp_horizontal_kernel<<<dim3((out_size + 255) / 256, p.ch), blk, 0, st>>>(p);
     pp_vertical_kernel<<<grid_out, blk, 0, st>>>(p);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);                    // the workspace is shared between calls

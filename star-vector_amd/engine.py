@@ -369,17 +369,18 @@ def op_argmax(logits):
     return out
 
 
-def op_preprocess_image(pixels: torch.Tensor, size: int, mean, std) -> torch.Tensor:
-    """uint8 [H, W, 3|4] on the GPU -> float32 [3, size, size]: composite on white, pad to square, Pillow-exact bicubic
-    resize, ToTensor, Normalize (starvector/data/util.py:40-68)."""
+def op_preprocess_image(pixels: torch.Tensor, size: int, mean, std, recipe: str = "starvector") -> torch.Tensor:
+    """uint8 [H, W, 3|4] on the GPU -> float32 [3, size, size].  recipe "starvector": composite on white, pad to square,
+    Pillow-exact bicubic resize, ToTensor, Normalize (starvector/data/util.py:40-68); "siglip": HF SiglipImageProcessor
+    (alpha dropped, stretch-resize, rescale 1/255, normalise) as the v2 tower uses it (image_encoder.py:45-48)."""
     lib = _lib.load()
     px = _need(pixels, torch.uint8, "pixels")
     if px.dim() != 3 or px.shape[2] not in (3, 4):
         raise ValueError("pixels must be uint8 [H, W, 3] (RGB) or [H, W, 4] (RGBA)")
     out = torch.empty(3, size, size, dtype=torch.float32, device=px.device)
     m3, s3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
-    check(lib.sv_preprocess_image(_ptr(px), px.shape[1], px.shape[0], px.shape[2], int(size), m3, s3, _ptr(out), _stream()),
-          "sv_preprocess_image")
+    check(lib.sv_preprocess_image(_ptr(px), px.shape[1], px.shape[0], px.shape[2], int(size),
+                                  {"starvector": 0, "siglip": 1}[recipe], m3, s3, _ptr(out), _stream()), "sv_preprocess_image")
     return out
 
 

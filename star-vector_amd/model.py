@@ -212,21 +212,58 @@ class _EngineModule(nn.Module):
         object.__setattr__(self, "_engine", engine)
 
 
-class ImageEncoder(_EngineModule):
-    """image_encoder.py:91-94 (clip branch): ln_vision(VisionTransformer(image)) -> [B,257,1024]."""
+class SiglipProcessor:
+    """What `AutoProcessor.from_pretrained("google/siglip-large-patch16-384")` does to images (image_encoder.py:45-48):
+    HF SiglipImageProcessor -- convert to RGB (alpha dropped), stretch to size x size with Pillow's BICUBIC resampler,
+    rescale by 1/255, normalise with mean = std = 0.5.  Runs on the engine's GPU (`sv_preprocess_image`, recipe 1; bit
+    identical to the HF PIL processor); call signature and return shape follow the HF processor."""
 
-    def __init__(self, engine: HipEngine, image_size: int = 224):
+    class _Out:
+        def __init__(self, pixel_values):
+            self.pixel_values = pixel_values
+
+        def __getitem__(self, k):
+            return getattr(self, k)
+
+    def __init__(self, size: int = 384, device=None, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)):
+        self.size, self.device, self.mean, self.std = size, device, tuple(mean), tuple(std)
+
+    def __call__(self, images=None, return_tensors="pt", **kw):
+        import numpy as np
+        from .engine import op_preprocess_image
+        if images is None:
+            raise ValueError("images is required")
+        imgs = images if isinstance(images, (list, tuple)) else [images]
+        out = []
+        for img in imgs:
+            if img.mode not in ("RGB", "RGBA"):
+                img = img.convert("RGB")
+            px = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).to(self.device)
+            out.append(op_preprocess_image(px, self.size, self.mean, self.std, recipe="siglip"))
+        return SiglipProcessor._Out(torch.stack(out, 0))
+
+
+class ImageEncoder(_EngineModule):
+    """image_encoder.py:91-94 (clip branch): ln_vision(VisionTransformer(image)) -> [B,257,1024]; siglip branch
+    (:108-109): the HF vision tower's last_hidden_state -> [B,576,1024]."""
+
+    def __init__(self, engine: HipEngine, image_size: int = 224, image_encoder_type: str = "clip"):
         super().__init__(engine)
-        self.image_encoder_type = "clip"
+        self.image_encoder_type = image_encoder_type
         # the engine lives on a GPU, so the images are pre-processed there as well (bit-identical to the Pillow recipe)
         dev = torch.device("cuda", engine.device) if engine is not None and hasattr(engine, "device") else None
-        self.processor = ImageTrainProcessor(size=image_size, device=dev)
+        if "siglip" in image_encoder_type:
+            self.processor = SiglipProcessor(size=image_size, device=dev)
+        else:
+            self.processor = ImageTrainProcessor(size=image_size, device=dev)
 
     def forward(self, image: torch.Tensor) -> torch.Tensor:
         return self._engine.encode_image(image)
 
     def process_images(self, images):                      # image_encoder.py:112-117
-        return [self.processor(image).unsqueeze(0) for image in images]
+        if self.image_encoder_type == "clip":
+            return [self.processor(image).unsqueeze(0) for image in images]
+        return self.processor(images=images, return_tensors="pt").pixel_values.unsqueeze(0)     # sic: [1, B, 3, S, S]
 
 
 class Adapter(_EngineModule):
@@ -373,7 +410,7 @@ class StarVectorStarCoder(nn.Module):
         self.model_precision = torch.bfloat16
         ec = engine.cfg
         self.svg_transformer = StarCoderModel(engine, tokenizer, config.max_length, v2=v2)
-        self.image_encoder = ImageEncoder(engine, ec.image_size)
+        self.image_encoder = ImageEncoder(engine, ec.image_size, config.image_encoder_type)
         self.query_length = ec.query_length                          # starvector_base.py:85-106
         self.image_projection = Adapter(engine, self.query_length, ec.adapter_norm)
         self.max_length = config.max_length_train - self.query_length - 4

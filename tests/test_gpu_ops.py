@@ -290,3 +290,19 @@ def test_preprocess_image_bit_exact(w, h, c):
     on_dev = ImageTrainProcessor(size=224, device=dev())(pil)
     on_host = ImageTrainProcessor(size=224)(pil)
     assert on_dev.is_cuda and torch.equal(on_dev.cpu().view(torch.int32), on_host.view(torch.int32))
+
+
+@pytest.mark.parametrize("w,h,c", [(517, 300, 4), (384, 384, 3), (224, 224, 3), (1000, 120, 3), (384, 100, 4), (3, 5, 3)])
+def test_preprocess_image_siglip_recipe_bit_exact(w, h, c):
+    """Recipe 1 = HF SiglipImageProcessor (v2 tower): alpha dropped, stretch to 384 x 384, rescale in double, mean = std = 0.5.
+    Bit-exact against the numpy oracle (pinned to HF's PIL processor on CPU) and, when importable here, against HF itself."""
+    import numpy as np
+    from PIL import Image
+    from oracle import image_preprocess as P
+    rng = np.random.default_rng(w + 13 * h)
+    px = rng.integers(0, 256, size=(h, w, c), dtype=np.uint8)
+    got = E.op_preprocess_image(torch.from_numpy(px).to(dev()), 384, (0.5,) * 3, (0.5,) * 3, recipe="siglip").cpu().numpy()
+    assert np.array_equal(got.view(np.int32), P.preprocess_siglip(px).view(np.int32))
+    from starvector_amd.model import SiglipProcessor
+    pv = SiglipProcessor(384, dev())(images=[Image.fromarray(px, "RGBA" if c == 4 else "RGB")] * 2).pixel_values
+    assert pv.shape == (2, 3, 384, 384) and np.array_equal(pv[1].cpu().numpy().view(np.int32), got.view(np.int32))

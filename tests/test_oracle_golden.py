@@ -3,6 +3,8 @@ plus the generation semantics that define parity.
 import dataclasses
 import os
 
+import importlib.util
+
 import pytest
 import torch
 from safetensors.torch import load_file
@@ -211,6 +213,8 @@ def test_image_preprocess_restatement_matches_pillow():
     pytest.importorskip("PIL")
     from oracle import image_preprocess as P
     P.pin(verbose=False)
+    if importlib.util.find_spec("transformers") is not None:
+        P.pin_siglip(verbose=False)                          # the v2 tower's HF image processor recipe
     b, t = P.resample_coeffs(448, 224)
     assert t.shape[1] == 9 and int(t[100, :b[100, 1]].sum()) in range((1 << 22) - 8, (1 << 22) + 9)   # taps sum to 1.0
     b, t = P.resample_coeffs(100, 224)                       # upscaling keeps the 2-pixel support
