@@ -128,7 +128,8 @@ def main():
         emb = torch.cat([vis, eng.embed_tokens(prompt)], 1)    # a1, a7
         new = eng.generate(emb, max_length=S0 + max_new, eos_token_id=-1,      # EOS disabled:
                            pad_token_id=cfg.pad_token_id,                      # fixed-length workload
-                           do_sample=is8b, temperature=1.0, top_p=0.95, seed=1)    # config 4 samples (top-p 0.95)
+                           do_sample=is8b, temperature=1.0, top_p=0.95, top_k=50 if is8b else 0,
+                           seed=1)       # config 4 samples: top-p 0.95 after HF 4.49's implicit top-k 50
         out = torch.cat([prompt, new], 1)                      # starvector_base.py:256
         if world > 1:
             out = all_gather_token_streams(out, cfg.pad_token_id, B_PER_GPU * world)
@@ -200,7 +201,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
             "data": f"synthetic: random-pixel {cfg.image_size}x{cfg.image_size} images (CLIP-normalised), random-init weights N(0,0.02) seed 1234",
-            "config": {"workload": (f"StarVector-8B im2svg, batch {B_PER_GPU}/GPU, bf16, top-p 0.95, 384x384, prompt rows "
+            "config": {"workload": (f"StarVector-8B im2svg, batch {B_PER_GPU}/GPU, bf16, top-k 50 + top-p 0.95, 384x384, prompt rows "
                                     f"{S0} (576 visual + {len(PROMPT_IDS)}), {n_new} new tokens/seq, EOS disabled") if is8b else
                                    (f"StarVector-1B im2svg, batch {B_PER_GPU}/GPU, bf16, greedy, 224x224, prompt rows "
                                     f"{S0} (257 visual + {len(PROMPT_IDS)}), {n_new} new tokens/seq, EOS disabled"),

@@ -1155,6 +1155,10 @@ void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st) {
     const int per_split = KS / a.splitk;
     // narrow outputs (few column tiles) get 16 waves per block so that no cross-block split-K is needed
     const bool narrow = (a.Npad / 32) * a.splitk * a.MT < 160;
+    const char* ew = getenv("SV_SKINNY_WAVES");          // experiment switch (tools/bench_skinny.py): force 16 / 8 waves
+    const int force = ew ? atoi(ew) : 0;
+    if (force == 16 && per_split % 16 == 0) { launch_sk<16>(a, grid, st); return; }
+    if (force == 8 && per_split % 8 == 0) { launch_sk<8>(a, grid, st); return; }
     if (per_split % 16 == 0 && narrow) launch_sk<16>(a, grid, st);
     else if (per_split % 8 == 0) launch_sk<8>(a, grid, st);
     else if (per_split % 4 == 0) launch_sk<4>(a, grid, st);

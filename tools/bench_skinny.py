@@ -31,6 +31,18 @@ cases = [
     ("lm_head f32", 32, 49156, 2048, 1, 0, 2),
     ("lm_head LN f32", 32, 49156, 2048, 1, 1, 2),
 ]
+if len(sys.argv) > 1 and sys.argv[1] == "waves":        # in-process A/B of the block size (8 vs 16 waves)
+    for name, M, N, K, sk, ln, mode in cases:
+        res = []
+        for rep in range(2):
+            res = []
+            for wv in ("8", "16"):
+                os.environ["SV_SKINNY_WAVES"] = wv
+                us = C.c_double(0)
+                rc = lib.sv_bench_decode_linear(M, N, K, sk, ln, mode, 200, C.byref(us), st)
+                res.append(us.value if rc == 0 else float("nan"))
+        print(f"{name:32s} 8 waves {res[0]:7.2f} us   16 waves {res[1]:7.2f} us", flush=True)
+    sys.exit(0)
 for name, M, N, K, sk, ln, mode in cases:
     us = C.c_double(0)
     rc = lib.sv_bench_decode_linear(M, N, K, sk, ln, mode, 200, C.byref(us), st)
