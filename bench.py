@@ -188,11 +188,22 @@ def main():
         except Exception:
             traffic = None
 
-    # secondary, MFMA-bound kernel (TTFT path): the prefill c_fc GEMM [B*S0, 8192] x [8192, 2048]^T, live
+    # secondary, MFMA-bound kernels (TTFT path): the four decoder GEMMs of one prefill layer at M = B * S0 rows, live,
+    # through the same dispatch the engine uses (128^2 / 256^2 tile kernel + tail kernel)
     from starvector_amd.engine import bench_linear
     Mp = B_PER_GPU * S0
-    us_fc = bench_linear(Mp, cfg.n_inner, cfg.hidden, act="gelu_tanh", iters=5 if is8b else 10)
-    tf_fc = 2.0 * Mp * cfg.n_inner * cfg.hidden / us_fc / 1e6
+    D, F = cfg.hidden, cfg.n_inner
+    qkv = D + 2 * (D // cfg.n_head) * cfg.n_kv_head
+    gemms = [("c_attn", qkv, D, "none", False), ("c_proj", D, D, "none", True),
+             ("c_fc", F, D, "gelu_tanh", False), ("down_proj", D, F, "none", True)]
+    pf_us, pf_flop, per_gemm = 0.0, 0.0, {}
+    for gname, n_, k_, act_, res_ in gemms:
+        us_ = bench_linear(Mp, n_, k_, act=act_, residual=res_, iters=5 if is8b else 10)
+        fl_ = 2.0 * Mp * n_ * k_
+        pf_us += us_
+        pf_flop += fl_
+        per_gemm[gname] = {"shape": [Mp, n_, k_], "us": round(us_, 1), "tflops": round(fl_ / us_ / 1e6, 1)}
+    tf_fc = pf_flop / pf_us / 1e6
 
     if rank == 0:
         res = {
@@ -217,9 +228,10 @@ def main():
                          "algorithmic_bytes_per_launch": round(W_BYTES_PER_STEP / launches),
                          "avg_launch_us": round(sk_ms * 1e3 / launches, 2),
                          "avg_exec_us_event_deltas": round(sk_exec_ms * 1e3 / launches, 2)},
-            "roofline_prefill_gemm": {"bound": "mfma", "kernel": "gemm_bf16_kernel (prefill c_fc + GELU epilogue)",
+            "roofline_prefill_gemm": {"bound": "mfma",
+                                      "kernel": "gemm_bf16_kernel / gemm256_kernel / gemm_tail_kernel (the 4 decoder GEMMs of a prefill layer)",
                                       "achieved": round(tf_fc, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                                      "frac": round(tf_fc / 2500.0, 4), "shape": [Mp, cfg.n_inner, cfg.hidden]},
+                                      "frac": round(tf_fc / 2500.0, 4), "us_per_layer": round(pf_us, 1), "gemms": per_gemm},
             "decode_step_profile_ms": {k: round(v["ms_per_step"], 4) for k, v in prof.items() if isinstance(v, dict)},
             "setup_s": round(t_setup, 1),
         }

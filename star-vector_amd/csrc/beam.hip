@@ -82,7 +82,7 @@ __global__ __launch_bounds__(WP_THREADS) void beam_row_warp_kernel(BeamDev p) {
     float M, logS;
     bm_row_lse(p, row, M, logS);
     auto sc = [&](int i) { return bm_logprob(p, x, seen, M, logS, i) * p.inv_temp; };
-    const WarpStats w = row_warp_stats(sc, p.V, p.top_k, p.top_p, 2, red);      // min_tokens_to_keep = 2 under beams
+    const WarpStats w = row_warp_stats<false>(sc, p.V, p.top_k, p.top_p, 2, red);   // min_tokens_to_keep = 2 under beams
     if (threadIdx.x == 0) {
         float* o = p.warp + (size_t)row * 8;
         o[0] = w.kth; o[1] = w.mx; o[2] = w.invZ; o[3] = w.v0; o[4] = w.smin;

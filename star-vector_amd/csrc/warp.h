@@ -51,14 +51,100 @@ __device__ __forceinline__ float wp_block_max(float v, float* red) {
     return t;
 }
 
+// v0 is itself the probability of the smallest kept token, computed in another pass: the same expression compiled in a
+// second place may round one ulp lower (different fma contraction around __expf), which would drop exactly that token.
+// A relative slack of 2^-18 restores it; a token that close to the threshold is inside HF's own float-cumsum noise.
 __device__ __forceinline__ bool wp_keep(const WarpStats& w, float s) {
     if (!(s >= w.kth)) return false;
-    return __expf(s - w.mx) * w.invZ >= w.v0 || s >= w.smin;
+    return __expf(s - w.mx) * w.invZ >= w.v0 * 0.99999619f || s >= w.smin;
 }
 __device__ __forceinline__ float wp_prob(const WarpStats& w, float s) { return __expf(s - w.mx) * w.invZ; }
 
+// The thresholds need ~70 passes over the row (two bisections).  The row is read ONCE into registers (NPT values per
+// thread, strided: value j of thread t is score t + 1024 j) and every pass runs on registers; `sc` is only evaluated in
+// that first sweep.  NPT * 1024 must cover V (StarVector: 49156 / 49157 -> NPT 52).
+template <int NPT, class F>
+__device__ WarpStats row_warp_stats_regs(F sc, int V, int top_k, float top_p, int min_keep, float* red) {
+    const int tid = threadIdx.x;
+    WarpStats w;
+    float v[NPT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int i = tid + j * WP_THREADS;
+        v[j] = i < V ? sc(i) : -INFINITY;
+        mx = fmaxf(mx, v[j]);
+    }
+    w.mx = mx = wp_block_max(mx, red);
+
+    // TopK: kth = the k-th largest score, k = max(top_k, min_keep); off when top_k <= 0 or k >= V.  Padding entries are
+    // -inf = the smallest key, so they only ever count towards thresholds at the very bottom (k < V keeps them out).
+    w.kth = -INFINITY;
+    const int k = top_k > 0 ? (top_k > min_keep ? top_k : min_keep) : 0;
+    if (k > 0 && k < V) {
+        uint32_t lo = 0u, hi = wp_key(mx) + 1u;          // count(key >= lo) >= k > count(key >= hi)
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            float c = 0.f;
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) c += wp_key(v[j]) >= mid ? 1.f : 0.f;
+            c = wp_block_sum(c, red);                     // exact: counts < 2^24
+            if (c >= (float)k) lo = mid; else hi = mid;
+        }
+        w.kth = wp_unkey(lo);
+    }
+    // probabilities over the top-k survivors (unnormalised e = exp(s - mx), 0 for the filtered and the padding)
+    float z = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        v[j] = (v[j] >= w.kth && v[j] > -INFINITY) ? __expf(v[j] - mx) : (v[j] == mx ? 1.f : 0.f);
+        z += v[j];
+    }
+    z = wp_block_sum(z, red);
+    w.invZ = 1.0f / z;
+
+    // TopP: ascending sort, drop while cumulative mass <= 1 - top_p  ==  keep p >= v0
+    w.v0 = 0.f;
+    if (top_p < 1.0f) {
+        uint32_t lo = 0u, hi = 0x3f800000u;               // (lo, hi]
+        const float cut = 1.0f - top_p;
+        while (hi - lo > 1u) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            const float thr = __uint_as_float(mid);
+            float f = 0.f;
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) {
+                const float pr = v[j] * w.invZ;
+                f += pr <= thr ? pr : 0.f;
+            }
+            f = wp_block_sum(f, red);
+            if (f > cut) hi = mid; else lo = mid;
+        }
+        w.v0 = __uint_as_float(hi);
+    }
+    // min_tokens_to_keep: 1 -> the maximum; 2 -> the second largest (== the maximum if it occurs twice).  v[] now holds
+    // exp(s - mx): monotone in s, the maximum maps to exactly 1, so the second largest s is mx + log(second largest e)
+    // only approximately -- recover it from the scores instead (one more sweep of `sc`, beam-sample only).
+    w.smin = mx;
+    if (min_keep >= 2) {
+        float cnt = 0.f, below = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const int i = tid + j * WP_THREADS;
+            if (i < V) {
+                const float s = sc(i);
+                if (s == mx) cnt += 1.f; else below = fmaxf(below, s);
+            }
+        }
+        cnt = wp_block_sum(cnt, red);
+        below = wp_block_max(below, red);
+        if (cnt < 2.f) w.smin = below;
+    }
+    return w;
+}
+
 template <class F>
-__device__ WarpStats row_warp_stats(F sc, int V, int top_k, float top_p, int min_keep, float* red) {
+__device__ WarpStats row_warp_stats_global(F sc, int V, int top_k, float top_p, int min_keep, float* red) {
     const int tid = threadIdx.x;
     WarpStats w;
     float mx = -INFINITY;
@@ -116,6 +202,15 @@ __device__ WarpStats row_warp_stats(F sc, int V, int top_k, float top_p, int min
         if (cnt < 2.f) w.smin = below;
     }
     return w;
+}
+
+// REGS = false keeps every pass on `sc` (beam-sample: its score functor is heavier and the register copy spills)
+template <bool REGS = true, class F>
+__device__ WarpStats row_warp_stats(F sc, int V, int top_k, float top_p, int min_keep, float* red) {
+    if (!REGS) return row_warp_stats_global(sc, V, top_k, top_p, min_keep, red);
+    if (V <= 16 * WP_THREADS) return row_warp_stats_regs<16>(sc, V, top_k, top_p, min_keep, red);
+    if (V <= 52 * WP_THREADS) return row_warp_stats_regs<52>(sc, V, top_k, top_p, min_keep, red);
+    return row_warp_stats_global(sc, V, top_k, top_p, min_keep, red);
 }
 
 __device__ __forceinline__ uint64_t wp_splitmix64(uint64_t x) {
