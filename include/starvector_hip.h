@@ -164,6 +164,14 @@ int  sv_preprocess_image(const uint8_t* dev_pixels, int32_t width, int32_t heigh
  * bf16 lm_head produces). */
 int  sv_prefill(sv_engine* e, const void* dev_embeds, int32_t B, int32_t S0, float* dev_logits,
                 sv_stream stream);
+/* Scoring forward = `StarVectorForCausalLM.forward(vision_embeds, input_ids, ..., num_logits_to_keep)`
+ * (starvector_arch.py:161-184; GRPO's log-prob pass, inference mode): the decoder over inputs_embeds [B,S,hidden] bf16
+ * (all-ones mask) and the lm_head over the LAST n_keep positions of every sequence.
+ * dev_logits_bf16: [B, n_keep, vocab] bf16, the dtype the reference's bf16 lm_head returns.  Also leaves the KV cache
+ * filled like sv_prefill. */
+int  sv_forward_logits(sv_engine* e, const void* dev_embeds, int32_t B, int32_t S, int32_t n_keep,
+                       void* dev_logits_bf16, sv_stream stream);
+
 /* One autoregressive step for tokens [B] int32 (device) appended after the cached context. */
 int  sv_decode_step(sv_engine* e, const int32_t* dev_tokens, int32_t B, float* dev_logits, sv_stream stream);
 

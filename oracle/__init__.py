@@ -25,6 +25,7 @@ from .starvector_oracle import (  # noqa: F401
     adapter_forward,
     decoder_prefill,
     decoder_decode_step,
+    decoder_forward_logits,
     prepare_generation_inputs,
     greedy_generate,
     beam_search_generate,

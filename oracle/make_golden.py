@@ -417,6 +417,26 @@ def run_window_case(write):
         print("  wrote tests/golden/tiny_v2_window.safetensors")
 
 
+def run_forward_case(write):
+    """StarVectorForCausalLM.forward (starvector_arch.py:161-184): logits of the last num_logits_to_keep positions of
+    [visual prefix | completion ids] -- against HF GPTBigCodeForCausalLM(inputs_embeds).logits."""
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=1234)
+    _, _, _, lm = build_reference(cfg, w)
+    image = O.synthetic_images(2, cfg.image_size, seed=3)
+    ids = torch.randint(0, 500, (2, 9), generator=torch.Generator().manual_seed(4))
+    emb = O.prepare_generation_inputs(w, cfg, image, ids)
+    ref = lm(inputs_embeds=emb, attention_mask=torch.ones(emb.shape[:2], dtype=torch.long)).logits
+    for n in (0, 5, 1):
+        mine = O.decoder_forward_logits(w, cfg, emb, n)
+        check(f"forward logits, keep {n or 'all'}", mine, ref if n == 0 else ref[:, -n:], 1e-5)
+    if write:
+        from safetensors.torch import save_file
+        save_file({"image": image, "ids": ids, "logits_keep5": ref[:, -5:].contiguous(), "meta": torch.tensor([1234, 2, 9])},
+                  os.path.join(GOLD, "tiny_forward.safetensors"))
+        print("  wrote tests/golden/tiny_forward.safetensors")
+
+
 def main():
     write = "--no-write" not in sys.argv
     torch.manual_seed(0)
@@ -429,6 +449,7 @@ def main():
     run_reppen_case(write)
     run_beam_cases(write)
     run_sampling_cases(write)
+    run_forward_case(write)
     run_case_v2("tiny_v2_b2", O.OracleConfig.tiny_v2(), seed=2024, batch=2, n_new=12, write=write)
     run_window_case(write)
     if "--full" in sys.argv:

@@ -485,6 +485,19 @@ def decoder_prefill(w, cfg: OracleConfig, inputs_embeds: Tensor, mode: str = "fp
     return _lm_logits(w, cfg, h[:, -1, :], r), cache
 
 
+def decoder_forward_logits(w, cfg: OracleConfig, inputs_embeds: Tensor, num_logits_to_keep: int = 0, mode: str = "fp32"):
+    """StarVectorForCausalLM.forward (starvector_arch.py:161-184): the decoder over inputs_embeds and the lm_head over the
+    last `num_logits_to_keep` positions (0 = all).  v1 only (GPTBigCode); returns [B, n, V]."""
+    assert cfg.arch == "v1"
+    r = _rounder(mode)
+    B, S, D = inputs_embeds.shape
+    h = r(inputs_embeds + w[P_DEC + "wpe.weight"][:S])
+    for i in range(cfg.n_layer):
+        h, _, _ = _block(w, cfg, f"{P_DEC}h.{i}.", h, None, None, r)
+    n = num_logits_to_keep if num_logits_to_keep and num_logits_to_keep > 0 else S
+    return _lm_logits(w, cfg, h[:, -n:, :], r)
+
+
 def decoder_decode_step(w, cfg: OracleConfig, tokens: Tensor, cache, mode: str = "fp32"):
     """One autoregressive step: wte[token] + wpe[pos] -> 24 blocks against the cache -> logits."""
     r = _rounder(mode)

@@ -71,6 +71,7 @@ PROTOTYPES = {
     "sv_embed_tokens": (_I, [_P, _P, _I, _P, _P]),
     "sv_preprocess_image": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P, _P]),
     "sv_prefill": (_I, [_P, _P, _I, _I, _P, _P]),
+    "sv_forward_logits": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "sv_decode_step": (_I, [_P, _P, _I, _P, _P]),
     "sv_generate": (_I, [_P, _P, _I, _I, C.POINTER(SvSampling), _P, C.POINTER(_I), _P]),
     "sv_beam_create": (_I, [C.POINTER(SvBeamConfig), C.POINTER(_P)]),

@@ -194,6 +194,8 @@ struct sv_engine {
     BeamScorer beam;
     char* beam_staging = nullptr;
     size_t beam_staging_bytes = 0;
+    bf16_t* score_ws = nullptr;      // scoring forward: kept hidden rows, their ln_f, bf16 logits [rows][Vpad]
+    size_t score_elems = 0;
     int cached_B = 0;
     int num_cus = 256;
     bool fused_decode = false;   // SV_DECODE_FUSED=1: LN-prologue / ticket pipeline (5 launches per layer)
@@ -375,6 +377,7 @@ extern "C" int sv_destroy(sv_engine* e) {
     for (void* p : e->allocs) (void)hipFree(p);
     e->beam.destroy();
     if (e->beam_staging) (void)hipFree(e->beam_staging);
+    if (e->score_ws) (void)hipFree(e->score_ws);
     if (e->h_flags) (void)hipHostFree(e->h_flags);
     for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
     if (e->gen_event) (void)hipEventDestroy(e->gen_event);
@@ -764,7 +767,8 @@ static void lm_head_logits(sv_engine* e, int MT, const bf16_t* xp, const LNp* ln
     launch_gemm_skinny(a, st);
 }
 
-static int prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hipStream_t st) {
+static int prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hipStream_t st, int n_keep = 0,
+                           bf16_t* dev_scores = nullptr) {
     const sv_config& c = e->cfg;
     const int D = c.hidden, dh = e->dh, F = c.n_inner, M = B * S0, QKV = e->QKV, nkv = e->nkv;
     const int QD = c.n_head * dh;                      // width of the query block (= D for both model families)
@@ -794,6 +798,27 @@ static int prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hi
         launch_layernorm_rows(e->ph, D, L.ln2.g, L.ln2.b, e->pln, D, M, D, c.ln_eps, st);
         gemm(e->pln, D, L.c_fc, nullptr, 0, e->pmlp, F, M, ACT_GELU_TANH, 0, st);
         gemm(e->pmlp, F, L.c_proj2, e->ph, D, e->ph, D, M, ACT_NONE, 0, st);
+    }
+    if (n_keep > 0) {
+        // scoring forward (starvector_arch.py:161-184): ln_f + lm_head over the last n_keep rows of every sequence, as one
+        // big-M GEMM; bf16 logits like the reference's bf16 lm_head.  The GEMM writes rows of Vpad columns (the packed
+        // weight's padding), the caller's tensor has `vocab` columns.
+        const size_t rows = (size_t)B * n_keep;
+        const size_t need = rows * (size_t)D * 2 + rows * (size_t)e->Vpad;      // [rows][D] hidden, [rows][D] ln_f, [rows][Vpad]
+        if (need > e->score_elems) {
+            if (e->score_ws) (void)hipFree(e->score_ws);
+            e->score_ws = nullptr; e->score_elems = 0;
+            HIPCHECK(hipMalloc(reinterpret_cast<void**>(&e->score_ws), need * sizeof(bf16_t)));
+            e->score_elems = need;
+        }
+        bf16_t* hk = e->score_ws;
+        bf16_t* hn = hk + rows * D;
+        bf16_t* lg = hn + rows * D;
+        launch_gather_tail_rows(e->ph, hk, B, S0, n_keep, D, st);
+        launch_layernorm_rows(hk, D, e->ln_f.g, e->ln_f.b, hn, D, (int)rows, D, c.ln_eps, st);
+        gemm(hn, D, e->lm_head, nullptr, 0, lg, e->Vpad, (int)rows, ACT_NONE, 0, st);
+        HIPCHECK(hipMemcpy2DAsync(dev_scores, (size_t)c.vocab * sizeof(bf16_t), lg, (size_t)e->Vpad * sizeof(bf16_t),
+                                  (size_t)c.vocab * sizeof(bf16_t), rows, hipMemcpyDeviceToDevice, st));
     }
     // only the last prompt row feeds ln_f + lm_head (HF computes all rows; same result)
     launch_gather_last_rows(e->ph, e->hl, B, S0, D, st);
@@ -1010,6 +1035,24 @@ extern "C" int sv_prefill(sv_engine* e, const void* dev_embeds, int32_t B, int32
     return 0;
 }
 
+extern "C" int sv_forward_logits(sv_engine* e, const void* dev_embeds, int32_t B, int32_t S, int32_t n_keep,
+                                 void* dev_logits_bf16, sv_stream stream) {
+    SVCHECK(check_ready(e));
+    if (!dev_embeds || !dev_logits_bf16) return fail(SV_EINVAL, "sv_forward_logits: null argument");
+    if (B < 1 || B > e->cfg.max_batch) return fail(SV_EINVAL, "sv_forward_logits: bad B=%d (max_batch %d)", B, e->cfg.max_batch);
+    if (S < 1 || S > e->cfg.max_seq_len) return fail(SV_EINVAL, "sv_forward_logits: S=%d out of range (max_seq_len %d)", S, e->cfg.max_seq_len);
+    if (n_keep < 1 || n_keep > S) return fail(SV_EINVAL, "sv_forward_logits: n_keep=%d must be in 1..S", n_keep);
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    SVCHECK(assign_pages(e, B, S, st));
+    SVCHECK(prefill_forward(e, (const bf16_t*)dev_embeds, B, S, st, n_keep, (bf16_t*)dev_logits_bf16));
+    fill_i32_kernel<<<(B + 63) / 64, 64, 0, st>>>(e->positions, S, B);
+    e->cached_B = B;
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int sv_decode_step(sv_engine* e, const int32_t* dev_tokens, int32_t B, float* dev_logits, sv_stream stream) {
     SVCHECK(check_ready(e));
     if (!dev_tokens || !dev_logits) return fail(SV_EINVAL, "sv_decode_step: null pointer");
@@ -1104,6 +1147,7 @@ static int generate_beam(sv_engine* e, const void* dev_embeds, int B, int S0, co
     const size_t stage_bytes = (size_t)R * c.n_layer * e->nkv * e->page_bytes;
     if (stage_bytes > e->beam_staging_bytes) {
         if (e->beam_staging) (void)hipFree(e->beam_staging);
+    if (e->score_ws) (void)hipFree(e->score_ws);
         e->beam_staging = nullptr; e->beam_staging_bytes = 0;
         HIPCHECK(hipMalloc(reinterpret_cast<void**>(&e->beam_staging), stage_bytes));
         e->beam_staging_bytes = stage_bytes;

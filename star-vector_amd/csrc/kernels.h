@@ -106,6 +106,7 @@ void launch_vit_embed_lnpre(const bf16_t* patch_out, int ldp, const bf16_t* cls,
 void launch_dec_embed(const bf16_t* emb, const bf16_t* wpe, bf16_t* h, int B, int S0, int D, hipStream_t st);
 void launch_gather_rows(const bf16_t* table, const int64_t* ids, bf16_t* out, int n, int D, hipStream_t st);
 void launch_gather_last_rows(const bf16_t* h, bf16_t* out, int B, int S0, int D, hipStream_t st);
+void launch_gather_tail_rows(const bf16_t* h, bf16_t* out, int B, int S0, int n_keep, int D, hipStream_t st);
 
 // ---- adapter norm -------------------------------------------------------------------------------
 void launch_plane_layernorm(const bf16_t* x, const bf16_t* g, const bf16_t* b, bf16_t* y, int B, int QD,

@@ -340,6 +340,25 @@ __global__ void gather_last_rows_kernel(const bf16_t* __restrict__ h, bf16_t* __
             *reinterpret_cast<const uint4*>(h + ((size_t)b * S0 + S0 - 1) * D + c * 8);
     }
 }
+// the last n_keep rows of every sequence, packed [B * n_keep][D] (scoring forward: logits of the kept positions only)
+__global__ void gather_tail_rows_kernel(const bf16_t* __restrict__ h, bf16_t* __restrict__ out, int B, int S0, int n_keep,
+                                        int D) {
+    const int NC = D >> 3;
+    const size_t total = (size_t)B * n_keep * NC;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % NC);
+        const size_t r = i / NC;
+        const int j = (int)(r % n_keep), b = (int)(r / n_keep);
+        *reinterpret_cast<uint4*>(out + r * D + c * 8) =
+            *reinterpret_cast<const uint4*>(h + ((size_t)b * S0 + S0 - n_keep + j) * D + c * 8);
+    }
+}
+void launch_gather_tail_rows(const bf16_t* h, bf16_t* out, int B, int S0, int n_keep, int D, hipStream_t st) {
+    size_t total = (size_t)B * n_keep * (D / 8);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    gather_tail_rows_kernel<<<blocks, 256, 0, st>>>(h, out, B, S0, n_keep, D);
+}
 void launch_gather_last_rows(const bf16_t* h, bf16_t* out, int B, int S0, int D, hipStream_t st) {
     int total = B * (D / 8);
     gather_last_rows_kernel<<<(total + 255) / 256, 256, 0, st>>>(h, out, B, S0, D);

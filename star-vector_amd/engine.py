@@ -161,6 +161,17 @@ class HipEngine:
         check(self.lib.sv_prefill(self._h, _ptr(x), B, S0, _ptr(logits), _stream()), "sv_prefill")
         return logits
 
+    def forward_logits(self, inputs_embeds: torch.Tensor, num_logits_to_keep: int = 0) -> torch.Tensor:
+        """Scoring forward: bf16 logits [B, n, vocab] of the last n = num_logits_to_keep positions (0 = all positions)."""
+        x = _need(inputs_embeds, torch.bfloat16, "inputs_embeds")
+        B, S, D = x.shape
+        if D != self.cfg.hidden:
+            raise ValueError("inputs_embeds hidden size mismatch")
+        n = int(num_logits_to_keep) if num_logits_to_keep and num_logits_to_keep > 0 else S
+        out = torch.empty(B, n, self.cfg.vocab, dtype=torch.bfloat16, device=x.device)
+        check(self.lib.sv_forward_logits(self._h, _ptr(x), B, S, n, _ptr(out), _stream()), "sv_forward_logits")
+        return out
+
     def decode_step(self, tokens: torch.Tensor) -> torch.Tensor:
         tokens = _need(tokens.to(torch.int32), torch.int32, "tokens")
         B = tokens.numel()

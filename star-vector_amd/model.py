@@ -554,8 +554,24 @@ class StarVectorForCausalLM(nn.Module):
                 tokenizer = None
         return cls(cfg, state_dict=sd, tokenizer=tokenizer)
 
-    def forward(self, *a, **k):
-        raise NotImplementedError("training forward (GRPO logits) is outside the inference hot path (SURVEY.md section 2 #1)")
+    @torch.no_grad()
+    def forward(self, vision_embeds, input_ids, num_generations, attention_mask, num_logits_to_keep):
+        """starvector_arch.py:161-184, inference mode (no autograd graph: the engine holds no torch parameters): logits of
+        the completions given the visual prefix, as GRPO's log-prob pass asks for them."""
+        completion_embeds = self.model._get_embeddings(input_ids)
+        inputs_embeds = torch.cat([vision_embeds.repeat(num_generations, 1, 1).to(completion_embeds.dtype),
+                                   completion_embeds], dim=1)
+        if attention_mask is not None and not bool((attention_mask == 1).all()):
+            raise NotImplementedError("padding masks are not built (the path's mask is all ones)")
+        logits = self.engine.forward_logits(inputs_embeds.to(torch.bfloat16), int(num_logits_to_keep or 0))
+        try:
+            from transformers.modeling_outputs import CausalLMOutputWithCrossAttentions
+            return CausalLMOutputWithCrossAttentions(loss=None, logits=logits, past_key_values=None, hidden_states=None,
+                                                     attentions=None, cross_attentions=None)
+        except Exception:                                   # transformers not importable: same field names
+            import types
+            return types.SimpleNamespace(loss=None, logits=logits, past_key_values=None, hidden_states=None,
+                                         attentions=None, cross_attentions=None)
 
     def generate_im2svg(self, batch, **kwargs):           # starvector_arch.py:186-187
         return self.model.generate_im2svg(batch, **kwargs)

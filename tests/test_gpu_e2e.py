@@ -387,6 +387,45 @@ def test_starcoder2_sliding_window():
     small.close()
 
 
+def test_scoring_forward_logits():
+    """sv_forward_logits / StarVectorForCausalLM.forward (starvector_arch.py:161-184): bf16 logits of the last n positions
+    against the oracle (bf16 cast points; pinned to HF by tests/golden/tiny_forward) and the HF golden itself."""
+    import starvector_amd as sva
+    g = _golden("tiny_forward")
+    seed, B, n_ids = [int(x) for x in g["meta"]]
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=seed)
+    eng = build_engine(cfg, w, max_batch=4, max_seq_len=64)
+    vis = eng.adapter(eng.encode_image(bf(g["image"])))
+    emb = torch.cat([vis, eng.embed_tokens(g["ids"].to(dev()))], 1)
+    S = emb.shape[1]
+    got = eng.forward_logits(emb, 5)
+    assert got.shape == (B, 5, cfg.vocab) and got.dtype == torch.bfloat16
+    ora = O.decoder_forward_logits(w, cfg, emb.float().cpu(), 5, mode="bf16")
+    scale = float(ora.abs().max())
+    assert float((got.float().cpu() - ora).abs().max()) <= LOGIT_TOL * scale
+    assert rel_err(got, g["logits_keep5"]) <= 5e-2                                  # and the fp32 HF golden
+    full = eng.forward_logits(emb, 0)
+    assert full.shape == (B, S, cfg.vocab)
+    assert torch.equal(full[:, -5:].cpu().view(torch.int16), got.cpu().view(torch.int16))
+    # the last position agrees with the prefill logits (different GEMM kernel, same arithmetic up to summation order)
+    assert float((full[:, -1].float() - eng.prefill(emb).float()).abs().max()) <= LOGIT_TOL * scale
+    # argmax of position t predicts the completion token t+1 the same way for both paths where margins allow
+    eng.close()
+    # the mirror's forward(): visual prefix repeated num_generations times + completion ids
+    scfg = sva.StarVectorConfig(image_size=cfg.image_size, hidden_size=cfg.hidden, num_hidden_layers=cfg.n_layer,
+                                num_attention_heads=cfg.n_head, vocab_size=cfg.vocab - 4, n_inner=cfg.n_inner,
+                                n_positions=cfg.n_positions, max_length=cfg.n_positions, vit_width=cfg.vit_width,
+                                vit_layers=cfg.vit_layers, vit_heads=cfg.vit_heads, max_batch=4)
+    model = sva.StarVectorForCausalLM(scfg, state_dict={k: v.to(torch.bfloat16) for k, v in w.items()})
+    v1 = model.model.image_projection(model.model.image_encoder(bf(g["image"][:1])))
+    ids = g["ids"].to(dev())
+    out = model(v1, ids, 2, torch.ones(2, v1.shape[1] + ids.shape[1], device=dev()), 4)
+    assert out.logits.shape == (2, 4, cfg.vocab) and out.loss is None
+    ref = model.engine.forward_logits(torch.cat([v1.repeat(2, 1, 1), model.model._get_embeddings(ids)], 1), 4)
+    assert torch.equal(out.logits.view(torch.int16), ref.view(torch.int16))
+
+
 def test_starvector_8b_full_size_properties():
     """BASELINE config 4 shapes (siglip_384 + starcoder2-7b: 7.2 B parameters, 36 query / 4 KV heads, D 4608):
     the CPU oracle cannot run this size in test time, so the full size is covered by size-independent properties -

@@ -219,3 +219,17 @@ def test_image_preprocess_restatement_matches_pillow():
     assert t.shape[1] == 9 and int(t[100, :b[100, 1]].sum()) in range((1 << 22) - 8, (1 << 22) + 9)   # taps sum to 1.0
     b, t = P.resample_coeffs(100, 224)                       # upscaling keeps the 2-pixel support
     assert t.shape[1] == 5 and int(b[:, 1].max()) <= 5
+
+
+def test_scoring_forward_matches_hf(golden_dir):
+    """StarVectorForCausalLM.forward: logits of the kept positions against HF's full-sequence logits (tiny_forward)."""
+    g = _load(golden_dir, "tiny_forward")
+    seed, B, n_ids = [int(x) for x in g["meta"]]
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=seed)
+    emb = O.prepare_generation_inputs(w, cfg, g["image"], g["ids"])
+    got = O.decoder_forward_logits(w, cfg, emb, 5)
+    assert got.shape == g["logits_keep5"].shape and float((got - g["logits_keep5"]).abs().max()) <= 1e-5
+    full = O.decoder_forward_logits(w, cfg, emb, 0)
+    assert full.shape[1] == emb.shape[1] and float((full[:, -5:] - got).abs().max()) <= 1e-5
+    assert float((full[:, -1] - O.decoder_prefill(w, cfg, emb)[0]).abs().max()) <= 1e-6     # last row == the prefill logits
