@@ -86,6 +86,12 @@ typedef struct sv_config {
                                   The prompt must fit inside the window. */
 } sv_config;
 
+/* Streaming: called on the host with the tokens that became final since the last call -- tokens [batch][n_cols] int32
+ * row-major, covering output columns first_col .. first_col + n_cols - 1 -- every `sync_every` steps and once at the end
+ * (what a HF `streamer` gets through put(); the reference's serve worker builds one, serve/model_worker.py:129,170, but its
+ * kwargs whitelist never lets it reach generate). */
+typedef void (*sv_token_callback)(void* user, const int32_t* tokens, int32_t batch, int32_t first_col, int32_t n_cols);
+
 /* generate(...) arguments that reach HF generate through starvector_base.py:228-241 */
 typedef struct sv_sampling {
     int32_t do_sample;         /* 0 = greedy argmax */
@@ -105,6 +111,8 @@ typedef struct sv_sampling {
     int32_t early_stopping;    /* beam search: 0 False (HF default), 1 True (:293), 2 "never" */
     int32_t top_k;             /* used when do_sample: HF TopKLogitsWarper before top-p; 0 = off.  The reference never
                                   passes it, but its pinned transformers==4.49.0 defaults GenerationConfig.top_k to 50 */
+    sv_token_callback on_tokens; /* optional streaming callback (NULL = off); not with num_beams > 1 (as in HF) */
+    void*   user_data;
 } sv_sampling;
 
 /* HF beam search bookkeeping as a standalone device-side scorer (what transformers' _beam_search does between two

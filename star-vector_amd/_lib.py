@@ -38,8 +38,11 @@ class SvSampling(C.Structure):
         ("n_stop", C.c_int32), ("stop_ids", C.POINTER(C.c_int32)), ("seed", C.c_uint64),
         ("sync_every", C.c_int32), ("repetition_penalty", C.c_float),
         ("num_beams", C.c_int32), ("length_penalty", C.c_float), ("early_stopping", C.c_int32),
-        ("top_k", C.c_int32),
+        ("top_k", C.c_int32), ("on_tokens", C.c_void_p), ("user_data", C.c_void_p),
     ]
+
+
+TOKEN_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32)
 
 
 class SvBeamConfig(C.Structure):

@@ -1250,6 +1250,7 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
     HIPCHECK(hipStreamWaitEvent(st, e->gen_event, 0));
 
     if (sp->num_beams > 1) {
+        if (sp->on_tokens) return fail(SV_EINVAL, "streaming is not supported with beam search (hypotheses are only final at the end; HF refuses too)");
         if (sp->n_stop > 0 && !sp->stop_ids) return fail(SV_EINVAL, "n_stop > 0 but stop_ids is null");
         return generate_beam(e, dev_embeds, B, S0, sp, max_new, dev_out_tokens, n_generated, st);
     }
@@ -1275,6 +1276,20 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
 
     int steps = 0;
     const int chunk = sp->sync_every > 0 ? sp->sync_every : 32;
+    // streaming: columns [0, steps] are final after every poll (a finished batch may have fewer: n_emitted caps it)
+    int streamed = 0;
+    std::vector<int32_t> stream_buf;
+    auto stream_upto = [&](int n_cols_final) -> int {
+        if (!sp->on_tokens || n_cols_final <= streamed) return 0;
+        const int n = n_cols_final - streamed;
+        stream_buf.resize((size_t)B * n);
+        HIPCHECK(hipMemcpy2DAsync(stream_buf.data(), (size_t)n * sizeof(int32_t), e->out_tok + streamed,
+                                  (size_t)e->out_ld * sizeof(int32_t), (size_t)n * sizeof(int32_t), B, hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+        sp->on_tokens(sp->user_data, stream_buf.data(), B, streamed, n);
+        streamed = n_cols_final;
+        return 0;
+    };
     const bool use_graph = getenv("SV_NO_GRAPH") == nullptr;
     hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
@@ -1310,12 +1325,14 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
         steps += n;
         HIPCHECK(hipMemcpyAsync(&e->h_flags[0], e->d_done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
+        if (!e->h_flags[0]) SVCHECK(stream_upto(steps + 1));      // still running: every column so far is final
     }
     const double gexec_used = gexec ? 1.0 : 0.0;
     if (gexec) (void)hipGraphExecDestroy(gexec);
     if (graph) (void)hipGraphDestroy(graph);
     HIPCHECK(hipMemcpyAsync(&e->h_flags[1], e->d_nemit, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
+    if (e->h_flags[1] >= 1 && e->h_flags[1] <= max_new) SVCHECK(stream_upto(e->h_flags[1]));
     if (e->overlap && !e->fused_decode) {
         HIPCHECK(hipMemcpyAsync(&e->h_flags[2], e->ru_err, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));

@@ -326,7 +326,7 @@ class HipCausalLM(_EngineModule):
                  num_beams: int = 1, max_length: int = 30, min_length: int = 0, repetition_penalty: float = 1.0,
                  length_penalty: float = 1.0, use_cache: bool = True, stopping_criteria=None,
                  early_stopping: bool = False, pad_token_id: Optional[int] = None, eos_token_id: Optional[int] = None,
-                 num_return_sequences: int = 1, top_k: Optional[int] = 50, **unused) -> torch.Tensor:
+                 num_return_sequences: int = 1, top_k: Optional[int] = 50, streamer=None, **unused) -> torch.Tensor:
         # top_k: the reference never passes it; its pinned transformers==4.49.0 (pyproject.toml:18) defaults
         # GenerationConfig.top_k to 50, so every do_sample call there is top-k 50 followed by top-p.  Same default here.
         if inputs_embeds is None:
@@ -357,7 +357,18 @@ class HipCausalLM(_EngineModule):
             raise NotImplementedError("min_length beyond the prompt length is not built")
         if not use_cache:
             pass        # the engine always uses its paged KV cache; results are identical
-        return self._engine.generate(
+        on_tokens = None
+        if streamer is not None:
+            # HF streamer protocol (generation/streamers.py): put(prompt ids) once, put(next_tokens [B]) per step, end().
+            # Tokens arrive in bursts of `sync_every` steps: the decode loop does not return to the host every token.
+            if num_beams > 1:
+                raise ValueError("`streamer` cannot be used with beam search")          # HF's own check
+            streamer.put(torch.empty(inputs_embeds.shape[0], 0, dtype=torch.long))     # no prompt ids with inputs_embeds
+
+            def on_tokens(tokens, first_col):
+                for c in range(tokens.shape[1]):
+                    streamer.put(tokens[:, c])
+        out = self._engine.generate(
             inputs_embeds.to(torch.bfloat16), max_length=int(max_length), do_sample=bool(do_sample),
             temperature=float(temperature if temperature is not None else 1.0),
             top_p=float(top_p if top_p is not None else 1.0),
@@ -366,7 +377,11 @@ class HipCausalLM(_EngineModule):
             stop_ids=self._stop_ids(stopping_criteria), seed=self.seed,
             repetition_penalty=float(repetition_penalty if repetition_penalty is not None else 1.0),
             num_beams=num_beams, length_penalty=float(length_penalty if length_penalty is not None else 1.0),
-            early_stopping=early_stopping, top_k=int(top_k or 0))
+            early_stopping=early_stopping, top_k=int(top_k or 0), on_tokens=on_tokens,
+            sync_every=8 if streamer is not None else 32)
+        if streamer is not None:
+            streamer.end()
+        return out
 
 
 class StoppingCriteriaSub:
@@ -453,6 +468,9 @@ class StarVectorStarCoder(nn.Module):
             "length_penalty": base_kwargs.get("length_penalty", 1.0),
             "use_cache": base_kwargs.get("use_cache", True),
             "stopping_criteria": [StoppingCriteriaSub(stops=[end_sequence])],
+            # not in the reference's whitelist (so its serve worker's streamer never streams, serve/model_worker.py:129-175);
+            # kept here so that the same call does stream
+            "streamer": base_kwargs.get("streamer"),
         }
 
     def _get_im2svg_specific_kwargs(self, kwargs):                    # starvector_base.py:289-295

@@ -387,6 +387,58 @@ def test_starcoder2_sliding_window():
     small.close()
 
 
+def test_streaming_callback_and_hf_streamer():
+    """Tokens are handed to the host in bursts of `sync_every` steps while the hipGraph loop keeps running: the streamed
+    columns, concatenated, are exactly the returned tokens -- also when EOS / the row-0 stop ends generation early.  The
+    mirror feeds a HF-style streamer (put / end), which the reference's worker builds but never gets called."""
+    g = _golden("tiny_stop")
+    seed, B, n_new, eos = [int(x) for x in g["meta"]]
+    cfg = dataclasses.replace(O.OracleConfig.tiny(), eos_token_id=eos)
+    w = O.make_weights(cfg, seed=seed)
+    eng = build_engine(cfg, w, max_batch=4, max_seq_len=96)
+    emb = torch.cat([eng.adapter(eng.encode_image(bf(g["image"]))), eng.embed_tokens(g["prompt_ids"].to(dev()))], 1)
+    S0 = emb.shape[1]
+    for kw in (dict(eos_token_id=-1), dict(eos_token_id=eos, stop_ids=g["stop_ids"].tolist())):
+        chunks = []
+        toks = eng.generate(emb, max_length=S0 + 40, pad_token_id=cfg.pad_token_id, sync_every=4,
+                            on_tokens=lambda t, c0: chunks.append((c0, t.clone())), **kw).cpu()
+        assert len(chunks) >= 2 and chunks[0][0] == 0
+        assert [c0 for c0, _ in chunks] == [sum(t.shape[1] for _, t in chunks[:i]) for i in range(len(chunks))]   # contiguous
+        assert torch.equal(torch.cat([t for _, t in chunks], 1), toks)
+        assert torch.equal(toks, eng.generate(emb, max_length=S0 + 40, pad_token_id=cfg.pad_token_id, **kw).cpu())
+    with pytest.raises(ValueError):
+        eng.generate(emb, max_length=S0 + 8, eos_token_id=-1, pad_token_id=0, num_beams=2, on_tokens=lambda t, c0: None)
+    eng.close()
+
+    import starvector_amd as sva
+
+    class Streamer:                                         # the protocol of transformers.generation.streamers
+        def __init__(self):
+            self.values, self.ended = [], False
+
+        def put(self, value):
+            self.values.append(value.clone())
+
+        def end(self):
+            self.ended = True
+
+    c0 = O.OracleConfig.tiny()
+    w0 = O.make_weights(c0, seed=41)
+    scfg = sva.StarVectorConfig(image_size=c0.image_size, hidden_size=c0.hidden, num_hidden_layers=c0.n_layer,
+                                num_attention_heads=c0.n_head, vocab_size=c0.vocab - 4, n_inner=c0.n_inner,
+                                n_positions=c0.n_positions, max_length=c0.n_positions, vit_width=c0.vit_width,
+                                vit_layers=c0.vit_layers, vit_heads=c0.vit_heads, max_batch=4)
+    model = sva.StarVectorForCausalLM(scfg, state_dict={k: v.to(torch.bfloat16) for k, v in w0.items()})
+    from PIL import Image
+    batch = {"image": model.process_images([Image.new("RGB", (c0.image_size, c0.image_size), (20, 200, 30))])[0]}
+    st = Streamer()
+    S0 = model.model.query_length + 4
+    res = model.model.generate_im2svg_grpo(batch, max_length=S0 + 20, num_beams=1, use_nucleus_sampling=False, streamer=st)
+    assert st.ended and st.values[0].shape == (1, 0)                       # empty prompt ids first, like HF with inputs_embeds
+    streamed = torch.stack(st.values[1:], 1)
+    assert torch.equal(streamed.to(res["outputs"].device), res["outputs"][:, 4:])
+
+
 def test_scoring_forward_logits():
     """sv_forward_logits / StarVectorForCausalLM.forward (starvector_arch.py:161-184): bf16 logits of the last n positions
     against the oracle (bf16 cast points; pinned to HF by tests/golden/tiny_forward) and the HF golden itself."""
