@@ -50,6 +50,9 @@ def parse():
     ap.add_argument("--new-tokens", type=int, default=1024)
     ap.add_argument("--model", choices=["1b", "8b"], default="1b",
                     help="1b: BASELINE config 2 (batch 32, greedy); 8b: config 4 (StarVector-8B, batch 16, top-p 0.95)")
+    ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16",
+                    help="fp8: decoder weights + lm_head quantised to e4m3 at load (BASELINE config 5's weight format); "
+                         "NOT the reference precision -- never the headline line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ttft-requests", type=int, default=20)
     return ap.parse_args()
@@ -100,12 +103,14 @@ def main():
     is8b = args.model == "8b"
     cfg = O.OracleConfig.starvector_8b() if is8b else O.OracleConfig()
     B_PER_GPU = 16 if is8b else 32
-    W_BYTES_PER_STEP = decoder_weight_bytes(cfg)
+    W_BYTES_PER_STEP = decoder_weight_bytes(cfg) // (2 if args.weights == "fp8" else 1)
     n_new = args.new_tokens
     S0 = cfg.query_length + len(PROMPT_IDS)
     t_setup = time.time()
     ec = (sva.EngineConfig.starvector_8b(max_batch=B_PER_GPU, max_seq_len=S0 + n_new) if is8b
           else sva.EngineConfig(max_batch=B_PER_GPU, max_seq_len=S0 + n_new))
+    if args.weights == "fp8":
+        ec.weight_dtype = "fp8_e4m3"
     eng = sva.HipEngine(ec, device=local_rank)
     keep_cpu = (world == 1 and rank == 0 and not args.no_cpu_baseline and not is8b)   # 8B fp32 on CPU: 29 GB, skipped
     w = {}
@@ -210,7 +215,8 @@ def main():
             "metric": f"SVG tokens/sec (whole job) + p50 time-to-first-token, StarVector-{args.model.upper()} im2svg batch{B_PER_GPU}/GPU",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.weights == "bf16" else "bf16 activations / fp8-e4m3 decoder weights (not the reference precision)",
             "data": f"synthetic: random-pixel {cfg.image_size}x{cfg.image_size} images (CLIP-normalised), random-init weights N(0,0.02) seed 1234",
             "config": {"workload": (f"StarVector-8B im2svg, batch {B_PER_GPU}/GPU, bf16, top-k 50 + top-p 0.95, 384x384, prompt rows "
                                     f"{S0} (576 visual + {len(PROMPT_IDS)}), {n_new} new tokens/seq, EOS disabled") if is8b else

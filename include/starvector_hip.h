@@ -37,6 +37,8 @@ extern "C" {
 #endif
 
 #define SV_ABI_VERSION 2
+#define SV_WEIGHT_BF16 0
+#define SV_WEIGHT_FP8_E4M3 1
 
 enum {
     SV_OK = 0,
@@ -84,6 +86,10 @@ typedef struct sv_config {
     int32_t sliding_window;    /* v2: a query sees the last `sliding_window` keys, itself included (4096 for
                                   bigcode/starcoder2-7b; HF's eager/sdpa mask `kv > q - W`); 0 = full attention.
                                   The prompt must fit inside the window. */
+    int32_t weight_dtype;      /* SV_WEIGHT_BF16 (reference precision) or SV_WEIGHT_FP8_E4M3: decoder Linear weights and the
+                                  lm_head are quantised at load to OCP e4m3 with one scale per output row (BASELINE config 5,
+                                  "fp8 weights"): the decode step streams half the bytes; activations, accumulation and every
+                                  other tensor stay as they are.  Not a reference numerics mode: see DESIGN.md. */
 } sv_config;
 
 /* Streaming: called on the host with the tokens that became final since the last call -- tokens [batch][n_cols] int32
@@ -224,6 +230,10 @@ int  sv_op_linear(const void* x, const void* W, const void* bias, const void* re
 /* the decode-path (M<=32 per tile, weight-streaming) implementation of the same contraction */
 int  sv_op_linear_skinny(const void* x, const void* W, const void* bias, void* y_f32, int32_t M, int32_t N,
                          int32_t K, int32_t splitk, sv_stream stream);
+/* the same contraction with the weight quantised to fp8 e4m3 (one scale per output row, as weight_dtype = SV_WEIGHT_FP8_E4M3
+ * does at load): y = x . dequant(quant(W))^T + bias, fp32; scale_out [N] (device, optional) receives the row scales */
+int  sv_op_linear_skinny_fp8(const void* x, const void* W, const void* bias, void* y_f32, float* scale_out, int32_t M,
+                             int32_t N, int32_t K, int32_t splitk, sv_stream stream);
 /* The fused decode-step GEMM: y[M,N] = act( LN_opt(h)[M,K] . W^T + bias ) (+ residual), with the LayerNorm
  * applied in the GEMM prologue from per-tile partial statistics, the split-K reduction done by the last
  * arriving block (ticket), and (residual mode) the new rows' LayerNorm statistics row_stats[M][2] =

@@ -36,4 +36,5 @@ from .starvector_oracle import (  # noqa: F401
     synthetic_images,
     siglip_forward,
     embed_key,
+    fake_quantize_fp8,
 )

@@ -235,6 +235,31 @@ def _iter_weights_v2(cfg: OracleConfig, init, nrm, lin, ln):
     yield from ln(P_DEC2 + "norm", D)
 
 
+def fake_quantize_fp8(w: Dict[str, Tensor], cfg: OracleConfig) -> Dict[str, Tensor]:
+    """The engine's `weight_dtype = fp8_e4m3` mode (BASELINE config 5's weight format; NOT a reference numerics mode --
+    the reference reaches fp8 only through vLLM, which is not in tree): every decoder Linear weight and the lm_head is
+    replaced by dequant(quant(W)): W taken as the bf16 tensor the engine is handed, one scale per output row
+    = max|row| / 448, q = RNE to OCP e4m3.  Embedding lookups keep the bf16 table.  Returns a new dict."""
+    out = dict(w)
+    pre = P_DEC2 if cfg.arch == "v2" else P_DEC
+    keys = [K_LMH]
+    for i in range(cfg.n_layer):
+        if cfg.arch == "v2":
+            b = f"{pre}layers.{i}."
+            keys += [b + n for n in ("self_attn.q_proj.weight", "self_attn.k_proj.weight", "self_attn.v_proj.weight",
+                                     "self_attn.o_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight")]
+        else:
+            b = f"{pre}h.{i}."
+            keys += [b + n for n in ("attn.c_attn.weight", "attn.c_proj.weight", "mlp.c_fc.weight", "mlp.c_proj.weight")]
+    for k in keys:
+        wb = w[k].to(torch.bfloat16).float()
+        amax = wb.abs().amax(dim=1, keepdim=True)
+        scale = torch.where(amax > 0, amax / 448.0, torch.ones_like(amax))
+        q = (wb / scale).to(torch.float8_e4m3fn).float()
+        out[k] = q * scale
+    return out
+
+
 def embed_key(cfg: OracleConfig) -> str:
     return (P_DEC + "wte.weight") if cfg.arch == "v1" else (P_DEC2 + "embed_tokens.weight")
 

@@ -27,7 +27,7 @@ class SvConfig(C.Structure):
         ("vocab", C.c_int32), ("n_positions", C.c_int32), ("max_batch", C.c_int32),
         ("max_seq_len", C.c_int32), ("ln_eps", C.c_float), ("device", C.c_int32),
         ("arch", C.c_int32), ("n_kv_head", C.c_int32), ("rope_theta", C.c_float), ("vit_mlp", C.c_int32),
-        ("vit_eps", C.c_float), ("sliding_window", C.c_int32),
+        ("vit_eps", C.c_float), ("sliding_window", C.c_int32), ("weight_dtype", C.c_int32),
     ]
 
 
@@ -87,6 +87,7 @@ PROTOTYPES = {
     "sv_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "sv_op_linear": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sv_op_linear_skinny": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sv_op_linear_skinny_fp8": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sv_op_decode_linear": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sv_bench_linear": (_I, [_I, _I, _I, _I, _I, _I, C.POINTER(C.c_double), _P]),
     "sv_bench_decode_linear": (_I, [_I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_double), _P]),

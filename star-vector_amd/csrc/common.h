@@ -7,6 +7,7 @@ typedef unsigned short bf16_t;  // raw bfloat16 bits
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;   // one MFMA A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(16))) float f32x16;   // 32x32 MFMA accumulator
 typedef __attribute__((ext_vector_type(4))) float f32x4;     // 16x16 MFMA accumulator
+typedef __attribute__((ext_vector_type(2))) float f32x2;     // fp8 pair conversions
 
 #define SV_WAVE 64
 

@@ -115,6 +115,9 @@ __global__ void reduce_partials_kernel(const float* ws, int splitk, int rows_ws,
 struct Linear {
     bf16_t* Wp = nullptr;
     bf16_t* bias = nullptr;
+    bool fp8 = false;          // decoder weights quantised to e4m3 at load (sv_config.weight_dtype = 1)
+    uint8_t* Wq = nullptr;     //   decode image (launch_pack_weight_fp8); Wp then holds the SAME q values as bf16
+    float* wscale = nullptr;   //   per-output-row scale [Npad]
     int N = 0, K = 0, Npad = 0, Kpad = 0;
     int splitk = 1;       // decode-path split-K factor (slab pipeline)
     int splitk_fused = 1; // decode-path split-K factor (fused pipeline: ticket merge)
@@ -357,7 +360,7 @@ extern "C" void sv_config_default_1b(sv_config* c) {
     c->vocab = 49156; c->n_positions = 8192; c->max_batch = 32; c->max_seq_len = 2048; c->ln_eps = 1e-5f;
     c->device = 0;
     c->arch = SV_ARCH_V1; c->n_kv_head = 1; c->rope_theta = 0.f; c->vit_mlp = 4096; c->vit_eps = 1e-5f;
-    c->sliding_window = 0;
+    c->sliding_window = 0; c->weight_dtype = SV_WEIGHT_BF16;
 }
 
 extern "C" void sv_config_default_8b(sv_config* c) {
@@ -367,7 +370,7 @@ extern "C" void sv_config_default_8b(sv_config* c) {
     c->vocab = 49152 + 5; c->n_positions = 16384; c->max_batch = 16; c->max_seq_len = 4096; c->ln_eps = 1e-5f;
     c->device = 0;
     c->arch = SV_ARCH_V2; c->n_kv_head = 4; c->rope_theta = 1e6f; c->vit_mlp = 4096; c->vit_eps = 1e-6f;
-    c->sliding_window = 4096;
+    c->sliding_window = 4096; c->weight_dtype = SV_WEIGHT_BF16;
 }
 
 extern "C" int sv_destroy(sv_engine* e) {
@@ -401,6 +404,8 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     if (c.n_head / nkv > 16) return fail(SV_EINVAL, "decode attention supports <= 16 query heads per KV head");
     if (c.vit_width % 64 || c.hidden % 64 || c.n_inner % 64) return fail(SV_EINVAL, "dims must be multiples of 64");
     if (v2 && (c.vit_mlp < 64 || c.vit_mlp % 64 || !(c.rope_theta > 1.f))) return fail(SV_EINVAL, "bad vit_mlp / rope_theta");
+    if (c.weight_dtype != SV_WEIGHT_BF16 && c.weight_dtype != SV_WEIGHT_FP8_E4M3)
+        return fail(SV_EINVAL, "weight_dtype must be SV_WEIGHT_BF16 (0) or SV_WEIGHT_FP8_E4M3 (1)");
     if (c.sliding_window < 0 || (!v2 && c.sliding_window != 0))
         return fail(SV_EINVAL, "sliding_window must be >= 0 (and 0 for the GPTBigCode decoder)");
     if (c.max_batch < 1 || c.max_seq_len < 2 || c.max_seq_len > c.n_positions)
@@ -486,6 +491,25 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     }
     reg_ln(e, pd + "ln_f.", &e->ln_f, D);
     }   // v1 registration
+
+    if (c.weight_dtype == SV_WEIGHT_FP8_E4M3) {
+        // decoder Linears + lm_head stream as fp8 at decode time; the fp8 kernel covers the slab pipeline only
+        e->lm_head.fp8 = true;
+        for (DecLayer& L : e->dec) {
+            Linear* ls[4] = {&L.c_attn, &L.c_proj, &L.c_fc, &L.c_proj2};
+            for (Linear* l : ls) {
+                l->fp8 = true;
+                // the fp8 kernel wants an even number (>= 2 per wave pair) of k-steps per wave: shrink split-K until it fits
+                const int KS = l->Kpad / 16;
+                while (l->splitk > 1 && (KS % l->splitk != 0 || (KS / l->splitk) % 4 != 0)) --l->splitk;
+                if (((l->Kpad / 16) / l->splitk) % 4 != 0) {
+                    const int code = fail(SV_ENOTSUP, "fp8 weights: K=%d with split-K %d has no fp8 decode kernel", l->Kpad, l->splitk);
+                    sv_destroy(e);
+                    return code;
+                }
+            }
+        }
+    }
 
     // ---- workspaces ----
     int rc = 0;
@@ -586,6 +610,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     if (2 * c.n_layer + 1 > 64) e->overlap = 0;
     e->fused_decode = getenv("SV_DECODE_FUSED") != nullptr && atoi(getenv("SV_DECODE_FUSED")) != 0;
     if (v2) e->fused_decode = false;       // the alternative pipelines are v1-only experiments
+    if (c.weight_dtype == SV_WEIGHT_FP8_E4M3) { e->fused_decode = false; e->overlap = 0; }
     if (rc) { sv_destroy(e); return rc; }
     *out = e;
     return 0;
@@ -613,7 +638,17 @@ extern "C" int sv_load_weight(sv_engine* e, const char* name, const void* dev_pt
     if (s.kind == SLOT_LINEAR_W || s.kind == SLOT_WTE) {
         Linear* l = s.kind == SLOT_WTE ? &e->lm_head : s.lin;
         const bool pack = !(s.kind == SLOT_WTE && e->lm_head_explicit);
-        if (pack) {
+        if (pack && l->fp8) {
+            // e4m3 weight-only quantisation: fp8 image for the decode kernels, bf16 image of the same values for the big-M ones
+            if (!l->Wp) SVCHECK(dalloc(e, &l->Wp, (size_t)l->Npad * l->Kpad, s.part_rows != 0));
+            if (!l->Wq) SVCHECK(dalloc(e, &l->Wq, (size_t)l->Npad * l->Kpad, s.part_rows != 0));
+            if (!l->wscale) SVCHECK(dalloc(e, &l->wscale, (size_t)l->Npad, true));
+            const int roff = s.part_rows ? s.row_off : 0, rows = s.part_rows ? s.part_rows : l->N;
+            if (roff % 32) return fail(SV_EINVAL, "weight '%s': part offset %d is not a multiple of 32", name, roff);
+            const size_t tile0 = (size_t)(roff / 32) * (l->Kpad / 16);
+            launch_pack_weight_fp8(dev_ptr, is_f32, l->Wp + tile0 * 512, l->Wq + tile0 * 512, l->wscale + roff, rows, l->K,
+                                   round_up(rows, 32), l->Kpad, st);
+        } else if (pack) {
             if (!l->Wp) SVCHECK(dalloc(e, &l->Wp, (size_t)l->Npad * l->Kpad, s.part_rows != 0));
             if (s.part_rows) {
                 // one part of a fused projection: rows [row_off, row_off + part_rows), tile aligned
@@ -659,6 +694,7 @@ static void gemm(const bf16_t* A, int lda, const Linear& l, const bf16_t* R, int
     GemmArgs g;
     g.A = A; g.lda = lda; g.Wp = l.Wp; g.bias = l.bias; g.R = R; g.ldr = ldr; g.C = C; g.ldc = ldc;
     g.M = M; g.N = l.N; g.K = l.Kpad; g.act = act; g.out_f32 = out_f32;
+    g.cscale = l.fp8 ? l.wscale : nullptr;
     launch_gemm(g, st);
 }
 
@@ -667,7 +703,7 @@ static void decode_gemm(sv_engine* e, const bf16_t* xp, const Linear& l, const L
                         hipStream_t st) {
     SkinnyArgs a;
     memset(&a, 0, sizeof(a));
-    a.xp = xp; a.Wp = l.Wp; a.bias = l.bias; a.MT = MT; a.Npad = l.Npad; a.K = l.Kpad; a.splitk = l.splitk_fused;
+    a.xp = xp; a.Wp = l.Wp; a.Wq = l.Wq; a.wscale = l.wscale; a.bias = l.bias; a.MT = MT; a.Npad = l.Npad; a.K = l.Kpad; a.splitk = l.splitk_fused;
     a.out_mode = out_mode; a.act = act; a.N = l.N;
     if (ln) { a.ln_stats = e->ln_stats; a.ln_tiles = l.Kpad / 32; a.ln_g = ln->g; a.ln_b = ln->b; a.ln_eps = e->cfg.ln_eps; }
     a.ws = e->ws; a.ldws = e->ldws; a.counters = e->sk_cnt;
@@ -760,7 +796,7 @@ static int assign_pages(sv_engine* e, int B, int total_len, hipStream_t st) {
 static void lm_head_logits(sv_engine* e, int MT, const bf16_t* xp, const LNp* ln, hipStream_t st) {
     SkinnyArgs a;
     memset(&a, 0, sizeof(a));
-    a.xp = xp; a.Wp = e->lm_head.Wp; a.MT = MT; a.Npad = e->lm_head.Npad; a.K = e->lm_head.Kpad;
+    a.xp = xp; a.Wp = e->lm_head.Wp; a.Wq = e->lm_head.Wq; a.wscale = e->lm_head.wscale; a.MT = MT; a.Npad = e->lm_head.Npad; a.K = e->lm_head.Kpad;
     a.splitk = 1; a.out_mode = SK_OUT_F32; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1;
     a.N = e->lm_head.N;
     if (ln) { a.ln_stats = e->ln_stats; a.ln_tiles = e->lm_head.Kpad / 32; a.ln_g = ln->g; a.ln_b = ln->b; a.ln_eps = e->cfg.ln_eps; }
@@ -899,7 +935,7 @@ static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
         {   // c_attn (+ the row update that produces its input: embedding or previous layer's down-proj)
             SkinnyArgs a;
             memset(&a, 0, sizeof(a));
-            a.xp = e->xp_a; a.Wp = L.c_attn.Wp; a.MT = MT; a.Npad = L.c_attn.Npad; a.K = L.c_attn.Kpad;
+            a.xp = e->xp_a; a.Wp = L.c_attn.Wp; a.Wq = L.c_attn.Wq; a.wscale = L.c_attn.wscale; a.MT = MT; a.Npad = L.c_attn.Npad; a.K = L.c_attn.Kpad;
             a.splitk = L.c_attn.splitk; a.out_mode = SK_OUT_PARTIAL; a.ws = wsA; a.ldws = e->ldws; a.N = L.c_attn.N;
             attach(a);
             prof_mark(e, PK_SKINNY, st);
@@ -919,7 +955,7 @@ static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
         {   // attention output projection -> slabs
             SkinnyArgs a;
             memset(&a, 0, sizeof(a));
-            a.xp = e->xp_attn; a.Wp = L.c_proj.Wp; a.MT = MT; a.Npad = L.c_proj.Npad; a.K = L.c_proj.Kpad;
+            a.xp = e->xp_attn; a.Wp = L.c_proj.Wp; a.Wq = L.c_proj.Wq; a.wscale = L.c_proj.wscale; a.MT = MT; a.Npad = L.c_proj.Npad; a.K = L.c_proj.Kpad;
             a.splitk = L.c_proj.splitk; a.out_mode = SK_OUT_PARTIAL; a.ws = wsB; a.ldws = e->ldws; a.N = L.c_proj.N;
             prof_mark(e, PK_SKINNY, st);
             launch_gemm_skinny(a, st);
@@ -928,7 +964,7 @@ static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
         {   // c_fc (+ row update: bias, residual, LN2), GELU epilogue
             SkinnyArgs a;
             memset(&a, 0, sizeof(a));
-            a.xp = e->xp_a; a.Wp = L.c_fc.Wp; a.bias = L.c_fc.bias; a.MT = MT; a.Npad = L.c_fc.Npad; a.K = L.c_fc.Kpad;
+            a.xp = e->xp_a; a.Wp = L.c_fc.Wp; a.Wq = L.c_fc.Wq; a.wscale = L.c_fc.wscale; a.bias = L.c_fc.bias; a.MT = MT; a.Npad = L.c_fc.Npad; a.K = L.c_fc.Kpad;
             a.splitk = 1; a.out_mode = SK_OUT_PACKED_ACT; a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16;
             a.N = L.c_fc.N;
             attach(a);
@@ -938,7 +974,7 @@ static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
         {   // down projection -> slabs
             SkinnyArgs a;
             memset(&a, 0, sizeof(a));
-            a.xp = e->xp_mlp; a.Wp = L.c_proj2.Wp; a.MT = MT; a.Npad = L.c_proj2.Npad; a.K = L.c_proj2.Kpad;
+            a.xp = e->xp_mlp; a.Wp = L.c_proj2.Wp; a.Wq = L.c_proj2.Wq; a.wscale = L.c_proj2.wscale; a.MT = MT; a.Npad = L.c_proj2.Npad; a.K = L.c_proj2.Kpad;
             a.splitk = L.c_proj2.splitk; a.out_mode = SK_OUT_PARTIAL; a.ws = wsB; a.ldws = e->ldws; a.N = L.c_proj2.N;
             prof_mark(e, PK_SKINNY, st);
             launch_gemm_skinny(a, st);
@@ -949,7 +985,7 @@ static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
     {   // lm_head (+ the last row update: bias, residual, ln_f)
         SkinnyArgs a;
         memset(&a, 0, sizeof(a));
-        a.xp = e->xp_a; a.Wp = e->lm_head.Wp; a.MT = MT; a.Npad = e->lm_head.Npad; a.K = e->lm_head.Kpad;
+        a.xp = e->xp_a; a.Wp = e->lm_head.Wp; a.Wq = e->lm_head.Wq; a.wscale = e->lm_head.wscale; a.MT = MT; a.Npad = e->lm_head.Npad; a.K = e->lm_head.Kpad;
         a.splitk = 1; a.out_mode = SK_OUT_F32; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1;
         a.N = e->lm_head.N;
         attach(a);
@@ -1636,6 +1672,39 @@ extern "C" int sv_op_linear_skinny(const void* x, const void* W, const void* bia
     launch_gemm_skinny(a, st);
     reduce_partials_kernel<<<(M * N + 255) / 256, 256, 0, st>>>(ws, splitk, MT * 32, Npad, (const bf16_t*)bias,
                                                                  (float*)y_f32, M, N);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// the fp8-weight decode GEMM on its own: W [N][K] bf16 is quantised like sv_load_weight does it with weight_dtype = fp8
+// (one e4m3 scale per row), y = x . dequant(quant(W))^T + bias in fp32; scale_out [N] (optional) returns the row scales
+extern "C" int sv_op_linear_skinny_fp8(const void* x, const void* W, const void* bias, void* y_f32, float* scale_out,
+                                       int32_t M, int32_t N, int32_t K, int32_t splitk, sv_stream stream) {
+    if (!x || !W || !y_f32 || M < 1 || N < 1 || K < 64 || K % 64 || splitk < 1 || (K / 16) % splitk || ((K / 16) / splitk) % 4)
+        return fail(SV_EINVAL, "sv_op_linear_skinny_fp8: bad argument (K %% 64 == 0 and (K/16/splitk) %% 4 == 0 required)");
+    hipStream_t st = (hipStream_t)stream;
+    TmpBufs tmp;
+    const int Npad = round_up(N, 32), MT = (M + 31) / 32;
+    bf16_t *Wp, *xp;
+    uint8_t* Wq;
+    float *ws, *sc;
+    SVCHECK(tmp.get(&Wp, (size_t)Npad * K));
+    SVCHECK(tmp.get(&Wq, (size_t)Npad * K));
+    SVCHECK(tmp.get(&sc, (size_t)Npad));
+    SVCHECK(tmp.get(&xp, (size_t)MT * 32 * K));
+    SVCHECK(tmp.get(&ws, (size_t)splitk * MT * 32 * Npad));
+    HIPCHECK(hipMemsetAsync(xp, 0, (size_t)MT * 32 * K * 2, st));
+    launch_pack_weight_fp8(W, 0, Wp, Wq, sc, N, K, Npad, K, st);
+    pack_rows_kernel<<<(M * (K / 8) + 255) / 256, 256, 0, st>>>((const bf16_t*)x, K, xp, M, K);
+    SkinnyArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xp = xp; a.Wp = Wp; a.Wq = Wq; a.wscale = sc; a.MT = MT; a.Npad = Npad; a.K = K; a.splitk = splitk;
+    a.out_mode = SK_OUT_PARTIAL; a.ws = ws; a.ldws = Npad; a.N = N;
+    launch_gemm_skinny(a, st);
+    reduce_partials_kernel<<<(M * N + 255) / 256, 256, 0, st>>>(ws, splitk, MT * 32, Npad, (const bf16_t*)bias,
+                                                                 (float*)y_f32, M, N);
+    if (scale_out) HIPCHECK(hipMemcpyAsync(scale_out, sc, (size_t)N * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(st));
     return 0;

@@ -79,6 +79,83 @@ void launch_convert_to_bf16(const void* src, int src_is_f32, bf16_t* dst, size_t
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp8 (OCP e4m3) weight-only quantisation at load time (BASELINE config 5: fp8 weights).  One scale per output row.
+// ------------------------------------------------------------------------------------------------
+template <typename SrcT>
+__device__ __forceinline__ float ld_as_f32(const SrcT* p) {
+    if constexpr (sizeof(SrcT) == 4) return (float)*p;
+    else return bf2f((bf16_t)*p);
+}
+template <typename SrcT>
+__global__ __launch_bounds__(256) void fp8_row_scale_kernel(const SrcT* __restrict__ src, float* __restrict__ scale, int N,
+                                                            int K, int Npad) {
+    __shared__ float red[4];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    float m = 0.f;
+    if (n < N)
+        for (int k = tid; k < K; k += 256) m = fmaxf(m, fabsf(ld_as_f32(src + (size_t)n * K + k)));
+    m = wave_max(m);
+    if ((tid & 63) == 0) red[tid >> 6] = m;
+    __syncthreads();
+    if (tid == 0) {
+        m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        scale[n] = m > 0.f ? m / 448.0f : 1.0f;             // e4m3 max normal = 448
+    }
+}
+// one thread = one lane's 16 fp8 bytes (two k-steps) of one (n-tile, k-step pair)
+template <typename SrcT>
+__global__ void pack_weight_fp8_kernel(const SrcT* __restrict__ src, const float* __restrict__ scale, bf16_t* __restrict__ dst_bf16,
+                                       uint8_t* __restrict__ dst_q, int N, int K, int Npad, int Kpad) {
+    const int KS = Kpad >> 4, KS2 = KS >> 1;
+    const size_t total = (size_t)(Npad >> 5) * KS2 * 64;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int lane = (int)(i & 63);
+        const size_t t = i >> 6;
+        const int ks2 = (int)(t % KS2), nt = (int)(t / KS2);
+        const int n = nt * 32 + (lane & 31);
+        const float sc = n < N ? scale[n] : 1.0f;
+        uint32_t words[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ks = 2 * ks2 + h;
+            float f[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 16 * ks + 8 * (lane >> 5) + e;
+                f[e] = (n < N && k < K) ? ld_as_f32(src + (size_t)n * K + k) / sc : 0.f;
+            }
+            int w0 = 0, w1 = 0;
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], w0, false);
+            w0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], w0, true);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], w1, false);
+            w1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], w1, true);
+            words[2 * h] = (uint32_t)w0;
+            words[2 * h + 1] = (uint32_t)w1;
+            // the same values as bf16 (exact: 3 mantissa bits) for the big-M kernels
+            float q[8];
+            const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8(w0, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8(w0, true);
+            const f32x2 a2 = __builtin_amdgcn_cvt_pk_f32_fp8(w1, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8(w1, true);
+            q[0] = a0[0]; q[1] = a0[1]; q[2] = a1[0]; q[3] = a1[1]; q[4] = a2[0]; q[5] = a2[1]; q[6] = a3[0]; q[7] = a3[1];
+            *reinterpret_cast<uint4*>(dst_bf16 + (((size_t)nt * KS + ks) * 64 + lane) * 8) = pack8(q);
+        }
+        *reinterpret_cast<uint4*>(dst_q + (((size_t)nt * KS2 + ks2) * 64 + lane) * 16) = make_uint4(words[0], words[1], words[2], words[3]);
+    }
+}
+void launch_pack_weight_fp8(const void* src, int src_is_f32, bf16_t* dst_bf16, uint8_t* dst_q, float* scale, int N, int K,
+                            int Npad, int Kpad, hipStream_t st) {
+    const size_t total = (size_t)(Npad / 32) * (Kpad / 32) * 64;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 16384) blocks = 16384;
+    if (src_is_f32) {
+        fp8_row_scale_kernel<float><<<Npad, 256, 0, st>>>((const float*)src, scale, N, K, Npad);
+        pack_weight_fp8_kernel<float><<<blocks, 256, 0, st>>>((const float*)src, scale, dst_bf16, dst_q, N, K, Npad, Kpad);
+    } else {
+        fp8_row_scale_kernel<bf16_t><<<Npad, 256, 0, st>>>((const bf16_t*)src, scale, N, K, Npad);
+        pack_weight_fp8_kernel<bf16_t><<<blocks, 256, 0, st>>>((const bf16_t*)src, scale, dst_bf16, dst_q, N, K, Npad, Kpad);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // big-M GEMM
 // ------------------------------------------------------------------------------------------------
 #define GB_M 128
@@ -205,10 +282,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
                 const int n = n0 + wn * 64 + nt * 32 + rg * 8 + half * 4;
                 const float bj[4] = {__uint_as_float(bq[nt][rg].x << 16), __uint_as_float(bq[nt][rg].x & 0xffff0000u),
                                      __uint_as_float(bq[nt][rg].y << 16), __uint_as_float(bq[nt][rg].y & 0xffff0000u)};
+                const float4 c4 = (p.cscale && n < p.N) ? *reinterpret_cast<const float4*>(p.cscale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+                const float cs[4] = {c4.x, c4.y, c4.z, c4.w};
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float x = acc[nt][mt][rg * 4 + e] + bj[e];
+                    float x = acc[nt][mt][rg * 4 + e] * cs[e] + bj[e];
                     if (p.act != ACT_NONE) x = sv_act(bfround(x), p.act);
                     v[e] = x;
                 }
@@ -428,10 +507,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p, int tiles_m, i
                 const int n = n0 + wc * 64 + j * 32 + rg * 8 + half * 4;
                 const float bj[4] = {__uint_as_float(bq[j][rg].x << 16), __uint_as_float(bq[j][rg].x & 0xffff0000u),
                                      __uint_as_float(bq[j][rg].y << 16), __uint_as_float(bq[j][rg].y & 0xffff0000u)};
+                const float4 c4 = (p.cscale && n < p.N) ? *reinterpret_cast<const float4*>(p.cscale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+                const float cs[4] = {c4.x, c4.y, c4.z, c4.w};
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float x = acc[j][mt][rg * 4 + e] + bj[e];
+                    float x = acc[j][mt][rg * 4 + e] * cs[e] + bj[e];
                     if (p.act != ACT_NONE) x = sv_act(bfround(x), p.act);
                     v[e] = x;
                 }
@@ -539,10 +620,12 @@ __global__ __launch_bounds__(64) void gemm_tail_kernel(GemmArgs p) {
         if (n >= p.N) continue;       // N % 4 == 0
         const float bj[4] = {__uint_as_float(bq[rg].x << 16), __uint_as_float(bq[rg].x & 0xffff0000u),
                              __uint_as_float(bq[rg].y << 16), __uint_as_float(bq[rg].y & 0xffff0000u)};
+        const float4 c4 = p.cscale ? *reinterpret_cast<const float4*>(p.cscale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float cs[4] = {c4.x, c4.y, c4.z, c4.w};
         float v[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float x = acc[rg * 4 + e] + bj[e];
+            float x = acc[rg * 4 + e] * cs[e] + bj[e];
             if (p.act != ACT_NONE) x = sv_act(bfround(x), p.act);
             v[e] = x;
         }
@@ -1149,7 +1232,162 @@ static void launch_sk(const SkinnyArgs& a, dim3 grid, hipStream_t st) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// skinny GEMM with fp8 (e4m3) weights: the decode step's weight stream at half the bytes.  Same structure as the slab
+// pipeline's bf16 kernel (K split over the waves of a block and over `splitk` blocks, all waves share the epilogue),
+// restricted to what that pipeline uses: fp32 slabs, packed activations with bias + activation, fp32 logits.
+// A lane's 16 B load holds two k-steps of 8 fp8 each; they are widened to bf16 in registers (exact: e4m3 has 3 mantissa
+// bits) and fed to the same bf16 MFMA, so activations and accumulation are untouched; the per-column scale multiplies the
+// fp32 accumulator before the cross-wave reduction.  8 k-steps per register chunk keep as many bytes in flight per wave
+// as the bf16 kernel has (one CU streams ~25 GB/s whatever the element size: it is the bytes in flight that count).
+// ------------------------------------------------------------------------------------------------
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_fp8_kernel(SkinnyArgs p) {
+    constexpr int CH = 8;
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(sk_smem);          // [WAVES][16][64]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = blockIdx.x, split = blockIdx.y, mt = blockIdx.z;
+    const int KS = p.K >> 4;
+    const int ks_per_split = KS / p.splitk;
+    const int ks_per_wave = ks_per_split / WAVES;          // even (launcher)
+    const int ks0 = split * ks_per_split + wave * ks_per_wave;
+    const int m = lane & 31, half = lane >> 5;
+
+    const u32x4* wq = reinterpret_cast<const u32x4*>(p.Wq) + ((size_t)nt * (KS >> 1) + (ks0 >> 1)) * 64 + lane;
+    const u32x4* xptr = reinterpret_cast<const u32x4*>(p.xp) + ((size_t)mt * KS + ks0) * 64 + lane;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float4 sc4[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) sc4[rg] = *reinterpret_cast<const float4*>(p.wscale + nt * 32 + rg * 8 + half * 4);
+
+    constexpr int RPW = 16 / WAVES;                       // WAVES in {2, 4, 8}
+    float bias_d[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        bias_d[i] = 0.f;
+        if (p.out_mode == SK_OUT_PACKED_ACT && p.bias) {
+            const int r = wave * RPW + i;
+            const int n = nt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+            if (n < p.N) bias_d[i] = bf2f(p.bias[n]);
+        }
+    }
+
+    struct Chunk { u32x4 w[CH / 2]; u32x4 x[CH]; };
+    Chunk ca, cb;
+    auto load = [&](Chunk& c, int ks) {
+#pragma unroll
+        for (int u2 = 0; u2 < CH / 2; ++u2)
+            if (ks + 2 * u2 < ks_per_wave) c.w[u2] = __builtin_nontemporal_load(wq + (size_t)((ks >> 1) + u2) * 64);
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+            if (ks + u < ks_per_wave) c.x[u] = xptr[(size_t)(ks + u) * 64];
+    };
+    auto compute = [&](Chunk& c, int ks) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            if (ks + u < ks_per_wave) {
+                const uint32_t lo = c.w[u >> 1][(u & 1) * 2], hi = c.w[u >> 1][(u & 1) * 2 + 1];
+                const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
+                const f32x2 a2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
+                u32x4 wf;
+                wf[0] = (__float_as_uint(a0[0]) >> 16) | (__float_as_uint(a0[1]) & 0xffff0000u);
+                wf[1] = (__float_as_uint(a1[0]) >> 16) | (__float_as_uint(a1[1]) & 0xffff0000u);
+                wf[2] = (__float_as_uint(a2[0]) >> 16) | (__float_as_uint(a2[1]) & 0xffff0000u);
+                wf[3] = (__float_as_uint(a3[0]) >> 16) | (__float_as_uint(a3[1]) & 0xffff0000u);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wf), as_frag4(c.x[u]), acc, 0, 0, 0);
+            }
+        }
+    };
+    load(ca, 0);
+    if (CH < ks_per_wave) load(cb, CH);
+    for (int ks = 0; ks < ks_per_wave; ks += 2 * CH) {
+        compute(ca, ks);
+        if (ks + 2 * CH < ks_per_wave) load(ca, ks + 2 * CH);
+        if (ks + CH < ks_per_wave) compute(cb, ks + CH);
+        if (ks + 3 * CH < ks_per_wave) load(cb, ks + 3 * CH);
+    }
+    // per-column scale (accumulator row r <-> column 8 (r >> 2) + 4 half + (r & 3)), then the K reduction across waves
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) {
+        acc[rg * 4 + 0] *= sc4[rg].x; acc[rg * 4 + 1] *= sc4[rg].y; acc[rg * 4 + 2] *= sc4[rg].z; acc[rg * 4 + 3] *= sc4[rg].w;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    float v[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = wave * RPW + i;
+        float t = red[0][r][lane];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) t += red[w][r][lane];
+        v[i] = t;
+    }
+    const int r0 = wave * RPW;
+    const int n0 = nt * 32 + 8 * (r0 >> 2) + 4 * half + (r0 & 3);       // RPW consecutive columns (two groups of 4 when RPW = 8)
+    auto store_f32 = [&](float* dst) {
+        if constexpr (RPW == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        else if constexpr (RPW == 2) *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
+        else {
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) dst[i + (i >> 2) * 4] = v[i];
+        }
+    };
+    // (two separate branches on purpose: written as one store through `cond ? ws + .. : out_f32 + ..` hipcc 7.2 kept the
+    //  out_f32 base register for both arms in this kernel and the slab store went to a null pointer)
+    if (p.out_mode == SK_OUT_PARTIAL) {
+        store_f32(p.ws + ((size_t)split * p.MT * 32 + mt * 32 + m) * p.ldws + n0);
+    } else if (p.out_mode == SK_OUT_F32) {
+        if (p.round_bf16) {
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) v[i] = bfround(v[i]);
+        }
+        store_f32(p.out_f32 + ((size_t)mt * 32 + m) * p.ldo + n0);
+    } else {   // SK_OUT_PACKED_ACT
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            float x = 0.f;
+            if (n0 + i + (i >> 2) * 4 < p.N) {
+                x = bfround(v[i] + bias_d[i]);
+                if (p.act != ACT_NONE) x = sv_act(x, p.act);
+            }
+            v[i] = x;
+        }
+        bf16_t* dst = p.out_xp + xp_index(mt, p.out_KS, m, n0);
+        if constexpr (RPW == 4) {
+            uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+            *reinterpret_cast<uint2*>(dst) = o;
+        } else if constexpr (RPW == 2) {
+            *reinterpret_cast<uint32_t*>(dst) = pack2bf(v[0], v[1]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) p.out_xp[xp_index(mt, p.out_KS, m, n0 + i + (i >> 2) * 4)] = f2bf(v[i]);
+        }
+    }
+}
+
+// returns false when the shape / mode has no fp8 variant (the caller reports it)
+static bool launch_gemm_skinny_fp8(const SkinnyArgs& a, hipStream_t st) {
+    if (a.ln_stats || a.ru_M > 0) return false;
+    if (!(a.out_mode == SK_OUT_PARTIAL || ((a.out_mode == SK_OUT_PACKED_ACT || a.out_mode == SK_OUT_F32) && a.splitk == 1)))
+        return false;
+    const dim3 grid(a.Npad / 32, a.splitk, a.MT);
+    const int per_split = (a.K / 16) / a.splitk;
+    if (per_split % 16 == 0) gemm_skinny_fp8_kernel<8><<<grid, 512, 8 * 16 * 64 * 4, st>>>(a);
+    else if (per_split % 8 == 0) gemm_skinny_fp8_kernel<4><<<grid, 256, 4 * 16 * 64 * 4, st>>>(a);
+    else if (per_split % 4 == 0) gemm_skinny_fp8_kernel<2><<<grid, 128, 2 * 16 * 64 * 4, st>>>(a);
+    else return false;
+    return true;
+}
+
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st) {
+    if (a.Wq && launch_gemm_skinny_fp8(a, st)) return;       // fp8 weights: its own kernel (falls through if unsupported)
     dim3 grid(a.Npad / 32, a.splitk, a.MT);
     const int KS = a.K / 16;
     const int per_split = KS / a.splitk;

@@ -13,6 +13,12 @@ inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 void launch_pack_weight(const void* src, int src_is_f32, bf16_t* dst, int N, int K, int Npad, int Kpad,
                         hipStream_t st);
 void launch_convert_to_bf16(const void* src, int src_is_f32, bf16_t* dst, size_t n, hipStream_t st);
+// fp8 (OCP e4m3) weight-only quantisation, one scale per output row: scale[n] = max_k |W[n][k]| / 448,
+// q = fp8_rne(W / scale).  Writes the decode image Wq [Npad/32][Kpad/32][64 lanes][16 B] (a lane's two consecutive
+// k-steps of 8 fp8 each), the bf16 image of the SAME q values in the usual packed layout (prefill / big-M kernels, which
+// apply the scale in their epilogue like the decode kernel does), and scale[Npad] (1 for padding rows).
+void launch_pack_weight_fp8(const void* src, int src_is_f32, bf16_t* dst_bf16, uint8_t* dst_q, float* scale, int N, int K,
+                            int Npad, int Kpad, hipStream_t st);
 
 // ---- big-M MFMA GEMM:  C[M][N] = epi( A[M][K] . W^T + bias ) (+ residual) ----------------------
 struct GemmArgs {
@@ -23,6 +29,7 @@ struct GemmArgs {
     void* C; int ldc;                // bf16 (out_f32==0) or float
     int M, N, K;                     // K = padded K (multiple of 64) shared by A and Wp
     int act; int out_f32;
+    const float* cscale = nullptr;   // fp8 weights: per-output-column scale applied to the accumulator (or nullptr)
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 
@@ -31,6 +38,8 @@ enum { SK_OUT_PARTIAL = 0, SK_OUT_PACKED_ACT = 1, SK_OUT_F32 = 2, SK_OUT_RESID =
 struct SkinnyArgs {
     const bf16_t* xp;                // packed activations [MT][K/16][64][8] (the raw residual stream h when ln_stats)
     const bf16_t* Wp;                // packed weight [Npad/32][K/16][64][8]
+    const uint8_t* Wq;               // fp8 image of the same weight (launch_pack_weight_fp8) or nullptr: then the fp8 kernel runs
+    const float* wscale;             //   with its per-column scales [Npad]
     const bf16_t* bias;              // [N] or nullptr
     int MT;                          // number of 32-row tiles
     int Npad, K;                     // Npad multiple of 32, K multiple of 16

@@ -36,6 +36,7 @@ class EngineConfig:
     vit_mlp: int = 4096
     vit_eps: float = 1e-6
     sliding_window: int = 0          # v2: keys visible to a query (4096 for bigcode/starcoder2-7b); 0 = all
+    weight_dtype: str = "bf16"       # "fp8_e4m3": decoder weights + lm_head quantised at load (per-row scales), BASELINE config 5
 
     @property
     def query_length(self) -> int:
@@ -81,7 +82,8 @@ class HipEngine:
                      cfg.max_batch, cfg.max_seq_len, cfg.ln_eps, self.device,
                      _lib.SV_ARCH_V2 if cfg.arch == "v2" else _lib.SV_ARCH_V1, cfg.n_kv_head, cfg.rope_theta,
                      cfg.vit_mlp, cfg.vit_eps if cfg.arch == "v2" else cfg.ln_eps,
-                     int(cfg.sliding_window) if cfg.arch == "v2" else 0)
+                     int(cfg.sliding_window) if cfg.arch == "v2" else 0,
+                     {"bf16": 0, "fp8_e4m3": 1}[cfg.weight_dtype])
         h = C.c_void_p()
         check(self.lib.sv_create(C.byref(c), C.byref(h)), "sv_create")
         self._h = h
@@ -335,6 +337,18 @@ def op_linear_skinny(x, W, bias=None, splitk=1):
     b = _need(bias, torch.bfloat16, "bias") if bias is not None else None
     check(lib.sv_op_linear_skinny(_ptr(x), _ptr(W), _ptr(b), _ptr(y), M, N, K, splitk, _stream()))
     return y
+
+
+def op_linear_skinny_fp8(x, W, bias=None, splitk=1):
+    """Returns (y fp32 [M, N], row scales fp32 [N]) of the fp8-weight decode GEMM (weights quantised on device)."""
+    lib = _lib.load()
+    x = _need(x, torch.bfloat16, "x"); W = _need(W, torch.bfloat16, "W")
+    M, K = x.shape; N = W.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    sc = torch.empty(N, dtype=torch.float32, device=x.device)
+    b = _need(bias, torch.bfloat16, "bias") if bias is not None else None
+    check(lib.sv_op_linear_skinny_fp8(_ptr(x), _ptr(W), _ptr(b), _ptr(y), _ptr(sc), M, N, K, splitk, _stream()))
+    return y, sc
 
 
 def op_decode_linear(h, W, bias=None, gamma=None, beta=None, residual=None, act="none", splitk=1, eps=1e-5):

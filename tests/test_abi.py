@@ -37,7 +37,7 @@ def test_binding_matches_header(lib):
 
 def test_struct_layouts():
     from starvector_amd._lib import SvConfig, SvSampling
-    assert C.sizeof(SvConfig) == 22 * 4
+    assert C.sizeof(SvConfig) == 23 * 4
     assert SvSampling.stop_ids.offset % 8 == 0 and SvSampling.seed.offset % 8 == 0
 
 
