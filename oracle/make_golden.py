@@ -437,6 +437,45 @@ def run_forward_case(write):
         print("  wrote tests/golden/tiny_forward.safetensors")
 
 
+def run_padding_case():
+    """Padded prompts (text2svg with captions of different lengths): HF masks the padded keys and numbers positions by
+    cumsum(attention_mask), so generating a padded batch equals generating every row alone with its padding removed --
+    for left padding (the v2 tokenizer, llm/starcoder2.py:53), for right padding before the trigger token (the v1 default),
+    GPTBigCode and StarCoder2.  The mirror relies on this to serve padded batches group by group (model.py::_generate_padded)."""
+    def run(lm, wte, cfg, side):
+        lens, n_new = [5, 9, 7], 10
+        S, B = max(lens) + 1, len(lens)
+        g = torch.Generator().manual_seed(3)
+        ids = [torch.randint(1, 500, (n,), generator=g) for n in lens]
+        trig = torch.tensor([501])
+        full = torch.zeros(B, S, dtype=torch.long)
+        mask = torch.zeros(B, S, dtype=torch.long)
+        for b, t in enumerate(ids):
+            n = len(t)
+            if side == "left":
+                full[b, S - 1 - n:S - 1] = t
+                mask[b, S - 1 - n:] = 1
+            else:
+                full[b, :n] = t
+                mask[b, :n] = 1
+                mask[b, S - 1] = 1
+            full[b, S - 1] = trig
+        kw = dict(do_sample=False, num_beams=1, max_length=S + n_new, use_cache=True, pad_token_id=0, eos_token_id=None)
+        ref = lm.generate(inputs_embeds=wte(full), attention_mask=mask, **kw)
+        for b, t in enumerate(ids):
+            e = wte(torch.cat([t, trig])[None])
+            solo = lm.generate(inputs_embeds=e, attention_mask=torch.ones(1, e.shape[1], dtype=torch.long), **kw)
+            assert torch.equal(ref[b, :n_new], solo[0, :n_new]), (side, b)
+    cfg = O.OracleConfig.tiny()
+    _, _, _, lm = build_reference(cfg, O.make_weights(cfg, seed=5))
+    run(lm, lm.transformer.wte, cfg, "left")
+    run(lm, lm.transformer.wte, cfg, "right")
+    cfg2 = O.OracleConfig.tiny_v2()
+    _, _, lm2 = build_reference_v2(cfg2, O.make_weights(cfg2, seed=5))
+    run(lm2, lm2.model.embed_tokens, cfg2, "left")
+    print("[padding] HF generate on a padded batch == every row alone without its padding (GPTBigCode left/right, StarCoder2 left)")
+
+
 def main():
     write = "--no-write" not in sys.argv
     torch.manual_seed(0)
@@ -450,6 +489,7 @@ def main():
     run_beam_cases(write)
     run_sampling_cases(write)
     run_forward_case(write)
+    run_padding_case()
     run_case_v2("tiny_v2_b2", O.OracleConfig.tiny_v2(), seed=2024, batch=2, n_new=12, write=write)
     run_window_case(write)
     if "--full" in sys.argv:

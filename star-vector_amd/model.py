@@ -142,8 +142,12 @@ class ByteTokenizer:
         ids = torch.full((len(rows), n), self.pad_token_id, dtype=torch.long)
         mask = torch.zeros((len(rows), n), dtype=torch.long)
         for i, r in enumerate(rows):
-            ids[i, : len(r)] = torch.tensor(r, dtype=torch.long)
-            mask[i, : len(r)] = 1
+            if getattr(self, "padding_side", "right") == "left":      # llm/starcoder2.py:53
+                ids[i, n - len(r):] = torch.tensor(r, dtype=torch.long)
+                mask[i, n - len(r):] = 1
+            else:
+                ids[i, : len(r)] = torch.tensor(r, dtype=torch.long)
+                mask[i, : len(r)] = 1
         return _Encoding(input_ids=ids, attention_mask=mask)
 
     def decode(self, ids, skip_special_tokens: bool = True) -> str:
@@ -320,6 +324,36 @@ class HipCausalLM(_EngineModule):
             raise NotImplementedError("one stop sequence is supported (the reference passes exactly one: '</svg>')")
         return stops[0] if stops else None
 
+    def _generate_padded(self, inputs_embeds, attention_mask, kw):
+        mask = attention_mask.to(torch.bool)
+        B, S, _ = inputs_embeds.shape
+        if not bool(mask[:, -1].all()):
+            raise ValueError("the last prompt position of every row must be a real token (generation continues from it)")
+        budget = int(kw["max_length"]) - S                         # HF counts the budget from the PADDED prompt length
+        if budget <= 0:
+            raise ValueError(f"max_length ({kw['max_length']}) must exceed the prompt length ({S})")
+        lengths = mask.sum(dim=1).tolist()
+        pad = int(self.pad_token_id if kw.get("pad_token_id") is None else kw["pad_token_id"])
+        stop = self._stop_ids(kw.get("stopping_criteria"))
+        outs, fired_at = [None] * B, None
+        for n in sorted(set(lengths)):
+            rows = [b for b in range(B) if lengths[b] == n]
+            emb = torch.stack([inputs_embeds[b][mask[b]] for b in rows], 0)
+            sub = dict(kw, max_length=n + budget)
+            if rows[0] != 0:
+                sub["stopping_criteria"] = None                    # the reference's stop looks at row 0 of the batch only
+            toks = self.generate(inputs_embeds=emb, attention_mask=None, **sub)
+            if rows[0] == 0 and stop and toks.shape[1] >= len(stop) and toks[0, -len(stop):].tolist() == list(stop):
+                fired_at = toks.shape[1]                           # row 0 ended the whole batch at this step
+            for i, b in enumerate(rows):
+                outs[b] = toks[i]
+        L = fired_at if fired_at is not None else max(t.shape[0] for t in outs)
+        res = torch.full((B, L), pad, dtype=torch.long, device=inputs_embeds.device)
+        for b, t in enumerate(outs):
+            k = min(L, t.shape[0])
+            res[b, :k] = t[:k]
+        return res
+
     @torch.no_grad()
     def generate(self, inputs_embeds: torch.Tensor = None, attention_mask: Optional[torch.Tensor] = None,
                  do_sample: bool = False, top_p: Optional[float] = 1.0, temperature: Optional[float] = 1.0,
@@ -350,7 +384,15 @@ class HipCausalLM(_EngineModule):
         if repetition_penalty is not None and not repetition_penalty > 0:
             raise ValueError("`repetition_penalty` has to be a strictly positive float")   # HF's own check
         if attention_mask is not None and not bool((attention_mask == 1).all()):
-            raise NotImplementedError("left/right padding masks are not on the im2svg path (mask is all ones)")
+            # Padded prompts (text2svg with captions of different lengths; the v2 tokenizer pads on the left, llm/starcoder2.py:53).
+            # HF masks the padded keys and numbers positions by cumsum(mask), so a padded row behaves exactly like the same row
+            # with its padding removed (checked against HF for left and right padding, GPTBigCode and StarCoder2).  The engine
+            # takes rectangular all-ones prompts, so rows are grouped by their real length and generated group by group.
+            return self._generate_padded(inputs_embeds, attention_mask, dict(
+                do_sample=do_sample, top_p=top_p, temperature=temperature, num_beams=num_beams, max_length=max_length,
+                min_length=min_length, repetition_penalty=repetition_penalty, length_penalty=length_penalty,
+                use_cache=use_cache, stopping_criteria=stopping_criteria, early_stopping=early_stopping,
+                pad_token_id=pad_token_id, eos_token_id=eos_token_id, top_k=top_k))
         S0 = inputs_embeds.shape[1]
         # HF: min_length is reduced by the prompt length, leaving 0 on this path
         if max(int(min_length or 0) - S0, 0) > 0:
@@ -484,7 +526,8 @@ class StarVectorStarCoder(nn.Module):
         """starvector_base.py:297-330, restated by intent: embed(caption ids + <svg-start>) -> generate -> new token ids.
         The snapshot's version cannot run (it passes two positional arguments to _get_generation_kwargs, :321-324, and
         subtracts the prompt length from max_length twice); here `max_length` counts the prompt once, as in im2svg.
-        Captions must tokenise to the same length (the engine takes an all-ones mask; padded batches are not built)."""
+        Captions of different lengths are padded by the tokenizer; the padded rows are generated group by group
+        (HipCausalLM._generate_padded), which reproduces HF's masked generation exactly."""
         device = batch["image"].device if "image" in batch else torch.device("cuda", self._engine_device())
         prompt_tokens = self._tokenize(list(batch["caption"]), kwargs.get("max_length", 30), device, add_special_tokens=False)
         trigger = self._tokenize([self.svg_transformer.svg_start_token] * len(batch["caption"]), None, device,

@@ -199,9 +199,18 @@ def test_drop_in_api_generate_im2svg():
     cap = {"caption": ["a red square", "a red square"], "image": batch["image"]}
     t2s = model.model.generate_text2svg(cap, max_length=13 + 9, num_beams=1, use_nucleus_sampling=False)
     assert t2s.shape[0] == 2 and 1 <= t2s.shape[1] <= 9 and torch.equal(t2s[0], t2s[1])
-    with pytest.raises(NotImplementedError):
-        model.model.generate_text2svg({"caption": ["short", "a much longer caption"], "image": batch["image"]},
-                                      max_length=64, num_beams=1, use_nucleus_sampling=False)     # padded batch
+    # captions of different lengths: the tokenizer pads, HF masks the pads and numbers positions by cumsum(mask) -- i.e. every
+    # row behaves like the same row alone (pinned against HF on CPU); the mirror generates the rows group by group
+    caps = ["short", "a much longer caption", "short"]
+    mixed = model.model.generate_text2svg({"caption": caps, "image": batch["image"]}, max_length=40, num_beams=1,
+                                          use_nucleus_sampling=False)
+    padded_len = max(len(c.encode()) for c in caps) + 1                 # longest caption + <svg-start>
+    assert mixed.shape == (3, 40 - padded_len) and torch.equal(mixed[0], mixed[2])
+    for i in (0, 1):
+        solo = model.model.generate_text2svg({"caption": [caps[i]], "image": batch["image"][:1]},
+                                             max_length=len(caps[i].encode()) + 1 + mixed.shape[1], num_beams=1,
+                                             use_nucleus_sampling=False)
+        assert torch.equal(solo[0], mixed[i])
     # module-level operator signatures
     enc = model.model.image_encoder(batch["image"].to(torch.bfloat16))
     assert enc.shape == (2, model.model.query_length, cfg.vit_width)

@@ -35,6 +35,11 @@ def test_byte_tokenizer_surface():
     assert isinstance(ids, list) and len(ids) == 6
     assert tok.batch_decode(torch.tensor([tok.encode("<svg width") + [tok.pad_token_id, 0]])) == ["<svg width"]
     assert tok.encode("<svg-start>") == [49153]
+    tok2 = ByteTokenizer(49152, v2=True)                     # llm/starcoder2.py:53: pads on the left
+    e2 = tok2(["ab", "abcd"], return_tensors="pt")
+    assert e2.attention_mask.tolist() == [[0, 0, 1, 1], [1, 1, 1, 1]] and e2.input_ids[0, :2].tolist() == [tok2.pad_token_id] * 2
+    e1 = tok(["ab", "abcd"], return_tensors="pt")
+    assert e1.attention_mask.tolist() == [[1, 1, 0, 0], [1, 1, 1, 1]]
 
 
 def test_image_processor_matches_reference_recipe():
