@@ -109,3 +109,90 @@ def test_package_never_imports_the_oracle():
         if fn.endswith(".py"):
             text = open(os.path.join(src_dir, fn)).read()
             assert "import oracle" not in text and "from oracle" not in text, fn
+
+
+class _FakeEngine:
+    """Stands in for HipEngine on CPU: the 'model' emits, for every row, tokens derived from the row's real prompt only
+    (sum of its embedding entries), so host-side batching logic can be checked without a GPU."""
+    device = 0
+
+    def __init__(self):
+        self.calls = []
+
+    def generate(self, inputs_embeds, max_length, stop_ids=None, eos_token_id=0, pad_token_id=0, on_tokens=None, **kw):
+        B, S, _ = inputs_embeds.shape
+        budget = max_length - S
+        self.calls.append((B, S, budget, stop_ids))
+        base = inputs_embeds.float().sum(dim=(1, 2)).round().long()
+        toks = torch.stack([(base + 3 * t) % 97 + 1 for t in range(budget)], 1)           # [B, budget], never 0
+        n = budget
+        if stop_ids:                                                                       # row-0 stop, like the engine
+            r0 = toks[0].tolist()
+            for t in range(len(stop_ids) - 1, budget):
+                if r0[t + 1 - len(stop_ids):t + 1] == list(stop_ids):
+                    n = t + 1
+                    break
+        if on_tokens is not None:
+            on_tokens(toks[:, :n], 0)
+        return toks[:, :n]
+
+
+def _fake_lm():
+    lm = HipCausalLM.__new__(HipCausalLM)
+    torch.nn.Module.__init__(lm)
+    object.__setattr__(lm, "_engine", _FakeEngine())
+    lm.eos_token_id, lm.pad_token_id, lm.seed = 0, 99, 0
+    return lm
+
+
+def test_padded_prompts_are_generated_by_length_groups():
+    lm = _fake_lm()
+    torch.manual_seed(0)
+    emb = torch.randint(0, 5, (4, 6, 3)).float()
+    mask = torch.tensor([[0, 0, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1], [0, 0, 1, 1, 1, 1], [0, 1, 1, 1, 1, 1]])
+    out = lm.generate(inputs_embeds=emb, attention_mask=mask, max_length=6 + 5)
+    assert out.shape == (4, 5)
+    calls = lm._engine.calls
+    assert sorted((B, S) for B, S, _, _ in calls) == [(1, 5), (1, 6), (2, 4)]             # one call per real length
+    assert all(budget == 5 for _, _, budget, _ in calls)                                  # budget counted from the PADDED length
+    # every row equals what the same row alone, without its padding, produces
+    for b in range(4):
+        solo = _fake_lm().generate(inputs_embeds=emb[b:b + 1, mask[b].bool()], max_length=int(mask[b].sum()) + 5)
+        assert torch.equal(solo[0], out[b])
+    with pytest.raises(ValueError):
+        lm.generate(inputs_embeds=emb, attention_mask=torch.tensor([[1, 1, 1, 1, 1, 0]] * 4), max_length=12)
+
+
+def test_padded_prompts_row0_stop_ends_every_group():
+    lm = _fake_lm()
+    emb = torch.ones(3, 4, 2)
+    emb[1] *= 2
+    mask = torch.tensor([[0, 1, 1, 1], [1, 1, 1, 1], [0, 1, 1, 1]])
+    free = lm.generate(inputs_embeds=emb, attention_mask=mask, max_length=4 + 8)
+    stop = free[0, 2:4].tolist()                                                           # row 0 emits this pair at steps 2-3
+    crit = [StoppingCriteriaSub(stops=[stop])]
+    got = lm.generate(inputs_embeds=emb, attention_mask=mask, max_length=4 + 8, stopping_criteria=crit)
+    assert got.shape == (3, 4) and torch.equal(got, free[:, :4])                           # all rows cut where row 0 stopped
+    # only the group that contains row 0 is given the stop sequence
+    with_stop = [c for c in lm._engine.calls[-2:] if c[3]]
+    assert len(with_stop) == 1 and with_stop[0][0] == 2
+
+
+def test_streamer_protocol_on_host():
+    lm = _fake_lm()
+
+    class S:
+        def __init__(self):
+            self.v, self.done = [], False
+
+        def put(self, x):
+            self.v.append(x.clone())
+
+        def end(self):
+            self.done = True
+
+    st = S()
+    out = lm.generate(inputs_embeds=torch.ones(2, 3, 2), max_length=3 + 6, streamer=st)
+    assert st.done and st.v[0].shape == (2, 0) and torch.equal(torch.stack(st.v[1:], 1), out)
+    with pytest.raises(ValueError):
+        lm.generate(inputs_embeds=torch.ones(2, 3, 2), max_length=9, streamer=S(), num_beams=2)
