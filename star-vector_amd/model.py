@@ -181,7 +181,11 @@ class ImageTrainProcessor:
     def __call__(self, img):
         from PIL import Image
         import numpy as np
-        if self.device is not None and img.mode in ("RGB", "RGBA"):
+        if self.device is not None:
+            # engine-side processor: always the device kernels (palette / grey / CMYK images are only re-encoded as RGB(A)
+            # first -- the reference itself cannot normalise a non-RGB image with its 3-channel mean)
+            if img.mode not in ("RGB", "RGBA"):
+                img = img.convert("RGBA" if "transparency" in img.info or img.mode in ("LA", "PA") else "RGB")
             from .engine import op_preprocess_image
             px = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).to(self.device)
             return op_preprocess_image(px, self.size, self._mean, self._std)
