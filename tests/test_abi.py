@@ -35,6 +35,36 @@ def test_binding_matches_header(lib):
     assert sorted(_lib.PROTOTYPES) == _declared_functions()
 
 
+def test_binding_arity_and_struct_fields_match_header():
+    """Every ctypes prototype has as many arguments as the C declaration, and the ctypes mirrors of the three structs list
+    the header's fields in the header's order (an ABI drift here corrupts arguments silently)."""
+    from starvector_amd import _lib
+    text = open(os.path.join(ROOT, "include", "starvector_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for name, params in re.findall(r"\b(sv_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+        if name not in _lib.PROTOTYPES:
+            continue                                            # typedef'd callback etc.
+        params = params.strip()
+        n = 0 if params in ("", "void") else len([p for p in params.split(",") if p.strip()])
+        assert n == len(_lib.PROTOTYPES[name][1]), f"{name}: header has {n} parameters, binding {len(_lib.PROTOTYPES[name][1])}"
+
+    def fields(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), text, flags=re.S).group(1)
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            names = decl.split(",")
+            out.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", names[0])[-1])
+            out += [re.findall(r"[A-Za-z_][A-Za-z0-9_]*", x)[-1] for x in names[1:]]
+        return out
+
+    assert fields("sv_config") == [f[0] for f in _lib.SvConfig._fields_]
+    assert fields("sv_sampling") == [f[0] for f in _lib.SvSampling._fields_]
+    assert fields("sv_beam_config") == [f[0] for f in _lib.SvBeamConfig._fields_]
+
+
 def test_struct_layouts():
     from starvector_amd._lib import SvConfig, SvSampling
     assert C.sizeof(SvConfig) == 23 * 4
