@@ -75,6 +75,22 @@ __global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
     const int D = p.D, NC = D >> 3;
     bf16_t* hr = p.h + (size_t)row * p.ldh;
 
+    // gamma / beta do not depend on anything this kernel computes: request them first, so that the last phase does not
+    // start with a global round trip (the kernel is a chain of latencies: slabs -> mean -> variance -> normalise)
+    constexpr int RU_PRE = 4;                       // chunks of 8 columns per thread held in registers: D <= 8192
+    const bool pre = NC <= RU_PRE * 256;
+    uint4 gpre[RU_PRE], bpre[RU_PRE];
+    if (pre) {
+#pragma unroll
+        for (int i = 0; i < RU_PRE; ++i) {
+            const int c = tid + i * 256;
+            if (c < NC) {
+                gpre[i] = *reinterpret_cast<const uint4*>(p.g + c * 8);
+                bpre[i] = *reinterpret_cast<const uint4*>(p.b + c * 8);
+            }
+        }
+    }
+
     float s = 0.f;
     for (int c = tid; c < NC; c += 256) {
         float f[8];
@@ -94,16 +110,30 @@ __global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
             float v[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = 0.f;
-            for (int sp = 0; sp < p.splitk; ++sp) {
-                const float* src = p.ws + ((size_t)sp * p.rows_ws + row) * p.ldws + c * 8;
-                const float4 a = *reinterpret_cast<const float4*>(src);
-                const float4 b4 = *reinterpret_cast<const float4*>(src + 4);
-                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
-                v[4] += b4.x; v[5] += b4.y; v[6] += b4.z; v[7] += b4.w;
+            // bias / residual and up to 4 slabs are requested together, then summed in slab order (a load per iteration,
+            // each waited for, is one L2 round trip per slab)
+            const uint4 bq = *reinterpret_cast<const uint4*>(p.bias + c * 8);
+            const uint4 hq = *reinterpret_cast<const uint4*>(hr + c * 8);
+            for (int base = 0; base < p.splitk; base += 4) {
+                float4 a[4], b4[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int sp = base + j < p.splitk ? base + j : p.splitk - 1;
+                    const float* src = p.ws + ((size_t)sp * p.rows_ws + row) * p.ldws + c * 8;
+                    a[j] = *reinterpret_cast<const float4*>(src);
+                    b4[j] = *reinterpret_cast<const float4*>(src + 4);
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (base + j < p.splitk) {
+                        v[0] += a[j].x; v[1] += a[j].y; v[2] += a[j].z; v[3] += a[j].w;
+                        v[4] += b4[j].x; v[5] += b4[j].y; v[6] += b4[j].z; v[7] += b4[j].w;
+                    }
+                }
             }
             float bb[8], hh[8];
-            unpack8(*reinterpret_cast<const uint4*>(p.bias + c * 8), bb);
-            unpack8(*reinterpret_cast<const uint4*>(hr + c * 8), hh);
+            unpack8(bq, bb);
+            unpack8(hq, hh);
 #pragma unroll
             for (int e = 0; e < 8; ++e) f[e] = bfround(hh[e] + bfround(v[e] + bb[e]));
         }
@@ -125,6 +155,21 @@ __global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
     __syncthreads();
     const float rstd = rsqrtf((redbuf[4] + redbuf[5] + redbuf[6] + redbuf[7]) / (float)D + p.eps);
     const int KS = D >> 4;
+    if (pre) {
+#pragma unroll
+        for (int i = 0; i < RU_PRE; ++i) {
+            const int c = tid + i * 256;
+            if (c < NC) {
+                float f[8], gg[8], bb[8];
+                unpack8(gpre[i], gg);
+                unpack8(bpre[i], bb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = (hrow[c * 8 + e] - mean) * rstd * gg[e] + bb[e];
+                *reinterpret_cast<uint4*>(p.xp_out + xp_index(row >> 5, KS, row & 31, c * 8)) = pack8(f);
+            }
+        }
+        return;
+    }
     for (int c = tid; c < NC; c += 256) {
         float f[8], gg[8], bb[8];
         unpack8(*reinterpret_cast<const uint4*>(p.g + c * 8), gg);
