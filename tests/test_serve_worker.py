@@ -1,0 +1,180 @@
+"""CPU: the serving worker over a scripted engine -- wire format, streaming, error reporting.
+
+The reference's contract: serve/model_worker.py:120-229 (NUL-terminated JSON objects {"text", "error_code"}, text = the
+whole SVG so far, starting with the prompt for Image2SVG)."""
+import base64
+import io
+import json
+import time
+
+import pytest
+import torch
+
+from starvector_amd.engine import EngineConfig
+from starvector_amd.model import ByteTokenizer, StarVectorConfig, StarVectorStarCoder
+from starvector_amd.serve import ModelWorker, TextQueueStreamer, build_app, server_error_msg
+
+SVG_TAIL = ' width="10" height="10"> <path d="M0 0 L5 5"/>\n <rect x="1"/> </svg>'
+
+
+class _ScriptedEngine:
+    """Stands in for HipEngine: 'generates' SVG_TAIL byte by byte, calling back in bursts like the decode loop does."""
+
+    def __init__(self, tok, fail_after=None, burst=3, delay=0.0):
+        self.cfg = EngineConfig(image_size=28, patch_size=14, vit_width=4, hidden=8, vocab=len(tok))
+        self.script = tok.encode(SVG_TAIL)
+        self.fail_after, self.burst, self.delay = fail_after, burst, delay
+        self.calls = []
+
+    def encode_image(self, image):
+        return image.float().mean(dim=(1, 2, 3)).view(-1, 1, 1).expand(-1, self.cfg.query_length, 4).to(torch.bfloat16)
+
+    def adapter(self, h):
+        return torch.cat([h, h], dim=-1)
+
+    def embed_tokens(self, ids):
+        return (ids.float().unsqueeze(-1) / 300.0).expand(-1, -1, 8).to(torch.bfloat16)
+
+    def generate(self, inputs_embeds, max_length, stop_ids=None, on_tokens=None, num_beams=1, **kw):
+        B, S, _ = inputs_embeds.shape
+        budget = max_length - S
+        if budget <= 0:
+            raise ValueError("max_length must exceed the prompt length")
+        self.calls.append(dict(B=B, S=S, budget=budget, stop=stop_ids, beams=num_beams, **kw))
+        toks = torch.tensor([self.script[:budget]] * B, dtype=torch.long)
+        for a in range(0, toks.shape[1], self.burst):
+            if self.fail_after is not None and a >= self.fail_after:
+                raise RuntimeError("device fault (scripted)")
+            if self.delay:
+                time.sleep(self.delay)
+            if on_tokens is not None:
+                on_tokens(toks[:, a:a + self.burst], a)
+        return toks
+
+
+class _Model:
+    """The slice of StarVectorForCausalLM the worker touches: `.config`, `.model` (the real mirror class)."""
+
+    def __init__(self, engine, tok):
+        self.config = StarVectorConfig()
+        self.model = StarVectorStarCoder(self.config, engine, tok)
+
+
+def _worker(name="starvector-1b-im2svg", **eng_kw):
+    tok = ByteTokenizer(49152)
+    eng = _ScriptedEngine(tok, **eng_kw)
+    m = _Model(eng, tok)
+    from starvector_amd.model import ImageTrainProcessor
+    w = ModelWorker("http://127.0.0.1:1", "http://127.0.0.1:2", "t0", True, model_path="/ckpt/" + name, device="cpu",
+                    model=m, tokenizer=tok, image_processor=ImageTrainProcessor(size=28), context_len=8192)
+    return w, eng
+
+
+def _png_b64(size=(20, 12)):
+    from PIL import Image
+    buf = io.BytesIO()
+    Image.new("RGBA", size, (200, 30, 30, 128)).save(buf, format="PNG")
+    return base64.b64encode(buf.getvalue()).decode()
+
+
+def _chunks(raw: bytes):
+    parts = raw.split(b"\0")
+    assert parts[-1] == b""                                  # every object is NUL-terminated
+    return [json.loads(p) for p in parts[:-1]]
+
+
+def test_stream_wire_format_and_text_growth():
+    w, eng = _worker()
+    out = _chunks(b"".join(w.generate_stream_gate({"prompt": "<svg", "images": [_png_b64()], "max_new_tokens": 512,
+                                                    "temperature": 0.7, "top_p": 0.95, "len_penalty": 1.0})))
+    assert all(set(c) == {"text", "error_code"} and c["error_code"] == 0 for c in out)
+    texts = [c["text"] for c in out]
+    assert texts[0].startswith("<svg") and all(b.startswith(a) for a, b in zip(texts, texts[1:]))   # whole text so far
+    assert texts[-1] == "<svg" + SVG_TAIL
+    assert len(set(texts)) > 3                               # it does stream: several distinct partial texts
+    call = eng.calls[0]
+    assert call["B"] == 1 and call["S"] == eng.cfg.query_length + 4 and call["budget"] == 512 - call["S"]
+    assert call["do_sample"] is True and call["temperature"] == pytest.approx(0.7) and call["top_p"] == pytest.approx(0.95)
+    assert call["stop"] == ByteTokenizer(49152).encode("</svg>") and call["beams"] == 1 and call["top_k"] == 50
+    assert w.task == "Image2SVG" and w.model_name == "starvector-1b-im2svg" and w.is_multimodal
+
+
+def test_engine_failure_is_reported_at_once():
+    w, _ = _worker(fail_after=9)
+    t0 = time.time()
+    out = _chunks(b"".join(w.generate_stream_gate({"prompt": "<svg", "images": [_png_b64()], "max_new_tokens": 512})))
+    assert time.time() - t0 < 5.0                            # not the streamer's 15 s timeout
+    assert out[-1] == {"text": server_error_msg, "error_code": 1}
+    assert all(c["error_code"] == 0 for c in out[:-1]) and out[-2]["text"].startswith("<svg")
+
+
+def test_request_validation_paths():
+    w, eng = _worker()
+    # no token budget: the reference's message, error_code 0 (model_worker.py:157-159)
+    out = _chunks(b"".join(w.generate_stream_gate({"prompt": "<svg", "images": [_png_b64()], "max_new_tokens": 0})))
+    assert out == [{"text": "<svg" + "Exceeds max token length. Please start a new conversation, thanks.", "error_code": 0}]
+    assert not eng.calls
+    # no image / budget below the visual prefix / streamer with beams (HF's ValueError): one error object each
+    for params in ({"prompt": "<svg", "images": []},
+                   {"prompt": "<svg", "images": [_png_b64()], "max_new_tokens": 3},
+                   {"prompt": "<svg", "images": [_png_b64()], "max_new_tokens": 64, "num_beams": 2},
+                   {"images": [_png_b64()]}):
+        out = _chunks(b"".join(w.generate_stream_gate(params)))
+        assert out[-1] == {"text": server_error_msg, "error_code": 1}
+
+
+def test_text2svg_worker_uses_caption_path():
+    w, eng = _worker(name="starvector-text2svg")
+    assert w.task == "Text2SVG"
+    out = _chunks(b"".join(w.generate_stream_gate({"prompt": "a red circle", "max_new_tokens": 64})))
+    assert out[-1]["error_code"] == 0 and out[-1]["text"] == SVG_TAIL[:64 - eng.calls[0]["S"]]      # no prompt pre-pended
+    assert eng.calls[0]["S"] == len("a red circle") + 1                                           # caption + <svg-start>
+
+
+def test_status_and_model_name_rules():
+    w, _ = _worker()
+    assert w.get_status() == {"model_names": ["starvector-1b-im2svg"], "speed": 1, "queue_length": 0}
+    tok = ByteTokenizer(49152)
+    m = _Model(_ScriptedEngine(tok), tok)
+    w2 = ModelWorker("c", "w", "id", True, model_path="/x/run7/checkpoint-1200/", device="cpu", model=m, tokenizer=tok,
+                     image_processor=None)
+    assert w2.model_name == "run7_checkpoint-1200"             # model_worker.py:46-52
+
+
+def test_text_queue_streamer_equals_hf_text_iterator_streamer():
+    transformers = pytest.importorskip("transformers")
+    tok = ByteTokenizer(49152)
+    ids = tok.encode('<svg a="1">\n <path d="M 0 0"/> é ü\n</svg> tail')
+    g = torch.Generator().manual_seed(0)
+    for trial in range(5):
+        mine = TextQueueStreamer(tok, skip_prompt=False, skip_special_tokens=True, timeout=5)
+        ref = transformers.TextIteratorStreamer(tok, skip_prompt=False, skip_special_tokens=True, timeout=5)
+        for s in (mine, ref):
+            s.put(torch.empty(1, 0, dtype=torch.long))
+        i = 0
+        while i < len(ids):
+            n = int(torch.randint(1, 6, (1,), generator=g))
+            for s in (mine, ref):
+                s.put(torch.tensor(ids[i:i + n]))
+            i += n
+        mine.end(), ref.end()
+        assert list(mine) == list(ref)
+    with pytest.raises(ValueError):
+        TextQueueStreamer(tok).put(torch.zeros(2, 3, dtype=torch.long))
+
+
+def test_fastapi_routes_stream_the_same_bytes():
+    pytest.importorskip("fastapi")
+    pytest.importorskip("httpx")
+    from fastapi.testclient import TestClient
+    w, _ = _worker()
+    client = TestClient(build_app(w))
+    params = {"prompt": "<svg", "images": [_png_b64()], "max_new_tokens": 512}
+    direct = b"".join(w.generate_stream_gate(params))
+    with client.stream("POST", "/worker_generate_stream", json=params) as r:
+        assert r.status_code == 200
+        body = b"".join(r.iter_bytes())
+    assert body == direct and _chunks(body)[-1]["text"] == "<svg" + SVG_TAIL
+    st = client.post("/worker_get_status").json()
+    assert st["model_names"] == ["starvector-1b-im2svg"] and st["queue_length"] == 0      # the slot was given back
+    assert w.global_counter == 1
