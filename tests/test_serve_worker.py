@@ -178,3 +178,29 @@ def test_fastapi_routes_stream_the_same_bytes():
     st = client.post("/worker_get_status").json()
     assert st["model_names"] == ["starvector-1b-im2svg"] and st["queue_length"] == 0      # the slot was given back
     assert w.global_counter == 1
+
+
+def test_validation_backend_generate_svg():
+    """starvector_hf_validator.py:75-88 over the mirror: task dispatch, the temperature-0 rewrite, whitelist drops."""
+    from starvector_amd.validation import generate_svg
+    tok = ByteTokenizer(49152)
+    eng = _ScriptedEngine(tok)
+    m = _Model(eng, tok)
+    cpu = torch.device("cpu")
+    batch = {"image": torch.rand(3, 3, 28, 28), "Svg": ["a", "b", "c"], "Filename": ["1", "2", "3"]}
+    params = {"max_length": 40, "min_length": 5,          # below the prompt length, as on the real path (10 < 261)
+               "num_beams": 1, "temperature": 0, "top_p": 0.95, "do_sample": True,
+              "use_nucleus_sampling": True, "logit_bias": 5, "stream": False, "num_captions": 1, "presence_penalty": 0.0,
+              "generation_sweep": False, "repetition_penalty": 1.0, "length_penalty": 1.0, "frequency_penalty": 0.0}
+    out = generate_svg(m, "im2svg", batch, params, device=cpu)
+    S = eng.cfg.query_length + 4
+    assert out == ["<svg" + SVG_TAIL[:40 - S]] * 3 and params["temperature"] == 0          # caller's config left alone
+    call = eng.calls[-1]
+    assert call["B"] == 3 and call["temperature"] == 1.0 and call["do_sample"] is True     # the whitelist reads use_nucleus_sampling
+    assert "logit_bias" not in call and "stream" not in call
+    generate_svg(m, "im2svg", batch, dict(params, use_nucleus_sampling=False), device=cpu)
+    assert eng.calls[-1]["do_sample"] is False
+    txt = generate_svg(m, "text2svg", {"image": torch.zeros(2, 3, 28, 28), "caption": ["a cat", "a dog"]},
+                       dict(params, max_length=30), device=cpu)
+    assert txt == [SVG_TAIL[:30 - 6]] * 2
+    assert generate_svg(m, "im2text", batch, params, device=cpu) == []
