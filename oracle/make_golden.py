@@ -81,7 +81,7 @@ def build_reference(cfg: O.OracleConfig, w):
 
 @torch.no_grad()
 def reference_outputs(cfg, w, image, prompt_ids, n_new, stop_ids=None, repetition_penalty=1.0, num_beams=1,
-                      length_penalty=1.0, early_stopping=None):
+                      length_penalty=1.0, early_stopping=None, min_length=1):
     vit, lnv, adp, lm = build_reference(cfg, w)
     enc = lnv(vit(image))                                   # image_encoder.py:92-94
     vis = adp(enc)                                          # starvector_base.py:209
@@ -89,7 +89,7 @@ def reference_outputs(cfg, w, image, prompt_ids, n_new, stop_ids=None, repetitio
     mask = torch.ones(emb.shape[:2], dtype=torch.long)
     S0 = emb.shape[1]
     kw = dict(inputs_embeds=emb, attention_mask=mask, do_sample=False, num_beams=num_beams, top_p=None,
-              temperature=None, max_length=S0 + n_new, min_length=1, repetition_penalty=repetition_penalty,
+              temperature=None, max_length=S0 + n_new, min_length=min_length, repetition_penalty=repetition_penalty,
               length_penalty=length_penalty, use_cache=True, pad_token_id=cfg.pad_token_id)
     if early_stopping is not None:
         kw["early_stopping"] = early_stopping
@@ -296,6 +296,39 @@ def run_reppen_case(write):
         print("  wrote tests/golden/tiny_reppen.safetensors")
 
 
+def run_minlen_case(write):
+    """min_length (starvector_base.py:236) beyond the prompt length: HF subtracts the prompt length, then keeps EOS at -inf
+    for the first min_length - S0 generated tokens.  EOS is a token row 1 reaches at step 2 of the free run."""
+    import dataclasses
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=77)
+    B, n_new = 3, 16
+    image = O.synthetic_images(B, cfg.image_size, seed=78)
+    prompt_ids = torch.tensor([[7, 11]] * B, dtype=torch.long)
+    emb = O.prepare_generation_inputs(w, cfg, image, prompt_ids)
+    S0 = emb.shape[1]
+    free = O.greedy_generate(w, dataclasses.replace(cfg, eos_token_id=-1), emb, S0 + n_new)
+    eos = int(free[1, 2])
+    cfg2 = dataclasses.replace(cfg, eos_token_id=eos)
+    out = {"image": image, "prompt_ids": prompt_ids}
+    seen = []
+    for extra in (0, 3, 6):                                 # min_length = S0 + extra
+        ref = reference_outputs(cfg2, w, image, prompt_ids, n_new, min_length=S0 + extra)
+        mine = O.greedy_generate(w, cfg2, emb, S0 + n_new, min_length=S0 + extra)
+        assert torch.equal(mine, ref["tokens"]), (extra, mine, ref["tokens"])
+        first_eos = [int((r == eos).nonzero()[0]) if bool((r == eos).any()) else -1 for r in mine]
+        assert all(f < 0 or f >= extra for f in first_eos)
+        print(f"[tiny_minlen] min_length = S0 + {extra}: tokens == HF, first EOS per row {first_eos}")
+        out[f"tokens_{extra}"] = ref["tokens"].contiguous()
+        seen.append(mine)
+    assert not torch.equal(seen[0][:, :8], seen[1][:, :8]), "the case must exercise the suppression"
+    if write:
+        from safetensors.torch import save_file
+        out["meta"] = torch.tensor([77, B, n_new, eos, S0])
+        save_file(out, os.path.join(GOLD, "tiny_minlen.safetensors"))
+        print("  wrote tests/golden/tiny_minlen.safetensors")
+
+
 def run_beam_cases(write):
     """num_beams > 1 (the reference's default is 2, starvector_base.py:234) through HF's beam search: early_stopping
     True (v1 im2svg, :293) and False (v2), length penalties, an EOS some hypotheses reach, the row-0 stop sequence and
@@ -486,6 +519,7 @@ def main():
              seed=4321, batch=2, n_new=8, write=write)
     run_stop_case(write)
     run_reppen_case(write)
+    run_minlen_case(write)
     run_beam_cases(write)
     run_sampling_cases(write)
     run_forward_case(write)

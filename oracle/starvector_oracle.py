@@ -550,7 +550,7 @@ def prepare_generation_inputs(w, cfg: OracleConfig, image: Tensor, prompt_ids: T
 
 def greedy_generate(w, cfg: OracleConfig, inputs_embeds: Tensor, max_length: int,
                     stop_ids: Optional[Sequence[int]] = None, mode: str = "fp32",
-                    return_logits: bool = False, repetition_penalty: float = 1.0):
+                    return_logits: bool = False, repetition_penalty: float = 1.0, min_length: int = 0):
     """HF GenerationMixin.generate -> _sample with do_sample=False, num_beams=1, as driven by
     starvector_base.py:228-241,255.  Semantics:
       * with inputs_embeds the new-token budget is max_length - S0;
@@ -559,9 +559,14 @@ def greedy_generate(w, cfg: OracleConfig, inputs_embeds: Tensor, max_length: int
       * StoppingCriteriaSub (starvector_base.py:9-20) looks at ROW 0 only and stops the batch;
       * generation ends when every row is finished, the stop fires, or the budget is spent;
       * repetition_penalty (starvector_base.py:237): HF RepetitionPenaltyLogitsProcessor over the ids generated
-        so far (with inputs_embeds the prompt has no ids): score < 0 ? score * p : score / p.
+        so far (with inputs_embeds the prompt has no ids): score < 0 ? score * p : score / p;
+      * min_length (starvector_base.py:236, default 1; validation configs pass 10): with inputs_embeds HF first
+        subtracts the prompt length (GenerationMixin._prepare_generated_length: min_length = max(min_length - S0, 0)),
+        then MinLengthLogitsProcessor sets the EOS score to -inf while fewer than that many tokens have been
+        generated.  On the im2svg path S0 >= 258 makes it 0; a short text2svg caption can leave it positive.
     """
     B, S0, _ = inputs_embeds.shape
+    min_new = max(int(min_length) - S0, 0)
     budget = max_length - S0
     if budget <= 0:
         raise ValueError("max_length must exceed the prompt length (HF raises here)")
@@ -577,6 +582,9 @@ def greedy_generate(w, cfg: OracleConfig, inputs_embeds: Tensor, max_length: int
             g = torch.gather(scores, 1, prev)
             g = torch.where(g < 0, g * repetition_penalty, g / repetition_penalty)
             scores = scores.scatter(1, prev, g)
+        if t < min_new and 0 <= cfg.eos_token_id < scores.shape[1]:
+            scores = scores.clone()
+            scores[:, cfg.eos_token_id] = -float("inf")
         if return_logits:
             all_logits.append(scores)
         nxt = torch.argmax(scores, dim=-1)

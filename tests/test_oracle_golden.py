@@ -126,6 +126,21 @@ def test_repetition_penalty_matches_hf(golden_dir):
     assert torch.equal(O.greedy_generate(w, cfg, emb, emb.shape[1] + n_new, repetition_penalty=pen), g["tokens"])
 
 
+def test_min_length_matches_hf(golden_dir):
+    """min_length above the prompt length: HF subtracts the prompt length and holds EOS at -inf for the remainder."""
+    import dataclasses
+    g = _load(golden_dir, "tiny_minlen")
+    seed, B, n_new, eos, S0 = [int(x) for x in g["meta"]]
+    cfg = dataclasses.replace(O.OracleConfig.tiny(), eos_token_id=eos)
+    w = O.make_weights(cfg, seed=seed)
+    emb = O.prepare_generation_inputs(w, cfg, g["image"], g["prompt_ids"])
+    assert emb.shape[1] == S0
+    for extra in (0, 3, 6):
+        got = O.greedy_generate(w, cfg, emb, S0 + n_new, min_length=S0 + extra)
+        assert torch.equal(got, g[f"tokens_{extra}"]), extra
+    assert not torch.equal(g["tokens_0"][:, :8], g["tokens_3"][:, :8])
+
+
 def test_beam_search_matches_hf(golden_dir):
     """num_beams > 1 (the reference's default is 2): the restated _beam_search against HF generate on every case of
     tests/golden/tiny_beam (early_stopping True / False / "never", length penalties, EOS, the row-0 stop, the
