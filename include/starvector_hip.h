@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SV_ABI_VERSION 2
+#define SV_ABI_VERSION 3
 #define SV_WEIGHT_BF16 0
 #define SV_WEIGHT_FP8_E4M3 1
 
@@ -119,6 +119,10 @@ typedef struct sv_sampling {
                                   passes it, but its pinned transformers==4.49.0 defaults GenerationConfig.top_k to 50 */
     sv_token_callback on_tokens; /* optional streaming callback (NULL = off); not with num_beams > 1 (as in HF) */
     void*   user_data;
+    int32_t min_new_tokens;    /* HF MinLengthLogitsProcessor: the EOS logit is held at -inf while fewer than this many tokens
+                                  have been generated.  The caller passes max(min_length - S0, 0) (HF subtracts the prompt
+                                  length when generating from inputs_embeds; starvector_base.py:236 passes min_length).
+                                  0 = off; not with num_beams > 1 (SV_ENOTSUP) */
 } sv_sampling;
 
 /* HF beam search bookkeeping as a standalone device-side scorer (what transformers' _beam_search does between two

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libstarvector_hip.so")
 HEADER_PATH = os.path.normpath(os.path.join(HERE, "..", "include", "starvector_hip.h"))
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 SV_DTYPE_BF16, SV_DTYPE_F32 = 0, 1
 SV_NORM_LAYER, SV_NORM_BATCH = 0, 1
 SV_ARCH_V1, SV_ARCH_V2 = 0, 1
@@ -39,6 +39,7 @@ class SvSampling(C.Structure):
         ("sync_every", C.c_int32), ("repetition_penalty", C.c_float),
         ("num_beams", C.c_int32), ("length_penalty", C.c_float), ("early_stopping", C.c_int32),
         ("top_k", C.c_int32), ("on_tokens", C.c_void_p), ("user_data", C.c_void_p),
+        ("min_new_tokens", C.c_int32),
     ]
 
 

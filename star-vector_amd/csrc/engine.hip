@@ -51,6 +51,11 @@ __global__ void fill_i32_kernel(int32_t* p, int32_t v, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
+// HF MinLengthLogitsProcessor: while fewer than `min_new` tokens have been generated the EOS logit of every row is -inf
+__global__ void suppress_token_kernel(float* logits, int ld, int token, const int32_t* step, int min_new, int B) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B && *step < min_new) logits[(size_t)b * ld + token] = -INFINITY;
+}
 __global__ void add_i32_kernel(int32_t* p, int32_t v, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] += v;
@@ -1108,6 +1113,8 @@ extern "C" int sv_decode_step(sv_engine* e, const int32_t* dev_tokens, int32_t B
 static void sample_and_finish(sv_engine* e, int B, const sv_sampling& sp, int max_new, hipStream_t st) {
     const bool pen = sp.repetition_penalty > 0.f && sp.repetition_penalty != 1.0f;
     const uint32_t* seen = pen ? e->seen : nullptr;
+    if (sp.min_new_tokens > 0 && sp.eos_token_id >= 0 && sp.eos_token_id < e->cfg.vocab)
+        suppress_token_kernel<<<(B + 63) / 64, 64, 0, st>>>(e->logits, e->Vpad, sp.eos_token_id, e->d_step, sp.min_new_tokens, B);
     if (sp.do_sample) {
         SampleArgs sa;
         sa.logits = e->logits; sa.ld = e->Vpad; sa.V = e->cfg.vocab; sa.B = B; sa.temperature = sp.temperature;
@@ -1286,6 +1293,7 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
     HIPCHECK(hipStreamWaitEvent(st, e->gen_event, 0));
 
     if (sp->num_beams > 1) {
+        if (sp->min_new_tokens > 0) return fail(SV_ENOTSUP, "min_new_tokens with beam search is not built (HF applies it to the log-probabilities there)");
         if (sp->on_tokens) return fail(SV_EINVAL, "streaming is not supported with beam search (hypotheses are only final at the end; HF refuses too)");
         if (sp->n_stop > 0 && !sp->stop_ids) return fail(SV_EINVAL, "n_stop > 0 but stop_ids is null");
         return generate_beam(e, dev_embeds, B, S0, sp, max_new, dev_out_tokens, n_generated, st);

@@ -185,12 +185,13 @@ class HipEngine:
                  temperature: float = 1.0, top_p: float = 1.0, eos_token_id: int = 0, pad_token_id: int = 0,
                  stop_ids: Optional[Sequence[int]] = None, seed: int = 0, sync_every: int = 32,
                  repetition_penalty: float = 1.0, num_beams: int = 1, length_penalty: float = 1.0,
-                 early_stopping=False, top_k: int = 0, on_tokens=None) -> torch.Tensor:
+                 early_stopping=False, top_k: int = 0, on_tokens=None, min_new_tokens: int = 0) -> torch.Tensor:
         """HF ``generate`` semantics for inputs_embeds: returns ONLY the new tokens, int64 [B, N].
         ``num_beams`` > 1 runs HF's beam search on device (``early_stopping``: False, True or "never"); with
         ``do_sample`` it is HF's beam-sample.  ``top_k`` (0 = off) is HF's TopKLogitsWarper, applied before top-p.
         ``on_tokens(tokens [B, n] int64 cpu, first_col)``: streaming callback, called every ``sync_every`` steps with the
-        columns that became final and once more at the end."""
+        columns that became final and once more at the end.  ``min_new_tokens``: HF's MinLengthLogitsProcessor after the
+        prompt length has been subtracted from ``min_length`` (EOS cannot be chosen before that many new tokens)."""
         x = _need(inputs_embeds, torch.bfloat16, "inputs_embeds")
         B, S0, D = x.shape
         if D != self.cfg.hidden:
@@ -203,7 +204,8 @@ class HipEngine:
         sp = SvSampling(int(bool(do_sample)), float(temperature), float(top_p), int(max_length), int(eos_token_id),
                         int(pad_token_id), len(stops), C.cast(arr, C.POINTER(C.c_int32)) if stops else None,
                         int(seed) & 0xFFFFFFFFFFFFFFFF, int(sync_every), float(repetition_penalty),
-                        int(num_beams), float(length_penalty), _early_code(early_stopping), int(top_k or 0), None, None)
+                        int(num_beams), float(length_penalty), _early_code(early_stopping), int(top_k or 0), None, None,
+                        max(int(min_new_tokens or 0), 0))
         cb = None
         if on_tokens is not None:
             def _cb(_user, ptr, batch, first_col, n_cols):

@@ -343,7 +343,8 @@ class HipCausalLM(_EngineModule):
         for n in sorted(set(lengths)):
             rows = [b for b in range(B) if lengths[b] == n]
             emb = torch.stack([inputs_embeds[b][mask[b]] for b in rows], 0)
-            sub = dict(kw, max_length=n + budget)
+            # HF subtracts the PADDED prompt length from min_length as well: the same number of EOS-free steps for every row
+            sub = dict(kw, max_length=n + budget, min_length=n + max(int(kw.get("min_length") or 0) - S, 0))
             if rows[0] != 0:
                 sub["stopping_criteria"] = None                    # the reference's stop looks at row 0 of the batch only
             toks = self.generate(inputs_embeds=emb, attention_mask=None, **sub)
@@ -398,9 +399,12 @@ class HipCausalLM(_EngineModule):
                 use_cache=use_cache, stopping_criteria=stopping_criteria, early_stopping=early_stopping,
                 pad_token_id=pad_token_id, eos_token_id=eos_token_id, top_k=top_k))
         S0 = inputs_embeds.shape[1]
-        # HF: min_length is reduced by the prompt length, leaving 0 on this path
-        if max(int(min_length or 0) - S0, 0) > 0:
-            raise NotImplementedError("min_length beyond the prompt length is not built")
+        # HF (_prepare_generated_length): with inputs_embeds min_length is reduced by the prompt length -- 0 on the im2svg path
+        # (SURVEY.md 8a-a11), positive only for a text2svg caption shorter than min_length; MinLengthLogitsProcessor then
+        # keeps EOS at -inf for that many new tokens.  In beam search HF applies it to the log-probabilities: not built.
+        min_new = max(int(min_length or 0) - S0, 0)
+        if min_new > 0 and num_beams > 1:
+            raise NotImplementedError("min_length beyond the prompt length together with beam search is not built")
         if not use_cache:
             pass        # the engine always uses its paged KV cache; results are identical
         on_tokens = None
@@ -424,7 +428,7 @@ class HipCausalLM(_EngineModule):
             repetition_penalty=float(repetition_penalty if repetition_penalty is not None else 1.0),
             num_beams=num_beams, length_penalty=float(length_penalty if length_penalty is not None else 1.0),
             early_stopping=early_stopping, top_k=int(top_k or 0), on_tokens=on_tokens,
-            sync_every=8 if streamer is not None else 32)
+            sync_every=8 if streamer is not None else 32, **({"min_new_tokens": min_new} if min_new else {}))
         if streamer is not None:
             streamer.end()
         return out

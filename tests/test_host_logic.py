@@ -123,6 +123,7 @@ class _FakeEngine:
         B, S, _ = inputs_embeds.shape
         budget = max_length - S
         self.calls.append((B, S, budget, stop_ids))
+        self.last_kw = kw
         base = inputs_embeds.float().sum(dim=(1, 2)).round().long()
         toks = torch.stack([(base + 3 * t) % 97 + 1 for t in range(budget)], 1)           # [B, budget], never 0
         n = budget
@@ -196,3 +197,20 @@ def test_streamer_protocol_on_host():
     assert st.done and st.v[0].shape == (2, 0) and torch.equal(torch.stack(st.v[1:], 1), out)
     with pytest.raises(ValueError):
         lm.generate(inputs_embeds=torch.ones(2, 3, 2), max_length=9, streamer=S(), num_beams=2)
+
+
+def test_min_length_is_reduced_by_the_prompt_length():
+    """HF _prepare_generated_length: with inputs_embeds, min_length -= prompt length (floored at 0)."""
+    lm = _fake_lm()
+    emb = torch.ones(1, 4, 2)
+    lm.generate(inputs_embeds=emb, min_length=10, max_length=20)
+    assert lm._engine.last_kw["min_new_tokens"] == 6
+    lm.generate(inputs_embeds=emb, min_length=3, max_length=20)              # the im2svg situation: nothing left
+    assert "min_new_tokens" not in lm._engine.last_kw
+    with pytest.raises(NotImplementedError):
+        lm.generate(inputs_embeds=emb, min_length=10, max_length=20, num_beams=2)
+    # padded rows: the PADDED length is what HF subtracts, so every length group gets the same number of EOS-free steps
+    emb2 = torch.ones(2, 6, 2)
+    mask = torch.tensor([[0, 0, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1]])
+    lm.generate(inputs_embeds=emb2, attention_mask=mask, min_length=9, max_length=6 + 5)
+    assert lm._engine.last_kw["min_new_tokens"] == 3 and [c[1] for c in lm._engine.calls[-2:]] == [4, 6]
