@@ -1190,7 +1190,6 @@ static int generate_beam(sv_engine* e, const void* dev_embeds, int B, int S0, co
     const size_t stage_bytes = (size_t)R * c.n_layer * e->nkv * e->page_bytes;
     if (stage_bytes > e->beam_staging_bytes) {
         if (e->beam_staging) (void)hipFree(e->beam_staging);
-    if (e->score_ws) (void)hipFree(e->score_ws);
         e->beam_staging = nullptr; e->beam_staging_bytes = 0;
         HIPCHECK(hipMalloc(reinterpret_cast<void**>(&e->beam_staging), stage_bytes));
         e->beam_staging_bytes = stage_bytes;
