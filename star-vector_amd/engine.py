@@ -206,16 +206,15 @@ class HipEngine:
                         int(seed) & 0xFFFFFFFFFFFFFFFF, int(sync_every), float(repetition_penalty),
                         int(num_beams), float(length_penalty), _early_code(early_stopping), int(top_k or 0), None, None,
                         max(int(min_new_tokens or 0), 0))
-        cb = None
+        cb, cb_errors = None, []
         if on_tokens is not None:
-            def _cb(_user, ptr, batch, first_col, n_cols):
-                flat = torch.tensor([ptr[i] for i in range(batch * n_cols)], dtype=torch.int64).view(batch, n_cols)
-                on_tokens(flat, int(first_col))
-            cb = _lib.TOKEN_CALLBACK(_cb)                     # keep a reference alive for the duration of the call
+            cb, cb_errors = token_callback(on_tokens)          # keep a reference alive for the duration of the call
             sp.on_tokens = C.cast(cb, C.c_void_p)
         out = torch.empty(B, max_new, dtype=torch.int64, device=x.device)
         n = C.c_int32(0)
         check(self.lib.sv_generate(self._h, _ptr(x), B, S0, C.byref(sp), _ptr(out), C.byref(n), _stream()), "sv_generate")
+        if cb_errors:
+            raise cb_errors[0]
         return out[:, : n.value]
 
     def beam_history(self):
@@ -241,6 +240,24 @@ class HipEngine:
         res["event_pair_overhead_ms"] = buf[6]
         res["skinny_chain_ms_per_step"] = buf[7]
         return res
+
+
+def token_callback(on_tokens):
+    """Wrap ``on_tokens(tokens [B, n] int64 cpu, first_col)`` as an `sv_token_callback`.  An exception cannot unwind through
+    the C frames of `sv_generate` (ctypes would print and drop it): the first one is kept, later bursts are skipped, and
+    the caller re-raises it when `sv_generate` has returned.  Returns (C callback, list that receives the exception)."""
+    errors = []
+
+    def _cb(_user, ptr, batch, first_col, n_cols):
+        if errors:
+            return
+        try:
+            flat = torch.tensor(ptr[: batch * n_cols], dtype=torch.int64).view(batch, n_cols)
+            on_tokens(flat, int(first_col))
+        except BaseException as ex:                        # noqa: BLE001 -- re-raised by the caller
+            errors.append(ex)
+
+    return _lib.TOKEN_CALLBACK(_cb), errors
 
 
 def _early_code(early_stopping) -> int:

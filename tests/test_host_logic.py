@@ -214,3 +214,25 @@ def test_min_length_is_reduced_by_the_prompt_length():
     mask = torch.tensor([[0, 0, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1]])
     lm.generate(inputs_embeds=emb2, attention_mask=mask, min_length=9, max_length=6 + 5)
     assert lm._engine.last_kw["min_new_tokens"] == 3 and [c[1] for c in lm._engine.calls[-2:]] == [4, 6]
+
+
+def test_token_callback_keeps_the_first_exception():
+    """An exception of the streaming callback cannot unwind through sv_generate: it is kept and re-raised afterwards."""
+    import ctypes as C
+    from starvector_amd.engine import token_callback
+    got = []
+    cb, errs = token_callback(lambda t, c: got.append((t.clone(), c)))
+    arr = (C.c_int32 * 6)(1, 2, 3, 4, 5, 6)
+    cb(None, arr, 2, 7, 3)
+    assert not errs and got[0][1] == 7 and got[0][0].tolist() == [[1, 2, 3], [4, 5, 6]] and got[0][0].dtype == torch.int64
+
+    calls = []
+
+    def bad(t, c):
+        calls.append(c)
+        raise RuntimeError("boom")
+
+    cb2, errs2 = token_callback(bad)
+    cb2(None, arr, 2, 0, 3)
+    cb2(None, arr, 2, 3, 3)                                  # skipped: the stream is already broken
+    assert calls == [0] and len(errs2) == 1 and isinstance(errs2[0], RuntimeError)
