@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--weights", choices=["bf16", "fp8"], default="bf16",
                     help="fp8: decoder weights + lm_head quantised to e4m3 at load (BASELINE config 5's weight format); "
                          "NOT the reference precision -- never the headline line")
+    ap.add_argument("--task", choices=["im2svg", "text2svg"], default="im2svg",
+                    help="text2svg: BASELINE config 5's workload (no image encoder; the prompt is 32 caption ids + <svg-start>, "
+                         "batch 64 per GPU with --model 8b) -- a secondary line, never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ttft-requests", type=int, default=20)
     return ap.parse_args()
@@ -102,17 +105,19 @@ def main():
 
     is8b = args.model == "8b"
     cfg = O.OracleConfig.starvector_8b() if is8b else O.OracleConfig()
-    B_PER_GPU = 16 if is8b else 32
+    t2s = args.task == "text2svg"
+    B_PER_GPU = (64 if t2s else 16) if is8b else 32
     W_BYTES_PER_STEP = decoder_weight_bytes(cfg) // (2 if args.weights == "fp8" else 1)
     n_new = args.new_tokens
-    S0 = cfg.query_length + len(PROMPT_IDS)
+    CAPTION_TOKENS = 32
+    S0 = CAPTION_TOKENS + 1 if t2s else cfg.query_length + len(PROMPT_IDS)
     t_setup = time.time()
     ec = (sva.EngineConfig.starvector_8b(max_batch=B_PER_GPU, max_seq_len=S0 + n_new) if is8b
           else sva.EngineConfig(max_batch=B_PER_GPU, max_seq_len=S0 + n_new))
     if args.weights == "fp8":
         ec.weight_dtype = "fp8_e4m3"
     eng = sva.HipEngine(ec, device=local_rank)
-    keep_cpu = (world == 1 and rank == 0 and not args.no_cpu_baseline and not is8b)   # 8B fp32 on CPU: 29 GB, skipped
+    keep_cpu = (world == 1 and rank == 0 and not args.no_cpu_baseline and not is8b and not t2s)   # 8B fp32 on CPU: 29 GB, skipped
     w = {}
     for name, t in O.iter_weights(cfg, seed=1234, init="std002"):      # streamed: fp32 -> bf16 + fragment
         eng.load_weight(name, t)                                       # packing on device, one tensor at a time
@@ -125,17 +130,25 @@ def main():
     images = O.synthetic_images(B_PER_GPU * world, cfg.image_size, seed=0)[rank * B_PER_GPU:(rank + 1) * B_PER_GPU]
     images = images.to(torch.bfloat16).to(dev)
     prompt = torch.tensor([PROMPT_IDS] * B_PER_GPU, dtype=torch.long, device=dev)
+    if t2s:
+        # starvector_base.py:297-330: caption ids + <svg-start>; seeded per global row like the images
+        g = torch.Generator().manual_seed(0)
+        caps = torch.randint(1, 49152, (B_PER_GPU * world, CAPTION_TOKENS), generator=g)[rank * B_PER_GPU:(rank + 1) * B_PER_GPU]
+        prompt = torch.cat([caps, torch.full((B_PER_GPU, 1), 49152 + 1, dtype=torch.long)], 1).to(dev)
     t_setup = time.time() - t_setup
 
     def step(max_new=n_new):
-        enc = eng.encode_image(images)                         # a2-a5
-        vis = eng.adapter(enc)                                 # a6
-        emb = torch.cat([vis, eng.embed_tokens(prompt)], 1)    # a1, a7
+        if t2s:
+            emb = eng.embed_tokens(prompt)                     # text2svg: no image encoder, no adapter
+        else:
+            enc = eng.encode_image(images)                     # a2-a5
+            vis = eng.adapter(enc)                             # a6
+            emb = torch.cat([vis, eng.embed_tokens(prompt)], 1)    # a1, a7
         new = eng.generate(emb, max_length=S0 + max_new, eos_token_id=-1,      # EOS disabled:
                            pad_token_id=cfg.pad_token_id,                      # fixed-length workload
                            do_sample=is8b, temperature=1.0, top_p=0.95, top_k=50 if is8b else 0,
                            seed=1)       # config 4 samples: top-p 0.95 after HF 4.49's implicit top-k 50
-        out = torch.cat([prompt, new], 1)                      # starvector_base.py:256
+        out = new if t2s else torch.cat([prompt, new], 1)      # starvector_base.py:256 (text2svg returns the new ids, :329-330)
         if world > 1:
             out = all_gather_token_streams(out, cfg.pad_token_id, B_PER_GPU * world)
         return out, new.shape[1]
@@ -212,13 +225,16 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": f"SVG tokens/sec (whole job) + p50 time-to-first-token, StarVector-{args.model.upper()} im2svg batch{B_PER_GPU}/GPU",
+            "metric": f"SVG tokens/sec (whole job) + p50 time-to-first-token, StarVector-{args.model.upper()} {args.task} batch{B_PER_GPU}/GPU",
             "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.weights == "bf16" else "bf16 activations / fp8-e4m3 decoder weights (not the reference precision)",
             "data": f"synthetic: random-pixel {cfg.image_size}x{cfg.image_size} images (CLIP-normalised), random-init weights N(0,0.02) seed 1234",
-            "config": {"workload": (f"StarVector-8B im2svg, batch {B_PER_GPU}/GPU, bf16, top-k 50 + top-p 0.95, 384x384, prompt rows "
+            "config": {"workload": (f"StarVector-{args.model.upper()} text2svg (no image encoder), batch {B_PER_GPU}/GPU, {args.weights} decoder weights, "
+                                    f"{'top-k 50 + top-p 0.95' if is8b else 'greedy'}, prompt rows {S0} ({CAPTION_TOKENS} caption ids + <svg-start>), "
+                                    f"{n_new} new tokens/seq, EOS disabled") if t2s else
+                                   (f"StarVector-8B im2svg, batch {B_PER_GPU}/GPU, bf16, top-k 50 + top-p 0.95, 384x384, prompt rows "
                                     f"{S0} (576 visual + {len(PROMPT_IDS)}), {n_new} new tokens/seq, EOS disabled") if is8b else
                                    (f"StarVector-1B im2svg, batch {B_PER_GPU}/GPU, bf16, greedy, 224x224, prompt rows "
                                     f"{S0} (257 visual + {len(PROMPT_IDS)}), {n_new} new tokens/seq, EOS disabled"),
