@@ -40,7 +40,7 @@ class StarVectorConfig:
                  hidden_size: int = 2048, num_kv_heads: int = 4, torch_dtype: str = "bfloat16",
                  # engine-only (not in the reference config): shapes that the reference takes from the HF
                  # sub-model configs, and the batch/sequence capacity the KV pool is sized for
-                 n_inner: Optional[int] = None, n_positions: int = 8192, added_tokens: int = 4,
+                 n_inner: Optional[int] = None, n_positions: Optional[int] = None, added_tokens: Optional[int] = None,
                  vit_width: int = 1024, vit_layers: int = 23, vit_heads: int = 16, patch_size: int = 14,
                  max_batch: int = 32, **kwargs):
         self.starcoder_model_name = starcoder_model_name
@@ -58,8 +58,11 @@ class StarVectorConfig:
         self.num_kv_heads = num_kv_heads
         self.torch_dtype = torch_dtype
         self.n_inner = n_inner if n_inner is not None else 4 * hidden_size
-        self.n_positions = n_positions
-        self.added_tokens = added_tokens          # [PAD] + <svg-start>,<image-start>,<caption-start>
+        v2 = "starcoder2" in starcoder_model_name
+        # bigcode/starcoderbase-1b: 8192 learned positions; bigcode/starcoder2-7b: max_position_embeddings 16384
+        self.n_positions = n_positions if n_positions is not None else (16384 if v2 else 8192)
+        # [PAD] + <svg-start>,<image-start>,<caption-start> (llm/starcoder.py:40-53); v2 adds <svg-end> (llm/starcoder2.py:47)
+        self.added_tokens = added_tokens if added_tokens is not None else (5 if v2 else 4)
         self.vit_width, self.vit_layers, self.vit_heads, self.patch_size = vit_width, vit_layers, vit_heads, patch_size
         self.max_batch = max_batch
         for k, v in kwargs.items():
@@ -95,6 +98,32 @@ class StarVectorConfig:
                             n_inner=self.n_inner, vocab=self.vocab_size + self.added_tokens,
                             n_positions=self.n_positions, max_batch=self.max_batch,
                             max_seq_len=min(self.max_length, self.n_positions))
+
+
+def config_from_checkpoint(cfg_json: Dict, shapes: Dict[str, tuple]) -> StarVectorConfig:
+    """`config.json` of a reference checkpoint + the shapes of its tensors -> StarVectorConfig.  The reference takes the
+    decoder's vocabulary (after `resize_token_embeddings`), position count and MLP width from the HF sub-model it
+    instantiates (llm/starcoder.py:33-53, llm/starcoder2.py:22-53); offline they are read off the saved tensors, which
+    is what those numbers ended up as.  Explicit entries of `cfg_json` win."""
+    cfg = StarVectorConfig(**{**cfg_json, "torch_dtype": "bfloat16"})
+    dec = "model.svg_transformer.transformer." + ("model." if cfg.is_v2 else "transformer.")
+    emb = shapes.get(dec + ("embed_tokens.weight" if cfg.is_v2 else "wte.weight"))
+    if emb is not None:
+        if "hidden_size" not in cfg_json:
+            cfg.hidden_size = int(emb[1])
+        if "added_tokens" not in cfg_json:
+            cfg.added_tokens = int(emb[0]) - int(cfg.vocab_size)
+            if cfg.added_tokens < 0:
+                raise ValueError(f"checkpoint embeds {emb[0]} tokens, fewer than vocab_size {cfg.vocab_size}")
+    wpe = shapes.get(dec + "wpe.weight")
+    if wpe is not None and "n_positions" not in cfg_json:
+        cfg.n_positions = int(wpe[0])
+    fc = shapes.get(dec + ("layers.0." if cfg.is_v2 else "h.0.") + "mlp.c_fc.weight")
+    if fc is not None and "n_inner" not in cfg_json:
+        cfg.n_inner = int(fc[0])
+    elif "n_inner" not in cfg_json:
+        cfg.n_inner = 4 * cfg.hidden_size
+    return cfg
 
 
 # --------------------------------------------------------------------------------------------------
@@ -609,12 +638,13 @@ class StarVectorForCausalLM(nn.Module):
         if not os.path.isdir(path):
             raise FileNotFoundError(f"{path!r} is not a local directory (hub download is unavailable offline)")
         with open(os.path.join(path, "config.json")) as f:
-            cfg = StarVectorConfig(**{**json.load(f), **kwargs, "torch_dtype": "bfloat16"})
+            cfg_json = json.load(f)
         from safetensors.torch import load_file
         sd: Dict[str, torch.Tensor] = {}
         for fn in sorted(os.listdir(path)):
             if fn.endswith(".safetensors"):
                 sd.update(load_file(os.path.join(path, fn)))
+        cfg = config_from_checkpoint({**cfg_json, **kwargs}, {k: tuple(v.shape) for k, v in sd.items()})
         if tokenizer is None:
             try:
                 from transformers import AutoTokenizer

@@ -236,3 +236,30 @@ def test_token_callback_keeps_the_first_exception():
     cb2(None, arr, 2, 0, 3)
     cb2(None, arr, 2, 3, 3)                                  # skipped: the stream is already broken
     assert calls == [0] and len(errs2) == 1 and isinstance(errs2[0], RuntimeError)
+
+
+def test_config_from_checkpoint_reads_sizes_off_the_tensors():
+    """Offline, the numbers the reference takes from the HF sub-model configs come from the checkpoint's own tensors."""
+    from starvector_amd.model import config_from_checkpoint
+    pd = "model.svg_transformer.transformer.transformer."
+    c1 = config_from_checkpoint({"starcoder_model_name": "bigcode/starcoderbase-1b", "image_encoder_type": "clip",
+                                 "hidden_size": 2048, "num_hidden_layers": 24, "num_attention_heads": 16, "vocab_size": 49152,
+                                 "torch_dtype": "float16", "max_length": 8192},
+                                {pd + "wte.weight": (49156, 2048), pd + "wpe.weight": (8192, 2048),
+                                 pd + "h.0.mlp.c_fc.weight": (8192, 2048)})
+    e1 = c1.engine_config()
+    assert (e1.vocab, e1.n_positions, e1.n_inner, e1.arch) == (49156, 8192, 8192, "v1")
+    p2 = "model.svg_transformer.transformer.model."
+    c2 = config_from_checkpoint({"starcoder_model_name": "bigcode/starcoder2-7b", "image_encoder_type": "siglip_384",
+                                 "hidden_size": 4608, "num_hidden_layers": 32, "num_attention_heads": 36, "num_kv_heads": 4,
+                                 "vocab_size": 49152, "max_length": 16000},
+                                {p2 + "embed_tokens.weight": (49157, 4608), p2 + "layers.0.mlp.c_fc.weight": (18432, 4608)})
+    e2 = c2.engine_config()
+    assert (e2.vocab, e2.n_positions, e2.n_inner, e2.arch, e2.max_seq_len) == (49157, 16384, 18432, "v2", 16000)
+    # without tensors the arch-aware defaults apply; explicit entries always win
+    assert StarVectorConfig(starcoder_model_name="bigcode/starcoder2-7b").added_tokens == 5
+    assert StarVectorConfig().added_tokens == 4 and StarVectorConfig().n_positions == 8192
+    c3 = config_from_checkpoint({"vocab_size": 49152, "added_tokens": 4, "n_inner": 1024}, {pd + "wte.weight": (49200, 2048)})
+    assert c3.added_tokens == 4 and c3.n_inner == 1024
+    with pytest.raises(ValueError):
+        config_from_checkpoint({"vocab_size": 49152}, {pd + "wte.weight": (100, 2048)})
