@@ -321,6 +321,12 @@ def run_minlen_case(write):
         print(f"[tiny_minlen] min_length = S0 + {extra}: tokens == HF, first EOS per row {first_eos}")
         out[f"tokens_{extra}"] = ref["tokens"].contiguous()
         seen.append(mine)
+        # the same remainder under beam search (HF applies the processor to the log-probabilities there)
+        refb = reference_outputs(cfg2, w, image, prompt_ids, n_new, min_length=S0 + extra, num_beams=2, early_stopping=True)
+        mineb = O.beam_search_generate(w, cfg2, emb, S0 + n_new, 2, early_stopping=True, min_length=S0 + extra)
+        assert torch.equal(mineb, refb["tokens"]), (extra, mineb, refb["tokens"])
+        print(f"[tiny_minlen] min_length = S0 + {extra}, num_beams 2: tokens == HF, shape {tuple(mineb.shape)}")
+        out[f"beam2_tokens_{extra}"] = refb["tokens"].contiguous()
     assert not torch.equal(seen[0][:, :8], seen[1][:, :8]), "the case must exercise the suppression"
     if write:
         from safetensors.torch import save_file

@@ -629,8 +629,9 @@ class BeamSearchState:
     def __init__(self, batch: int, num_beams: int, vocab: int, budget: int, eos_token_id: int, pad_token_id: int,
                  length_penalty: float = 1.0, early_stopping=True, stop_ids: Optional[Sequence[int]] = None,
                  repetition_penalty: float = 1.0, do_sample: bool = False, temperature: float = 1.0,
-                 top_p: float = 1.0, top_k: int = 0):
+                 top_p: float = 1.0, top_k: int = 0, min_new_tokens: int = 0):
         self.sample = (bool(do_sample), temperature, top_p, top_k)
+        self.min_new = int(min_new_tokens)       # MinLengthLogitsProcessor, applied to the LOG-PROBS (after the penalty)
         self.B, self.nb, self.V, self.budget = batch, int(num_beams), vocab, budget
         self.K = 2 * self.nb
         self.eos, self.lp, self.es, self.pen = eos_token_id, length_penalty, early_stopping, repetition_penalty
@@ -658,6 +659,9 @@ class BeamSearchState:
             g = torch.gather(lp, 1, prev)
             g = torch.where(g < 0, g * self.pen, g / self.pen)
             lp = lp.scatter(1, prev, g)
+        if cur < self.min_new and 0 <= self.eos < V:
+            lp = lp.clone()
+            lp[:, self.eos] = -float("inf")
         if self.sample[0]:                                                # beam-sample: warpers act on the log-probs
             lp = warp_scores(lp, self.sample[1], self.sample[2], self.sample[3], min_tokens_to_keep=2)
         acc = (lp.view(B, nb, V) + self.run_score[:, :, None]).reshape(B, nb * V)
@@ -714,7 +718,7 @@ def beam_search_generate(w, cfg: OracleConfig, inputs_embeds: Tensor, max_length
                          length_penalty: float = 1.0, early_stopping=True,
                          stop_ids: Optional[Sequence[int]] = None, mode: str = "fp32",
                          repetition_penalty: float = 1.0, return_scores: bool = False, do_sample: bool = False,
-                         temperature: float = 1.0, top_p: float = 1.0, top_k: int = 0):
+                         temperature: float = 1.0, top_p: float = 1.0, top_k: int = 0, min_length: int = 0):
     """generate(num_beams > 1): the prompt expanded to num_beams rows (repeat_interleave), BeamSearchState between the
     forward passes, the KV cache re-indexed by the surviving beams' parents.  Returns new tokens [B, L]
     (and the best scores [B] with return_scores)."""
@@ -724,7 +728,8 @@ def beam_search_generate(w, cfg: OracleConfig, inputs_embeds: Tensor, max_length
         raise ValueError("max_length must exceed the prompt length (HF raises here)")
     nb = int(num_beams)
     state = BeamSearchState(B, nb, cfg.vocab, budget, cfg.eos_token_id, cfg.pad_token_id, length_penalty,
-                            early_stopping, stop_ids, repetition_penalty, do_sample, temperature, top_p, top_k)
+                            early_stopping, stop_ids, repetition_penalty, do_sample, temperature, top_p, top_k,
+                            min_new_tokens=max(int(min_length) - S0, 0))      # HF subtracts the prompt length first
     logits, cache = decoder_prefill(w, cfg, inputs_embeds.repeat_interleave(nb, dim=0), mode)
     while True:
         go_on, flat_parent, tokens = state.step(logits)

@@ -138,6 +138,9 @@ def test_min_length_matches_hf(golden_dir):
     for extra in (0, 3, 6):
         got = O.greedy_generate(w, cfg, emb, S0 + n_new, min_length=S0 + extra)
         assert torch.equal(got, g[f"tokens_{extra}"]), extra
+        # under beam search HF applies the same processor to the log-probabilities
+        gotb = O.beam_search_generate(w, cfg, emb, S0 + n_new, 2, early_stopping=True, min_length=S0 + extra)
+        assert torch.equal(gotb, g[f"beam2_tokens_{extra}"]), extra
     assert not torch.equal(g["tokens_0"][:, :8], g["tokens_3"][:, :8])
 
 
