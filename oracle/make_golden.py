@@ -469,6 +469,15 @@ def run_forward_case(write):
     for n in (0, 5, 1):
         mine = O.decoder_forward_logits(w, cfg, emb, n)
         check(f"forward logits, keep {n or 'all'}", mine, ref if n == 0 else ref[:, -n:], 1e-5)
+    # right-padded mask (completions padded after EOS, a GRPO trainer's call): the real positions of HF's masked run equal the
+    # unmasked run's -- what the mirror's forward relies on (model.py StarVectorForCausalLM.forward)
+    mask = torch.ones(emb.shape[:2], dtype=torch.long)
+    mask[1, -3:] = 0
+    masked = lm(inputs_embeds=emb, attention_mask=mask).logits.detach()
+    d_real = float((masked - ref.detach())[mask.bool()].abs().max())
+    d_pad = float((masked - ref.detach())[~mask.bool()].abs().max())
+    print(f"[tiny_forward] right-padded mask: max|diff| at real positions {d_real:.2e} (at padded ones {d_pad:.2e}: unspecified)")
+    assert d_real < 1e-5
     if write:
         from safetensors.torch import save_file
         save_file({"image": image, "ids": ids, "logits_keep5": ref[:, -5:].contiguous(), "meta": torch.tensor([1234, 2, 9])},

@@ -661,7 +661,15 @@ class StarVectorForCausalLM(nn.Module):
         inputs_embeds = torch.cat([vision_embeds.repeat(num_generations, 1, 1).to(completion_embeds.dtype),
                                    completion_embeds], dim=1)
         if attention_mask is not None and not bool((attention_mask == 1).all()):
-            raise NotImplementedError("padding masks are not built (the path's mask is all ones)")
+            # Right padding (completions padded after their EOS, what a GRPO trainer passes): under the causal mask a real
+            # position never sees a later key and HF's positions (cumsum(mask) - 1) equal the plain index for it, so the
+            # logits of every real position are those of the unmasked run.  Rows at padded positions are unspecified (HF's
+            # differ there too from any unpadded run; the caller multiplies them away with the same mask).
+            m = attention_mask.to(torch.bool)
+            if m.shape != inputs_embeds.shape[:2]:
+                raise ValueError(f"attention_mask {tuple(m.shape)} does not cover inputs_embeds {tuple(inputs_embeds.shape[:2])}")
+            if bool((m[:, 1:] & ~m[:, :-1]).any()) or not bool(m[:, 0].all()):
+                raise NotImplementedError("only right-padded attention masks are built for the scoring forward")
         logits = self.engine.forward_logits(inputs_embeds.to(torch.bfloat16), int(num_logits_to_keep or 0))
         try:
             from transformers.modeling_outputs import CausalLMOutputWithCrossAttentions

@@ -263,3 +263,37 @@ def test_config_from_checkpoint_reads_sizes_off_the_tensors():
     assert c3.added_tokens == 4 and c3.n_inner == 1024
     with pytest.raises(ValueError):
         config_from_checkpoint({"vocab_size": 49152}, {pd + "wte.weight": (100, 2048)})
+
+
+def test_scoring_forward_accepts_right_padded_masks_only():
+    """starvector_arch.py:161-184 with the mask a GRPO trainer passes (completions padded after EOS)."""
+    import types
+    from starvector_amd.model import StarVectorForCausalLM
+
+    class Eng:
+        def __init__(self):
+            self.seen = None
+
+        def embed_tokens(self, ids):
+            return ids.float().unsqueeze(-1).expand(-1, -1, 4).to(torch.bfloat16)
+
+        def forward_logits(self, emb, keep):
+            self.seen = (tuple(emb.shape), keep)
+            return torch.zeros(emb.shape[0], keep or emb.shape[1], 7)
+
+    m = StarVectorForCausalLM.__new__(StarVectorForCausalLM)
+    torch.nn.Module.__init__(m)
+    eng = Eng()
+    object.__setattr__(m, "engine", eng)
+    object.__setattr__(m, "model", types.SimpleNamespace(_get_embeddings=eng.embed_tokens))
+    vis = torch.ones(1, 3, 4, dtype=torch.bfloat16)
+    ids = torch.tensor([[5, 6, 7, 0], [5, 6, 0, 0]])
+    right = torch.tensor([[1, 1, 1, 1, 1, 1, 1], [1, 1, 1, 1, 1, 0, 0]])
+    out = m.forward(vis, ids, 2, right, 4)
+    assert out.logits.shape == (2, 4, 7) and eng.seen == ((2, 7, 4), 4)
+    with pytest.raises(NotImplementedError):
+        m.forward(vis, ids, 2, torch.tensor([[1] * 7, [0, 1, 1, 1, 1, 1, 1]]), 4)        # left padding
+    with pytest.raises(NotImplementedError):
+        m.forward(vis, ids, 2, torch.tensor([[1] * 7, [1, 1, 0, 1, 1, 1, 1]]), 4)        # a hole
+    with pytest.raises(ValueError):
+        m.forward(vis, ids, 2, torch.ones(2, 4, dtype=torch.long)[:, :3] * torch.tensor([[1, 1, 0]]), 4)
