@@ -7,10 +7,10 @@ from ._lib import StarVectorHipError, LIB_PATH, HEADER_PATH  # noqa: F401
 from .engine import EngineConfig, HipEngine  # noqa: F401
 from .model import (  # noqa: F401
     StarVectorConfig, StarVectorForCausalLM, StarVectorStarCoder, StarVectorStarCoder2, StarCoderModel, ImageEncoder, Adapter,
-    HipCausalLM, StoppingCriteriaSub, ImageTrainProcessor, ByteTokenizer,
+    HipCausalLM, StoppingCriteriaSub, ImageTrainProcessor, SimpleStarVectorProcessor, ByteTokenizer,
 )
 from . import parallel  # noqa: F401
 
 __all__ = ["EngineConfig", "HipEngine", "StarVectorConfig", "StarVectorForCausalLM", "StarVectorStarCoder", "StarVectorStarCoder2",
            "StarCoderModel", "ImageEncoder", "Adapter", "HipCausalLM", "StoppingCriteriaSub",
-           "ImageTrainProcessor", "ByteTokenizer", "StarVectorHipError", "parallel"]
+           "ImageTrainProcessor", "SimpleStarVectorProcessor", "ByteTokenizer", "StarVectorHipError", "parallel"]

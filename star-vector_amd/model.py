@@ -237,6 +237,41 @@ class ImageTrainProcessor:
         return x if self.device is None else x.to(self.device)
 
 
+class SimpleStarVectorProcessor:
+    """starvector_arch.py:17-90: the HF-style processor a v1 checkpoint's `AutoProcessor` resolves to, reached as
+    `starvector.model.processor` (starvector_v1.py:10; scripts/quickstart-hf.py and the validation dataset call it as
+    `processor(image, return_tensors="pt")["pixel_values"]`).  Same pixels as ImageTrainProcessor except for RGBA input:
+    here the alpha band is DROPPED (`img.convert("RGB")`, :41), not composited on white.  One image -> [3, S, S], a list ->
+    [B, 3, S, S]; `text` goes through the tokenizer with the reference's arguments (:76-83).
+    With `device` set the resize / normalise run on that GPU (`sv_preprocess_image`), bit-identical to the host recipe."""
+
+    def __init__(self, tokenizer=None, size: int = 224, mean=None, std=None, device=None, **kwargs):
+        self.tokenizer = tokenizer
+        self.mean, self.std, self.size = tuple(mean or CLIP_MEAN), tuple(std or CLIP_STD), size
+        self._pixels = ImageTrainProcessor(mean=self.mean, std=self.std, size=size, device=device)
+
+    def _one(self, img):
+        if img.mode == "RGBA":
+            img = img.convert("RGB")
+        return self._pixels(img)
+
+    def __call__(self, images=None, text=None, max_length=None, **kwargs):
+        if images is None and text is None:
+            raise ValueError("You have to specify at least one of `images` or `text`.")
+        data = {}
+        if text is not None:
+            data.update(self.tokenizer(text, truncation=True, add_special_tokens=True, padding="longest",
+                                       max_length=max_length, return_tensors="pt"))
+        if images is not None:
+            data["pixel_values"] = (torch.stack([self._one(i) for i in images]) if isinstance(images, (list, tuple))
+                                    else self._one(images))
+        try:
+            from transformers import BatchFeature
+            return BatchFeature(data=data)
+        except Exception:                                   # transformers not importable: same mapping + attribute access
+            return _Encoding(**data)
+
+
 # --------------------------------------------------------------------------------------------------
 # modules
 # --------------------------------------------------------------------------------------------------
@@ -508,7 +543,10 @@ class StarVectorStarCoder(nn.Module):
         self.query_length = ec.query_length                          # starvector_base.py:85-106
         self.image_projection = Adapter(engine, self.query_length, ec.adapter_norm)
         self.max_length = config.max_length_train - self.query_length - 4
-        self.processor = self.image_encoder.processor
+        # starvector_v1.py:10 -> AutoProcessor = SimpleStarVectorProcessor (HF-style call); starvector_v2.py:12 -> the tower's
+        # image processor.  `image_encoder.processor` stays the plain callable `process_images` uses (image_encoder.py:112-117)
+        self.processor = self.image_encoder.processor if v2 else SimpleStarVectorProcessor(
+            tokenizer, size=ec.image_size, device=getattr(self.image_encoder.processor, "device", None))
 
     def use_image_encoder(self):
         return True
@@ -523,6 +561,8 @@ class StarVectorStarCoder(nn.Module):
 
     def _prepare_generation_inputs(self, batch, prompt, device):      # starvector_base.py:203-221
         image = batch["image"].to(device).to(self.model_precision)
+        if image.dim() == 3:                  # one un-batched image, what `processor(pil)["pixel_values"]` returns for v1
+            image = image.unsqueeze(0)
         embedded_image = self.image_projection(self.image_encoder(image))
         embedded_att = torch.ones(embedded_image.size()[:-1], dtype=torch.long, device=device)
         if prompt is None:

@@ -44,7 +44,10 @@ def load_image_from_base64(image):                                   # serve/uti
 
 
 def process_images(image, image_processor):                          # serve/util.py:126-129
-    return image_processor(image).unsqueeze(0)
+    out = image_processor(image)
+    if not torch.is_tensor(out):                                     # HF-style processor (the v2 tower's): {"pixel_values": ...}
+        out = out["pixel_values"]
+    return out if out.dim() == 4 else out.unsqueeze(0)
 
 
 def load_pretrained_model(model_path, device="cuda", **kwargs):      # model/builder.py:6-11
@@ -53,7 +56,7 @@ def load_pretrained_model(model_path, device="cuda", **kwargs):      # model/bui
     tokenizer = model.model.svg_transformer.tokenizer
     # the reference builds a host ImageTrainProcessor() for every checkpoint; the engine-side processor of the tower gives
     # the same float32 tensor bit for bit (sv_preprocess_image) without leaving the GPU, and is the right recipe for v2
-    image_processor = model.model.processor
+    image_processor = model.model.image_encoder.processor
     context_len = model.model.query_length + model.model.max_length
     return tokenizer, model, image_processor, context_len
 

@@ -297,3 +297,27 @@ def test_scoring_forward_accepts_right_padded_masks_only():
         m.forward(vis, ids, 2, torch.tensor([[1] * 7, [1, 1, 0, 1, 1, 1, 1]]), 4)        # a hole
     with pytest.raises(ValueError):
         m.forward(vis, ids, 2, torch.ones(2, 4, dtype=torch.long)[:, :3] * torch.tensor([[1, 1, 0]]), 4)
+
+
+def test_simple_starvector_processor_is_hf_style():
+    """starvector_arch.py:17-90 (what `starvector.model.processor` is for a v1 checkpoint; scripts/quickstart-hf.py)."""
+    from PIL import Image
+    from starvector_amd import SimpleStarVectorProcessor
+    tok = ByteTokenizer(49152)
+    proc = SimpleStarVectorProcessor(tok, size=224)
+    g = torch.Generator().manual_seed(1)
+    rgb = Image.fromarray((torch.rand(100, 160, 3, generator=g) * 255).to(torch.uint8).numpy(), "RGB")
+    one = proc(rgb, return_tensors="pt")["pixel_values"]
+    assert one.shape == (3, 224, 224) and torch.equal(one, ImageTrainProcessor(size=224)(rgb))
+    assert proc(images=[rgb, rgb]).pixel_values.shape == (2, 3, 224, 224)
+    # RGBA: the alpha band is dropped (img.convert("RGB")), NOT composited on white like ImageTrainProcessor does
+    rgba = Image.new("RGBA", (224, 224), (10, 200, 30, 0))
+    x = proc(rgba)["pixel_values"]
+    dropped = (torch.tensor([10, 200, 30]) / 255.0 - torch.tensor(sva.model.CLIP_MEAN)) / torch.tensor(sva.model.CLIP_STD)
+    torch.testing.assert_close(x[:, 5, 5], dropped, rtol=0, atol=1e-6)
+    white = (1.0 - torch.tensor(sva.model.CLIP_MEAN)) / torch.tensor(sva.model.CLIP_STD)
+    torch.testing.assert_close(ImageTrainProcessor(size=224)(rgba)[:, 5, 5], white, rtol=0, atol=1e-5)
+    enc = proc(text=["ab", "abcd"], images=rgb)
+    assert enc["input_ids"].shape == (2, 4) and enc["pixel_values"].shape == (3, 224, 224)
+    with pytest.raises(ValueError):
+        proc()
