@@ -177,6 +177,17 @@ int  sv_embed_tokens(sv_engine* e, const int64_t* dev_ids, int32_t n, void* dev_
 int  sv_preprocess_image(const uint8_t* dev_pixels, int32_t width, int32_t height, int32_t channels, int32_t out_size,
                          int32_t recipe, const float* mean3, const float* std3, float* dev_out, sv_stream stream);
 
+/* Host-side decisions of the library, callable WITHOUT a GPU (the CPU test suite pins them):
+ *   sv_debug_resample_coeffs  the fixed-point table sv_preprocess_image feeds its two passes = Pillow's
+ *                             precompute_coeffs + normalize_coeffs_8bpc (libImaging/Resample.c) for BICUBIC, box (0, in_size):
+ *                             bounds [out_size][2] = (first input index, tap count), taps [out_size][cap]; returns ksize
+ *                             (> 0) or SV_EINVAL when cap < ksize
+ *   sv_debug_gemm_plan        what the big-M GEMM dispatch does with an M x N x K problem: out5 = {peel the row remainder,
+ *                             remainder rows, remainder as a 128^2 tile row (else one wave per 32x32 tile), main part on the
+ *                             256^2 kernel, modelled time in us}; every choice computes the same bits */
+int  sv_debug_resample_coeffs(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* taps, int32_t cap);
+int  sv_debug_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t act, int32_t* out5);
+
 /* Prompt pass over inputs_embeds [B,S0,hidden] bf16 (all-ones attention mask): fills the paged KV
  * cache and writes the last-row logits [B, vocab] fp32 (bf16-rounded values, as the reference's
  * bf16 lm_head produces). */

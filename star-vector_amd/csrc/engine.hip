@@ -1399,6 +1399,17 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
 }
 
 // ------------------------------------------------------------------------------------------------
+// C ABI: host-side decisions, callable without a GPU (CPU tests)
+// ------------------------------------------------------------------------------------------------
+extern "C" int sv_debug_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t act, int32_t* out5) {
+    if (!out5 || M < 1 || N < 1 || K < 1) return fail(SV_EINVAL, "sv_debug_gemm_plan: bad argument");
+    const GemmPlan pl = gemm_plan(M, N, K, act, 1);
+    out5[0] = pl.peel; out5[1] = pl.tail_rows; out5[2] = pl.tail_by_tiles; out5[3] = pl.main_256;
+    out5[4] = (int32_t)(pl.est_us + 0.5);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // C ABI: image pre-processing on device (no engine handle: it depends on nothing but the pixels)
 // ------------------------------------------------------------------------------------------------
 extern "C" int sv_preprocess_image(const uint8_t* dev_pixels, int32_t width, int32_t height, int32_t channels,

@@ -685,19 +685,35 @@ static void launch_gemm_tiles(const GemmArgs& a, hipStream_t st, bool force128 =
         gemm_bf16_kernel<bf16_t, 0><<<grid, 256, 2 * GB_BUF, st>>>(a);
 }
 
+// The dispatch decision for an M x N x K big-M GEMM as plain host arithmetic (exported for the CPU tests through
+// sv_debug_gemm_plan): peel the row remainder or not, how the remainder runs, and which tile kernel the main part takes.
+GemmPlan gemm_plan(int M, int N, int K, int act, int tail_on) {
+    GemmPlan pl;
+    const int tail = M % 256, main_rows = M - tail;
+    bool peel = tail_on && tail > 0 && tail <= 96 && main_rows >= 2048;
+    // two ways to do the remainder: one wave per 32x32 tile (good for few column tiles / long K), or one row of 128^2
+    // tiles (LDS-shared operands: good for wide N, but a single block per 128 columns walks the whole K alone)
+    const double t_wave = tail_us(tail, N, K), t_tile = 10.0 + 0.03 * (double)K;   // measured: a lone K=2048 tile row ~70 us
+    const bool tail_by_tiles = t_tile < t_wave;
+    if (peel && tail_on == 1)
+        peel = tiles_us(M, N, K, act, nullptr) - tiles_us(main_rows, N, K, act, nullptr) > (tail_by_tiles ? t_tile : t_wave);
+    pl.peel = peel ? 1 : 0;
+    pl.tail_rows = peel ? tail : 0;
+    pl.tail_by_tiles = peel && tail_by_tiles ? 1 : 0;
+    bool use256 = false;
+    pl.est_us = tiles_us(peel ? main_rows : M, N, K, act, &use256) + (peel ? (tail_by_tiles ? t_tile : t_wave) : 0.0);
+    pl.main_256 = use256 ? 1 : 0;
+    return pl;
+}
+
 void launch_gemm(const GemmArgs& a, hipStream_t st) {
     // a small remainder over a multiple of 256 rows is peeled off to the tail kernel when the model says the saved
     // round is worth more than the tail kernel costs (SV_GEMM_TAIL: 0 never, 2 always, default 1 = model)
     const char* et = getenv("SV_GEMM_TAIL");
     const int tail_on = et ? atoi(et) : 1;
+    const GemmPlan pl = gemm_plan(a.M, a.N, a.K, a.act, tail_on);
     const int tail = a.M % 256, main_rows = a.M - tail;
-    bool peel = tail_on && tail > 0 && tail <= 96 && main_rows >= 2048;
-    // two ways to do the remainder: one wave per 32x32 tile (good for few column tiles / long K), or one row of 128^2
-    // tiles (LDS-shared operands: good for wide N, but a single block per 128 columns walks the whole K alone)
-    const double t_wave = tail_us(tail, a.N, a.K), t_tile = 10.0 + 0.03 * (double)a.K;   // measured: a lone K=2048 tile row ~70 us
-    const bool tail_by_tiles = t_tile < t_wave;
-    if (peel && tail_on == 1)
-        peel = tiles_us(a.M, a.N, a.K, a.act, nullptr) - tiles_us(main_rows, a.N, a.K, a.act, nullptr) > (tail_by_tiles ? t_tile : t_wave);
+    const bool peel = pl.peel != 0, tail_by_tiles = pl.tail_by_tiles != 0;
     if (peel) {
         GemmArgs m = a;
         m.M = main_rows;

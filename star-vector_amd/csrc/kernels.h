@@ -32,6 +32,9 @@ struct GemmArgs {
     const float* cscale = nullptr;   // fp8 weights: per-output-column scale applied to the accumulator (or nullptr)
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
+// what launch_gemm decides for a shape (host arithmetic only; tail_on: 0 never peel, 1 cost model, 2 always)
+struct GemmPlan { int peel, tail_rows, tail_by_tiles, main_256; double est_us; };
+GemmPlan gemm_plan(int M, int N, int K, int act, int tail_on);
 
 // ---- skinny (M<=32 per tile) weight-streaming GEMM --------------------------------------------
 enum { SK_OUT_PARTIAL = 0, SK_OUT_PACKED_ACT = 1, SK_OUT_F32 = 2, SK_OUT_RESID = 3, SK_OUT_ROWMAJOR = 4 };

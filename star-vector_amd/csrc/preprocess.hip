@@ -197,3 +197,20 @@ int preprocess_image(const uint8_t* dev_pixels, int width, int height, int chann
 }
 
 }  // namespace sv
+
+// Host-only test surface (callable without a GPU): the fixed-point resampling table the device passes consume, so the
+// CPU suite can hold it against the oracle's restatement of Pillow's precompute_coeffs / normalize_coeffs_8bpc.
+// bounds [out_size][2] (first input index, tap count), taps [out_size][cap] (row stride = cap >= ksize); returns ksize.
+extern "C" int sv_debug_resample_coeffs(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* taps, int32_t cap) {
+    if (in_size < 1 || out_size < 1 || !bounds || !taps) return -22;
+    std::vector<int32_t> b, t;
+    const int ksize = sv::pp_coeffs(in_size, out_size, b, t);
+    if (ksize > cap) return -22;
+    for (int i = 0; i < out_size; ++i) {
+        bounds[2 * i] = b[2 * i];
+        bounds[2 * i + 1] = b[2 * i + 1];
+        for (int k = 0; k < cap; ++k) taps[(size_t)i * cap + k] = k < ksize ? t[(size_t)i * ksize + k] : 0;
+    }
+    return ksize;
+}
+

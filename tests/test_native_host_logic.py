@@ -1,0 +1,68 @@
+"""CPU: host-side decisions that live inside libstarvector_hip.so, through its C ABI (no GPU involved).
+
+  * the fixed-point resampling table of `sv_preprocess_image` against the oracle's restatement of Pillow's
+    precompute_coeffs / normalize_coeffs_8bpc (which `oracle/image_preprocess.py::pin` holds to Pillow itself);
+  * the big-M GEMM dispatch (tile kernel / row-remainder peeling) at the shapes whose A/B measurements are committed in
+    profiles/gemm_r01_dispatch_ab.log."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from oracle.image_preprocess import resample_coeffs
+from starvector_amd import _lib
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _lib.load()
+
+
+@pytest.mark.parametrize("in_size,out_size", [(517, 224), (224, 224), (100, 224), (1024, 384), (50, 224), (3000, 224),
+                                              (225, 224), (223, 224), (384, 384), (640, 384), (7, 5), (1, 3), (16384, 224)])
+def test_resample_table_is_pillows(lib, in_size, out_size):
+    cap = int(math.ceil(2.0 * max(in_size / out_size, 1.0))) * 2 + 1           # Resample.c: ksize
+    b = (C.c_int32 * (2 * out_size))()
+    t = (C.c_int32 * (out_size * cap))()
+    k = lib.sv_debug_resample_coeffs(in_size, out_size, b, t, cap)
+    rb, rt = resample_coeffs(in_size, out_size)
+    assert k == rt.shape[1] == cap
+    assert np.array_equal(np.array(b).reshape(out_size, 2), rb)
+    assert np.array_equal(np.array(t).reshape(out_size, cap), rt)              # bit for bit: integer taps
+    assert lib.sv_debug_resample_coeffs(in_size, out_size, b, t, cap - 1) == -22   # table would not fit: SV_EINVAL
+    if in_size != out_size:                                                    # every row of taps sums to ~1.0 in 22-bit fixed point
+        sums = np.array(t).reshape(out_size, cap).sum(axis=1)
+        assert np.abs(sums - (1 << 22)).max() <= cap
+
+
+def _plan(lib, M, N, K, act=0):
+    out = (C.c_int32 * 5)()
+    assert lib.sv_debug_gemm_plan(M, N, K, act, out) == 0
+    return dict(peel=out[0], tail_rows=out[1], tail_by_tiles=out[2], main_256=out[3], est_us=out[4])
+
+
+def test_gemm_dispatch_at_the_measured_shapes(lib):
+    # StarVector-1B prefill, batch 32: 32 x 259 = 8288 rows = 32 tiles of 256 + 96 (profiles/gemm_r01_dispatch_ab.log:
+    # "auto" tracks the faster of peel / no-peel at every one of these shapes)
+    assert _plan(lib, 8288, 2304, 2048)["peel"] == 0                         # c_attn: no-peel 102.6 us vs peel 112.4 us
+    p = _plan(lib, 8288, 2048, 2048)                                         # c_proj: peel 100.1 vs 108.3
+    assert (p["peel"], p["tail_rows"], p["main_256"]) == (1, 96, 1)
+    assert _plan(lib, 8288, 8192, 2048, act=3)["peel"] == 0                  # c_fc (GELU): 374.0 vs 376.3
+    p = _plan(lib, 8288, 2048, 8192)                                         # down-proj: peel 275.2 vs 353.5
+    assert (p["peel"], p["tail_rows"], p["main_256"]) == (1, 96, 1)
+    # ViT, batch 32: 32 x 257 = 8224 rows = 32 tiles + 32 rows
+    assert _plan(lib, 8224, 3072, 1024)["peel"] == 0
+    assert _plan(lib, 8224, 1024, 1024)["peel"] == 1 and _plan(lib, 8224, 1024, 4096)["peel"] == 1
+    # nothing to peel: exact multiples, small problems (a peeled main part must still fill the chip), large remainders
+    for M, N, K in [(8192, 3072, 1024), (1036, 2048, 2048), (259, 2048, 2048), (8192 + 128, 2048, 2048)]:
+        p = _plan(lib, M, N, K)
+        assert (p["peel"], p["tail_rows"], p["tail_by_tiles"]) == (0, 0, 0), (M, N, K)
+    # the 256^2 kernel only when its grid fills the chip (>= 200 tiles): B = 4 prefill stays on 128^2
+    assert _plan(lib, 4 * 259, 8192, 2048)["main_256"] == 0
+    # the modelled time is within 15 % of the measured one at the prefill shapes
+    for (M, N, K, act), us in {(8288, 2304, 2048, 0): 104.8, (8288, 2048, 2048, 0): 100.1, (8288, 8192, 2048, 3): 378.1,
+                               (8288, 2048, 8192, 0): 274.4}.items():
+        assert abs(_plan(lib, M, N, K, act)["est_us"] - us) / us < 0.15
+    out = (C.c_int32 * 5)()
+    assert lib.sv_debug_gemm_plan(0, 8, 8, 0, out) == -22
