@@ -110,3 +110,41 @@ def test_product_path_has_no_cpu_fallback():
     for fn in os.listdir(src_dir):
         if fn.endswith(".py"):
             assert "oracle" not in open(os.path.join(src_dir, fn)).read().replace("oracle/", "").lower() or fn == "never"
+
+
+def test_argument_validation_precedes_any_device_work(lib):
+    """Every entry point rejects bad arguments with SV_EINVAL and a message before it touches the GPU (so the same checks
+    run here, without one); a valid configuration fails loudly with SV_EHIP -- there is no CPU path to fall into."""
+    import torch
+    from starvector_amd._lib import SvBeamConfig, SvConfig
+
+    def err():
+        return lib.sv_last_error().decode()
+
+    n, h = C.c_int32(0), C.c_void_p()
+    assert lib.sv_generate(None, None, 1, 4, None, None, C.byref(n), None) == -22 and "null engine" in err()
+    assert lib.sv_prefill(None, None, 1, 4, None, None) == -22
+    assert lib.sv_decode_step(None, None, 1, None, None) == -22
+    assert lib.sv_encode_image(None, None, 1, None, None) == -22
+    assert lib.sv_weights_complete(None) == -22
+    assert lib.sv_load_weight(None, b"x", None, 0, 1, None, None) == -22
+    ok3, bad3 = (C.c_float * 3)(0.5, 0.5, 0.5), (C.c_float * 3)(0.5, 0.0, 0.5)
+    p = C.c_void_p(16)                                         # never dereferenced: the checks come first
+    assert lib.sv_preprocess_image(None, 10, 10, 3, 224, 0, ok3, ok3, None, None) == -22
+    assert lib.sv_preprocess_image(p, 10, 10, 3, 224, 7, ok3, ok3, p, None) == -22 and "recipe" in err()
+    assert lib.sv_preprocess_image(p, 10, 10, 3, 224, 0, ok3, bad3, p, None) == -22 and "std" in err()
+    assert lib.sv_preprocess_image(p, 10, 10, 2, 224, 0, ok3, ok3, p, None) == -22 and "channels" in err()
+    assert lib.sv_preprocess_image(p, 0, 10, 3, 224, 0, ok3, ok3, p, None) == -22
+    assert lib.sv_beam_create(C.byref(SvBeamConfig()), C.byref(h)) == -22 and "bad shape" in err()
+    assert lib.sv_beam_create(C.byref(SvBeamConfig(batch=2000, num_beams=2, vocab=100, max_new=4)), C.byref(h)) == -22
+    for field, val, msg in [("patch_size", 15, "patch_size"), ("n_head", 15, "heads"), ("weight_dtype", 9, "weight_dtype"),
+                            ("sliding_window", 5, "sliding_window"), ("max_seq_len", 1, "max_seq_len"),
+                            ("max_seq_len", 9000, "max_seq_len"), ("arch", 4, "arch"), ("max_batch", 0, "max_batch")]:
+        c = SvConfig()
+        lib.sv_config_default_1b(C.byref(c))
+        setattr(c, field, val)
+        assert lib.sv_create(C.byref(c), C.byref(h)) == -22 and msg in err(), (field, err())
+    if not torch.cuda.is_available():
+        c = SvConfig()
+        lib.sv_config_default_1b(C.byref(c))
+        assert lib.sv_create(C.byref(c), C.byref(h)) == -5 and "hipSetDevice" in err()
