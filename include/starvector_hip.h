@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SV_ABI_VERSION 3
+#define SV_ABI_VERSION 4
 #define SV_WEIGHT_BF16 0
 #define SV_WEIGHT_FP8_E4M3 1
 
@@ -264,6 +264,22 @@ int  sv_bench_linear(int32_t M, int32_t N, int32_t K, int32_t act, int32_t resid
  * 1 bias+GELU fragment order, 3 bias+residual+statistics, 4 bias row-major) */
 int  sv_bench_decode_linear(int32_t M, int32_t N, int32_t K, int32_t splitk, int32_t ln, int32_t mode,
                             int32_t iters, double* avg_us, sv_stream stream);
+/* The full-K decode GEMMs of the default pipeline (csrc/decode_gemm.hip; gpt_bigcode/modeling_gpt_bigcode.py:694-755), one at a time:
+ *   sv_op_decode_cols      y[M,N] = LN_opt(x)[M,K] . W[N,K]^T + bias; with `residual` [M,N]: y = bf16(residual + bf16(.)).
+ *                          A block owns `cpb` output columns (0 = the engine's choice) over the whole K; the LayerNorm
+ *                          (gamma/beta not NULL; two-pass statistics like nn.LayerNorm) is computed inside the block.
+ *                          y: bf16 [M][N], or float32 when out_f32 != 0 (no residual then).  K %% 32 == 0.
+ *   sv_op_decode_skinny_ln y[M,N] = act(LN(x) . W^T + bias) as bf16 rows (N %% 8 == 0), or with out_f32 the lm_head form:
+ *                          float32 rows holding bf16-rounded values (bias ignored).
+ *   sv_bench_decode_gemm   average microseconds per launch over `iters` back-to-back launches; kind 0 cols row-major,
+ *                          1 cols + LayerNorm prologue, 2 cols bias + residual, 3 skinny_ln GELU, 4 skinny_ln fp32 logits */
+int  sv_op_decode_cols(const void* x, const void* gamma, const void* beta, float eps, const void* W, const void* bias,
+                       const void* residual, void* y, int32_t M, int32_t N, int32_t K, int32_t cpb, int32_t out_f32,
+                       sv_stream stream);
+int  sv_op_decode_skinny_ln(const void* x, const void* gamma, const void* beta, float eps, const void* W, const void* bias,
+                            void* y, int32_t M, int32_t N, int32_t K, int32_t act, int32_t out_f32, sv_stream stream);
+int  sv_bench_decode_gemm(int32_t M, int32_t N, int32_t K, int32_t kind, int32_t cpb, int32_t iters, double* avg_us,
+                          sv_stream stream);
 /* f32 -> bf16 through the hardware convert used inside the kernels (rounding-mode check) */
 int  sv_op_cvt_bf16_hw(const float* x, void* y, int64_t n, sv_stream stream);
 /* q,k,v token-major [B,S,H*D] / [B,S,Hkv*D]; out [B,S,H*D] */

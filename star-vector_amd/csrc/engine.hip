@@ -124,6 +124,7 @@ struct Linear {
     uint8_t* Wq = nullptr;     //   decode image (launch_pack_weight_fp8); Wp then holds the SAME q values as bf16
     float* wscale = nullptr;   //   per-output-row scale [Npad]
     int N = 0, K = 0, Npad = 0, Kpad = 0;
+    int cpb = 8;          // decode-path columns per block (full-K pipeline, decode_gemm.hip)
     int splitk = 1;       // decode-path split-K factor (slab pipeline)
     int splitk_fused = 1; // decode-path split-K factor (fused pipeline: ticket merge)
 };
@@ -207,6 +208,9 @@ struct sv_engine {
     int cached_B = 0;
     int num_cus = 256;
     bool fused_decode = false;   // SV_DECODE_FUSED=1: LN-prologue / ticket pipeline (5 launches per layer)
+    bool cols_decode = false;    // SV_DECODE_PIPE=cols: full-K pipeline (decode_gemm.hip), 5 launches per layer, no hand-offs.
+                                 // Parity-green but measured SLOWER than the 7-launch slab pipeline (1453 vs 1336 us per step,
+                                 // profiles/decode_gemm_r02_fullk_vs_slabs.log): LayerNorm repeated in every block is VALU-bound
     double timing[3] = {0, 0, 0};
     double timing_graph = 0;
     // generation runs on an engine-owned non-blocking stream (the caller's stream may be the legacy
@@ -420,6 +424,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
 
     if (int ar = init_attention_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
     if (int ar = init_gemm_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
+    if (int ar = init_decode_gemm_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
 
     sv_engine* e = new sv_engine();
     e->cfg = c;
@@ -616,6 +621,18 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     e->fused_decode = getenv("SV_DECODE_FUSED") != nullptr && atoi(getenv("SV_DECODE_FUSED")) != 0;
     if (v2) e->fused_decode = false;       // the alternative pipelines are v1-only experiments
     if (c.weight_dtype == SV_WEIGHT_FP8_E4M3) { e->fused_decode = false; e->overlap = 0; }
+    {
+        const char* pipe = getenv("SV_DECODE_PIPE");
+        e->cols_decode = pipe && strcmp(pipe, "cols") == 0;
+        if (e->fused_decode || e->overlap) e->cols_decode = false;
+        if (c.weight_dtype == SV_WEIGHT_FP8_E4M3) e->cols_decode = false;      // fp8 weights stream through the slab kernels
+        if (D % 32 || F % 32 || (D / 16) % 2) e->cols_decode = false;
+        for (DecLayer& L : e->dec) {
+            L.c_attn.cpb = cols_pick_cpb(L.c_attn.N);
+            L.c_proj.cpb = cols_pick_cpb(L.c_proj.N);
+            L.c_proj2.cpb = cols_pick_cpb(L.c_proj2.N);
+        }
+    }
     if (rc) { sv_destroy(e); return rc; }
     *out = e;
     return 0;
@@ -1000,8 +1017,86 @@ static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
     prof_mark(e, PK_SAMPLE, st);      // closes the lm_head interval; whatever follows is sampling
 }
 
+// full-K pipeline (SV_DECODE_PIPE=cols): 5 launches per layer, no split-K slabs, no hand-offs (decode_gemm.hip)
+//   c_attn [LN1 prologue, +bias -> q|k|v rows] | attention | c_proj [+bias +residual -> h] | c_fc [LN2 prologue, +bias, GELU]
+//   | c_proj [+bias +residual -> h] ; lm_head [ln_f prologue].  h lives in fragment order (e->h_xp).
+static void decode_forward_cols(sv_engine* e, int B, hipStream_t st) {
+    const sv_config& c = e->cfg;
+    const int D = c.hidden, dh = e->dh, F = c.n_inner, MT = (B + 31) / 32;
+    if (!e->only_skinny) {
+        EmbedRowsArgs er;
+        memset(&er, 0, sizeof(er));
+        er.wte = e->wte; er.wpe = e->wpe; er.tokens = e->cur_tok; er.positions = e->positions;
+        er.h_xp = e->h_xp; er.stats = e->ln_stats; er.M = B; er.D = D;
+        prof_mark(e, PK_ROWLN, st);
+        launch_embed_rows(er, st);
+    }
+    for (int i = 0; i < c.n_layer; ++i) {
+        DecLayer& L = e->dec[i];
+        {   // c_attn over LN1(h) -> q|k|v rows (bf16, bias added)
+            ColsArgs a;
+            memset(&a, 0, sizeof(a));
+            a.xp = e->h_xp; a.Wp = L.c_attn.Wp; a.bias = L.c_attn.bias; a.MT = MT; a.N = L.c_attn.N; a.K = L.c_attn.Kpad;
+            a.cpb = L.c_attn.cpb; a.ln_g = L.ln1.g; a.ln_b = L.ln1.b; a.ln_eps = c.ln_eps;
+            a.out_mode = CO_ROWMAJOR; a.out_rm = e->qkv_rm; a.ld_rm = e->ldq;
+            prof_mark(e, PK_SKINNY, st);
+            launch_gemm_cols(a, st);
+        }
+        if (!e->only_skinny) {
+            AttnDecodeArgs ad;
+            memset(&ad, 0, sizeof(ad));
+            ad.qkv = e->qkv_rm; ad.ld_qkv = e->ldq;
+            ad.pool_layer = e->kv_pool + (size_t)i * e->layer_stride; ad.block_table = e->block_table;
+            ad.max_pages = e->pages_per_seq; ad.positions = e->positions; ad.out_xp = e->xp_attn; ad.out_KS = (c.n_head * dh) / 16;
+            ad.window = c.sliding_window;
+            ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
+            ad.part = e->attn_part; ad.counters = e->attn_cnt;
+            { const int ms = e->num_cus / (B * e->nkv); ad.max_splits = ms < 1 ? 1 : (ms > 16 ? 16 : ms); }
+            ad.n_kv = e->nkv; ad.kv_head_stride = e->kv_head_stride; ad.rope_cos = e->rope_cos; ad.rope_sin = e->rope_sin;
+            prof_mark(e, PK_ATTN, st);
+            launch_attn_decode(ad, st);
+        }
+        {   // attention output projection, + bias + residual -> h
+            ColsArgs a;
+            memset(&a, 0, sizeof(a));
+            a.xp = e->xp_attn; a.Wp = L.c_proj.Wp; a.bias = L.c_proj.bias; a.MT = MT; a.N = L.c_proj.N; a.K = L.c_proj.Kpad;
+            a.cpb = L.c_proj.cpb; a.out_mode = CO_RESID_XP; a.h_xp = e->h_xp; a.out_KS = D / 16;
+            prof_mark(e, PK_SKINNY, st);
+            launch_gemm_cols(a, st);
+        }
+        {   // c_fc over LN2(h), bias + GELU -> fragment-order activations
+            SkinnyLnArgs a;
+            memset(&a, 0, sizeof(a));
+            a.xp = e->h_xp; a.Wp = L.c_fc.Wp; a.bias = L.c_fc.bias; a.MT = MT; a.Npad = L.c_fc.Npad; a.N = L.c_fc.N; a.K = L.c_fc.Kpad;
+            a.ln_g = L.ln2.g; a.ln_b = L.ln2.b; a.ln_eps = c.ln_eps;
+            a.out_mode = SK_OUT_PACKED_ACT; a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16;
+            prof_mark(e, PK_SKINNY, st);
+            launch_gemm_skinny_ln(a, st);
+        }
+        {   // down projection, + bias + residual -> h
+            ColsArgs a;
+            memset(&a, 0, sizeof(a));
+            a.xp = e->xp_mlp; a.Wp = L.c_proj2.Wp; a.bias = L.c_proj2.bias; a.MT = MT; a.N = L.c_proj2.N; a.K = L.c_proj2.Kpad;
+            a.cpb = L.c_proj2.cpb; a.out_mode = CO_RESID_XP; a.h_xp = e->h_xp; a.out_KS = D / 16;
+            prof_mark(e, PK_SKINNY, st);
+            launch_gemm_cols(a, st);
+        }
+    }
+    {   // lm_head over ln_f(h): fp32 logits rounded to bf16 values
+        SkinnyLnArgs a;
+        memset(&a, 0, sizeof(a));
+        a.xp = e->h_xp; a.Wp = e->lm_head.Wp; a.MT = MT; a.Npad = e->lm_head.Npad; a.N = e->lm_head.N; a.K = e->lm_head.Kpad;
+        a.ln_g = e->ln_f.g; a.ln_b = e->ln_f.b; a.ln_eps = c.ln_eps;
+        a.out_mode = SK_OUT_F32; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1;
+        prof_mark(e, PK_SKINNY, st);
+        launch_gemm_skinny_ln(a, st);
+    }
+    prof_mark(e, PK_SAMPLE, st);
+}
+
 static void decode_forward(sv_engine* e, int B, hipStream_t st) {
-    if (e->fused_decode) decode_forward_fused(e, B, st);
+    if (e->cols_decode) decode_forward_cols(e, B, st);
+    else if (e->fused_decode) decode_forward_fused(e, B, st);
     else decode_forward_slabs(e, B, st);
 }
 
@@ -1556,7 +1651,7 @@ extern "C" int sv_profile_decode_step(sv_engine* e, int32_t B, int32_t iters, do
     out[2 * PK_SAMPLE] = overhead_ms;         // slot 6: time between two back-to-back events with no kernel
     // slot 7: the step's weight-streaming GEMMs alone, back to back between ONE event pair: average
     // dispatch-to-dispatch time per launch (what rocprofv3's kernel trace calls the kernel duration)
-    if (!e->fused_decode && !e->overlap) {
+    if (e->cols_decode || (!e->fused_decode && !e->overlap)) {
         hipEvent_t a, b;
         HIPCHECK(hipEventCreate(&a)); HIPCHECK(hipEventCreate(&b));
         e->only_skinny = true;
@@ -1821,6 +1916,138 @@ extern "C" int sv_bench_decode_linear(int32_t M, int32_t N, int32_t K, int32_t s
     for (int i = 0; i < 3; ++i) launch_gemm_skinny(a, st);
     HIPCHECK(hipEventRecord(e0, st));
     for (int i = 0; i < iters; ++i) launch_gemm_skinny(a, st);
+    HIPCHECK(hipEventRecord(e1, st));
+    HIPCHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *avg_us = (double)ms * 1e3 / iters;
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+// the full-K decode GEMMs on their own (decode_gemm.hip).  Row-major in, row-major out; packing is done here.
+//   sv_op_decode_cols:      y[M,N] = LN_opt(x)[M,K] . W^T + bias  (+ residual -> bf16 rows h = bf(res + bf(.)));
+//                           y is bf16 [M][N], or fp32 when out_f32 != 0 (no residual then)
+//   sv_op_decode_skinny_ln: y[M,N] = act(LN(x) . W^T + bias) as bf16 rows, or (out_f32) fp32 rows rounded to bf16 values, no bias
+extern "C" int sv_op_decode_cols(const void* x, const void* gamma, const void* beta, float eps, const void* W, const void* bias,
+                                 const void* residual, void* y, int32_t M, int32_t N, int32_t K, int32_t cpb, int32_t out_f32,
+                                 sv_stream stream) {
+    if (!x || !W || !y || M < 1 || N < 1 || K < 32 || K % 32) return fail(SV_EINVAL, "sv_op_decode_cols: bad argument (K %% 32 == 0 required)");
+    if ((gamma == nullptr) != (beta == nullptr)) return fail(SV_EINVAL, "gamma and beta go together");
+    if (residual && (out_f32 || N % 16)) return fail(SV_EINVAL, "residual mode writes bf16 rows and needs N %% 16 == 0");
+    if (cpb == 0) cpb = cols_pick_cpb(N);
+    if (cpb < 1 || cpb > 16) return fail(SV_EINVAL, "cpb must be 1..16 (0 = automatic)");
+    if (int ar = init_decode_gemm_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
+    hipStream_t st = (hipStream_t)stream;
+    TmpBufs tmp;
+    const int Npad = round_up(N, 32), MT = (M + 31) / 32, R = MT * 32;
+    bf16_t *Wp, *xp, *hxp, *orm;
+    float* of;
+    SVCHECK(tmp.get(&Wp, (size_t)Npad * K));
+    SVCHECK(tmp.get(&xp, (size_t)R * K));
+    SVCHECK(tmp.get(&hxp, (size_t)R * Npad));
+    SVCHECK(tmp.get(&orm, (size_t)R * Npad));
+    SVCHECK(tmp.get(&of, (size_t)R * Npad));
+    HIPCHECK(hipMemsetAsync(xp, 0, (size_t)R * K * 2, st));
+    HIPCHECK(hipMemsetAsync(hxp, 0, (size_t)R * Npad * 2, st));
+    launch_pack_weight(W, 0, Wp, N, K, Npad, K, st);
+    pack_rows_kernel<<<(M * (K / 8) + 255) / 256, 256, 0, st>>>((const bf16_t*)x, K, xp, M, K);
+    ColsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xp = xp; a.Wp = Wp; a.bias = (const bf16_t*)bias; a.MT = MT; a.N = N; a.K = K; a.cpb = cpb;
+    a.ln_g = (const bf16_t*)gamma; a.ln_b = (const bf16_t*)beta; a.ln_eps = eps;
+    if (residual) {
+        pack_rows_kernel<<<(M * (N / 8) + 255) / 256, 256, 0, st>>>((const bf16_t*)residual, N, hxp, M, N);
+        a.out_mode = CO_RESID_XP; a.h_xp = hxp; a.out_KS = N / 16;
+    } else if (out_f32) {
+        a.out_mode = CO_F32; a.out_f32 = of; a.ldo = Npad;
+    } else {
+        a.out_mode = CO_ROWMAJOR; a.out_rm = orm; a.ld_rm = Npad;
+    }
+    if (launch_gemm_cols(a, st)) return fail(SV_ENOTSUP, "sv_op_decode_cols: no kernel for K=%d", K);
+    if (residual) unpack_rows_kernel<<<(M * (N / 8) + 255) / 256, 256, 0, st>>>(hxp, (bf16_t*)y, N, M, N);
+    else if (out_f32) HIPCHECK(hipMemcpy2DAsync(y, (size_t)N * 4, of, (size_t)Npad * 4, (size_t)N * 4, M, hipMemcpyDeviceToDevice, st));
+    else HIPCHECK(hipMemcpy2DAsync(y, (size_t)N * 2, orm, (size_t)Npad * 2, (size_t)N * 2, M, hipMemcpyDeviceToDevice, st));
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+extern "C" int sv_op_decode_skinny_ln(const void* x, const void* gamma, const void* beta, float eps, const void* W, const void* bias,
+                                      void* y, int32_t M, int32_t N, int32_t K, int32_t act, int32_t out_f32, sv_stream stream) {
+    if (!x || !W || !y || !gamma || !beta || M < 1 || N < 1 || K < 32 || K % 32)
+        return fail(SV_EINVAL, "sv_op_decode_skinny_ln: bad argument");
+    if (!out_f32 && N % 8) return fail(SV_EINVAL, "bf16 output needs N %% 8 == 0");
+    if (int ar = init_decode_gemm_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
+    hipStream_t st = (hipStream_t)stream;
+    TmpBufs tmp;
+    const int Npad = round_up(N, 32), MT = (M + 31) / 32, R = MT * 32;
+    bf16_t *Wp, *xp, *oxp;
+    float* of;
+    SVCHECK(tmp.get(&Wp, (size_t)Npad * K));
+    SVCHECK(tmp.get(&xp, (size_t)R * K));
+    SVCHECK(tmp.get(&oxp, (size_t)R * Npad));
+    SVCHECK(tmp.get(&of, (size_t)R * Npad));
+    HIPCHECK(hipMemsetAsync(xp, 0, (size_t)R * K * 2, st));
+    launch_pack_weight(W, 0, Wp, N, K, Npad, K, st);
+    pack_rows_kernel<<<(M * (K / 8) + 255) / 256, 256, 0, st>>>((const bf16_t*)x, K, xp, M, K);
+    SkinnyLnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xp = xp; a.Wp = Wp; a.bias = (const bf16_t*)bias; a.MT = MT; a.Npad = Npad; a.N = N; a.K = K;
+    a.ln_g = (const bf16_t*)gamma; a.ln_b = (const bf16_t*)beta; a.ln_eps = eps; a.act = act;
+    if (out_f32) { a.out_mode = SK_OUT_F32; a.out_f32 = of; a.ldo = Npad; a.round_bf16 = 1; }
+    else { a.out_mode = SK_OUT_PACKED_ACT; a.out_xp = oxp; a.out_KS = Npad / 16; }
+    if (launch_gemm_skinny_ln(a, st)) return fail(SV_ENOTSUP, "sv_op_decode_skinny_ln: no kernel for K=%d", K);
+    if (out_f32) HIPCHECK(hipMemcpy2DAsync(y, (size_t)N * 4, of, (size_t)Npad * 4, (size_t)N * 4, M, hipMemcpyDeviceToDevice, st));
+    else unpack_rows_kernel<<<(M * (N / 8) + 255) / 256, 256, 0, st>>>(oxp, (bf16_t*)y, N, M, N);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// micro-benchmark of the two kernels (pseudo-random weights, HIP events over `iters` back-to-back launches).
+// kind 0: gemm_cols row-major out; 1: gemm_cols + LayerNorm prologue; 2: gemm_cols bias + residual; 3: skinny_ln GELU; 4: skinny_ln fp32
+extern "C" int sv_bench_decode_gemm(int32_t M, int32_t N, int32_t K, int32_t kind, int32_t cpb, int32_t iters, double* avg_us,
+                                    sv_stream stream) {
+    if (!avg_us || M < 1 || N < 32 || K < 32 || K % 32 || iters < 1 || kind < 0 || kind > 4) return fail(SV_EINVAL, "sv_bench_decode_gemm: bad argument");
+    if (int ar = init_decode_gemm_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
+    hipStream_t st = (hipStream_t)stream;
+    TmpBufs tmp;
+    const int Npad = round_up(N, 32), MT = (M + 31) / 32, R = MT * 32;
+    if (cpb == 0) cpb = cols_pick_cpb(N);
+    bf16_t *Wp, *xp, *hxp, *orm, *gb, *bias;
+    float* of;
+    SVCHECK(tmp.get(&Wp, (size_t)Npad * K));
+    SVCHECK(tmp.get(&xp, (size_t)R * K));
+    SVCHECK(tmp.get(&hxp, (size_t)R * Npad));
+    SVCHECK(tmp.get(&orm, (size_t)R * Npad));
+    SVCHECK(tmp.get(&of, (size_t)R * Npad));
+    SVCHECK(tmp.get(&gb, (size_t)2 * K));
+    SVCHECK(tmp.get(&bias, (size_t)Npad));
+    fill_random_bf16_kernel<<<4096, 256, 0, st>>>(Wp, (size_t)Npad * K, 2u);
+    fill_random_bf16_kernel<<<256, 256, 0, st>>>(xp, (size_t)R * K, 1u);
+    fill_random_bf16_kernel<<<64, 256, 0, st>>>(gb, (size_t)2 * K, 5u);
+    fill_random_bf16_kernel<<<64, 256, 0, st>>>(bias, (size_t)Npad, 3u);
+    HIPCHECK(hipMemsetAsync(hxp, 0, (size_t)R * Npad * 2, st));
+    ColsArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xp = xp; a.Wp = Wp; a.bias = bias; a.MT = MT; a.N = N; a.K = K; a.cpb = cpb;
+    if (kind == 1) { a.ln_g = gb; a.ln_b = gb + K; a.ln_eps = 1e-5f; }
+    if (kind == 2) { a.out_mode = CO_RESID_XP; a.h_xp = hxp; a.out_KS = Npad / 16; }
+    else { a.out_mode = CO_ROWMAJOR; a.out_rm = orm; a.ld_rm = Npad; }
+    SkinnyLnArgs b;
+    memset(&b, 0, sizeof(b));
+    b.xp = xp; b.Wp = Wp; b.bias = bias; b.MT = MT; b.Npad = Npad; b.N = N; b.K = K; b.ln_g = gb; b.ln_b = gb + K; b.ln_eps = 1e-5f;
+    if (kind == 3) { b.out_mode = SK_OUT_PACKED_ACT; b.act = ACT_GELU_TANH; b.out_xp = hxp; b.out_KS = Npad / 16; }
+    else { b.out_mode = SK_OUT_F32; b.out_f32 = of; b.ldo = Npad; b.round_bf16 = 1; }
+    auto once = [&]() { return kind <= 2 ? launch_gemm_cols(a, st) : launch_gemm_skinny_ln(b, st); };
+    if (once()) return fail(SV_ENOTSUP, "sv_bench_decode_gemm: no kernel for this shape");
+    hipEvent_t e0, e1;
+    HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) once();
+    HIPCHECK(hipEventRecord(e0, st));
+    for (int i = 0; i < iters; ++i) once();
     HIPCHECK(hipEventRecord(e1, st));
     HIPCHECK(hipEventSynchronize(e1));
     float ms = 0.f;

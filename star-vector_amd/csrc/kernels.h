@@ -77,6 +77,35 @@ struct SkinnyArgs {
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st);
 int init_gemm_kernels();        // hipFuncSetAttribute for the large-LDS variants (0 = ok)
 
+
+// ---- decode GEMMs with full K per block (decode_gemm.hip): no split-K slabs, LayerNorm as an in-block prologue -----
+enum { CO_ROWMAJOR = 0, CO_RESID_XP = 1, CO_F32 = 2 };
+struct ColsArgs {
+    const bf16_t* xp;                // packed activations [MT][K/16][64][8]; the RAW residual stream when ln_g is set
+    const bf16_t* Wp;                // packed weight [Npad/32][K/16][64][8] (the same image the 32-column kernels read)
+    const bf16_t* bias;              // [N] or nullptr
+    int MT, N, K;                    // K multiple of 32
+    int cpb;                         // output columns per block (1..16): cols_pick_cpb(N)
+    const bf16_t* ln_g; const bf16_t* ln_b; float ln_eps;     // LayerNorm prologue over K (nullptr: off)
+    int out_mode;
+    bf16_t* out_rm; int ld_rm;       // CO_ROWMAJOR: [MT*32][ld_rm] bf16 = bf(x W^T + b)
+    bf16_t* h_xp; int out_KS;        // CO_RESID_XP: residual stream in fragment order, N = 16 * out_KS columns: h = bf(h + bf(x W^T + b))
+    float* out_f32; int ldo;         // CO_F32 (test surface): fp32 x W^T + b
+};
+int cols_pick_cpb(int N);
+int launch_gemm_cols(const ColsArgs& a, hipStream_t st);        // 0 = ok, -1 = unsupported shape
+struct SkinnyLnArgs {
+    const bf16_t* xp;                // packed activations (raw residual stream when ln_g is set)
+    const bf16_t* Wp; const bf16_t* bias;
+    int MT, Npad, N, K;
+    const bf16_t* ln_g; const bf16_t* ln_b; float ln_eps;     // LayerNorm prologue (nullptr: off)
+    int out_mode; int act;           // SK_OUT_PACKED_ACT | SK_OUT_F32
+    bf16_t* out_xp; int out_KS;
+    float* out_f32; int ldo; int round_bf16;
+};
+int launch_gemm_skinny_ln(const SkinnyLnArgs& a, hipStream_t st);
+int init_decode_gemm_kernels();
+
 struct EmbedRowsArgs {
     const bf16_t* rows; int ld_rows;                       // generic: row-major input rows; or nullptr:
     const bf16_t* wte; const bf16_t* wpe;                  //   wte[tokens[row]] + wpe[positions[row]]

@@ -384,6 +384,42 @@ def op_decode_linear(h, W, bias=None, gamma=None, beta=None, residual=None, act=
     return y, stats
 
 
+def op_decode_cols(x, W, bias=None, gamma=None, beta=None, residual=None, cpb=0, out_f32=False, eps=1e-5):
+    """One full-K decode GEMM (csrc/decode_gemm.hip): y = LN_opt(x) . W^T + bias (+ residual, rounded like the reference's
+    bf16 residual add).  Returns bf16 [M, N] (float32 when out_f32)."""
+    lib = _lib.load()
+    x = _need(x, torch.bfloat16, "x"); W = _need(W, torch.bfloat16, "W")
+    M, K = x.shape; N = W.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    opt = lambda t, n: _need(t, torch.bfloat16, n) if t is not None else None
+    b, g, be, r = opt(bias, "bias"), opt(gamma, "gamma"), opt(beta, "beta"), opt(residual, "residual")
+    check(lib.sv_op_decode_cols(_ptr(x), _ptr(g), _ptr(be), float(eps), _ptr(W), _ptr(b), _ptr(r), _ptr(y), M, N, K, int(cpb),
+                                int(out_f32), _stream()), "sv_op_decode_cols")
+    return y
+
+
+def op_decode_skinny_ln(x, W, gamma, beta, bias=None, act="none", out_f32=False, eps=1e-5):
+    """The 32-column-tile decode GEMM with the in-block LayerNorm prologue: act(LN(x) . W^T + bias) as bf16 rows, or (out_f32)
+    the lm_head form: float32 rows of bf16-rounded values."""
+    lib = _lib.load()
+    x = _need(x, torch.bfloat16, "x"); W = _need(W, torch.bfloat16, "W")
+    M, K = x.shape; N = W.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    b = _need(bias, torch.bfloat16, "bias") if bias is not None else None
+    check(lib.sv_op_decode_skinny_ln(_ptr(x), _ptr(_need(gamma, torch.bfloat16, "gamma")), _ptr(_need(beta, torch.bfloat16, "beta")),
+                                     float(eps), _ptr(W), _ptr(b), _ptr(y), M, N, K, _lib.ACT[act], int(out_f32), _stream()),
+          "sv_op_decode_skinny_ln")
+    return y
+
+
+def bench_decode_gemm(M: int, N: int, K: int, kind: int, cpb: int = 0, iters: int = 50) -> float:
+    """Average microseconds per launch of one decode GEMM (kinds: see include/starvector_hip.h)."""
+    lib = _lib.load()
+    us = C.c_double(0.0)
+    check(lib.sv_bench_decode_gemm(M, N, K, kind, cpb, iters, C.byref(us), _stream()), "sv_bench_decode_gemm")
+    return us.value
+
+
 def op_cvt_bf16_hw(x):
     lib = _lib.load()
     x = _need(x, torch.float32, "x")

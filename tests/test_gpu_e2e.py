@@ -334,6 +334,15 @@ def test_alternative_decode_pipelines_stay_correct():
     worst, scale, checked, near, _, _ = _teacher_forced_check(eng, e2, w, cfg, 12)
     assert checked > 0
     eng.close()
+    # the full-K pipeline (csrc/decode_gemm.hip; 5 launches per layer, LayerNorm inside the GEMM blocks): two-pass statistics
+    # in another summation order -> logits within the stated tolerance, streams deterministic and batch-invariant
+    eng, e3, t3 = _gen_with_env({"SV_DECODE_PIPE": "cols"}, cfg, w, emb.cpu(), 24)
+    worst, scale, checked, near, _, _ = _teacher_forced_check(eng, e3, w, cfg, 12)
+    assert checked > 0
+    kw = dict(max_length=e3.shape[1] + 24, eos_token_id=-1, pad_token_id=cfg.pad_token_id)
+    assert torch.equal(t3, eng.generate(e3, **kw).cpu())
+    assert torch.equal(t3[1], eng.generate(e3[1:2].contiguous(), **kw).cpu()[0])
+    eng.close()
 
 
 def test_starvector_8b_op_graph_against_reference_golden():

@@ -306,3 +306,81 @@ def test_preprocess_image_siglip_recipe_bit_exact(w, h, c):
     from starvector_amd.model import SiglipProcessor
     pv = SiglipProcessor(384, dev())(images=[Image.fromarray(px, "RGBA" if c == 4 else "RGB")] * 2).pixel_values
     assert pv.shape == (2, 3, 384, 384) and np.array_equal(pv[1].cpu().numpy().view(np.int32), got.view(np.int32))
+
+
+# ---- the full-K decode GEMMs (csrc/decode_gemm.hip): the default decode pipeline's kernels, one at a time -------------
+def _ln_ref(x, w, b, eps=1e-5):
+    return torch.nn.functional.layer_norm(x, (x.shape[-1],), w, b, eps).bfloat16().float()      # the reference's bf16 LayerNorm output
+
+
+@pytest.mark.parametrize("M,N,K,cpb", [
+    (32, 2048, 2048, 0),        # attention c_proj (1B): 8 columns per block, 16 waves x 4 chunks
+    (32, 2048, 8192, 0),        # MLP c_proj (1B): 16 chunks per wave, streamed in groups
+    (5, 2304, 2048, 0),         # c_attn width: 9 columns per block
+    (40, 256, 1024, 0),         # two row tiles (tiny MLP c_proj)
+    (16, 4608, 18432, 0),       # StarVector-8B MLP c_proj
+    (3, 516, 256, 7), (32, 96, 64, 16), (33, 70, 96, 1),      # odd widths / ragged last block / one column per block
+])
+def test_decode_cols_matches_float32(M, N, K, cpb):
+    g = torch.Generator().manual_seed(M + 3 * N + K)
+    x = torch.randn(M, K, generator=g).bfloat16().float()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().float()
+    b = (0.1 * torch.randn(N, generator=g)).bfloat16().float()
+    ref = x @ W.T + b
+    got32 = E.op_decode_cols(bf(x), bf(W), bf(b), cpb=cpb, out_f32=True)
+    assert rel_err(got32, ref) <= 2e-5                                   # fp32 accumulation: order only
+    got = E.op_decode_cols(bf(x), bf(W), bf(b), cpb=cpb)
+    assert rel_err(got, ref) <= 1.1 * BF16_1ULP
+    if N % 16 == 0:
+        r = torch.randn(M, N, generator=g).bfloat16().float()
+        want = (r + ref.bfloat16().float())                             # h = bf(h + bf(x W^T + b)): gpt_bigcode :694-755
+        res = E.op_decode_cols(bf(x), bf(W), bf(b), residual=bf(r), cpb=cpb)
+        assert rel_err(res, want) <= 1.1 * BF16_1ULP and mean_err(res, want) <= 6e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(32, 2304, 2048), (7, 2304, 2048), (40, 512, 256), (16, 5632, 4608), (9, 640, 768)])
+def test_decode_cols_layernorm_prologue(M, N, K):
+    """LayerNorm computed INSIDE the GEMM block (two-pass statistics over the rows the block reads anyway)."""
+    g = torch.Generator().manual_seed(11 * M + N + K)
+    h = (1.5 * torch.randn(M, K, generator=g) + 0.3).bfloat16().float()
+    gam = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().float()
+    bet = (0.1 * torch.randn(K, generator=g)).bfloat16().float()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().float()
+    b = (0.1 * torch.randn(N, generator=g)).bfloat16().float()
+    ref = _ln_ref(h, gam, bet) @ W.T + b
+    got = E.op_decode_cols(bf(h), bf(W), bf(b), gamma=bf(gam), beta=bf(bet), out_f32=True)
+    # the LayerNorm output is rounded to bf16 before the GEMM on both sides; a 1-ulp flip of one normalised value moves an
+    # output by <= 2^-8 |x| |W| ~ 1e-4 of the output scale
+    assert rel_err(got, ref) <= 1e-3 and mean_err(got, ref) <= 2e-5
+    rows = E.op_decode_cols(bf(h), bf(W), bf(b), gamma=bf(gam), beta=bf(bet))
+    assert rel_err(rows, ref) <= 1.2 * BF16_1ULP
+
+
+@pytest.mark.parametrize("M,N,K,act", [(32, 8192, 2048, "gelu_tanh"), (3, 1024, 256, "gelu_tanh"), (40, 1024, 768, "none"),
+                                       (16, 18432, 4608, "gelu_tanh")])
+def test_decode_skinny_ln_activation(M, N, K, act):
+    g = torch.Generator().manual_seed(5 * M + N + K)
+    h = (1.5 * torch.randn(M, K, generator=g) - 0.2).bfloat16().float()
+    gam = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().float()
+    bet = (0.1 * torch.randn(K, generator=g)).bfloat16().float()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().float()
+    b = (0.1 * torch.randn(N, generator=g)).bfloat16().float()
+    y = (_ln_ref(h, gam, bet) @ W.T + b).bfloat16().float()               # the Linear output is rounded before the activation
+    if act == "gelu_tanh":
+        y = torch.nn.functional.gelu(y, approximate="tanh")
+    got = E.op_decode_skinny_ln(bf(h), bf(W), bf(gam), bf(bet), bias=bf(b), act=act)
+    assert rel_err(got, y) <= 2.2 * BF16_1ULP and mean_err(got, y) <= 6e-4
+
+
+@pytest.mark.parametrize("M,V,K", [(32, 49156, 2048), (2, 516, 256), (16, 49157, 4608)])
+def test_decode_skinny_ln_logits(M, V, K):
+    """lm_head form: ln_f prologue, no bias, float32 logits holding bf16-rounded values (HF casts bf16 logits to float)."""
+    g = torch.Generator().manual_seed(M + V + K)
+    h = (2.0 * torch.randn(M, K, generator=g)).bfloat16().float()
+    gam = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().float()
+    bet = (0.1 * torch.randn(K, generator=g)).bfloat16().float()
+    W = (0.02 * torch.randn(V, K, generator=g)).bfloat16().float()
+    ref = _ln_ref(h, gam, bet) @ W.T
+    got = E.op_decode_skinny_ln(bf(h), bf(W), bf(gam), bf(bet), out_f32=True)
+    assert got.dtype == torch.float32 and torch.equal(got, got.bfloat16().float())      # values are bf16-exact
+    assert rel_err(got, ref) <= 1.2 * BF16_1ULP
