@@ -177,6 +177,16 @@ int  sv_embed_tokens(sv_engine* e, const int64_t* dev_ids, int32_t n, void* dev_
 int  sv_preprocess_image(const uint8_t* dev_pixels, int32_t width, int32_t height, int32_t channels, int32_t out_size,
                          int32_t recipe, const float* mean3, const float* std3, float* dev_out, sv_stream stream);
 
+/* The same recipe for a BATCH of images of any sizes (the serving TTFT path: one call, three launches per 32 images):
+ * dev_pixels / widths / heights / channels are HOST arrays of n entries (device pointers in dev_pixels); dev_out is float32
+ * [n][3][out_size][out_size].  Stateless: the caller owns the workspace (sv_preprocess_workspace_bytes, a host computation),
+ * the fixed-point tap tables are computed on device into it, every per-image parameter travels in the kernel arguments --
+ * no host copy, no lock, no stream synchronisation, no library-owned buffer. */
+int64_t sv_preprocess_workspace_bytes(const int32_t* widths, const int32_t* heights, int32_t n, int32_t out_size, int32_t recipe);
+int  sv_preprocess_images(const uint8_t* const* dev_pixels, const int32_t* widths, const int32_t* heights,
+                          const int32_t* channels, int32_t n, int32_t out_size, int32_t recipe, const float* mean3,
+                          const float* std3, float* dev_out, void* dev_workspace, int64_t workspace_bytes, sv_stream stream);
+
 /* Host-side decisions of the library, callable WITHOUT a GPU (the CPU test suite pins them):
  *   sv_debug_resample_coeffs  the fixed-point table sv_preprocess_image feeds its two passes = Pillow's
  *                             precompute_coeffs + normalize_coeffs_8bpc (libImaging/Resample.c) for BICUBIC, box (0, in_size):

@@ -105,7 +105,27 @@ def _rounder(mode: str):
         return lambda t: t
     if mode == "bf16":
         return lambda t: t.to(torch.bfloat16).to(torch.float32)
+    if mode == "native":
+        # the tensors ARE torch.bfloat16 (weights and inputs cast by the caller, any device): every op rounds where ATen
+        # rounds -- a REAL bf16 execution of the same modules, used as the second comparator of the GPU parity tests
+        # (SURVEY.md section 8c "run the same torch modules in bf16 on GPU when available")
+        return lambda t: t
     raise ValueError(f"unknown mode {mode!r}")
+
+
+def _patch_conv(image: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int) -> Tensor:
+    """Conv2d with kernel = stride = patch (clip_model.py:174; SigLIP patch_embedding).  In "native" bf16 mode on a GPU the
+    convolution is written as the equivalent unfold + matmul so that the comparator does not depend on MIOpen's bf16
+    convolution find step; float32 keeps F.conv2d (what the pinned goldens were minted with)."""
+    if image.dtype == torch.float32:
+        return F.conv2d(image, weight, bias, stride=stride)
+    B, Cc, H, Wd = image.shape
+    G = H // stride
+    x = image.view(B, Cc, G, stride, G, stride).permute(0, 2, 4, 1, 3, 5).reshape(B, G * G, Cc * stride * stride)
+    y = x @ weight.reshape(weight.shape[0], -1).T
+    if bias is not None:
+        y = y + bias
+    return y.permute(0, 2, 1).reshape(B, weight.shape[0], G, G)
 
 
 def _ln(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
@@ -272,6 +292,20 @@ def make_weights(cfg: OracleConfig, seed: int = 1234, init: str = "parity") -> D
     return w
 
 
+def apply_fixture_weights(w: Dict[str, Tensor], cfg: OracleConfig, fixture: Dict[str, Tensor]) -> Dict[str, Tensor]:
+    """Fixtures minted by oracle/make_golden.py::fit_embedding carry a fitted tied embedding table ("wte", bf16): random-init
+    transformers either repeat one token or decide by near-ties, so the table is fitted (a few hundred Adam steps on the
+    oracle itself) until a designed, diverse token stream is the greedy one with a top-1/top-2 margin of a quarter of the
+    logit scale -- far outside bf16 noise, so integer token parity is a hard assertion.  Returns a new dict."""
+    if "wte" not in fixture:
+        return w
+    out = dict(w)
+    t = fixture["wte"].to(torch.float32)
+    out[embed_key(cfg)] = t
+    out[K_LMH] = t
+    return out
+
+
 _CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)   # data/util.py:33-38
 _CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 
@@ -295,7 +329,7 @@ def vit_forward(w: Dict[str, Tensor], cfg: OracleConfig, image: Tensor, mode: st
     Dv, H = cfg.vit_width, cfg.vit_heads
     dh = Dv // H
     # conv1, stride = kernel = patch, no bias (clip_model.py:174,182)
-    x = F.conv2d(image, w[P_VIT + "conv1.weight"], stride=cfg.patch_size)
+    x = _patch_conv(image, w[P_VIT + "conv1.weight"], None, cfg.patch_size)
     x = r(x.reshape(B, Dv, -1).permute(0, 2, 1))                       # :183-184
     cls = r(w[P_VIT + "class_embedding"]).expand(B, 1, Dv)              # :185
     x = torch.cat([cls, x], dim=1)
@@ -334,7 +368,7 @@ def siglip_forward(w: Dict[str, Tensor], cfg: OracleConfig, image: Tensor, mode:
     Dv, H = cfg.vit_width, cfg.vit_heads
     dh = Dv // H
     pe = P_VIT + "embeddings."
-    x = F.conv2d(image, w[pe + "patch_embedding.weight"], w[pe + "patch_embedding.bias"], stride=cfg.patch_size)
+    x = _patch_conv(image, w[pe + "patch_embedding.weight"], w[pe + "patch_embedding.bias"], cfg.patch_size)
     x = r(x.flatten(2).transpose(1, 2))
     x = r(x + w[pe + "position_embedding.weight"])
     for i in range(cfg.vit_layers):

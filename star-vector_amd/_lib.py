@@ -74,6 +74,9 @@ PROTOTYPES = {
     "sv_adapter": (_I, [_P, _P, _I, _P, _P]),
     "sv_embed_tokens": (_I, [_P, _P, _I, _P, _P]),
     "sv_preprocess_image": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P, _P]),
+    "sv_preprocess_workspace_bytes": (C.c_int64, [C.POINTER(_I), C.POINTER(_I), _I, _I, _I]),
+    "sv_preprocess_images": (_I, [C.POINTER(_P), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _I, _I, _I, C.POINTER(_F),
+                                  C.POINTER(_F), _P, _P, C.c_int64, _P]),
     "sv_debug_resample_coeffs": (_I, [_I, _I, C.POINTER(_I), C.POINTER(_I), _I]),
     "sv_debug_gemm_plan": (_I, [_I, _I, _I, _I, C.POINTER(_I)]),
     "sv_prefill": (_I, [_P, _P, _I, _I, _P, _P]),

@@ -1522,6 +1522,37 @@ extern "C" int sv_preprocess_image(const uint8_t* dev_pixels, int32_t width, int
     return 0;
 }
 
+extern "C" int64_t sv_preprocess_workspace_bytes(const int32_t* widths, const int32_t* heights, int32_t n, int32_t out_size,
+                                                 int32_t recipe) {
+    if (!widths || !heights || n < 1 || out_size < 1 || out_size > 4096 || (recipe != 0 && recipe != 1)) return fail(SV_EINVAL, "sv_preprocess_workspace_bytes: bad argument");
+    for (int i = 0; i < n; ++i)
+        if (widths[i] < 1 || heights[i] < 1 || widths[i] > 16384 || heights[i] > 16384) return fail(SV_EINVAL, "sv_preprocess_workspace_bytes: bad image size %dx%d", widths[i], heights[i]);
+    return (int64_t)preprocess_workspace_bytes(widths, heights, n, out_size, recipe);
+}
+
+extern "C" int sv_preprocess_images(const uint8_t* const* dev_pixels, const int32_t* widths, const int32_t* heights,
+                                    const int32_t* channels, int32_t n, int32_t out_size, int32_t recipe, const float* mean3,
+                                    const float* std3, float* dev_out, void* dev_workspace, int64_t workspace_bytes,
+                                    sv_stream stream) {
+    if (recipe != 0 && recipe != 1) return fail(SV_EINVAL, "sv_preprocess_images: recipe must be 0 (ImageTrainProcessor) or 1 (SigLIP processor)");
+    if (!dev_pixels || !widths || !heights || !channels || !dev_out || !mean3 || !std3 || n < 1) return fail(SV_EINVAL, "sv_preprocess_images: null argument or empty batch");
+    if (out_size < 1 || out_size > 4096) return fail(SV_EINVAL, "sv_preprocess_images: bad output size %d", out_size);
+    for (int i = 0; i < n; ++i) {
+        if (!dev_pixels[i]) return fail(SV_EINVAL, "sv_preprocess_images: image %d is null", i);
+        if (widths[i] < 1 || heights[i] < 1 || widths[i] > 16384 || heights[i] > 16384) return fail(SV_EINVAL, "sv_preprocess_images: bad image size %dx%d", widths[i], heights[i]);
+        if (channels[i] != 3 && channels[i] != 4) return fail(SV_EINVAL, "sv_preprocess_images: channels must be 3 (RGB) or 4 (RGBA), got %d", channels[i]);
+    }
+    for (int c = 0; c < 3; ++c)
+        if (!(std3[c] > 0.f)) return fail(SV_EINVAL, "sv_preprocess_images: std must be positive");
+    const size_t need = preprocess_workspace_bytes(widths, heights, n, out_size, recipe);
+    if (workspace_bytes < 0 || (size_t)workspace_bytes < need || (!dev_workspace && need > 256))
+        return fail(SV_EINVAL, "sv_preprocess_images: workspace of %lld bytes, %zu needed (sv_preprocess_workspace_bytes)", (long long)workspace_bytes, need);
+    const int r = preprocess_images(dev_pixels, widths, heights, channels, n, out_size, recipe, mean3, std3, dev_out, dev_workspace,
+                                    (size_t)workspace_bytes, (hipStream_t)stream);
+    if (r) return fail(SV_EHIP, "sv_preprocess_images: %s", r < 0 ? "workspace too small" : hipGetErrorString((hipError_t)r));
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI: the beam scorer on its own (parity tests drive it with synthetic logits)
 // ------------------------------------------------------------------------------------------------

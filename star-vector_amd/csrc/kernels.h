@@ -234,5 +234,11 @@ void launch_finish_step(const FinishArgs& a, hipStream_t st);
 // ---- image pre-processing (preprocess.hip): uint8 HWC (3 or 4 channels) -> float32 [3][S][S], returns a hipError_t value
 int preprocess_image(const uint8_t* dev_pixels, int width, int height, int channels, int out_size, int recipe,
                      const float* mean3, const float* std3, float* dev_out, hipStream_t st);
+// batched + stateless: n images (any sizes) -> [n][3][S][S]; the caller owns the workspace (preprocess_workspace_bytes);
+// nothing is copied from the host or synchronised inside.  Returns a hipError_t value, or -1 if the workspace is too small.
+size_t preprocess_workspace_bytes(const int32_t* widths, const int32_t* heights, int n, int out_size, int recipe);
+int preprocess_images(const uint8_t* const* dev_pixels, const int32_t* widths, const int32_t* heights, const int32_t* channels,
+                      int n, int out_size, int recipe, const float* mean3, const float* std3, float* dev_out, void* workspace,
+                      size_t workspace_bytes, hipStream_t st);
 
 }  // namespace sv

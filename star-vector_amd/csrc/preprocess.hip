@@ -17,33 +17,44 @@
 #include <math.h>
 #include <stdint.h>
 
-#include <mutex>
 #include <vector>
 
 #include "kernels.h"
 
+// Stateless and batched: one call handles up to any number of images in chunks of PP_MAXB; every per-image parameter
+// travels in the kernel arguments, the fixed-point tap tables are computed ON DEVICE (same double-precision arithmetic as
+// Pillow's precompute_coeffs / normalize_coeffs_8bpc, contraction off) into the caller's workspace, and nothing is copied
+// from the host or synchronised inside the call: no process-global buffer, no lock, no hipStreamSynchronize.
+
 namespace sv {
 
 #define PP_BITS 22
+#define PP_MAXB 32
 
-struct PpArgs {
+struct PpImg {
     const uint8_t* px; int W, H, C;      // source pixels, HWC
     int cw, ch, left, top;               // canvas (padded square, or the image itself) and the source offset inside it
-    int S;                               // output side
-    int recipe;                          // 0: ImageTrainProcessor (composite on white, pad, u/255 in float32)
-                                         // 1: HF SiglipImageProcessor (alpha dropped, stretch, u * (1/255) in double)
-    const int32_t* bounds_h; const int32_t* taps_h; int ksize_h;   // [S][2], [S][ksize]: canvas width  -> S
-    const int32_t* bounds_v; const int32_t* taps_v; int ksize_v;   //                     canvas height -> S
-    uint8_t* tmp;                        // [ch][S][3] horizontal pass output
-    float* out;                          // [3][S][S]
+    int ksize_h, ksize_v;                // taps per output pixel of the two passes
+    int copy;                            // 1: the canvas already has the target size (no resampling)
+    unsigned tab_off, tmp_off;           // byte offsets inside the workspace: tables | horizontal-pass output [ch][S][3]
+};
+struct PpBatch {
+    PpImg im[PP_MAXB];
+    int n, S, recipe;                    // recipe 0: ImageTrainProcessor (composite on white, pad, u/255 in float32)
+                                         //        1: HF SiglipImageProcessor (alpha dropped, stretch, u * (1/255) in double)
     float mean[3], stdv[3];
+    char* ws;                            // workspace
+    float* out;                          // [n][3][S][S]
 };
 
-__device__ __forceinline__ int pp_src(const PpArgs& p, int y, int x, int c) {
-    const int yy = y - p.top, xx = x - p.left;
-    if (yy < 0 || yy >= p.H || xx < 0 || xx >= p.W) return 255;          // white padding
-    const uint8_t* q = p.px + ((size_t)yy * p.W + xx) * p.C;
-    if (p.C == 3 || p.recipe == 1) return q[c];                         // recipe 1: image.convert("RGB") drops alpha
+// table layout of one image at ws + tab_off (int32): bounds_h [S][2] | taps_h [S][ksize_h] | bounds_v [S][2] | taps_v [S][ksize_v]
+__host__ __device__ inline size_t pp_tab_ints(int S, int kh, int kv) { return (size_t)S * (4 + kh + kv); }
+
+__device__ __forceinline__ int pp_src(const PpBatch& p, const PpImg& im, int y, int x, int c) {
+    const int yy = y - im.top, xx = x - im.left;
+    if (yy < 0 || yy >= im.H || xx < 0 || xx >= im.W) return 255;        // white padding
+    const uint8_t* q = im.px + ((size_t)yy * im.W + xx) * im.C;
+    if (im.C == 3 || p.recipe == 1) return q[c];                        // recipe 1: image.convert("RGB") drops alpha
     const int a = q[3];
     const int t = 255 * (255 - a) + (int)q[c] * a + 128;
     return ((t >> 8) + t) >> 8;
@@ -52,148 +63,189 @@ __device__ __forceinline__ int pp_clip8(int v) {
     v >>= PP_BITS;
     return v < 0 ? 0 : (v > 255 ? 255 : v);
 }
-__device__ __forceinline__ float pp_norm(const PpArgs& p, int u, int c) {
+__device__ __forceinline__ float pp_norm(const PpBatch& p, int u, int c) {
     // recipe 0: ToTensor = float32 u / 255.  recipe 1: HF rescale = float32(double(u) * (1 / 255))
     const float x = p.recipe == 1 ? (float)((double)u * 0.00392156862745098) : (float)u / 255.0f;
     return (x - p.mean[c]) / p.stdv[c];                                   // Normalize
 }
 
-__global__ __launch_bounds__(256) void pp_horizontal_kernel(PpArgs p) {
-    const int xo = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (xo >= p.S) return;
-    const int x0 = p.bounds_h[2 * xo], n = p.bounds_h[2 * xo + 1];
-    const int32_t* k = p.taps_h + (size_t)xo * p.ksize_h;
-    int acc[3] = {1 << (PP_BITS - 1), 1 << (PP_BITS - 1), 1 << (PP_BITS - 1)};
-    for (int i = 0; i < n; ++i) {
-        const int w = k[i];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) acc[c] += pp_src(p, y, x0 + i, c) * w;
-    }
-    uint8_t* o = p.tmp + ((size_t)y * p.S + xo) * 3;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) o[c] = (uint8_t)pp_clip8(acc[c]);
-}
-
-__global__ __launch_bounds__(256) void pp_vertical_kernel(PpArgs p) {
-    const int xo = blockIdx.x * blockDim.x + threadIdx.x, yo = blockIdx.y;
-    if (xo >= p.S) return;
-    const int y0 = p.bounds_v[2 * yo], n = p.bounds_v[2 * yo + 1];
-    const int32_t* k = p.taps_v + (size_t)yo * p.ksize_v;
-    int acc[3] = {1 << (PP_BITS - 1), 1 << (PP_BITS - 1), 1 << (PP_BITS - 1)};
-    for (int i = 0; i < n; ++i) {
-        const int w = k[i];
-        const uint8_t* q = p.tmp + ((size_t)(y0 + i) * p.S + xo) * 3;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) acc[c] += (int)q[c] * w;
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c) p.out[((size_t)c * p.S + yo) * p.S + xo] = pp_norm(p, pp_clip8(acc[c]), c);
-}
-
-// the padded square already has the target size: no resampling (torchvision Resize returns the image as is)
-__global__ __launch_bounds__(256) void pp_copy_kernel(PpArgs p) {
-    const int xo = blockIdx.x * blockDim.x + threadIdx.x, yo = blockIdx.y;
-    if (xo >= p.S) return;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) p.out[((size_t)c * p.S + yo) * p.S + xo] = pp_norm(p, pp_src(p, yo, xo, c), c);
-}
-
-// ---- host: Resample.c precompute_coeffs + normalize_coeffs_8bpc (double precision, no contraction) ---------------
+// ---- Resample.c precompute_coeffs + normalize_coeffs_8bpc, double precision, NO contraction (host and device) ----
 #pragma clang fp contract(off)
-static double pp_bicubic(double x) {
+__host__ __device__ inline double pp_bicubic(double x) {
     const double a = -0.5;
     if (x < 0.0) x = -x;
     if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
     if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
     return 0.0;
 }
-static int pp_coeffs(int in_size, int out_size, std::vector<int32_t>& bounds, std::vector<int32_t>& taps) {
+__host__ __device__ inline int pp_ksize(int in_size, int out_size) {
+    const double scale = (double)in_size / (double)out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    return (int)ceil(2.0 * filterscale) * 2 + 1;
+}
+// one output position xx: bounds (first input index, tap count) and the ksize fixed-point taps
+__host__ __device__ inline void pp_coeff_row(int in_size, int out_size, int ksize, int xx, int32_t* bounds2, int32_t* taps) {
     const double scale = (double)in_size / (double)out_size;
     const double filterscale = scale < 1.0 ? 1.0 : scale;
     const double support = 2.0 * filterscale;
-    const int ksize = (int)ceil(support) * 2 + 1;
-    bounds.assign((size_t)out_size * 2, 0);
-    taps.assign((size_t)out_size * ksize, 0);
-    std::vector<double> k(ksize);
     const double ss = 1.0 / filterscale;
-    for (int xx = 0; xx < out_size; ++xx) {
-        const double center = (xx + 0.5) * scale;
-        int xmin = (int)(center - support + 0.5);
-        if (xmin < 0) xmin = 0;
-        int xmax = (int)(center + support + 0.5);
-        if (xmax > in_size) xmax = in_size;
-        xmax -= xmin;
-        double ww = 0.0;
-        for (int x = 0; x < xmax; ++x) {
+    const double center = (xx + 0.5) * scale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    double ww = 0.0;
+    for (int x = 0; x < xmax; ++x) ww += pp_bicubic((x + xmin - center + 0.5) * ss);
+    for (int x = 0; x < ksize; ++x) {
+        int t = 0;
+        if (x < xmax) {
             const double w = pp_bicubic((x + xmin - center + 0.5) * ss);
-            k[x] = w;
-            ww += w;
+            const double v = ww != 0.0 ? w / ww : w;
+            t = v < 0 ? (int)(-0.5 + v * (1 << PP_BITS)) : (int)(0.5 + v * (1 << PP_BITS));
         }
-        for (int x = 0; x < xmax; ++x) {
-            const double v = ww != 0.0 ? k[x] / ww : k[x];
-            taps[(size_t)xx * ksize + x] = v < 0 ? (int)(-0.5 + v * (1 << PP_BITS)) : (int)(0.5 + v * (1 << PP_BITS));
-        }
-        bounds[2 * xx] = xmin;
-        bounds[2 * xx + 1] = xmax;
+        taps[x] = t;
     }
-    return ksize;
+    bounds2[0] = xmin;
+    bounds2[1] = xmax;
 }
 
-// workspace shared by all calls (grown on demand); one call at a time
-static std::mutex g_pp_mu;
-static void* g_pp_buf = nullptr;
-static size_t g_pp_bytes = 0;
+__global__ __launch_bounds__(64) void pp_tables_kernel(PpBatch p) {
+    const PpImg& im = p.im[blockIdx.z];
+    if (im.copy) return;
+    const int xx = blockIdx.x * 64 + threadIdx.x;
+    if (xx >= p.S) return;
+    int32_t* tab = reinterpret_cast<int32_t*>(p.ws + im.tab_off);
+    if (blockIdx.y == 0) {
+        pp_coeff_row(im.cw, p.S, im.ksize_h, xx, tab + 2 * xx, tab + 2 * p.S + (size_t)xx * im.ksize_h);
+    } else {
+        int32_t* tv = tab + (size_t)p.S * (2 + im.ksize_h);
+        pp_coeff_row(im.ch, p.S, im.ksize_v, xx, tv + 2 * xx, tv + 2 * p.S + (size_t)xx * im.ksize_v);
+    }
+}
 
+__global__ __launch_bounds__(256) void pp_horizontal_kernel(PpBatch p) {
+    const PpImg& im = p.im[blockIdx.z];
+    const int xo = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (im.copy || y >= im.ch || xo >= p.S) return;
+    const int32_t* tab = reinterpret_cast<const int32_t*>(p.ws + im.tab_off);
+    const int x0 = tab[2 * xo], n = tab[2 * xo + 1];
+    const int32_t* k = tab + 2 * p.S + (size_t)xo * im.ksize_h;
+    int acc[3] = {1 << (PP_BITS - 1), 1 << (PP_BITS - 1), 1 << (PP_BITS - 1)};
+    for (int i = 0; i < n; ++i) {
+        const int w = k[i];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] += pp_src(p, im, y, x0 + i, c) * w;
+    }
+    uint8_t* o = reinterpret_cast<uint8_t*>(p.ws + im.tmp_off) + ((size_t)y * p.S + xo) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) o[c] = (uint8_t)pp_clip8(acc[c]);
+}
+
+__global__ __launch_bounds__(256) void pp_vertical_kernel(PpBatch p) {
+    const PpImg& im = p.im[blockIdx.z];
+    const int xo = blockIdx.x * blockDim.x + threadIdx.x, yo = blockIdx.y;
+    if (xo >= p.S) return;
+    float* out = p.out + (size_t)blockIdx.z * 3 * p.S * p.S;
+    if (im.copy) {        // the padded square already has the target size: torchvision Resize returns the image as is
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out[((size_t)c * p.S + yo) * p.S + xo] = pp_norm(p, pp_src(p, im, yo, xo, c), c);
+        return;
+    }
+    const int32_t* tv = reinterpret_cast<const int32_t*>(p.ws + im.tab_off) + (size_t)p.S * (2 + im.ksize_h);
+    const int y0 = tv[2 * yo], n = tv[2 * yo + 1];
+    const int32_t* k = tv + 2 * p.S + (size_t)yo * im.ksize_v;
+    const uint8_t* tmp = reinterpret_cast<const uint8_t*>(p.ws + im.tmp_off);
+    int acc[3] = {1 << (PP_BITS - 1), 1 << (PP_BITS - 1), 1 << (PP_BITS - 1)};
+    for (int i = 0; i < n; ++i) {
+        const int w = k[i];
+        const uint8_t* q = tmp + ((size_t)(y0 + i) * p.S + xo) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] += (int)q[c] * w;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[((size_t)c * p.S + yo) * p.S + xo] = pp_norm(p, pp_clip8(acc[c]), c);
+}
+
+static void pp_geometry(int width, int height, int out_size, int recipe, PpImg& im) {
+    if (recipe == 0) {                    // white pad to square (data/util.py:56-62)
+        im.cw = im.ch = width > height ? width : height;
+        im.left = (im.cw - width) / 2; im.top = (im.ch - height) / 2;
+    } else {                              // stretch: no padding
+        im.cw = width; im.ch = height; im.left = im.top = 0;
+    }
+    im.copy = (im.cw == out_size && im.ch == out_size) ? 1 : 0;
+    // a pass whose input size equals the output size has identity taps (bicubic(0) = 1, bicubic(+-1) = 0): the same bytes
+    im.ksize_h = im.copy ? 0 : pp_ksize(im.cw, out_size);
+    im.ksize_v = im.copy ? 0 : pp_ksize(im.ch, out_size);
+}
+static size_t pp_al(size_t b) { return (b + 255) & ~(size_t)255; }
+
+size_t preprocess_workspace_bytes(const int32_t* widths, const int32_t* heights, int n, int out_size, int recipe) {
+    size_t need = 256;
+    for (int i = 0; i < n; ++i) {
+        PpImg im;
+        pp_geometry(widths[i], heights[i], out_size, recipe, im);
+        if (im.copy) continue;
+        need += pp_al(pp_tab_ints(out_size, im.ksize_h, im.ksize_v) * 4) + pp_al((size_t)im.ch * out_size * 3);
+    }
+    return need;
+}
+
+// returns a hipError_t value, or -1 when the workspace is too small
+int preprocess_images(const uint8_t* const* dev_pixels, const int32_t* widths, const int32_t* heights, const int32_t* channels,
+                      int n, int out_size, int recipe, const float* mean3, const float* std3, float* dev_out, void* workspace,
+                      size_t workspace_bytes, hipStream_t st) {
+    if (preprocess_workspace_bytes(widths, heights, n, out_size, recipe) > workspace_bytes) return -1;
+    size_t off = 0;
+    for (int i0 = 0; i0 < n; i0 += PP_MAXB) {
+        PpBatch p;
+        p.n = n - i0 < PP_MAXB ? n - i0 : PP_MAXB;
+        p.S = out_size; p.recipe = recipe; p.ws = (char*)workspace;
+        p.out = dev_out + (size_t)i0 * 3 * out_size * out_size;
+        for (int c = 0; c < 3; ++c) { p.mean[c] = mean3[c]; p.stdv[c] = std3[c]; }
+        int max_ch = 0, any_resize = 0;
+        for (int j = 0; j < p.n; ++j) {
+            PpImg& im = p.im[j];
+            im.px = dev_pixels[i0 + j]; im.W = widths[i0 + j]; im.H = heights[i0 + j]; im.C = channels[i0 + j];
+            pp_geometry(im.W, im.H, out_size, recipe, im);
+            im.tab_off = im.tmp_off = 0;
+            if (!im.copy) {
+                im.tab_off = (unsigned)off; off += pp_al(pp_tab_ints(out_size, im.ksize_h, im.ksize_v) * 4);
+                im.tmp_off = (unsigned)off; off += pp_al((size_t)im.ch * out_size * 3);
+                max_ch = im.ch > max_ch ? im.ch : max_ch;
+                any_resize = 1;
+            }
+        }
+        if (any_resize) {
+            pp_tables_kernel<<<dim3((out_size + 63) / 64, 2, p.n), 64, 0, st>>>(p);
+            pp_horizontal_kernel<<<dim3((out_size + 255) / 256, max_ch, p.n), 256, 0, st>>>(p);
+        }
+        pp_vertical_kernel<<<dim3((out_size + 255) / 256, out_size, p.n), 256, 0, st>>>(p);
+    }
+    return (int)hipGetLastError();
+}
+
+// one image, no caller workspace: a stream-ordered allocation (no global buffer, no synchronisation)
 int preprocess_image(const uint8_t* dev_pixels, int width, int height, int channels, int out_size, int recipe,
                      const float* mean3, const float* std3, float* dev_out, hipStream_t st) {
-    std::lock_guard<std::mutex> lk(g_pp_mu);
-    PpArgs p;
-    p.px = dev_pixels; p.W = width; p.H = height; p.C = channels; p.recipe = recipe;
-    if (recipe == 0) {                    // white pad to square (data/util.py:56-62)
-        p.cw = p.ch = width > height ? width : height;
-        p.left = (p.cw - width) / 2; p.top = (p.ch - height) / 2;
-    } else {                              // stretch: no padding
-        p.cw = width; p.ch = height; p.left = p.top = 0;
-    }
-    p.S = out_size; p.out = dev_out;
-    for (int c = 0; c < 3; ++c) { p.mean[c] = mean3[c]; p.stdv[c] = std3[c]; }
-    p.bounds_h = p.bounds_v = nullptr; p.taps_h = p.taps_v = nullptr; p.ksize_h = p.ksize_v = 0; p.tmp = nullptr;
-    const dim3 blk(256), grid_out((out_size + 255) / 256, out_size);
-    if (p.cw == out_size && p.ch == out_size) {
-        pp_copy_kernel<<<grid_out, blk, 0, st>>>(p);
-        return (int)hipGetLastError();
-    }
-    // a pass whose input size equals the output size has identity taps (bicubic(0) = 1, bicubic(+-1) = 0): Pillow skips it
-    std::vector<int32_t> bh, th, bv, tv;
-    const int kh = pp_coeffs(p.cw, out_size, bh, th), kv = pp_coeffs(p.ch, out_size, bv, tv);
-    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
-    const size_t tmp_bytes = (size_t)p.ch * out_size * 3;
-    const size_t need = al(bh.size() * 4) + al(th.size() * 4) + al(bv.size() * 4) + al(tv.size() * 4) + tmp_bytes + 256;
-    if (need > g_pp_bytes) {
-        if (g_pp_buf) (void)hipFree(g_pp_buf);
-        g_pp_buf = nullptr; g_pp_bytes = 0;
-        hipError_t e = hipMalloc(&g_pp_buf, need);
-        if (e != hipSuccess) return (int)e;
-        g_pp_bytes = need;
-    }
-    char* q = (char*)g_pp_buf;
-    int32_t* d_bh = (int32_t*)q; q += al(bh.size() * 4);
-    int32_t* d_th = (int32_t*)q; q += al(th.size() * 4);
-    int32_t* d_bv = (int32_t*)q; q += al(bv.size() * 4);
-    int32_t* d_tv = (int32_t*)q; q += al(tv.size() * 4);
-    uint8_t* d_tmp = (uint8_t*)q;
-    hipError_t e = hipMemcpyAsync(d_bh, bh.data(), bh.size() * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_th, th.data(), th.size() * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_bv, bv.data(), bv.size() * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_tv, tv.data(), tv.size() * 4, hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);                    // the tables are host temporaries
+    const int32_t w = width, h = height, c = channels;
+    const size_t need = preprocess_workspace_bytes(&w, &h, 1, out_size, recipe);
+    void* ws = nullptr;
+    hipError_t e = hipMallocAsync(&ws, need, st);
     if (e != hipSuccess) return (int)e;
-    p.bounds_h = d_bh; p.taps_h = d_th; p.ksize_h = kh; p.bounds_v = d_bv; p.taps_v = d_tv; p.ksize_v = kv; p.tmp = d_tmp;
-    pp_horizontal_kernel<<<dim3((out_size + 255) / 256, p.ch), blk, 0, st>>>(p);
-    pp_vertical_kernel<<<grid_out, blk, 0, st>>>(p);
-    e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(st);                    // the workspace is shared between calls
-    return (int)e;
+    const int r = preprocess_images(&dev_pixels, &w, &h, &c, 1, out_size, recipe, mean3, std3, dev_out, ws, need, st);
+    e = hipFreeAsync(ws, st);
+    return r ? r : (int)e;
+}
+
+// host copy of the table the device computes (CPU test surface)
+static int pp_coeffs(int in_size, int out_size, std::vector<int32_t>& bounds, std::vector<int32_t>& taps) {
+    const int ksize = pp_ksize(in_size, out_size);
+    bounds.assign((size_t)out_size * 2, 0);
+    taps.assign((size_t)out_size * ksize, 0);
+    for (int xx = 0; xx < out_size; ++xx) pp_coeff_row(in_size, out_size, ksize, xx, &bounds[2 * xx], &taps[(size_t)xx * ksize]);
+    return ksize;
 }
 
 }  // namespace sv

@@ -473,6 +473,33 @@ def op_preprocess_image(pixels: torch.Tensor, size: int, mean, std, recipe: str 
     return out
 
 
+def op_preprocess_images(pixels, size: int, mean, std, recipe: str = "starvector") -> torch.Tensor:
+    """A batch of uint8 [H, W, 3|4] GPU tensors (any sizes) -> float32 [n, 3, size, size], one call (`sv_preprocess_images`):
+    three launches per 32 images, no host copy, no synchronisation, workspace from torch's caching allocator."""
+    lib = _lib.load()
+    if len(pixels) == 0:
+        raise ValueError("empty batch")
+    px = [_need(t, torch.uint8, "pixels") for t in pixels]
+    for t in px:
+        if t.dim() != 3 or t.shape[2] not in (3, 4):
+            raise ValueError("pixels must be uint8 [H, W, 3] (RGB) or [H, W, 4] (RGBA)")
+    n = len(px)
+    ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in px])
+    ws_ = (C.c_int32 * n)(*[t.shape[1] for t in px])
+    hs_ = (C.c_int32 * n)(*[t.shape[0] for t in px])
+    cs_ = (C.c_int32 * n)(*[t.shape[2] for t in px])
+    rc = {"starvector": 0, "siglip": 1}[recipe]
+    need = lib.sv_preprocess_workspace_bytes(ws_, hs_, n, int(size), rc)
+    if need < 0:
+        check(int(need), "sv_preprocess_workspace_bytes")
+    work = torch.empty(int(need), dtype=torch.uint8, device=px[0].device)
+    out = torch.empty(n, 3, size, size, dtype=torch.float32, device=px[0].device)
+    m3, s3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
+    check(lib.sv_preprocess_images(ptrs, ws_, hs_, cs_, n, int(size), rc, m3, s3, _ptr(out), _ptr(work), int(need), _stream()),
+          "sv_preprocess_images")
+    return out
+
+
 def op_sample_top_p(logits, temperature, top_p, seed, step, top_k=0):
     lib = _lib.load()
     logits = _need(logits, torch.float32, "logits"); B, V = logits.shape

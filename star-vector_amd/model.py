@@ -207,17 +207,28 @@ class ImageTrainProcessor:
         self.size = size
         self.device = device
 
+    def _pixels(self, img):
+        import numpy as np
+        # engine-side processor: always the device kernels (palette / grey / CMYK images are only re-encoded as RGB(A)
+        # first -- the reference itself cannot normalise a non-RGB image with its 3-channel mean)
+        if img.mode not in ("RGB", "RGBA"):
+            img = img.convert("RGBA" if "transparency" in img.info or img.mode in ("LA", "PA") else "RGB")
+        return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).to(self.device, non_blocking=True)
+
+    def batch(self, images) -> torch.Tensor:
+        """A list of PIL images -> float32 [n, 3, size, size] in ONE device call (`sv_preprocess_images`): the serving path
+        pre-processes a whole request batch with three launches instead of one synchronised round trip per image."""
+        if self.device is None:
+            return torch.stack([self(img) for img in images], 0)
+        from .engine import op_preprocess_images
+        return op_preprocess_images([self._pixels(img) for img in images], self.size, self._mean, self._std)
+
     def __call__(self, img):
         from PIL import Image
         import numpy as np
         if self.device is not None:
-            # engine-side processor: always the device kernels (palette / grey / CMYK images are only re-encoded as RGB(A)
-            # first -- the reference itself cannot normalise a non-RGB image with its 3-channel mean)
-            if img.mode not in ("RGB", "RGBA"):
-                img = img.convert("RGBA" if "transparency" in img.info or img.mode in ("LA", "PA") else "RGB")
             from .engine import op_preprocess_image
-            px = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).to(self.device)
-            return op_preprocess_image(px, self.size, self._mean, self._std)
+            return op_preprocess_image(self._pixels(img), self.size, self._mean, self._std)
         if img.mode == "RGBA":                               # _rgba_to_rgb_white (data/util.py:64-67)
             bg = Image.new("RGB", img.size, (255, 255, 255))
             bg.paste(img, mask=img.split()[3])
@@ -302,17 +313,16 @@ class SiglipProcessor:
 
     def __call__(self, images=None, return_tensors="pt", **kw):
         import numpy as np
-        from .engine import op_preprocess_image
+        from .engine import op_preprocess_images
         if images is None:
             raise ValueError("images is required")
         imgs = images if isinstance(images, (list, tuple)) else [images]
-        out = []
+        px = []
         for img in imgs:
             if img.mode not in ("RGB", "RGBA"):
                 img = img.convert("RGB")
-            px = torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).to(self.device)
-            out.append(op_preprocess_image(px, self.size, self.mean, self.std, recipe="siglip"))
-        return SiglipProcessor._Out(torch.stack(out, 0))
+            px.append(torch.from_numpy(np.asarray(img, dtype=np.uint8).copy()).to(self.device, non_blocking=True))
+        return SiglipProcessor._Out(op_preprocess_images(px, self.size, self.mean, self.std, recipe="siglip"))   # one call
 
 
 class ImageEncoder(_EngineModule):
@@ -334,6 +344,8 @@ class ImageEncoder(_EngineModule):
 
     def process_images(self, images):                      # image_encoder.py:112-117
         if self.image_encoder_type == "clip":
+            if hasattr(self.processor, "batch") and len(images) > 1:        # same list of [1, 3, S, S] tensors, one device call
+                return list(self.processor.batch(list(images)).unsqueeze(1).unbind(0))
             return [self.processor(image).unsqueeze(0) for image in images]
         return self.processor(images=images, return_tensors="pt").pixel_values.unsqueeze(0)     # sic: [1, B, 3, S, S]
 
@@ -375,7 +387,7 @@ class HipCausalLM(_EngineModule):
         self.model = self.transformer                 # Starcoder2ForCausalLM.model
         self.eos_token_id = eos_token_id
         self.pad_token_id = pad_token_id
-        self.seed = 0
+        self.seed = None          # None: every sampling call draws its seed from torch's generator; an int pins it
 
     @staticmethod
     def _stop_ids(stopping_criteria) -> Optional[List[int]]:
@@ -429,11 +441,20 @@ class HipCausalLM(_EngineModule):
                  num_beams: int = 1, max_length: int = 30, min_length: int = 0, repetition_penalty: float = 1.0,
                  length_penalty: float = 1.0, use_cache: bool = True, stopping_criteria=None,
                  early_stopping: bool = False, pad_token_id: Optional[int] = None, eos_token_id: Optional[int] = None,
-                 num_return_sequences: int = 1, top_k: Optional[int] = 50, streamer=None, **unused) -> torch.Tensor:
+                 num_return_sequences: int = 1, top_k: Optional[int] = 50, streamer=None, seed: Optional[int] = None,
+                 **unused) -> torch.Tensor:
         # top_k: the reference never passes it; its pinned transformers==4.49.0 (pyproject.toml:18) defaults
         # GenerationConfig.top_k to 50, so every do_sample call there is top-k 50 followed by top-p.  Same default here.
         if inputs_embeds is None:
             raise ValueError("inputs_embeds is required (the reference always generates from embeddings)")
+        # Random stream: HF draws from torch's global generator, so repeated calls differ and torch.manual_seed controls them.
+        # The device sampler is a pure function of (seed, step, row): the per-call seed is therefore DRAWN from torch's
+        # generator (same reproducibility contract), unless the caller pins it with `seed=` (tests, data-parallel ranks).
+        if seed is None:
+            seed = self.seed
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, ()).item()) if do_sample else 0
+        seed = int(seed) & (2 ** 63 - 1)
         num_beams = int(num_beams)
         if num_beams < 1:
             raise ValueError("`num_beams` has to be an integer strictly greater than 0")     # HF's own check
@@ -461,7 +482,7 @@ class HipCausalLM(_EngineModule):
                 do_sample=do_sample, top_p=top_p, temperature=temperature, num_beams=num_beams, max_length=max_length,
                 min_length=min_length, repetition_penalty=repetition_penalty, length_penalty=length_penalty,
                 use_cache=use_cache, stopping_criteria=stopping_criteria, early_stopping=early_stopping,
-                pad_token_id=pad_token_id, eos_token_id=eos_token_id, top_k=top_k))
+                pad_token_id=pad_token_id, eos_token_id=eos_token_id, top_k=top_k, seed=seed))
         S0 = inputs_embeds.shape[1]
         # HF (_prepare_generated_length): with inputs_embeds min_length is reduced by the prompt length -- 0 on the im2svg path
         # (SURVEY.md 8a-a11), positive only for a text2svg caption shorter than min_length; MinLengthLogitsProcessor then
@@ -488,7 +509,7 @@ class HipCausalLM(_EngineModule):
             top_p=float(top_p if top_p is not None else 1.0),
             eos_token_id=int(self.eos_token_id if eos_token_id is None else eos_token_id),
             pad_token_id=int(self.pad_token_id if pad_token_id is None else pad_token_id),
-            stop_ids=self._stop_ids(stopping_criteria), seed=self.seed,
+            stop_ids=self._stop_ids(stopping_criteria), seed=seed,
             repetition_penalty=float(repetition_penalty if repetition_penalty is not None else 1.0),
             num_beams=num_beams, length_penalty=float(length_penalty if length_penalty is not None else 1.0),
             early_stopping=early_stopping, top_k=int(top_k or 0), on_tokens=on_tokens,
@@ -590,6 +611,9 @@ class StarVectorStarCoder(nn.Module):
             # not in the reference's whitelist (so its serve worker's streamer never streams, serve/model_worker.py:129-175);
             # kept here so that the same call does stream
             "streamer": base_kwargs.get("streamer"),
+            # extension: pins the device sampler's random stream (default: drawn per call from torch's generator, so that
+            # `torch.manual_seed` reproduces a run and repeated calls differ, as with HF's torch.multinomial)
+            "seed": base_kwargs.get("seed"),
         }
 
     def _get_im2svg_specific_kwargs(self, kwargs):                    # starvector_base.py:289-295
@@ -684,13 +708,24 @@ class StarVectorForCausalLM(nn.Module):
         for fn in sorted(os.listdir(path)):
             if fn.endswith(".safetensors"):
                 sd.update(load_file(os.path.join(path, fn)))
-        cfg = config_from_checkpoint({**cfg_json, **kwargs}, {k: tuple(v.shape) for k, v in sd.items()})
+        cfg = config_from_checkpoint({**cfg_json, **{k: v for k, v in kwargs.items() if k != "byte_tokenizer_fallback"}},
+                                     {k: tuple(v.shape) for k, v in sd.items()})
         if tokenizer is None:
-            try:
+            tok_files = ("tokenizer.json", "tokenizer_config.json", "vocab.json", "tokenizer.model", "merges.txt")
+            if any(os.path.exists(os.path.join(path, f)) for f in tok_files):
+                # a checkpoint that ships a tokenizer must load it: a silent byte-level stand-in would turn '<svg' / '</svg>'
+                # into the wrong ids (the stop would never fire, the output would decode to garbage) -- errors propagate
                 from transformers import AutoTokenizer
                 tokenizer = AutoTokenizer.from_pretrained(path, use_fast=False)
-            except Exception:
+            elif kwargs.get("byte_tokenizer_fallback", False):
+                import warnings
+                warnings.warn(f"{path!r} has no tokenizer files: using the byte-level stand-in tokenizer (ids are bytes + 1; "
+                              "NOT the StarCoder vocabulary -- only meaningful for synthetic weights)", RuntimeWarning)
                 tokenizer = None
+            else:
+                raise FileNotFoundError(
+                    f"{path!r} has no tokenizer files (tokenizer.json / vocab.json / ...): pass tokenizer=..., or "
+                    "byte_tokenizer_fallback=True to use the byte-level stand-in (synthetic weights only)")
         return cls(cfg, state_dict=sd, tokenizer=tokenizer)
 
     @torch.no_grad()

@@ -59,7 +59,7 @@ def test_against_reference_goldens(name, norm):
     g = _golden(name)
     seed, B, n_new = [int(x) for x in g["meta"]]
     cfg = dataclasses.replace(O.OracleConfig.tiny(), adapter_norm=norm)
-    w = O.make_weights(cfg, seed=seed)
+    w = O.apply_fixture_weights(O.make_weights(cfg, seed=seed), cfg, g)
     eng = build_engine(cfg, w, max_batch=4, max_seq_len=64)
     enc = eng.encode_image(bf(g["image"]))
     vis = eng.adapter(enc)
@@ -75,6 +75,12 @@ def test_against_reference_goldens(name, norm):
     assert checked > 0
     print(f"[{name}] logits max|err| {worst:.3e} (scale {scale:.3e}); {checked} token positions checked exactly, "
           f"{near} near-tie flips")
+    if "wte" in g:
+        # tiny_b3: the designed stream (fitted embedding table, margins >= 0.25 x the logit scale, 37 distinct tokens).  EVERY
+        # position is checked, and the free-running engine reproduces HF generate token for token -- no margin filter.
+        assert checked == B * n_new and near == 0
+        toks = eng.generate(emb, max_length=emb.shape[1] + n_new, eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id).cpu()
+        assert torch.equal(toks, g["tokens"])
     eng.close()
 
 
@@ -84,18 +90,15 @@ def test_generate_semantics_eos_pad_stop_on_device():
     g = _golden("tiny_stop")
     seed, B, n_new, eos = [int(x) for x in g["meta"]]
     cfg = dataclasses.replace(O.OracleConfig.tiny(), eos_token_id=eos)
-    w = O.make_weights(cfg, seed=seed)
+    w = O.apply_fixture_weights(O.make_weights(cfg, seed=seed), cfg, g)      # designed stream: margins >= 0.25 x the logit scale
     eng = build_engine(cfg, w, 4, 64)
     emb = torch.cat([eng.adapter(eng.encode_image(bf(g["image"]))), eng.embed_tokens(g["prompt_ids"].to(dev()))], 1)
     S0 = emb.shape[1]
     stop = g["stop_ids"].tolist()
     toks = eng.generate(emb, max_length=S0 + n_new, eos_token_id=eos, pad_token_id=cfg.pad_token_id, stop_ids=stop).cpu()
-    o_toks, o_lg = O.greedy_generate(w, cfg, emb.float().cpu(), S0 + n_new, stop_ids=stop, mode="bf16", return_logits=True)
-    top2 = o_lg.topk(2, -1).values
-    safe = bool(((top2[..., 0] - top2[..., 1]) > 2 * LOGIT_TOL * float(o_lg.abs().max())).all())
-    if safe:
-        assert torch.equal(toks, g["tokens"])                      # identical to HF generate, incl. early stop + pads
-    # structural semantics hold regardless of near-ties:
+    assert torch.equal(toks, g["tokens"])                          # identical to HF generate, incl. early stop + pads
+    assert toks.shape[1] == 11 and (toks[1] == cfg.pad_token_id).sum() == 6 and toks[0, -2:].tolist() == stop
+    # structural semantics, restated:
     assert toks.shape[0] == B and 1 <= toks.shape[1] <= n_new
     for b in range(B):
         row = toks[b].tolist()
@@ -221,26 +224,123 @@ def test_drop_in_api_generate_im2svg():
         model.model.image_encoder(torch.zeros(1, 3, cfg.image_size, cfg.image_size))      # CPU tensor: no CPU path
 
 
+def _stream_equal_until_band(got, o_toks, margin, band):
+    """A free-running stream may leave the oracle's only AT a position whose top-1/top-2 margin is inside the tolerance band
+    (a legitimate bf16 near-tie; after it the two contexts differ and nothing can be compared).  Returns, per row, the
+    number of leading positions that are identical."""
+    n = []
+    for b in range(got.shape[0]):
+        diff = (got[b] != o_toks[b]).nonzero()
+        t = int(diff[0]) if diff.numel() else got.shape[1]
+        if t < got.shape[1]:
+            assert margin[b, t] <= band, (f"row {b} step {t}: engine token {int(got[b, t])} != oracle {int(o_toks[b, t])} "
+                                          f"at margin {float(margin[b, t]):.3e} (band {band:.3e})")
+        n.append(t)
+    return n
+
+
 def test_starvector_1b_shapes_against_oracle():
-    """BASELINE config 2 shapes (StarVector-1B, bf16) at a batch the CPU oracle finishes quickly."""
+    """BASELINE config 2 shapes (StarVector-1B, bf16), B = 2, 130 new tokens: the context runs 259 -> 389, i.e. through the
+    KV page boundaries at 320 and 384.  Teacher-forced logits at EVERY step against the oracle (bf16 cast points); token ids
+    bit-exact at every position whose margin clears the band, which must be >= 95 % of the 260 positions; the free-running
+    engine stream equals the oracle's up to the first in-band position; the same free-running check with a repetition
+    penalty (a diverse stream: random-init greedy streams repeat one token)."""
     torch.set_num_threads(host_cores())
-    cfg = O.OracleConfig()
+    cfg = dataclasses.replace(O.OracleConfig(), eos_token_id=-1)
     w = O.make_weights(cfg, seed=1234)
-    B, n_new = 2, 3
-    eng = build_engine(cfg, w, max_batch=2, max_seq_len=300)
+    B, n_new = 2, 130
+    eng = build_engine(cfg, w, max_batch=2, max_seq_len=259 + n_new + 8)
     img = O.synthetic_images(B, 224, seed=1235)
     prompt = torch.tensor([[7, 11]] * B)
     enc = eng.encode_image(bf(img))
     vis = eng.adapter(enc)
     emb = torch.cat([vis, eng.embed_tokens(prompt.to(dev()))], 1)
+    S0 = emb.shape[1]
+    assert S0 == 259 and S0 + n_new > 384
     o_enc = O.image_encoder_forward(w, cfg, img, "bf16")
     o_vis = O.adapter_forward(w, cfg, o_enc, "bf16")
     e1, e2 = rel_err(enc, o_enc), rel_err(vis, o_vis)
     print(f"[1b] encoder rel err {e1:.3e}, adapter rel err {e2:.3e}")
     assert e1 <= 4e-2 and e2 <= 4e-2
     worst, scale, checked, near, o_toks, margin = _teacher_forced_check(eng, emb, w, cfg, n_new)
-    print(f"[1b] logits max|err| {worst:.3e} (scale {scale:.3e}); {checked} positions exact, {near} near-tie flips")
+    print(f"[1b] {n_new} steps x {B} rows: logits max|err| {worst:.3e} (scale {scale:.3e}); {checked}/{B * n_new} positions "
+          f"token-exact outside the band, {near} near-tie flips inside it; min margin {float(margin.min()):.3e}")
+    assert checked >= 0.95 * B * n_new
+    kw = dict(max_length=S0 + n_new, eos_token_id=-1, pad_token_id=cfg.pad_token_id)
+    got = eng.generate(emb, **kw).cpu()
+    lead = _stream_equal_until_band(got, o_toks, margin, 2 * LOGIT_TOL * scale)
+    print(f"[1b] free-running greedy stream == oracle for the first {lead} positions per row (of {n_new}); a row may only "
+          f"leave the oracle's stream at an in-band near-tie")
+    # a diverse stream: repetition penalty 1.3 (HF RepetitionPenaltyLogitsProcessor, pinned by tests/golden/tiny_reppen)
+    n2, pen = 24, 1.3
+    p_toks, p_sc = O.greedy_generate(w, cfg, emb.float().cpu(), S0 + n2, mode="bf16", return_logits=True, repetition_penalty=pen)
+    top2 = p_sc.topk(2, -1).values
+    got2 = eng.generate(emb, max_length=S0 + n2, eos_token_id=-1, pad_token_id=cfg.pad_token_id, repetition_penalty=pen).cpu()
+    lead2 = _stream_equal_until_band(got2, p_toks, top2[..., 0] - top2[..., 1], 2 * LOGIT_TOL * float(p_sc.abs().max()))
+    print(f"[1b] repetition_penalty {pen}: {len(set(p_toks.flatten().tolist()))} distinct tokens; stream == oracle for the first {lead2} positions")
     eng.close()
+
+
+def _rms(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float(((a - b) ** 2).mean().sqrt() / (b ** 2).mean().sqrt())
+
+
+def _comparator_case(cfg, w, img, prompt, n_steps, tag):
+    """errors against the float32 oracle of (a) the engine and (b) a REAL bf16 execution of the same modules by torch on this
+    GPU (ATen / rocBLAS bf16 kernels; the decoder is HF's own class): the engine may not be further from float32 than
+    1.5 x what torch's bf16 is (relative RMS; the maxima are reported too)."""
+    from tests.gpu_util import hf_decoder_bf16, hf_teacher_forced_logits
+    B = img.shape[0]
+    o_enc = O.image_encoder_forward(w, cfg, img)
+    o_vis = O.adapter_forward(w, cfg, o_enc)
+    o_emb = O.prepare_generation_inputs(w, cfg, img, prompt)
+    o_toks, o_lg = O.greedy_generate(w, cfg, o_emb, o_emb.shape[1] + n_steps, return_logits=True)       # float32 reference
+    wb = {k: v.to(torch.bfloat16).to(dev()) for k, v in w.items() if not k.startswith("model.svg_transformer")}
+    with torch.no_grad():
+        t_enc = O.image_encoder_forward(wb, cfg, bf(img), "native")
+        t_vis = O.adapter_forward(wb, cfg, t_enc, "native")
+    lm = hf_decoder_bf16(cfg, w)
+    wte = lm.get_input_embeddings()
+    t_emb = torch.cat([t_vis, wte(prompt.to(dev()))], 1)
+    t_lg = hf_teacher_forced_logits(lm, t_emb, wte, o_toks)
+    del lm
+    eng = build_engine(cfg, w, max_batch=max(B, 2), max_seq_len=o_emb.shape[1] + n_steps + 8)
+    e_enc = eng.encode_image(bf(img))
+    e_vis = eng.adapter(e_enc)
+    e_emb = torch.cat([e_vis, eng.embed_tokens(prompt.to(dev()))], 1)
+    rows = [eng.prefill(e_emb).float().cpu()]
+    for t in range(1, o_toks.shape[1]):
+        rows.append(eng.decode_step(o_toks[:, t - 1].to(dev())).float().cpu())
+    e_lg = torch.stack(rows, 1)
+    eng.close()
+    out = {}
+    for name, e, t, o in (("encoder", e_enc, t_enc, o_enc), ("adapter", e_vis, t_vis, o_vis), ("logits", e_lg, t_lg, o_lg)):
+        re_, rt_ = _rms(e, o), _rms(t, o)
+        me_, mt_ = rel_err(e, o), rel_err(t, o)
+        out[name] = (re_, rt_, me_, mt_)
+        print(f"[{tag}] {name:8s} vs float32: engine rms {re_:.3e} max {me_:.3e} | torch bf16 rms {rt_:.3e} max {mt_:.3e} | ratio {re_ / rt_:.2f}")
+    return out
+
+
+def test_engine_error_against_real_bf16_execution():
+    """The tolerance is not self-chosen: a real torch.bfloat16 run of the reference's modules on the same GPU sets it."""
+    torch.set_num_threads(host_cores())
+    g = _golden("tiny_b3")
+    seed, B, n_new = [int(x) for x in g["meta"]]
+    cfg = O.OracleConfig.tiny()
+    w = O.apply_fixture_weights(O.make_weights(cfg, seed=seed), cfg, g)
+    res = _comparator_case(cfg, w, g["image"], g["prompt_ids"], n_new, "tiny")
+    for name, (re_, rt_, me_, mt_) in res.items():
+        assert re_ <= 1.5 * rt_, f"{name}: engine rms error {re_:.3e} > 1.5 x torch-bf16's {rt_:.3e}"
+        assert me_ <= 2.5 * mt_, f"{name}: engine max error {me_:.3e} > 2.5 x torch-bf16's {mt_:.3e}"
+    # StarVector-1B dims, one image, prefill + 6 teacher-forced steps
+    cfg1 = dataclasses.replace(O.OracleConfig(), eos_token_id=-1)
+    w1 = O.make_weights(cfg1, seed=1234)
+    res = _comparator_case(cfg1, w1, O.synthetic_images(1, 224, seed=1235), torch.tensor([[7, 11]]), 7, "1b")
+    for name, (re_, rt_, me_, mt_) in res.items():
+        assert re_ <= 1.5 * rt_, f"1b {name}: engine rms error {re_:.3e} > 1.5 x torch-bf16's {rt_:.3e}"
+        assert me_ <= 2.5 * mt_, f"1b {name}: engine max error {me_:.3e} > 2.5 x torch-bf16's {mt_:.3e}"
 
 
 def test_full_size_properties_batch32():
@@ -412,7 +512,7 @@ def test_streaming_callback_and_hf_streamer():
     g = _golden("tiny_stop")
     seed, B, n_new, eos = [int(x) for x in g["meta"]]
     cfg = dataclasses.replace(O.OracleConfig.tiny(), eos_token_id=eos)
-    w = O.make_weights(cfg, seed=seed)
+    w = O.apply_fixture_weights(O.make_weights(cfg, seed=seed), cfg, g)
     eng = build_engine(cfg, w, max_batch=4, max_seq_len=96)
     emb = torch.cat([eng.adapter(eng.encode_image(bf(g["image"]))), eng.embed_tokens(g["prompt_ids"].to(dev()))], 1)
     S0 = emb.shape[1]

@@ -308,6 +308,50 @@ def test_preprocess_image_siglip_recipe_bit_exact(w, h, c):
     assert pv.shape == (2, 3, 384, 384) and np.array_equal(pv[1].cpu().numpy().view(np.int32), got.view(np.int32))
 
 
+def test_preprocess_images_batched_stateless_bit_exact():
+    """sv_preprocess_images: a batch of 37 images of mixed sizes / channel counts (copy-only, up- and down-scaling, RGBA) in
+    ONE call (two chunks of <= 32: three launches each), tap tables computed on device -- every image bit-identical to the
+    numpy restatement of Pillow + torchvision and to the single-image entry point; two interleaved callers on two streams do
+    not disturb each other (no shared state: the workspace is the caller's)."""
+    import numpy as np
+    from PIL import Image
+    from oracle import image_preprocess as P
+    rng = np.random.default_rng(5)
+    shapes = [(224, 224, 3), (224, 224, 4), (517, 300, 4), (64, 64, 3), (1000, 120, 3), (3, 5, 3), (1, 1, 4), (300, 517, 3),
+              (2048, 1536, 3), (225, 224, 3)]
+    imgs = []
+    for i in range(37):
+        w, h, c = shapes[i % len(shapes)]
+        px = rng.integers(0, 256, size=(h, w, c), dtype=np.uint8)
+        if c == 4:
+            px[..., 3] = rng.choice([0, 255, 128, 7, 254], size=(h, w))
+        imgs.append(px)
+    dev_px = [torch.from_numpy(p).to(dev()) for p in imgs]
+    got = E.op_preprocess_images(dev_px, 224, P.CLIP_MEAN, P.CLIP_STD)
+    assert got.shape == (37, 3, 224, 224)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):                       # a second caller, concurrently, on its own stream and workspace
+        other = E.op_preprocess_images(dev_px[::-1], 224, P.CLIP_MEAN, P.CLIP_STD)
+    torch.cuda.synchronize()
+    for i, px in enumerate(imgs):
+        ref = P.preprocess(px)
+        assert np.array_equal(got[i].cpu().numpy().view(np.int32), ref.view(np.int32)), i
+        assert np.array_equal(other[36 - i].cpu().numpy().view(np.int32), ref.view(np.int32)), i
+    one = E.op_preprocess_image(dev_px[2], 224, P.CLIP_MEAN, P.CLIP_STD)
+    assert torch.equal(one.view(torch.int32), got[2].view(torch.int32))
+    # the mirror's process_images batches the same way and keeps the reference's return shape (list of [1, 3, S, S])
+    from starvector_amd.model import ImageTrainProcessor
+    proc = ImageTrainProcessor(size=224, device=dev())
+    pils = [Image.fromarray(px, "RGBA" if px.shape[2] == 4 else "RGB") for px in imgs[:5]]
+    b = proc.batch(pils)
+    assert b.shape == (5, 3, 224, 224) and torch.equal(b.view(torch.int32), got[:5].view(torch.int32))
+    sig = E.op_preprocess_images(dev_px[:4], 384, (0.5,) * 3, (0.5,) * 3, recipe="siglip")
+    for i in range(4):
+        assert np.array_equal(sig[i].cpu().numpy().view(np.int32), P.preprocess_siglip(imgs[i]).view(np.int32)), i
+    with pytest.raises(ValueError):
+        E.op_preprocess_images([], 224, P.CLIP_MEAN, P.CLIP_STD)
+
+
 # ---- the full-K decode GEMMs (csrc/decode_gemm.hip): the default decode pipeline's kernels, one at a time -------------
 def _ln_ref(x, w, b, eps=1e-5):
     return torch.nn.functional.layer_norm(x, (x.shape[-1],), w, b, eps).bfloat16().float()      # the reference's bf16 LayerNorm output

@@ -21,7 +21,7 @@ def test_oracle_reproduces_reference_goldens(golden_dir, name, norm):
     g = _load(golden_dir, name)
     seed, B, n_new = [int(x) for x in g["meta"]]
     cfg = dataclasses.replace(O.OracleConfig.tiny(), adapter_norm=norm)
-    w = O.make_weights(cfg, seed=seed)
+    w = O.apply_fixture_weights(O.make_weights(cfg, seed=seed), cfg, g)     # tiny_b3 carries a fitted embedding table
     assert torch.equal(O.synthetic_images(B, cfg.image_size, seed=seed + 1), g["image"])
     enc = O.image_encoder_forward(w, cfg, g["image"])
     vis = O.adapter_forward(w, cfg, enc)
@@ -32,8 +32,16 @@ def test_oracle_reproduces_reference_goldens(golden_dir, name, norm):
     torch.testing.assert_close(vis, g["vis"], rtol=0, atol=2e-5 * float(g["vis"].abs().max()))
     torch.testing.assert_close(emb, g["emb"], rtol=0, atol=2e-5 * float(g["emb"].abs().max()))
     torch.testing.assert_close(logits0, g["logits0"], rtol=0, atol=5e-5 * max(1.0, float(g["logits0"].abs().max())))
-    toks = O.greedy_generate(w, cfg, emb, emb.shape[1] + n_new)
+    toks, lg = O.greedy_generate(w, cfg, emb, emb.shape[1] + n_new, return_logits=True)
     assert torch.equal(toks, g["tokens"])                  # integer token ids: bit-exact
+    if "wte" in g:
+        # the designed stream: diverse, and decided by margins far outside bf16 noise
+        top2 = lg.topk(2, -1).values
+        assert float(((top2[..., 0] - top2[..., 1]) / lg.abs().max()).min()) >= 0.1
+        assert len(set(toks.flatten().tolist())) >= 20
+        tb = O.greedy_generate(w, cfg, O.prepare_generation_inputs(w, cfg, g["image"], g["prompt_ids"], "bf16"),
+                               emb.shape[1] + n_new, mode="bf16")
+        assert torch.equal(tb, g["tokens"])                # the bf16 cast points do not move a single token
     full = O.generate_im2svg_tokens(w, cfg, g["image"], g["prompt_ids"], emb.shape[1] + n_new)
     assert torch.equal(full, torch.cat([g["prompt_ids"], g["tokens"]], 1))
 
@@ -42,7 +50,7 @@ def test_stop_eos_pad_semantics_match_hf(golden_dir):
     g = _load(golden_dir, "tiny_stop")
     seed, B, n_new, eos = [int(x) for x in g["meta"]]
     cfg = dataclasses.replace(O.OracleConfig.tiny(), eos_token_id=eos)
-    w = O.make_weights(cfg, seed=seed)
+    w = O.apply_fixture_weights(O.make_weights(cfg, seed=seed), cfg, g)
     emb = O.prepare_generation_inputs(w, cfg, g["image"], g["prompt_ids"])
     toks = O.greedy_generate(w, cfg, emb, emb.shape[1] + n_new, stop_ids=g["stop_ids"].tolist())
     assert torch.equal(toks, g["tokens"])

@@ -218,7 +218,7 @@ def e2e_golden_stop():
     seed, B, n_new, eos = [int(x) for x in gold["meta"]]
     import dataclasses
     cfg = dataclasses.replace(O.OracleConfig.tiny(), eos_token_id=eos)
-    w = O.make_weights(cfg, seed=seed)
+    w = O.apply_fixture_weights(O.make_weights(cfg, seed=seed), cfg, gold)
     eng = build_engine(cfg, w, 4, 64)
     emb = torch.cat([eng.adapter(eng.encode_image(bf(gold["image"]))), eng.embed_tokens(gold["prompt_ids"].to(dev))], 1)
     toks = eng.generate(emb, max_length=emb.shape[1] + n_new, eos_token_id=eos, pad_token_id=cfg.pad_token_id,
