@@ -150,7 +150,8 @@ def main():
                            seed=1)       # config 4 samples: top-p 0.95 after HF 4.49's implicit top-k 50
         out = new if t2s else torch.cat([prompt, new], 1)      # starvector_base.py:256 (text2svg returns the new ids, :329-330)
         if world > 1:
-            out = all_gather_token_streams(out, cfg.pad_token_id, B_PER_GPU * world)
+            # ONE collective: int32 [B, 1 + width] per rank (column 0 = the row's length); the width is known up front
+            out = all_gather_token_streams(out, cfg.pad_token_id, B_PER_GPU * world, width=(0 if t2s else len(PROMPT_IDS)) + max_new)
         return out, new.shape[1]
 
     def sync_all():
@@ -198,11 +199,16 @@ def main():
     sk_ms = prof.get("skinny_chain_ms_per_step", 0.0) or sk["ms_per_step"]
     sk_exec_ms = sk["ms_per_step"]                 # per-launch event deltas minus the empty event-pair time
     achieved = W_BYTES_PER_STEP / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else None
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")       # filled from the rocprofv3 --pmc pass
-    if os.path.exists(tfile) and not is8b:
+    # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is
+    # the one a separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` pass of this command left in profiles/ -- labelled
+    # as such (source + the kernel it was taken on); null when it does not apply to this configuration
+    traffic, traffic_source = None, None
+    tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tfile) and not is8b and args.weights == "bf16" and not t2s:
         try:
-            traffic = json.load(open(tfile)).get("skinny_gemm_bytes_per_launch")
+            tj = json.load(open(tfile))
+            traffic = tj.get("skinny_gemm_bytes_per_launch")
+            traffic_source = ("static: profiles/hbm_traffic.json (" + tj.get("measured", "rocprofv3 --pmc pass, separate run") + ")")
         except Exception:
             traffic = None
 
@@ -247,6 +253,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": f"gemm_skinny_kernel (decoder weight streaming, {int(launches)} launches/step)",
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": round(W_BYTES_PER_STEP / launches),
                          "avg_launch_us": round(sk_ms * 1e3 / launches, 2),
                          "avg_exec_us_event_deltas": round(sk_exec_ms * 1e3 / launches, 2)},
@@ -254,6 +261,15 @@ def main():
                                       "kernel": "gemm_bf16_kernel / gemm256_kernel / gemm_tail_kernel (the 4 decoder GEMMs of a prefill layer)",
                                       "achieved": round(tf_fc, 1), "peak": 2500.0, "unit": "TFLOP/s",
                                       "frac": round(tf_fc / 2500.0, 4), "us_per_layer": round(pf_us, 1), "gemms": per_gemm},
+            # the whole decode step against the same roof: every byte a step must move (decoder weights once + the KV cache of
+            # every sequence at the mean context of the run) over the measured time of a step
+            "roofline_whole_step": (lambda kvb, us: {
+                "bound": "hbm", "bytes_per_step": int(W_BYTES_PER_STEP + kvb), "us_per_step": round(us, 1),
+                "achieved": round((W_BYTES_PER_STEP + kvb) / (us * 1e-6) / 1e9, 1) if us > 0 else None, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round((W_BYTES_PER_STEP + kvb) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us > 0 else None,
+                "launches_per_step": int(sum(v["launches_per_step"] for v in prof.values() if isinstance(v, dict))) + 2})(
+                    B_PER_GPU * (S0 + n_new / 2.0) * cfg.n_layer * 2 * cfg.n_kv_head * cfg.head_dim * 2,
+                    decode_ms / max(decode_steps, 1) * 1e3),
             "decode_step_profile_ms": {k: round(v["ms_per_step"], 4) for k, v in prof.items() if isinstance(v, dict)},
             "setup_s": round(t_setup, 1),
         }

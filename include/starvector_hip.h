@@ -47,7 +47,8 @@ enum {
     SV_ENOENT = -2,       /* unknown weight name / missing weight */
     SV_EHIP = -5,         /* HIP runtime error */
     SV_ESTATE = -1,       /* call order (e.g. generate before weights are complete) */
-    SV_ENOTSUP = -95      /* a combination the engine does not implement (says which) */
+    SV_ENOTSUP = -95,     /* a combination the engine does not implement (says which) */
+    SV_EBUSY = -16        /* continuous batching: no free slot / KV pages for the request right now (release finished slots, retry) */
 };
 
 enum { SV_DTYPE_BF16 = 0, SV_DTYPE_F32 = 1 };
@@ -219,6 +220,38 @@ int  sv_decode_step(sv_engine* e, const int32_t* dev_tokens, int32_t B, float* d
  * columns are left untouched.  Blocks until generation has finished (polls a device flag). */
 int  sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int32_t S0, const sv_sampling* sp,
                  int64_t* dev_out_tokens, int32_t* n_generated, sv_stream stream);
+/* ---- continuous batching (the reference worker's 5 concurrent requests, serve/model_worker.py:161-172,
+ * 216-229, as ONE decode loop).  Every row ("slot") of the engine's batch is an independent request: own sampling parameters,
+ * budget, EOS, stop sequence (the reference's row-0 stop, starvector_base.py:9-20, is right for one request per generate call
+ * and becomes each request's own stop here) and random stream.  A request yields the same tokens as when it runs alone through
+ * sv_generate.  While a continuous batch is active the classic entry points (sv_prefill / sv_generate / ...) return SV_ESTATE.
+ *   sv_cb_admit    prompt pass of n new requests of equal prompt length S0 (dev_embeds [n][S0][hidden] bf16) into free slots --
+ *                  the live slots keep their KV pages -- and their first token; slots_out [n] = the slots taken.
+ *                  SV_EBUSY when slots or KV pages are short (nothing is admitted then).
+ *   sv_cb_step     n_steps decode steps for all live slots (one captured hipGraph per row bucket, kept on the engine);
+ *                  *n_live = slots still generating afterwards.  Finished slots idle until released.
+ *   sv_cb_poll     per slot: live flag and number of tokens emitted so far (host arrays of `capacity` >= max_batch entries)
+ *   sv_cb_read     tokens [first, first + count) of a slot -> host int64
+ *   sv_cb_release  frees a slot and its KV pages (stops it if it is still generating)
+ *   sv_cb_reset    releases everything; the engine is back to the classic entry points */
+typedef struct sv_cb_request {
+    int32_t do_sample; float temperature; float top_p; int32_t top_k;     /* as in sv_sampling */
+    uint64_t seed;
+    int32_t max_new_tokens;    /* new-token budget of THIS request (HF: max_length - prompt length) */
+    int32_t eos_token_id, pad_token_id;
+    int32_t min_new_tokens;
+    float   repetition_penalty;
+    int32_t n_stop;            /* 0..16 */
+    int32_t stop_ids[16];
+} sv_cb_request;
+int  sv_cb_admit(sv_engine* e, const void* dev_embeds, int32_t n, int32_t S0, const sv_cb_request* reqs, int32_t* slots_out,
+                 sv_stream stream);
+int  sv_cb_step(sv_engine* e, int32_t n_steps, int32_t* n_live, sv_stream stream);
+int  sv_cb_poll(sv_engine* e, int32_t* host_live, int32_t* host_steps, int32_t capacity);
+int  sv_cb_read(sv_engine* e, int32_t slot, int32_t first, int32_t count, int64_t* host_tokens);
+int  sv_cb_release(sv_engine* e, int32_t slot);
+int  sv_cb_reset(sv_engine* e);
+
 /* beam scorer: one step consumes dev_logits [batch * num_beams][ld] (row r = request r / num_beams, beam r % num_beams)
  * and reports (host arrays, each batch * num_beams long, may be NULL) the flat parent row, the token and the running
  * score of every beam that continues; *done = 1 once HF's loop would stop.  sv_beam_finalize returns the best

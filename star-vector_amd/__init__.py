@@ -9,8 +9,9 @@ from .model import (  # noqa: F401
     StarVectorConfig, StarVectorForCausalLM, StarVectorStarCoder, StarVectorStarCoder2, StarCoderModel, ImageEncoder, Adapter,
     HipCausalLM, StoppingCriteriaSub, ImageTrainProcessor, SimpleStarVectorProcessor, ByteTokenizer,
 )
+from .batching import ContinuousBatcher  # noqa: F401
 from . import parallel  # noqa: F401
 
 __all__ = ["EngineConfig", "HipEngine", "StarVectorConfig", "StarVectorForCausalLM", "StarVectorStarCoder", "StarVectorStarCoder2",
            "StarCoderModel", "ImageEncoder", "Adapter", "HipCausalLM", "StoppingCriteriaSub",
-           "ImageTrainProcessor", "SimpleStarVectorProcessor", "ByteTokenizer", "StarVectorHipError", "parallel"]
+           "ImageTrainProcessor", "SimpleStarVectorProcessor", "ByteTokenizer", "StarVectorHipError", "ContinuousBatcher", "parallel"]

@@ -46,6 +46,15 @@ class SvSampling(C.Structure):
 TOKEN_CALLBACK = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32)
 
 
+class SvCbRequest(C.Structure):
+    _fields_ = [
+        ("do_sample", C.c_int32), ("temperature", C.c_float), ("top_p", C.c_float), ("top_k", C.c_int32),
+        ("seed", C.c_uint64), ("max_new_tokens", C.c_int32), ("eos_token_id", C.c_int32), ("pad_token_id", C.c_int32),
+        ("min_new_tokens", C.c_int32), ("repetition_penalty", C.c_float), ("n_stop", C.c_int32),
+        ("stop_ids", C.c_int32 * 16),
+    ]
+
+
 class SvBeamConfig(C.Structure):
     _fields_ = [
         ("batch", C.c_int32), ("num_beams", C.c_int32), ("vocab", C.c_int32), ("max_new", C.c_int32),
@@ -83,6 +92,12 @@ PROTOTYPES = {
     "sv_forward_logits": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "sv_decode_step": (_I, [_P, _P, _I, _P, _P]),
     "sv_generate": (_I, [_P, _P, _I, _I, C.POINTER(SvSampling), _P, C.POINTER(_I), _P]),
+    "sv_cb_admit": (_I, [_P, _P, _I, _I, C.POINTER(SvCbRequest), C.POINTER(_I), _P]),
+    "sv_cb_step": (_I, [_P, _I, C.POINTER(_I), _P]),
+    "sv_cb_poll": (_I, [_P, C.POINTER(_I), C.POINTER(_I), _I]),
+    "sv_cb_read": (_I, [_P, _I, _I, _I, C.POINTER(C.c_int64)]),
+    "sv_cb_release": (_I, [_P, _I]),
+    "sv_cb_reset": (_I, [_P]),
     "sv_beam_create": (_I, [C.POINTER(SvBeamConfig), C.POINTER(_P)]),
     "sv_beam_destroy": (_I, [_P]),
     "sv_beam_step": (_I, [_P, _P, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_F), _P]),
@@ -113,6 +128,10 @@ _lib = None
 
 class StarVectorHipError(RuntimeError):
     pass
+
+
+class StarVectorBusy(StarVectorHipError):
+    """sv_cb_admit: no free slot / KV pages right now (SV_EBUSY); release finished requests and retry."""
 
 
 def load() -> C.CDLL:
@@ -155,4 +174,6 @@ def check(rc: int, what: str = "") -> None:
         raise KeyError(text)
     if rc == -95:
         raise NotImplementedError(text)
+    if rc == -16:
+        raise StarVectorBusy(text)
     raise StarVectorHipError(f"{text} (code {rc})")

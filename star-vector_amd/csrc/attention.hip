@@ -325,7 +325,14 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     int act = (ngroups - g0 + AD_GROUPS_PER_BLOCK - 1) / AD_GROUPS_PER_BLOCK;
     act = act > p.max_splits ? p.max_splits : act;      // host cap: B * act <= #CUs (one block per CU) and <= AD_SPLIT
     act = act < 1 ? 1 : act;
-    if (split >= act) return;
+    if (split >= act) {
+        // splits >= max_splits never work: they stream the attention output projection's weights towards L2 / the Infinity
+        // Cache while the active splits wait on KV latency (a hint only)
+        if (split >= p.max_splits && p.pf_ptr)
+            sv_prefetch_slice(p.pf_ptr, p.pf_bytes, (split - p.max_splits) * gridDim.x + bx, (AD_SPLIT - p.max_splits) * gridDim.x,
+                              threadIdx.x, AD_WAVES * 64);
+        return;
+    }
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* q_s = reinterpret_cast<bf16_t*>(smem);                       // [16][D]

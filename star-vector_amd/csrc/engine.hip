@@ -184,6 +184,8 @@ struct sv_engine {
     int* ru_err = nullptr;
     int overlap = 0;                // SV_DECODE_OVERLAP=1: row updates ride inside the consumer GEMM's launch (measured slower)
     bool only_skinny = false;       // profiling: enqueue only the weight-streaming GEMMs of a step
+    int prefetch = 1;               // SV_PREFETCH=0: the idle blocks of attention / row update do not prefetch the next GEMM's weights
+    int prefetch_kb = 64;           // SV_PREFETCH_KB: bytes a prefetching block streams at most (its launch must not get longer)
     int ldq = 0;
     float *ws = nullptr, *ws2 = nullptr, *logits = nullptr, *sample_scratch = nullptr, *attn_part = nullptr;
     unsigned* attn_cnt = nullptr;
@@ -217,6 +219,18 @@ struct sv_engine {
     // null stream, which cannot be captured into a hipGraph); ordered after the caller's stream by an event
     hipStream_t gen_stream = nullptr;
     hipEvent_t gen_event = nullptr;
+    // continuous batching: one request per row ("slot")
+    bool cb_active = false;
+    std::vector<char> cb_used;                    // slot in use (admitted, not yet released)
+    std::vector<std::vector<int>> cb_pages;       // pages held by each slot
+    CbSlot* cb_slots = nullptr;                   // device [max_batch]
+    int32_t *cb_map = nullptr, *cb_nlive = nullptr, *cb_events = nullptr, *cb_table_pf = nullptr;
+    int trash_page = 0;                           // what the block-table rows of free slots point at
+    std::unordered_map<int, std::pair<hipGraph_t, hipGraphExec_t>> cb_graphs;      // one captured step per row bucket
+    // sv_generate: the captured decode step is kept while the next call has the same shape and sampling parameters
+    std::string gen_graph_key;
+    hipGraph_t gen_graph = nullptr;
+    hipGraphExec_t gen_gexec = nullptr;
     // optional per-kernel HIP-event profiling of the decode step (bench.py roofline leg)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -388,6 +402,9 @@ extern "C" int sv_destroy(sv_engine* e) {
     (void)hipDeviceSynchronize();
     for (void* p : e->allocs) (void)hipFree(p);
     e->beam.destroy();
+    for (auto& kv : e->cb_graphs) { if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second); if (kv.second.first) (void)hipGraphDestroy(kv.second.first); }
+    if (e->gen_gexec) (void)hipGraphExecDestroy(e->gen_gexec);
+    if (e->gen_graph) (void)hipGraphDestroy(e->gen_graph);
     if (e->beam_staging) (void)hipFree(e->beam_staging);
     if (e->score_ws) (void)hipFree(e->score_ws);
     if (e->h_flags) (void)hipHostFree(e->h_flags);
@@ -577,10 +594,18 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     e->page_bytes = kv_page_bytes(dh);
     e->pages_per_seq = (c.max_seq_len + SV_PAGE_TOKENS - 1) / SV_PAGE_TOKENS;
     e->num_pages = c.max_batch * e->pages_per_seq;
-    e->kv_head_stride = (size_t)e->num_pages * e->page_bytes;
+    e->trash_page = e->num_pages;                 // one page past the allocatable ones: free slots of a continuous batch write there
+    e->kv_head_stride = (size_t)(e->num_pages + 1) * e->page_bytes;
     e->layer_stride = e->kv_head_stride * nkv;
     A(dev_alloc(e, reinterpret_cast<void**>(&e->kv_pool), e->layer_stride * c.n_layer, true));
     A(dalloc(e, &e->block_table, (size_t)c.max_batch * e->pages_per_seq));
+    A(dalloc(e, &e->cb_table_pf, (size_t)c.max_batch * e->pages_per_seq));
+    A(dalloc(e, &e->cb_slots, (size_t)R));
+    A(dalloc(e, &e->cb_map, (size_t)R));
+    A(dalloc(e, &e->cb_nlive, 4));
+    A(dalloc(e, &e->cb_events, 4));
+    e->cb_used.assign(c.max_batch, 0);
+    e->cb_pages.assign(c.max_batch, {});
 #undef A
     if (!rc) {
         hipError_t hr = hipHostMalloc(reinterpret_cast<void**>(&e->h_flags), 64, hipHostMallocDefault);
@@ -619,6 +644,8 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     if (getenv("SV_DECODE_OVERLAP")) e->overlap = atoi(getenv("SV_DECODE_OVERLAP")) != 0;
     if (2 * c.n_layer + 1 > 64) e->overlap = 0;
     e->fused_decode = getenv("SV_DECODE_FUSED") != nullptr && atoi(getenv("SV_DECODE_FUSED")) != 0;
+    if (getenv("SV_PREFETCH")) e->prefetch = atoi(getenv("SV_PREFETCH"));
+    if (getenv("SV_PREFETCH_KB") && atoi(getenv("SV_PREFETCH_KB")) > 0) e->prefetch_kb = atoi(getenv("SV_PREFETCH_KB"));
     if (v2) e->fused_decode = false;       // the alternative pipelines are v1-only experiments
     if (c.weight_dtype == SV_WEIGHT_FP8_E4M3) { e->fused_decode = false; e->overlap = 0; }
     {
@@ -718,6 +745,15 @@ static void gemm(const bf16_t* A, int lda, const Linear& l, const bf16_t* R, int
     g.M = M; g.N = l.N; g.K = l.Kpad; g.act = act; g.out_f32 = out_f32;
     g.cscale = l.fp8 ? l.wscale : nullptr;
     launch_gemm(g, st);
+}
+
+// Context splits of the decode attention: a constant of the engine (sized for the engine's max_batch), NOT of the batch of the
+// call, so that a sequence's partial results are merged in the same grouping whatever shares the batch with it: a row is
+// bit-identical alone, inside a batch and inside a continuous batch at any context length.
+static int attn_max_splits(const sv_engine* e) {
+    const int rows = (e->cfg.max_batch < 32 ? e->cfg.max_batch : 32) * e->nkv;
+    const int ms = e->num_cus / (rows < 1 ? 1 : rows);
+    return ms < 1 ? 1 : (ms > 8 ? 8 : ms);
 }
 
 // decode-path GEMM on the engine's buffers
@@ -826,7 +862,8 @@ static void lm_head_logits(sv_engine* e, int MT, const bf16_t* xp, const LNp* ln
 }
 
 static int prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hipStream_t st, int n_keep = 0,
-                           bf16_t* dev_scores = nullptr) {
+                           bf16_t* dev_scores = nullptr, const int32_t* table = nullptr) {
+    if (!table) table = e->block_table;           // continuous batching prefills NEW requests through a table of their slots' pages
     const sv_config& c = e->cfg;
     const int D = c.hidden, dh = e->dh, F = c.n_inner, M = B * S0, QKV = e->QKV, nkv = e->nkv;
     const int QD = c.n_head * dh;                      // width of the query block (= D for both model families)
@@ -850,7 +887,7 @@ static int prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hi
         for (int kh = 0; kh < nkv; ++kh)
             launch_kv_write_prefill(e->pqkv, QKV, QD + kh * dh, QD + nkv * dh + kh * dh,
                                     e->kv_pool + (size_t)i * e->layer_stride + (size_t)kh * e->kv_head_stride,
-                                    e->block_table, e->pages_per_seq, B, S0, dh, st);
+                                    table, e->pages_per_seq, B, S0, dh, st);
         launch_attn_prefill(at, st);
         gemm(e->pattn, QD, L.c_proj, e->ph, D, e->ph, D, M, ACT_NONE, 0, st);
         launch_layernorm_rows(e->ph, D, L.ln2.g, L.ln2.b, e->pln, D, M, D, c.ln_eps, st);
@@ -908,7 +945,7 @@ static void decode_forward_fused(sv_engine* e, int B, hipStream_t st) {
         ad.window = c.sliding_window;
         ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
         ad.part = e->attn_part; ad.counters = e->attn_cnt;
-        { const int ms = e->num_cus / (B * e->nkv); ad.max_splits = ms < 1 ? 1 : (ms > 16 ? 16 : ms); }
+        ad.max_splits = attn_max_splits(e);
         ad.n_kv = e->nkv; ad.kv_head_stride = e->kv_head_stride; ad.rope_cos = e->rope_cos; ad.rope_sin = e->rope_sin;
         prof_mark(e, PK_ATTN, st);
         launch_attn_decode(ad, st);
@@ -945,7 +982,22 @@ static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
     int site = 0;
     if (e->overlap) (void)hipMemsetAsync(e->ru_ready, 0, 64 * sizeof(unsigned), st);
     // the pending row update either runs as its own launch or rides inside the next GEMM's launch
+    // the weight image a decode GEMM streams (bf16 fragments, or the fp8 image)
+    auto wimg = [&](const Linear& l, const void** ptr, size_t* bytes) {
+        *ptr = l.fp8 ? (const void*)l.Wq : (const void*)l.Wp;
+        *bytes = (size_t)l.Npad * l.Kpad * (l.fp8 ? 1 : 2);
+    };
+    const Linear* next_gemm = &e->dec[0].c_attn;      // what follows the pending row update
     auto attach = [&](SkinnyArgs& a) {
+        ru.pf_ptr = nullptr; ru.pf_bytes = 0; ru.pf_blocks = 0;
+        if (e->prefetch && next_gemm && !e->overlap) {
+            // 32 CUs do the row update; the others stream (up to ~32 MB of) the following GEMM's weights meanwhile
+            wimg(*next_gemm, &ru.pf_ptr, &ru.pf_bytes);
+            ru.pf_blocks = e->num_cus > B ? e->num_cus - B : 0;
+            const size_t cap = (size_t)ru.pf_blocks * e->prefetch_kb * 1024;       // the head of the image: the first tiles hit
+            if (ru.pf_bytes > cap) ru.pf_bytes = cap;
+            if (ru.pf_blocks == 0) ru.pf_ptr = nullptr;
+        }
         if (!e->overlap) { if (!e->only_skinny) { prof_mark(e, PK_ROWLN, st); launch_row_update_ln(ru, st); } return; }
         a.ru_M = B; a.ru_ws = ru.ws; a.ru_splitk = ru.splitk; a.ru_ldws = ru.ldws; a.ru_rows_ws = ru.rows_ws;
         a.ru_bias = ru.bias; a.ru_h = ru.h; a.ru_ldh = ru.ldh; a.ru_wte = ru.wte; a.ru_wpe = ru.wpe;
@@ -971,8 +1023,13 @@ static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
         ad.window = c.sliding_window;
         ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
         ad.part = e->attn_part; ad.counters = e->attn_cnt;
-        { const int ms = e->num_cus / (B * e->nkv); ad.max_splits = ms < 1 ? 1 : (ms > 16 ? 16 : ms); }
+        ad.max_splits = attn_max_splits(e);
         ad.n_kv = e->nkv; ad.kv_head_stride = e->kv_head_stride; ad.rope_cos = e->rope_cos; ad.rope_sin = e->rope_sin;
+        if (e->prefetch && ad.max_splits < 16) {
+            wimg(L.c_proj, &ad.pf_ptr, &ad.pf_bytes);
+            const size_t cap = (size_t)(16 - ad.max_splits) * B * e->nkv * e->prefetch_kb * 1024;
+            if (ad.pf_bytes > cap) ad.pf_bytes = cap;
+        }
         if (!e->only_skinny) { prof_mark(e, PK_ATTN, st); launch_attn_decode(ad, st); }
         {   // attention output projection -> slabs
             SkinnyArgs a;
@@ -983,6 +1040,7 @@ static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
             launch_gemm_skinny(a, st);
         }
         ru.ws = wsB; ru.splitk = L.c_proj.splitk; ru.bias = L.c_proj.bias; ru.g = L.ln2.g; ru.b = L.ln2.b;
+        next_gemm = &L.c_fc;
         {   // c_fc (+ row update: bias, residual, LN2), GELU epilogue
             SkinnyArgs a;
             memset(&a, 0, sizeof(a));
@@ -1003,6 +1061,7 @@ static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
         }
         const LNp& nxt = (i + 1 < c.n_layer) ? e->dec[i + 1].ln1 : e->ln_f;
         ru.ws = wsB; ru.splitk = L.c_proj2.splitk; ru.bias = L.c_proj2.bias; ru.g = nxt.g; ru.b = nxt.b;
+        next_gemm = (i + 1 < c.n_layer) ? &e->dec[i + 1].c_attn : &e->lm_head;
     }
     {   // lm_head (+ the last row update: bias, residual, ln_f)
         SkinnyArgs a;
@@ -1051,7 +1110,7 @@ static void decode_forward_cols(sv_engine* e, int B, hipStream_t st) {
             ad.window = c.sliding_window;
             ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
             ad.part = e->attn_part; ad.counters = e->attn_cnt;
-            { const int ms = e->num_cus / (B * e->nkv); ad.max_splits = ms < 1 ? 1 : (ms > 16 ? 16 : ms); }
+            ad.max_splits = attn_max_splits(e);
             ad.n_kv = e->nkv; ad.kv_head_stride = e->kv_head_stride; ad.rope_cos = e->rope_cos; ad.rope_sin = e->rope_sin;
             prof_mark(e, PK_ATTN, st);
             launch_attn_decode(ad, st);
@@ -1148,7 +1207,13 @@ static int copy_logits_out(sv_engine* e, int B, float* dev_logits, hipStream_t s
     return 0;
 }
 
+static int cb_guard(sv_engine* e, const char* who) {
+    if (e->cb_active) return fail(SV_ESTATE, "%s: a continuous batch holds the KV cache of this engine (sv_cb_reset first)", who);
+    return 0;
+}
+
 static int prefill_locked(sv_engine* e, const void* dev_embeds, int B, int S0, int total_len, hipStream_t st) {
+    SVCHECK(cb_guard(e, "prefill"));
     if (!dev_embeds || B < 1 || B > e->cfg.max_batch) return fail(SV_EINVAL, "prefill: bad B=%d (max_batch %d)", B, e->cfg.max_batch);
     if (S0 < 1 || S0 > e->cfg.max_seq_len) return fail(SV_EINVAL, "prefill: S0=%d out of range (max_seq_len %d)", S0, e->cfg.max_seq_len);
     SVCHECK(assign_pages(e, B, total_len, st));
@@ -1181,6 +1246,7 @@ extern "C" int sv_forward_logits(sv_engine* e, const void* dev_embeds, int32_t B
     std::lock_guard<std::mutex> lk(e->mu);
     HIPCHECK(hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
+    SVCHECK(cb_guard(e, "sv_forward_logits"));
     SVCHECK(assign_pages(e, B, S, st));
     SVCHECK(prefill_forward(e, (const bf16_t*)dev_embeds, B, S, st, n_keep, (bf16_t*)dev_logits_bf16));
     fill_i32_kernel<<<(B + 63) / 64, 64, 0, st>>>(e->positions, S, B);
@@ -1193,6 +1259,7 @@ extern "C" int sv_decode_step(sv_engine* e, const int32_t* dev_tokens, int32_t B
     SVCHECK(check_ready(e));
     if (!dev_tokens || !dev_logits) return fail(SV_EINVAL, "sv_decode_step: null pointer");
     std::lock_guard<std::mutex> lk(e->mu);
+    SVCHECK(cb_guard(e, "sv_decode_step"));
     if (B != e->cached_B) return fail(SV_ESTATE, "sv_decode_step: B=%d but the cache holds %d sequences", B, e->cached_B);
     HIPCHECK(hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
@@ -1386,6 +1453,7 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
     hipStream_t st = e->gen_stream;
     HIPCHECK(hipStreamWaitEvent(st, e->gen_event, 0));
 
+    SVCHECK(cb_guard(e, "sv_generate"));
     if (sp->num_beams > 1) {
         if (sp->min_new_tokens > 0) return fail(SV_ENOTSUP, "min_new_tokens with beam search is not built (HF applies it to the log-probabilities there)");
         if (sp->on_tokens) return fail(SV_EINVAL, "streaming is not supported with beam search (hypotheses are only final at the end; HF refuses too)");
@@ -1429,23 +1497,39 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
         return 0;
     };
     const bool use_graph = getenv("SV_NO_GRAPH") == nullptr;
-    hipGraph_t graph = nullptr;
     hipGraphExec_t gexec = nullptr;
     if (!e->h_flags[0] && use_graph) {
-        // capture one decode step (all kernel arguments are stable device pointers; the step index,
-        // positions and stop state live in device memory), replay it every step
-        hipError_t ce = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
-        if (ce == hipSuccess) {
-            decode_forward(e, B, st);
-            sample_and_finish(e, B, *sp, max_new, st);
-            ce = hipStreamEndCapture(st, &graph);
-            if (ce == hipSuccess && graph) ce = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0);
-        }
-        if (ce != hipSuccess) {          // fall back to plain launches of the SAME kernels
-            (void)hipGetLastError();
-            if (gexec) { (void)hipGraphExecDestroy(gexec); gexec = nullptr; }
-            if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
-            if (getenv("SV_REQUIRE_GRAPH")) return fail(SV_EHIP, "hipGraph capture failed: %s", hipGetErrorString(ce));
+        // One decode step is captured as a hipGraph (all kernel arguments are stable device pointers; the step index,
+        // positions and stop state live in device memory) and replayed every step.  The instantiated graph is KEPT on the
+        // engine and reused by the next call whose batch, budget and sampling parameters are the same (a serving request
+        // stream, the benchmark), so a short request does not pay a 172-node capture + instantiate; a call with other
+        // parameters replaces it.  Owned by the engine: no early return below can leak it.
+        char key[256];
+        snprintf(key, sizeof(key), "B%d|n%d|ds%d|T%a|p%a|k%d|seed%llu|eos%d|pad%d|ns%d|rp%a|mn%d|pipe%d%d%d", B, max_new, sp->do_sample,
+                 sp->temperature, sp->top_p, sp->top_k, (unsigned long long)sp->seed, sp->eos_token_id, sp->pad_token_id, sp->n_stop,
+                 sp->repetition_penalty, sp->min_new_tokens, (int)e->cols_decode, (int)e->fused_decode, e->overlap);
+        if (e->gen_gexec && e->gen_graph_key == key) {
+            gexec = e->gen_gexec;
+        } else {
+            if (e->gen_gexec) { (void)hipGraphExecDestroy(e->gen_gexec); e->gen_gexec = nullptr; }
+            if (e->gen_graph) { (void)hipGraphDestroy(e->gen_graph); e->gen_graph = nullptr; }
+            e->gen_graph_key.clear();
+            hipError_t ce = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+            if (ce == hipSuccess) {
+                decode_forward(e, B, st);
+                sample_and_finish(e, B, *sp, max_new, st);
+                ce = hipStreamEndCapture(st, &e->gen_graph);
+                if (ce == hipSuccess && e->gen_graph) ce = hipGraphInstantiate(&e->gen_gexec, e->gen_graph, nullptr, nullptr, 0);
+            }
+            if (ce != hipSuccess) {          // fall back to plain launches of the SAME kernels
+                (void)hipGetLastError();
+                if (e->gen_gexec) { (void)hipGraphExecDestroy(e->gen_gexec); e->gen_gexec = nullptr; }
+                if (e->gen_graph) { (void)hipGraphDestroy(e->gen_graph); e->gen_graph = nullptr; }
+                if (getenv("SV_REQUIRE_GRAPH")) return fail(SV_EHIP, "hipGraph capture failed: %s", hipGetErrorString(ce));
+            } else {
+                e->gen_graph_key = key;
+                gexec = e->gen_gexec;
+            }
         }
     }
     while (!e->h_flags[0]) {
@@ -1466,8 +1550,6 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
         if (!e->h_flags[0]) SVCHECK(stream_upto(steps + 1));      // still running: every column so far is final
     }
     const double gexec_used = gexec ? 1.0 : 0.0;
-    if (gexec) (void)hipGraphExecDestroy(gexec);
-    if (graph) (void)hipGraphDestroy(graph);
     HIPCHECK(hipMemcpyAsync(&e->h_flags[1], e->d_nemit, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
     if (e->h_flags[1] >= 1 && e->h_flags[1] <= max_new) SVCHECK(stream_upto(e->h_flags[1]));
@@ -1490,6 +1572,240 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
     e->timing[1] = std::chrono::duration<double, std::milli>(t2 - t1).count();
     e->timing[2] = (double)steps;
     e->timing_graph = gexec_used;
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI: continuous batching.  The reference's worker admits up to 5 concurrent requests
+// (serve/model_worker.py:161-172,216-229) and runs each as its own HF generate; here they share ONE decode loop: every
+// row ("slot") of the batch is a request with its own sampling parameters, budget, EOS and stop sequence, requests join
+// (prefill into free slots while the others keep their KV pages) and leave at any step, and the captured decode step is kept
+// per row bucket.  A request produces the same tokens as when it runs alone through sv_generate.
+// ------------------------------------------------------------------------------------------------
+static int cb_bucket(const sv_engine* e) {
+    int hi = 0;
+    for (int s2 = 0; s2 < e->cfg.max_batch; ++s2) if (e->cb_used[s2]) hi = s2 + 1;
+    int b = 8;
+    while (b < hi) b <<= 1;
+    return b > e->cfg.max_batch ? e->cfg.max_batch : b;
+}
+
+static void cb_step_args(sv_engine* e, CbStepArgs& a, const int32_t* map) {
+    a.logits = e->logits; a.ld = e->Vpad; a.V = e->cfg.vocab; a.slots = e->cb_slots; a.slot_map = map;
+    a.cur_tok = e->cur_tok; a.positions = e->positions; a.out_tokens = e->out_tok; a.ld_out = e->out_ld;
+    a.seen = e->seen; a.seen_words = e->seen_words; a.n_live = e->cb_nlive; a.events = e->cb_events;
+}
+
+static int cb_begin(sv_engine* e, hipStream_t st) {
+    if (e->cb_active) return 0;
+    e->free_pages.clear();
+    for (int p = e->num_pages - 1; p >= 0; --p) e->free_pages.push_back(p);
+    std::fill(e->cb_used.begin(), e->cb_used.end(), 0);
+    for (auto& v : e->cb_pages) v.clear();
+    const size_t R = (size_t)e->MT * 32;
+    std::vector<int32_t> table((size_t)e->cfg.max_batch * e->pages_per_seq, e->trash_page);
+    HIPCHECK(hipMemcpyAsync(e->block_table, table.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemsetAsync(e->cb_slots, 0, R * sizeof(CbSlot), st));
+    HIPCHECK(hipMemsetAsync(e->positions, 0, R * sizeof(int32_t), st));
+    HIPCHECK(hipMemsetAsync(e->cur_tok, 0, R * sizeof(int32_t), st));
+    HIPCHECK(hipMemsetAsync(e->cb_nlive, 0, sizeof(int32_t), st));
+    HIPCHECK(hipMemsetAsync(e->cb_events, 0, sizeof(int32_t), st));
+    HIPCHECK(hipStreamSynchronize(st));                  // `table` is a host temporary
+    e->cb_active = true;
+    e->cached_B = 0;
+    return 0;
+}
+
+extern "C" int sv_cb_admit(sv_engine* e, const void* dev_embeds, int32_t n, int32_t S0, const sv_cb_request* reqs,
+                           int32_t* slots_out, sv_stream stream) {
+    SVCHECK(check_ready(e));
+    if (!dev_embeds || !reqs || !slots_out || n < 1) return fail(SV_EINVAL, "sv_cb_admit: null argument or empty batch");
+    const sv_config& c = e->cfg;
+    if (n > c.max_batch) return fail(SV_EINVAL, "sv_cb_admit: %d requests exceed max_batch %d", n, c.max_batch);
+    if (S0 < 1) return fail(SV_EINVAL, "sv_cb_admit: bad prompt length %d", S0);
+    for (int i = 0; i < n; ++i) {
+        const sv_cb_request& r = reqs[i];
+        if (r.max_new_tokens < 1 || S0 + r.max_new_tokens > c.max_seq_len)
+            return fail(SV_EINVAL, "sv_cb_admit: request %d: prompt %d + max_new_tokens %d out of range (max_seq_len %d)", i, S0, r.max_new_tokens, c.max_seq_len);
+        if (r.n_stop < 0 || r.n_stop > SV_CB_MAXSTOP) return fail(SV_EINVAL, "sv_cb_admit: request %d: stop sequence length %d unsupported (0..%d)", i, r.n_stop, SV_CB_MAXSTOP);
+        if (r.do_sample && !(r.temperature > 0.f && r.top_p > 0.f)) return fail(SV_EINVAL, "sv_cb_admit: request %d: temperature and top_p must be > 0", i);
+    }
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHECK(hipSetDevice(c.device));
+    HIPCHECK(hipEventRecord(e->gen_event, (hipStream_t)stream));
+    hipStream_t st = e->gen_stream;
+    HIPCHECK(hipStreamWaitEvent(st, e->gen_event, 0));
+    SVCHECK(cb_begin(e, st));
+    // free slots (lowest first: keeps the row bucket of the decode graph small) and pages for the whole budget
+    std::vector<int> slots;
+    size_t need_pages = 0;
+    for (int s2 = 0; s2 < c.max_batch && (int)slots.size() < n; ++s2) if (!e->cb_used[s2]) slots.push_back(s2);
+    for (int i = 0; i < n; ++i) need_pages += (size_t)(S0 + reqs[i].max_new_tokens + SV_PAGE_TOKENS - 1) / SV_PAGE_TOKENS;
+    if ((int)slots.size() < n || need_pages > e->free_pages.size())
+        return fail(SV_EBUSY, "sv_cb_admit: %d requests need %d slots / %zu KV pages, %zu / %zu are free (release finished slots first)",
+                    n, n, need_pages, slots.size(), e->free_pages.size());
+    std::vector<int32_t> rows((size_t)n * e->pages_per_seq, e->trash_page);
+    std::vector<CbSlot> hs(n);
+    std::vector<int32_t> map(n), pos(n, S0 - 1);
+    const bool any_pen = [&] { for (int i = 0; i < n; ++i) if (reqs[i].repetition_penalty > 0.f && reqs[i].repetition_penalty != 1.0f) return true; return false; }();
+    for (int i = 0; i < n; ++i) {
+        const int s2 = slots[i];
+        const sv_cb_request& r = reqs[i];
+        const int need = (S0 + r.max_new_tokens + SV_PAGE_TOKENS - 1) / SV_PAGE_TOKENS;
+        e->cb_pages[s2].clear();
+        for (int k = 0; k < need; ++k) {
+            rows[(size_t)i * e->pages_per_seq + k] = e->free_pages.back();
+            e->cb_pages[s2].push_back(e->free_pages.back());
+            e->free_pages.pop_back();
+        }
+        e->cb_used[s2] = 1;
+        CbSlot& h = hs[i];
+        memset(&h, 0, sizeof(h));
+        h.live = 1; h.step = 0; h.budget = r.max_new_tokens; h.do_sample = r.do_sample ? 1 : 0; h.temperature = r.temperature;
+        h.top_p = r.top_p; h.top_k = r.top_k; h.eos = r.eos_token_id; h.pad = r.pad_token_id; h.min_new = r.min_new_tokens;
+        h.penalty = r.repetition_penalty > 0.f ? r.repetition_penalty : 1.0f; h.n_stop = r.n_stop; h.seed = r.seed;
+        for (int k = 0; k < r.n_stop; ++k) h.stop[k] = r.stop_ids[k];
+        map[i] = s2;
+        slots_out[i] = s2;
+    }
+    for (int i = 0; i < n; ++i) {
+        const int s2 = slots[i];
+        HIPCHECK(hipMemcpyAsync(e->block_table + (size_t)s2 * e->pages_per_seq, rows.data() + (size_t)i * e->pages_per_seq,
+                                e->pages_per_seq * sizeof(int32_t), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(e->cb_slots + s2, &hs[i], sizeof(CbSlot), hipMemcpyHostToDevice, st));
+        HIPCHECK(hipMemcpyAsync(e->positions + s2, &pos[i], sizeof(int32_t), hipMemcpyHostToDevice, st));
+        if (any_pen) HIPCHECK(hipMemsetAsync(e->seen + (size_t)s2 * e->seen_words, 0, e->seen_words * sizeof(uint32_t), st));
+    }
+    HIPCHECK(hipMemcpyAsync(e->cb_table_pf, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipMemcpyAsync(e->cb_map, map.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    add_i32_kernel<<<1, 64, 0, st>>>(e->cb_nlive, n, 1);
+    // prompt pass of the NEW requests only (their pages through cb_table_pf); the live slots keep decoding afterwards
+    SVCHECK(prefill_forward(e, (const bf16_t*)dev_embeds, n, S0, st, 0, nullptr, e->cb_table_pf));
+    CbStepArgs a;
+    cb_step_args(e, a, e->cb_map);
+    launch_cb_step(a, n, st);                              // first token of every new request, from the prefill logits
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(st));                    // the staging vectors above are host temporaries
+    return 0;
+}
+
+extern "C" int sv_cb_step(sv_engine* e, int32_t n_steps, int32_t* n_live_out, sv_stream stream) {
+    SVCHECK(check_ready(e));
+    if (n_steps < 1 || !n_live_out) return fail(SV_EINVAL, "sv_cb_step: bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->cb_active) return fail(SV_ESTATE, "sv_cb_step: no continuous batch (sv_cb_admit first)");
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    hipStream_t st = e->gen_stream;
+    const int Bb = cb_bucket(e);
+    hipGraphExec_t gexec = nullptr;
+    if (getenv("SV_NO_GRAPH") == nullptr) {
+        auto it = e->cb_graphs.find(Bb);
+        if (it != e->cb_graphs.end()) {
+            gexec = it->second.second;
+        } else {
+            hipGraph_t g = nullptr;
+            hipGraphExec_t ge = nullptr;
+            hipError_t ce = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+            if (ce == hipSuccess) {
+                decode_forward(e, Bb, st);
+                CbStepArgs a;
+                cb_step_args(e, a, nullptr);
+                launch_cb_step(a, Bb, st);
+                ce = hipStreamEndCapture(st, &g);
+                if (ce == hipSuccess && g) ce = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+            }
+            if (ce != hipSuccess) {
+                (void)hipGetLastError();
+                if (ge) (void)hipGraphExecDestroy(ge);
+                if (g) (void)hipGraphDestroy(g);
+                if (getenv("SV_REQUIRE_GRAPH")) return fail(SV_EHIP, "hipGraph capture failed: %s", hipGetErrorString(ce));
+            } else {
+                e->cb_graphs[Bb] = {g, ge};                // kept for the life of the engine: every argument is engine-owned
+                gexec = ge;
+            }
+        }
+    }
+    for (int i = 0; i < n_steps; ++i) {
+        if (gexec) {
+            HIPCHECK(hipGraphLaunch(gexec, st));
+        } else {
+            decode_forward(e, Bb, st);
+            CbStepArgs a;
+            cb_step_args(e, a, nullptr);
+            launch_cb_step(a, Bb, st);
+        }
+    }
+    HIPCHECK(hipMemcpyAsync(&e->h_flags[3], e->cb_nlive, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    *n_live_out = e->h_flags[3];
+    e->timing_graph = gexec ? 1.0 : 0.0;
+    return 0;
+}
+
+extern "C" int sv_cb_poll(sv_engine* e, int32_t* host_live, int32_t* host_steps, int32_t capacity) {
+    if (!e || !host_live || !host_steps) return fail(SV_EINVAL, "sv_cb_poll: null argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (capacity < e->cfg.max_batch) return fail(SV_EINVAL, "sv_cb_poll: capacity %d < max_batch %d", capacity, e->cfg.max_batch);
+    for (int s2 = 0; s2 < e->cfg.max_batch; ++s2) { host_live[s2] = 0; host_steps[s2] = 0; }
+    if (!e->cb_active) return 0;
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    std::vector<CbSlot> hs(e->cfg.max_batch);
+    HIPCHECK(hipMemcpyAsync(hs.data(), e->cb_slots, hs.size() * sizeof(CbSlot), hipMemcpyDeviceToHost, e->gen_stream));
+    HIPCHECK(hipStreamSynchronize(e->gen_stream));
+    for (int s2 = 0; s2 < e->cfg.max_batch; ++s2)
+        if (e->cb_used[s2]) { host_live[s2] = hs[s2].live; host_steps[s2] = hs[s2].step; }
+    return 0;
+}
+
+extern "C" int sv_cb_read(sv_engine* e, int32_t slot, int32_t first, int32_t count, int64_t* host_tokens) {
+    if (!e || !host_tokens) return fail(SV_EINVAL, "sv_cb_read: null argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->cb_active || slot < 0 || slot >= e->cfg.max_batch || !e->cb_used[slot]) return fail(SV_EINVAL, "sv_cb_read: slot %d is not in use", slot);
+    if (first < 0 || count < 0 || first + count > e->out_ld) return fail(SV_EINVAL, "sv_cb_read: columns [%d, %d) out of range", first, first + count);
+    if (count == 0) return 0;
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    std::vector<int32_t> tmp(count);
+    HIPCHECK(hipMemcpyAsync(tmp.data(), e->out_tok + (size_t)slot * e->out_ld + first, (size_t)count * sizeof(int32_t),
+                            hipMemcpyDeviceToHost, e->gen_stream));
+    HIPCHECK(hipStreamSynchronize(e->gen_stream));
+    for (int i = 0; i < count; ++i) host_tokens[i] = tmp[i];
+    return 0;
+}
+
+static int cb_release_locked(sv_engine* e, int slot, hipStream_t st) {
+    // a slot released while still generating is stopped first (live -> 0, live counter adjusted on the host's view)
+    CbSlot h;
+    HIPCHECK(hipMemcpyAsync(&h, e->cb_slots + slot, sizeof(CbSlot), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    if (h.live) add_i32_kernel<<<1, 64, 0, st>>>(e->cb_nlive, -1, 1);
+    HIPCHECK(hipMemsetAsync(e->cb_slots + slot, 0, sizeof(CbSlot), st));
+    HIPCHECK(hipMemsetAsync(e->positions + slot, 0, sizeof(int32_t), st));
+    HIPCHECK(hipMemsetAsync(e->cur_tok + slot, 0, sizeof(int32_t), st));
+    fill_i32_kernel<<<(e->pages_per_seq + 63) / 64, 64, 0, st>>>(e->block_table + (size_t)slot * e->pages_per_seq, e->trash_page, e->pages_per_seq);
+    for (int pg : e->cb_pages[slot]) e->free_pages.push_back(pg);
+    e->cb_pages[slot].clear();
+    e->cb_used[slot] = 0;
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int sv_cb_release(sv_engine* e, int32_t slot) {
+    if (!e) return fail(SV_EINVAL, "null engine");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->cb_active || slot < 0 || slot >= e->cfg.max_batch || !e->cb_used[slot]) return fail(SV_EINVAL, "sv_cb_release: slot %d is not in use", slot);
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    return cb_release_locked(e, slot, e->gen_stream);
+}
+
+extern "C" int sv_cb_reset(sv_engine* e) {
+    if (!e) return fail(SV_EINVAL, "null engine");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->cb_active) return 0;
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    for (int s2 = 0; s2 < e->cfg.max_batch; ++s2)
+        if (e->cb_used[s2]) SVCHECK(cb_release_locked(e, s2, e->gen_stream));
+    HIPCHECK(hipStreamSynchronize(e->gen_stream));
+    e->cb_active = false;
     return 0;
 }
 

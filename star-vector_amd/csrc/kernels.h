@@ -133,6 +133,7 @@ struct RowUpdateArgs {
     const bf16_t* g; const bf16_t* b; float eps;           // LayerNorm applied to the updated row
     bf16_t* xp_out;                                        // packed LN output
     int M, D;
+    const void* pf_ptr; size_t pf_bytes; int pf_blocks;    // extra blocks [M, M + pf_blocks) prefetch the next GEMM's weights (or 0)
 };
 void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st);
 
@@ -192,6 +193,7 @@ struct AttnDecodeArgs {
     size_t kv_head_stride;                                 // bytes between the page pools of consecutive KV heads
     const float* rope_cos; const float* rope_sin;          // [positions][D/2] rotary tables (nullptr: no RoPE)
     int window;                                            // sliding window: keys pos - window < j <= pos (0 = all)
+    const void* pf_ptr; size_t pf_bytes;                   // the always-inactive splits prefetch the next GEMM's weights (or null)
 };
 // in-place rotary embedding of the q and k heads of a prefill c_attn output (rotate_half convention)
 void launch_rope_prefill(bf16_t* qkv, int row_stride, int rows, int S0, int n_heads, int head_dim,
@@ -230,6 +232,27 @@ struct FinishArgs {
     uint32_t* seen; int seen_words;   // repetition-penalty bitmap to update with the emitted ids (nullptr = off)
 };
 void launch_finish_step(const FinishArgs& a, hipStream_t st);
+
+// ---- continuous batching: one request per row ("slot"), everything per row (sampling.hip) ---------------------------
+#define SV_CB_MAXSTOP 16
+struct CbSlot {                  // device-resident, one per slot
+    int32_t live;                // 1 = generating
+    int32_t step;                // tokens emitted so far
+    int32_t budget;              // new-token budget of the request
+    int32_t do_sample; float temperature, top_p; int32_t top_k;
+    int32_t eos, pad, min_new; float penalty;
+    int32_t n_stop; int32_t stop[SV_CB_MAXSTOP];
+    int32_t pad_[1];
+    uint64_t seed;
+};
+struct CbStepArgs {
+    const float* logits; int ld; int V;
+    CbSlot* slots; const int32_t* slot_map;      // block b works for slot slot_map[b] (nullptr: b) on logits row b
+    int32_t* cur_tok; int32_t* positions; int32_t* out_tokens; int ld_out;
+    uint32_t* seen; int seen_words;
+    int32_t* n_live; int32_t* events;           // device counters: live slots, finished-slot events
+};
+void launch_cb_step(const CbStepArgs& a, int nblocks, hipStream_t st);
 
 // ---- image pre-processing (preprocess.hip): uint8 HWC (3 or 4 channels) -> float32 [3][S][S], returns a hipError_t value
 int preprocess_image(const uint8_t* dev_pixels, int width, int height, int channels, int out_size, int recipe,

@@ -72,6 +72,10 @@ __global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
     __shared__ float redbuf[8];
     const int row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (row >= p.M) {       // spare blocks: stream the next GEMM's weights towards L2 / the Infinity Cache (a hint only)
+        sv_prefetch_slice(p.pf_ptr, p.pf_bytes, row - p.M, p.pf_blocks, tid, 256);
+        return;
+    }
     const int D = p.D, NC = D >> 3;
     bf16_t* hr = p.h + (size_t)row * p.ldh;
 
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
 }
 
 void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st) {
-    row_update_ln_kernel<<<a.M, 256, a.D * sizeof(float), st>>>(a);
+    row_update_ln_kernel<<<a.M + (a.pf_ptr ? a.pf_blocks : 0), 256, a.D * sizeof(float), st>>>(a);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -74,18 +74,13 @@ void launch_argmax(const float* logits, int ld, int V, int32_t* out, float* pval
     argmax_merge_kernel<<<(B + 63) / 64, 64, 0, st>>>(pval, pidx, out, B);
 }
 
-__global__ __launch_bounds__(SP_THREADS) void sample_top_p_kernel(SampleArgs p) {
-    __shared__ float red[SP_THREADS / 64];
-    __shared__ float scan[SP_THREADS];
-    __shared__ int result;
+// one multinomial draw from softmax(warped scores) of a row, by the whole 1024-thread block; `lg(i)` = the row's score after
+// processors and temperature.  The random number is a pure function of (seed, step, row).  Every thread returns the token.
+template <class F>
+__device__ int sample_row(F lg, int V, int top_k, float top_p, uint64_t seed, uint32_t step, uint32_t rowid, float* red,
+                          float* scan, int* result) {
     const int tid = threadIdx.x;
-    const int V = p.V;
-    const float* row = p.logits + (size_t)blockIdx.x * p.ld;
-    const uint32_t* srow = p.seen ? p.seen + (size_t)blockIdx.x * p.seen_words : nullptr;
-    const float invT = 1.0f / p.temperature;
-    auto lg = [&](int i) { return rep_penalty(row[i], i, srow, p.penalty) * invT; };     // processors, then temperature
-    const WarpStats w = row_warp_stats(lg, V, p.top_k, p.top_p, 1, red);                 // TopK -> TopP thresholds
-
+    const WarpStats w = row_warp_stats(lg, V, top_k, top_p, 1, red);                     // TopK -> TopP thresholds
     // multinomial over the survivors, in index order: per-thread contiguous ranges + block scan
     const int per = (V + SP_THREADS - 1) / SP_THREADS;
     const int beg = tid * per, end = min(beg + per, V);
@@ -94,17 +89,18 @@ __global__ __launch_bounds__(SP_THREADS) void sample_top_p_kernel(SampleArgs p) 
         const float s = lg(i);
         mine += wp_keep(w, s) ? wp_prob(w, s) : 0.f;
     }
+    __syncthreads();
     scan[tid] = mine;
     __syncthreads();
     if (tid == 0) {
         float run = 0.f;
         for (int t = 0; t < SP_THREADS; ++t) { const float x = scan[t]; scan[t] = run; run += x; }
         red[0] = run;
-        result = -1;
+        *result = -1;
     }
     __syncthreads();
     const float total = red[0];
-    const uint64_t h = wp_splitmix64(p.seed ^ wp_splitmix64(((uint64_t)(uint32_t)p.step[0] << 32) | (uint32_t)blockIdx.x));
+    const uint64_t h = wp_splitmix64(seed ^ wp_splitmix64(((uint64_t)step << 32) | rowid));
     const float u = (float)((h >> 40) * (1.0 / 16777216.0)) * total;
     const float base = scan[tid];
     if (mine > 0.f && u >= base && u < base + mine) {
@@ -118,18 +114,29 @@ __global__ __launch_bounds__(SP_THREADS) void sample_top_p_kernel(SampleArgs p) 
                 if (u < run) break;
             }
         }
-        result = pick;
+        *result = pick;
     }
     __syncthreads();
-    if (tid == 0) {
-        if (result < 0) {
-            // round-off fell between ranges: take the most probable token (always a survivor)
-            float best = -INFINITY; int bi = 0;
-            for (int i = 0; i < V; ++i) if (lg(i) > best) { best = lg(i); bi = i; }
-            result = bi;
-        }
-        p.out[blockIdx.x] = result;
+    if (tid == 0 && *result < 0) {
+        // round-off fell between ranges: take the most probable token (always a survivor)
+        float best = -INFINITY; int bi = 0;
+        for (int i = 0; i < V; ++i) if (lg(i) > best) { best = lg(i); bi = i; }
+        *result = bi;
     }
+    __syncthreads();
+    return *result;
+}
+
+__global__ __launch_bounds__(SP_THREADS) void sample_top_p_kernel(SampleArgs p) {
+    __shared__ float red[SP_THREADS / 64];
+    __shared__ float scan[SP_THREADS];
+    __shared__ int result;
+    const float* row = p.logits + (size_t)blockIdx.x * p.ld;
+    const uint32_t* srow = p.seen ? p.seen + (size_t)blockIdx.x * p.seen_words : nullptr;
+    const float invT = 1.0f / p.temperature;
+    auto lg = [&](int i) { return rep_penalty(row[i], i, srow, p.penalty) * invT; };     // processors, then temperature
+    const int tok = sample_row(lg, p.V, p.top_k, p.top_p, p.seed, (uint32_t)p.step[0], (uint32_t)blockIdx.x, red, scan, &result);
+    if (threadIdx.x == 0) p.out[blockIdx.x] = tok;
 }
 void launch_sample_top_p(const SampleArgs& a, hipStream_t st) {
     sample_top_p_kernel<<<a.B, SP_THREADS, 0, st>>>(a);
@@ -179,6 +186,83 @@ __global__ void finish_step_kernel(FinishArgs p) {
 void launch_finish_step(const FinishArgs& a, hipStream_t st) {
     int threads = ((a.B + 63) / 64) * 64;
     finish_step_kernel<<<1, threads, 0, st>>>(a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Continuous batching (the reference's worker admits 5 concurrent requests, serve/model_worker.py:
+// 216-229, and runs them one HF generate each): every row ("slot") of the decode batch is an independent REQUEST with its
+// own sampling parameters, budget, EOS and stop sequence.  One block per slot selects the token (greedy argmax, lowest
+// index on ties; or temperature -> top-k -> top-p -> multinomial) and does the slot's bookkeeping -- everything is per row,
+// so the reference's row-0 stop (starvector_base.py:9-20: right for ONE request per generate call) becomes each request's
+// own stop.  The random stream of a slot depends on (its seed, its own step, row 0): a request produces the same tokens
+// as when it runs alone through sv_generate.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(SP_THREADS) void cb_step_kernel(CbStepArgs p) {
+    __shared__ float red[SP_THREADS / 64];
+    __shared__ float scan[SP_THREADS];
+    __shared__ int result;
+    __shared__ float am_v[SP_THREADS / 64];
+    __shared__ int am_i[SP_THREADS / 64];
+    const int b = blockIdx.x;
+    const int s = p.slot_map ? p.slot_map[b] : b;
+    const CbSlot sl = p.slots[s];
+    if (!sl.live) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = p.logits + (size_t)b * p.ld;
+    const uint32_t* srow = (p.seen && sl.penalty > 0.f && sl.penalty != 1.0f) ? p.seen + (size_t)s * p.seen_words : nullptr;
+    const bool hold_eos = sl.step < sl.min_new;                     // MinLengthLogitsProcessor
+    int tok;
+    if (sl.do_sample) {
+        const float invT = 1.0f / sl.temperature;
+        auto lg = [&](int i) { return (hold_eos && i == sl.eos) ? -INFINITY : rep_penalty(row[i], i, srow, sl.penalty) * invT; };
+        tok = sample_row(lg, p.V, sl.top_k, sl.top_p, sl.seed, (uint32_t)sl.step, 0u, red, scan, &result);
+    } else {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int i = tid * 4; i < p.V; i += SP_THREADS * 4) {
+            const float4 v = *reinterpret_cast<const float4*>(row + i);
+            const float a[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (i + e < p.V && !(hold_eos && i + e == sl.eos)) argmax_pair(best, bi, rep_penalty(a[e], i + e, srow, sl.penalty), i + e);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            argmax_pair(best, bi, ov, oi);
+        }
+        if (lane == 0) { am_v[wave] = best; am_i[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < SP_THREADS / 64; ++w) argmax_pair(best, bi, am_v[w], am_i[w]);
+            result = bi;
+        }
+        __syncthreads();
+        tok = result;
+    }
+    if (tid != 0) return;
+    const int t = sl.step;
+    int32_t* out = p.out_tokens + (size_t)s * p.ld_out;
+    out[t] = tok;
+    p.cur_tok[s] = tok;
+    p.positions[s] += 1;
+    if (srow) atomicOr(p.seen + (size_t)s * p.seen_words + (tok >> 5), 1u << (tok & 31));
+    bool fin = tok == sl.eos || t + 1 >= sl.budget;
+    if (!fin && sl.n_stop > 0 && t + 1 >= sl.n_stop) {
+        fin = true;
+        for (int i = 0; i < sl.n_stop; ++i)
+            if (out[t + 1 - sl.n_stop + i] != sl.stop[i]) { fin = false; break; }
+    }
+    p.slots[s].step = t + 1;
+    if (fin) {
+        p.slots[s].live = 0;
+        atomicSub(p.n_live, 1);
+        atomicAdd(p.events, 1);
+    }
+}
+void launch_cb_step(const CbStepArgs& a, int nblocks, hipStream_t st) {
+    cb_step_kernel<<<nblocks, SP_THREADS, 0, st>>>(a);
 }
 
 }  // namespace sv

@@ -3,7 +3,7 @@ from __future__ import annotations
 
 import ctypes as C
 from dataclasses import dataclass
-from typing import Dict, Iterable, Optional, Sequence
+from typing import Dict, Iterable, List, Optional, Sequence
 
 import torch
 
@@ -216,6 +216,58 @@ class HipEngine:
         if cb_errors:
             raise cb_errors[0]
         return out[:, : n.value]
+
+    # ---- continuous batching: one request per row of the engine's batch (include/starvector_hip.h, sv_cb_*) ----------------
+    def cb_admit(self, inputs_embeds: torch.Tensor, requests: Sequence[dict]) -> List[int]:
+        """Prompt pass of len(requests) new requests (inputs_embeds [n, S0, D] bf16, equal prompt length) into free slots while
+        the live slots keep their KV cache; samples their first token.  Each request: dict(max_new_tokens, do_sample=False,
+        temperature=1, top_p=1, top_k=0, seed=0, eos_token_id=0, pad_token_id=0, stop_ids=None, repetition_penalty=1,
+        min_new_tokens=0).  Returns the slot ids.  Raises StarVectorBusy when slots or KV pages are short."""
+        x = _need(inputs_embeds, torch.bfloat16, "inputs_embeds")
+        n, S0, D = x.shape
+        if D != self.cfg.hidden or n != len(requests):
+            raise ValueError("inputs_embeds / requests mismatch")
+        arr = (_lib.SvCbRequest * n)()
+        for i, r in enumerate(requests):
+            stops = list(r.get("stop_ids") or [])
+            if len(stops) > 16:
+                raise ValueError("stop sequence longer than 16 ids")
+            a = arr[i]
+            a.do_sample = int(bool(r.get("do_sample", False))); a.temperature = float(r.get("temperature", 1.0))
+            a.top_p = float(r.get("top_p", 1.0)); a.top_k = int(r.get("top_k", 0) or 0)
+            a.seed = int(r.get("seed", 0)) & 0xFFFFFFFFFFFFFFFF; a.max_new_tokens = int(r["max_new_tokens"])
+            a.eos_token_id = int(r.get("eos_token_id", 0)); a.pad_token_id = int(r.get("pad_token_id", 0))
+            a.min_new_tokens = int(r.get("min_new_tokens", 0) or 0); a.repetition_penalty = float(r.get("repetition_penalty", 1.0) or 1.0)
+            a.n_stop = len(stops)
+            for k, t in enumerate(stops):
+                a.stop_ids[k] = int(t)
+        slots = (C.c_int32 * n)()
+        check(self.lib.sv_cb_admit(self._h, _ptr(x), n, S0, arr, slots, _stream()), "sv_cb_admit")
+        return list(slots)
+
+    def cb_step(self, n_steps: int = 8) -> int:
+        """n_steps decode steps for every live slot (hipGraph replay); returns how many slots are still generating."""
+        live = C.c_int32(0)
+        check(self.lib.sv_cb_step(self._h, int(n_steps), C.byref(live), _stream()), "sv_cb_step")
+        return live.value
+
+    def cb_poll(self):
+        """(live flags, tokens emitted so far) per slot, two lists of max_batch ints."""
+        n = self.cfg.max_batch
+        lv, st = (C.c_int32 * n)(), (C.c_int32 * n)()
+        check(self.lib.sv_cb_poll(self._h, lv, st, n), "sv_cb_poll")
+        return list(lv), list(st)
+
+    def cb_read(self, slot: int, first: int, count: int) -> torch.Tensor:
+        buf = (C.c_int64 * max(count, 1))()
+        check(self.lib.sv_cb_read(self._h, int(slot), int(first), int(count), buf), "sv_cb_read")
+        return torch.tensor(list(buf)[:count], dtype=torch.int64)
+
+    def cb_release(self, slot: int) -> None:
+        check(self.lib.sv_cb_release(self._h, int(slot)), "sv_cb_release")
+
+    def cb_reset(self) -> None:
+        check(self.lib.sv_cb_reset(self._h), "sv_cb_reset")
 
     def beam_history(self):
         """(parent beams, tokens), each int32 [n_steps, batch * num_beams], of the last beam-search ``generate``."""

@@ -388,6 +388,7 @@ class HipCausalLM(_EngineModule):
         self.eos_token_id = eos_token_id
         self.pad_token_id = pad_token_id
         self.seed = None          # None: every sampling call draws its seed from torch's generator; an int pins it
+        self.batcher = None       # a batching.ContinuousBatcher: concurrent single-sequence calls share one decode loop
 
     @staticmethod
     def _stop_ids(stopping_criteria) -> Optional[List[int]]:
@@ -503,6 +504,24 @@ class HipCausalLM(_EngineModule):
             def on_tokens(tokens, first_col):
                 for c in range(tokens.shape[1]):
                     streamer.put(tokens[:, c])
+        if getattr(self, "batcher", None) is not None and num_beams == 1 and inputs_embeds.shape[0] == 1:
+            # serving: one request per call (serve/model_worker.py:120-181), many calls in flight -> they share the engine's
+            # decode loop instead of taking turns; the tokens are those of the solo call below
+            def on_chunk(toks, first):
+                if on_tokens is not None:
+                    on_tokens(toks.view(1, -1), first)
+            out = self.batcher.generate(inputs_embeds.to(torch.bfloat16), dict(
+                max_new_tokens=int(max_length) - S0, do_sample=bool(do_sample),
+                temperature=float(temperature if temperature is not None else 1.0),
+                top_p=float(top_p if top_p is not None else 1.0), top_k=int(top_k or 0), seed=seed,
+                eos_token_id=int(self.eos_token_id if eos_token_id is None else eos_token_id),
+                pad_token_id=int(self.pad_token_id if pad_token_id is None else pad_token_id),
+                stop_ids=self._stop_ids(stopping_criteria),
+                repetition_penalty=float(repetition_penalty if repetition_penalty is not None else 1.0),
+                min_new_tokens=min_new), on_chunk if on_tokens is not None else None).to(inputs_embeds.device)
+            if streamer is not None:
+                streamer.end()
+            return out
         out = self._engine.generate(
             inputs_embeds.to(torch.bfloat16), max_length=int(max_length), do_sample=bool(do_sample),
             temperature=float(temperature if temperature is not None else 1.0),

@@ -118,7 +118,8 @@ class ModelWorker:
 
     def __init__(self, controller_addr: str, worker_addr: str, worker_id: str, no_register: bool, model_path: str = "",
                  model_name: Optional[str] = None, device="cuda", limit_model_concurrency: int = 5, *,
-                 model=None, tokenizer=None, image_processor=None, context_len: Optional[int] = None):
+                 model=None, tokenizer=None, image_processor=None, context_len: Optional[int] = None,
+                 continuous_batching: bool = True):
         self.controller_addr, self.worker_addr, self.worker_id = controller_addr, worker_addr, worker_id
         model_path = model_path[:-1] if model_path.endswith("/") else model_path
         if model_name is None:                                         # :46-52
@@ -132,6 +133,16 @@ class ModelWorker:
             tokenizer, model, image_processor, context_len = load_pretrained_model(model_path, device=device)
         self.tokenizer, self.model, self.image_processor, self.context_len = tokenizer, model, image_processor, context_len
         self.is_multimodal = "starvector" in model_name.lower()       # :66
+        # The reference admits `limit_model_concurrency` requests at once and lets their generate calls take turns on the GPU
+        # (:161-172, 216-229).  Here the admitted requests share ONE decode loop (batching.ContinuousBatcher over the
+        # engine's sv_cb_* entry points): each request is a row of the batch with its own sampling parameters and stop.
+        self.batcher = None
+        lm = getattr(getattr(getattr(self.model, "model", None), "svg_transformer", None), "transformer", None)
+        eng = getattr(lm, "_engine", None)
+        if continuous_batching and lm is not None and eng is not None and hasattr(eng, "cb_admit"):
+            from .batching import ContinuousBatcher
+            self.batcher = ContinuousBatcher(eng)
+            lm.batcher = self.batcher
         self.limit_model_concurrency = limit_model_concurrency
         self.model_semaphore = None                                    # created on the event loop by the first request
         self.global_counter = 0
@@ -299,10 +310,13 @@ def main(argv=None):                                                   # :235-26
     p.add_argument("--device", type=str, default="cuda")
     p.add_argument("--limit-model-concurrency", type=int, default=5)
     p.add_argument("--no-register", action="store_true")
+    p.add_argument("--no-continuous-batching", action="store_true",
+                   help="run concurrent requests one generate call at a time (the reference's behaviour)")
     args = p.parse_args(argv)
     import uvicorn
     worker = ModelWorker(args.controller_address, args.worker_address, str(uuid.uuid4())[:6], args.no_register,
-                         args.model_path, args.model_name, args.device, args.limit_model_concurrency)
+                         args.model_path, args.model_name, args.device, args.limit_model_concurrency,
+                         continuous_batching=not args.no_continuous_batching)
     uvicorn.run(build_app(worker), host=args.host, port=args.port, log_level="info")
 
 

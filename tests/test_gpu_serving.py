@@ -1,0 +1,148 @@
+"""-m gpu: continuous batching in the engine (the reference worker's concurrent requests,
+serve/model_worker.py:120-229, as ONE decode loop).  The property that defines it: a request admitted into a live batch --
+at any time, next to any other requests, with its own sampling parameters, budget, EOS and stop sequence -- produces
+token for token what it produces alone through sv_generate."""
+import dataclasses
+import os
+import threading
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+from oracle import starvector_oracle as O
+from tests.gpu_util import bf, build_engine, dev
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _setup(max_batch=8, max_seq_len=120, n_img=6):
+    g = load_file(os.path.join(ROOT, "tests", "golden", "tiny_b3.safetensors"))
+    cfg = O.OracleConfig.tiny()
+    w = O.apply_fixture_weights(O.make_weights(cfg, seed=int(g["meta"][0])), cfg, g)
+    eng = build_engine(cfg, w, max_batch=max_batch, max_seq_len=max_seq_len)
+    img = bf(O.synthetic_images(n_img, cfg.image_size, seed=91))
+    img[:3] = bf(g["image"])                                   # rows 0-2: the designed streams of the golden fixture
+    prompt = torch.tensor([[7, 11]] * n_img, device=dev())
+    emb = torch.cat([eng.adapter(eng.encode_image(img)), eng.embed_tokens(prompt)], 1)
+    return cfg, eng, emb, g
+
+
+def _solo(eng, emb_row, r):
+    S0 = emb_row.shape[1]
+    return eng.generate(emb_row, max_length=S0 + r["max_new_tokens"], do_sample=r.get("do_sample", False),
+                        temperature=r.get("temperature", 1.0), top_p=r.get("top_p", 1.0), top_k=r.get("top_k", 0),
+                        seed=r.get("seed", 0), eos_token_id=r.get("eos_token_id", -1), pad_token_id=r.get("pad_token_id", 0),
+                        stop_ids=r.get("stop_ids"), repetition_penalty=r.get("repetition_penalty", 1.0),
+                        min_new_tokens=r.get("min_new_tokens", 0)).cpu()[0]
+
+
+def test_requests_join_and_leave_a_live_batch_token_identical_to_solo_runs():
+    cfg, eng, emb, g = _setup()
+    gold = g["tokens"]
+    reqs = [
+        dict(max_new_tokens=24, eos_token_id=-1),                                            # greedy, the golden stream of row 0
+        dict(max_new_tokens=70, eos_token_id=-1, repetition_penalty=1.3),                    # crosses a KV page (5 + 2 + 70 > 64)
+        dict(max_new_tokens=40, do_sample=True, temperature=0.8, top_p=0.9, top_k=50, seed=11, eos_token_id=-1),
+        dict(max_new_tokens=30, eos_token_id=int(gold[0, 5])),                               # same image as request 0: ends at its 6th token
+        dict(max_new_tokens=30, eos_token_id=-1, stop_ids=[int(gold[1, 8]), int(gold[1, 9])]),   # stop pair of ITS OWN stream (row 1 of the fixture)
+        dict(max_new_tokens=33, do_sample=True, temperature=1.2, top_p=0.95, seed=5, eos_token_id=-1, min_new_tokens=4),
+    ]
+    rows = [0, 3, 4, 0, 1, 5]                                   # which image each request looks at
+    solo = [_solo(eng, emb[r:r + 1].contiguous(), q) for r, q in zip(rows, reqs)]
+    assert torch.equal(solo[0], gold[0]) and solo[3].tolist() == gold[0, :6].tolist() and solo[4].tolist() == gold[1, :10].tolist()
+    # staggered admission: 2 requests, a few steps, 2 more (one prompt pass while the first two keep their KV), steps, the rest
+    slots = {}
+    def admit(idx):
+        ss = eng.cb_admit(torch.cat([emb[rows[i]:rows[i] + 1] for i in idx], 0).contiguous(), [reqs[i] for i in idx])
+        for i, s in zip(idx, ss):
+            slots[i] = s
+    admit([0, 1])
+    assert eng.cb_step(3) == 2
+    admit([2, 3])
+    live = eng.cb_step(4)
+    assert live == 3                                            # request 3 hit its EOS at its 6th token and left
+    admit([4, 5])
+    with pytest.raises(RuntimeError):
+        eng.generate(emb[:1].contiguous(), max_length=emb.shape[1] + 4)      # the classic path refuses while slots are live
+    while eng.cb_step(8) > 0:
+        pass
+    lv, st = eng.cb_poll()
+    for i, r in enumerate(reqs):
+        s = slots[i]
+        assert lv[s] == 0 and st[s] == solo[i].numel(), (i, st[s], solo[i].numel())
+        assert torch.equal(eng.cb_read(s, 0, st[s]), solo[i]), f"request {i} differs from its solo run"
+    assert len(set(slots.values())) == 6 and eng.last_timing()["graph"]
+    # slots and pages are recycled: release everything, admit again into the same rows
+    for s in slots.values():
+        eng.cb_release(s)
+    again = eng.cb_admit(emb[:2].contiguous(), [reqs[0], reqs[0]])
+    while eng.cb_step(8) > 0:
+        pass
+    assert torch.equal(eng.cb_read(again[1], 0, 24), gold[1])
+    eng.cb_reset()
+    assert torch.equal(eng.generate(emb[:3].contiguous(), max_length=emb.shape[1] + 24, eos_token_id=cfg.eos_token_id,
+                                    pad_token_id=cfg.pad_token_id).cpu(), gold)          # classic path is back, unchanged
+    eng.close()
+
+
+def test_admission_is_refused_not_partial_when_slots_or_pages_are_short():
+    from starvector_amd._lib import StarVectorBusy
+    cfg, eng, emb, g = _setup(max_batch=4, max_seq_len=96, n_img=5)
+    S0 = emb.shape[1]
+    with pytest.raises(StarVectorBusy):
+        eng.cb_admit(emb[:5].contiguous(), [dict(max_new_tokens=8)] * 5)     # five requests, four slots
+    a = eng.cb_admit(emb[:3].contiguous(), [dict(max_new_tokens=8, eos_token_id=-1)] * 3)
+    with pytest.raises(StarVectorBusy):
+        eng.cb_admit(emb[3:5].contiguous(), [dict(max_new_tokens=8)] * 2)    # one slot left
+    with pytest.raises(ValueError):
+        eng.cb_admit(emb[3:4].contiguous(), [dict(max_new_tokens=96)])       # beyond max_seq_len
+    b = eng.cb_admit(emb[3:4].contiguous(), [dict(max_new_tokens=8, eos_token_id=-1)])
+    assert sorted(a + b) == [0, 1, 2, 3]
+    while eng.cb_step(4) > 0:
+        pass
+    eng.cb_release(a[1])
+    c = eng.cb_admit(emb[4:5].contiguous(), [dict(max_new_tokens=90 - S0, eos_token_id=-1)])
+    assert c == [a[1]]                                         # the lowest free slot is reused
+    eng.cb_reset()
+    eng.close()
+
+
+def test_worker_threads_share_the_decode_loop_through_the_mirror():
+    """Five threads call the mirror's `generate_im2svg` at once (what the FastAPI worker's request threads do): with the
+    batcher attached they run as rows of one batch; every result equals the same call made alone, sampling included."""
+    import starvector_amd as sva
+    from PIL import Image
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=41)
+    scfg = sva.StarVectorConfig(image_size=cfg.image_size, hidden_size=cfg.hidden, num_hidden_layers=cfg.n_layer,
+                                num_attention_heads=cfg.n_head, vocab_size=cfg.vocab - 4, n_inner=cfg.n_inner,
+                                n_positions=cfg.n_positions, max_length=cfg.n_positions, vit_width=cfg.vit_width,
+                                vit_layers=cfg.vit_layers, vit_heads=cfg.vit_heads, max_batch=8)
+    model = sva.StarVectorForCausalLM(scfg, state_dict={k: v.to(torch.bfloat16) for k, v in w.items()})
+    cols = [(200, 30, 30), (20, 200, 30), (30, 30, 220), (240, 240, 10), (5, 5, 5)]
+    batches = [{"image": model.process_images([Image.new("RGB", (cfg.image_size, cfg.image_size), c)])[0]} for c in cols]
+    S0 = model.model.query_length + 4
+    kws = [dict(max_length=S0 + 20 + 3 * i, num_beams=1, use_nucleus_sampling=bool(i % 2), temperature=0.9, top_p=0.9, seed=100 + i)
+           for i in range(5)]
+    alone = [model.model.generate_im2svg_grpo(b, **k)["outputs"].cpu() for b, k in zip(batches, kws)]
+    lm = model.model.svg_transformer.transformer
+    lm.batcher = sva.ContinuousBatcher(model.engine, steps_per_poll=4)
+    got = [None] * 5
+
+    def run(i):
+        torch.cuda.set_device(0)
+        got[i] = model.model.generate_im2svg_grpo(batches[i], **kws[i])["outputs"].cpu()
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(5)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    for i in range(5):
+        assert got[i] is not None and torch.equal(got[i], alone[i]), i
+    assert lm.batcher.max_concurrent >= 4, lm.batcher.max_concurrent      # the requests really shared the loop
+    lm.batcher.close()
+    lm.batcher = None
+    assert torch.equal(model.model.generate_im2svg_grpo(batches[0], **kws[0])["outputs"].cpu(), alone[0])
