@@ -123,7 +123,7 @@ typedef struct sv_sampling {
     int32_t min_new_tokens;    /* HF MinLengthLogitsProcessor: the EOS logit is held at -inf while fewer than this many tokens
                                   have been generated.  The caller passes max(min_length - S0, 0) (HF subtracts the prompt
                                   length when generating from inputs_embeds; starvector_base.py:236 passes min_length).
-                                  0 = off; not with num_beams > 1 (SV_ENOTSUP) */
+                                  0 = off.  With num_beams > 1 HF applies it to the log-probabilities: so does the scorer */
 } sv_sampling;
 
 /* HF beam search bookkeeping as a standalone device-side scorer (what transformers' _beam_search does between two
@@ -143,6 +143,7 @@ typedef struct sv_beam_config {
     float   temperature, top_p;
     int32_t top_k;
     uint64_t seed;
+    int32_t min_new_tokens;    /* HF MinLengthLogitsProcessor on the log-probabilities (as _beam_search applies processors) */
 } sv_beam_config;
 
 int  sv_abi_version(void);

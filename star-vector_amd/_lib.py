@@ -61,7 +61,7 @@ class SvBeamConfig(C.Structure):
         ("eos_token_id", C.c_int32), ("pad_token_id", C.c_int32), ("early_stopping", C.c_int32),
         ("length_penalty", C.c_float), ("repetition_penalty", C.c_float), ("n_stop", C.c_int32),
         ("stop_ids", C.POINTER(C.c_int32)), ("do_sample", C.c_int32), ("temperature", C.c_float),
-        ("top_p", C.c_float), ("top_k", C.c_int32), ("seed", C.c_uint64),
+        ("top_p", C.c_float), ("top_k", C.c_int32), ("seed", C.c_uint64), ("min_new_tokens", C.c_int32),
     ]
 
 

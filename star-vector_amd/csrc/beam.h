@@ -24,6 +24,7 @@ struct BeamConfig {
     float penalty = 1.f;            // repetition penalty (on the log-probs, as HF's beam search applies processors)
     int n_stop = 0;
     int32_t stop[BM_MAXSTOP] = {0};
+    int min_new = 0;                // MinLengthLogitsProcessor on the log-probs: EOS at -inf while fewer tokens were generated
     // beam-sample (do_sample with num_beams > 1): warpers on the log-probs, K draws without replacement
     int do_sample = 0;
     float temperature = 1.f, top_p = 1.f;
@@ -33,7 +34,7 @@ struct BeamConfig {
 
 // everything the kernels need, passed by value
 struct BeamDev {
-    int B, nb, K, V, max_new, eos, early, n_stop;
+    int B, nb, K, V, max_new, eos, early, n_stop, min_new;
     float length_penalty, penalty;
     const float* logits; int ld; int logit_div;       // logits row of beam row r = r / logit_div
     float* run_score;                                  // [R] accumulated log-prob of each running beam

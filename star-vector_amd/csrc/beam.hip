@@ -69,6 +69,8 @@ __device__ __forceinline__ void bm_row_lse(const BeamDev& p, int row, float& M, 
 __device__ __forceinline__ float bm_logprob(const BeamDev& p, const float* x, const uint32_t* seen, float M, float logS, int id) {
     float lp = (x[id] - M) - logS;
     if (seen && ((seen[id >> 5] >> (id & 31)) & 1u)) lp = lp < 0.f ? lp * p.penalty : lp / p.penalty;
+    // HF builds [RepetitionPenalty, MinLength] and, under beam search, runs them on the LOG-PROBS (GenerationMixin._beam_search)
+    if (id == p.eos && *p.step < p.min_new) lp = -INFINITY;
     return lp;
 }
 
@@ -415,6 +417,7 @@ int BeamScorer::init(const BeamConfig& cfg, int32_t* ext_cur_tok, int32_t* ext_p
 int BeamScorer::reset(hipStream_t st) {
     // per-call parameters (shape-independent: the device buffers are reused across calls of the same shape)
     d.eos = c.eos; d.early = c.early; d.n_stop = c.n_stop; d.length_penalty = c.length_penalty; d.penalty = c.penalty;
+    d.min_new = c.min_new;
     d.do_sample = c.do_sample; d.inv_temp = 1.0f / c.temperature; d.top_p = c.top_p; d.top_k = c.top_k; d.seed = c.seed;
     std::vector<float> lp((size_t)c.max_new + 1);
     // HF divides by the Python float (cur_len + 1) ** length_penalty: computed in double, used as an fp32 scalar

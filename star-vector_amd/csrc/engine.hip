@@ -184,7 +184,9 @@ struct sv_engine {
     int* ru_err = nullptr;
     int overlap = 0;                // SV_DECODE_OVERLAP=1: row updates ride inside the consumer GEMM's launch (measured slower)
     bool only_skinny = false;       // profiling: enqueue only the weight-streaming GEMMs of a step
-    int prefetch = 1;               // SV_PREFETCH=0: the idle blocks of attention / row update do not prefetch the next GEMM's weights
+    int prefetch = 0;               // SV_PREFETCH=1: the idle blocks of attention / row update stream the next GEMM's weights towards
+                                    // L2 / the Infinity Cache.  Measured null (profiles/prefetch_r02_ab.log: 1347 vs 1346-1349 us per
+                                    // step; the GEMMs gain what attention and the row update lose), so it stays off
     int prefetch_kb = 64;           // SV_PREFETCH_KB: bytes a prefetching block streams at most (its launch must not get longer)
     int ldq = 0;
     float *ws = nullptr, *ws2 = nullptr, *logits = nullptr, *sample_scratch = nullptr, *attn_part = nullptr;
@@ -1344,6 +1346,7 @@ static int generate_beam(sv_engine* e, const void* dev_embeds, int B, int S0, co
     for (int i = 0; i < sp->n_stop; ++i) bc.stop[i] = sp->stop_ids[i];
     bc.do_sample = sp->do_sample ? 1 : 0; bc.temperature = sp->temperature; bc.top_p = sp->top_p; bc.top_k = sp->top_k;
     bc.seed = sp->seed;
+    bc.min_new = sp->min_new_tokens > 0 ? sp->min_new_tokens : 0;
     if (!e->beam.matches(bc)) {
         int r = e->beam.init(bc, e->cur_tok, e->positions, e->d_step, e->d_done);
         if (r) return fail(SV_ENOMEM, "beam scorer allocation failed (hip error %d)", r);
@@ -1455,7 +1458,6 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
 
     SVCHECK(cb_guard(e, "sv_generate"));
     if (sp->num_beams > 1) {
-        if (sp->min_new_tokens > 0) return fail(SV_ENOTSUP, "min_new_tokens with beam search is not built (HF applies it to the log-probabilities there)");
         if (sp->on_tokens) return fail(SV_EINVAL, "streaming is not supported with beam search (hypotheses are only final at the end; HF refuses too)");
         if (sp->n_stop > 0 && !sp->stop_ids) return fail(SV_EINVAL, "n_stop > 0 but stop_ids is null");
         return generate_beam(e, dev_embeds, B, S0, sp, max_new, dev_out_tokens, n_generated, st);
@@ -1890,6 +1892,7 @@ extern "C" int sv_beam_create(const sv_beam_config* cfg, sv_beam** out) {
     if (cfg->do_sample && !(cfg->temperature > 0.f && cfg->top_p > 0.f)) return fail(SV_EINVAL, "sv_beam_create: temperature and top_p must be > 0");
     bc.do_sample = cfg->do_sample ? 1 : 0; bc.temperature = cfg->do_sample ? cfg->temperature : 1.f;
     bc.top_p = cfg->do_sample ? cfg->top_p : 1.f; bc.top_k = cfg->top_k; bc.seed = cfg->seed;
+    bc.min_new = cfg->min_new_tokens > 0 ? cfg->min_new_tokens : 0;
     sv_beam* h = new sv_beam();
     int r = h->s.init(bc, nullptr, nullptr, nullptr, nullptr);
     if (!r) r = h->s.reset(nullptr);

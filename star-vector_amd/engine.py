@@ -329,7 +329,7 @@ class HipBeamScorer:
     def __init__(self, batch: int, num_beams: int, vocab: int, max_new: int, eos_token_id: int, pad_token_id: int,
                  length_penalty: float = 1.0, early_stopping=False, repetition_penalty: float = 1.0,
                  stop_ids: Optional[Sequence[int]] = None, do_sample: bool = False, temperature: float = 1.0,
-                 top_p: float = 1.0, top_k: int = 0, seed: int = 0):
+                 top_p: float = 1.0, top_k: int = 0, seed: int = 0, min_new_tokens: int = 0):
         self.lib = _lib.load()
         stops = list(stop_ids) if stop_ids else []
         arr = (C.c_int32 * max(len(stops), 1))(*stops) if stops else None
@@ -337,7 +337,8 @@ class HipBeamScorer:
                                 int(pad_token_id), _early_code(early_stopping), float(length_penalty),
                                 float(repetition_penalty), len(stops),
                                 C.cast(arr, C.POINTER(C.c_int32)) if stops else None, int(bool(do_sample)),
-                                float(temperature), float(top_p), int(top_k or 0), int(seed) & 0xFFFFFFFFFFFFFFFF)
+                                float(temperature), float(top_p), int(top_k or 0), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                max(int(min_new_tokens or 0), 0))
         self._h = C.c_void_p()
         self.rows, self.batch, self.vocab, self.max_new = batch * num_beams, batch, vocab, max_new
         check(self.lib.sv_beam_create(C.byref(cfg), C.byref(self._h)), "sv_beam_create")

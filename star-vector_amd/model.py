@@ -487,10 +487,8 @@ class HipCausalLM(_EngineModule):
         S0 = inputs_embeds.shape[1]
         # HF (_prepare_generated_length): with inputs_embeds min_length is reduced by the prompt length -- 0 on the im2svg path
         # (SURVEY.md 8a-a11), positive only for a text2svg caption shorter than min_length; MinLengthLogitsProcessor then
-        # keeps EOS at -inf for that many new tokens.  In beam search HF applies it to the log-probabilities: not built.
+        # keeps EOS at -inf for that many new tokens (in beam search HF applies it to the log-probabilities: so does the scorer).
         min_new = max(int(min_length or 0) - S0, 0)
-        if min_new > 0 and num_beams > 1:
-            raise NotImplementedError("min_length beyond the prompt length together with beam search is not built")
         if not use_cache:
             pass        # the engine always uses its paged KV cache; results are identical
         on_tokens = None

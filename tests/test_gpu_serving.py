@@ -25,7 +25,8 @@ def _setup(max_batch=8, max_seq_len=120, n_img=6):
     img = bf(O.synthetic_images(n_img, cfg.image_size, seed=91))
     img[:3] = bf(g["image"])                                   # rows 0-2: the designed streams of the golden fixture
     prompt = torch.tensor([[7, 11]] * n_img, device=dev())
-    emb = torch.cat([eng.adapter(eng.encode_image(img)), eng.embed_tokens(prompt)], 1)
+    vis = torch.cat([eng.adapter(eng.encode_image(img[i:i + max_batch])) for i in range(0, n_img, max_batch)], 0)
+    emb = torch.cat([vis, eng.embed_tokens(prompt)], 1)
     return cfg, eng, emb, g
 
 
@@ -61,7 +62,7 @@ def test_requests_join_and_leave_a_live_batch_token_identical_to_solo_runs():
     admit([0, 1])
     assert eng.cb_step(3) == 2
     admit([2, 3])
-    live = eng.cb_step(4)
+    live = eng.cb_step(5)                                       # first token at admission + 5 steps = 6 tokens
     assert live == 3                                            # request 3 hit its EOS at its 6th token and left
     admit([4, 5])
     with pytest.raises(RuntimeError):

@@ -207,8 +207,8 @@ def test_min_length_is_reduced_by_the_prompt_length():
     assert lm._engine.last_kw["min_new_tokens"] == 6
     lm.generate(inputs_embeds=emb, min_length=3, max_length=20)              # the im2svg situation: nothing left
     assert "min_new_tokens" not in lm._engine.last_kw
-    with pytest.raises(NotImplementedError):
-        lm.generate(inputs_embeds=emb, min_length=10, max_length=20, num_beams=2)
+    lm.generate(inputs_embeds=emb, min_length=10, max_length=20, num_beams=2)     # beams: the scorer masks EOS in the log-probs
+    assert lm._engine.last_kw["min_new_tokens"] == 6 and lm._engine.last_kw["num_beams"] == 2
     # padded rows: the PADDED length is what HF subtracts, so every length group gets the same number of EOS-free steps
     emb2 = torch.ones(2, 6, 2)
     mask = torch.tensor([[0, 0, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1]])
