@@ -24,8 +24,10 @@ from ._lib import StarVectorBusy
 
 
 class _Request:
-    def __init__(self, emb: torch.Tensor, params: dict, on_tokens: Optional[Callable]):
+    def __init__(self, emb: Optional[torch.Tensor], params: dict, on_tokens: Optional[Callable], exclusive: Optional[Callable] = None):
         self.emb, self.params, self.on_tokens = emb, params, on_tokens
+        self.exclusive = exclusive         # a callable that needs the engine to itself (beam search, scoring forward)
+        self.value = None
         self.slot: Optional[int] = None
         self.sent = 0                      # tokens already handed over
         self.chunks: List[torch.Tensor] = []
@@ -38,6 +40,8 @@ class _Request:
             raise TimeoutError("generation did not finish in time")
         if self.error is not None:
             raise self.error
+        if self.exclusive is not None:
+            return self.value
         toks = torch.cat(self.chunks) if self.chunks else torch.empty(0, dtype=torch.int64)
         return toks.view(1, -1)
 
@@ -78,6 +82,18 @@ class ContinuousBatcher:
                  timeout: Optional[float] = None) -> torch.Tensor:
         return self.submit(inputs_embeds, params, on_tokens).result(timeout)
 
+    def run_exclusive(self, fn: Callable, timeout: Optional[float] = None):
+        """Run `fn()` with the engine to itself: what the slots cannot express (beam search keeps its own search state in
+        the batch rows, the scoring forward wants the whole KV pool).  FIFO with the generation requests: the ones admitted
+        before it finish first, the ones behind it wait; the continuous batch is reset around the call."""
+        req = _Request(None, {}, None, exclusive=fn)
+        with self._lock:
+            if self._closing:
+                raise RuntimeError("the batcher is closed")
+            self._pending.append(req)
+            self._lock.notify_all()
+        return req.result(timeout)
+
     def queue_length(self) -> int:
         with self._lock:
             return len(self._pending) + len(self._active)
@@ -92,7 +108,11 @@ class ContinuousBatcher:
     def _admit(self):
         """Move waiting requests into free slots, one `cb_admit` per prompt length (the prompt pass is rectangular)."""
         with self._lock:
-            waiting = list(self._pending)
+            waiting = []
+            for r in self._pending:                 # FIFO up to the first exclusive job: nothing overtakes it
+                if r.exclusive is not None:
+                    break
+                waiting.append(r)
         by_len: Dict[int, List[_Request]] = {}
         for r in waiting:
             by_len.setdefault(int(r.emb.shape[1]), []).append(r)
@@ -160,7 +180,20 @@ class ContinuousBatcher:
                         self._lock.wait()
                     if self._closing and not self._pending and not self._active:
                         break
-                if self._pending and len(self._active) < self.engine.cfg.max_batch:
+                with self._lock:
+                    head = self._pending[0] if self._pending else None
+                if head is not None and head.exclusive is not None:
+                    if not self._active:            # the engine is idle: hand it over
+                        with self._lock:
+                            self._pending.popleft()
+                        try:
+                            self.engine.cb_reset()
+                            head.value = head.exclusive()
+                            self._finish(head)
+                        except BaseException as e:
+                            self._finish(head, e)
+                        continue
+                elif self._pending and len(self._active) < self.engine.cfg.max_batch:
                     self._admit()
                     self._deliver()                 # first tokens (and one-token requests) right away
                 if self._active:

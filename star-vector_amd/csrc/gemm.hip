@@ -17,6 +17,12 @@
 // fragment (j = row m).  D[i=n][j=m]: lane l holds m = l&31 and n = 8*(r>>2) + 4*(l>>5) + (r&3),
 // i.e. 4 consecutive output columns per register group -> 8-byte bf16 stores per row.
 #include <cstdlib>
+#include <cstring>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <type_traits>
 #include "kernels.h"
 
 namespace sv {
@@ -171,6 +177,53 @@ __device__ __forceinline__ void lds_dma16(const void* g, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Epilogue through LDS (bf16 outputs).  The MFMA accumulator layout is "one output ROW per lane": stored straight from
+// registers, a wave instruction writes 8 bytes into each of 32 different rows (32 cache lines, 16 B used of each), and the
+// residual is read the same way -- the store tail is issue-bound, not bandwidth-bound (cdna guide T21).  Instead every wave
+// parks its finished values (bias, activation, first rounding already applied: bf16, exact) in its own LDS strip of
+// 64 rows x 64 columns (row stride 144 B), then reads the strip back ROW-CONTIGUOUS: lane -> (row it*8 + l>>3, 16-byte
+// chunk l&7), so a wave instruction covers 8 rows x 128 contiguous bytes: full lines for the residual loads and the stores.
+// Same arithmetic in the same order as the register epilogue (the residual add happens on the bf16-rounded value, as
+// before), so results are bit-identical.
+// ------------------------------------------------------------------------------------------------
+#define EPI_ROW_BYTES 144
+__device__ __forceinline__ void epi_park4(char* strip, int row, int col, const float v[4]) {
+    uint2 o;
+    o.x = pack2bf(v[0], v[1]);
+    o.y = pack2bf(v[2], v[3]);
+    *reinterpret_cast<uint2*>(strip + row * EPI_ROW_BYTES + col * 2) = o;
+}
+// strip: this wave's 64 x 64 values; (gm0, gn0): global coordinates of the strip's corner
+__device__ __forceinline__ void epi_flush_strip(const char* strip, const GemmArgs& p, int gm0, int gn0, int lane) {
+    const int rsub = lane >> 3, chunk = lane & 7;
+    const int n = gn0 + chunk * 8;
+    const bool nok = n < p.N;                               // N % 8 == 0 on this path (checked by the launcher)
+    uint4 rq[8];
+    if (p.R) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int m = gm0 + it * 8 + rsub;
+            rq[it] = (nok && m < p.M) ? *reinterpret_cast<const uint4*>(p.R + (size_t)m * p.ldr + n) : make_uint4(0u, 0u, 0u, 0u);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int r = it * 8 + rsub;
+        const int m = gm0 + r;
+        uint4 v = *reinterpret_cast<const uint4*>(strip + r * EPI_ROW_BYTES + chunk * 16);
+        if (p.R) {
+            float a[8], b[8];
+            unpack8(v, a);
+            unpack8(rq[it], b);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a[e] += b[e];         // bf(x W^T + b) + residual, rounded by the store below
+            v = pack8(a);
+        }
+        if (nok && m < p.M) *reinterpret_cast<uint4*>((bf16_t*)p.C + (size_t)m * p.ldc + n) = v;
+    }
+}
+
 template <typename OutT, int VAR>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -250,8 +303,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s][nt], xf[s][mt], acc[nt][mt], 0, 0, 0);
     }
 
-    // epilogue: bias -> round to bf16 (the reference's Linear output) -> activation -> (+ residual).  The bias of the
-    // wave's columns is fetched once and the residual of a whole m-tile is requested before the first value is needed
     const int half = lane >> 5;
     uint2 bq[2][4];
 #pragma unroll
@@ -261,6 +312,51 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
             const int n = n0 + wn * 64 + nt * 32 + rg * 8 + half * 4;
             bq[nt][rg] = (p.bias && n < p.N) ? *reinterpret_cast<const uint2*>(p.bias + n) : make_uint2(0u, 0u);
         }
+    if constexpr (sizeof(OutT) == 2) {
+        if (!p.epi_regs && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.R || (p.ldr & 7) == 0)) {
+            // ---- epilogue through LDS (see epi_flush_strip): park the wave's 64 x 64 values as bf16, flush row-contiguous
+            __syncthreads();                                   // every wave has read its last K-tile fragments
+            char* strip = smem + wave * (64 * EPI_ROW_BYTES);
+            // the activation is resolved ONCE, outside the 64 unrolled values: with a run-time switch inside, every value
+            // carries all three exp/divide sequences and the epilogue no longer fits the instruction cache
+            auto park = [&](auto tag) {
+                constexpr int ACT = decltype(tag)::value;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const int n = n0 + wn * 64 + nt * 32 + rg * 8 + half * 4;
+                            const float bj[4] = {__uint_as_float(bq[nt][rg].x << 16), __uint_as_float(bq[nt][rg].x & 0xffff0000u),
+                                                 __uint_as_float(bq[nt][rg].y << 16), __uint_as_float(bq[nt][rg].y & 0xffff0000u)};
+                            float cs[4] = {1.f, 1.f, 1.f, 1.f};
+                            if (p.cscale && n < p.N) {
+                                const float4 c4 = *reinterpret_cast<const float4*>(p.cscale + n);
+                                cs[0] = c4.x; cs[1] = c4.y; cs[2] = c4.z; cs[3] = c4.w;
+                            }
+                            float v[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float x = acc[nt][mt][rg * 4 + e] * cs[e] + bj[e];
+                                if constexpr (ACT != ACT_NONE) x = sv_act(bfround(x), ACT);
+                                v[e] = x;
+                            }
+                            epi_park4(strip, mt * 32 + (lane & 31), nt * 32 + rg * 8 + half * 4, v);
+                        }
+            };
+            switch (p.act) {
+                case ACT_QUICKGELU: park(std::integral_constant<int, ACT_QUICKGELU>{}); break;
+                case ACT_SWISH: park(std::integral_constant<int, ACT_SWISH>{}); break;
+                case ACT_GELU_TANH: park(std::integral_constant<int, ACT_GELU_TANH>{}); break;
+                default: park(std::integral_constant<int, ACT_NONE>{}); break;
+            }
+            epi_flush_strip(strip, p, m0 + wm * 64, n0 + wn * 64, lane);      // the strip is this wave's own: no barrier
+            return;
+        }
+    }
+    // register epilogue (fp32 outputs, odd shapes): bias -> round to bf16 (the reference's Linear output) -> activation
+    // -> (+ residual); the residual of a whole m-tile is requested before the first value is needed
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int m = m0 + wm * 64 + mt * 32 + (lane & 31);
@@ -473,10 +569,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p, int tiles_m, i
 #undef G2_WAIT
     if (wr == 0) G2_BARRIER();                            // both groups execute the same number of barriers
 
-    // epilogue: bias -> round to bf16 (the reference's Linear output) -> activation -> (+ residual).
-    // One block per CU: nothing else hides a load here, so the bias of the wave's 64 columns is fetched once and the
-    // residual of a whole m-tile is requested before the first value is needed (a load per value, each waited for
-    // on its own, cost twice the K loop at K = 2048).
     const int half = lane >> 5;
     uint2 bq[2][4];
 #pragma unroll
@@ -486,6 +578,57 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p, int tiles_m, i
             const int n = n0 + wc * 64 + j * 32 + rg * 8 + half * 4;
             bq[j][rg] = (p.bias && n < p.N) ? *reinterpret_cast<const uint2*>(p.bias + n) : make_uint2(0u, 0u);
         }
+    if constexpr (sizeof(OutT) == 2) {
+        if (!p.epi_regs && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.R || (p.ldr & 7) == 0)) {
+            // ---- epilogue through LDS (see epi_flush_strip), two passes of 64 rows per wave (8 waves x 9 KiB strips) ----
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            G2_BARRIER();                                      // both groups are past their last LDS reads
+            char* strip = smem + wave * (64 * EPI_ROW_BYTES);
+            // activation resolved once, outside the 128 unrolled values (see the 128^2 kernel): the run-time switch inside
+            // the unrolled epilogue cost ~100 us per tile here (c_fc + GELU on this kernel: 400 TF instead of ~1000)
+            auto run = [&](auto tag) {
+                constexpr int ACT = decltype(tag)::value;
+#pragma unroll
+                for (int hp = 0; hp < 2; ++hp) {
+#pragma unroll
+                    for (int mq = 0; mq < 2; ++mq) {
+                        const int mt = hp * 2 + mq;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int rg = 0; rg < 4; ++rg) {
+                                const int n = n0 + wc * 64 + j * 32 + rg * 8 + half * 4;
+                                const float bj[4] = {__uint_as_float(bq[j][rg].x << 16), __uint_as_float(bq[j][rg].x & 0xffff0000u),
+                                                     __uint_as_float(bq[j][rg].y << 16), __uint_as_float(bq[j][rg].y & 0xffff0000u)};
+                                float cs[4] = {1.f, 1.f, 1.f, 1.f};
+                                if (p.cscale && n < p.N) {
+                                    const float4 c4 = *reinterpret_cast<const float4*>(p.cscale + n);
+                                    cs[0] = c4.x; cs[1] = c4.y; cs[2] = c4.z; cs[3] = c4.w;
+                                }
+                                float v[4];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) {
+                                    float x = acc[j][mt][rg * 4 + e] * cs[e] + bj[e];
+                                    if constexpr (ACT != ACT_NONE) x = sv_act(bfround(x), ACT);
+                                    v[e] = x;
+                                }
+                                epi_park4(strip, mq * 32 + (lane & 31), j * 32 + rg * 8 + half * 4, v);
+                            }
+                    }
+                    // rows of pass hp: m0 + wr*128 + hp*64 + (mq*32 + lane&31)  (mt = 2*hp + mq  ->  (mt>>1)*64 + (mt&1)*32)
+                    epi_flush_strip(strip, p, m0 + wr * 128 + hp * 64, n0 + wc * 64, lane);
+                }
+            };
+            switch (p.act) {
+                case ACT_QUICKGELU: run(std::integral_constant<int, ACT_QUICKGELU>{}); break;
+                case ACT_SWISH: run(std::integral_constant<int, ACT_SWISH>{}); break;
+                case ACT_GELU_TANH: run(std::integral_constant<int, ACT_GELU_TANH>{}); break;
+                default: run(std::integral_constant<int, ACT_NONE>{}); break;
+            }
+            return;
+        }
+    }
+    // register epilogue (fp32 outputs, odd shapes)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         const int m = m0 + wr * 128 + (mt >> 1) * 64 + (mt & 1) * 32 + (lane & 31);
@@ -706,12 +849,110 @@ GemmPlan gemm_plan(int M, int N, int K, int act, int tail_on) {
     return pl;
 }
 
-void launch_gemm(const GemmArgs& a, hipStream_t st) {
-    // a small remainder over a multiple of 256 rows is peeled off to the tail kernel when the model says the saved
-    // round is worth more than the tail kernel costs (SV_GEMM_TAIL: 0 never, 2 always, default 1 = model)
+// One launch of the chosen configuration: tile kernel (kernel = 0: 128^2, 1: 256^2) and whether the row remainder over a
+// multiple of 256 is peeled into the tail kernel.  Every configuration computes the same bits (same MFMA, operand roles
+// and ascending-k order: tests/test_gpu_ops.py::test_linear_big_m_kernels_agree_bitwise), so the choice is speed only.
+static void launch_gemm_config(const GemmArgs& a, hipStream_t st, int kernel256, bool peel, bool tail_by_tiles) {
+    auto tiles = [&](const GemmArgs& g, bool force128) {
+        dim3 grid((g.N + GB_N - 1) / GB_N, (g.M + GB_M - 1) / GB_M);
+        if (kernel256 && !force128) { launch_gemm256(g, st); return; }
+        if (g.out_f32) gemm_bf16_kernel<float, 0><<<grid, 256, 2 * GB_BUF, st>>>(g);
+        else gemm_bf16_kernel<bf16_t, 0><<<grid, 256, 2 * GB_BUF, st>>>(g);
+    };
+    const int tail = a.M % 256, main_rows = a.M - tail;
+    if (peel && tail > 0 && main_rows > 0) {
+        GemmArgs m = a;
+        m.M = main_rows;
+        tiles(m, false);
+        GemmArgs t = a;
+        t.A = a.A + (size_t)main_rows * a.lda;
+        t.R = a.R ? a.R + (size_t)main_rows * a.ldr : nullptr;
+        t.C = a.out_f32 ? (void*)((float*)a.C + (size_t)main_rows * a.ldc) : (void*)((bf16_t*)a.C + (size_t)main_rows * a.ldc);
+        t.M = tail;
+        if (tail_by_tiles) tiles(t, true);
+        else gemm_tail_kernel<<<dim3((a.N + 31) / 32, (tail + 31) / 32), 64, 0, st>>>(t);
+        return;
+    }
+    tiles(a, false);
+}
+
+// "Measure, don't guess": the first time a big-M shape shows up (outside a stream capture) the candidate configurations are
+// timed on the real operands into a scratch output (the residual operand may alias the real output, so the real one is not
+// touched), and the fastest is remembered for the process.  The analytic model above (gemm_plan) stays the choice for small
+// problems, inside captures and when SV_GEMM_AUTOTUNE=0; it is also what the CPU tests pin.
+struct TuneKey {
+    int M, N, K, act, res, f32, fp8;
+    bool operator<(const TuneKey& o) const {
+        return std::tie(M, N, K, act, res, f32, fp8) < std::tie(o.M, o.N, o.K, o.act, o.res, o.f32, o.fp8);
+    }
+};
+static std::mutex g_tune_mu;
+static std::map<TuneKey, int> g_tune;          // bit 0: 256^2 kernel, bit 1: peel, bit 2: tail as a row of 128^2 tiles
+
+static int autotune_gemm(const GemmArgs& a, hipStream_t st, const GemmPlan& model) {
+    const int fallback = (model.main_256 ? 1 : 0) | (model.peel ? 2 : 0) | (model.tail_by_tiles ? 4 : 0);
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return fallback; }
+    const size_t esz = a.out_f32 ? 4 : 2;
+    void* scratch = nullptr;
+    if (hipMalloc(&scratch, (size_t)a.M * a.ldc * esz) != hipSuccess) { (void)hipGetLastError(); return fallback; }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(scratch); return fallback; }
+    GemmArgs t = a;
+    t.C = scratch;
+    const int tail = a.M % 256, main_rows = a.M - tail;
+    const bool can_peel = tail > 0 && tail <= 96 && main_rows >= 2048;
+    const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    int best = fallback;
+    float best_ms = 1e30f;
+    for (int k256 = 0; k256 < 2; ++k256) {
+        if (k256 && t256 < 100) continue;               // a 256^2 grid that leaves most CUs idle is never the answer
+        for (int peel = 0; peel < (can_peel ? 2 : 1); ++peel) {
+            const int cfg = k256 | (peel ? 2 : 0) | (peel && model.tail_by_tiles ? 4 : 0);
+            launch_gemm_config(t, st, k256, peel != 0, (cfg & 4) != 0);                 // warm-up
+            (void)hipEventRecord(e0, st);
+            for (int r = 0; r < 3; ++r) launch_gemm_config(t, st, k256, peel != 0, (cfg & 4) != 0);
+            (void)hipEventRecord(e1, st);
+            if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) { best_ms = ms; best = cfg; }
+        }
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(scratch);
+    if (getenv("SV_GEMM_AUTOTUNE_LOG"))
+        fprintf(stderr, "[sv gemm autotune] M %d N %d K %d act %d res %d -> %s%s (%.1f us; model said %s%s)\n", a.M, a.N, a.K, a.act,
+                a.R ? 1 : 0, (best & 1) ? "256^2" : "128^2", (best & 2) ? " + peeled tail" : "", best_ms * 1000.f / 3.f,
+                (fallback & 1) ? "256^2" : "128^2", (fallback & 2) ? " + peeled tail" : "");
+    return best;
+}
+
+void launch_gemm(const GemmArgs& a0, hipStream_t st) {
+    GemmArgs a = a0;
+    { const char* ee = getenv("SV_GEMM_EPI"); if (ee && strcmp(ee, "regs") == 0) a.epi_regs = 1; }     // A/B switch (tools/bench_gemm_epi.py)
+    // explicit switches (tools / A-B runs): SV_GEMM_TAIL 0 never peel, 2 always, 1 model; SV_GEMM_VARIANT 0 / 1 the 128^2
+    // kernel (plain / sched_barrier), 2 the 256^2 kernel.  Either one disables the autotuner.
     const char* et = getenv("SV_GEMM_TAIL");
+    const char* ev = getenv("SV_GEMM_VARIANT");
     const int tail_on = et ? atoi(et) : 1;
     const GemmPlan pl = gemm_plan(a.M, a.N, a.K, a.act, tail_on);
+    static const bool tune_on = !(getenv("SV_GEMM_AUTOTUNE") && atoi(getenv("SV_GEMM_AUTOTUNE")) == 0);
+    if (!et && !ev && tune_on && a.M >= 1024 && (long)a.M * a.N >= (1L << 22)) {
+        const TuneKey key{a.M, a.N, a.K, a.act, a.R ? 1 : 0, a.out_f32, a.cscale ? 1 : 0};
+        int cfg = -1;
+        {
+            std::lock_guard<std::mutex> lk(g_tune_mu);
+            auto it = g_tune.find(key);
+            if (it != g_tune.end()) cfg = it->second;
+        }
+        if (cfg < 0) {
+            cfg = autotune_gemm(a, st, pl);
+            std::lock_guard<std::mutex> lk(g_tune_mu);
+            g_tune[key] = cfg;
+        }
+        launch_gemm_config(a, st, cfg & 1, (cfg & 2) != 0, (cfg & 4) != 0);
+        return;
+    }
     const int tail = a.M % 256, main_rows = a.M - tail;
     const bool peel = pl.peel != 0, tail_by_tiles = pl.tail_by_tiles != 0;
     if (peel) {

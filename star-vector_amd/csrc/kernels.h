@@ -30,6 +30,7 @@ struct GemmArgs {
     int M, N, K;                     // K = padded K (multiple of 64) shared by A and Wp
     int act; int out_f32;
     const float* cscale = nullptr;   // fp8 weights: per-output-column scale applied to the accumulator (or nullptr)
+    int epi_regs = 0;                // 1: the register epilogue (row-per-lane stores) instead of the LDS-transposed one (A/B switch)
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 // what launch_gemm decides for a shape (host arithmetic only; tail_on: 0 never peel, 1 cost model, 2 always)

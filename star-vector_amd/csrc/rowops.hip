@@ -19,6 +19,60 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* __res
     if (row >= M) return;
     const bf16_t* xr = x + (size_t)row * ldx;
     const int NC = D >> 3;
+    const int KS = D >> 4;
+    constexpr int LN_MAXC = 9;                 // 16-byte chunks per lane kept in registers: D <= 4608 reads the row ONCE
+    if (NC <= 64 * LN_MAXC) {
+        // the row, gamma and beta are requested up front; statistics and the output come from registers (the three-pass
+        // version re-read the row twice: 25 us for the 8288 x 2048 prefill rows, this one is bandwidth-bound)
+        uint4 xq[LN_MAXC];
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + i * 64;
+            if (c < NC) xq[i] = *reinterpret_cast<const uint4*>(xr + c * 8);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i)
+            if (lane + i * 64 < NC) {
+                float f[8];
+                unpack8(xq[i], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s += f[e];
+            }
+        const float mean = wave_sum(s) / (float)D;
+        // (opaque: otherwise the compiler keeps the 8 unpacked floats of every chunk alive across the passes -- 3x the registers)
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) asm volatile("" : "+v"(xq[i].x), "+v"(xq[i].y), "+v"(xq[i].z), "+v"(xq[i].w));
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i)
+            if (lane + i * 64 < NC) {
+                float f[8];
+                unpack8(xq[i], f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = f[e] - mean; q += d * d; }
+            }
+        const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) asm volatile("" : "+v"(xq[i].x), "+v"(xq[i].y), "+v"(xq[i].z), "+v"(xq[i].w));
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + i * 64;
+            if (c < NC) {
+                float f[8], gg[8], bb[8];
+                unpack8(xq[i], f);
+                unpack8(*reinterpret_cast<const uint4*>(g + c * 8), gg);
+                unpack8(*reinterpret_cast<const uint4*>(b + c * 8), bb);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * rstd * gg[e] + bb[e];
+                if (PACKED)
+                    *reinterpret_cast<uint4*>(y + xp_index(row >> 5, KS, row & 31, c * 8)) = pack8(f);
+                else
+                    *reinterpret_cast<uint4*>(y + (size_t)row * ldy + c * 8) = pack8(f);
+            }
+        }
+        return;
+    }
     float s = 0.f;
     for (int c = lane; c < NC; c += 64) {
         float f[8];
@@ -35,7 +89,6 @@ __global__ __launch_bounds__(256) void layernorm_rows_kernel(const bf16_t* __res
         for (int e = 0; e < 8; ++e) { float d = f[e] - mean; q += d * d; }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
-    const int KS = D >> 4;
     for (int c = lane; c < NC; c += 64) {
         float f[8], gg[8], bb[8];
         unpack8(*reinterpret_cast<const uint4*>(xr + c * 8), f);

@@ -416,6 +416,10 @@ class HipCausalLM(_EngineModule):
         lengths = mask.sum(dim=1).tolist()
         pad = int(self.pad_token_id if kw.get("pad_token_id") is None else kw["pad_token_id"])
         stop = self._stop_ids(kw.get("stopping_criteria"))
+        eng = self._engine
+        if (int(kw.get("num_beams") or 1) == 1 and hasattr(eng, "cb_admit") and B <= eng.cfg.max_batch
+                and (getattr(self, "batcher", None) is None or getattr(self, "_exclusive", False))):
+            return self._generate_padded_slots(inputs_embeds, mask, lengths, budget, pad, stop, kw)
         outs, fired_at = [None] * B, None
         for n in sorted(set(lengths)):
             rows = [b for b in range(B) if lengths[b] == n]
@@ -434,6 +438,52 @@ class HipCausalLM(_EngineModule):
         for b, t in enumerate(outs):
             k = min(L, t.shape[0])
             res[b, :k] = t[:k]
+        return res
+
+    def _generate_padded_slots(self, inputs_embeds, mask, lengths, budget, pad, stop, kw):
+        """Rows of different real length in ONE decode loop: every row is a slot of the engine's continuous batch (own prompt
+        length, positions and KV pages), prompt passes run per length group (they are rectangular), and all rows then decode
+        together -- instead of one full generate call per length group.  HF semantics of the padded batch are restored on
+        the host: the reference's row-0 stop ends every row at row 0's step, finished rows are padded."""
+        eng = self._engine
+        B, S, _ = inputs_embeds.shape
+        eos = int(self.eos_token_id if kw.get("eos_token_id") is None else kw["eos_token_id"])
+        min_new = max(int(kw.get("min_length") or 0) - S, 0)
+        seed = int(kw.get("seed") or 0)
+        base = dict(max_new_tokens=budget, do_sample=bool(kw.get("do_sample")), eos_token_id=eos, pad_token_id=pad,
+                    temperature=float(kw.get("temperature") if kw.get("temperature") is not None else 1.0),
+                    top_p=float(kw.get("top_p") if kw.get("top_p") is not None else 1.0), top_k=int(kw.get("top_k") or 0),
+                    repetition_penalty=float(kw.get("repetition_penalty") or 1.0), min_new_tokens=min_new)
+        slot_of = [None] * B
+        eng.cb_reset()
+        try:
+            for n in sorted(set(lengths)):
+                rows = [b for b in range(B) if lengths[b] == n]
+                emb = torch.stack([inputs_embeds[b][mask[b]] for b in rows], 0).to(torch.bfloat16).contiguous()
+                reqs = [dict(base, seed=(seed + 0x9E3779B97F4A7C15 * b) & (2 ** 63 - 1), stop_ids=stop if b == 0 else None)
+                        for b in rows]
+                for b, s_ in zip(rows, eng.cb_admit(emb, reqs)):
+                    slot_of[b] = s_
+            fired_len = None
+            while True:
+                live = eng.cb_step(16)
+                lv, st = eng.cb_poll()
+                if stop and not lv[slot_of[0]]:
+                    r0 = eng.cb_read(slot_of[0], 0, st[slot_of[0]]).tolist()
+                    if len(r0) >= len(stop) and r0[-len(stop):] == list(stop):
+                        fired_len = len(r0)            # row 0 ended the whole batch at this step (starvector_base.py:9-20)
+                        break
+                if live == 0:
+                    break
+            lv, st = eng.cb_poll()
+            outs = [eng.cb_read(slot_of[b], 0, st[slot_of[b]]) for b in range(B)]
+        finally:
+            eng.cb_reset()
+        L = fired_len if fired_len is not None else max(t.shape[0] for t in outs)
+        res = torch.full((B, L), pad, dtype=torch.long, device=inputs_embeds.device)
+        for b, t in enumerate(outs):
+            k = min(L, t.shape[0])
+            res[b, :k] = t[:k].to(res.device)
         return res
 
     @torch.no_grad()
@@ -502,7 +552,22 @@ class HipCausalLM(_EngineModule):
             def on_tokens(tokens, first_col):
                 for c in range(tokens.shape[1]):
                     streamer.put(tokens[:, c])
-        if getattr(self, "batcher", None) is not None and num_beams == 1 and inputs_embeds.shape[0] == 1:
+        batcher = getattr(self, "batcher", None)
+        if batcher is not None and not (num_beams == 1 and inputs_embeds.shape[0] == 1) and not getattr(self, "_exclusive", False):
+            # beam search / a multi-row HF batch while requests share the engine: run it with the engine to itself, in turn
+            def call():
+                object.__setattr__(self, "_exclusive", True)
+                try:
+                    return self.generate(inputs_embeds=inputs_embeds, attention_mask=attention_mask, do_sample=do_sample,
+                                         top_p=top_p, temperature=temperature, num_beams=num_beams, max_length=max_length,
+                                         min_length=min_length, repetition_penalty=repetition_penalty,
+                                         length_penalty=length_penalty, use_cache=use_cache, stopping_criteria=stopping_criteria,
+                                         early_stopping=early_stopping, pad_token_id=pad_token_id, eos_token_id=eos_token_id,
+                                         top_k=top_k, streamer=streamer, seed=seed)
+                finally:
+                    object.__setattr__(self, "_exclusive", False)
+            return batcher.run_exclusive(call)
+        if batcher is not None and num_beams == 1 and inputs_embeds.shape[0] == 1 and not getattr(self, "_exclusive", False):
             # serving: one request per call (serve/model_worker.py:120-181), many calls in flight -> they share the engine's
             # decode loop instead of taking turns; the tokens are those of the solo call below
             def on_chunk(toks, first):

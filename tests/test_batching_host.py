@@ -79,7 +79,7 @@ def _emb(m, S0=3):
 
 
 def test_concurrent_requests_share_one_loop_and_keep_their_own_streams():
-    eng = _CbEngine(max_batch=4)
+    eng = _CbEngine(max_batch=4, delay=0.01)           # a step takes time: requests arriving meanwhile join the live batch
     b = ContinuousBatcher(eng, steps_per_poll=2)
     got, chunks = {}, {i: [] for i in range(6)}
 
@@ -152,7 +152,7 @@ def test_engine_failure_reaches_every_request():
 def test_mirror_generate_routes_single_sequences_through_the_batcher():
     """HipCausalLM.generate with a batcher attached: B = 1, num_beams = 1 calls become slots; the HF kwargs are mapped."""
     from starvector_amd.model import HipCausalLM
-    eng = _CbEngine(max_batch=4)
+    eng = _CbEngine(max_batch=4, delay=0.01)
     lm = HipCausalLM.__new__(HipCausalLM)
     torch.nn.Module.__init__(lm)
     object.__setattr__(lm, "_engine", eng)
@@ -172,3 +172,31 @@ def test_mirror_generate_routes_single_sequences_through_the_batcher():
         assert out[i].tolist() == [[20 * i + k for k in range(6)]]
     assert lm.batcher.max_concurrent >= 2
     lm.batcher.close()
+
+
+def test_exclusive_jobs_take_the_engine_in_turn():
+    """Beam search / multi-row HF batches cannot be slots: `run_exclusive` gives them the engine between the requests that
+    were admitted before and those that came after (FIFO), with the continuous batch reset around the call."""
+    eng = _CbEngine(max_batch=4, delay=0.005)
+    b = ContinuousBatcher(eng, steps_per_poll=1)
+    order = []
+    r1 = b.submit(_emb(1), dict(max_new_tokens=20), lambda t, f: order.append("r1"))
+
+    def job():
+        assert not eng.slots                                # nothing is live while the job owns the engine
+        order.append("job")
+        return 42
+    res = {}
+    th = threading.Thread(target=lambda: res.setdefault("v", b.run_exclusive(job)))
+    th.start()
+    time.sleep(0.02)
+    r2 = b.submit(_emb(2), dict(max_new_tokens=4), lambda t, f: order.append("r2"))
+    assert r1.result(timeout=30)[0].tolist() == list(range(1, 21))
+    th.join(timeout=30)
+    assert res["v"] == 42 and r2.result(timeout=30)[0].tolist() == [2, 3, 4, 5]
+    j = order.index("job")
+    assert "r1" in order[:j] and "r1" not in order[j:] and "r2" not in order[:j]       # r1 finished, then the job, then r2
+    with pytest.raises(ZeroDivisionError):
+        b.run_exclusive(lambda: 1 / 0)                      # the job's exception reaches its caller, the loop lives on
+    assert b.generate(_emb(7), dict(max_new_tokens=3))[0].tolist() == [7, 8, 9]
+    b.close()

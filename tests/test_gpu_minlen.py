@@ -24,7 +24,7 @@ def test_min_length_holds_eos_back():
     seed, B, n_new, eos, S0g = [int(x) for x in g["meta"]]
     cfg = dataclasses.replace(O.OracleConfig.tiny(), eos_token_id=eos)
     w = O.make_weights(cfg, seed=seed)
-    eng = build_engine(cfg, w, 4, 96)
+    eng = build_engine(cfg, w, 8, 96)                        # beams: batch x num_beams rows
     emb = torch.cat([eng.adapter(eng.encode_image(bf(g["image"]))), eng.embed_tokens(g["prompt_ids"].to(dev()))], 1)
     S0 = emb.shape[1]
     assert S0 == S0g

@@ -147,3 +147,38 @@ def test_worker_threads_share_the_decode_loop_through_the_mirror():
     lm.batcher.close()
     lm.batcher = None
     assert torch.equal(model.model.generate_im2svg_grpo(batches[0], **kws[0])["outputs"].cpu(), alone[0])
+
+
+def test_padded_prompts_decode_as_slots_and_equal_the_unpadded_rows():
+    """text2svg with prompts of different length (starvector_base.py:129-165 pads them on the left): the mirror runs every row
+    as a slot of ONE decode loop; each row must equal the same row generated alone without its padding, and the reference's
+    row-0 stop must cut every row where row 0 stopped."""
+    from starvector_amd.model import HipCausalLM, StoppingCriteriaSub
+    cfg, eng, emb, g = _setup(max_batch=8, max_seq_len=120, n_img=4)
+    lm = HipCausalLM(eng, eos_token_id=-1, pad_token_id=0)
+    S = emb.shape[1]
+    real = [S, S - 2, S - 1, S - 2]                            # left padding of 0 / 2 / 1 / 2 positions
+    mask = torch.zeros(4, S, dtype=torch.long, device=dev())
+    padded = torch.zeros_like(emb)
+    for b, n in enumerate(real):
+        mask[b, S - n:] = 1
+        padded[b, S - n:] = emb[b, S - n:]                     # the row's prompt = the last n rows of its embedding
+    budget = 40
+    out = lm.generate(inputs_embeds=padded, attention_mask=mask, max_length=S + budget, eos_token_id=-1)
+    assert out.shape == (4, budget)
+    solo = []
+    for b, n in enumerate(real):
+        t = eng.generate(emb[b:b + 1, S - n:].contiguous(), max_length=n + budget, eos_token_id=-1).cpu()[0]
+        solo.append(t)
+        assert torch.equal(out[b].cpu(), t), f"row {b} (real length {n}) differs from its unpadded run"
+    assert torch.equal(solo[0][:24], g["tokens"][0])           # row 0 is unpadded: the golden stream
+    stop = solo[0][9:11].tolist()
+    first = next(i for i in range(1, budget) if solo[0][i - 1:i + 1].tolist() == stop)
+    cut = lm.generate(inputs_embeds=padded, attention_mask=mask, max_length=S + budget, eos_token_id=-1,
+                      stopping_criteria=[StoppingCriteriaSub(stops=[stop])])
+    assert cut.shape == (4, first + 1)
+    for b in range(4):
+        assert torch.equal(cut[b].cpu(), solo[b][:first + 1])
+    # the classic entry points work again afterwards (the slots were reset)
+    again = eng.generate(emb[:1].contiguous(), max_length=S + 24, eos_token_id=-1).cpu()[0]
+    assert torch.equal(again, g["tokens"][0])
