@@ -92,8 +92,8 @@ def test_admission_is_refused_not_partial_when_slots_or_pages_are_short():
     from starvector_amd._lib import StarVectorBusy
     cfg, eng, emb, g = _setup(max_batch=4, max_seq_len=96, n_img=5)
     S0 = emb.shape[1]
-    with pytest.raises(StarVectorBusy):
-        eng.cb_admit(emb[:5].contiguous(), [dict(max_new_tokens=8)] * 5)     # five requests, four slots
+    with pytest.raises(ValueError):
+        eng.cb_admit(emb[:5].contiguous(), [dict(max_new_tokens=8)] * 5)     # five requests can never fit four slots: a caller error
     a = eng.cb_admit(emb[:3].contiguous(), [dict(max_new_tokens=8, eos_token_id=-1)] * 3)
     with pytest.raises(StarVectorBusy):
         eng.cb_admit(emb[3:5].contiguous(), [dict(max_new_tokens=8)] * 2)    # one slot left
