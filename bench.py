@@ -93,11 +93,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # One process per GPU.  With fewer GPUs than ranks (the 1-GPU development box) the ranks share devices and rendezvous
+    # over gloo: a FUNCTIONAL run of the very same sharded path (full replica per rank, rank shard of the global batch, one
+    # all_gather of token streams); its rate is not a scaling number and the line says so ("dist_backend").
+    n_dev = torch.cuda.device_count()
+    shared = world > n_dev or os.environ.get("SV_DIST_BACKEND", "") == "gloo"
+    dev_index = local_rank % max(n_dev, 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
 
     import starvector_amd as sva
     from starvector_amd.parallel import all_gather_token_streams
@@ -116,7 +125,7 @@ def main():
           else sva.EngineConfig(max_batch=B_PER_GPU, max_seq_len=S0 + n_new))
     if args.weights == "fp8":
         ec.weight_dtype = "fp8_e4m3"
-    eng = sva.HipEngine(ec, device=local_rank)
+    eng = sva.HipEngine(ec, device=dev_index)
     keep_cpu = (world == 1 and rank == 0 and not args.no_cpu_baseline and not is8b and not t2s)   # 8B fp32 on CPU: 29 GB, skipped
     w = {}
     for name, t in O.iter_weights(cfg, seed=1234, init="std002"):      # streamed: fp32 -> bf16 + fragment
@@ -151,7 +160,8 @@ def main():
         out = new if t2s else torch.cat([prompt, new], 1)      # starvector_base.py:256 (text2svg returns the new ids, :329-330)
         if world > 1:
             # ONE collective: int32 [B, 1 + width] per rank (column 0 = the row's length); the width is known up front
-            out = all_gather_token_streams(out, cfg.pad_token_id, B_PER_GPU * world, width=(0 if t2s else len(PROMPT_IDS)) + max_new)
+            out = all_gather_token_streams(out.cpu() if shared else out, cfg.pad_token_id, B_PER_GPU * world,
+                                           width=(0 if t2s else len(PROMPT_IDS)) + max_new)
         return out, new.shape[1]
 
     def sync_all():
@@ -174,7 +184,7 @@ def main():
     sync_all()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     total_tokens = n_tok * B_PER_GPU * world
@@ -246,6 +256,8 @@ def main():
                                     f"{S0} (257 visual + {len(PROMPT_IDS)}), {n_new} new tokens/seq, EOS disabled"),
                        "global_batch": B_PER_GPU * world, "new_tokens": n_new,
                        "parallelism": f"dp{world}" if world > 1 else "single",
+                       **({"dist_backend": ("gloo, ranks SHARE GPUs (functional run of the sharded path on a box with fewer GPUs than "
+                                            "ranks; not a scaling number)") if shared else "nccl (RCCL)"} if world > 1 else {}),
                        "hipgraph_decode": bool(graph)},
             "tokens_per_s_per_gpu": round(value / world, 1),
             "ttft_p50_ms": round(ttft_p50, 2) if ttft_p50 is not None else None,

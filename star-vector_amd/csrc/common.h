@@ -13,18 +13,17 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;     // fp8 pair convers
 
 __device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
 
-// round-to-nearest-even, NaN kept quiet: identical to torch's float -> bfloat16 cast
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
-__device__ __forceinline__ float bfround(float f) { return bf2f(f2bf(f)); }
-
+// float -> bfloat16, round-to-nearest-even like torch's cast: gfx950's v_cvt_pk_bf16_f32 (two values per instruction; checked
+// bit for bit against torch -- halfway cases, denormals -- by tests/test_gpu_ops.py::test_bf16_rounding_is_rne).  The software
+// rounding this replaces (NaN test, add 0x7fff + lsb, shift: ~7 VALU operations per value) was a third of the big-M GEMMs'
+// epilogue (profiles/gemm_r02_fixed_cost_sweep.log).
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, f) & 0xffffu); }
+__device__ __forceinline__ float bfround(float f) { return __uint_as_float(pack2bf(f, f) << 16); }
 
 // 8 bf16 <-> 8 floats
 __device__ __forceinline__ void unpack8(const uint4& u, float* f) {
@@ -84,13 +83,15 @@ enum { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_SWISH = 2, ACT_GELU_TANH = 3 };
 
 __device__ __forceinline__ float sv_act(float x, int act) {
     switch (act) {
-        case ACT_QUICKGELU: return x / (1.0f + __expf(-1.702f * x));         // clip_model.py:126-128
-        case ACT_SWISH:     return x / (1.0f + __expf(-x));                   // adapter.py:5-10
+        // x * rcp(1 + e): v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division; the result is rounded to bf16 by every
+        // caller, and every kernel of the path uses this one function, so rows stay bit-identical across kernels
+        case ACT_QUICKGELU: return x * __builtin_amdgcn_rcpf(1.0f + __expf(-1.702f * x));         // clip_model.py:126-128
+        case ACT_SWISH:     return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x));                   // adapter.py:5-10
         case ACT_GELU_TANH: {                                                 // gelu_pytorch_tanh
             // 0.5 x (1 + tanh(u)) = x / (1 + exp(-2u)),  u = sqrt(2/pi) (x + 0.044715 x^3)
             const float k0 = 0.7978845608028654f, k1 = 0.044715f;
             const float u = k0 * (x + k1 * x * x * x);
-            return x / (1.0f + __expf(-2.0f * u));
+            return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));
         }
         default: return x;
     }

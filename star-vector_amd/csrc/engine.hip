@@ -1507,9 +1507,10 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
         // stream, the benchmark), so a short request does not pay a 172-node capture + instantiate; a call with other
         // parameters replaces it.  Owned by the engine: no early return below can leak it.
         char key[256];
-        snprintf(key, sizeof(key), "B%d|n%d|ds%d|T%a|p%a|k%d|seed%llu|eos%d|pad%d|ns%d|rp%a|mn%d|pipe%d%d%d", B, max_new, sp->do_sample,
+        snprintf(key, sizeof(key), "B%d|n%d|ds%d|T%a|p%a|k%d|seed%llu|eos%d|pad%d|ns%d|rp%a|mn%d|pipe%d%d%d|mt2%s", B, max_new, sp->do_sample,
                  sp->temperature, sp->top_p, sp->top_k, (unsigned long long)sp->seed, sp->eos_token_id, sp->pad_token_id, sp->n_stop,
-                 sp->repetition_penalty, sp->min_new_tokens, (int)e->cols_decode, (int)e->fused_decode, e->overlap);
+                 sp->repetition_penalty, sp->min_new_tokens, (int)e->cols_decode, (int)e->fused_decode, e->overlap,
+                 getenv("SV_SKINNY_MT2") ? getenv("SV_SKINNY_MT2") : "");       // kernel-choice switches are part of what was captured
         if (e->gen_gexec && e->gen_graph_key == key) {
             gexec = e->gen_gexec;
         } else {

@@ -568,6 +568,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p, int tiles_m, i
     }
 #undef G2_WAIT
     if (wr == 0) G2_BARRIER();                            // both groups execute the same number of barriers
+    if (p.epi_regs == 2) {                                // timing ablation: no epilogue at all (keeps the accumulators alive)
+        float t = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) t += acc[a][b][0] + acc[a][b][15];
+        if (t == 123456.789f) ((float*)p.C)[0] = t;
+        return;
+    }
 
     const int half = lane >> 5;
     uint2 bq[2][4];
@@ -579,7 +588,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p, int tiles_m, i
             bq[j][rg] = (p.bias && n < p.N) ? *reinterpret_cast<const uint2*>(p.bias + n) : make_uint2(0u, 0u);
         }
     if constexpr (sizeof(OutT) == 2) {
-        if (!p.epi_regs && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.R || (p.ldr & 7) == 0)) {
+        if (p.epi_regs != 1 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.R || (p.ldr & 7) == 0)) {
             // ---- epilogue through LDS (see epi_flush_strip), two passes of 64 rows per wave (8 waves x 9 KiB strips) ----
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             G2_BARRIER();                                      // both groups are past their last LDS reads
@@ -616,7 +625,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p, int tiles_m, i
                             }
                     }
                     // rows of pass hp: m0 + wr*128 + hp*64 + (mq*32 + lane&31)  (mt = 2*hp + mq  ->  (mt>>1)*64 + (mt&1)*32)
-                    epi_flush_strip(strip, p, m0 + wr * 128 + hp * 64, n0 + wc * 64, lane);
+                    epi_flush_strip(strip, p, p.epi_regs == 3 ? p.M : m0 + wr * 128 + hp * 64, n0 + wc * 64, lane);   // 3: timing ablation, no global traffic
                 }
             };
             switch (p.act) {
@@ -929,7 +938,12 @@ static int autotune_gemm(const GemmArgs& a, hipStream_t st, const GemmPlan& mode
 
 void launch_gemm(const GemmArgs& a0, hipStream_t st) {
     GemmArgs a = a0;
-    { const char* ee = getenv("SV_GEMM_EPI"); if (ee && strcmp(ee, "regs") == 0) a.epi_regs = 1; }     // A/B switch (tools/bench_gemm_epi.py)
+    {   // A/B switch (tools/bench_gemm_epi.py); "none" / "ldsonly" are TIMING ablations of the 256^2 kernel (wrong results)
+        const char* ee = getenv("SV_GEMM_EPI");
+        if (ee && strcmp(ee, "regs") == 0) a.epi_regs = 1;
+        else if (ee && strcmp(ee, "none") == 0) a.epi_regs = 2;
+        else if (ee && strcmp(ee, "ldsonly") == 0) a.epi_regs = 3;
+    }
     // explicit switches (tools / A-B runs): SV_GEMM_TAIL 0 never peel, 2 always, 1 model; SV_GEMM_VARIANT 0 / 1 the 128^2
     // kernel (plain / sched_barrier), 2 the 256^2 kernel.  Either one disables the autotuner.
     const char* et = getenv("SV_GEMM_TAIL");
@@ -1448,6 +1462,7 @@ static size_t skinny_smem(int waves, int K, bool ln) {
     return (size_t)waves * 16 * 64 * 4 + 64 * 4 + (size_t)2 * waves * 64 * 4 + (ln ? (size_t)K * 4 : 0) + 16;
 }
 
+static int init_mt2_attrs();
 template <int W, int PRE>
 static int set_attr(int bytes) {
     return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<W, PRE>),
@@ -1461,6 +1476,7 @@ int init_gemm_kernels() {
     if (!r) r = set_attr<8, 1>(128 * 1024);
     if (!r) r = set_attr<8, 0>(128 * 1024);
     if (!r) r = set_attr<8, 2>(128 * 1024);
+    if (!r) r = init_mt2_attrs();
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<bf16_t, 0>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<bf16_t, 2>),
@@ -1629,6 +1645,31 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_fp8_kernel(SkinnyArgs 
     }
 }
 
+// Waves per block of the skinny kernels = how K is cut inside a block, i.e. the order in which a row's partial sums are
+// added.  A function of the GEMM (N, K, split-K) ONLY -- never of the number of rows -- so that a row's bits do not depend on
+// the batch it is computed in (one tile, two tiles per block, grid.z tiles all cut K the same way).
+static int skinny_waves(int Npad, int KS, int splitk) {
+    const int per_split = KS / splitk;
+    // narrow outputs (few column tiles) get 16 waves per block so that no cross-block split-K is needed
+    const bool narrow = (Npad / 32) * splitk < 160;
+    const char* ew = getenv("SV_SKINNY_WAVES");          // experiment switch (tools/bench_skinny.py): force 16 / 8 waves
+    const int force = ew ? atoi(ew) : 0;
+    if (force == 16 && per_split % 16 == 0) return 16;
+    if (force == 8 && per_split % 8 == 0) return 8;
+    if (per_split % 16 == 0 && narrow) return 16;
+    if (per_split % 8 == 0) return 8;
+    if (per_split % 4 == 0) return 4;
+    if (per_split % 2 == 0) return 2;
+    return 1;
+}
+static int skinny_waves_fp8(int KS, int splitk) {       // a lane's 16 bytes hold two k-steps: even k-steps per wave
+    const int per_split = KS / splitk;
+    if (per_split % 16 == 0) return 8;
+    if (per_split % 8 == 0) return 4;
+    if (per_split % 4 == 0) return 2;
+    return 0;
+}
+
 // returns false when the shape / mode has no fp8 variant (the caller reports it)
 static bool launch_gemm_skinny_fp8(const SkinnyArgs& a, hipStream_t st) {
     if (a.ln_stats || a.ru_M > 0) return false;
@@ -1636,29 +1677,206 @@ static bool launch_gemm_skinny_fp8(const SkinnyArgs& a, hipStream_t st) {
         return false;
     const dim3 grid(a.Npad / 32, a.splitk, a.MT);
     const int per_split = (a.K / 16) / a.splitk;
-    if (per_split % 16 == 0) gemm_skinny_fp8_kernel<8><<<grid, 512, 8 * 16 * 64 * 4, st>>>(a);
-    else if (per_split % 8 == 0) gemm_skinny_fp8_kernel<4><<<grid, 256, 4 * 16 * 64 * 4, st>>>(a);
-    else if (per_split % 4 == 0) gemm_skinny_fp8_kernel<2><<<grid, 128, 2 * 16 * 64 * 4, st>>>(a);
+    (void)per_split;
+    const int waves = skinny_waves_fp8(a.K / 16, a.splitk);
+    if (waves == 8) gemm_skinny_fp8_kernel<8><<<grid, 512, 8 * 16 * 64 * 4, st>>>(a);
+    else if (waves == 4) gemm_skinny_fp8_kernel<4><<<grid, 256, 4 * 16 * 64 * 4, st>>>(a);
+    else if (waves == 2) gemm_skinny_fp8_kernel<2><<<grid, 128, 2 * 16 * 64 * 4, st>>>(a);
     else return false;
     return true;
 }
 
+// ------------------------------------------------------------------------------------------------
+// skinny GEMM for 33..64 rows (batch 64 of BASELINE config 5): TWO 32-row tiles per block.  The one-tile kernels put the
+// row tile on grid.z, so at batch 64 every weight byte crossed HBM -> CU twice (8B text2svg, batch 64: 5.6 ms of GEMM per
+// step against 3.4 ms at batch 16).  Here a wave feeds each weight fragment to two MFMAs (B operands = the fragments of row
+// tile 0 and 1): the weight stream is read once, the per-row arithmetic -- same MFMA, same ascending k order, same wave /
+// slab reduction order -- is the one-tile kernels', so a row's result does not depend on which kernel produced it.
+// Scope = what the slab pipeline launches: fp32 slabs, packed activations with bias + activation, fp32 logits; bf16 or
+// fp8 (e4m3, widened in registers, per-column scale on the accumulator) weights.  NBUF register chunks of CH k-steps ring.
+// ------------------------------------------------------------------------------------------------
+template <int WAVES, bool FP8>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(SkinnyArgs p) {
+    constexpr int CH = 4;
+    constexpr int NBUF = FP8 ? 3 : 2;
+    constexpr int WCH = FP8 ? CH / 2 : CH;                 // 16-byte weight loads per chunk and lane
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    float (*red)[WAVES][16][64] = reinterpret_cast<float (*)[WAVES][16][64]>(sk_smem);          // [2][WAVES][16][64]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = blockIdx.x, split = blockIdx.y, mt0 = blockIdx.z * 2;
+    const int KS = p.K >> 4;
+    const int ks_per_split = KS / p.splitk;
+    const int ks_per_wave = ks_per_split / WAVES;          // fp8: even (launcher)
+    const int ks0 = split * ks_per_split + wave * ks_per_wave;
+    const int m = lane & 31, half = lane >> 5;
+
+    const u32x4* wptr = FP8 ? reinterpret_cast<const u32x4*>(p.Wq) + ((size_t)nt * (KS >> 1) + (ks0 >> 1)) * 64 + lane
+                            : reinterpret_cast<const u32x4*>(p.Wp) + ((size_t)nt * KS + ks0) * 64 + lane;
+    const u32x4* xptr0 = reinterpret_cast<const u32x4*>(p.xp) + ((size_t)mt0 * KS + ks0) * 64 + lane;
+    const u32x4* xptr1 = xptr0 + (size_t)KS * 64;
+
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    constexpr int RPW = 16 / WAVES;                       // WAVES in {4, 8}
+    float bias_d[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        bias_d[i] = 0.f;
+        if (p.out_mode == SK_OUT_PACKED_ACT && p.bias) {
+            const int r = wave * RPW + i;
+            const int n = nt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+            if (n < p.N) bias_d[i] = bf2f(p.bias[n]);
+        }
+    }
+
+    struct Chunk { u32x4 w[WCH]; u32x4 x0[CH]; u32x4 x1[CH]; };
+    Chunk c[NBUF];
+    auto load = [&](Chunk& k, int ks) {                    // ks multiple of CH; the last chunk of a wave may be ragged
+#pragma unroll
+        for (int u = 0; u < WCH; ++u)
+            if (ks + (FP8 ? 2 * u : u) < ks_per_wave)       // wave-uniform
+                k.w[u] = __builtin_nontemporal_load(wptr + (size_t)(FP8 ? (ks >> 1) + u : ks + u) * 64);
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+            if (ks + u < ks_per_wave) {
+                k.x0[u] = xptr0[(size_t)(ks + u) * 64];
+                k.x1[u] = xptr1[(size_t)(ks + u) * 64];
+            }
+    };
+    auto compute = [&](Chunk& k, int ks) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            if (ks + u >= ks_per_wave) continue;            // wave-uniform
+            u32x4 wf;
+            if constexpr (FP8) {
+                const uint32_t lo = k.w[u >> 1][(u & 1) * 2], hi = k.w[u >> 1][(u & 1) * 2 + 1];
+                const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
+                const f32x2 a2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
+                wf[0] = (__float_as_uint(a0[0]) >> 16) | (__float_as_uint(a0[1]) & 0xffff0000u);
+                wf[1] = (__float_as_uint(a1[0]) >> 16) | (__float_as_uint(a1[1]) & 0xffff0000u);
+                wf[2] = (__float_as_uint(a2[0]) >> 16) | (__float_as_uint(a2[1]) & 0xffff0000u);
+                wf[3] = (__float_as_uint(a3[0]) >> 16) | (__float_as_uint(a3[1]) & 0xffff0000u);
+            } else {
+                wf = k.w[u];
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wf), as_frag4(k.x0[u]), acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wf), as_frag4(k.x1[u]), acc1, 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int b = 0; b < NBUF; ++b)
+        if (b * CH < ks_per_wave) load(c[b], b * CH);
+    for (int ks = 0; ks < ks_per_wave; ks += NBUF * CH) {
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b) {
+            if (ks + b * CH < ks_per_wave) compute(c[b], ks + b * CH);
+            if (ks + (b + NBUF) * CH < ks_per_wave) load(c[b], ks + (b + NBUF) * CH);
+        }
+    }
+    if constexpr (FP8) {
+        // per-column scale (accumulator row r <-> column 8 (r >> 2) + 4 half + (r & 3)) before the reduction, as the one-tile kernel
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const float4 sc = *reinterpret_cast<const float4*>(p.wscale + nt * 32 + rg * 8 + half * 4);
+            acc0[rg * 4 + 0] *= sc.x; acc0[rg * 4 + 1] *= sc.y; acc0[rg * 4 + 2] *= sc.z; acc0[rg * 4 + 3] *= sc.w;
+            acc1[rg * 4 + 0] *= sc.x; acc1[rg * 4 + 1] *= sc.y; acc1[rg * 4 + 2] *= sc.z; acc1[rg * 4 + 3] *= sc.w;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { red[0][wave][r][lane] = acc0[r]; red[1][wave][r][lane] = acc1[r]; }
+    __syncthreads();
+    const int r0 = wave * RPW;
+    const int n0 = nt * 32 + 8 * (r0 >> 2) + 4 * half + (r0 & 3);       // RPW consecutive columns
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const int mt = mt0 + mi;
+        float v[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int r = wave * RPW + i;
+            float t = red[mi][0][r][lane];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) t += red[mi][w][r][lane];
+            v[i] = t;
+        }
+        auto store_f32 = [&](float* dst) {
+            if constexpr (RPW == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+            else *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
+        };
+        if (p.out_mode == SK_OUT_PARTIAL) {
+            store_f32(p.ws + ((size_t)split * p.MT * 32 + mt * 32 + m) * p.ldws + n0);
+        } else if (p.out_mode == SK_OUT_F32) {
+            if (p.round_bf16) {
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) v[i] = bfround(v[i]);
+            }
+            store_f32(p.out_f32 + ((size_t)mt * 32 + m) * p.ldo + n0);
+        } else {   // SK_OUT_PACKED_ACT
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                float x = 0.f;
+                if (n0 + i < p.N) {
+                    x = bfround(v[i] + bias_d[i]);
+                    if (p.act != ACT_NONE) x = sv_act(x, p.act);
+                }
+                v[i] = x;
+            }
+            bf16_t* dst = p.out_xp + xp_index(mt, p.out_KS, m, n0);
+            if constexpr (RPW == 4) {
+                uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
+                *reinterpret_cast<uint2*>(dst) = o;
+            } else {
+                *reinterpret_cast<uint32_t*>(dst) = pack2bf(v[0], v[1]);
+            }
+        }
+    }
+}
+
+static int init_mt2_attrs() {
+    int r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 16 * 64 * 4);
+    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 16 * 64 * 4);
+    return r;
+}
+// two-row-tile launch: false when the shape / mode is outside the kernel's scope (the caller falls back to one tile per block)
+static bool launch_gemm_skinny_mt2(const SkinnyArgs& a, hipStream_t st) {
+    const char* e2 = getenv("SV_SKINNY_MT2");                                                 // A/B switch (read per launch: tests flip it)
+    const bool off = e2 && atoi(e2) == 0;
+    if (off || a.MT < 2 || (a.MT & 1) || a.ln_stats || a.ru_M > 0) return false;
+    if (!(a.out_mode == SK_OUT_PARTIAL || ((a.out_mode == SK_OUT_PACKED_ACT || a.out_mode == SK_OUT_F32) && a.splitk == 1)))
+        return false;
+    if (a.Wq && !a.wscale) return false;
+    const dim3 grid(a.Npad / 32, a.splitk, a.MT / 2);
+    if ((a.K / 16) % a.splitk) return false;
+    // the SAME number of waves (= the same per-wave k ranges and reduction order) as the one-tile kernel of this GEMM
+    const int waves = a.Wq ? skinny_waves_fp8(a.K / 16, a.splitk) : skinny_waves(a.Npad, a.K / 16, a.splitk);
+    if (waves == 8) {
+        if (a.Wq) gemm_skinny_mt2_kernel<8, true><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(a);
+        else gemm_skinny_mt2_kernel<8, false><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(a);
+        return true;
+    }
+    if (waves == 4) {
+        if (a.Wq) gemm_skinny_mt2_kernel<4, true><<<grid, 256, 2 * 4 * 16 * 64 * 4, st>>>(a);
+        else gemm_skinny_mt2_kernel<4, false><<<grid, 256, 2 * 4 * 16 * 64 * 4, st>>>(a);
+        return true;
+    }
+    return false;       // 16-wave (narrow outputs) and 1/2-wave (tiny K) shapes keep one row tile per block
+}
+
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st) {
+    if (launch_gemm_skinny_mt2(a, st)) return;                  // 33..64 rows: two row tiles per block, weights streamed once
     if (a.Wq && launch_gemm_skinny_fp8(a, st)) return;       // fp8 weights: its own kernel (falls through if unsupported)
     dim3 grid(a.Npad / 32, a.splitk, a.MT);
-    const int KS = a.K / 16;
-    const int per_split = KS / a.splitk;
-    // narrow outputs (few column tiles) get 16 waves per block so that no cross-block split-K is needed
-    const bool narrow = (a.Npad / 32) * a.splitk * a.MT < 160;
-    const char* ew = getenv("SV_SKINNY_WAVES");          // experiment switch (tools/bench_skinny.py): force 16 / 8 waves
-    const int force = ew ? atoi(ew) : 0;
-    if (force == 16 && per_split % 16 == 0) { launch_sk<16>(a, grid, st); return; }
-    if (force == 8 && per_split % 8 == 0) { launch_sk<8>(a, grid, st); return; }
-    if (per_split % 16 == 0 && narrow) launch_sk<16>(a, grid, st);
-    else if (per_split % 8 == 0) launch_sk<8>(a, grid, st);
-    else if (per_split % 4 == 0) launch_sk<4>(a, grid, st);
-    else if (per_split % 2 == 0) launch_sk<2>(a, grid, st);
-    else launch_sk<1>(a, grid, st);
+    switch (skinny_waves(a.Npad, a.K / 16, a.splitk)) {
+        case 16: launch_sk<16>(a, grid, st); break;
+        case 8: launch_sk<8>(a, grid, st); break;
+        case 4: launch_sk<4>(a, grid, st); break;
+        case 2: launch_sk<2>(a, grid, st); break;
+        default: launch_sk<1>(a, grid, st); break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

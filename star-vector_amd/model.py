@@ -68,14 +68,30 @@ class StarVectorConfig:
         for k, v in kwargs.items():
             setattr(self, k, v)
 
+    @staticmethod
+    def _visible_keys(window: int, semantics: str) -> int:
+        if semantics not in ("flash_attention_2", "sdpa", "eager"):
+            raise ValueError(f"window_semantics={semantics!r}: 'flash_attention_2' (W + 1 keys, transformers 4.49's FA2 call, "
+                             "what the reference loads) or 'sdpa' / 'eager' (W keys)")
+        window = int(window or 0)
+        return window + 1 if (window > 0 and semantics == "flash_attention_2") else window
+
     @property
     def is_v2(self) -> bool:                      # starvector_arch.py:139-144 picks the class the same way
         return "starcoder2" in self.starcoder_model_name
 
     def engine_config(self) -> EngineConfig:
-        if str(self.torch_dtype).replace("torch.", "") not in ("bfloat16", "auto"):
-            raise ValueError("the HIP engine computes in bfloat16 (BASELINE config 2); got torch_dtype="
-                             f"{self.torch_dtype}")
+        dt = str(self.torch_dtype).replace("torch.", "")
+        if dt in ("float16", "half", "float32", "float"):
+            # the reference's 1B validation config is fp16 (configs/generation/hf/starvector-1b/im2svg.yaml:16) and
+            # scripts/quickstart.py:16 casts the image to fp16: such callers keep working -- weights and inputs are converted at
+            # the boundary, the engine computes in bfloat16 (same exponent range as fp32; token streams may differ from an fp16
+            # run at near-ties, which is what any dtype change does)
+            import warnings
+            warnings.warn(f"torch_dtype={self.torch_dtype}: the HIP engine computes in bfloat16; weights and inputs are "
+                          "converted at the boundary", stacklevel=2)
+        elif dt not in ("bfloat16", "auto"):
+            raise ValueError(f"unsupported torch_dtype={self.torch_dtype} (bfloat16, or float16 / float32 converted to it)")
         if self.is_v2:
             # StarVector-8B: siglip_384 tower + StarCoder2 decoder (configs/models/starvector-8b/im2svg-stack.yaml)
             if self.image_encoder_type != "siglip_384":
@@ -89,7 +105,12 @@ class StarVectorConfig:
                                 max_batch=self.max_batch, max_seq_len=min(self.max_length, self.n_positions), arch="v2",
                                 n_kv_head=self.num_kv_heads, rope_theta=g("rope_theta", 1e6),
                                 vit_mlp=g("siglip_mlp", 4096), vit_eps=1e-6,
-                                sliding_window=g("sliding_window", 4096))      # bigcode/starcoder2-7b config.json
+                                # bigcode/starcoder2-7b config.json: sliding_window 4096.  The reference loads the decoder with
+                                # attn_implementation="flash_attention_2" (llm/starcoder2.py:21-26); transformers 4.49 hands FA2
+                                # window_size=(W, W), i.e. the query sees W + 1 keys, while its eager/sdpa mask (and later releases
+                                # everywhere) show W.  `window_semantics` picks which one the engine's window (= number of visible
+                                # keys) mirrors: "flash_attention_2" (default: what the reference runs) or "sdpa".
+                                sliding_window=self._visible_keys(g("sliding_window", 4096), g("window_semantics", "flash_attention_2")))
         if self.image_encoder_type != "clip":
             raise NotImplementedError(f"image_encoder_type={self.image_encoder_type!r}: v1 is built for the clip branch")
         return EngineConfig(image_size=self.image_size, patch_size=self.patch_size, vit_width=self.vit_width,

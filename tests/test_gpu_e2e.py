@@ -348,7 +348,7 @@ def test_full_size_properties_batch32():
     graph == eager, batch-invariance of a row, token range."""
     cfg = O.OracleConfig()
     w = O.make_weights(cfg, seed=7, init="std002")
-    eng = build_engine(cfg, w, max_batch=32, max_seq_len=259 + 40)
+    eng = build_engine(cfg, w, max_batch=64, max_seq_len=259 + 40)
     del w
     img = bf(O.synthetic_images(32, 224, seed=8))
     prompt = torch.tensor([[7, 11]] * 32, device=dev())
@@ -365,6 +365,20 @@ def test_full_size_properties_batch32():
     finally:
         os.environ.pop("SV_NO_GRAPH", None)
     assert torch.equal(a[17], eng.generate(emb[17:18].contiguous(), **kw).cpu()[0])
+    # batch 64 (BASELINE config 5's rows per GPU): the decode GEMMs run two row tiles per block (weights streamed once);
+    # same tokens as with one tile per block, and a row of the second tile equals its solo run
+    ids = torch.randint(0, cfg.vocab - 8, (64, 8), generator=torch.Generator().manual_seed(3)).to(dev())
+    e64 = eng.embed_tokens(ids)
+    kw64 = dict(max_length=8 + 24, eos_token_id=-1, pad_token_id=cfg.pad_token_id)
+    t64 = eng.generate(e64, **kw64).cpu()
+    assert t64.shape == (64, 24) and len({tuple(r.tolist()) for r in t64}) > 32
+    os.environ["SV_SKINNY_MT2"] = "0"
+    try:
+        assert torch.equal(t64, eng.generate(e64, **kw64).cpu())
+    finally:
+        os.environ.pop("SV_SKINNY_MT2", None)
+    for b in (5, 40, 63):
+        assert torch.equal(t64[b], eng.generate(e64[b:b + 1].contiguous(), **kw64).cpu()[0]), b
     eng.close()
 
 

@@ -4,6 +4,8 @@ restatement of the same operator on the same bf16-exact inputs.
 Tolerances (stated, floating point): bf16 outputs must sit within ONE bf16 rounding of the float32
 result -> |err| <= 2^-8 * max|ref| (plus the second rounding where the reference rounds an
 intermediate); float32 outputs within 1e-5 relative (accumulation order only)."""
+import os
+
 import pytest
 import torch
 
@@ -113,6 +115,30 @@ def test_linear_skinny_weight_streaming(M, N, K, sk):
     assert torch.equal(got2, 2 * got1)
     # deterministic (fixed-order split-K reduction)
     assert torch.equal(got1, E.op_linear_skinny(bf(x), bf(W), None, splitk=sk))
+
+
+@pytest.mark.parametrize("M,N,K,sk", [(64, 2304, 2048, 4), (33, 8192, 2048, 1), (64, 2048, 8192, 4), (50, 6144, 4608, 3),
+                                       (64, 4608, 18432, 4), (40, 1024, 1024, 2)])
+def test_linear_skinny_two_row_tiles_per_block_is_bitwise_the_one_tile_kernel(M, N, K, sk):
+    """33..64 rows (BASELINE config 5's batch 64): one block feeds each weight fragment to both row tiles, so the weight stream
+    crosses HBM once.  Same MFMA / k order / reduction order per row -> bit-identical to the one-tile-per-block kernels, bf16
+    and fp8 weights."""
+    g = torch.Generator().manual_seed(M + N + K + sk)
+    x = torch.randn(M, K, generator=g).bfloat16().float()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().float()
+    b = (0.1 * torch.randn(N, generator=g)).bfloat16().float()
+    two = E.op_linear_skinny(bf(x), bf(W), bf(b), splitk=sk)
+    two8, sc = E.op_linear_skinny_fp8(bf(x), bf(W), bf(b), splitk=sk)
+    os.environ["SV_SKINNY_MT2"] = "0"
+    try:
+        one = E.op_linear_skinny(bf(x), bf(W), bf(b), splitk=sk)
+        one8, _ = E.op_linear_skinny_fp8(bf(x), bf(W), bf(b), splitk=sk)
+    finally:
+        os.environ.pop("SV_SKINNY_MT2", None)
+    assert torch.equal(two, one) and torch.equal(two8, one8)
+    assert rel_err(two, x @ W.T + b) <= 1e-5
+    # rows of the second tile alone (a one-tile launch) give the same bits: batch composition cannot change a row
+    assert torch.equal(E.op_linear_skinny(bf(x[32:M]), bf(W), bf(b), splitk=sk), two[32:M])
 
 
 @pytest.mark.parametrize("B,S,H,Hkv,hd,causal", [

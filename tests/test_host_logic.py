@@ -19,11 +19,17 @@ def test_config_maps_to_engine_shapes():
                           n_positions=16384, max_length=16000, max_batch=16).engine_config()
     assert (v2.arch, v2.n_kv_head, v2.hidden, v2.n_head, v2.n_inner, v2.vocab) == ("v2", 4, 4608, 36, 18432, 49157)
     assert v2.query_length == 576 and v2.max_seq_len == 16000           # siglip_384: 24x24 patches, no class token
-    assert v2.sliding_window == 4096                                    # StarCoder2 attends to the last 4096 keys
+    assert v2.sliding_window == 4097        # visible keys: the reference loads StarCoder2 with FA2, 4.49 passes window_size=(W, W)
+    sd = StarVectorConfig(starcoder_model_name="bigcode/starcoder2-7b", image_encoder_type="siglip_384", hidden_size=4608,
+                          num_hidden_layers=32, num_attention_heads=36, num_kv_heads=4, n_inner=18432, added_tokens=5,
+                          n_positions=16384, max_length=16000, max_batch=16, window_semantics="sdpa").engine_config()
+    assert sd.sliding_window == 4096                                    # the eager / sdpa mask shows W keys
     with pytest.raises(NotImplementedError):
         StarVectorConfig(starcoder_model_name="bigcode/starcoder2-7b", image_encoder_type="clip").engine_config()
+    with pytest.warns(UserWarning, match="computes in bfloat16"):        # the reference's fp16 configs keep working, converted
+        assert StarVectorConfig(torch_dtype="float16").engine_config().hidden == 2048
     with pytest.raises(ValueError):
-        StarVectorConfig(torch_dtype="float16").engine_config()
+        StarVectorConfig(torch_dtype="int8").engine_config()
 
 
 def test_byte_tokenizer_surface():
