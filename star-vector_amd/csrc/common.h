@@ -16,11 +16,15 @@ __device__ __forceinline__ float bf2f(bf16_t x) { return __uint_as_float(((uint3
 // float -> bfloat16, round-to-nearest-even like torch's cast: gfx950's v_cvt_pk_bf16_f32 (two values per instruction; checked
 // bit for bit against torch -- halfway cases, denormals -- by tests/test_gpu_ops.py::test_bf16_rounding_is_rne).  The software
 // rounding this replaces (NaN test, add 0x7fff + lsb, shift: ~7 VALU operations per value) was a third of the big-M GEMMs'
-// epilogue (profiles/gemm_r02_fixed_cost_sweep.log).
+// epilogue (profiles/gemm_r02_fixed_cost_sweep.log).  Written as a vector conversion the COMPILER selects the instruction
+// for -- never as inline asm: gfx950 needs a wait state between a transcendental (v_exp / v_rcp) and a VALU instruction
+// reading its result, the compiler inserts it for its own instructions and does not look inside an asm statement (the asm
+// version read stale exp() results in the attention softmax: garbage probabilities, NaN logits).
+typedef __attribute__((ext_vector_type(2))) __bf16 sv_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float sv_f32x2;
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    const sv_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, sv_bf16x2));
 }
 __device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack2bf(f, f) & 0xffffu); }
 __device__ __forceinline__ float bfround(float f) { return __uint_as_float(pack2bf(f, f) << 16); }

@@ -34,11 +34,22 @@
 
 namespace sv {
 
+#if defined(DG_VARIANT) && DG_VARIANT == 1          // diagnosis builds (tools/gpu_r02_q.sh): software rounding
+__device__ __forceinline__ uint32_t dg_soft(float f) {
+    uint32_t u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ uint32_t dg_cvt_pk_bf16(float lo, float hi) { return dg_soft(lo) | (dg_soft(hi) << 16); }
+#elif defined(DG_VARIANT) && DG_VARIANT == 3        // the old inline-asm conversion
 __device__ __forceinline__ uint32_t dg_cvt_pk_bf16(float lo, float hi) {
     uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));     // RNE, same as torch's cast (test_bf16_rounding_is_rne)
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
+#else
+__device__ __forceinline__ uint32_t dg_cvt_pk_bf16(float lo, float hi) { return pack2bf(lo, hi); }   // common.h (never inline asm: hazards)
+#endif
 
 // 8 bf16 in a 16-byte register group -> sum, or sum of squared deviations
 __device__ __forceinline__ float dg_sum8(const u32x4& v) {
@@ -186,8 +197,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_cols_kernel(ColsArgs p) {
                 const u32x4 bv = *reinterpret_cast<const u32x4*>(gb_s + p.K + k0);
                 const u32x4 y0 = dg_normalize8(xr[c][0], m0, rs0, gv, bv);
                 const u32x4 y1 = dg_normalize8(xr[c][1], m1, rs1, gv, bv);
+#if defined(DG_VARIANT) && DG_VARIANT == 2          // diagnosis: every MFMA operand settled, nothing overlaps the MFMAs
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_nop(7);
+#endif
                 acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag4(wr[c % WG]), as_frag4(y0), acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag4(wr[c % WG]), as_frag4(y1), acc1, 0, 0, 0);
+#if defined(DG_VARIANT) && DG_VARIANT == 2
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_nop(7);
+                __builtin_amdgcn_s_nop(7);
+#endif
                 if (c + WG < MAXC && c + WG < nc) {
                     wr[c % WG] = zero4;
                     if (wvalid) wr[c % WG] = __builtin_nontemporal_load(wbase + (size_t)(c + WG) * 128);

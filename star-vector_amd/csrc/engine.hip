@@ -194,7 +194,7 @@ struct sv_engine {
     float* am_val = nullptr; int32_t* am_idx = nullptr;
     uint32_t* seen = nullptr; int seen_words = 0;      // repetition-penalty bitmap [rows][Vpad/32]
     int32_t *cur_tok = nullptr, *next_tok = nullptr, *unfinished = nullptr, *positions = nullptr,
-            *out_tok = nullptr, *d_step = nullptr, *d_done = nullptr, *d_nemit = nullptr, *d_stop = nullptr;
+            *out_tok = nullptr, *d_step = nullptr, *d_done = nullptr, *d_nemit = nullptr, *d_stop = nullptr, *d_bad = nullptr;
     int out_ld = 0;
     int32_t* h_flags = nullptr;   // pinned: [0]=done [1]=n_emitted
     // KV pool
@@ -591,6 +591,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     A(dalloc(e, &e->d_step, 4));
     A(dalloc(e, &e->d_done, 4));
     A(dalloc(e, &e->d_nemit, 4));
+    A(dalloc(e, &e->d_bad, 4));       // raised by the selection kernels when a row has no finite logit
     A(dalloc(e, &e->d_stop, 64));
 
     e->page_bytes = kv_page_bytes(dh);
@@ -1296,6 +1297,7 @@ static void sample_and_finish(sv_engine* e, int B, const sv_sampling& sp, int ma
     f.stop_ids = e->d_stop; f.n_stop = sp.n_stop; f.eos = sp.eos_token_id; f.pad = sp.pad_token_id; f.B = B;
     f.max_new = max_new;
     f.seen = pen ? e->seen : nullptr; f.seen_words = e->seen_words;
+    f.V = e->cfg.vocab; f.bad = e->d_bad;
     launch_finish_step(f, st);
 }
 
@@ -1439,6 +1441,18 @@ static int generate_beam(sv_engine* e, const void* dev_embeds, int B, int S0, co
     return 0;
 }
 
+// The selection kernels raise a device flag when a row had no finite logit (a numeric failure upstream: the token they emit
+// is then 0 instead of the out-of-range sentinel, so nothing indexes the embedding table out of bounds); the entry points
+// turn it into an error instead of returning made-up tokens.
+static int check_finite_logits(sv_engine* e, hipStream_t st, const char* who) {
+    HIPCHECK(hipMemcpyAsync(&e->h_flags[4], e->d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipStreamSynchronize(st));
+    if (!e->h_flags[4]) return 0;
+    HIPCHECK(hipMemsetAsync(e->d_bad, 0, sizeof(int32_t), st));
+    HIPCHECK(hipStreamSynchronize(st));
+    return fail(SV_EHIP, "%s: a row of logits had no finite value (NaN / Inf in the weights or inputs?)", who);
+}
+
 extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int32_t S0, const sv_sampling* sp,
                            int64_t* dev_out_tokens, int32_t* n_generated, sv_stream stream) {
     SVCHECK(check_ready(e));
@@ -1564,6 +1578,7 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
             return fail(SV_EHIP, "in-launch row-update hand-off timed out (set SV_DECODE_OVERLAP=0)");
         }
     }
+    SVCHECK(check_finite_logits(e, st, "sv_generate"));
     const int n_emit = e->h_flags[1];
     if (n_emit < 1 || n_emit > max_new) return fail(SV_EHIP, "generation bookkeeping failed (n_emitted=%d)", n_emit);
     tokens_to_i64_kernel<<<(B * n_emit + 255) / 256, 256, 0, st>>>(e->out_tok, e->out_ld, dev_out_tokens, B, n_emit, max_new);
@@ -1596,7 +1611,7 @@ static int cb_bucket(const sv_engine* e) {
 static void cb_step_args(sv_engine* e, CbStepArgs& a, const int32_t* map) {
     a.logits = e->logits; a.ld = e->Vpad; a.V = e->cfg.vocab; a.slots = e->cb_slots; a.slot_map = map;
     a.cur_tok = e->cur_tok; a.positions = e->positions; a.out_tokens = e->out_tok; a.ld_out = e->out_ld;
-    a.seen = e->seen; a.seen_words = e->seen_words; a.n_live = e->cb_nlive; a.events = e->cb_events;
+    a.seen = e->seen; a.seen_words = e->seen_words; a.n_live = e->cb_nlive; a.events = e->cb_events; a.bad = e->d_bad;
 }
 
 static int cb_begin(sv_engine* e, hipStream_t st) {
@@ -1741,6 +1756,7 @@ extern "C" int sv_cb_step(sv_engine* e, int32_t n_steps, int32_t* n_live_out, sv
     HIPCHECK(hipMemcpyAsync(&e->h_flags[3], e->cb_nlive, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
     *n_live_out = e->h_flags[3];
+    SVCHECK(check_finite_logits(e, st, "sv_cb_step"));
     e->timing_graph = gexec ? 1.0 : 0.0;
     return 0;
 }

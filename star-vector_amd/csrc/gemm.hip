@@ -1000,13 +1000,7 @@ void launch_gemm(const GemmArgs& a0, hipStream_t st) {
 //     bias + residual -> new residual stream in fragment order + its LayerNorm partial statistics
 //     (both c_proj); fp32 logits rounded to bf16 values (lm_head); raw fp32 slabs (test surface).
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
-    // v_cvt_pk_bf16_f32: two f32 -> packed bf16, round-to-nearest-even (checked bit-exactly against
-    // torch's cast by tests/test_gpu_ops.py::test_bf16_rounding_is_rne)
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
-}
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) { return pack2bf(lo, hi); }   // common.h: v_cvt_pk_bf16_f32
 
 // one chunk of the weight / activation stream held in registers
 template <int CH>

@@ -231,6 +231,8 @@ struct FinishArgs {
     const int32_t* stop_ids; int n_stop;
     int eos, pad, B, max_new;
     uint32_t* seen; int seen_words;   // repetition-penalty bitmap to update with the emitted ids (nullptr = off)
+    int V; int32_t* bad;          // vocabulary size; device flag raised when a row has no valid token (all logits NaN): the id
+                                  // fed to the next step is then 0, never an out-of-range row of the embedding table
 };
 void launch_finish_step(const FinishArgs& a, hipStream_t st);
 
@@ -252,6 +254,7 @@ struct CbStepArgs {
     int32_t* cur_tok; int32_t* positions; int32_t* out_tokens; int ld_out;
     uint32_t* seen; int seen_words;
     int32_t* n_live; int32_t* events;           // device counters: live slots, finished-slot events
+    int32_t* bad;                               // raised when a slot has no valid token (all logits NaN); the id becomes 0
 };
 void launch_cb_step(const CbStepArgs& a, int nblocks, hipStream_t st);
 

@@ -119,8 +119,8 @@ __device__ int sample_row(F lg, int V, int top_k, float top_p, uint64_t seed, ui
     __syncthreads();
     if (tid == 0 && *result < 0) {
         // round-off fell between ranges: take the most probable token (always a survivor)
-        float best = -INFINITY; int bi = 0;
-        for (int i = 0; i < V; ++i) if (lg(i) > best) { best = lg(i); bi = i; }
+        float best = -INFINITY; int bi = 0x7fffffff;        // stays the out-of-range sentinel when no score is finite: the
+        for (int i = 0; i < V; ++i) if (lg(i) > best) { best = lg(i); bi = i; }     // caller reports it (never used as an id)
         *result = bi;
     }
     __syncthreads();
@@ -158,6 +158,10 @@ __global__ void finish_step_kernel(FinishArgs p) {
             for (int s = 0; s < AM_SPLIT; ++s) argmax_pair(best, nxt, p.pval[b * AM_SPLIT + s], p.pidx[b * AM_SPLIT + s]);
         } else {
             nxt = p.next[b];
+        }
+        if (unf && (unsigned)nxt >= (unsigned)p.V) {     // no finite logit in this row: never index the embedding table with it
+            nxt = 0;
+            if (p.bad) *p.bad = 1;
         }
         const int tok = unf ? nxt : p.pad;
         p.out_tokens[(size_t)b * p.ld_out + t] = tok;
@@ -242,6 +246,10 @@ __global__ __launch_bounds__(SP_THREADS) void cb_step_kernel(CbStepArgs p) {
         tok = result;
     }
     if (tid != 0) return;
+    if ((unsigned)tok >= (unsigned)p.V) {               // no finite logit: never index the embedding table with the sentinel
+        tok = 0;
+        if (p.bad) *p.bad = 1;
+    }
     const int t = sl.step;
     int32_t* out = p.out_tokens + (size_t)s * p.ld_out;
     out[t] = tok;

@@ -712,3 +712,30 @@ def test_repetition_penalty_on_device():
     s1 = eng.generate(emb, do_sample=True, temperature=0.8, top_p=0.9, seed=3, repetition_penalty=pen, **kw).cpu()
     assert torch.equal(s1, eng.generate(emb, do_sample=True, temperature=0.8, top_p=0.9, seed=3, repetition_penalty=pen, **kw).cpu())
     eng.close()
+
+
+def test_non_finite_logits_are_an_error_not_a_memory_fault():
+    """A row of logits with no finite value (NaN weights here) has no argmax: the selection kernels must not hand their
+    out-of-range sentinel to the next step's embedding gather (that was a GPU memory fault), and the call must fail loudly
+    instead of returning made-up tokens.  The engine stays usable afterwards."""
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=5)
+    bad = dict(w)
+    k = O.P_DEC + "ln_f.weight"
+    bad[k] = torch.full_like(w[k], float("nan"))
+    eng = build_engine(cfg, bad, 4, 96)
+    img = bf(O.synthetic_images(2, cfg.image_size, seed=6))
+    emb = torch.cat([eng.adapter(eng.encode_image(img)), eng.embed_tokens(torch.tensor([[7, 11]] * 2, device=dev()))], 1)
+    S0 = emb.shape[1]
+    for kw in (dict(), dict(do_sample=True, temperature=1.0, top_p=0.9, seed=3)):
+        with pytest.raises(RuntimeError, match="no finite value"):
+            eng.generate(emb, max_length=S0 + 12, eos_token_id=-1, pad_token_id=0, **kw)
+    with pytest.raises(RuntimeError, match="no finite value"):
+        eng.cb_admit(emb[:1].contiguous(), [dict(max_new_tokens=8)])
+        eng.cb_step(4)
+    eng.cb_reset()
+    eng.close()
+    good = build_engine(cfg, w, 4, 96)                       # same process, healthy weights: unaffected
+    emb = torch.cat([good.adapter(good.encode_image(img)), good.embed_tokens(torch.tensor([[7, 11]] * 2, device=dev()))], 1)
+    assert good.generate(emb, max_length=S0 + 12, eos_token_id=-1, pad_token_id=0).shape == (2, 12)
+    good.close()
