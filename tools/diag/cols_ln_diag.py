@@ -47,6 +47,21 @@ def probe(tag, n=6):
 
 
 probe("cold")
+# an engine created and closed in the same process (what every other GPU test file does first)
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from oracle import starvector_oracle as O  # noqa: E402  (diagnosis tool: weight factory)
+from tests.gpu_util import build_engine  # noqa: E402
+cfg = O.OracleConfig.tiny()
+w = O.make_weights(cfg, seed=5)
+eng = build_engine(cfg, w, 4, 96)
+probe("engine alive, unused")
+img = O.synthetic_images(2, cfg.image_size, seed=6).to(torch.bfloat16).cuda()
+emb = torch.cat([eng.adapter(eng.encode_image(img)), eng.embed_tokens(torch.tensor([[7, 11]] * 2).cuda())], 1)
+probe("after encode_image / adapter")
+eng.generate(emb, max_length=emb.shape[1] + 8, eos_token_id=-1, pad_token_id=0)
+probe("after generate")
+eng.close()
+probe("engine closed")
 # warm-up: what the test file runs before this op (big GEMMs, LayerNorm rows, skinny GEMMs, attention)
 x = torch.randn(8288, 2048).bfloat16().float()
 Wb = (torch.randn(2048, 2048) / 45).bfloat16().float()
