@@ -231,8 +231,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * GB_M;
-    const int n0 = blockIdx.x * GB_N;
+    // XCD-aware tile order (as in the 256^2 kernel below): workgroups are dealt round-robin to the 8 XCDs in launch order, each
+    // XCD has its own L2.  In launch order every XCD walks the WHOLE activation matrix and every weight tile (rocprofv3
+    // FETCH_SIZE of this kernel: 273 MB per launch against ~80 MB of operands).  Instead each XCD gets a contiguous run of
+    // tile ids and walks it in bands of 8 m-tiles, m fastest: the 64 tiles resident on an XCD (32 CUs x 2 blocks) form an
+    // 8 x 8 patch that shares 8 activation and 8 weight tiles through that XCD's L2.
+    int tm = blockIdx.y, tn = blockIdx.x;
+    if (!p.plain_order) {
+        const int tiles_n = gridDim.x, tiles_m = gridDim.y, T = tiles_m * tiles_n;
+        const int id = blockIdx.y * tiles_n + blockIdx.x;
+        const int q = T >> 3, rem = T & 7, xcd = id & 7, loc = id >> 3;
+        const int wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
+        const int band = wg / (8 * tiles_n), r_in = wg - band * 8 * tiles_n;
+        const int band_rows = min(8, tiles_m - band * 8);
+        tm = band * 8 + r_in % band_rows;
+        tn = r_in / band_rows;
+    }
+    const int m0 = tm * GB_M;
+    const int n0 = tn * GB_N;
     const int KS = p.K >> 4;
     const int KT = p.K / GB_K;
     const int NT_total = (p.N + 31) >> 5;   // packed n-tiles available (Npad/32 >= this)
@@ -943,6 +959,8 @@ void launch_gemm(const GemmArgs& a0, hipStream_t st) {
         if (ee && strcmp(ee, "regs") == 0) a.epi_regs = 1;
         else if (ee && strcmp(ee, "none") == 0) a.epi_regs = 2;
         else if (ee && strcmp(ee, "ldsonly") == 0) a.epi_regs = 3;
+        const char* eo = getenv("SV_GEMM_ORDER");
+        if (eo && strcmp(eo, "plain") == 0) a.plain_order = 1;
     }
     // explicit switches (tools / A-B runs): SV_GEMM_TAIL 0 never peel, 2 always, 1 model; SV_GEMM_VARIANT 0 / 1 the 128^2
     // kernel (plain / sched_barrier), 2 the 256^2 kernel.  Either one disables the autotuner.

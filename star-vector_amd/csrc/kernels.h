@@ -30,6 +30,7 @@ struct GemmArgs {
     int M, N, K;                     // K = padded K (multiple of 64) shared by A and Wp
     int act; int out_f32;
     const float* cscale = nullptr;   // fp8 weights: per-output-column scale applied to the accumulator (or nullptr)
+    int plain_order = 0;             // 1: the 128^2 kernel walks tiles in launch order (A/B switch SV_GEMM_ORDER=plain); 0: XCD-aware
     int epi_regs = 0;                // 1: the register epilogue (row-per-lane stores) instead of the LDS-transposed one (A/B switch)
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
