@@ -1848,7 +1848,114 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(SkinnyArgs 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// skinny GEMM, TWO 32-column tiles per wave sharing one activation fragment (an experiment, off by default).  Hypothesis: the
+// decode GEMMs are bound by what the CUs can ingest (c_fc 67 MB of weights + activation fragments in 6.8 us, lm_head 402 MB
+// in 39.9 us: both ~10 TB/s), half of it activation fragments every block re-reads; a wave that loads one activation fragment
+// per k-step for two weight fragments (column tiles 2j, 2j + 1) ingests a third less per weight byte.  Measured: no gain
+// (see launch_gemm_skinny_nt2) -- the hypothesis is wrong, the fragments come out of L2 for free next to the HBM stream.
+// K is cut exactly like the one-tile kernel cuts it (8 waves per block over the block's K range, `splitk` blocks, the
+// partials of a column tile reduced in wave order, slabs in slab order), so every output keeps its bits whichever of the
+// two kernels produced it.  Scope: bf16 weights, fp32 slabs or fp32 logits; used where the pairs still fill the chip.
+// ------------------------------------------------------------------------------------------------
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_nt2_kernel(SkinnyArgs p) {
+    constexpr int CH = 4;
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    float (*red)[WAVES][16][64] = reinterpret_cast<float (*)[WAVES][16][64]>(sk_smem);          // [2][WAVES][16][64]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int NT = p.Npad >> 5;
+    const int nt0 = 2 * blockIdx.x, nt1 = nt0 + 1 < NT ? nt0 + 1 : nt0;        // an odd last tile is computed twice, stored once
+    const bool two = nt0 + 1 < NT;
+    const int split = blockIdx.y, mt = blockIdx.z;
+    const int KS = p.K >> 4;
+    const int ks_per_split = KS / p.splitk;
+    const int ks_per_wave = ks_per_split / WAVES;
+    const int ks0 = split * ks_per_split + wave * ks_per_wave;
+    const int m = lane & 31, half = lane >> 5;
+    const u32x4* w0p = reinterpret_cast<const u32x4*>(p.Wp) + ((size_t)nt0 * KS + ks0) * 64 + lane;
+    const u32x4* w1p = reinterpret_cast<const u32x4*>(p.Wp) + ((size_t)nt1 * KS + ks0) * 64 + lane;
+    const u32x4* xptr = reinterpret_cast<const u32x4*>(p.xp) + ((size_t)mt * KS + ks0) * 64 + lane;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    struct Chunk { u32x4 w0[CH], w1[CH], x[CH]; };
+    Chunk ca, cb;
+    auto load = [&](Chunk& c, int ks) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+            if (ks + u < ks_per_wave) {                                           // wave-uniform
+                c.w0[u] = __builtin_nontemporal_load(w0p + (size_t)(ks + u) * 64);
+                c.w1[u] = __builtin_nontemporal_load(w1p + (size_t)(ks + u) * 64);
+                c.x[u] = xptr[(size_t)(ks + u) * 64];
+            }
+    };
+    auto compute = [&](Chunk& c, int ks) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u)
+            if (ks + u < ks_per_wave) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(c.w0[u]), as_frag4(c.x[u]), acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(c.w1[u]), as_frag4(c.x[u]), acc1, 0, 0, 0);
+            }
+    };
+    load(ca, 0);
+    if (CH < ks_per_wave) load(cb, CH);
+    for (int ks = 0; ks < ks_per_wave; ks += 2 * CH) {
+        compute(ca, ks);
+        if (ks + 2 * CH < ks_per_wave) load(ca, ks + 2 * CH);
+        if (ks + CH < ks_per_wave) compute(cb, ks + CH);
+        if (ks + 3 * CH < ks_per_wave) load(cb, ks + 3 * CH);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { red[0][wave][r][lane] = acc0[r]; red[1][wave][r][lane] = acc1[r]; }
+    __syncthreads();
+    constexpr int RPW = 16 / WAVES;                       // WAVES = 8: 2 accumulator rows (= 2 consecutive columns) per wave
+    const int r0 = wave * RPW;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (t == 1 && !two) break;
+        const int nt = t ? nt1 : nt0;
+        float v[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int r = r0 + i;
+            float s = red[t][0][r][lane];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) s += red[t][w][r][lane];
+            v[i] = s;
+        }
+        const int n0 = nt * 32 + 8 * (r0 >> 2) + 4 * half + (r0 & 3);
+        if (p.out_mode == SK_OUT_PARTIAL) {
+            *reinterpret_cast<float2*>(p.ws + ((size_t)split * p.MT * 32 + mt * 32 + m) * p.ldws + n0) = make_float2(v[0], v[1]);
+        } else {                                          // SK_OUT_F32
+            if (p.round_bf16) { v[0] = bfround(v[0]); v[1] = bfround(v[1]); }
+            *reinterpret_cast<float2*>(p.out_f32 + ((size_t)mt * 32 + m) * p.ldo + n0) = make_float2(v[0], v[1]);
+        }
+    }
+}
+
+// false: outside the kernel's scope, or the column pairs would leave CUs idle (the caller runs one tile per block)
+static bool launch_gemm_skinny_nt2(const SkinnyArgs& a, hipStream_t st) {
+    // OFF by default: measured (profiles/skinny_r02_two_column_tiles_ab.log) the shared fragment does not pay -- lm_head 43.6 vs
+    // 38.4 us, 8B c_fc 39.1 vs 36.4 us, down-projection 6.4 vs 6.7 us only together with split-K 8 -- so the activation
+    // re-reads are NOT what bounds these kernels.  SV_SKINNY_NT2=1 enables it (read per launch: the A/B tool and the bitwise test).
+    const char* e2 = getenv("SV_SKINNY_NT2");
+    if (!(e2 && atoi(e2) == 1)) return false;
+    if (a.Wq || a.ln_stats || a.ru_M > 0 || (a.K / 16) % a.splitk) return false;
+    if (!(a.out_mode == SK_OUT_PARTIAL || (a.out_mode == SK_OUT_F32 && a.splitk == 1))) return false;
+    if (skinny_waves(a.Npad, a.K / 16, a.splitk) != 8) return false;
+    const int pairs = (a.Npad / 32 + 1) / 2;
+    const int ks_per_wave = (a.K / 16) / a.splitk / 8;
+    if (pairs * a.splitk < 224 || ks_per_wave < 8) return false;                             // fill the chip; enough K per wave to stream
+    gemm_skinny_nt2_kernel<8><<<dim3(pairs, a.splitk, a.MT), 512, 2 * 8 * 16 * 64 * 4, st>>>(a);
+    return true;
+}
+
 static int init_mt2_attrs() {
+    int r0 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_nt2_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 16 * 64 * 4);
+    if (r0) return r0;
     int r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 16 * 64 * 4);
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 16 * 64 * 4);
     return r;
@@ -1880,6 +1987,7 @@ static bool launch_gemm_skinny_mt2(const SkinnyArgs& a, hipStream_t st) {
 
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st) {
     if (launch_gemm_skinny_mt2(a, st)) return;                  // 33..64 rows: two row tiles per block, weights streamed once
+    if (launch_gemm_skinny_nt2(a, st)) return;                  // two column tiles per wave share an activation fragment
     if (a.Wq && launch_gemm_skinny_fp8(a, st)) return;       // fp8 weights: its own kernel (falls through if unsupported)
     dim3 grid(a.Npad / 32, a.splitk, a.MT);
     switch (skinny_waves(a.Npad, a.K / 16, a.splitk)) {

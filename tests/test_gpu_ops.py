@@ -141,6 +141,26 @@ def test_linear_skinny_two_row_tiles_per_block_is_bitwise_the_one_tile_kernel(M,
     assert torch.equal(E.op_linear_skinny(bf(x[32:M]), bf(W), bf(b), splitk=sk), two[32:M])
 
 
+@pytest.mark.parametrize("M,N,K,sk", [(32, 2048, 8192, 8), (7, 49156, 2048, 1), (32, 2304, 4096, 4), (20, 16384, 2048, 1),
+                                       (64, 2048, 8192, 8)])
+def test_linear_skinny_two_column_tiles_per_wave_is_bitwise_the_one_tile_kernel(M, N, K, sk):
+    """Two 32-column tiles per wave share one activation fragment (an experiment kept behind SV_SKINNY_NT2=1); K is cut exactly as
+    the one-tile kernel cuts it, so the bits are the same (odd tile counts, several split-K factors, 64 rows = the two-row-tile
+    kernel takes over and must agree as well)."""
+    g = torch.Generator().manual_seed(M + N + K + sk)
+    x = torch.randn(M, K, generator=g).bfloat16().float()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().float()
+    b = (0.1 * torch.randn(N, generator=g)).bfloat16().float()
+    one = E.op_linear_skinny(bf(x), bf(W), bf(b), splitk=sk)
+    os.environ["SV_SKINNY_NT2"] = "1"                     # the experiment is off by default (measured: no gain)
+    try:
+        two = E.op_linear_skinny(bf(x), bf(W), bf(b), splitk=sk)
+    finally:
+        os.environ.pop("SV_SKINNY_NT2", None)
+    assert torch.equal(two, one)
+    assert rel_err(two, x @ W.T + b) <= 1e-5
+
+
 @pytest.mark.parametrize("B,S,H,Hkv,hd,causal", [
     (2, 1, 2, 2, 64, 0), (2, 17, 2, 2, 64, 0), (2, 257, 16, 16, 64, 0),       # ViT MHSA shapes
     (3, 19, 2, 1, 128, 1), (2, 259, 16, 1, 128, 1),                           # decoder MQA prefill
