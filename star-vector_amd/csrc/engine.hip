@@ -615,7 +615,17 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         if (hr != hipSuccess) rc = fail(SV_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(hr));
     }
     if (!rc) {
-        hipError_t hr = hipStreamCreateWithFlags(&e->gen_stream, hipStreamNonBlocking);
+        // SV_STREAM_PRIORITY=high|low: experiment switch (does the command processor serve a high-priority queue's dependent
+        // dispatches any faster?  profiles/runtime_r02_launch_knobs_ab.log)
+        hipError_t hr;
+        const char* pr = getenv("SV_STREAM_PRIORITY");
+        if (pr && (strcmp(pr, "high") == 0 || strcmp(pr, "low") == 0)) {
+            int lo = 0, hi = 0;
+            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo = least, hi = greatest priority (numerically lower)
+            hr = hipStreamCreateWithPriority(&e->gen_stream, hipStreamNonBlocking, strcmp(pr, "high") == 0 ? hi : lo);
+        } else {
+            hr = hipStreamCreateWithFlags(&e->gen_stream, hipStreamNonBlocking);
+        }
         if (hr == hipSuccess) hr = hipEventCreateWithFlags(&e->gen_event, hipEventDisableTiming);
         if (hr != hipSuccess) rc = fail(SV_EHIP, "stream/event creation: %s", hipGetErrorString(hr));
     }
