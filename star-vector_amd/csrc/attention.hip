@@ -67,6 +67,11 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs p)
 
     int last = (qblock_end < S ? qblock_end : S) - 1;        // last query row of the block
     const int ntiles = p.causal ? (last / 64 + 1) : ((S + 63) / 64);
+    // sliding window (StarCoder2, prompts longer than the window): key tiles entirely below the block's first query's window
+    // are never loaded; inside the first tiles a query row may see nothing yet (statistics stay at -inf / 0, see m_use below)
+    const int win = p.causal ? p.window : 0;
+    const int qfirst = HPB == 1 ? blockIdx.x * 128 : q0;
+    const int kt0 = (win > 0 && qfirst - win + 1 > 0) ? (qfirst - win + 1) / 64 : 0;
     const bf16_t* kbase = p.k + (size_t)b * S * p.kv_row_stride + (size_t)kvh * p.kv_head_stride;
     const bf16_t* vbase = p.v + (size_t)b * S * p.kv_row_stride + (size_t)kvh * p.kv_head_stride;
 
@@ -109,9 +114,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs p)
             dst[6 * VSTR] = (bf16_t)(v[3] & 0xffffu); dst[7 * VSTR] = (bf16_t)(v[3] >> 16);
         }
     };
-    gload(0);
-    for (int kt = 0; kt < ntiles; ++kt) {
-        if (kt) __syncthreads();                             // every wave is done with the previous tile
+    gload(kt0);
+    for (int kt = kt0; kt < ntiles; ++kt) {
+        if (kt > kt0) __syncthreads();                       // every wave is done with the previous tile
         lstore();
         __syncthreads();
         if (kt + 1 < ntiles) gload(kt + 1);
@@ -135,20 +140,21 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt * 64 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * c;
-                const bool ok = key < S && (!p.causal || key <= qabs);
+                const bool ok = key < S && (!p.causal || key <= qabs) && (win <= 0 || key > qabs - win);
                 const float sc = ok ? accS[j][r] * p.scale : -INFINITY;
                 accS[j][r] = sc;
                 mt = fmaxf(mt, sc);
             }
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float m_new = fmaxf(m_run, mt);
-        const float alpha = __expf(m_run - m_new);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;    // a row that has seen no key yet (window): exp(-inf - 0) = 0, no NaN
+        const float alpha = __expf(m_run - m_use);
         float ls = 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __expf(accS[j][r] - m_new);
+                const float pv = __expf(accS[j][r] - m_use);
                 accS[j][r] = pv;
                 ls += pv;
             }

@@ -880,8 +880,6 @@ static int prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hi
     const sv_config& c = e->cfg;
     const int D = c.hidden, dh = e->dh, F = c.n_inner, M = B * S0, QKV = e->QKV, nkv = e->nkv;
     const int QD = c.n_head * dh;                      // width of the query block (= D for both model families)
-    if (c.sliding_window > 0 && S0 > c.sliding_window)
-        return fail(SV_ENOTSUP, "prompt of %d rows exceeds the %d-token sliding window (windowed prefill is not built)", S0, c.sliding_window);
     SVCHECK(ensure_prefill_ws(e, (size_t)M));
     if (e->v2)      // StarCoder2: no learned positions (rotary), hidden = inputs_embeds
         HIPCHECK(hipMemcpyAsync(e->ph, embeds, (size_t)M * D * sizeof(bf16_t), hipMemcpyDeviceToDevice, st));
@@ -892,6 +890,7 @@ static int prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hi
     at.q_row_stride = QKV; at.kv_row_stride = QKV; at.q_head_stride = dh; at.kv_head_stride = nkv > 1 ? dh : 0;
     at.o = e->pattn; at.o_row_stride = QD; at.B = B; at.S = S0; at.H = c.n_head; at.head_dim = dh;
     at.kv_group = c.n_head / nkv; at.causal = 1; at.scale = 1.0f / sqrtf((float)dh);
+    at.window = c.sliding_window > 0 ? c.sliding_window : 0;      // StarCoder2: also inside the prompt pass (prompts longer than the window)
     for (int i = 0; i < c.n_layer; ++i) {
         DecLayer& L = e->dec[i];
         launch_layernorm_rows(e->ph, D, L.ln1.g, L.ln1.b, e->pln, D, M, D, c.ln_eps, st);

@@ -166,6 +166,7 @@ struct AttnPrefillArgs {
     bf16_t* o; int o_row_stride;                          // [B*S][H*D]
     int B, S, H, head_dim, kv_group;                      // kv head = head / kv_group
     int causal; float scale;
+    int window = 0;                                       // causal only: query q sees keys q - window < k <= q (StarCoder2); 0 = all
 };
 void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st);
 

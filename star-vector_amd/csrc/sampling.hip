@@ -260,7 +260,7 @@ __global__ __launch_bounds__(SP_THREADS) void cb_step_kernel(CbStepArgs p) {
     if (!fin && sl.n_stop > 0 && t + 1 >= sl.n_stop) {
         fin = true;
         for (int i = 0; i < sl.n_stop; ++i)
-            if (out[t + 1 - sl.n_stop + i] != sl.stop[i]) { fin = false; break; }
+            if (out[t + 1 - sl.n_stop + i] != p.slots[s].stop[i]) { fin = false; break; }      // from memory: indexing the register copy puts it on the stack
     }
     p.slots[s].step = t + 1;
     if (fin) {
