@@ -319,11 +319,11 @@ struct KvFrags {
 };
 
 template <int D>
-__device__ __forceinline__ void load_group(KvFrags<D>& f, const char* pool, const int32_t* table, int page_bytes,
+__device__ __forceinline__ void load_group(KvFrags<D>& f, const char* pool, int page_index, int page_bytes,
                                            int g, int lane) {
     constexpr int NKS = D / 32, NDV = D / 16;
     const int t0 = g << 5;
-    const char* page = pool + (size_t)table[t0 >> 6] * page_bytes;
+    const char* page = pool + (size_t)page_index * page_bytes;
     const int half = (t0 >> 5) & 1;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -344,6 +344,11 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     const int b = bx / p.n_kv;
     const int kvh = bx % p.n_kv;
     const int split = blockIdx.y;
+    // the first 64 entries of this sequence's block-table row (4096 tokens) are requested together with the position: the
+    // page of a key group is then a cross-lane read instead of a second dependent global round trip (position -> table -> KV)
+    const int32_t* table = p.block_table + (size_t)b * p.max_pages;
+    const int tl = threadIdx.x & 63;
+    const int tpre = tl < p.max_pages ? table[tl] : 0;
     const int pos = p.positions[b];
     const int L = pos + 1;
     const int ngroups = (L + 31) >> 5;
@@ -378,12 +383,15 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     char* const pool = p.pool_layer + (size_t)kvh * p.kv_head_stride;
 
     const int page_bytes = kv_page_bytes(D);
-    const int32_t* table = p.block_table + (size_t)b * p.max_pages;
+    auto page_of = [&](int grp) -> int {                   // grp is wave-uniform
+        const int pi = grp >> 1;                           // 64-token pages, 32-key groups
+        return pi < 64 ? __builtin_amdgcn_readlane(tpre, pi) : table[pi];
+    };
     // the KV stream does not depend on q: request the first group before anything else
     const int stride = act * AD_WAVES;
     int g = g0 + split + act * wave;
     KvFrags<D> fa, fb;
-    if (g < ngroups) load_group<D>(fa, pool, table, page_bytes, g, lane);
+    if (g < ngroups) load_group<D>(fa, pool, page_of(g), page_bytes, g, lane);
 
     // q / k_new / v_new of this sequence -> LDS (bf16).  Input: the c_attn output rows (bf16, bias added)
     // or, slab pipeline, the fp32 split-K slabs of the c_attn GEMM, summed here in slab order + bias.
@@ -520,11 +528,11 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     // two register buffers: the loads of group i+1 are in flight while group i is processed
     while (g < ngroups) {
         const int g1 = g + stride;
-        if (g1 < ngroups) load_group<D>(fb, pool, table, page_bytes, g1, lane);
+        if (g1 < ngroups) load_group<D>(fb, pool, page_of(g1), page_bytes, g1, lane);
         process(fa, g);
         if (g1 >= ngroups) break;
         const int g2 = g1 + stride;
-        if (g2 < ngroups) load_group<D>(fa, pool, table, page_bytes, g2, lane);
+        if (g2 < ngroups) load_group<D>(fa, pool, page_of(g2), page_bytes, g2, lane);
         process(fb, g1);
         g = g2;
     }
