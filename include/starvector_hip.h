@@ -197,7 +197,12 @@ int  sv_preprocess_images(const uint8_t* const* dev_pixels, const int32_t* width
  *   sv_debug_gemm_plan        what the big-M GEMM dispatch does with an M x N x K problem: out5 = {peel the row remainder,
  *                             remainder rows, remainder as a 128^2 tile row (else one wave per 32x32 tile), main part on the
  *                             256^2 kernel, modelled time in us}; every choice computes the same bits */
+/*   sv_debug_skinny_plan      how a decode GEMM (rows <= 64, W [N][K], split-K `splitk`, bf16 or fp8 weights) is launched:
+ *                             out2 = {waves per block = how K is cut inside a block, i.e. the order in which a row's partial
+ *                             sums are added -- a function of the GEMM only, never of `rows`; 1 when a block carries two
+ *                             32-row tiles (33..64 rows: the weights are streamed once)} */
 int  sv_debug_resample_coeffs(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* taps, int32_t cap);
+int  sv_debug_skinny_plan(int32_t rows, int32_t N, int32_t K, int32_t splitk, int32_t fp8, int32_t* out2);
 int  sv_debug_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t act, int32_t* out5);
 
 /* Prompt pass over inputs_embeds [B,S0,hidden] bf16 (all-ones attention mask): fills the paged KV

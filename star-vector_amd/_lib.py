@@ -88,6 +88,7 @@ PROTOTYPES = {
                                   C.POINTER(_F), _P, _P, C.c_int64, _P]),
     "sv_debug_resample_coeffs": (_I, [_I, _I, C.POINTER(_I), C.POINTER(_I), _I]),
     "sv_debug_gemm_plan": (_I, [_I, _I, _I, _I, C.POINTER(_I)]),
+    "sv_debug_skinny_plan": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),
     "sv_prefill": (_I, [_P, _P, _I, _I, _P, _P]),
     "sv_forward_logits": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "sv_decode_step": (_I, [_P, _P, _I, _P, _P]),

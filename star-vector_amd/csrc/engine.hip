@@ -1840,6 +1840,15 @@ extern "C" int sv_cb_reset(sv_engine* e) {
 // ------------------------------------------------------------------------------------------------
 // C ABI: host-side decisions, callable without a GPU (CPU tests)
 // ------------------------------------------------------------------------------------------------
+extern "C" int sv_debug_skinny_plan(int32_t rows, int32_t N, int32_t K, int32_t splitk, int32_t fp8, int32_t* out2) {
+    if (!out2 || rows < 1 || N < 1 || K < 16 || K % 16 || splitk < 1 || (K / 16) % splitk)
+        return fail(SV_EINVAL, "sv_debug_skinny_plan: bad argument");
+    int waves = 0, two = 0;
+    skinny_plan(round_up(N, 32), K, splitk, fp8, (rows + 31) / 32, &waves, &two);
+    out2[0] = waves; out2[1] = two;
+    return 0;
+}
+
 extern "C" int sv_debug_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t act, int32_t* out5) {
     if (!out5 || M < 1 || N < 1 || K < 1) return fail(SV_EINVAL, "sv_debug_gemm_plan: bad argument");
     const GemmPlan pl = gemm_plan(M, N, K, act, 1);

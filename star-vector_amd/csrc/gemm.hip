@@ -1985,6 +1985,14 @@ static bool launch_gemm_skinny_mt2(const SkinnyArgs& a, hipStream_t st) {
     return false;       // 16-wave (narrow outputs) and 1/2-wave (tiny K) shapes keep one row tile per block
 }
 
+void skinny_plan(int Npad, int K, int splitk, int fp8, int MT, int* waves, int* two_row_tiles) {
+    const int KS = K / 16;
+    const int w = fp8 ? skinny_waves_fp8(KS, splitk) : skinny_waves(Npad, KS, splitk);
+    *waves = w;
+    const char* e2 = getenv("SV_SKINNY_MT2");
+    *two_row_tiles = (!(e2 && atoi(e2) == 0) && MT >= 2 && !(MT & 1) && (w == 8 || w == 4) && KS % splitk == 0) ? 1 : 0;
+}
+
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st) {
     if (launch_gemm_skinny_mt2(a, st)) return;                  // 33..64 rows: two row tiles per block, weights streamed once
     if (launch_gemm_skinny_nt2(a, st)) return;                  // two column tiles per wave share an activation fragment

@@ -77,6 +77,9 @@ struct SkinnyArgs {
     int* ru_err;                     // set if the bounded wait gives up
 };
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st);
+// host arithmetic of the launch: waves per block (how K is cut inside a block = the summation order of a row) and whether a
+// block carries two row tiles; a function of the GEMM only for the former (sv_debug_skinny_plan, CPU tests)
+void skinny_plan(int Npad, int K, int splitk, int fp8, int MT, int* waves, int* two_row_tiles);
 int init_gemm_kernels();        // hipFuncSetAttribute for the large-LDS variants (0 = ok)
 
 

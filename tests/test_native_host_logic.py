@@ -66,3 +66,31 @@ def test_gemm_dispatch_at_the_measured_shapes(lib):
         assert abs(_plan(lib, M, N, K, act)["est_us"] - us) / us < 0.15
     out = (C.c_int32 * 5)()
     assert lib.sv_debug_gemm_plan(0, 8, 8, 0, out) == -22
+
+
+def _skinny(lib, rows, N, K, sk, fp8=0):
+    out = (C.c_int32 * 2)()
+    assert lib.sv_debug_skinny_plan(rows, N, K, sk, fp8, out) == 0
+    return out[0], out[1]
+
+
+def test_decode_gemm_wave_split_depends_on_the_gemm_only(lib):
+    """How K is cut inside a block decides the order a row's partial sums are added in: it must not change with the batch
+    (round 2 fixed a dependence on the number of row tiles), while 33..64 rows switch to two row tiles per block."""
+    shapes = [(2304, 2048, 4), (2048, 2048, 4), (8192, 2048, 1), (2048, 8192, 4), (49156, 2048, 1),          # StarVector-1B decode
+              (5632, 4608, 2), (4608, 4608, 2), (18432, 4608, 1), (4608, 18432, 2), (49157, 4608, 1),        # StarVector-8B decode
+              (516, 128, 1), (512, 256, 2), (1024, 1024, 2)]                                                   # tiny / narrow outputs
+    for N, K, sk in shapes:
+        for fp8 in (0, 1):
+            if fp8 and ((K // 16) // sk) % 4:
+                continue
+            w1, two1 = _skinny(lib, 1, N, K, sk, fp8)
+            for rows in (7, 32, 33, 64):
+                w, two = _skinny(lib, rows, N, K, sk, fp8)
+                assert w == w1, (N, K, sk, fp8, rows)                      # the batch never changes the summation order
+                assert two == (1 if rows > 32 and w in (4, 8) else 0)
+            assert two1 == 0
+    assert _skinny(lib, 32, 2304, 2048, 4)[0] == 8 and _skinny(lib, 32, 8192, 2048, 1)[0] == 8      # the 1B decode GEMMs: 8 waves
+    assert _skinny(lib, 32, 1024, 1024, 2)[0] == 16                                                   # narrow output: 16 waves, one tile
+    out = (C.c_int32 * 2)()
+    assert lib.sv_debug_skinny_plan(32, 64, 100, 1, 0, out) == -22                                    # K % 16
