@@ -327,3 +327,82 @@ def test_simple_starvector_processor_is_hf_style():
     assert enc["input_ids"].shape == (2, 4) and enc["pixel_values"].shape == (3, 224, 224)
     with pytest.raises(ValueError):
         proc()
+
+
+class _FakeSlotEngine(_FakeEngine):
+    """_FakeEngine plus the continuous-batching entry points (cb_admit / cb_step / cb_poll / cb_read / cb_reset): every slot
+    runs the same per-row 'model' with its own prompt, budget, EOS and stop sequence."""
+
+    def __init__(self, max_batch=8):
+        super().__init__()
+        from starvector_amd.engine import EngineConfig
+        self.cfg = EngineConfig(max_batch=max_batch)
+        self.slots = {}
+        self.admits = []
+
+    def cb_reset(self):
+        self.slots = {}
+
+    def cb_admit(self, emb, reqs):
+        B, S, _ = emb.shape
+        self.admits.append((B, S))
+        base = emb.float().sum(dim=(1, 2)).round().long().tolist()
+        out = []
+        for b, r in zip(base, reqs):
+            s = min(set(range(self.cfg.max_batch)) - set(self.slots))
+            stream = [(b + 3 * t) % 97 + 1 for t in range(r["max_new_tokens"])]
+            self.slots[s] = dict(stream=stream, n=1, live=True, stop=r.get("stop_ids"), eos=r.get("eos_token_id", -1))
+            self._finish(s)
+            out.append(s)
+        return out
+
+    def _finish(self, s):
+        sl = self.slots[s]
+        got = sl["stream"][:sl["n"]]
+        if sl["n"] >= len(sl["stream"]) or got[-1] == sl["eos"] or (sl["stop"] and got[-len(sl["stop"]):] == list(sl["stop"])):
+            sl["live"] = False
+
+    def cb_step(self, n):
+        for _ in range(n):
+            for s, sl in self.slots.items():
+                if sl["live"]:
+                    sl["n"] += 1
+                    self._finish(s)
+        return sum(1 for sl in self.slots.values() if sl["live"])
+
+    def cb_poll(self):
+        lv = [int(self.slots[s]["live"]) if s in self.slots else 0 for s in range(self.cfg.max_batch)]
+        st = [self.slots[s]["n"] if s in self.slots else 0 for s in range(self.cfg.max_batch)]
+        return lv, st
+
+    def cb_read(self, s, start, n):
+        return torch.tensor(self.slots[s]["stream"][start:start + n], dtype=torch.long)
+
+
+def _slot_lm():
+    lm = HipCausalLM.__new__(HipCausalLM)
+    torch.nn.Module.__init__(lm)
+    object.__setattr__(lm, "_engine", _FakeSlotEngine())
+    lm.eos_token_id, lm.pad_token_id, lm.seed = 0, 99, 0
+    return lm
+
+
+def test_padded_prompts_run_as_slots_of_one_decode_loop():
+    """With the continuous-batching entry points available, rows of different real length decode TOGETHER (one prompt pass per
+    length group, then one loop); every row equals its unpadded solo run; HF's row-0 stop cuts every row; nothing is left live."""
+    lm = _slot_lm()
+    torch.manual_seed(0)
+    emb = torch.randint(0, 5, (4, 6, 3)).float()
+    mask = torch.tensor([[0, 0, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1], [0, 0, 1, 1, 1, 1], [0, 1, 1, 1, 1, 1]])
+    out = lm.generate(inputs_embeds=emb, attention_mask=mask, max_length=6 + 7)
+    assert out.shape == (4, 7) and lm._engine.calls == []                                   # no classic generate call at all
+    assert sorted(lm._engine.admits) == [(1, 5), (1, 6), (2, 4)]                            # prompt passes per real length
+    for b in range(4):
+        solo = _fake_lm().generate(inputs_embeds=emb[b:b + 1, mask[b].bool()], max_length=int(mask[b].sum()) + 7)
+        assert torch.equal(solo[0], out[b])
+    assert lm._engine.slots == {}                                                           # the slots were reset
+    stop = out[0, 2:4].tolist()
+    cut = lm.generate(inputs_embeds=emb, attention_mask=mask, max_length=6 + 7, stopping_criteria=[StoppingCriteriaSub(stops=[stop])])
+    assert cut.shape == (4, 4) and torch.equal(cut, out[:, :4])                             # row 0's stop ends every row
+    with pytest.raises(ValueError):
+        lm.generate(inputs_embeds=emb, attention_mask=torch.tensor([[1, 1, 1, 1, 1, 0]] * 4), max_length=12)
