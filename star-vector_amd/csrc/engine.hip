@@ -1533,7 +1533,8 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
         snprintf(key, sizeof(key), "B%d|n%d|ds%d|T%a|p%a|k%d|seed%llu|eos%d|pad%d|ns%d|rp%a|mn%d|pipe%d%d%d|mt2%s", B, max_new, sp->do_sample,
                  sp->temperature, sp->top_p, sp->top_k, (unsigned long long)sp->seed, sp->eos_token_id, sp->pad_token_id, sp->n_stop,
                  sp->repetition_penalty, sp->min_new_tokens, (int)e->cols_decode, (int)e->fused_decode, e->overlap,
-                 getenv("SV_SKINNY_MT2") ? getenv("SV_SKINNY_MT2") : "");       // kernel-choice switches are part of what was captured
+                 (std::string(getenv("SV_SKINNY_MT2") ? getenv("SV_SKINNY_MT2") : "") + "|d" +
+                  (getenv("SV_SKINNY_DEPTH") ? getenv("SV_SKINNY_DEPTH") : "")).c_str());       // kernel-choice switches are part of what was captured
         if (e->gen_gexec && e->gen_graph_key == key) {
             gexec = e->gen_gexec;
         } else {

@@ -1143,7 +1143,9 @@ __device__ __forceinline__ void ru_row(const SkinnyArgs& p, int row, char* smem,
     if (tid == 0) __hip_atomic_fetch_add(p.ru_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <int WAVES, int PRE>
+// NB = register chunks of CH k-steps in flight per wave.  2 (8 KiB of weights per wave) is the measured default; NB = 4 puts a
+// wave's whole 16-k-step share of the K = 2048 / 8192 GEMMs in flight at once (one HBM latency round instead of two).
+template <int WAVES, int PRE, int NB = 2>
 __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && PRE == 2) ? 4 : 1) void gemm_skinny_kernel(SkinnyArgs p) {
     constexpr bool LN = PRE == 1;
     constexpr bool RU = PRE == 2;
@@ -1224,9 +1226,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && PRE == 2) ? 4 : 1) void 
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<bf16_t*>(p.xp), 0, (unsigned)((size_t)p.MT * 32 * p.K * 2), 0x00020000);
     const int xoff = (int)((((size_t)mt * KS + ks0) * 64 + lane) * 16);
-    SkChunk<CH> ca, cb;
-    sk_load_w<CH>(ca, wptr, 0, ks_per_wave);
-    if (CH < ks_per_wave) sk_load_w<CH>(cb, wptr, CH, ks_per_wave);
+    SkChunk<CH> ck[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        if (b * CH < ks_per_wave) sk_load_w<CH>(ck[b], wptr, b * CH, ks_per_wave);
     if (RU) {
         // the weight stream is in flight; now produce / wait for this GEMM's activation rows
         const int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -1240,8 +1243,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && PRE == 2) ? 4 : 1) void 
         }
         __syncthreads();
     }
-    sk_load_x<CH, RU>(ca, xptr, rs_x, xoff, 0, ks_per_wave);
-    if (CH < ks_per_wave) sk_load_x<CH, RU>(cb, xptr, rs_x, xoff, CH, ks_per_wave);
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+        if (b * CH < ks_per_wave) sk_load_x<CH, RU>(ck[b], xptr, rs_x, xoff, b * CH, ks_per_wave);
 
     float ra = 1.f, rb = 0.f;
     if (LN) {
@@ -1291,11 +1295,12 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && PRE == 2) ? 4 : 1) void 
         }
     };
 
-    for (int ks = 0; ks < ks_per_wave; ks += 2 * CH) {
-        compute(ca, ks);
-        if (ks + 2 * CH < ks_per_wave) sk_load<CH, RU>(ca, wptr, xptr, rs_x, xoff, ks + 2 * CH, ks_per_wave);
-        if (ks + CH < ks_per_wave) compute(cb, ks + CH);
-        if (ks + 3 * CH < ks_per_wave) sk_load<CH, RU>(cb, wptr, xptr, rs_x, xoff, ks + 3 * CH, ks_per_wave);
+    for (int ks = 0; ks < ks_per_wave; ks += NB * CH) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (ks + b * CH < ks_per_wave) compute(ck[b], ks + b * CH);
+            if (ks + (b + NB) * CH < ks_per_wave) sk_load<CH, RU>(ck[b], wptr, xptr, rs_x, xoff, ks + (b + NB) * CH, ks_per_wave);
+        }
     }
 
     // ---- K reduction across the waves of the block (wave order) ---------------------------------
@@ -1487,6 +1492,7 @@ int init_gemm_kernels() {
     if (!r) r = set_attr<16, 2>(160 * 1024);
     if (!r) r = set_attr<8, 1>(128 * 1024);
     if (!r) r = set_attr<8, 0>(128 * 1024);
+    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<8, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (!r) r = set_attr<8, 2>(128 * 1024);
     if (!r) r = init_mt2_attrs();
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<bf16_t, 0>),
@@ -1513,7 +1519,10 @@ static void launch_sk(const SkinnyArgs& a, dim3 grid, hipStream_t st) {
     } else if (ln) {
         gemm_skinny_kernel<W, 1><<<grid, W * 64, smem, st>>>(a);
     } else {
-        gemm_skinny_kernel<W, 0><<<grid, W * 64, smem, st>>>(a);
+        // SV_SKINNY_DEPTH=4: four chunks in flight (experiment switch, read per launch; 8-wave blocks only)
+        const char* ed = getenv("SV_SKINNY_DEPTH");
+        if (W == 8 && ed && atoi(ed) == 4 && (a.K / 16) / a.splitk / 8 >= 12) gemm_skinny_kernel<8, 0, 4><<<grid, 512, smem, st>>>(a);
+        else gemm_skinny_kernel<W, 0><<<grid, W * 64, smem, st>>>(a);
     }
 }
 
