@@ -541,9 +541,24 @@ def run_window_case(write):
     print(f"[tiny_v2_window] W=24, S0={emb.shape[1]}, {n_new} new tokens: tokens == HF {torch.equal(ref, mine)}; "
           f"differs from full attention: {not torch.equal(mine, nowin)}")
     assert torch.equal(ref, mine) and not torch.equal(mine, nowin)
+    # a prompt LONGER than the window (W = 8 < S0): HF applies the same mask inside the prompt pass; the engine's windowed
+    # prompt pass (attention.hip: masked + tile-skipping flash prefill) is checked against this oracle path
+    W8, n8 = 8, 24
+    cfg8 = dataclasses.replace(O.OracleConfig.tiny_v2(), sliding_window=W8)
+    _, _, lm8 = build_reference_v2(cfg8, w)
+    ref8 = lm8.generate(inputs_embeds=emb, attention_mask=torch.ones(emb.shape[:2], dtype=torch.long), do_sample=False,
+                        num_beams=1, max_length=emb.shape[1] + n8, use_cache=True, pad_token_id=cfg.pad_token_id,
+                        eos_token_id=None)
+    mine8 = O.greedy_generate(w, dataclasses.replace(cfg8, eos_token_id=-1), emb, emb.shape[1] + n8)
+    lg_ref8 = lm8(inputs_embeds=emb, attention_mask=torch.ones(emb.shape[:2], dtype=torch.long)).logits[:, -1].detach()
+    lg_mine8 = O.greedy_generate(w, dataclasses.replace(cfg8, eos_token_id=-1), emb, emb.shape[1] + 1, return_logits=True)[1][:, 0]
+    d8 = float((lg_ref8 - lg_mine8).abs().max())
+    print(f"[tiny_v2_window] W={W8} < S0={emb.shape[1]} (windowed prompt pass): prefill logits max|diff| {d8:.2e}; "
+          f"{n8} tokens == HF {torch.equal(ref8, mine8)}; differs from W=24: {not torch.equal(mine8, mine[:, :n8])}")
+    assert emb.shape[1] > W8 and d8 < 1e-4 and torch.equal(ref8, mine8)
     if write:
         from safetensors.torch import save_file
-        save_file({"image": image, "prompt_ids": prompt_ids, "tokens": ref.contiguous(),
+        save_file({"image": image, "prompt_ids": prompt_ids, "tokens": ref.contiguous(), "tokens_w8": ref8.contiguous(),
                    "meta": torch.tensor([2024, B, n_new, 24])}, os.path.join(GOLD, "tiny_v2_window.safetensors"))
         print("  wrote tests/golden/tiny_v2_window.safetensors")
 
@@ -620,6 +635,9 @@ def main():
     write = "--no-write" not in sys.argv
     torch.manual_seed(0)
     torch.set_num_threads(host_cores())
+    if "--only-window" in sys.argv:                 # re-mint tests/golden/tiny_v2_window.safetensors alone
+        run_window_case(write)
+        return
     run_fitted_case("tiny_b3", O.OracleConfig.tiny(), seed=1234, batch=3, n_new=24, write=write)
     import dataclasses
     run_case("tiny_bn_b2", dataclasses.replace(O.OracleConfig.tiny(), adapter_norm="batch_norm"),

@@ -521,6 +521,9 @@ def test_starcoder2_sliding_window():
     worst8, scale8, checked8, near8, _, _ = _teacher_forced_check(small, emb, w, cfg8, 24)
     print(f"[v2 window] W=8 < S0={S0}: logits max|err| {worst8:.3e} (scale {scale8:.3e}); {checked8} exact, {near8} near-tie flips")
     assert checked8 > 0
+    got8 = small.generate(emb, max_length=S0 + g["tokens_w8"].shape[1], eos_token_id=-1, pad_token_id=0).cpu()
+    print(f"[v2 window] W=8: {sum(int(torch.equal(got8[b], g['tokens_w8'][b])) for b in range(B))}/{B} streams identical to HF's "
+          "generate with the window inside the prompt pass")
     small.close()
 
 

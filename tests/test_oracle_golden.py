@@ -231,6 +231,10 @@ def test_starcoder2_sliding_window_matches_hf(golden_dir):
     emb = O.prepare_generation_inputs(w, cfg, g["image"], g["prompt_ids"])
     assert emb.shape[1] < W < emb.shape[1] + n_new
     assert torch.equal(O.greedy_generate(w, cfg, emb, emb.shape[1] + n_new), g["tokens"])
+    # a prompt LONGER than the window: the mask applies inside the prompt pass as well (HF's streams for W = 8 < S0)
+    cfg8 = dataclasses.replace(cfg, sliding_window=8)
+    assert emb.shape[1] > 8
+    assert torch.equal(O.greedy_generate(w, cfg8, emb, emb.shape[1] + g["tokens_w8"].shape[1]), g["tokens_w8"])
 
 
 def test_image_preprocess_restatement_matches_pillow():
