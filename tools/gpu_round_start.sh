@@ -7,6 +7,7 @@ TAG="${1:-rXX}"
 OUT="gpurun_out/${TAG}"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+bash tools/box_info.sh > "$OUT/box.txt" 2>&1        # results have differed between the pool's GPUs: keep the identity
 
 # 1. parity: the whole GPU suite through the C ABI
 timeout 400 python -m pytest tests -m gpu -q 2>&1 | tail -40 > "$OUT/pytest_gpu.log"
