@@ -182,25 +182,36 @@ class ContinuousBatcher:
                         break
                 with self._lock:
                     head = self._pending[0] if self._pending else None
-                if head is not None and head.exclusive is not None:
-                    if not self._active:            # the engine is idle: hand it over
-                        with self._lock:
-                            self._pending.popleft()
-                        try:
-                            self.engine.cb_reset()
-                            head.value = head.exclusive()
-                            self._finish(head)
-                        except BaseException as e:
-                            self._finish(head, e)
-                        continue
-                elif self._pending and len(self._active) < self.engine.cfg.max_batch:
-                    self._admit()
-                    self._deliver()                 # first tokens (and one-token requests) right away
-                if self._active:
-                    self.engine.cb_step(self.steps_per_poll)
-                    self.steps_run += self.steps_per_poll
-                    self._deliver()
-        except BaseException as e:                  # engine failure: every request learns about it at once
+                try:
+                    if head is not None and head.exclusive is not None:
+                        if not self._active:        # the engine is idle: hand it over
+                            with self._lock:
+                                self._pending.popleft()
+                            try:
+                                self.engine.cb_reset()
+                                head.value = head.exclusive()
+                                self._finish(head)
+                            except BaseException as e:
+                                self._finish(head, e)
+                            continue
+                    elif self._pending and len(self._active) < self.engine.cfg.max_batch:
+                        self._admit()
+                        self._deliver()             # first tokens (and one-token requests) right away
+                    if self._active:
+                        self.engine.cb_step(self.steps_per_poll)
+                        self.steps_run += self.steps_per_poll
+                        self._deliver()
+                except Exception as e:              # the engine failed under this batch (a device error, a row of non-finite
+                    with self._lock:                # logits): the requests SHARING the batch learn about it at once, the
+                        reqs = list(self._active.values())      # waiting ones stay queued and the loop lives on -- one
+                        self._active.clear()                    # poisoned request must not take the worker down
+                    for r in reqs:
+                        self._finish(r, e)
+                    try:
+                        self.engine.cb_reset()
+                    except Exception:
+                        pass
+        except BaseException as e:                  # interpreter shutdown and the like: every request learns about it at once
             with self._lock:
                 reqs = list(self._active.values()) + list(self._pending)
                 self._active.clear()

@@ -149,6 +149,28 @@ def test_engine_failure_reaches_every_request():
     b.close()
 
 
+def test_the_loop_survives_an_engine_failure_and_serves_the_next_request():
+    """A failure under one batch (e.g. a request whose logits went non-finite) fails the requests sharing that batch; the
+    scheduler resets the slots and keeps serving."""
+    eng = _CbEngine(max_batch=4, delay=0.005)
+    real_step = eng.cb_step
+    state = {"fail": True}
+
+    def flaky(n):
+        if state["fail"]:
+            state["fail"] = False
+            raise RuntimeError("a row of logits had no finite value (scripted)")
+        return real_step(n)
+    eng.cb_step = flaky
+    b = ContinuousBatcher(eng, steps_per_poll=2)
+    r1 = b.submit(_emb(1), dict(max_new_tokens=12))
+    with pytest.raises(RuntimeError):
+        r1.result(timeout=30)
+    r2 = b.submit(_emb(2), dict(max_new_tokens=12))           # the same batcher, afterwards
+    assert r2.result(timeout=30).shape == (1, 12)
+    b.close()
+
+
 def test_mirror_generate_routes_single_sequences_through_the_batcher():
     """HipCausalLM.generate with a batcher attached: B = 1, num_beams = 1 calls become slots; the HF kwargs are mapped."""
     from starvector_amd.model import HipCausalLM
