@@ -18,12 +18,21 @@ from __future__ import annotations
 
 import json
 import os
+import threading
 from typing import Dict, List, Optional, Sequence
 
 import torch
 import torch.nn as nn
 
 from .engine import EngineConfig, HipEngine
+
+# Set while the calling thread runs an exclusive job of a ContinuousBatcher (beam search, multi-row batches): inside it the
+# mirror talks to the engine directly; every OTHER thread keeps going through the batcher's queue.
+_EXCLUSIVE = threading.local()
+
+
+def _in_exclusive_job() -> bool:
+    return bool(getattr(_EXCLUSIVE, "active", False))
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)   # data/util.py:33-38
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -439,7 +448,7 @@ class HipCausalLM(_EngineModule):
         stop = self._stop_ids(kw.get("stopping_criteria"))
         eng = self._engine
         if (int(kw.get("num_beams") or 1) == 1 and hasattr(eng, "cb_admit") and B <= eng.cfg.max_batch
-                and (getattr(self, "batcher", None) is None or getattr(self, "_exclusive", False))):
+                and (getattr(self, "batcher", None) is None or _in_exclusive_job())):
             return self._generate_padded_slots(inputs_embeds, mask, lengths, budget, pad, stop, kw)
         outs, fired_at = [None] * B, None
         for n in sorted(set(lengths)):
@@ -574,10 +583,10 @@ class HipCausalLM(_EngineModule):
                 for c in range(tokens.shape[1]):
                     streamer.put(tokens[:, c])
         batcher = getattr(self, "batcher", None)
-        if batcher is not None and not (num_beams == 1 and inputs_embeds.shape[0] == 1) and not getattr(self, "_exclusive", False):
+        if batcher is not None and not (num_beams == 1 and inputs_embeds.shape[0] == 1) and not _in_exclusive_job():
             # beam search / a multi-row HF batch while requests share the engine: run it with the engine to itself, in turn
             def call():
-                object.__setattr__(self, "_exclusive", True)
+                _EXCLUSIVE.active = True          # thread-local: only the scheduler thread running this job sees it
                 try:
                     return self.generate(inputs_embeds=inputs_embeds, attention_mask=attention_mask, do_sample=do_sample,
                                          top_p=top_p, temperature=temperature, num_beams=num_beams, max_length=max_length,
@@ -586,9 +595,9 @@ class HipCausalLM(_EngineModule):
                                          early_stopping=early_stopping, pad_token_id=pad_token_id, eos_token_id=eos_token_id,
                                          top_k=top_k, streamer=streamer, seed=seed)
                 finally:
-                    object.__setattr__(self, "_exclusive", False)
+                    _EXCLUSIVE.active = False
             return batcher.run_exclusive(call)
-        if batcher is not None and num_beams == 1 and inputs_embeds.shape[0] == 1 and not getattr(self, "_exclusive", False):
+        if batcher is not None and num_beams == 1 and inputs_embeds.shape[0] == 1 and not _in_exclusive_job():
             # serving: one request per call (serve/model_worker.py:120-181), many calls in flight -> they share the engine's
             # decode loop instead of taking turns; the tokens are those of the solo call below
             def on_chunk(toks, first):
