@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SV_ABI_VERSION 4
+#define SV_ABI_VERSION 5
 #define SV_WEIGHT_BF16 0
 #define SV_WEIGHT_FP8_E4M3 1
 
@@ -298,37 +298,17 @@ int  sv_op_linear_skinny(const void* x, const void* W, const void* bias, void* y
  * does at load): y = x . dequant(quant(W))^T + bias, fp32; scale_out [N] (device, optional) receives the row scales */
 int  sv_op_linear_skinny_fp8(const void* x, const void* W, const void* bias, void* y_f32, float* scale_out, int32_t M,
                              int32_t N, int32_t K, int32_t splitk, sv_stream stream);
-/* The fused decode-step GEMM: y[M,N] = act( LN_opt(h)[M,K] . W^T + bias ) (+ residual), with the LayerNorm
- * applied in the GEMM prologue from per-tile partial statistics, the split-K reduction done by the last
- * arriving block (ticket), and (residual mode) the new rows' LayerNorm statistics row_stats[M][2] =
- * (sum, sum of squares).  gamma/beta/residual/row_stats may be NULL. */
-int  sv_op_decode_linear(const void* h, const void* gamma, const void* beta, float eps, const void* W,
-                         const void* bias, const void* residual, void* y, float* row_stats, int32_t M, int32_t N,
-                         int32_t K, int32_t splitk, int32_t act, sv_stream stream);
+/* the decode GEMM's fused epilogues on their own (split-K 1): out_f32 == 0: y[M,N] = act(bf16(x W^T + bias)) as bf16 rows
+ * (the c_fc form, N %% 8 == 0); out_f32 != 0: float32 rows of x W^T holding bf16-rounded values, bias ignored (the lm_head form) */
+int  sv_op_linear_skinny_epi(const void* x, const void* W, const void* bias, void* y, int32_t M, int32_t N, int32_t K,
+                             int32_t act, int32_t out_f32, sv_stream stream);
 /* micro-benchmark of the big-M MFMA GEMM alone (pseudo-random operands): average microseconds per launch */
 int  sv_bench_linear(int32_t M, int32_t N, int32_t K, int32_t act, int32_t residual, int32_t iters, double* avg_us,
                      sv_stream stream);
-/* micro-benchmark of the decode GEMM kernel alone: average microseconds per launch over `iters`
- * back-to-back launches (HIP events); ln = LayerNorm prologue on/off; mode = epilogue (0 fp32 slabs,
- * 1 bias+GELU fragment order, 3 bias+residual+statistics, 4 bias row-major) */
-int  sv_bench_decode_linear(int32_t M, int32_t N, int32_t K, int32_t splitk, int32_t ln, int32_t mode,
-                            int32_t iters, double* avg_us, sv_stream stream);
-/* The full-K decode GEMMs of the default pipeline (csrc/decode_gemm.hip; gpt_bigcode/modeling_gpt_bigcode.py:694-755), one at a time:
- *   sv_op_decode_cols      y[M,N] = LN_opt(x)[M,K] . W[N,K]^T + bias; with `residual` [M,N]: y = bf16(residual + bf16(.)).
- *                          A block owns `cpb` output columns (0 = the engine's choice) over the whole K; the LayerNorm
- *                          (gamma/beta not NULL; two-pass statistics like nn.LayerNorm) is computed inside the block.
- *                          y: bf16 [M][N], or float32 when out_f32 != 0 (no residual then).  K %% 32 == 0.
- *   sv_op_decode_skinny_ln y[M,N] = act(LN(x) . W^T + bias) as bf16 rows (N %% 8 == 0), or with out_f32 the lm_head form:
- *                          float32 rows holding bf16-rounded values (bias ignored).
- *   sv_bench_decode_gemm   average microseconds per launch over `iters` back-to-back launches; kind 0 cols row-major,
- *                          1 cols + LayerNorm prologue, 2 cols bias + residual, 3 skinny_ln GELU, 4 skinny_ln fp32 logits */
-int  sv_op_decode_cols(const void* x, const void* gamma, const void* beta, float eps, const void* W, const void* bias,
-                       const void* residual, void* y, int32_t M, int32_t N, int32_t K, int32_t cpb, int32_t out_f32,
-                       sv_stream stream);
-int  sv_op_decode_skinny_ln(const void* x, const void* gamma, const void* beta, float eps, const void* W, const void* bias,
-                            void* y, int32_t M, int32_t N, int32_t K, int32_t act, int32_t out_f32, sv_stream stream);
-int  sv_bench_decode_gemm(int32_t M, int32_t N, int32_t K, int32_t kind, int32_t cpb, int32_t iters, double* avg_us,
-                          sv_stream stream);
+/* micro-benchmark of the decode GEMM kernel alone: average microseconds per launch over `iters` back-to-back launches (HIP
+ * events); mode = 0 fp32 slabs (split-K `splitk`), 1 bias + GELU -> fragment order, 2 fp32 logits (modes 1, 2: splitk == 1) */
+int  sv_bench_decode_linear(int32_t M, int32_t N, int32_t K, int32_t splitk, int32_t mode, int32_t iters, double* avg_us,
+                            sv_stream stream);
 /* f32 -> bf16 through the hardware convert used inside the kernels (rounding-mode check) */
 int  sv_op_cvt_bf16_hw(const float* x, void* y, int64_t n, sv_stream stream);
 /* q,k,v token-major [B,S,H*D] / [B,S,Hkv*D]; out [B,S,H*D] */

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libstarvector_hip.so")
 HEADER_PATH = os.path.normpath(os.path.join(HERE, "..", "include", "starvector_hip.h"))
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 SV_DTYPE_BF16, SV_DTYPE_F32 = 0, 1
 SV_NORM_LAYER, SV_NORM_BATCH = 0, 1
 SV_ARCH_V1, SV_ARCH_V2 = 0, 1
@@ -110,12 +110,9 @@ PROTOTYPES = {
     "sv_op_linear": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sv_op_linear_skinny": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sv_op_linear_skinny_fp8": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "sv_op_decode_linear": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sv_op_linear_skinny_epi": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sv_bench_linear": (_I, [_I, _I, _I, _I, _I, _I, C.POINTER(C.c_double), _P]),
-    "sv_bench_decode_linear": (_I, [_I, _I, _I, _I, _I, _I, _I, C.POINTER(C.c_double), _P]),
-    "sv_op_decode_cols": (_I, [_P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "sv_op_decode_skinny_ln": (_I, [_P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
-    "sv_bench_decode_gemm": (_I, [_I, _I, _I, _I, _I, _I, C.POINTER(C.c_double), _P]),
+    "sv_bench_decode_linear": (_I, [_I, _I, _I, _I, _I, _I, C.POINTER(C.c_double), _P]),
     "sv_op_cvt_bf16_hw": (_I, [_P, _P, C.c_int64, _P]),
     "sv_op_attention": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _P]),
     "sv_op_plane_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),

@@ -105,8 +105,10 @@ class ContinuousBatcher:
         self._thread.join(timeout=30)
 
     # ---- scheduler thread ----------------------------------------------------------------------------------------------
-    def _admit(self):
-        """Move waiting requests into free slots, one `cb_admit` per prompt length (the prompt pass is rectangular)."""
+    def _admit(self) -> int:
+        """Move waiting requests into free slots, one `cb_admit` per prompt length (the prompt pass is rectangular).
+        Returns how many requests left the queue (admitted, or failed alone)."""
+        moved = 0
         with self._lock:
             waiting = []
             for r in self._pending:                 # FIFO up to the first exclusive job: nothing overtakes it
@@ -133,6 +135,7 @@ class ContinuousBatcher:
                     self._finish(bad[0], e)
                     with self._lock:
                         self._pending.remove(bad[0])
+                    moved += 1
                     break
                 with self._lock:
                     for r, s in zip(group, slots):
@@ -140,7 +143,9 @@ class ContinuousBatcher:
                         self._active[s] = r
                         self._pending.remove(r)
                     self.max_concurrent = max(self.max_concurrent, len(self._active))
+                moved += len(group)
                 break
+        return moved
 
     def _finish(self, req: _Request, error: Optional[BaseException] = None):
         req.error = error
@@ -195,7 +200,19 @@ class ContinuousBatcher:
                                 self._finish(head, e)
                             continue
                     elif self._pending and len(self._active) < self.engine.cfg.max_batch:
-                        self._admit()
+                        moved = self._admit()
+                        if moved == 0 and not self._active:
+                            # nothing runs and the head request still does not fit: no release will ever make room.  Reset the
+                            # continuous batch once (recovers anything a failed admit left behind); if it still does not fit,
+                            # the request fails with an error instead of the loop spinning on it forever.
+                            self.engine.cb_reset()
+                            if self._admit() == 0:
+                                with self._lock:
+                                    head = self._pending.popleft() if self._pending else None
+                                if head is not None:
+                                    self._finish(head, StarVectorBusy(
+                                        "the request does not fit an idle engine (KV pages / slots for prompt + max_new_tokens)"))
+                                continue
                         self._deliver()             # first tokens (and one-token requests) right away
                     if self._active:
                         self.engine.cb_step(self.steps_per_poll)

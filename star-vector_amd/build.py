@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libstarvector_hip.so")
-SOURCES = ["gemm.hip", "decode_gemm.hip", "rowops.hip", "attention.hip", "sampling.hip", "beam.hip", "preprocess.hip", "engine.hip"]
+SOURCES = ["gemm.hip", "rowops.hip", "attention.hip", "sampling.hip", "beam.hip", "preprocess.hip", "engine.hip"]
 HEADERS = ["common.h", "kernels.h", "beam.h", "warp.h", os.path.join("..", "..", "include", "starvector_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + os.environ.get("SV_HIPCC_FLAGS", "").split()
 

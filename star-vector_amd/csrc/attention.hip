@@ -358,14 +358,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     int act = (ngroups - g0 + AD_GROUPS_PER_BLOCK - 1) / AD_GROUPS_PER_BLOCK;
     act = act > p.max_splits ? p.max_splits : act;      // host cap: B * act <= #CUs (one block per CU) and <= AD_SPLIT
     act = act < 1 ? 1 : act;
-    if (split >= act) {
-        // splits >= max_splits never work: they stream the attention output projection's weights towards L2 / the Infinity
-        // Cache while the active splits wait on KV latency (a hint only)
-        if (split >= p.max_splits && p.pf_ptr)
-            sv_prefetch_slice(p.pf_ptr, p.pf_bytes, (split - p.max_splits) * gridDim.x + bx, (AD_SPLIT - p.max_splits) * gridDim.x,
-                              threadIdx.x, AD_WAVES * 64);
-        return;
-    }
+    if (split >= act) return;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* q_s = reinterpret_cast<bf16_t*>(smem);                       // [16][D]
@@ -393,8 +386,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     KvFrags<D> fa, fb;
     if (g < ngroups) load_group<D>(fa, pool, page_of(g), page_bytes, g, lane);
 
-    // q / k_new / v_new of this sequence -> LDS (bf16).  Input: the c_attn output rows (bf16, bias added)
-    // or, slab pipeline, the fp32 split-K slabs of the c_attn GEMM, summed here in slab order + bias.
+    // q / k_new / v_new of this sequence -> LDS (bf16): the fp32 split-K slabs of the c_attn GEMM, summed here in slab order + bias.
     // 4 columns per thread and every load issued before the first add: one memory round trip.
     for (int c4 = tid; c4 < (16 * D + 2 * D) / 4; c4 += AD_WAVES * 64) {
         const int n = c4 * 4;                    // LDS slot: q rows [0,16*D) (rows >= G are zero), k_new, v_new
@@ -404,9 +396,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
         else col = H * D + p.n_kv * D + kvh * D + (n - 17 * D);
         uint2 o = make_uint2(0u, 0u);
         if (col >= 0) {
-            if (p.qkv) {
-                o = *reinterpret_cast<const uint2*>(p.qkv + (size_t)b * p.ld_qkv + col);
-            } else {
+            {
                 float4 acc4[8];
                 const uint2 bb = *reinterpret_cast<const uint2*>(p.bias + col);
 #pragma unroll

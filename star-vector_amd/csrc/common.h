@@ -57,31 +57,6 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// Weight prefetch by blocks that have nothing else to do (the always-inactive context splits of the decode attention, the
-// spare CUs of the 32-block row update): stream slice `idx` of `n` of [ptr, ptr + bytes) with default-policy loads so that the
-// lines are in the XCD's L2 / the Infinity Cache when the NEXT launch (a weight-streaming GEMM whose first HBM round trip is
-// most of its duration) asks for them.  Pure hint: nothing is written, results cannot change.
-__device__ __forceinline__ void sv_prefetch_slice(const void* ptr, size_t bytes, int idx, int n, int tid, int nthreads) {
-    if (!ptr || n <= 0) return;
-    const size_t per = ((bytes / (size_t)n) + 1023) & ~(size_t)1023;
-    const size_t beg = (size_t)idx * per;
-    size_t end = beg + per;
-    end = end > bytes ? bytes : end;
-    const char* base = reinterpret_cast<const char*>(ptr);
-    for (size_t off = beg + (size_t)tid * 16; off + 16 <= end; off += (size_t)nthreads * 16 * 4) {
-        // four 16-byte loads per lane in flight, then one sink (a sink per load would wait for each load in turn)
-        uint4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const size_t o = off + (size_t)u * nthreads * 16;
-            v[u] = make_uint4(0u, 0u, 0u, 0u);
-            if (o + 16 <= end) v[u] = *reinterpret_cast<const uint4*>(base + o);
-        }
-        asm volatile("" ::"v"(v[0].x ^ v[1].x ^ v[2].x ^ v[3].x), "v"(v[0].y ^ v[1].y ^ v[2].y ^ v[3].y),
-                     "v"(v[0].z ^ v[1].z ^ v[2].z ^ v[3].z), "v"(v[0].w ^ v[1].w ^ v[2].w ^ v[3].w));
-    }
-}
-
 // activations used by the path's fused epilogues
 enum { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_SWISH = 2, ACT_GELU_TANH = 3 };
 

@@ -92,17 +92,7 @@ __global__ void unpack_rows_kernel(const bf16_t* xp, bf16_t* x, int ldx, int M, 
             *reinterpret_cast<const uint4*>(xp + xp_index(m >> 5, K >> 4, m & 31, c * 8));
     }
 }
-// per-row totals of the per-tile LayerNorm partials (tile order)
-__global__ void sum_stats_kernel(const float2* st, int tiles, float* out, int M) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    float a = 0.f, b = 0.f;
-    for (int t = 0; t < tiles; ++t) {
-        const float2 v = st[((size_t)(m >> 5) * tiles + t) * 32 + (m & 31)];
-        a += v.x; b += v.y;
-    }
-    out[2 * m] = a; out[2 * m + 1] = b;
-}
+// split-K slabs -> fp32 rows (+ bias), slab order (test surface of the skinny GEMM)
 __global__ void reduce_partials_kernel(const float* ws, int splitk, int rows_ws, int ldws, const bf16_t* bias,
                                        float* y, int M, int N) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M * N; i += gridDim.x * blockDim.x) {
@@ -124,9 +114,7 @@ struct Linear {
     uint8_t* Wq = nullptr;     //   decode image (launch_pack_weight_fp8); Wp then holds the SAME q values as bf16
     float* wscale = nullptr;   //   per-output-row scale [Npad]
     int N = 0, K = 0, Npad = 0, Kpad = 0;
-    int cpb = 8;          // decode-path columns per block (full-K pipeline, decode_gemm.hip)
-    int splitk = 1;       // decode-path split-K factor (slab pipeline)
-    int splitk_fused = 1; // decode-path split-K factor (fused pipeline: ticket merge)
+    int splitk = 1;       // decode-path split-K factor (fp32 slabs summed by the consumer)
 };
 struct LNp { bf16_t* g = nullptr; bf16_t* b = nullptr; };
 struct VitLayer { LNp ln1, ln2; Linear in_proj, out_proj, c_fc, c_proj; };
@@ -177,18 +165,8 @@ struct sv_engine {
     bf16_t *ph = nullptr, *pln = nullptr, *pqkv = nullptr, *pattn = nullptr, *pmlp = nullptr;
     // decode workspaces
     int MT = 0, ldws = 0, Vpad = 0;
-    bf16_t *h_dec = nullptr, *h_xp = nullptr, *hl = nullptr, *xp_a = nullptr, *xp_attn = nullptr, *xp_mlp = nullptr, *qkv_rm = nullptr;
-    float2* ln_stats = nullptr;
-    unsigned* sk_cnt = nullptr;
-    unsigned* ru_ready = nullptr;   // one arrival counter per overlapped launch site, zeroed at the start of a step
-    int* ru_err = nullptr;
-    int overlap = 0;                // SV_DECODE_OVERLAP=1: row updates ride inside the consumer GEMM's launch (measured slower)
+    bf16_t *h_dec = nullptr, *hl = nullptr, *xp_a = nullptr, *xp_attn = nullptr, *xp_mlp = nullptr;
     bool only_skinny = false;       // profiling: enqueue only the weight-streaming GEMMs of a step
-    int prefetch = 0;               // SV_PREFETCH=1: the idle blocks of attention / row update stream the next GEMM's weights towards
-                                    // L2 / the Infinity Cache.  Measured null (profiles/prefetch_r02_ab.log: 1347 vs 1346-1349 us per
-                                    // step; the GEMMs gain what attention and the row update lose), so it stays off
-    int prefetch_kb = 64;           // SV_PREFETCH_KB: bytes a prefetching block streams at most (its launch must not get longer)
-    int ldq = 0;
     float *ws = nullptr, *ws2 = nullptr, *logits = nullptr, *sample_scratch = nullptr, *attn_part = nullptr;
     unsigned* attn_cnt = nullptr;
     float* am_val = nullptr; int32_t* am_idx = nullptr;
@@ -211,10 +189,6 @@ struct sv_engine {
     size_t score_elems = 0;
     int cached_B = 0;
     int num_cus = 256;
-    bool fused_decode = false;   // SV_DECODE_FUSED=1: LN-prologue / ticket pipeline (5 launches per layer)
-    bool cols_decode = false;    // SV_DECODE_PIPE=cols: full-K pipeline (decode_gemm.hip), 5 launches per layer, no hand-offs.
-                                 // Parity-green but measured SLOWER than the 7-launch slab pipeline (1453 vs 1336 us per step,
-                                 // profiles/decode_gemm_r02_fullk_vs_slabs.log): LayerNorm repeated in every block is VALU-bound
     double timing[3] = {0, 0, 0};
     double timing_graph = 0;
     // generation runs on an engine-owned non-blocking stream (the caller's stream may be the legacy
@@ -368,7 +342,6 @@ static void register_v2(sv_engine* e) {
         L.c_proj.splitk = pick_splitk(L.c_proj.Npad / 32, QD / 16);
         L.c_fc.splitk = 1;
         L.c_proj2.splitk = pick_splitk(L.c_proj2.Npad / 32, F / 16);
-        L.c_attn.splitk_fused = L.c_proj.splitk_fused = L.c_fc.splitk_fused = L.c_proj2.splitk_fused = 1;
     }
     reg_ln(e, pd + "norm.", &e->ln_f, D);
 }
@@ -443,7 +416,6 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
 
     if (int ar = init_attention_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
     if (int ar = init_gemm_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
-    if (int ar = init_decode_gemm_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
 
     sv_engine* e = new sv_engine();
     e->cfg = c;
@@ -513,10 +485,6 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         L.c_proj.splitk = pick_splitk(L.c_proj.Npad / 32, D / 16);
         L.c_fc.splitk = 1;
         L.c_proj2.splitk = pick_splitk(L.c_proj2.Npad / 32, F / 16);
-        // fused pipeline: K is split across the 16 waves of a block; only the long-K down projection is
-        // split across blocks (one CU streams ~25 GB/s) and merged by the last arriver (ticket)
-        L.c_attn.splitk_fused = L.c_proj.splitk_fused = L.c_fc.splitk_fused = L.c_proj2.splitk_fused = 1;
-        if (L.c_proj2.Npad / 32 < 128 && (F / 16) % 32 == 0 && F >= 4096) L.c_proj2.splitk_fused = 4;
     }
     reg_ln(e, pd + "ln_f.", &e->ln_f, D);
     }   // v1 registration
@@ -561,19 +529,12 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     e->ldws = round_up(e->QKV, 32);
     if (e->ldws < D) e->ldws = D;
     A(dalloc(e, &e->h_dec, R * D));
-    A(dalloc(e, &e->h_xp, R * D));
-    e->ldq = e->QKV;
-    A(dalloc(e, &e->qkv_rm, R * e->ldq));
-    A(dalloc(e, &e->ln_stats, R * (D / 32)));
-    A(dalloc(e, &e->sk_cnt, (size_t)e->MT * 4096));
     A(dalloc(e, &e->hl, R * D));
     A(dalloc(e, &e->xp_a, R * D));
     A(dalloc(e, &e->xp_attn, R * D));
     A(dalloc(e, &e->xp_mlp, R * F));
     A(dalloc(e, &e->ws, (size_t)8 * R * e->ldws));
     A(dalloc(e, &e->ws2, (size_t)8 * R * e->ldws));
-    A(dalloc(e, &e->ru_ready, 64));
-    A(dalloc(e, &e->ru_err, 4));
     A(dalloc(e, &e->logits, R * e->Vpad));
     A(dalloc(e, &e->sample_scratch, R * 4));
     A(dalloc(e, &e->attn_part, R * nkv * attn_decode_part_floats(dh)));
@@ -615,17 +576,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         if (hr != hipSuccess) rc = fail(SV_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(hr));
     }
     if (!rc) {
-        // SV_STREAM_PRIORITY=high|low: experiment switch (does the command processor serve a high-priority queue's dependent
-        // dispatches any faster?  profiles/runtime_r02_launch_knobs_ab.log)
-        hipError_t hr;
-        const char* pr = getenv("SV_STREAM_PRIORITY");
-        if (pr && (strcmp(pr, "high") == 0 || strcmp(pr, "low") == 0)) {
-            int lo = 0, hi = 0;
-            (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo = least, hi = greatest priority (numerically lower)
-            hr = hipStreamCreateWithPriority(&e->gen_stream, hipStreamNonBlocking, strcmp(pr, "high") == 0 ? hi : lo);
-        } else {
-            hr = hipStreamCreateWithFlags(&e->gen_stream, hipStreamNonBlocking);
-        }
+        hipError_t hr = hipStreamCreateWithFlags(&e->gen_stream, hipStreamNonBlocking);
         if (hr == hipSuccess) hr = hipEventCreateWithFlags(&e->gen_event, hipEventDisableTiming);
         if (hr != hipSuccess) rc = fail(SV_EHIP, "stream/event creation: %s", hipGetErrorString(hr));
     }
@@ -653,25 +604,6 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         if (!rc && (hipMemcpy(e->rope_cos, hc.data(), hc.size() * 4, hipMemcpyHostToDevice) != hipSuccess ||
                     hipMemcpy(e->rope_sin, hs.data(), hs.size() * 4, hipMemcpyHostToDevice) != hipSuccess))
             rc = fail(SV_EHIP, "rope table upload failed");
-    }
-    if (getenv("SV_DECODE_OVERLAP")) e->overlap = atoi(getenv("SV_DECODE_OVERLAP")) != 0;
-    if (2 * c.n_layer + 1 > 64) e->overlap = 0;
-    e->fused_decode = getenv("SV_DECODE_FUSED") != nullptr && atoi(getenv("SV_DECODE_FUSED")) != 0;
-    if (getenv("SV_PREFETCH")) e->prefetch = atoi(getenv("SV_PREFETCH"));
-    if (getenv("SV_PREFETCH_KB") && atoi(getenv("SV_PREFETCH_KB")) > 0) e->prefetch_kb = atoi(getenv("SV_PREFETCH_KB"));
-    if (v2) e->fused_decode = false;       // the alternative pipelines are v1-only experiments
-    if (c.weight_dtype == SV_WEIGHT_FP8_E4M3) { e->fused_decode = false; e->overlap = 0; }
-    {
-        const char* pipe = getenv("SV_DECODE_PIPE");
-        e->cols_decode = pipe && strcmp(pipe, "cols") == 0;
-        if (e->fused_decode || e->overlap) e->cols_decode = false;
-        if (c.weight_dtype == SV_WEIGHT_FP8_E4M3) e->cols_decode = false;      // fp8 weights stream through the slab kernels
-        if (D % 32 || F % 32 || (D / 16) % 2) e->cols_decode = false;
-        for (DecLayer& L : e->dec) {
-            L.c_attn.cpb = cols_pick_cpb(L.c_attn.N);
-            L.c_proj.cpb = cols_pick_cpb(L.c_proj.N);
-            L.c_proj2.cpb = cols_pick_cpb(L.c_proj2.N);
-        }
     }
     if (rc) { sv_destroy(e); return rc; }
     *out = e;
@@ -769,25 +701,6 @@ static int attn_max_splits(const sv_engine* e) {
     return ms < 1 ? 1 : (ms > 8 ? 8 : ms);
 }
 
-// decode-path GEMM on the engine's buffers
-static void decode_gemm(sv_engine* e, const bf16_t* xp, const Linear& l, const LNp* ln, int MT, int out_mode, int act,
-                        hipStream_t st) {
-    SkinnyArgs a;
-    memset(&a, 0, sizeof(a));
-    a.xp = xp; a.Wp = l.Wp; a.Wq = l.Wq; a.wscale = l.wscale; a.bias = l.bias; a.MT = MT; a.Npad = l.Npad; a.K = l.Kpad; a.splitk = l.splitk_fused;
-    a.out_mode = out_mode; a.act = act; a.N = l.N;
-    if (ln) { a.ln_stats = e->ln_stats; a.ln_tiles = l.Kpad / 32; a.ln_g = ln->g; a.ln_b = ln->b; a.ln_eps = e->cfg.ln_eps; }
-    a.ws = e->ws; a.ldws = e->ldws; a.counters = e->sk_cnt;
-    if (out_mode == SK_OUT_RESID) {
-        a.out_xp = e->h_xp; a.resid_xp = e->h_xp; a.out_KS = l.Npad / 16; a.stats_out = e->ln_stats;
-    } else if (out_mode == SK_OUT_PACKED_ACT) {
-        a.out_xp = e->xp_mlp; a.out_KS = l.Npad / 16;
-    } else if (out_mode == SK_OUT_ROWMAJOR) {
-        a.out_rm = e->qkv_rm; a.ld_rm = e->ldq;
-    }
-    launch_gemm_skinny(a, st);
-}
-
 static int vision_forward(sv_engine* e, const bf16_t* img, int B, bf16_t* out, hipStream_t st) {
     const sv_config& c = e->cfg;
     const int Dv = c.vit_width, T = e->T, NP = e->NP, M = B * T, Fv = e->vit_F;
@@ -863,14 +776,13 @@ static int assign_pages(sv_engine* e, int B, int total_len, hipStream_t st) {
     return 0;
 }
 
-// lm_head -> e->logits.  ln == nullptr: xp already holds ln_f(h); else xp = raw h and ln_f is applied in the prologue
-static void lm_head_logits(sv_engine* e, int MT, const bf16_t* xp, const LNp* ln, hipStream_t st) {
+// lm_head -> e->logits; xp holds ln_f(h) in fragment order
+static void lm_head_logits(sv_engine* e, int MT, const bf16_t* xp, hipStream_t st) {
     SkinnyArgs a;
     memset(&a, 0, sizeof(a));
     a.xp = xp; a.Wp = e->lm_head.Wp; a.Wq = e->lm_head.Wq; a.wscale = e->lm_head.wscale; a.MT = MT; a.Npad = e->lm_head.Npad; a.K = e->lm_head.Kpad;
     a.splitk = 1; a.out_mode = SK_OUT_F32; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1;
     a.N = e->lm_head.N;
-    if (ln) { a.ln_stats = e->ln_stats; a.ln_tiles = e->lm_head.Kpad / 32; a.ln_g = ln->g; a.ln_b = ln->b; a.ln_eps = e->cfg.ln_eps; }
     launch_gemm_skinny(a, st);
 }
 
@@ -930,195 +842,52 @@ static int prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hi
     // only the last prompt row feeds ln_f + lm_head (HF computes all rows; same result)
     launch_gather_last_rows(e->ph, e->hl, B, S0, D, st);
     launch_layernorm_rows_packed(e->hl, D, e->ln_f.g, e->ln_f.b, e->xp_a, B, D, c.ln_eps, st);
-    lm_head_logits(e, (B + 31) / 32, e->xp_a, nullptr, st);
+    lm_head_logits(e, (B + 31) / 32, e->xp_a, st);
     return 0;
 }
 
-// one autoregressive step: consumes cur_tok/positions, leaves logits in e->logits.
-// 1 + 5 per layer + 1 launches: embed | c_attn(LN1) . attention . c_proj(+res) . c_fc(LN2,GELU) . c_proj(+res) | lm_head(ln_f)
-static void decode_forward_fused(sv_engine* e, int B, hipStream_t st) {
-    const sv_config& c = e->cfg;
-    const int D = c.hidden, dh = e->dh, MT = (B + 31) / 32;
-    EmbedRowsArgs er;
-    memset(&er, 0, sizeof(er));
-    er.wte = e->wte; er.wpe = e->wpe; er.tokens = e->cur_tok; er.positions = e->positions;
-    er.h_xp = e->h_xp; er.stats = e->ln_stats; er.M = B; er.D = D;
-    prof_mark(e, PK_ROWLN, st);
-    launch_embed_rows(er, st);
-    for (int i = 0; i < c.n_layer; ++i) {
-        DecLayer& L = e->dec[i];
-        prof_mark(e, PK_SKINNY, st);
-        decode_gemm(e, e->h_xp, L.c_attn, &L.ln1, MT, SK_OUT_ROWMAJOR, ACT_NONE, st);
-        AttnDecodeArgs ad;
-        memset(&ad, 0, sizeof(ad));
-        ad.qkv = e->qkv_rm; ad.ld_qkv = e->ldq;
-        ad.pool_layer = e->kv_pool + (size_t)i * e->layer_stride; ad.block_table = e->block_table;
-        ad.max_pages = e->pages_per_seq; ad.positions = e->positions; ad.out_xp = e->xp_attn; ad.out_KS = D / 16;
-        ad.window = c.sliding_window;
-        ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
-        ad.part = e->attn_part; ad.counters = e->attn_cnt;
-        ad.max_splits = attn_max_splits(e);
-        ad.n_kv = e->nkv; ad.kv_head_stride = e->kv_head_stride; ad.rope_cos = e->rope_cos; ad.rope_sin = e->rope_sin;
-        prof_mark(e, PK_ATTN, st);
-        launch_attn_decode(ad, st);
-        prof_mark(e, PK_SKINNY, st);
-        decode_gemm(e, e->xp_attn, L.c_proj, nullptr, MT, SK_OUT_RESID, ACT_NONE, st);
-        prof_mark(e, PK_SKINNY, st);
-        decode_gemm(e, e->h_xp, L.c_fc, &L.ln2, MT, SK_OUT_PACKED_ACT, ACT_GELU_TANH, st);
-        prof_mark(e, PK_SKINNY, st);
-        decode_gemm(e, e->xp_mlp, L.c_proj2, nullptr, MT, SK_OUT_RESID, ACT_NONE, st);
-    }
-    // ln_f is applied ONCE (all 1537 lm_head blocks would otherwise repeat the prologue)
-    prof_mark(e, PK_ROWLN, st);
-    launch_ln_apply_packed(e->h_xp, e->ln_stats, e->ln_f.g, e->ln_f.b, e->xp_a, B, D, c.ln_eps, st);
-    prof_mark(e, PK_SKINNY, st);
-    lm_head_logits(e, MT, e->xp_a, nullptr, st);
-    prof_mark(e, PK_SAMPLE, st);      // closes the lm_head interval; whatever follows is sampling
-}
-
-// slab pipeline (default; measured faster in situ, profiles/): 7 launches per layer
-//   c_attn -> fp32 slabs | attention (sums the slabs, +bias) | c_proj -> slabs | row update (+bias, +residual, LN2)
-//   | c_fc (bias+GELU epilogue) | c_proj -> slabs | row update (+residual, LN1 of the next layer / ln_f)
-static void decode_forward_slabs(sv_engine* e, int B, hipStream_t st) {
+// One autoregressive step: consumes cur_tok / positions, leaves logits in e->logits.  7 launches per layer + 2:
+//   row update (embedding | + bias + residual of the previous down-proj, LN1) | c_attn -> fp32 slabs | attention (sums the
+//   slabs, + bias) | c_proj -> slabs | row update (+ bias, + residual, LN2) | c_fc (bias + GELU epilogue) | down-proj -> slabs
+//   ... | row update (ln_f) | lm_head
+static void decode_forward(sv_engine* e, int B, hipStream_t st) {
     const sv_config& c = e->cfg;
     const int D = c.hidden, dh = e->dh, F = c.n_inner, MT = (B + 31) / 32;
     // slab double buffer: A = c_attn slabs (read by attention); B = c_proj / down-proj slabs (read by the row update)
     float* wsA = e->ws;
-    float* wsB = e->overlap ? e->ws2 : e->ws;
+    float* wsB = e->ws2;
     RowUpdateArgs ru;
     memset(&ru, 0, sizeof(ru));
     ru.h = e->h_dec; ru.ldh = D; ru.M = B; ru.D = D; ru.eps = c.ln_eps; ru.xp_out = e->xp_a;
     ru.ldws = e->ldws; ru.rows_ws = MT * 32;
     ru.ws = nullptr; ru.wte = e->wte; ru.wpe = e->wpe; ru.tokens = e->cur_tok; ru.positions = e->positions;
     ru.g = e->dec[0].ln1.g; ru.b = e->dec[0].ln1.b;
-    int site = 0;
-    if (e->overlap) (void)hipMemsetAsync(e->ru_ready, 0, 64 * sizeof(unsigned), st);
-    // the pending row update either runs as its own launch or rides inside the next GEMM's launch
-    // the weight image a decode GEMM streams (bf16 fragments, or the fp8 image)
-    auto wimg = [&](const Linear& l, const void** ptr, size_t* bytes) {
-        *ptr = l.fp8 ? (const void*)l.Wq : (const void*)l.Wp;
-        *bytes = (size_t)l.Npad * l.Kpad * (l.fp8 ? 1 : 2);
+    auto row_update = [&]() {
+        if (e->only_skinny) return;
+        prof_mark(e, PK_ROWLN, st);
+        launch_row_update_ln(ru, st);
     };
-    const Linear* next_gemm = &e->dec[0].c_attn;      // what follows the pending row update
-    auto attach = [&](SkinnyArgs& a) {
-        ru.pf_ptr = nullptr; ru.pf_bytes = 0; ru.pf_blocks = 0;
-        if (e->prefetch && next_gemm && !e->overlap) {
-            // 32 CUs do the row update; the others stream (up to ~32 MB of) the following GEMM's weights meanwhile
-            wimg(*next_gemm, &ru.pf_ptr, &ru.pf_bytes);
-            ru.pf_blocks = e->num_cus > B ? e->num_cus - B : 0;
-            const size_t cap = (size_t)ru.pf_blocks * e->prefetch_kb * 1024;       // the head of the image: the first tiles hit
-            if (ru.pf_bytes > cap) ru.pf_bytes = cap;
-            if (ru.pf_blocks == 0) ru.pf_ptr = nullptr;
-        }
-        if (!e->overlap) { if (!e->only_skinny) { prof_mark(e, PK_ROWLN, st); launch_row_update_ln(ru, st); } return; }
-        a.ru_M = B; a.ru_ws = ru.ws; a.ru_splitk = ru.splitk; a.ru_ldws = ru.ldws; a.ru_rows_ws = ru.rows_ws;
-        a.ru_bias = ru.bias; a.ru_h = ru.h; a.ru_ldh = ru.ldh; a.ru_wte = ru.wte; a.ru_wpe = ru.wpe;
-        a.ru_tokens = ru.tokens; a.ru_positions = ru.positions; a.ru_g = ru.g; a.ru_b = ru.b; a.ru_eps = ru.eps;
-        a.ru_ready = e->ru_ready + (site++); a.ru_err = e->ru_err;
-    };
-    for (int i = 0; i < c.n_layer; ++i) {
-        DecLayer& L = e->dec[i];
-        {   // c_attn (+ the row update that produces its input: embedding or previous layer's down-proj)
-            SkinnyArgs a;
-            memset(&a, 0, sizeof(a));
-            a.xp = e->xp_a; a.Wp = L.c_attn.Wp; a.Wq = L.c_attn.Wq; a.wscale = L.c_attn.wscale; a.MT = MT; a.Npad = L.c_attn.Npad; a.K = L.c_attn.Kpad;
-            a.splitk = L.c_attn.splitk; a.out_mode = SK_OUT_PARTIAL; a.ws = wsA; a.ldws = e->ldws; a.N = L.c_attn.N;
-            attach(a);
-            prof_mark(e, PK_SKINNY, st);
-            launch_gemm_skinny(a, st);
-        }
-        AttnDecodeArgs ad;
-        memset(&ad, 0, sizeof(ad));
-        ad.ws = wsA; ad.splitk = L.c_attn.splitk; ad.ldws = e->ldws; ad.rows_ws = MT * 32; ad.bias = L.c_attn.bias;
-        ad.pool_layer = e->kv_pool + (size_t)i * e->layer_stride; ad.block_table = e->block_table;
-        ad.max_pages = e->pages_per_seq; ad.positions = e->positions; ad.out_xp = e->xp_attn; ad.out_KS = D / 16;
-        ad.window = c.sliding_window;
-        ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
-        ad.part = e->attn_part; ad.counters = e->attn_cnt;
-        ad.max_splits = attn_max_splits(e);
-        ad.n_kv = e->nkv; ad.kv_head_stride = e->kv_head_stride; ad.rope_cos = e->rope_cos; ad.rope_sin = e->rope_sin;
-        if (e->prefetch && ad.max_splits < 16) {
-            wimg(L.c_proj, &ad.pf_ptr, &ad.pf_bytes);
-            const size_t cap = (size_t)(16 - ad.max_splits) * B * e->nkv * e->prefetch_kb * 1024;
-            if (ad.pf_bytes > cap) ad.pf_bytes = cap;
-        }
-        if (!e->only_skinny) { prof_mark(e, PK_ATTN, st); launch_attn_decode(ad, st); }
-        {   // attention output projection -> slabs
-            SkinnyArgs a;
-            memset(&a, 0, sizeof(a));
-            a.xp = e->xp_attn; a.Wp = L.c_proj.Wp; a.Wq = L.c_proj.Wq; a.wscale = L.c_proj.wscale; a.MT = MT; a.Npad = L.c_proj.Npad; a.K = L.c_proj.Kpad;
-            a.splitk = L.c_proj.splitk; a.out_mode = SK_OUT_PARTIAL; a.ws = wsB; a.ldws = e->ldws; a.N = L.c_proj.N;
-            prof_mark(e, PK_SKINNY, st);
-            launch_gemm_skinny(a, st);
-        }
-        ru.ws = wsB; ru.splitk = L.c_proj.splitk; ru.bias = L.c_proj.bias; ru.g = L.ln2.g; ru.b = L.ln2.b;
-        next_gemm = &L.c_fc;
-        {   // c_fc (+ row update: bias, residual, LN2), GELU epilogue
-            SkinnyArgs a;
-            memset(&a, 0, sizeof(a));
-            a.xp = e->xp_a; a.Wp = L.c_fc.Wp; a.Wq = L.c_fc.Wq; a.wscale = L.c_fc.wscale; a.bias = L.c_fc.bias; a.MT = MT; a.Npad = L.c_fc.Npad; a.K = L.c_fc.Kpad;
-            a.splitk = 1; a.out_mode = SK_OUT_PACKED_ACT; a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16;
-            a.N = L.c_fc.N;
-            attach(a);
-            prof_mark(e, PK_SKINNY, st);
-            launch_gemm_skinny(a, st);
-        }
-        {   // down projection -> slabs
-            SkinnyArgs a;
-            memset(&a, 0, sizeof(a));
-            a.xp = e->xp_mlp; a.Wp = L.c_proj2.Wp; a.Wq = L.c_proj2.Wq; a.wscale = L.c_proj2.wscale; a.MT = MT; a.Npad = L.c_proj2.Npad; a.K = L.c_proj2.Kpad;
-            a.splitk = L.c_proj2.splitk; a.out_mode = SK_OUT_PARTIAL; a.ws = wsB; a.ldws = e->ldws; a.N = L.c_proj2.N;
-            prof_mark(e, PK_SKINNY, st);
-            launch_gemm_skinny(a, st);
-        }
-        const LNp& nxt = (i + 1 < c.n_layer) ? e->dec[i + 1].ln1 : e->ln_f;
-        ru.ws = wsB; ru.splitk = L.c_proj2.splitk; ru.bias = L.c_proj2.bias; ru.g = nxt.g; ru.b = nxt.b;
-        next_gemm = (i + 1 < c.n_layer) ? &e->dec[i + 1].c_attn : &e->lm_head;
-    }
-    {   // lm_head (+ the last row update: bias, residual, ln_f)
+    auto skinny = [&](const bf16_t* xp, const Linear& l, int out_mode, float* ws) {
         SkinnyArgs a;
         memset(&a, 0, sizeof(a));
-        a.xp = e->xp_a; a.Wp = e->lm_head.Wp; a.Wq = e->lm_head.Wq; a.wscale = e->lm_head.wscale; a.MT = MT; a.Npad = e->lm_head.Npad; a.K = e->lm_head.Kpad;
-        a.splitk = 1; a.out_mode = SK_OUT_F32; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1;
-        a.N = e->lm_head.N;
-        attach(a);
+        a.xp = xp; a.Wp = l.Wp; a.Wq = l.Wq; a.wscale = l.wscale; a.MT = MT; a.Npad = l.Npad; a.K = l.Kpad; a.N = l.N;
+        a.out_mode = out_mode;
+        if (out_mode == SK_OUT_PARTIAL) { a.splitk = l.splitk; a.ws = ws; a.ldws = e->ldws; }
+        else if (out_mode == SK_OUT_PACKED_ACT) { a.splitk = 1; a.bias = l.bias; a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16; }
+        else { a.splitk = 1; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1; }
         prof_mark(e, PK_SKINNY, st);
         launch_gemm_skinny(a, st);
-    }
-    prof_mark(e, PK_SAMPLE, st);      // closes the lm_head interval; whatever follows is sampling
-}
-
-// full-K pipeline (SV_DECODE_PIPE=cols): 5 launches per layer, no split-K slabs, no hand-offs (decode_gemm.hip)
-//   c_attn [LN1 prologue, +bias -> q|k|v rows] | attention | c_proj [+bias +residual -> h] | c_fc [LN2 prologue, +bias, GELU]
-//   | c_proj [+bias +residual -> h] ; lm_head [ln_f prologue].  h lives in fragment order (e->h_xp).
-static void decode_forward_cols(sv_engine* e, int B, hipStream_t st) {
-    const sv_config& c = e->cfg;
-    const int D = c.hidden, dh = e->dh, F = c.n_inner, MT = (B + 31) / 32;
-    if (!e->only_skinny) {
-        EmbedRowsArgs er;
-        memset(&er, 0, sizeof(er));
-        er.wte = e->wte; er.wpe = e->wpe; er.tokens = e->cur_tok; er.positions = e->positions;
-        er.h_xp = e->h_xp; er.stats = e->ln_stats; er.M = B; er.D = D;
-        prof_mark(e, PK_ROWLN, st);
-        launch_embed_rows(er, st);
-    }
+    };
     for (int i = 0; i < c.n_layer; ++i) {
         DecLayer& L = e->dec[i];
-        {   // c_attn over LN1(h) -> q|k|v rows (bf16, bias added)
-            ColsArgs a;
-            memset(&a, 0, sizeof(a));
-            a.xp = e->h_xp; a.Wp = L.c_attn.Wp; a.bias = L.c_attn.bias; a.MT = MT; a.N = L.c_attn.N; a.K = L.c_attn.Kpad;
-            a.cpb = L.c_attn.cpb; a.ln_g = L.ln1.g; a.ln_b = L.ln1.b; a.ln_eps = c.ln_eps;
-            a.out_mode = CO_ROWMAJOR; a.out_rm = e->qkv_rm; a.ld_rm = e->ldq;
-            prof_mark(e, PK_SKINNY, st);
-            launch_gemm_cols(a, st);
-        }
+        row_update();                                            // embedding or the previous layer's down-proj -> LN1(h)
+        skinny(e->xp_a, L.c_attn, SK_OUT_PARTIAL, wsA);
         if (!e->only_skinny) {
             AttnDecodeArgs ad;
             memset(&ad, 0, sizeof(ad));
-            ad.qkv = e->qkv_rm; ad.ld_qkv = e->ldq;
+            ad.ws = wsA; ad.splitk = L.c_attn.splitk; ad.ldws = e->ldws; ad.rows_ws = MT * 32; ad.bias = L.c_attn.bias;
             ad.pool_layer = e->kv_pool + (size_t)i * e->layer_stride; ad.block_table = e->block_table;
-            ad.max_pages = e->pages_per_seq; ad.positions = e->positions; ad.out_xp = e->xp_attn; ad.out_KS = (c.n_head * dh) / 16;
+            ad.max_pages = e->pages_per_seq; ad.positions = e->positions; ad.out_xp = e->xp_attn; ad.out_KS = D / 16;
             ad.window = c.sliding_window;
             ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
             ad.part = e->attn_part; ad.counters = e->attn_cnt;
@@ -1127,48 +896,17 @@ static void decode_forward_cols(sv_engine* e, int B, hipStream_t st) {
             prof_mark(e, PK_ATTN, st);
             launch_attn_decode(ad, st);
         }
-        {   // attention output projection, + bias + residual -> h
-            ColsArgs a;
-            memset(&a, 0, sizeof(a));
-            a.xp = e->xp_attn; a.Wp = L.c_proj.Wp; a.bias = L.c_proj.bias; a.MT = MT; a.N = L.c_proj.N; a.K = L.c_proj.Kpad;
-            a.cpb = L.c_proj.cpb; a.out_mode = CO_RESID_XP; a.h_xp = e->h_xp; a.out_KS = D / 16;
-            prof_mark(e, PK_SKINNY, st);
-            launch_gemm_cols(a, st);
-        }
-        {   // c_fc over LN2(h), bias + GELU -> fragment-order activations
-            SkinnyLnArgs a;
-            memset(&a, 0, sizeof(a));
-            a.xp = e->h_xp; a.Wp = L.c_fc.Wp; a.bias = L.c_fc.bias; a.MT = MT; a.Npad = L.c_fc.Npad; a.N = L.c_fc.N; a.K = L.c_fc.Kpad;
-            a.ln_g = L.ln2.g; a.ln_b = L.ln2.b; a.ln_eps = c.ln_eps;
-            a.out_mode = SK_OUT_PACKED_ACT; a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16;
-            prof_mark(e, PK_SKINNY, st);
-            launch_gemm_skinny_ln(a, st);
-        }
-        {   // down projection, + bias + residual -> h
-            ColsArgs a;
-            memset(&a, 0, sizeof(a));
-            a.xp = e->xp_mlp; a.Wp = L.c_proj2.Wp; a.bias = L.c_proj2.bias; a.MT = MT; a.N = L.c_proj2.N; a.K = L.c_proj2.Kpad;
-            a.cpb = L.c_proj2.cpb; a.out_mode = CO_RESID_XP; a.h_xp = e->h_xp; a.out_KS = D / 16;
-            prof_mark(e, PK_SKINNY, st);
-            launch_gemm_cols(a, st);
-        }
+        skinny(e->xp_attn, L.c_proj, SK_OUT_PARTIAL, wsB);
+        ru.ws = wsB; ru.splitk = L.c_proj.splitk; ru.bias = L.c_proj.bias; ru.g = L.ln2.g; ru.b = L.ln2.b;
+        row_update();                                            // + bias + residual, LN2
+        skinny(e->xp_a, L.c_fc, SK_OUT_PACKED_ACT, nullptr);
+        skinny(e->xp_mlp, L.c_proj2, SK_OUT_PARTIAL, wsB);
+        const LNp& nxt = (i + 1 < c.n_layer) ? e->dec[i + 1].ln1 : e->ln_f;
+        ru.ws = wsB; ru.splitk = L.c_proj2.splitk; ru.bias = L.c_proj2.bias; ru.g = nxt.g; ru.b = nxt.b;
     }
-    {   // lm_head over ln_f(h): fp32 logits rounded to bf16 values
-        SkinnyLnArgs a;
-        memset(&a, 0, sizeof(a));
-        a.xp = e->h_xp; a.Wp = e->lm_head.Wp; a.MT = MT; a.Npad = e->lm_head.Npad; a.N = e->lm_head.N; a.K = e->lm_head.Kpad;
-        a.ln_g = e->ln_f.g; a.ln_b = e->ln_f.b; a.ln_eps = c.ln_eps;
-        a.out_mode = SK_OUT_F32; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1;
-        prof_mark(e, PK_SKINNY, st);
-        launch_gemm_skinny_ln(a, st);
-    }
-    prof_mark(e, PK_SAMPLE, st);
-}
-
-static void decode_forward(sv_engine* e, int B, hipStream_t st) {
-    if (e->cols_decode) decode_forward_cols(e, B, st);
-    else if (e->fused_decode) decode_forward_fused(e, B, st);
-    else decode_forward_slabs(e, B, st);
+    row_update();                                                // + bias + residual, ln_f
+    skinny(e->xp_a, e->lm_head, SK_OUT_F32, nullptr);
+    prof_mark(e, PK_SAMPLE, st);      // closes the lm_head interval; whatever follows is sampling
 }
 
 static int check_ready(sv_engine* e) {
@@ -1530,11 +1268,9 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
         // stream, the benchmark), so a short request does not pay a 172-node capture + instantiate; a call with other
         // parameters replaces it.  Owned by the engine: no early return below can leak it.
         char key[256];
-        snprintf(key, sizeof(key), "B%d|n%d|ds%d|T%a|p%a|k%d|seed%llu|eos%d|pad%d|ns%d|rp%a|mn%d|pipe%d%d%d|mt2%s", B, max_new, sp->do_sample,
+        snprintf(key, sizeof(key), "B%d|n%d|ds%d|T%a|p%a|k%d|seed%llu|eos%d|pad%d|ns%d|rp%a|mn%d", B, max_new, sp->do_sample,
                  sp->temperature, sp->top_p, sp->top_k, (unsigned long long)sp->seed, sp->eos_token_id, sp->pad_token_id, sp->n_stop,
-                 sp->repetition_penalty, sp->min_new_tokens, (int)e->cols_decode, (int)e->fused_decode, e->overlap,
-                 (std::string(getenv("SV_SKINNY_MT2") ? getenv("SV_SKINNY_MT2") : "") + "|d" +
-                  (getenv("SV_SKINNY_DEPTH") ? getenv("SV_SKINNY_DEPTH") : "")).c_str());       // kernel-choice switches are part of what was captured
+                 sp->repetition_penalty, sp->min_new_tokens);
         if (e->gen_gexec && e->gen_graph_key == key) {
             gexec = e->gen_gexec;
         } else {
@@ -1580,14 +1316,6 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
     HIPCHECK(hipMemcpyAsync(&e->h_flags[1], e->d_nemit, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
     if (e->h_flags[1] >= 1 && e->h_flags[1] <= max_new) SVCHECK(stream_upto(e->h_flags[1]));
-    if (e->overlap && !e->fused_decode) {
-        HIPCHECK(hipMemcpyAsync(&e->h_flags[2], e->ru_err, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIPCHECK(hipStreamSynchronize(st));
-        if (e->h_flags[2]) {
-            HIPCHECK(hipMemsetAsync(e->ru_err, 0, sizeof(int32_t), st));
-            return fail(SV_EHIP, "in-launch row-update hand-off timed out (set SV_DECODE_OVERLAP=0)");
-        }
-    }
     SVCHECK(check_finite_logits(e, st, "sv_generate"));
     const int n_emit = e->h_flags[1];
     if (n_emit < 1 || n_emit > max_new) return fail(SV_EHIP, "generation bookkeeping failed (n_emitted=%d)", n_emit);
@@ -1696,6 +1424,10 @@ extern "C" int sv_cb_admit(sv_engine* e, const void* dev_embeds, int32_t n, int3
         map[i] = s2;
         slots_out[i] = s2;
     }
+    // Device side.  Any failure below rolls the host bookkeeping back (slots, pages) and parks the slots' device state, so a
+    // failed admit leaks nothing and the caller may simply retry: the slots it was told about are NOT in use on error.
+    bool nlive_added = false;
+    const int rc = [&]() -> int {
     for (int i = 0; i < n; ++i) {
         const int s2 = slots[i];
         HIPCHECK(hipMemcpyAsync(e->block_table + (size_t)s2 * e->pages_per_seq, rows.data() + (size_t)i * e->pages_per_seq,
@@ -1707,6 +1439,7 @@ extern "C" int sv_cb_admit(sv_engine* e, const void* dev_embeds, int32_t n, int3
     HIPCHECK(hipMemcpyAsync(e->cb_table_pf, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
     HIPCHECK(hipMemcpyAsync(e->cb_map, map.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, st));
     add_i32_kernel<<<1, 64, 0, st>>>(e->cb_nlive, n, 1);
+    nlive_added = true;
     // prompt pass of the NEW requests only (their pages through cb_table_pf); the live slots keep decoding afterwards
     SVCHECK(prefill_forward(e, (const bf16_t*)dev_embeds, n, S0, st, 0, nullptr, e->cb_table_pf));
     CbStepArgs a;
@@ -1714,6 +1447,30 @@ extern "C" int sv_cb_admit(sv_engine* e, const void* dev_embeds, int32_t n, int3
     launch_cb_step(a, n, st);                              // first token of every new request, from the prefill logits
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(st));                    // the staging vectors above are host temporaries
+    return 0;
+    }();
+    if (rc) {
+        const std::string why = g_err;                      // keep the first error's text
+        (void)hipStreamSynchronize(st);
+        (void)hipGetLastError();
+        std::vector<int32_t> trash(e->pages_per_seq, e->trash_page);
+        for (int i = n - 1; i >= 0; --i) {                  // pages go back in reverse order: the free list is as it was
+            const int s2 = slots[i];
+            for (size_t k = e->cb_pages[s2].size(); k-- > 0;) e->free_pages.push_back(e->cb_pages[s2][k]);
+            e->cb_pages[s2].clear();
+            e->cb_used[s2] = 0;
+            slots_out[i] = -1;
+            // best effort on the device: the slot is dead and its block-table row points at the trash page again
+            (void)hipMemsetAsync(e->cb_slots + s2, 0, sizeof(CbSlot), st);
+            (void)hipMemcpyAsync(e->block_table + (size_t)s2 * e->pages_per_seq, trash.data(), trash.size() * sizeof(int32_t),
+                                 hipMemcpyHostToDevice, st);
+        }
+        if (nlive_added) add_i32_kernel<<<1, 64, 0, st>>>(e->cb_nlive, -n, 1);
+        (void)hipStreamSynchronize(st);
+        (void)hipGetLastError();
+        g_err = why;
+        return rc;
+    }
     return 0;
 }
 
@@ -2037,7 +1794,7 @@ extern "C" int sv_profile_decode_step(sv_engine* e, int32_t B, int32_t iters, do
     out[2 * PK_SAMPLE] = overhead_ms;         // slot 6: time between two back-to-back events with no kernel
     // slot 7: the step's weight-streaming GEMMs alone, back to back between ONE event pair: average
     // dispatch-to-dispatch time per launch (what rocprofv3's kernel trace calls the kernel duration)
-    if (e->cols_decode || (!e->fused_decode && !e->overlap)) {
+    {
         hipEvent_t a, b;
         HIPCHECK(hipEventCreate(&a)); HIPCHECK(hipEventCreate(&b));
         e->only_skinny = true;
@@ -2209,163 +1966,12 @@ extern "C" int sv_op_linear_skinny_fp8(const void* x, const void* W, const void*
     return 0;
 }
 
-extern "C" int sv_op_decode_linear(const void* h, const void* gamma, const void* beta, float eps, const void* W,
-                                   const void* bias, const void* residual, void* y, float* row_stats, int32_t M,
-                                   int32_t N, int32_t K, int32_t splitk, int32_t act, sv_stream stream) {
-    if (!h || !W || !y || M < 1 || N < 4 || N % 4 || K < 32 || K % 32 || splitk < 1 || (K / 16) % splitk)
-        return fail(SV_EINVAL, "sv_op_decode_linear: bad argument");
-    if ((gamma == nullptr) != (beta == nullptr)) return fail(SV_EINVAL, "gamma and beta go together");
-    if (residual && N % 32) return fail(SV_EINVAL, "residual mode needs N %% 32 == 0");
-    hipStream_t st = (hipStream_t)stream;
-    TmpBufs tmp;
-    const int Npad = round_up(N, 32), MT = (M + 31) / 32, R = MT * 32;
-    bf16_t *Wp, *hxp, *oxp, *orm;
-    float* ws; float2 *st_in, *st_out; unsigned* cnt;
-    SVCHECK(tmp.get(&Wp, (size_t)Npad * K));
-    SVCHECK(tmp.get(&hxp, (size_t)R * K));
-    SVCHECK(tmp.get(&oxp, (size_t)R * Npad));
-    SVCHECK(tmp.get(&orm, (size_t)R * Npad));
-    SVCHECK(tmp.get(&ws, (size_t)splitk * R * Npad));
-    SVCHECK(tmp.get(&st_in, (size_t)R * (K / 32)));
-    SVCHECK(tmp.get(&st_out, (size_t)R * (Npad / 32)));
-    SVCHECK(tmp.get(&cnt, (size_t)MT * (Npad / 32)));
-    HIPCHECK(hipMemsetAsync(hxp, 0, (size_t)R * K * 2, st));
-    HIPCHECK(hipMemsetAsync(oxp, 0, (size_t)R * Npad * 2, st));
-    HIPCHECK(hipMemsetAsync(cnt, 0, (size_t)MT * (Npad / 32) * sizeof(unsigned), st));
-    HIPCHECK(hipMemsetAsync(st_in, 0, (size_t)R * (K / 32) * sizeof(float2), st));
-    launch_pack_weight(W, 0, Wp, N, K, Npad, K, st);
-    EmbedRowsArgs er;
-    memset(&er, 0, sizeof(er));
-    er.rows = (const bf16_t*)h; er.ld_rows = K; er.h_xp = hxp; er.stats = st_in; er.M = M; er.D = K;
-    launch_embed_rows(er, st);
-    SkinnyArgs a;
-    memset(&a, 0, sizeof(a));
-    a.xp = hxp; a.Wp = Wp; a.bias = (const bf16_t*)bias; a.MT = MT; a.Npad = Npad; a.K = K; a.splitk = splitk;
-    a.act = act; a.N = N; a.ws = ws; a.ldws = Npad; a.counters = cnt;
-    if (gamma) { a.ln_stats = st_in; a.ln_tiles = K / 32; a.ln_g = (const bf16_t*)gamma; a.ln_b = (const bf16_t*)beta; a.ln_eps = eps; }
-    if (residual) {
-        pack_rows_kernel<<<(M * (N / 8) + 255) / 256, 256, 0, st>>>((const bf16_t*)residual, N, oxp, M, N);
-        a.out_mode = SK_OUT_RESID; a.out_xp = oxp; a.resid_xp = oxp; a.out_KS = Npad / 16; a.stats_out = st_out;
-    } else {
-        a.out_mode = SK_OUT_ROWMAJOR; a.out_rm = orm; a.ld_rm = Npad;
-    }
-    launch_gemm_skinny(a, st);
-    if (residual) {
-        unpack_rows_kernel<<<(M * (N / 8) + 255) / 256, 256, 0, st>>>(oxp, (bf16_t*)y, N, M, N);
-        if (row_stats) sum_stats_kernel<<<(M + 63) / 64, 64, 0, st>>>(st_out, Npad / 32, row_stats, M);
-    } else {
-        HIPCHECK(hipMemcpy2DAsync(y, (size_t)N * 2, orm, (size_t)Npad * 2, (size_t)N * 2, M, hipMemcpyDeviceToDevice, st));
-    }
-    HIPCHECK(hipGetLastError());
-    HIPCHECK(hipStreamSynchronize(st));
-    return 0;
-}
-
-// Micro-benchmark of the decode GEMM kernel alone (HIP events, `iters` back-to-back launches on one
-// stream): mode 0 = fp32 slabs (no epilogue), 1 = bias+act -> fragment order, 3 = bias+residual+stats,
-// 4 = bias -> row-major.  Weights / activations are zero-filled device buffers (bandwidth only).
-extern "C" int sv_bench_decode_linear(int32_t M, int32_t N, int32_t K, int32_t splitk, int32_t ln, int32_t mode,
-                                      int32_t iters, double* avg_us, sv_stream stream) {
-    if (!avg_us || M < 1 || N < 32 || K < 32 || K % 32 || splitk < 1 || (K / 16) % splitk || iters < 1)
-        return fail(SV_EINVAL, "sv_bench_decode_linear: bad argument");
-    hipStream_t st = (hipStream_t)stream;
-    TmpBufs tmp;
-    const int Npad = round_up(N, 32), MT = (M + 31) / 32, R = MT * 32;
-    bf16_t *Wp, *hxp, *oxp, *orm, *gb, *bias;
-    float* ws; float2 *st_in, *st_out; unsigned* cnt;
-    SVCHECK(tmp.get(&Wp, (size_t)Npad * K));
-    SVCHECK(tmp.get(&hxp, (size_t)R * K));
-    SVCHECK(tmp.get(&oxp, (size_t)R * Npad));
-    SVCHECK(tmp.get(&orm, (size_t)R * Npad));
-    SVCHECK(tmp.get(&gb, (size_t)2 * K));
-    SVCHECK(tmp.get(&bias, (size_t)Npad));
-    SVCHECK(tmp.get(&ws, (size_t)splitk * R * Npad));
-    SVCHECK(tmp.get(&st_in, (size_t)R * (K / 32)));
-    SVCHECK(tmp.get(&st_out, (size_t)R * (Npad / 32)));
-    SVCHECK(tmp.get(&cnt, (size_t)MT * (Npad / 32)));
-    HIPCHECK(hipMemsetAsync(Wp, 0, (size_t)Npad * K * 2, st));
-    HIPCHECK(hipMemsetAsync(hxp, 0, (size_t)R * K * 2, st));
-    HIPCHECK(hipMemsetAsync(oxp, 0, (size_t)R * Npad * 2, st));
-    HIPCHECK(hipMemsetAsync(gb, 0, (size_t)2 * K * 2, st));
-    HIPCHECK(hipMemsetAsync(bias, 0, (size_t)Npad * 2, st));
-    HIPCHECK(hipMemsetAsync(cnt, 0, (size_t)MT * (Npad / 32) * sizeof(unsigned), st));
-    HIPCHECK(hipMemsetAsync(st_in, 0, (size_t)R * (K / 32) * sizeof(float2), st));
-    SkinnyArgs a;
-    memset(&a, 0, sizeof(a));
-    a.xp = hxp; a.Wp = Wp; a.bias = bias; a.MT = MT; a.Npad = Npad; a.K = K; a.splitk = splitk;
-    a.act = mode == 1 ? ACT_GELU_TANH : ACT_NONE; a.N = N; a.ws = ws; a.ldws = Npad; a.counters = cnt; a.out_mode = mode;
-    if (ln) { a.ln_stats = st_in; a.ln_tiles = K / 32; a.ln_g = gb; a.ln_b = gb + K; a.ln_eps = 1e-5f; }
-    a.out_xp = oxp; a.resid_xp = oxp; a.out_KS = Npad / 16; a.stats_out = st_out; a.out_rm = orm; a.ld_rm = Npad;
-    a.out_f32 = ws; a.ldo = Npad;
-    hipEvent_t e0, e1;
-    HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) launch_gemm_skinny(a, st);
-    HIPCHECK(hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i) launch_gemm_skinny(a, st);
-    HIPCHECK(hipEventRecord(e1, st));
-    HIPCHECK(hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIPCHECK(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    *avg_us = (double)ms * 1e3 / iters;
-    HIPCHECK(hipGetLastError());
-    return 0;
-}
-
-// the full-K decode GEMMs on their own (decode_gemm.hip).  Row-major in, row-major out; packing is done here.
-//   sv_op_decode_cols:      y[M,N] = LN_opt(x)[M,K] . W^T + bias  (+ residual -> bf16 rows h = bf(res + bf(.)));
-//                           y is bf16 [M][N], or fp32 when out_f32 != 0 (no residual then)
-//   sv_op_decode_skinny_ln: y[M,N] = act(LN(x) . W^T + bias) as bf16 rows, or (out_f32) fp32 rows rounded to bf16 values, no bias
-extern "C" int sv_op_decode_cols(const void* x, const void* gamma, const void* beta, float eps, const void* W, const void* bias,
-                                 const void* residual, void* y, int32_t M, int32_t N, int32_t K, int32_t cpb, int32_t out_f32,
-                                 sv_stream stream) {
-    if (!x || !W || !y || M < 1 || N < 1 || K < 32 || K % 32) return fail(SV_EINVAL, "sv_op_decode_cols: bad argument (K %% 32 == 0 required)");
-    if ((gamma == nullptr) != (beta == nullptr)) return fail(SV_EINVAL, "gamma and beta go together");
-    if (residual && (out_f32 || N % 16)) return fail(SV_EINVAL, "residual mode writes bf16 rows and needs N %% 16 == 0");
-    if (cpb == 0) cpb = cols_pick_cpb(N);
-    if (cpb < 1 || cpb > 16) return fail(SV_EINVAL, "cpb must be 1..16 (0 = automatic)");
-    if (int ar = init_decode_gemm_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
-    hipStream_t st = (hipStream_t)stream;
-    TmpBufs tmp;
-    const int Npad = round_up(N, 32), MT = (M + 31) / 32, R = MT * 32;
-    bf16_t *Wp, *xp, *hxp, *orm;
-    float* of;
-    SVCHECK(tmp.get(&Wp, (size_t)Npad * K));
-    SVCHECK(tmp.get(&xp, (size_t)R * K));
-    SVCHECK(tmp.get(&hxp, (size_t)R * Npad));
-    SVCHECK(tmp.get(&orm, (size_t)R * Npad));
-    SVCHECK(tmp.get(&of, (size_t)R * Npad));
-    HIPCHECK(hipMemsetAsync(xp, 0, (size_t)R * K * 2, st));
-    HIPCHECK(hipMemsetAsync(hxp, 0, (size_t)R * Npad * 2, st));
-    launch_pack_weight(W, 0, Wp, N, K, Npad, K, st);
-    pack_rows_kernel<<<(M * (K / 8) + 255) / 256, 256, 0, st>>>((const bf16_t*)x, K, xp, M, K);
-    ColsArgs a;
-    memset(&a, 0, sizeof(a));
-    a.xp = xp; a.Wp = Wp; a.bias = (const bf16_t*)bias; a.MT = MT; a.N = N; a.K = K; a.cpb = cpb;
-    a.ln_g = (const bf16_t*)gamma; a.ln_b = (const bf16_t*)beta; a.ln_eps = eps;
-    if (residual) {
-        pack_rows_kernel<<<(M * (N / 8) + 255) / 256, 256, 0, st>>>((const bf16_t*)residual, N, hxp, M, N);
-        a.out_mode = CO_RESID_XP; a.h_xp = hxp; a.out_KS = N / 16;
-    } else if (out_f32) {
-        a.out_mode = CO_F32; a.out_f32 = of; a.ldo = Npad;
-    } else {
-        a.out_mode = CO_ROWMAJOR; a.out_rm = orm; a.ld_rm = Npad;
-    }
-    if (launch_gemm_cols(a, st)) return fail(SV_ENOTSUP, "sv_op_decode_cols: no kernel for K=%d", K);
-    if (residual) unpack_rows_kernel<<<(M * (N / 8) + 255) / 256, 256, 0, st>>>(hxp, (bf16_t*)y, N, M, N);
-    else if (out_f32) HIPCHECK(hipMemcpy2DAsync(y, (size_t)N * 4, of, (size_t)Npad * 4, (size_t)N * 4, M, hipMemcpyDeviceToDevice, st));
-    else HIPCHECK(hipMemcpy2DAsync(y, (size_t)N * 2, orm, (size_t)Npad * 2, (size_t)N * 2, M, hipMemcpyDeviceToDevice, st));
-    HIPCHECK(hipGetLastError());
-    HIPCHECK(hipStreamSynchronize(st));
-    return 0;
-}
-
-extern "C" int sv_op_decode_skinny_ln(const void* x, const void* gamma, const void* beta, float eps, const void* W, const void* bias,
-                                      void* y, int32_t M, int32_t N, int32_t K, int32_t act, int32_t out_f32, sv_stream stream) {
-    if (!x || !W || !y || !gamma || !beta || M < 1 || N < 1 || K < 32 || K % 32)
-        return fail(SV_EINVAL, "sv_op_decode_skinny_ln: bad argument");
+// the decode GEMM's two fused epilogues on their own (split-K 1): out_f32 == 0: y[M,N] = act(bf16(x W^T + bias)) as bf16 rows
+// (c_fc: N %% 8 == 0); out_f32 != 0: fp32 rows of x W^T rounded to bf16 values, no bias (lm_head)
+extern "C" int sv_op_linear_skinny_epi(const void* x, const void* W, const void* bias, void* y, int32_t M, int32_t N, int32_t K,
+                                       int32_t act, int32_t out_f32, sv_stream stream) {
+    if (!x || !W || !y || M < 1 || N < 1 || K < 16 || K % 16) return fail(SV_EINVAL, "sv_op_linear_skinny_epi: bad argument");
     if (!out_f32 && N % 8) return fail(SV_EINVAL, "bf16 output needs N %% 8 == 0");
-    if (int ar = init_decode_gemm_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
     hipStream_t st = (hipStream_t)stream;
     TmpBufs tmp;
     const int Npad = round_up(N, 32), MT = (M + 31) / 32, R = MT * 32;
@@ -2378,13 +1984,12 @@ extern "C" int sv_op_decode_skinny_ln(const void* x, const void* gamma, const vo
     HIPCHECK(hipMemsetAsync(xp, 0, (size_t)R * K * 2, st));
     launch_pack_weight(W, 0, Wp, N, K, Npad, K, st);
     pack_rows_kernel<<<(M * (K / 8) + 255) / 256, 256, 0, st>>>((const bf16_t*)x, K, xp, M, K);
-    SkinnyLnArgs a;
+    SkinnyArgs a;
     memset(&a, 0, sizeof(a));
-    a.xp = xp; a.Wp = Wp; a.bias = (const bf16_t*)bias; a.MT = MT; a.Npad = Npad; a.N = N; a.K = K;
-    a.ln_g = (const bf16_t*)gamma; a.ln_b = (const bf16_t*)beta; a.ln_eps = eps; a.act = act;
+    a.xp = xp; a.Wp = Wp; a.MT = MT; a.Npad = Npad; a.K = K; a.splitk = 1; a.N = N;
     if (out_f32) { a.out_mode = SK_OUT_F32; a.out_f32 = of; a.ldo = Npad; a.round_bf16 = 1; }
-    else { a.out_mode = SK_OUT_PACKED_ACT; a.out_xp = oxp; a.out_KS = Npad / 16; }
-    if (launch_gemm_skinny_ln(a, st)) return fail(SV_ENOTSUP, "sv_op_decode_skinny_ln: no kernel for K=%d", K);
+    else { a.out_mode = SK_OUT_PACKED_ACT; a.bias = (const bf16_t*)bias; a.act = act; a.out_xp = oxp; a.out_KS = Npad / 16; }
+    launch_gemm_skinny(a, st);
     if (out_f32) HIPCHECK(hipMemcpy2DAsync(y, (size_t)N * 4, of, (size_t)Npad * 4, (size_t)N * 4, M, hipMemcpyDeviceToDevice, st));
     else unpack_rows_kernel<<<(M * (N / 8) + 255) / 256, 256, 0, st>>>(oxp, (bf16_t*)y, N, M, N);
     HIPCHECK(hipGetLastError());
@@ -2392,48 +1997,38 @@ extern "C" int sv_op_decode_skinny_ln(const void* x, const void* gamma, const vo
     return 0;
 }
 
-// micro-benchmark of the two kernels (pseudo-random weights, HIP events over `iters` back-to-back launches).
-// kind 0: gemm_cols row-major out; 1: gemm_cols + LayerNorm prologue; 2: gemm_cols bias + residual; 3: skinny_ln GELU; 4: skinny_ln fp32
-extern "C" int sv_bench_decode_gemm(int32_t M, int32_t N, int32_t K, int32_t kind, int32_t cpb, int32_t iters, double* avg_us,
-                                    sv_stream stream) {
-    if (!avg_us || M < 1 || N < 32 || K < 32 || K % 32 || iters < 1 || kind < 0 || kind > 4) return fail(SV_EINVAL, "sv_bench_decode_gemm: bad argument");
-    if (int ar = init_decode_gemm_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
+// Micro-benchmark of the decode GEMM kernel alone (HIP events, `iters` back-to-back launches on one stream):
+// mode 0 = fp32 slabs (split-K `splitk`), 1 = bias + GELU -> fragment order, 2 = fp32 rows rounded to bf16 values (lm_head).
+// Weights / activations are zero-filled device buffers (bandwidth only).  NOTE: back-to-back launches of ONE GEMM re-read
+// the same weights, so anything below ~200 MB is served by the Infinity Cache / L2 -- an upper bound, not the in-situ time.
+extern "C" int sv_bench_decode_linear(int32_t M, int32_t N, int32_t K, int32_t splitk, int32_t mode, int32_t iters, double* avg_us,
+                                      sv_stream stream) {
+    if (!avg_us || M < 1 || N < 32 || K < 32 || K % 32 || splitk < 1 || (K / 16) % splitk || iters < 1 || mode < 0 || mode > 2)
+        return fail(SV_EINVAL, "sv_bench_decode_linear: bad argument");
+    if (mode != 0 && splitk != 1) return fail(SV_EINVAL, "sv_bench_decode_linear: modes 1 and 2 need splitk == 1");
     hipStream_t st = (hipStream_t)stream;
     TmpBufs tmp;
     const int Npad = round_up(N, 32), MT = (M + 31) / 32, R = MT * 32;
-    if (cpb == 0) cpb = cols_pick_cpb(N);
-    bf16_t *Wp, *xp, *hxp, *orm, *gb, *bias;
-    float* of;
+    bf16_t *Wp, *xp, *oxp, *bias;
+    float* ws;
     SVCHECK(tmp.get(&Wp, (size_t)Npad * K));
     SVCHECK(tmp.get(&xp, (size_t)R * K));
-    SVCHECK(tmp.get(&hxp, (size_t)R * Npad));
-    SVCHECK(tmp.get(&orm, (size_t)R * Npad));
-    SVCHECK(tmp.get(&of, (size_t)R * Npad));
-    SVCHECK(tmp.get(&gb, (size_t)2 * K));
+    SVCHECK(tmp.get(&oxp, (size_t)R * Npad));
     SVCHECK(tmp.get(&bias, (size_t)Npad));
-    fill_random_bf16_kernel<<<4096, 256, 0, st>>>(Wp, (size_t)Npad * K, 2u);
-    fill_random_bf16_kernel<<<256, 256, 0, st>>>(xp, (size_t)R * K, 1u);
-    fill_random_bf16_kernel<<<64, 256, 0, st>>>(gb, (size_t)2 * K, 5u);
-    fill_random_bf16_kernel<<<64, 256, 0, st>>>(bias, (size_t)Npad, 3u);
-    HIPCHECK(hipMemsetAsync(hxp, 0, (size_t)R * Npad * 2, st));
-    ColsArgs a;
+    SVCHECK(tmp.get(&ws, (size_t)splitk * R * Npad));
+    HIPCHECK(hipMemsetAsync(Wp, 0, (size_t)Npad * K * 2, st));
+    HIPCHECK(hipMemsetAsync(xp, 0, (size_t)R * K * 2, st));
+    HIPCHECK(hipMemsetAsync(bias, 0, (size_t)Npad * 2, st));
+    SkinnyArgs a;
     memset(&a, 0, sizeof(a));
-    a.xp = xp; a.Wp = Wp; a.bias = bias; a.MT = MT; a.N = N; a.K = K; a.cpb = cpb;
-    if (kind == 1) { a.ln_g = gb; a.ln_b = gb + K; a.ln_eps = 1e-5f; }
-    if (kind == 2) { a.out_mode = CO_RESID_XP; a.h_xp = hxp; a.out_KS = Npad / 16; }
-    else { a.out_mode = CO_ROWMAJOR; a.out_rm = orm; a.ld_rm = Npad; }
-    SkinnyLnArgs b;
-    memset(&b, 0, sizeof(b));
-    b.xp = xp; b.Wp = Wp; b.bias = bias; b.MT = MT; b.Npad = Npad; b.N = N; b.K = K; b.ln_g = gb; b.ln_b = gb + K; b.ln_eps = 1e-5f;
-    if (kind == 3) { b.out_mode = SK_OUT_PACKED_ACT; b.act = ACT_GELU_TANH; b.out_xp = hxp; b.out_KS = Npad / 16; }
-    else { b.out_mode = SK_OUT_F32; b.out_f32 = of; b.ldo = Npad; b.round_bf16 = 1; }
-    auto once = [&]() { return kind <= 2 ? launch_gemm_cols(a, st) : launch_gemm_skinny_ln(b, st); };
-    if (once()) return fail(SV_ENOTSUP, "sv_bench_decode_gemm: no kernel for this shape");
+    a.xp = xp; a.Wp = Wp; a.bias = bias; a.MT = MT; a.Npad = Npad; a.K = K; a.splitk = splitk; a.N = N;
+    a.out_mode = mode; a.act = mode == 1 ? ACT_GELU_TANH : ACT_NONE;
+    a.ws = ws; a.ldws = Npad; a.out_xp = oxp; a.out_KS = Npad / 16; a.out_f32 = ws; a.ldo = Npad; a.round_bf16 = 1;
     hipEvent_t e0, e1;
     HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) once();
+    for (int i = 0; i < 3; ++i) launch_gemm_skinny(a, st);
     HIPCHECK(hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i) once();
+    for (int i = 0; i < iters; ++i) launch_gemm_skinny(a, st);
     HIPCHECK(hipEventRecord(e1, st));
     HIPCHECK(hipEventSynchronize(e1));
     float ms = 0.f;

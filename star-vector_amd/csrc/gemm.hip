@@ -224,7 +224,7 @@ __device__ __forceinline__ void epi_flush_strip(const char* strip, const GemmArg
     }
 }
 
-template <typename OutT, int VAR>
+template <typename OutT>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -236,8 +236,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     // FETCH_SIZE of this kernel: 273 MB per launch against ~80 MB of operands).  Instead each XCD gets a contiguous run of
     // tile ids and walks it in bands of 8 m-tiles, m fastest: the 64 tiles resident on an XCD (32 CUs x 2 blocks) form an
     // 8 x 8 patch that shares 8 activation and 8 weight tiles through that XCD's L2.
-    int tm = blockIdx.y, tn = blockIdx.x;
-    if (!p.plain_order) {
+    int tm, tn;
+    {
         const int tiles_n = gridDim.x, tiles_m = gridDim.y, T = tiles_m * tiles_n;
         const int id = blockIdx.y * tiles_n + blockIdx.x;
         const int q = T >> 3, rem = T & 7, xcd = id & 7, loc = id >> 3;
@@ -309,7 +309,6 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
                 xf[s][mt] = *reinterpret_cast<const bf16x8*>(base + r * 128 + c * 16);
             }
         }
-        if (VAR == 1) __builtin_amdgcn_sched_barrier(0);      // keep the 16 ds_reads ahead of the MFMAs
 #pragma unroll
         for (int s = 0; s < 4; ++s)
 #pragma unroll
@@ -329,7 +328,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
             bq[nt][rg] = (p.bias && n < p.N) ? *reinterpret_cast<const uint2*>(p.bias + n) : make_uint2(0u, 0u);
         }
     if constexpr (sizeof(OutT) == 2) {
-        if (!p.epi_regs && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.R || (p.ldr & 7) == 0)) {
+        if ((p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.R || (p.ldr & 7) == 0)) {
             // ---- epilogue through LDS (see epi_flush_strip): park the wave's 64 x 64 values as bf16, flush row-contiguous
             __syncthreads();                                   // every wave has read its last K-tile fragments
             char* strip = smem + wave * (64 * EPI_ROW_BYTES);
@@ -453,7 +452,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 
 #define G2_BARRIER() asm volatile("s_barrier" ::: "memory")
 
-template <typename OutT, int SCHED>
+template <typename OutT>
 __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p, int tiles_m, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -557,7 +556,6 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p, int tiles_m, i
     G2_BARRIER();
     if (wr == 1) G2_BARRIER();                            // group B runs one barrier behind group A
     read_x(x0, smem);                                     // X0 of K-tile 0 (later tiles: read in phase 3 of the tile before)
-    if constexpr (SCHED >= 3) { read_x(x1, smem + G2_HALF); read_w(w0, smem + 2 * G2_HALF); read_w(w1, smem + 3 * G2_HALF); }
 
 #define G2_WAIT(n) do { if (more) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
     for (int t = 0; t < KT; ++t) {
@@ -566,33 +564,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p, int tiles_m, i
         const bool more = t + 1 < KT;
         // one half-tile per phase, X0 W0 W1 X1: every half-tile has ~2 phases to land.  (Staging the whole next K-tile in
         // phases 0-1 instead, 3-4 phases of slack, measured the same: the loop is not waiting on LDS-DMA latency.)
-        // SCHED 2/3/4 are timing ablations only (wrong results): no staging / no LDS reads / neither.
-        constexpr bool ST = SCHED == 0 || SCHED == 3, RD = SCHED == 0 || SCHED == 2;
-        if (RD) read_w(w0, buf + 2 * G2_HALF);
-        if (ST && more) stage(0, t + 1, nbuf);
+        read_w(w0, buf + 2 * G2_HALF);
+        if (more) stage(0, t + 1, nbuf);
         G2_BARRIER(); quad(w0, x0, 0, 0); G2_WAIT(2); G2_BARRIER();
-        if (RD) read_w(w1, buf + 3 * G2_HALF);
-        if (ST && more) stage(1, t + 1, nbuf);
+        read_w(w1, buf + 3 * G2_HALF);
+        if (more) stage(1, t + 1, nbuf);
         G2_BARRIER(); quad(w1, x0, 1, 0); G2_WAIT(2); G2_BARRIER();
-        if (RD) read_x(x1, buf + G2_HALF);
-        if (ST && more) stage(2, t + 1, nbuf);
+        read_x(x1, buf + G2_HALF);
+        if (more) stage(2, t + 1, nbuf);
         G2_BARRIER(); quad(w1, x1, 1, 1); G2_WAIT(2); G2_BARRIER();
         // x0 is free again: fetch X0 of the next K-tile (staged in phase 0, retired by every wave's wait at the
         // end of phase 1) so that no phase issues more than 8 LDS reads
-        if (more) { if (RD) read_x(x0, nbuf); if (ST) stage(3, t + 1, nbuf); }
+        if (more) { read_x(x0, nbuf); stage(3, t + 1, nbuf); }
         G2_BARRIER(); quad(w0, x1, 0, 1); G2_WAIT(2); G2_BARRIER();
     }
 #undef G2_WAIT
     if (wr == 0) G2_BARRIER();                            // both groups execute the same number of barriers
-    if (p.epi_regs == 2) {                                // timing ablation: no epilogue at all (keeps the accumulators alive)
-        float t = 0.f;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 4; ++b) t += acc[a][b][0] + acc[a][b][15];
-        if (t == 123456.789f) ((float*)p.C)[0] = t;
-        return;
-    }
 
     const int half = lane >> 5;
     uint2 bq[2][4];
@@ -604,7 +591,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p, int tiles_m, i
             bq[j][rg] = (p.bias && n < p.N) ? *reinterpret_cast<const uint2*>(p.bias + n) : make_uint2(0u, 0u);
         }
     if constexpr (sizeof(OutT) == 2) {
-        if (p.epi_regs != 1 && (p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.R || (p.ldr & 7) == 0)) {
+        if ((p.N & 7) == 0 && (p.ldc & 7) == 0 && (!p.R || (p.ldr & 7) == 0)) {
             // ---- epilogue through LDS (see epi_flush_strip), two passes of 64 rows per wave (8 waves x 9 KiB strips) ----
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             G2_BARRIER();                                      // both groups are past their last LDS reads
@@ -641,7 +628,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p, int tiles_m, i
                             }
                     }
                     // rows of pass hp: m0 + wr*128 + hp*64 + (mq*32 + lane&31)  (mt = 2*hp + mq  ->  (mt>>1)*64 + (mt&1)*32)
-                    epi_flush_strip(strip, p, p.epi_regs == 3 ? p.M : m0 + wr * 128 + hp * 64, n0 + wc * 64, lane);   // 3: timing ablation, no global traffic
+                    epi_flush_strip(strip, p, m0 + wr * 128 + hp * 64, n0 + wc * 64, lane);
                 }
             };
             switch (p.act) {
@@ -706,17 +693,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p, int tiles_m, i
 
 static void launch_gemm256(const GemmArgs& a, hipStream_t st) {
     const int tiles_m = (a.M + G2_T - 1) / G2_T, tiles_n = (a.N + G2_T - 1) / G2_T;
-    static const int sched = getenv("SV_GEMM_SCHED") ? atoi(getenv("SV_GEMM_SCHED")) : 0;
-    if (a.out_f32)
-        gemm256_kernel<float, 0><<<tiles_m * tiles_n, 512, 2 * G2_BUF, st>>>(a, tiles_m, tiles_n);
-    else if (sched == 2)
-        gemm256_kernel<bf16_t, 2><<<tiles_m * tiles_n, 512, 2 * G2_BUF, st>>>(a, tiles_m, tiles_n);
-    else if (sched == 3)
-        gemm256_kernel<bf16_t, 3><<<tiles_m * tiles_n, 512, 2 * G2_BUF, st>>>(a, tiles_m, tiles_n);
-    else if (sched == 4)
-        gemm256_kernel<bf16_t, 4><<<tiles_m * tiles_n, 512, 2 * G2_BUF, st>>>(a, tiles_m, tiles_n);
-    else
-        gemm256_kernel<bf16_t, 0><<<tiles_m * tiles_n, 512, 2 * G2_BUF, st>>>(a, tiles_m, tiles_n);
+    if (a.out_f32) gemm256_kernel<float><<<tiles_m * tiles_n, 512, 2 * G2_BUF, st>>>(a, tiles_m, tiles_n);
+    else gemm256_kernel<bf16_t><<<tiles_m * tiles_n, 512, 2 * G2_BUF, st>>>(a, tiles_m, tiles_n);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -839,18 +817,11 @@ static double tail_us(int tail, int N, int K) {
 
 static void launch_gemm_tiles(const GemmArgs& a, hipStream_t st, bool force128 = false) {
     dim3 grid((a.N + GB_N - 1) / GB_N, (a.M + GB_M - 1) / GB_M);
-    // SV_GEMM_VARIANT: -1 (default) cost model; 0 / 1 force the 128^2 kernel (plain / sched_barrier); 2 force 256^2
-    const char* ev = getenv("SV_GEMM_VARIANT");          // read per launch: tools flip it inside one process for A/B runs
-    const int variant = ev ? atoi(ev) : -1;
     bool use256 = false;
     (void)tiles_us(a.M, a.N, a.K, a.act, &use256);
-    if (!force128 && (variant == 2 || (variant < 0 && use256))) { launch_gemm256(a, st); return; }
-    if (a.out_f32)
-        gemm_bf16_kernel<float, 0><<<grid, 256, 2 * GB_BUF, st>>>(a);
-    else if (variant == 1)
-        gemm_bf16_kernel<bf16_t, 1><<<grid, 256, 2 * GB_BUF, st>>>(a);
-    else
-        gemm_bf16_kernel<bf16_t, 0><<<grid, 256, 2 * GB_BUF, st>>>(a);
+    if (!force128 && use256) { launch_gemm256(a, st); return; }
+    if (a.out_f32) gemm_bf16_kernel<float><<<grid, 256, 2 * GB_BUF, st>>>(a);
+    else gemm_bf16_kernel<bf16_t><<<grid, 256, 2 * GB_BUF, st>>>(a);
 }
 
 // The dispatch decision for an M x N x K big-M GEMM as plain host arithmetic (exported for the CPU tests through
@@ -881,8 +852,8 @@ static void launch_gemm_config(const GemmArgs& a, hipStream_t st, int kernel256,
     auto tiles = [&](const GemmArgs& g, bool force128) {
         dim3 grid((g.N + GB_N - 1) / GB_N, (g.M + GB_M - 1) / GB_M);
         if (kernel256 && !force128) { launch_gemm256(g, st); return; }
-        if (g.out_f32) gemm_bf16_kernel<float, 0><<<grid, 256, 2 * GB_BUF, st>>>(g);
-        else gemm_bf16_kernel<bf16_t, 0><<<grid, 256, 2 * GB_BUF, st>>>(g);
+        if (g.out_f32) gemm_bf16_kernel<float><<<grid, 256, 2 * GB_BUF, st>>>(g);
+        else gemm_bf16_kernel<bf16_t><<<grid, 256, 2 * GB_BUF, st>>>(g);
     };
     const int tail = a.M % 256, main_rows = a.M - tail;
     if (peel && tail > 0 && main_rows > 0) {
@@ -905,24 +876,34 @@ static void launch_gemm_config(const GemmArgs& a, hipStream_t st, int kernel256,
 // timed on the real operands into a scratch output (the residual operand may alias the real output, so the real one is not
 // touched), and the fastest is remembered for the process.  The analytic model above (gemm_plan) stays the choice for small
 // problems, inside captures and when SV_GEMM_AUTOTUNE=0; it is also what the CPU tests pin.
+// The key buckets M (rows rounded up to 1024, plus whether a peelable remainder exists): variable prompt lengths / admit sizes
+// of a serving process map to a bounded set of keys, so a live request stream does not keep re-tuning (and g_tune stays small).
 struct TuneKey {
-    int M, N, K, act, res, f32, fp8;
+    int Mb, peelable, N, K, act, res, f32, fp8;
     bool operator<(const TuneKey& o) const {
-        return std::tie(M, N, K, act, res, f32, fp8) < std::tie(o.M, o.N, o.K, o.act, o.res, o.f32, o.fp8);
+        return std::tie(Mb, peelable, N, K, act, res, f32, fp8) < std::tie(o.Mb, o.peelable, o.N, o.K, o.act, o.res, o.f32, o.fp8);
     }
 };
 static std::mutex g_tune_mu;
 static std::map<TuneKey, int> g_tune;          // bit 0: 256^2 kernel, bit 1: peel, bit 2: tail as a row of 128^2 tiles
+static void* g_tune_scratch = nullptr;         // grow-only scratch output of the timing runs (no hipFree = no device sync per shape)
+static size_t g_tune_scratch_bytes = 0;
 
 static int autotune_gemm(const GemmArgs& a, hipStream_t st, const GemmPlan& model) {
     const int fallback = (model.main_256 ? 1 : 0) | (model.peel ? 2 : 0) | (model.tail_by_tiles ? 4 : 0);
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return fallback; }
     const size_t esz = a.out_f32 ? 4 : 2;
-    void* scratch = nullptr;
-    if (hipMalloc(&scratch, (size_t)a.M * a.ldc * esz) != hipSuccess) { (void)hipGetLastError(); return fallback; }
+    const size_t need = (size_t)a.M * a.ldc * esz;
+    if (need > g_tune_scratch_bytes) {                  // (the caller holds g_tune_mu)
+        void* bigger = nullptr;
+        if (hipMalloc(&bigger, need + need / 2) != hipSuccess) { (void)hipGetLastError(); return fallback; }
+        if (g_tune_scratch) (void)hipFree(g_tune_scratch);
+        g_tune_scratch = bigger; g_tune_scratch_bytes = need + need / 2;
+    }
+    void* scratch = g_tune_scratch;
     hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipFree(scratch); return fallback; }
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fallback;
     GemmArgs t = a;
     t.C = scratch;
     const int tail = a.M % 256, main_rows = a.M - tail;
@@ -944,7 +925,6 @@ static int autotune_gemm(const GemmArgs& a, hipStream_t st, const GemmPlan& mode
         }
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    (void)hipFree(scratch);
     if (getenv("SV_GEMM_AUTOTUNE_LOG"))
         fprintf(stderr, "[sv gemm autotune] M %d N %d K %d act %d res %d -> %s%s (%.1f us; model said %s%s)\n", a.M, a.N, a.K, a.act,
                 a.R ? 1 : 0, (best & 1) ? "256^2" : "128^2", (best & 2) ? " + peeled tail" : "", best_ms * 1000.f / 3.f,
@@ -953,34 +933,19 @@ static int autotune_gemm(const GemmArgs& a, hipStream_t st, const GemmPlan& mode
 }
 
 void launch_gemm(const GemmArgs& a0, hipStream_t st) {
-    GemmArgs a = a0;
-    {   // A/B switch (tools/bench_gemm_epi.py); "none" / "ldsonly" are TIMING ablations of the 256^2 kernel (wrong results)
-        const char* ee = getenv("SV_GEMM_EPI");
-        if (ee && strcmp(ee, "regs") == 0) a.epi_regs = 1;
-        else if (ee && strcmp(ee, "none") == 0) a.epi_regs = 2;
-        else if (ee && strcmp(ee, "ldsonly") == 0) a.epi_regs = 3;
-        const char* eo = getenv("SV_GEMM_ORDER");
-        if (eo && strcmp(eo, "plain") == 0) a.plain_order = 1;
-    }
-    // explicit switches (tools / A-B runs): SV_GEMM_TAIL 0 never peel, 2 always, 1 model; SV_GEMM_VARIANT 0 / 1 the 128^2
-    // kernel (plain / sched_barrier), 2 the 256^2 kernel.  Either one disables the autotuner.
-    const char* et = getenv("SV_GEMM_TAIL");
-    const char* ev = getenv("SV_GEMM_VARIANT");
-    const int tail_on = et ? atoi(et) : 1;
-    const GemmPlan pl = gemm_plan(a.M, a.N, a.K, a.act, tail_on);
+    const GemmArgs& a = a0;
+    const GemmPlan pl = gemm_plan(a.M, a.N, a.K, a.act, 1);
     static const bool tune_on = !(getenv("SV_GEMM_AUTOTUNE") && atoi(getenv("SV_GEMM_AUTOTUNE")) == 0);
-    if (!et && !ev && tune_on && a.M >= 1024 && (long)a.M * a.N >= (1L << 22)) {
-        const TuneKey key{a.M, a.N, a.K, a.act, a.R ? 1 : 0, a.out_f32, a.cscale ? 1 : 0};
-        int cfg = -1;
+    if (tune_on && a.M >= 1024 && (long)a.M * a.N >= (1L << 22)) {
+        const int tail = a.M % 256;
+        const TuneKey key{(a.M + 1023) / 1024, (tail > 0 && tail <= 96 && a.M - tail >= 2048) ? 1 : 0, a.N, a.K, a.act, a.R ? 1 : 0,
+                          a.out_f32, a.cscale ? 1 : 0};
+        int cfg;
         {
-            std::lock_guard<std::mutex> lk(g_tune_mu);
+            std::lock_guard<std::mutex> lk(g_tune_mu);        // held across the timing runs: one tuner at a time, one scratch
             auto it = g_tune.find(key);
             if (it != g_tune.end()) cfg = it->second;
-        }
-        if (cfg < 0) {
-            cfg = autotune_gemm(a, st, pl);
-            std::lock_guard<std::mutex> lk(g_tune_mu);
-            g_tune[key] = cfg;
+            else { cfg = autotune_gemm(a, st, pl); g_tune[key] = cfg; }
         }
         launch_gemm_config(a, st, cfg & 1, (cfg & 2) != 0, (cfg & 4) != 0);
         return;
@@ -1006,17 +971,16 @@ void launch_gemm(const GemmArgs& a0, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // skinny GEMM (decode step)
 //   out[m][n] = epi( sum_k x[m][k] W[n][k] ),  M <= 32 rows per tile, HBM-bound weight streaming.
-//   * optional LayerNorm PROLOGUE: the activation operand is the raw residual stream h (fragment order)
-//     and x = LN(h) is formed in registers on the way to the MFMA; the per-row mean / rstd come from
-//     per-32-column partial sums (sum, sum of squares) that the PRODUCER of h left in `ln_stats`,
-//     combined here in tile order (deterministic).
-//   * K split across the 8 waves of a block (LDS reduce) and, for narrow outputs, across `splitk`
-//     blocks: each block writes an fp32 slab (write-through), draws an arrival ticket, and the LAST block
-//     of a tile sums the slabs in slab order and runs the epilogue (no separate reduce kernel, no fences,
-//     bitwise deterministic).
-//   * epilogues: bias+activation -> fragment-order bf16 (c_fc); bias -> row-major bf16 (c_attn: q|k|v);
-//     bias + residual -> new residual stream in fragment order + its LayerNorm partial statistics
-//     (both c_proj); fp32 logits rounded to bf16 values (lm_head); raw fp32 slabs (test surface).
+//   * weights and activations both in MFMA fragment order: every wave load is one contiguous 1 KiB;
+//   * K split across the waves of a block (LDS reduce in wave order; every wave finishes 16 / WAVES of the
+//     accumulator rows, so the tail of the kernel is WAVES times shorter than a wave-0 epilogue) and, for
+//     narrow outputs, across `splitk` blocks: each block writes an fp32 slab and the CONSUMER (decode
+//     attention / row update) sums the slabs in slab order -- no hand-off inside the launch, bitwise deterministic;
+//   * outputs: fp32 slabs (c_attn, both c_proj); bias + activation -> fragment-order bf16 (c_fc);
+//     fp32 logits rounded to bf16 values (lm_head).
+//   Round 1-2 variants that were measured and lost (LayerNorm prologue, ticket-merged split-K with fused residual
+//   epilogues, the row update inside the consumer launch, two column tiles per wave, four register chunks in
+//   flight, full-K blocks) are in git history and in profiles/SUMMARY_r02.md, not in the library.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) { return pack2bf(lo, hi); }   // common.h: v_cvt_pk_bf16_f32
 
@@ -1028,133 +992,82 @@ struct SkChunk {
 };
 
 template <int CH>
-__device__ __forceinline__ void sk_load_w(SkChunk<CH>& c, const u32x4* wptr, int ks, int ks_end) {
+__device__ __forceinline__ void sk_load(SkChunk<CH>& c, const u32x4* wptr, const u32x4* xptr, int ks, int ks_end) {
 #pragma unroll
     for (int u = 0; u < CH; ++u)
         if (ks + u < ks_end) c.w[u] = __builtin_nontemporal_load(wptr + (size_t)(ks + u) * 64);   // streamed once
-}
-// SC1: the activation rows were produced by other workgroups of THIS launch (write-through stores) ->
-// read them past the L1 (sc1); otherwise plain loads
-template <int CH, bool SC1>
-__device__ __forceinline__ void sk_load_x(SkChunk<CH>& c, const u32x4* xptr, __amdgpu_buffer_rsrc_t rs, int xoff,
-                                          int ks, int ks_end) {
 #pragma unroll
-    for (int u = 0; u < CH; ++u) {
-        if (ks + u < ks_end) {                                                  // wave-uniform
-            if (SC1) c.x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, xoff + (ks + u) * 1024, 0, 16);
-            else c.x[u] = xptr[(size_t)(ks + u) * 64];
+    for (int u = 0; u < CH; ++u)
+        if (ks + u < ks_end) c.x[u] = xptr[(size_t)(ks + u) * 64];                                 // wave-uniform guard
+}
+
+// the bias of this lane's RPW output columns, requested BEFORE the weight stream (the epilogue must not start with a round trip)
+template <int RPW>
+__device__ __forceinline__ void sk_bias(const SkinnyArgs& p, float* bias_d, int r0, int nt, int half) {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        bias_d[i] = 0.f;
+        if (p.out_mode == SK_OUT_PACKED_ACT && p.bias) {
+            const int r = r0 + i;
+            const int n = nt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+            if (n < p.N) bias_d[i] = bf2f(p.bias[n]);
         }
     }
 }
-template <int CH, bool SC1>
-__device__ __forceinline__ void sk_load(SkChunk<CH>& c, const u32x4* wptr, const u32x4* xptr,
-                                        __amdgpu_buffer_rsrc_t rs, int xoff, int ks, int ks_end) {
-    sk_load_w<CH>(c, wptr, ks, ks_end);
-    sk_load_x<CH, SC1>(c, xptr, rs, xoff, ks, ks_end);
-}
-
-// one row of the decode row update, executed by a whole block inside the consumer GEMM's launch:
-//   embedding mode : h = bf(wte[tok] + wpe[pos])                       (gpt_bigcode :1060-1063)
-//   residual mode  : h = bf(h + bf(sum_s slab_s[row] + bias))          (slab order -> deterministic)
-//   then           : xp = LN(h) in fragment order, stored WRITE-THROUGH (sc1) for the waiting blocks
-template <int WAVES>
-__device__ __forceinline__ void ru_row(const SkinnyArgs& p, int row, char* smem, __amdgpu_buffer_rsrc_t rs_x) {
-    constexpr int NT = WAVES * 64;
-    const int D = p.K, NC = D >> 3, KS = D >> 4;
-    float* hrow = reinterpret_cast<float*>(smem);          // [D]
-    float* redbuf = hrow + D;                              // [2][WAVES]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    bf16_t* hr = p.ru_h + (size_t)row * p.ru_ldh;
-    float s = 0.f;
-    for (int c = tid; c < NC; c += NT) {
-        float f[8];
-        if (p.ru_ws == nullptr) {
-            const int tok = p.ru_tokens[row], pos = p.ru_positions[row];
-            float a[8], w[8];
-            unpack8(*reinterpret_cast<const uint4*>(p.ru_wte + (size_t)tok * D + c * 8), a);
-            if (p.ru_wpe) {
-                unpack8(*reinterpret_cast<const uint4*>(p.ru_wpe + (size_t)pos * D + c * 8), w);
+// shared tail of the skinny kernels: v[i] = the reduced accumulator row r0 + i of lane (m, half), i.e. output
+// column n(r) = nt*32 + 8*(r >> 2) + 4*half + (r & 3) of row mt*32 + m; RPW consecutive rows r (RPW in {1, 2, 4, 8, 16})
+template <int RPW>
+__device__ __forceinline__ void sk_store(const SkinnyArgs& p, float* v, const float* bias_d, int r0, int nt, int mt, int split, int m,
+                                         int half) {
+    constexpr int G = RPW >= 4 ? RPW / 4 : 1;          // groups of (up to) 4 consecutive columns
+    constexpr int W = RPW >= 4 ? 4 : RPW;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = bfround(a[e] + w[e]);
+    for (int g = 0; g < G; ++g) {
+        const int r = r0 + 4 * g;
+        const int n0 = nt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+        float* vv = v + 4 * g;
+        if (p.out_mode == SK_OUT_PARTIAL || p.out_mode == SK_OUT_F32) {
+            // (two separate destinations on purpose: one store through `cond ? ws + .. : out_f32 + ..` made hipcc 7.2 keep the
+            //  out_f32 base for both arms in the fp8 kernel)
+            float* dst;
+            if (p.out_mode == SK_OUT_PARTIAL) dst = p.ws + ((size_t)split * p.MT * 32 + mt * 32 + m) * p.ldws + n0;
+            else dst = p.out_f32 + ((size_t)mt * 32 + m) * p.ldo + n0;
+            if (p.out_mode == SK_OUT_F32 && p.round_bf16) {
+#pragma unroll
+                for (int i = 0; i < W; ++i) vv[i] = bfround(vv[i]);
+            }
+            if constexpr (W == 4) *reinterpret_cast<float4*>(dst) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+            else if constexpr (W == 2) *reinterpret_cast<float2*>(dst) = make_float2(vv[0], vv[1]);
+            else dst[0] = vv[0];
+        } else {   // SK_OUT_PACKED_ACT
+#pragma unroll
+            for (int i = 0; i < W; ++i) {
+                float x = 0.f;
+                if (n0 + i < p.N) {
+                    x = bfround(vv[i] + bias_d[4 * g + i]);
+                    if (p.act != ACT_NONE) x = sv_act(x, p.act);
+                }
+                vv[i] = x;
+            }
+            bf16_t* dst = p.out_xp + xp_index(mt, p.out_KS, m, n0);
+            if constexpr (W == 4) {
+                uint2 o; o.x = pack2bf(vv[0], vv[1]); o.y = pack2bf(vv[2], vv[3]);
+                *reinterpret_cast<uint2*>(dst) = o;
+            } else if constexpr (W == 2) {
+                *reinterpret_cast<uint32_t*>(dst) = pack2bf(vv[0], vv[1]);
             } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = a[e];
+                dst[0] = f2bf(vv[0]);
             }
-        } else {
-            float bb[8], hh[8], v[8];
-            unpack8(*reinterpret_cast<const uint4*>(p.ru_bias + c * 8), bb);
-            unpack8(*reinterpret_cast<const uint4*>(hr + c * 8), hh);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = 0.f;
-            for (int base = 0; base < p.ru_splitk; base += 4) {        // slab order; 4 slabs in flight at a time
-                float4 q0[4], q1[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (base + j < p.ru_splitk) {
-                        const float* src = p.ru_ws + ((size_t)(base + j) * p.ru_rows_ws + row) * p.ru_ldws + c * 8;
-                        q0[j] = *reinterpret_cast<const float4*>(src);
-                        q1[j] = *reinterpret_cast<const float4*>(src + 4);
-                    }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (base + j < p.ru_splitk) {
-                        v[0] += q0[j].x; v[1] += q0[j].y; v[2] += q0[j].z; v[3] += q0[j].w;
-                        v[4] += q1[j].x; v[5] += q1[j].y; v[6] += q1[j].z; v[7] += q1[j].w;
-                    }
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[e] = bfround(hh[e] + bfround(v[e] + bb[e]));
         }
-        *reinterpret_cast<uint4*>(hr + c * 8) = pack8(f);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { hrow[c * 8 + e] = f[e]; s += f[e]; }
     }
-    s = wave_sum(s);
-    if (lane == 0) redbuf[wave] = s;
-    __syncthreads();
-    float tot = 0.f;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) tot += redbuf[w];
-    const float mean = tot / (float)D;
-    float q = 0.f;
-    for (int c = tid; c < NC; c += NT) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { const float d = hrow[c * 8 + e] - mean; q += d * d; }
-    }
-    q = wave_sum(q);
-    if (lane == 0) redbuf[WAVES + wave] = q;
-    __syncthreads();
-    float qt = 0.f;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) qt += redbuf[WAVES + w];
-    const float rstd = rsqrtf(qt / (float)D + p.ru_eps);
-    for (int c = tid; c < NC; c += NT) {
-        float f[8], gg[8], bb[8];
-        unpack8(*reinterpret_cast<const uint4*>(p.ru_g + c * 8), gg);
-        unpack8(*reinterpret_cast<const uint4*>(p.ru_b + c * 8), bb);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = (hrow[c * 8 + e] - mean) * rstd * gg[e] + bb[e];
-        const uint4 o = pack8(f);
-        u32x4 v; v[0] = o.x; v[1] = o.y; v[2] = o.z; v[3] = o.w;
-        __builtin_amdgcn_raw_buffer_store_b128(v, rs_x, (int)(xp_index(row >> 5, KS, row & 31, c * 8) * 2), 0, 16);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains its write-through stores
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(p.ru_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// NB = register chunks of CH k-steps in flight per wave.  2 (8 KiB of weights per wave) is the measured default; NB = 4 puts a
-// wave's whole 16-k-step share of the K = 2048 / 8192 GEMMs in flight at once (one HBM latency round instead of two).
-template <int WAVES, int PRE, int NB = 2>
-__global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && PRE == 2) ? 4 : 1) void gemm_skinny_kernel(SkinnyArgs p) {
-    constexpr bool LN = PRE == 1;
-    constexpr bool RU = PRE == 2;
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     constexpr int CH = 4;                            // k-steps per register chunk (two chunks = 8 KiB of W in flight per wave)
+    constexpr int NB = 2;
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(sk_smem);          // [WAVES][16][64]
-    float* lnp = reinterpret_cast<float*>(sk_smem + (size_t)WAVES * 16 * 64 * 4);  // [32][2]
-    float* lpart = lnp + 64;                                                        // [2*WAVES][32][2]
-    bf16_t* gb_s = reinterpret_cast<bf16_t*>(lpart + 2 * WAVES * 64);               // gamma[K] | beta[K]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1175,355 +1088,63 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 && PRE == 2) ? 4 : 1) void 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    // ---- everything the kernel will need from memory is requested up front, smallest first: LayerNorm
-    // partials + gamma/beta (LDS), the epilogue's bias / residual (wave 0), then the weight stream ----
-    constexpr int PARTS = WAVES * 2;
-    float s1p = 0.f, s2p = 0.f;
-    uint4 gq[2], bq[2];
-    if (LN) {
-        const int prt = tid >> 5;
-        for (int t = prt; t < p.ln_tiles; t += PARTS) {
-            const float2 v = p.ln_stats[((size_t)mt * p.ln_tiles + t) * 32 + m];
-            s1p += v.x; s2p += v.y;
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {                     // K <= 2 * 8 * WAVES*64 elements
-            const int c = tid + i * WAVES * 64;
-            if (c < (p.K >> 3)) {
-                gq[i] = *reinterpret_cast<const uint4*>(p.ln_g + c * 8);
-                bq[i] = *reinterpret_cast<const uint4*>(p.ln_b + c * 8);
-            }
-        }
-    }
-    uint2 bias_q[4], res_q[4];
-    const bool epi_wave = wave == 0 && p.out_mode != SK_OUT_PARTIAL && p.out_mode != SK_OUT_F32;
-    if (epi_wave) {
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int n = nt * 32 + rg * 8 + half * 4;
-            bias_q[rg] = make_uint2(0u, 0u);
-            if (p.bias && n < p.N) bias_q[rg] = *reinterpret_cast<const uint2*>(p.bias + n);
-            if (p.out_mode == SK_OUT_RESID)
-                res_q[rg] = *reinterpret_cast<const uint2*>(p.resid_xp + xp_index(mt, p.out_KS, m, n));
-        }
-    }
-    // distributed epilogue (no cross-block hand-off, no row statistics): every wave finishes RPW of the 16
-    // accumulator rows, so the tail of the kernel is WAVES times shorter than a wave-0 epilogue
-    constexpr int RPW = WAVES >= 16 ? 1 : 16 / WAVES;
-    const bool dist = WAVES > 1 && WAVES <= 16 &&
-                      (p.out_mode == SK_OUT_PARTIAL ||
-                       (p.splitk == 1 && (p.out_mode == SK_OUT_PACKED_ACT || p.out_mode == SK_OUT_F32)));
+    constexpr int RPW = 16 / WAVES;
     float bias_d[RPW];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        bias_d[i] = 0.f;
-        if (dist && p.out_mode == SK_OUT_PACKED_ACT && p.bias) {
-            const int r = wave * RPW + i;
-            const int n = nt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-            if (n < p.N) bias_d[i] = bf2f(p.bias[n]);
-        }
-    }
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<bf16_t*>(p.xp), 0, (unsigned)((size_t)p.MT * 32 * p.K * 2), 0x00020000);
-    const int xoff = (int)((((size_t)mt * KS + ks0) * 64 + lane) * 16);
+    sk_bias<RPW>(p, bias_d, wave * RPW, nt, half);
     SkChunk<CH> ck[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b)
-        if (b * CH < ks_per_wave) sk_load_w<CH>(ck[b], wptr, b * CH, ks_per_wave);
-    if (RU) {
-        // the weight stream is in flight; now produce / wait for this GEMM's activation rows
-        const int bid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-        if (bid < p.ru_M) ru_row<WAVES>(p, bid, sk_smem, rs_x);
-        if (tid == 0) {
-            unsigned spins = 0;
-            while (__hip_atomic_load(p.ru_ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)p.ru_M) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 22)) { *p.ru_err = 1; break; }       // bounded: never hang the GPU
-            }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-        if (b * CH < ks_per_wave) sk_load_x<CH, RU>(ck[b], xptr, rs_x, xoff, b * CH, ks_per_wave);
-
-    float ra = 1.f, rb = 0.f;
-    if (LN) {
-        // ---- LayerNorm prologue: gamma/beta -> LDS; row statistics from the producer's per-tile partials
-        const int prt = tid >> 5;
-        lpart[(prt * 32 + m) * 2 + 0] = s1p;
-        lpart[(prt * 32 + m) * 2 + 1] = s2p;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + i * WAVES * 64;
-            if (c < (p.K >> 3)) {
-                *reinterpret_cast<uint4*>(gb_s + c * 8) = gq[i];
-                *reinterpret_cast<uint4*>(gb_s + p.K + c * 8) = bq[i];
-            }
-        }
-        __syncthreads();
-        float a = 0.f, b = 0.f;
-#pragma unroll
-        for (int q = 0; q < PARTS; ++q) { a += lpart[(q * 32 + m) * 2]; b += lpart[(q * 32 + m) * 2 + 1]; }
-        const float invD = 1.0f / (float)(p.ln_tiles * 32);
-        const float mean = a * invD;
-        float var = b * invD - mean * mean;
-        var = var > 0.f ? var : 0.f;
-        ra = rsqrtf(var + p.ln_eps);
-        rb = -mean * ra;
-    }
-
-    auto compute = [&](SkChunk<CH>& c, int ks) {
-#pragma unroll
-        for (int u = 0; u < CH; ++u) {
-            if (ks + u < ks_per_wave) {
-                u32x4 xv = c.x[u];
-                if (LN) {
-                    const int k0 = (ks0 + ks + u) * 16 + half * 8;
-                    const u32x4 gv = *reinterpret_cast<const u32x4*>(gb_s + k0);
-                    const u32x4 bv = *reinterpret_cast<const u32x4*>(gb_s + p.K + k0);
-#pragma unroll
-                    for (int w = 0; w < 4; ++w) {
-                        const float h0 = __uint_as_float(xv[w] << 16), h1 = __uint_as_float(xv[w] & 0xffff0000u);
-                        const float g0 = __uint_as_float(gv[w] << 16), g1 = __uint_as_float(gv[w] & 0xffff0000u);
-                        const float b0 = __uint_as_float(bv[w] << 16), b1 = __uint_as_float(bv[w] & 0xffff0000u);
-                        xv[w] = cvt_pk_bf16(fmaf(fmaf(h0, ra, rb), g0, b0), fmaf(fmaf(h1, ra, rb), g1, b1));
-                    }
-                }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(c.w[u]), as_frag4(xv), acc, 0, 0, 0);
-            }
-        }
-    };
+        if (b * CH < ks_per_wave) sk_load<CH>(ck[b], wptr, xptr, b * CH, ks_per_wave);
 
     for (int ks = 0; ks < ks_per_wave; ks += NB * CH) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
-            if (ks + b * CH < ks_per_wave) compute(ck[b], ks + b * CH);
-            if (ks + (b + NB) * CH < ks_per_wave) sk_load<CH, RU>(ck[b], wptr, xptr, rs_x, xoff, ks + (b + NB) * CH, ks_per_wave);
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+                if (ks + b * CH + u < ks_per_wave)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(ck[b].w[u]), as_frag4(ck[b].x[u]), acc, 0, 0, 0);
+            if (ks + (b + NB) * CH < ks_per_wave) sk_load<CH>(ck[b], wptr, xptr, ks + (b + NB) * CH, ks_per_wave);
         }
     }
 
-    // ---- K reduction across the waves of the block (wave order) ---------------------------------
-    if (WAVES > 1) {
+    // ---- K reduction across the waves of the block (wave order), every wave finishes RPW accumulator rows ----
+    float v[RPW];
+    if constexpr (WAVES > 1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
         __syncthreads();
-        if (dist) {
-            float v[RPW];
 #pragma unroll
-            for (int i = 0; i < RPW; ++i) {
-                const int r = wave * RPW + i;
-                float t = red[0][r][lane];
+        for (int i = 0; i < RPW; ++i) {
+            const int r = wave * RPW + i;
+            float t = red[0][r][lane];
 #pragma unroll
-                for (int w = 1; w < WAVES; ++w) t += red[w][r][lane];
-                v[i] = t;
-            }
-            const int r0 = wave * RPW;
-            const int n0 = nt * 32 + 8 * (r0 >> 2) + 4 * half + (r0 & 3);       // RPW consecutive columns (RPW <= 4)
-            if (p.out_mode == SK_OUT_PARTIAL || p.out_mode == SK_OUT_F32) {
-                float* dst = p.out_mode == SK_OUT_PARTIAL
-                                 ? p.ws + ((size_t)split * p.MT * 32 + mt * 32 + m) * p.ldws + n0
-                                 : p.out_f32 + ((size_t)mt * 32 + m) * p.ldo + n0;
-                if (p.out_mode == SK_OUT_F32 && p.round_bf16) {
-#pragma unroll
-                    for (int i = 0; i < RPW; ++i) v[i] = bfround(v[i]);
-                }
-                if constexpr (RPW == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                else if constexpr (RPW == 2) *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
-                else {
-#pragma unroll
-                    for (int i = 0; i < RPW; ++i) dst[i + (i >> 2) * 4] = v[i];      // RPW 1 (or 8: two groups of 4)
-                }
-            } else {   // SK_OUT_PACKED_ACT
-#pragma unroll
-                for (int i = 0; i < RPW; ++i) {
-                    float x = 0.f;
-                    if (n0 + i + (i >> 2) * 4 < p.N) {
-                        x = bfround(v[i] + bias_d[i]);
-                        if (p.act != ACT_NONE) x = sv_act(x, p.act);
-                    }
-                    v[i] = x;
-                }
-                bf16_t* dst = p.out_xp + xp_index(mt, p.out_KS, m, n0);
-                if constexpr (RPW == 4) {
-                    uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(dst) = o;
-                } else if constexpr (RPW == 2) {
-                    *reinterpret_cast<uint32_t*>(dst) = pack2bf(v[0], v[1]);
-                } else {
-#pragma unroll
-                    for (int i = 0; i < RPW; ++i)        // RPW 1, or 8 = two groups of 4 columns 8 apart
-                        p.out_xp[xp_index(mt, p.out_KS, m, n0 + i + (i >> 2) * 4)] = f2bf(v[i]);
-                }
-            }
-            return;
+            for (int w = 1; w < WAVES; ++w) t += red[w][r][lane];
+            v[i] = t;
         }
-        if (wave != 0) return;
+    } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float s = red[0][r][lane];
-#pragma unroll
-            for (int w = 1; w < WAVES; ++w) s += red[w][r][lane];
-            acc[r] = s;
-        }
+        for (int i = 0; i < 16; ++i) v[i] = acc[i];
     }
-    // only wave 0 continues: lane (m = l&31, half) owns columns n = nt*32 + 8*rg + 4*half + j
-
-    if (p.out_mode == SK_OUT_PARTIAL) {
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            float* dst = p.ws + ((size_t)split * p.MT * 32 + mt * 32 + m) * p.ldws + nt * 32 + rg * 8 + half * 4;
-            *reinterpret_cast<float4*>(dst) = make_float4(acc[rg * 4], acc[rg * 4 + 1], acc[rg * 4 + 2], acc[rg * 4 + 3]);
-        }
-        return;
-    }
-
-    if (p.splitk > 1) {
-        // ---- cross-block K reduction: slab -> ticket -> the last block of this tile sums all slabs ----
-        // Hand-off without fences: the slab is stored WRITE-THROUGH (sc1, 16 B per lane), every storing
-        // lane drains (vmcnt 0), one lane draws a relaxed agent-scope ticket; the last arriver reads all
-        // slabs with sc1 loads (L1 bypass).  Placement independent; slabs are summed in slab order.
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            p.ws, 0, (unsigned)((size_t)p.splitk * p.MT * 32 * p.ldws * sizeof(float)), 0x00020000);
-        const int row_off = ((mt * 32 + m) * p.ldws + nt * 32 + half * 4) * 4;     // bytes inside one slab
-        const int slab_bytes = p.MT * 32 * p.ldws * 4;
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            u32x4 v;
-            v[0] = __float_as_uint(acc[rg * 4]); v[1] = __float_as_uint(acc[rg * 4 + 1]);
-            v[2] = __float_as_uint(acc[rg * 4 + 2]); v[3] = __float_as_uint(acc[rg * 4 + 3]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs, split * slab_bytes + row_off + rg * 32, 0, 16);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned* cnt = p.counters + (size_t)mt * gridDim.x + nt;
-        unsigned t = 0;
-        if (lane == 0) t = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t = __builtin_amdgcn_readfirstlane(t);
-        if (t != (unsigned)(p.splitk - 1)) return;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        for (int sp = 0; sp < p.splitk; ++sp) {
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, sp * slab_bytes + row_off + rg * 32, 0, 16);
-                acc[rg * 4] += __uint_as_float(v[0]); acc[rg * 4 + 1] += __uint_as_float(v[1]);
-                acc[rg * 4 + 2] += __uint_as_float(v[2]); acc[rg * 4 + 3] += __uint_as_float(v[3]);
-            }
-        }
-        if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
-    }
-
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-        const int n = nt * 32 + rg * 8 + half * 4;
-        float v[4] = {acc[rg * 4 + 0], acc[rg * 4 + 1], acc[rg * 4 + 2], acc[rg * 4 + 3]};
-        if (p.out_mode == SK_OUT_F32) {
-            if (p.round_bf16) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = bfround(v[j]);
-            }
-            float* dst = p.out_f32 + ((size_t)mt * 32 + m) * p.ldo + n;
-            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-            continue;
-        }
-        const float bj[4] = {__uint_as_float(bias_q[rg].x << 16), __uint_as_float(bias_q[rg].x & 0xffff0000u),
-                             __uint_as_float(bias_q[rg].y << 16), __uint_as_float(bias_q[rg].y & 0xffff0000u)};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float x = v[j];
-            if (n + j < p.N) {
-                x = bfround(x + bj[j]);
-                if (p.act != ACT_NONE) x = sv_act(x, p.act);
-            } else {
-                x = 0.f;
-            }
-            v[j] = x;
-        }
-        if (p.out_mode == SK_OUT_RESID) {
-            const size_t off = xp_index(mt, p.out_KS, m, n);
-            const uint2 rr = res_q[rg];
-            v[0] = bfround(v[0] + __uint_as_float(rr.x << 16));
-            v[1] = bfround(v[1] + __uint_as_float(rr.x & 0xffff0000u));
-            v[2] = bfround(v[2] + __uint_as_float(rr.y << 16));
-            v[3] = bfround(v[3] + __uint_as_float(rr.y & 0xffff0000u));
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (n + j < p.N) { s1 += v[j]; s2 += v[j] * v[j]; }
-            uint2 o;
-            o.x = pack2bf(v[0], v[1]);
-            o.y = pack2bf(v[2], v[3]);
-            *reinterpret_cast<uint2*>(p.out_xp + off) = o;
-        } else if (p.out_mode == SK_OUT_PACKED_ACT) {
-            uint2 o;
-            o.x = pack2bf(v[0], v[1]);
-            o.y = pack2bf(v[2], v[3]);
-            *reinterpret_cast<uint2*>(p.out_xp + xp_index(mt, p.out_KS, m, n)) = o;
-        } else {   // SK_OUT_ROWMAJOR
-            if (n < p.N) {
-                uint2 o;
-                o.x = pack2bf(v[0], v[1]);
-                o.y = pack2bf(v[2], v[3]);
-                *reinterpret_cast<uint2*>(p.out_rm + ((size_t)mt * 32 + m) * p.ld_rm + n) = o;
-            }
-        }
-    }
-    if (p.out_mode == SK_OUT_RESID && p.stats_out) {
-        s1 += __shfl_xor(s1, 32, 64);
-        s2 += __shfl_xor(s2, 32, 64);
-        if (half == 0) p.stats_out[((size_t)mt * gridDim.x + nt) * 32 + m] = make_float2(s1, s2);
-    }
+    sk_store<RPW>(p, v, bias_d, wave * RPW, nt, mt, split, m, half);
 }
 
-static size_t skinny_smem(int waves, int K, bool ln) {
-    return (size_t)waves * 16 * 64 * 4 + 64 * 4 + (size_t)2 * waves * 64 * 4 + (ln ? (size_t)K * 4 : 0) + 16;
-}
+static size_t skinny_smem(int waves) { return (size_t)waves * 16 * 64 * 4 + 16; }
 
 static int init_mt2_attrs();
-template <int W, int PRE>
-static int set_attr(int bytes) {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<W, PRE>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-}
 int init_gemm_kernels() {
-    // 16-wave blocks reduce through 64 KiB of LDS (+ gamma/beta): above the default dynamic-LDS limit
-    int r = set_attr<16, 1>(160 * 1024);
-    if (!r) r = set_attr<16, 0>(160 * 1024);
-    if (!r) r = set_attr<16, 2>(160 * 1024);
-    if (!r) r = set_attr<8, 1>(128 * 1024);
-    if (!r) r = set_attr<8, 0>(128 * 1024);
-    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<8, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    if (!r) r = set_attr<8, 2>(128 * 1024);
+    // 16-wave blocks reduce through 64 KiB of LDS: above the default dynamic-LDS limit
+    int r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (!r) r = init_mt2_attrs();
-    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<bf16_t, 0>),
+    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<bf16_t>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
-    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<bf16_t, 2>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
-    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<bf16_t, 3>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
-    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<bf16_t, 4>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
-    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<float, 0>),
+    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<float>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
     return r;
 }
 
 template <int W>
 static void launch_sk(const SkinnyArgs& a, dim3 grid, hipStream_t st) {
-    const bool ln = a.ln_stats != nullptr;
-    size_t smem = skinny_smem(W, a.K, ln);
-    if (a.ru_M > 0) {
-        const size_t need = (size_t)a.K * 4 + 2 * W * 4 + 64;       // row buffer of the overlapped row update
-        if (smem < need) smem = need;
-        gemm_skinny_kernel<W, 2><<<grid, W * 64, smem, st>>>(a);
-    } else if (ln) {
-        gemm_skinny_kernel<W, 1><<<grid, W * 64, smem, st>>>(a);
-    } else {
-        // SV_SKINNY_DEPTH=4: four chunks in flight (experiment switch, read per launch; 8-wave blocks only)
-        const char* ed = getenv("SV_SKINNY_DEPTH");
-        if (W == 8 && ed && atoi(ed) == 4 && (a.K / 16) / a.splitk / 8 >= 12) gemm_skinny_kernel<8, 0, 4><<<grid, 512, smem, st>>>(a);
-        else gemm_skinny_kernel<W, 0><<<grid, W * 64, smem, st>>>(a);
-    }
+    gemm_skinny_kernel<W><<<grid, W * 64, skinny_smem(W), st>>>(a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1562,15 +1183,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_fp8_kernel(SkinnyArgs 
 
     constexpr int RPW = 16 / WAVES;                       // WAVES in {2, 4, 8}
     float bias_d[RPW];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        bias_d[i] = 0.f;
-        if (p.out_mode == SK_OUT_PACKED_ACT && p.bias) {
-            const int r = wave * RPW + i;
-            const int n = nt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-            if (n < p.N) bias_d[i] = bf2f(p.bias[n]);
-        }
-    }
+    sk_bias<RPW>(p, bias_d, wave * RPW, nt, half);
 
     struct Chunk { u32x4 w[CH / 2]; u32x4 x[CH]; };
     Chunk ca, cb;
@@ -1623,47 +1236,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_fp8_kernel(SkinnyArgs 
         for (int w = 1; w < WAVES; ++w) t += red[w][r][lane];
         v[i] = t;
     }
-    const int r0 = wave * RPW;
-    const int n0 = nt * 32 + 8 * (r0 >> 2) + 4 * half + (r0 & 3);       // RPW consecutive columns (two groups of 4 when RPW = 8)
-    auto store_f32 = [&](float* dst) {
-        if constexpr (RPW == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-        else if constexpr (RPW == 2) *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
-        else {
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) dst[i + (i >> 2) * 4] = v[i];
-        }
-    };
-    // (two separate branches on purpose: written as one store through `cond ? ws + .. : out_f32 + ..` hipcc 7.2 kept the
-    //  out_f32 base register for both arms in this kernel and the slab store went to a null pointer)
-    if (p.out_mode == SK_OUT_PARTIAL) {
-        store_f32(p.ws + ((size_t)split * p.MT * 32 + mt * 32 + m) * p.ldws + n0);
-    } else if (p.out_mode == SK_OUT_F32) {
-        if (p.round_bf16) {
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) v[i] = bfround(v[i]);
-        }
-        store_f32(p.out_f32 + ((size_t)mt * 32 + m) * p.ldo + n0);
-    } else {   // SK_OUT_PACKED_ACT
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            float x = 0.f;
-            if (n0 + i + (i >> 2) * 4 < p.N) {
-                x = bfround(v[i] + bias_d[i]);
-                if (p.act != ACT_NONE) x = sv_act(x, p.act);
-            }
-            v[i] = x;
-        }
-        bf16_t* dst = p.out_xp + xp_index(mt, p.out_KS, m, n0);
-        if constexpr (RPW == 4) {
-            uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-            *reinterpret_cast<uint2*>(dst) = o;
-        } else if constexpr (RPW == 2) {
-            *reinterpret_cast<uint32_t*>(dst) = pack2bf(v[0], v[1]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) p.out_xp[xp_index(mt, p.out_KS, m, n0 + i + (i >> 2) * 4)] = f2bf(v[i]);
-        }
-    }
+    sk_store<RPW>(p, v, bias_d, wave * RPW, nt, mt, split, m, half);
 }
 
 // Waves per block of the skinny kernels = how K is cut inside a block, i.e. the order in which a row's partial sums are
@@ -1673,10 +1246,6 @@ static int skinny_waves(int Npad, int KS, int splitk) {
     const int per_split = KS / splitk;
     // narrow outputs (few column tiles) get 16 waves per block so that no cross-block split-K is needed
     const bool narrow = (Npad / 32) * splitk < 160;
-    const char* ew = getenv("SV_SKINNY_WAVES");          // experiment switch (tools/bench_skinny.py): force 16 / 8 waves
-    const int force = ew ? atoi(ew) : 0;
-    if (force == 16 && per_split % 16 == 0) return 16;
-    if (force == 8 && per_split % 8 == 0) return 8;
     if (per_split % 16 == 0 && narrow) return 16;
     if (per_split % 8 == 0) return 8;
     if (per_split % 4 == 0) return 4;
@@ -1693,7 +1262,6 @@ static int skinny_waves_fp8(int KS, int splitk) {       // a lane's 16 bytes hol
 
 // returns false when the shape / mode has no fp8 variant (the caller reports it)
 static bool launch_gemm_skinny_fp8(const SkinnyArgs& a, hipStream_t st) {
-    if (a.ln_stats || a.ru_M > 0) return false;
     if (!(a.out_mode == SK_OUT_PARTIAL || ((a.out_mode == SK_OUT_PACKED_ACT || a.out_mode == SK_OUT_F32) && a.splitk == 1)))
         return false;
     const dim3 grid(a.Npad / 32, a.splitk, a.MT);
@@ -1744,15 +1312,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(SkinnyArgs 
 
     constexpr int RPW = 16 / WAVES;                       // WAVES in {4, 8}
     float bias_d[RPW];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        bias_d[i] = 0.f;
-        if (p.out_mode == SK_OUT_PACKED_ACT && p.bias) {
-            const int r = wave * RPW + i;
-            const int n = nt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-            if (n < p.N) bias_d[i] = bf2f(p.bias[n]);
-        }
-    }
+    sk_bias<RPW>(p, bias_d, wave * RPW, nt, half);
 
     struct Chunk { u32x4 w[WCH]; u32x4 x0[CH]; u32x4 x1[CH]; };
     Chunk c[NBUF];
@@ -1810,11 +1370,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(SkinnyArgs 
 #pragma unroll
     for (int r = 0; r < 16; ++r) { red[0][wave][r][lane] = acc0[r]; red[1][wave][r][lane] = acc1[r]; }
     __syncthreads();
-    const int r0 = wave * RPW;
-    const int n0 = nt * 32 + 8 * (r0 >> 2) + 4 * half + (r0 & 3);       // RPW consecutive columns
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi) {
-        const int mt = mt0 + mi;
         float v[RPW];
 #pragma unroll
         for (int i = 0; i < RPW; ++i) {
@@ -1824,156 +1381,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(SkinnyArgs 
             for (int w = 1; w < WAVES; ++w) t += red[mi][w][r][lane];
             v[i] = t;
         }
-        auto store_f32 = [&](float* dst) {
-            if constexpr (RPW == 4) *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-            else *reinterpret_cast<float2*>(dst) = make_float2(v[0], v[1]);
-        };
-        if (p.out_mode == SK_OUT_PARTIAL) {
-            store_f32(p.ws + ((size_t)split * p.MT * 32 + mt * 32 + m) * p.ldws + n0);
-        } else if (p.out_mode == SK_OUT_F32) {
-            if (p.round_bf16) {
-#pragma unroll
-                for (int i = 0; i < RPW; ++i) v[i] = bfround(v[i]);
-            }
-            store_f32(p.out_f32 + ((size_t)mt * 32 + m) * p.ldo + n0);
-        } else {   // SK_OUT_PACKED_ACT
-#pragma unroll
-            for (int i = 0; i < RPW; ++i) {
-                float x = 0.f;
-                if (n0 + i < p.N) {
-                    x = bfround(v[i] + bias_d[i]);
-                    if (p.act != ACT_NONE) x = sv_act(x, p.act);
-                }
-                v[i] = x;
-            }
-            bf16_t* dst = p.out_xp + xp_index(mt, p.out_KS, m, n0);
-            if constexpr (RPW == 4) {
-                uint2 o; o.x = pack2bf(v[0], v[1]); o.y = pack2bf(v[2], v[3]);
-                *reinterpret_cast<uint2*>(dst) = o;
-            } else {
-                *reinterpret_cast<uint32_t*>(dst) = pack2bf(v[0], v[1]);
-            }
-        }
+        sk_store<RPW>(p, v, bias_d, wave * RPW, nt, mt0 + mi, split, m, half);
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// skinny GEMM, TWO 32-column tiles per wave sharing one activation fragment (an experiment, off by default).  Hypothesis: the
-// decode GEMMs are bound by what the CUs can ingest (c_fc 67 MB of weights + activation fragments in 6.8 us, lm_head 402 MB
-// in 39.9 us: both ~10 TB/s), half of it activation fragments every block re-reads; a wave that loads one activation fragment
-// per k-step for two weight fragments (column tiles 2j, 2j + 1) ingests a third less per weight byte.  Measured: no gain
-// (see launch_gemm_skinny_nt2) -- the hypothesis is wrong, the fragments come out of L2 for free next to the HBM stream.
-// K is cut exactly like the one-tile kernel cuts it (8 waves per block over the block's K range, `splitk` blocks, the
-// partials of a column tile reduced in wave order, slabs in slab order), so every output keeps its bits whichever of the
-// two kernels produced it.  Scope: bf16 weights, fp32 slabs or fp32 logits; used where the pairs still fill the chip.
-// ------------------------------------------------------------------------------------------------
-template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_nt2_kernel(SkinnyArgs p) {
-    constexpr int CH = 4;
-    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
-    float (*red)[WAVES][16][64] = reinterpret_cast<float (*)[WAVES][16][64]>(sk_smem);          // [2][WAVES][16][64]
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NT = p.Npad >> 5;
-    const int nt0 = 2 * blockIdx.x, nt1 = nt0 + 1 < NT ? nt0 + 1 : nt0;        // an odd last tile is computed twice, stored once
-    const bool two = nt0 + 1 < NT;
-    const int split = blockIdx.y, mt = blockIdx.z;
-    const int KS = p.K >> 4;
-    const int ks_per_split = KS / p.splitk;
-    const int ks_per_wave = ks_per_split / WAVES;
-    const int ks0 = split * ks_per_split + wave * ks_per_wave;
-    const int m = lane & 31, half = lane >> 5;
-    const u32x4* w0p = reinterpret_cast<const u32x4*>(p.Wp) + ((size_t)nt0 * KS + ks0) * 64 + lane;
-    const u32x4* w1p = reinterpret_cast<const u32x4*>(p.Wp) + ((size_t)nt1 * KS + ks0) * 64 + lane;
-    const u32x4* xptr = reinterpret_cast<const u32x4*>(p.xp) + ((size_t)mt * KS + ks0) * 64 + lane;
-    f32x16 acc0, acc1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-    struct Chunk { u32x4 w0[CH], w1[CH], x[CH]; };
-    Chunk ca, cb;
-    auto load = [&](Chunk& c, int ks) {
-#pragma unroll
-        for (int u = 0; u < CH; ++u)
-            if (ks + u < ks_per_wave) {                                           // wave-uniform
-                c.w0[u] = __builtin_nontemporal_load(w0p + (size_t)(ks + u) * 64);
-                c.w1[u] = __builtin_nontemporal_load(w1p + (size_t)(ks + u) * 64);
-                c.x[u] = xptr[(size_t)(ks + u) * 64];
-            }
-    };
-    auto compute = [&](Chunk& c, int ks) {
-#pragma unroll
-        for (int u = 0; u < CH; ++u)
-            if (ks + u < ks_per_wave) {
-                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(c.w0[u]), as_frag4(c.x[u]), acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(c.w1[u]), as_frag4(c.x[u]), acc1, 0, 0, 0);
-            }
-    };
-    load(ca, 0);
-    if (CH < ks_per_wave) load(cb, CH);
-    for (int ks = 0; ks < ks_per_wave; ks += 2 * CH) {
-        compute(ca, ks);
-        if (ks + 2 * CH < ks_per_wave) load(ca, ks + 2 * CH);
-        if (ks + CH < ks_per_wave) compute(cb, ks + CH);
-        if (ks + 3 * CH < ks_per_wave) load(cb, ks + 3 * CH);
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { red[0][wave][r][lane] = acc0[r]; red[1][wave][r][lane] = acc1[r]; }
-    __syncthreads();
-    constexpr int RPW = 16 / WAVES;                       // WAVES = 8: 2 accumulator rows (= 2 consecutive columns) per wave
-    const int r0 = wave * RPW;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        if (t == 1 && !two) break;
-        const int nt = t ? nt1 : nt0;
-        float v[RPW];
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int r = r0 + i;
-            float s = red[t][0][r][lane];
-#pragma unroll
-            for (int w = 1; w < WAVES; ++w) s += red[t][w][r][lane];
-            v[i] = s;
-        }
-        const int n0 = nt * 32 + 8 * (r0 >> 2) + 4 * half + (r0 & 3);
-        if (p.out_mode == SK_OUT_PARTIAL) {
-            *reinterpret_cast<float2*>(p.ws + ((size_t)split * p.MT * 32 + mt * 32 + m) * p.ldws + n0) = make_float2(v[0], v[1]);
-        } else {                                          // SK_OUT_F32
-            if (p.round_bf16) { v[0] = bfround(v[0]); v[1] = bfround(v[1]); }
-            *reinterpret_cast<float2*>(p.out_f32 + ((size_t)mt * 32 + m) * p.ldo + n0) = make_float2(v[0], v[1]);
-        }
-    }
-}
-
-// false: outside the kernel's scope, or the column pairs would leave CUs idle (the caller runs one tile per block)
-static bool launch_gemm_skinny_nt2(const SkinnyArgs& a, hipStream_t st) {
-    // OFF by default: measured (profiles/skinny_r02_two_column_tiles_ab.log) the shared fragment does not pay -- lm_head 43.6 vs
-    // 38.4 us, 8B c_fc 39.1 vs 36.4 us, down-projection 6.4 vs 6.7 us only together with split-K 8 -- so the activation
-    // re-reads are NOT what bounds these kernels.  SV_SKINNY_NT2=1 enables it (read per launch: the A/B tool and the bitwise test).
-    const char* e2 = getenv("SV_SKINNY_NT2");
-    if (!(e2 && atoi(e2) == 1)) return false;
-    if (a.Wq || a.ln_stats || a.ru_M > 0 || (a.K / 16) % a.splitk) return false;
-    if (!(a.out_mode == SK_OUT_PARTIAL || (a.out_mode == SK_OUT_F32 && a.splitk == 1))) return false;
-    if (skinny_waves(a.Npad, a.K / 16, a.splitk) != 8) return false;
-    const int pairs = (a.Npad / 32 + 1) / 2;
-    const int ks_per_wave = (a.K / 16) / a.splitk / 8;
-    if (pairs * a.splitk < 224 || ks_per_wave < 8) return false;                             // fill the chip; enough K per wave to stream
-    gemm_skinny_nt2_kernel<8><<<dim3(pairs, a.splitk, a.MT), 512, 2 * 8 * 16 * 64 * 4, st>>>(a);
-    return true;
 }
 
 static int init_mt2_attrs() {
-    int r0 = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_nt2_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 16 * 64 * 4);
-    if (r0) return r0;
     int r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 16 * 64 * 4);
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 16 * 64 * 4);
     return r;
 }
 // two-row-tile launch: false when the shape / mode is outside the kernel's scope (the caller falls back to one tile per block)
 static bool launch_gemm_skinny_mt2(const SkinnyArgs& a, hipStream_t st) {
-    const char* e2 = getenv("SV_SKINNY_MT2");                                                 // A/B switch (read per launch: tests flip it)
-    const bool off = e2 && atoi(e2) == 0;
-    if (off || a.MT < 2 || (a.MT & 1) || a.ln_stats || a.ru_M > 0) return false;
+    if (a.MT < 2 || (a.MT & 1)) return false;
     if (!(a.out_mode == SK_OUT_PARTIAL || ((a.out_mode == SK_OUT_PACKED_ACT || a.out_mode == SK_OUT_F32) && a.splitk == 1)))
         return false;
     if (a.Wq && !a.wscale) return false;
@@ -1998,13 +1417,11 @@ void skinny_plan(int Npad, int K, int splitk, int fp8, int MT, int* waves, int* 
     const int KS = K / 16;
     const int w = fp8 ? skinny_waves_fp8(KS, splitk) : skinny_waves(Npad, KS, splitk);
     *waves = w;
-    const char* e2 = getenv("SV_SKINNY_MT2");
-    *two_row_tiles = (!(e2 && atoi(e2) == 0) && MT >= 2 && !(MT & 1) && (w == 8 || w == 4) && KS % splitk == 0) ? 1 : 0;
+    *two_row_tiles = (MT >= 2 && !(MT & 1) && (w == 8 || w == 4) && KS % splitk == 0) ? 1 : 0;
 }
 
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st) {
     if (launch_gemm_skinny_mt2(a, st)) return;                  // 33..64 rows: two row tiles per block, weights streamed once
-    if (launch_gemm_skinny_nt2(a, st)) return;                  // two column tiles per wave share an activation fragment
     if (a.Wq && launch_gemm_skinny_fp8(a, st)) return;       // fp8 weights: its own kernel (falls through if unsupported)
     dim3 grid(a.Npad / 32, a.splitk, a.MT);
     switch (skinny_waves(a.Npad, a.K / 16, a.splitk)) {
@@ -2016,45 +1433,7 @@ void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// decode-step entry: h = bf(wte[tok] + wpe[pos]) in fragment order + its LayerNorm partial statistics
-// (gpt_bigcode :1060-1063).  One block per sequence.  Also used (generic form) to turn row-major rows
-// into the (h, stats) pair the LN-prologue GEMM consumes.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void embed_rows_kernel(EmbedRowsArgs p) {
-    const int row = blockIdx.x;
-    const int tid = threadIdx.x;
-    const int D = p.D, NC = D >> 3, KS = D >> 4, NT = D >> 5;
-    for (int c = tid; c < NC; c += 256) {                 // chunk c = 8 features; 4 chunks per 32-col tile
-        float f[8];
-        if (p.rows) {
-            unpack8(*reinterpret_cast<const uint4*>(p.rows + (size_t)row * p.ld_rows + c * 8), f);
-        } else {
-            const int tok = p.tokens[row], pos = p.positions[row];
-            float a[8], w[8];
-            unpack8(*reinterpret_cast<const uint4*>(p.wte + (size_t)tok * D + c * 8), a);
-            if (p.wpe) {
-                unpack8(*reinterpret_cast<const uint4*>(p.wpe + (size_t)pos * D + c * 8), w);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = bfround(a[e] + w[e]);
-            } else {                    // rotary models: no learned position table
-#pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = a[e];
-            }
-        }
-        *reinterpret_cast<uint4*>(p.h_xp + xp_index(row >> 5, KS, row & 31, c * 8)) = pack8(f);
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { s1 += f[e]; s2 += f[e] * f[e]; }
-        // the 4 chunks of one tile sit in 4 consecutive lanes (NC % 4 == 0, 256 % 4 == 0)
-        s1 += __shfl_xor(s1, 1, 64); s2 += __shfl_xor(s2, 1, 64);
-        s1 += __shfl_xor(s1, 2, 64); s2 += __shfl_xor(s2, 2, 64);
-        if ((c & 3) == 0) p.stats[((size_t)(row >> 5) * NT + (c >> 2)) * 32 + (row & 31)] = make_float2(s1, s2);
-    }
-}
-void launch_embed_rows(const EmbedRowsArgs& a, hipStream_t st) { embed_rows_kernel<<<a.M, 256, 0, st>>>(a); }
-
-// f32 -> bf16 through the hardware convert used by the LN prologue (test surface)
+// f32 -> bf16 through the hardware convert every epilogue uses (test surface)
 __global__ void cvt_bf16_hw_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, size_t n) {
     const size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     if (i + 1 < n) {

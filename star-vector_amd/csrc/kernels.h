@@ -30,8 +30,6 @@ struct GemmArgs {
     int M, N, K;                     // K = padded K (multiple of 64) shared by A and Wp
     int act; int out_f32;
     const float* cscale = nullptr;   // fp8 weights: per-output-column scale applied to the accumulator (or nullptr)
-    int plain_order = 0;             // 1: the 128^2 kernel walks tiles in launch order (A/B switch SV_GEMM_ORDER=plain); 0: XCD-aware
-    int epi_regs = 0;                // 1: the register epilogue (row-per-lane stores) instead of the LDS-transposed one (A/B switch)
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 // what launch_gemm decides for a shape (host arithmetic only; tail_on: 0 never peel, 1 cost model, 2 always)
@@ -39,42 +37,22 @@ struct GemmPlan { int peel, tail_rows, tail_by_tiles, main_256; double est_us; }
 GemmPlan gemm_plan(int M, int N, int K, int act, int tail_on);
 
 // ---- skinny (M<=32 per tile) weight-streaming GEMM --------------------------------------------
-enum { SK_OUT_PARTIAL = 0, SK_OUT_PACKED_ACT = 1, SK_OUT_F32 = 2, SK_OUT_RESID = 3, SK_OUT_ROWMAJOR = 4 };
+enum { SK_OUT_PARTIAL = 0, SK_OUT_PACKED_ACT = 1, SK_OUT_F32 = 2 };
 struct SkinnyArgs {
-    const bf16_t* xp;                // packed activations [MT][K/16][64][8] (the raw residual stream h when ln_stats)
+    const bf16_t* xp;                // packed activations [MT][K/16][64][8]
     const bf16_t* Wp;                // packed weight [Npad/32][K/16][64][8]
     const uint8_t* Wq;               // fp8 image of the same weight (launch_pack_weight_fp8) or nullptr: then the fp8 kernel runs
     const float* wscale;             //   with its per-column scales [Npad]
-    const bf16_t* bias;              // [N] or nullptr
+    const bf16_t* bias;              // [N] or nullptr (PACKED_ACT only)
     int MT;                          // number of 32-row tiles
     int Npad, K;                     // Npad multiple of 32, K multiple of 16
     int splitk;                      // >=1; (K/16) must be divisible by splitk*waves
     int out_mode; int act;
     int N;                           // valid columns (<= Npad)
-    // LayerNorm prologue (optional): x = LN(h); statistics from per-32-column partial (sum, sumsq)
-    const float2* ln_stats; int ln_tiles;     // [MT][ln_tiles][32], ln_tiles = K/32
-    const bf16_t* ln_g; const bf16_t* ln_b; float ln_eps;
-    // split-K hand-off
-    float* ws; int ldws;             // fp32 slabs ws[split][MT*32][ldws]
-    unsigned* counters;              // [MT][Npad/32] arrival tickets, zero between launches
-    // outputs
-    bf16_t* out_xp; int out_KS;      // PACKED_ACT / RESID: fragment-order buffer with out_KS = Npad/16 k-steps
-    const bf16_t* resid_xp;          // RESID: residual stream (same layout; may alias out_xp)
-    float2* stats_out;               // RESID: [MT][Npad/32][32] LayerNorm partials of the new rows
-    bf16_t* out_rm; int ld_rm;       // ROWMAJOR: [MT*32][ld_rm]
+    float* ws; int ldws;             // PARTIAL: fp32 slabs ws[split][MT*32][ldws], summed in slab order by the consumer
+    bf16_t* out_xp; int out_KS;      // PACKED_ACT: fragment-order buffer with out_KS = Npad/16 k-steps
     float* out_f32; int ldo;         // F32: [MT*32][ldo]; rounded to bf16 values if round_bf16
     int round_bf16;
-    // overlapped row update (optional): the first ru_M blocks of the grid first produce one row each of THIS
-    // GEMM's activation operand (split-K slab sum + bias + residual + LayerNorm, or token embedding + LayerNorm)
-    // while every block's weight stream is already in flight; the others wait on `ru_ready`
-    int ru_M;                        // 0 = off
-    const float* ru_ws; int ru_splitk, ru_ldws, ru_rows_ws;      // slabs of the PREVIOUS GEMM (nullptr: embedding mode)
-    const bf16_t* ru_bias;
-    bf16_t* ru_h; int ru_ldh;        // residual stream rows [M][D] (row-major, in/out)
-    const bf16_t* ru_wte; const bf16_t* ru_wpe; const int32_t* ru_tokens; const int32_t* ru_positions;
-    const bf16_t* ru_g; const bf16_t* ru_b; float ru_eps;
-    unsigned* ru_ready;              // arrival counter of this launch site (zeroed at the start of the step)
-    int* ru_err;                     // set if the bounded wait gives up
 };
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st);
 // host arithmetic of the launch: waves per block (how K is cut inside a block = the summation order of a row) and whether a
@@ -82,43 +60,6 @@ void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st);
 void skinny_plan(int Npad, int K, int splitk, int fp8, int MT, int* waves, int* two_row_tiles);
 int init_gemm_kernels();        // hipFuncSetAttribute for the large-LDS variants (0 = ok)
 
-
-// ---- decode GEMMs with full K per block (decode_gemm.hip): no split-K slabs, LayerNorm as an in-block prologue -----
-enum { CO_ROWMAJOR = 0, CO_RESID_XP = 1, CO_F32 = 2 };
-struct ColsArgs {
-    const bf16_t* xp;                // packed activations [MT][K/16][64][8]; the RAW residual stream when ln_g is set
-    const bf16_t* Wp;                // packed weight [Npad/32][K/16][64][8] (the same image the 32-column kernels read)
-    const bf16_t* bias;              // [N] or nullptr
-    int MT, N, K;                    // K multiple of 32
-    int cpb;                         // output columns per block (1..16): cols_pick_cpb(N)
-    const bf16_t* ln_g; const bf16_t* ln_b; float ln_eps;     // LayerNorm prologue over K (nullptr: off)
-    int out_mode;
-    bf16_t* out_rm; int ld_rm;       // CO_ROWMAJOR: [MT*32][ld_rm] bf16 = bf(x W^T + b)
-    bf16_t* h_xp; int out_KS;        // CO_RESID_XP: residual stream in fragment order, N = 16 * out_KS columns: h = bf(h + bf(x W^T + b))
-    float* out_f32; int ldo;         // CO_F32 (test surface): fp32 x W^T + b
-};
-int cols_pick_cpb(int N);
-int launch_gemm_cols(const ColsArgs& a, hipStream_t st);        // 0 = ok, -1 = unsupported shape
-struct SkinnyLnArgs {
-    const bf16_t* xp;                // packed activations (raw residual stream when ln_g is set)
-    const bf16_t* Wp; const bf16_t* bias;
-    int MT, Npad, N, K;
-    const bf16_t* ln_g; const bf16_t* ln_b; float ln_eps;     // LayerNorm prologue (nullptr: off)
-    int out_mode; int act;           // SK_OUT_PACKED_ACT | SK_OUT_F32
-    bf16_t* out_xp; int out_KS;
-    float* out_f32; int ldo; int round_bf16;
-};
-int launch_gemm_skinny_ln(const SkinnyLnArgs& a, hipStream_t st);
-int init_decode_gemm_kernels();
-
-struct EmbedRowsArgs {
-    const bf16_t* rows; int ld_rows;                       // generic: row-major input rows; or nullptr:
-    const bf16_t* wte; const bf16_t* wpe;                  //   wte[tokens[row]] + wpe[positions[row]]
-    const int32_t* tokens; const int32_t* positions;
-    bf16_t* h_xp; float2* stats;                           // fragment-order rows + [MT][D/32][32] partials
-    int M, D;
-};
-void launch_embed_rows(const EmbedRowsArgs& a, hipStream_t st);
 void launch_cvt_bf16_hw(const float* x, bf16_t* y, size_t n, hipStream_t st);
 
 // ---- row kernels ---------------------------------------------------------------------------------
@@ -138,12 +79,8 @@ struct RowUpdateArgs {
     const bf16_t* g; const bf16_t* b; float eps;           // LayerNorm applied to the updated row
     bf16_t* xp_out;                                        // packed LN output
     int M, D;
-    const void* pf_ptr; size_t pf_bytes; int pf_blocks;    // extra blocks [M, M + pf_blocks) prefetch the next GEMM's weights (or 0)
 };
 void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st);
-
-void launch_ln_apply_packed(const bf16_t* hxp, const float2* stats, const bf16_t* g, const bf16_t* b, bf16_t* yxp,
-                            int M, int D, float eps, hipStream_t st);
 
 // ---- embeddings ---------------------------------------------------------------------------------
 void launch_im2col(const bf16_t* img, bf16_t* out, int B, int img_size, int patch, int Kpad, hipStream_t st);
@@ -184,9 +121,8 @@ void launch_kv_write_prefill(const bf16_t* qkv, int row_stride, int k_off, int v
                              hipStream_t st);
 
 struct AttnDecodeArgs {
-    const bf16_t* qkv; int ld_qkv;                         // c_attn output rows [B][ld] bf16 (bias added); or nullptr:
-    const float* ws; int splitk; int ldws; int rows_ws;   //   legacy fp32 split-K slabs [splitk][rows][ldws]
-    const bf16_t* bias;                                    //   + c_attn bias [H*D + 2*D]
+    const float* ws; int splitk; int ldws; int rows_ws;   // c_attn output as fp32 split-K slabs [splitk][rows][ldws], summed here in slab order
+    const bf16_t* bias;                                    //   + c_attn bias [H*D + 2*n_kv*D]
     char* pool_layer;                                      // this layer's page pool
     const int32_t* block_table; int max_pages;
     const int32_t* positions;                              // [B] index of the new token (= tokens already cached)
@@ -199,7 +135,6 @@ struct AttnDecodeArgs {
     size_t kv_head_stride;                                 // bytes between the page pools of consecutive KV heads
     const float* rope_cos; const float* rope_sin;          // [positions][D/2] rotary tables (nullptr: no RoPE)
     int window;                                            // sliding window: keys pos - window < j <= pos (0 = all)
-    const void* pf_ptr; size_t pf_bytes;                   // the always-inactive splits prefetch the next GEMM's weights (or null)
 };
 // in-place rotary embedding of the q and k heads of a prefill c_attn output (rotate_half convention)
 void launch_rope_prefill(bf16_t* qkv, int row_stride, int rows, int S0, int n_heads, int head_dim,

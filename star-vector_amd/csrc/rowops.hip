@@ -125,10 +125,6 @@ __global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
     __shared__ float redbuf[8];
     const int row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (row >= p.M) {       // spare blocks: stream the next GEMM's weights towards L2 / the Infinity Cache (a hint only)
-        sv_prefetch_slice(p.pf_ptr, p.pf_bytes, row - p.M, p.pf_blocks, tid, 256);
-        return;
-    }
     const int D = p.D, NC = D >> 3;
     bf16_t* hr = p.h + (size_t)row * p.ldh;
 
@@ -238,49 +234,7 @@ __global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
 }
 
 void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st) {
-    row_update_ln_kernel<<<a.M + (a.pf_ptr ? a.pf_blocks : 0), 256, a.D * sizeof(float), st>>>(a);
-}
-
-// ------------------------------------------------------------------------------------------------
-// decode: y = LN(h) for rows held in fragment order, statistics from the per-32-column partials left by
-// the producer GEMM (summed in tile order).  One block per row.  Used once per step for ln_f.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ln_apply_packed_kernel(const bf16_t* __restrict__ hxp,
-                                                              const float2* __restrict__ stats,
-                                                              const bf16_t* __restrict__ g,
-                                                              const bf16_t* __restrict__ b,
-                                                              bf16_t* __restrict__ yxp, int D, float eps) {
-    __shared__ float red[2][4];
-    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int NT = D >> 5, KS = D >> 4, NC = D >> 3;
-    float s1 = 0.f, s2 = 0.f;
-    for (int t = tid; t < NT; t += 256) {
-        const float2 v = stats[((size_t)(row >> 5) * NT + t) * 32 + (row & 31)];
-        s1 += v.x; s2 += v.y;
-    }
-    s1 = wave_sum(s1); s2 = wave_sum(s2);
-    if (lane == 0) { red[0][wave] = s1; red[1][wave] = s2; }
-    __syncthreads();
-    const float a = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    const float q = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-    const float mean = a / (float)D;
-    float var = q / (float)D - mean * mean;
-    var = var > 0.f ? var : 0.f;
-    const float rstd = rsqrtf(var + eps), rb = -mean * rstd;
-    for (int c = tid; c < NC; c += 256) {
-        const size_t off = xp_index(row >> 5, KS, row & 31, c * 8);
-        float f[8], gg[8], bb[8];
-        unpack8(*reinterpret_cast<const uint4*>(hxp + off), f);
-        unpack8(*reinterpret_cast<const uint4*>(g + c * 8), gg);
-        unpack8(*reinterpret_cast<const uint4*>(b + c * 8), bb);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = fmaf(fmaf(f[e], rstd, rb), gg[e], bb[e]);
-        *reinterpret_cast<uint4*>(yxp + off) = pack8(f);
-    }
-}
-void launch_ln_apply_packed(const bf16_t* hxp, const float2* stats, const bf16_t* g, const bf16_t* b, bf16_t* yxp,
-                            int M, int D, float eps, hipStream_t st) {
-    ln_apply_packed_kernel<<<M, 256, 0, st>>>(hxp, stats, g, b, yxp, D, eps);
+    row_update_ln_kernel<<<a.M, 256, a.D * sizeof(float), st>>>(a);
 }
 
 // ------------------------------------------------------------------------------------------------

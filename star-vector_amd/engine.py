@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from dataclasses import dataclass
 from typing import Dict, Iterable, List, Optional, Sequence
 
@@ -88,6 +89,10 @@ class HipEngine:
         check(self.lib.sv_create(C.byref(c), C.byref(h)), "sv_create")
         self._h = h
         self._dev = torch.device("cuda", self.device)
+        # One multi-call sequence at a time per engine: a padded batch run as slots (cb_reset ... cb_reset), a classic
+        # generate, a scoring forward.  The library serialises single calls with its own mutex; THIS lock keeps two host
+        # threads from interleaving their call sequences (thread B's cb_reset would release thread A's slots).
+        self.call_lock = threading.RLock()
 
     def close(self):
         if getattr(self, "_h", None):
@@ -423,53 +428,24 @@ def op_linear_skinny_fp8(x, W, bias=None, splitk=1):
     return y, sc
 
 
-def op_decode_linear(h, W, bias=None, gamma=None, beta=None, residual=None, act="none", splitk=1, eps=1e-5):
-    """Returns (y bf16 [M,N], row_stats f32 [M,2] or None)."""
-    lib = _lib.load()
-    h = _need(h, torch.bfloat16, "h"); W = _need(W, torch.bfloat16, "W")
-    M, K = h.shape; N = W.shape[0]
-    y = torch.empty(M, N, dtype=torch.bfloat16, device=h.device)
-    opt = lambda t, n: _need(t, torch.bfloat16, n) if t is not None else None
-    b, g, be, r = opt(bias, "bias"), opt(gamma, "gamma"), opt(beta, "beta"), opt(residual, "residual")
-    stats = torch.empty(M, 2, dtype=torch.float32, device=h.device) if residual is not None else None
-    check(lib.sv_op_decode_linear(_ptr(h), _ptr(g), _ptr(be), float(eps), _ptr(W), _ptr(b), _ptr(r), _ptr(y), _ptr(stats),
-                                  M, N, K, splitk, _lib.ACT[act], _stream()))
-    return y, stats
-
-
-def op_decode_cols(x, W, bias=None, gamma=None, beta=None, residual=None, cpb=0, out_f32=False, eps=1e-5):
-    """One full-K decode GEMM (csrc/decode_gemm.hip): y = LN_opt(x) . W^T + bias (+ residual, rounded like the reference's
-    bf16 residual add).  Returns bf16 [M, N] (float32 when out_f32)."""
-    lib = _lib.load()
-    x = _need(x, torch.bfloat16, "x"); W = _need(W, torch.bfloat16, "W")
-    M, K = x.shape; N = W.shape[0]
-    y = torch.empty(M, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
-    opt = lambda t, n: _need(t, torch.bfloat16, n) if t is not None else None
-    b, g, be, r = opt(bias, "bias"), opt(gamma, "gamma"), opt(beta, "beta"), opt(residual, "residual")
-    check(lib.sv_op_decode_cols(_ptr(x), _ptr(g), _ptr(be), float(eps), _ptr(W), _ptr(b), _ptr(r), _ptr(y), M, N, K, int(cpb),
-                                int(out_f32), _stream()), "sv_op_decode_cols")
-    return y
-
-
-def op_decode_skinny_ln(x, W, gamma, beta, bias=None, act="none", out_f32=False, eps=1e-5):
-    """The 32-column-tile decode GEMM with the in-block LayerNorm prologue: act(LN(x) . W^T + bias) as bf16 rows, or (out_f32)
-    the lm_head form: float32 rows of bf16-rounded values."""
+def op_linear_skinny_epi(x, W, bias=None, act="none", out_f32=False):
+    """The decode GEMM's fused epilogues (split-K 1): act(bf16(x W^T + bias)) as bf16 rows (the c_fc form), or with out_f32
+    the lm_head form: float32 rows of x W^T holding bf16-rounded values (no bias)."""
     lib = _lib.load()
     x = _need(x, torch.bfloat16, "x"); W = _need(W, torch.bfloat16, "W")
     M, K = x.shape; N = W.shape[0]
     y = torch.empty(M, N, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     b = _need(bias, torch.bfloat16, "bias") if bias is not None else None
-    check(lib.sv_op_decode_skinny_ln(_ptr(x), _ptr(_need(gamma, torch.bfloat16, "gamma")), _ptr(_need(beta, torch.bfloat16, "beta")),
-                                     float(eps), _ptr(W), _ptr(b), _ptr(y), M, N, K, _lib.ACT[act], int(out_f32), _stream()),
-          "sv_op_decode_skinny_ln")
+    check(lib.sv_op_linear_skinny_epi(_ptr(x), _ptr(W), _ptr(b), _ptr(y), M, N, K, _lib.ACT[act], int(out_f32), _stream()),
+          "sv_op_linear_skinny_epi")
     return y
 
 
-def bench_decode_gemm(M: int, N: int, K: int, kind: int, cpb: int = 0, iters: int = 50) -> float:
-    """Average microseconds per launch of one decode GEMM (kinds: see include/starvector_hip.h)."""
+def bench_decode_linear(M: int, N: int, K: int, splitk: int = 1, mode: int = 0, iters: int = 100) -> float:
+    """Average microseconds per launch of one decode GEMM (mode 0 fp32 slabs, 1 bias + GELU, 2 fp32 logits)."""
     lib = _lib.load()
     us = C.c_double(0.0)
-    check(lib.sv_bench_decode_gemm(M, N, K, kind, cpb, iters, C.byref(us), _stream()), "sv_bench_decode_gemm")
+    check(lib.sv_bench_decode_linear(M, N, K, splitk, mode, iters, C.byref(us), _stream()), "sv_bench_decode_linear")
     return us.value
 
 

@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import json
 import os
+import contextlib
 import threading
 from typing import Dict, List, Optional, Sequence
 
@@ -485,6 +486,19 @@ class HipCausalLM(_EngineModule):
                     top_p=float(kw.get("top_p") if kw.get("top_p") is not None else 1.0), top_k=int(kw.get("top_k") or 0),
                     repetition_penalty=float(kw.get("repetition_penalty") or 1.0), min_new_tokens=min_new)
         slot_of = [None] * B
+        lock = getattr(eng, "call_lock", None) or contextlib.nullcontext()
+        with lock:            # from the first cb_reset to the last: another thread's generate must not reset or admit in between
+            outs, fired_len = self._run_slots(eng, inputs_embeds, mask, lengths, base, seed, stop, slot_of)
+        L = fired_len if fired_len is not None else max(t.shape[0] for t in outs)
+        res = torch.full((B, L), pad, dtype=torch.long, device=inputs_embeds.device)
+        for b, t in enumerate(outs):
+            k = min(L, t.shape[0])
+            res[b, :k] = t[:k].to(res.device)
+        return res
+
+    @staticmethod
+    def _run_slots(eng, inputs_embeds, mask, lengths, base, seed, stop, slot_of):
+        B = inputs_embeds.shape[0]
         eng.cb_reset()
         try:
             for n in sorted(set(lengths)):
@@ -509,12 +523,7 @@ class HipCausalLM(_EngineModule):
             outs = [eng.cb_read(slot_of[b], 0, st[slot_of[b]]) for b in range(B)]
         finally:
             eng.cb_reset()
-        L = fired_len if fired_len is not None else max(t.shape[0] for t in outs)
-        res = torch.full((B, L), pad, dtype=torch.long, device=inputs_embeds.device)
-        for b, t in enumerate(outs):
-            k = min(L, t.shape[0])
-            res[b, :k] = t[:k].to(res.device)
-        return res
+        return outs, fired_len
 
     @torch.no_grad()
     def generate(self, inputs_embeds: torch.Tensor = None, attention_mask: Optional[torch.Tensor] = None,
@@ -615,7 +624,19 @@ class HipCausalLM(_EngineModule):
             if streamer is not None:
                 streamer.end()
             return out
-        out = self._engine.generate(
+        lock = getattr(self._engine, "call_lock", None) or contextlib.nullcontext()
+        with lock:          # the same lock the slot path holds: a classic generate never lands between its cb_reset / cb_admit
+            out = self._classic_generate(inputs_embeds, max_length, do_sample, temperature, top_p, eos_token_id, pad_token_id,
+                                         stopping_criteria, seed, repetition_penalty, num_beams, length_penalty, early_stopping,
+                                         top_k, on_tokens, streamer, min_new)
+        if streamer is not None:
+            streamer.end()
+        return out
+
+    def _classic_generate(self, inputs_embeds, max_length, do_sample, temperature, top_p, eos_token_id, pad_token_id,
+                          stopping_criteria, seed, repetition_penalty, num_beams, length_penalty, early_stopping, top_k,
+                          on_tokens, streamer, min_new):
+        return self._engine.generate(
             inputs_embeds.to(torch.bfloat16), max_length=int(max_length), do_sample=bool(do_sample),
             temperature=float(temperature if temperature is not None else 1.0),
             top_p=float(top_p if top_p is not None else 1.0),
@@ -626,9 +647,6 @@ class HipCausalLM(_EngineModule):
             num_beams=num_beams, length_penalty=float(length_penalty if length_penalty is not None else 1.0),
             early_stopping=early_stopping, top_k=int(top_k or 0), on_tokens=on_tokens,
             sync_every=8 if streamer is not None else 32, **({"min_new_tokens": min_new} if min_new else {}))
-        if streamer is not None:
-            streamer.end()
-        return out
 
 
 class StoppingCriteriaSub:
@@ -857,7 +875,21 @@ class StarVectorForCausalLM(nn.Module):
                 raise ValueError(f"attention_mask {tuple(m.shape)} does not cover inputs_embeds {tuple(inputs_embeds.shape[:2])}")
             if bool((m[:, 1:] & ~m[:, :-1]).any()) or not bool(m[:, 0].all()):
                 raise NotImplementedError("only right-padded attention masks are built for the scoring forward")
-        logits = self.engine.forward_logits(inputs_embeds.to(torch.bfloat16), int(num_logits_to_keep or 0))
+        emb16, keep = inputs_embeds.to(torch.bfloat16), int(num_logits_to_keep or 0)
+        batcher = getattr(self.model.svg_transformer.transformer, "batcher", None)
+        if batcher is not None and not _in_exclusive_job():
+            # requests share the engine's decode loop: the scoring pass wants the engine to itself (it would fail with SV_ESTATE
+            # while slots are live) -> queue it as an exclusive job, FIFO with the generation requests
+            def call():
+                _EXCLUSIVE.active = True
+                try:
+                    return self.engine.forward_logits(emb16, keep)
+                finally:
+                    _EXCLUSIVE.active = False
+            logits = batcher.run_exclusive(call)
+        else:
+            with (getattr(self.engine, "call_lock", None) or contextlib.nullcontext()):
+                logits = self.engine.forward_logits(emb16, keep)
         try:
             from transformers.modeling_outputs import CausalLMOutputWithCrossAttentions
             return CausalLMOutputWithCrossAttentions(loss=None, logits=logits, past_key_values=None, hidden_states=None,

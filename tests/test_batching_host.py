@@ -222,3 +222,63 @@ def test_exclusive_jobs_take_the_engine_in_turn():
         b.run_exclusive(lambda: 1 / 0)                      # the job's exception reaches its caller, the loop lives on
     assert b.generate(_emb(7), dict(max_new_tokens=3))[0].tolist() == [7, 8, 9]
     b.close()
+
+
+def test_request_that_never_fits_fails_instead_of_spinning_the_scheduler():
+    """A request whose budget exceeds what an IDLE engine can hold gets SV_EBUSY from every admit: with nothing running no
+    release will ever make room, so it must fail with an error (and the ones behind it be served), not keep the scheduler
+    thread in a busy loop while its caller hangs."""
+    eng = _CbEngine(max_batch=4, page_budget=12)
+    b = ContinuousBatcher(eng, steps_per_poll=1)
+    big = b.submit(_emb(1), dict(max_new_tokens=40))            # 40 > the 12-token page budget of the whole engine
+    ok = b.submit(_emb(7), dict(max_new_tokens=4))
+    with pytest.raises(StarVectorBusy):
+        big.result(timeout=20)
+    assert ok.result(timeout=20)[0].tolist() == [7, 8, 9, 10]
+    assert not eng.slots
+    b.close()
+
+
+def test_padded_batches_from_two_threads_do_not_reset_each_other():
+    """The mirror runs a padded multi-row batch as slots: cb_reset, cb_admit per length group, cb_step ..., cb_read, cb_reset.
+    Two host threads doing that on one engine must take turns for the WHOLE sequence (the engine's call_lock), otherwise one
+    thread's cb_reset releases the other's slots."""
+    from starvector_amd.model import HipCausalLM
+
+    class _Eng(_CbEngine):
+        def __init__(self):
+            super().__init__(max_batch=4, delay=0.005)
+            self.call_lock = threading.RLock()
+            self.resets_while_live = 0
+
+        def cb_reset(self):
+            with self.lock:
+                if any(v["live"] for v in self.slots.values()):
+                    self.resets_while_live += 1
+            super().cb_reset()
+
+    eng = _Eng()
+    lm = HipCausalLM.__new__(HipCausalLM)
+    torch.nn.Module.__init__(lm)
+    object.__setattr__(lm, "_engine", eng)
+    lm.eos_token_id, lm.pad_token_id, lm.seed, lm.batcher = -1, 0, None, None
+    out, err = {}, []
+
+    def run(i):
+        try:
+            emb = torch.stack([torch.full((4, 8), float(10 * i)), torch.full((4, 8), float(10 * i + 5))])
+            mask = torch.tensor([[1, 1, 1, 1], [0, 1, 1, 1]])          # row 1 is left-padded: two length groups
+            out[i] = lm.generate(inputs_embeds=emb, attention_mask=mask, max_length=4 + 6, eos_token_id=-1, pad_token_id=0)
+        except BaseException as e:       # noqa: BLE001
+            err.append(e)
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=60)
+    assert not err, err
+    assert eng.resets_while_live == 0
+    for i in range(3):
+        assert out[i].shape == (2, 6)
+        assert out[i][0].tolist() == [10 * i + k for k in range(6)] and out[i][1].tolist() == [10 * i + 5 + k for k in range(6)]

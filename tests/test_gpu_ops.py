@@ -129,36 +129,40 @@ def test_linear_skinny_two_row_tiles_per_block_is_bitwise_the_one_tile_kernel(M,
     b = (0.1 * torch.randn(N, generator=g)).bfloat16().float()
     two = E.op_linear_skinny(bf(x), bf(W), bf(b), splitk=sk)
     two8, sc = E.op_linear_skinny_fp8(bf(x), bf(W), bf(b), splitk=sk)
-    os.environ["SV_SKINNY_MT2"] = "0"
-    try:
-        one = E.op_linear_skinny(bf(x), bf(W), bf(b), splitk=sk)
-        one8, _ = E.op_linear_skinny_fp8(bf(x), bf(W), bf(b), splitk=sk)
-    finally:
-        os.environ.pop("SV_SKINNY_MT2", None)
-    assert torch.equal(two, one) and torch.equal(two8, one8)
     assert rel_err(two, x @ W.T + b) <= 1e-5
-    # rows of the second tile alone (a one-tile launch) give the same bits: batch composition cannot change a row
-    assert torch.equal(E.op_linear_skinny(bf(x[32:M]), bf(W), bf(b), splitk=sk), two[32:M])
+    # each row tile alone (<= 32 rows: the one-tile-per-block kernel) gives the same bits as inside the two-tile launch: batch
+    # composition cannot change a row
+    for lo, hi in ((0, 32), (32, M)):
+        assert torch.equal(E.op_linear_skinny(bf(x[lo:hi]), bf(W), bf(b), splitk=sk), two[lo:hi])
+        assert torch.equal(E.op_linear_skinny_fp8(bf(x[lo:hi]), bf(W), bf(b), splitk=sk)[0], two8[lo:hi])
 
 
-@pytest.mark.parametrize("M,N,K,sk", [(32, 2048, 8192, 8), (7, 49156, 2048, 1), (32, 2304, 4096, 4), (20, 16384, 2048, 1),
-                                       (64, 2048, 8192, 8)])
-def test_linear_skinny_two_column_tiles_per_wave_is_bitwise_the_one_tile_kernel(M, N, K, sk):
-    """Two 32-column tiles per wave share one activation fragment (an experiment kept behind SV_SKINNY_NT2=1); K is cut exactly as
-    the one-tile kernel cuts it, so the bits are the same (odd tile counts, several split-K factors, 64 rows = the two-row-tile
-    kernel takes over and must agree as well)."""
-    g = torch.Generator().manual_seed(M + N + K + sk)
+@pytest.mark.parametrize("M,N,K,act", [(32, 8192, 2048, "gelu_tanh"), (5, 512, 256, "none"), (40, 256, 1024, "gelu_tanh"),
+                                        (3, 96, 64, "swish"), (64, 18432, 4608, "gelu_tanh"), (17, 40, 32, "quickgelu")])
+def test_linear_skinny_fused_activation_epilogue(M, N, K, act):
+    """The c_fc form of the decode GEMM: bias, round to bf16 (the reference's Linear output), activation, round -- in the kernel's
+    epilogue, fragment-order output."""
+    g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g).bfloat16().float()
     W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().float()
     b = (0.1 * torch.randn(N, generator=g)).bfloat16().float()
-    one = E.op_linear_skinny(bf(x), bf(W), bf(b), splitk=sk)
-    os.environ["SV_SKINNY_NT2"] = "1"                     # the experiment is off by default (measured: no gain)
-    try:
-        two = E.op_linear_skinny(bf(x), bf(W), bf(b), splitk=sk)
-    finally:
-        os.environ.pop("SV_SKINNY_NT2", None)
-    assert torch.equal(two, one)
-    assert rel_err(two, x @ W.T + b) <= 1e-5
+    y = (x @ W.T + b).bfloat16().float()
+    y = {"gelu_tanh": lambda t: torch.nn.functional.gelu(t, approximate="tanh"), "swish": lambda t: t * torch.sigmoid(t),
+         "quickgelu": lambda t: t * torch.sigmoid(1.702 * t), "none": lambda t: t}[act](y)
+    got = E.op_linear_skinny_epi(bf(x), bf(W), bf(b), act=act)
+    assert rel_err(got, y) <= 2.2 * BF16_1ULP and mean_err(got, y) <= 1.5e-3
+    assert torch.equal(got, E.op_linear_skinny_epi(bf(x), bf(W), bf(b), act=act))
+
+
+@pytest.mark.parametrize("M,V,K", [(32, 49156, 2048), (3, 1000, 256), (64, 49157, 4608)])
+def test_linear_skinny_logits_epilogue(M, V, K):
+    """The lm_head form: fp32 rows holding bf16-rounded values (HF casts the bf16 logits to float before the argmax)."""
+    g = torch.Generator().manual_seed(M + V + K)
+    x = torch.randn(M, K, generator=g).bfloat16().float()
+    W = (torch.randn(V, K, generator=g) / K ** 0.5).bfloat16().float()
+    got = E.op_linear_skinny_epi(bf(x), bf(W), out_f32=True).cpu()
+    assert torch.equal(got, got.bfloat16().float())                      # every value is a bf16 value
+    assert rel_err(got, x @ W.T) <= 1.1 * BF16_1ULP
 
 
 @pytest.mark.parametrize("B,S,H,Hkv,hd,causal", [
@@ -264,44 +268,6 @@ def test_bf16_rounding_is_rne():
     assert torch.equal(y, expect)
 
 
-@pytest.mark.parametrize("M,N,K,sk,ln,res,act", [
-    (32, 2304, 2048, 4, True, False, "none"),      # c_attn: LN1 prologue, split-K ticket, row-major q|k|v
-    (32, 2048, 2048, 4, False, True, "none"),      # attn c_proj: ticket + residual + LN statistics
-    (32, 8192, 2048, 1, True, False, "gelu_tanh"), # c_fc: LN2 prologue + GELU
-    (32, 2048, 8192, 4, False, True, "none"),      # mlp c_proj
-    (5, 512, 256, 8, True, False, "none"), (40, 256, 1024, 2, False, True, "none"), (3, 96, 64, 1, True, False, "swish"),
-])
-def test_decode_linear_fused(M, N, K, sk, ln, res, act):
-    g = torch.Generator().manual_seed(M + N + K + sk)
-    h = (torch.randn(M, K, generator=g) * 1.5 + 0.2).bfloat16().float()
-    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().float()
-    b = (0.1 * torch.randn(N, generator=g)).bfloat16().float()
-    gam = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().float()
-    bet = (0.1 * torch.randn(K, generator=g)).bfloat16().float()
-    r = torch.randn(M, N, generator=g).bfloat16().float()
-    x = torch.nn.functional.layer_norm(h, (K,), gam, bet, 1e-5).bfloat16().float() if ln else h
-    y = (x @ W.T + b).bfloat16().float()
-    if act == "gelu_tanh":
-        y = torch.nn.functional.gelu(y, approximate="tanh")
-    elif act == "swish":
-        y = y * torch.sigmoid(y)
-    if res:
-        y = y.bfloat16().float() + r
-    got, stats = E.op_decode_linear(bf(h), bf(W), bf(b), bf(gam) if ln else None, bf(bet) if ln else None,
-                                    bf(r) if res else None, act=act, splitk=sk)
-    assert not torch.isnan(got.float()).any()
-    # LN-prologue inputs are bf16-rounded before the GEMM, so a 1-ulp flip of x moves y by ~|W| * ulp
-    assert rel_err(got, y) <= (4 if ln else 2.2) * BF16_1ULP and mean_err(got, y) <= 1.5e-3
-    if res:
-        gg = got.float().cpu()
-        torch.testing.assert_close(stats.cpu()[:, 0], gg.sum(-1), rtol=1e-5, atol=1e-3)
-        torch.testing.assert_close(stats.cpu()[:, 1], (gg * gg).sum(-1), rtol=1e-5, atol=1e-3)
-    # ticket-elected reducer sums slabs in slab order: bitwise repeatable
-    got2, _ = E.op_decode_linear(bf(h), bf(W), bf(b), bf(gam) if ln else None, bf(bet) if ln else None,
-                                 bf(r) if res else None, act=act, splitk=sk)
-    assert torch.equal(got, got2)
-
-
 @pytest.mark.parametrize("w,h,c", [(224, 224, 3), (300, 300, 3), (100, 60, 4), (517, 333, 3), (64, 200, 4), (1024, 768, 3),
                                    (50, 50, 4), (223, 225, 4), (2048, 1536, 3), (1, 1, 3)])
 def test_preprocess_image_bit_exact(w, h, c):
@@ -396,90 +362,3 @@ def test_preprocess_images_batched_stateless_bit_exact():
         assert np.array_equal(sig[i].cpu().numpy().view(np.int32), P.preprocess_siglip(imgs[i]).view(np.int32)), i
     with pytest.raises(ValueError):
         E.op_preprocess_images([], 224, P.CLIP_MEAN, P.CLIP_STD)
-
-
-# ---- the full-K decode GEMMs (csrc/decode_gemm.hip): the default decode pipeline's kernels, one at a time -------------
-def _ln_ref(x, w, b, eps=1e-5):
-    return torch.nn.functional.layer_norm(x, (x.shape[-1],), w, b, eps).bfloat16().float()      # the reference's bf16 LayerNorm output
-
-
-@pytest.mark.parametrize("M,N,K,cpb", [
-    (32, 2048, 2048, 0),        # attention c_proj (1B): 8 columns per block, 16 waves x 4 chunks
-    (32, 2048, 8192, 0),        # MLP c_proj (1B): 16 chunks per wave, streamed in groups
-    (5, 2304, 2048, 0),         # c_attn width: 9 columns per block
-    (40, 256, 1024, 0),         # two row tiles (tiny MLP c_proj)
-    (16, 4608, 18432, 0),       # StarVector-8B MLP c_proj
-    (3, 516, 256, 7), (32, 96, 64, 16), (33, 70, 96, 1),      # odd widths / ragged last block / one column per block
-])
-def test_decode_cols_matches_float32(M, N, K, cpb):
-    g = torch.Generator().manual_seed(M + 3 * N + K)
-    x = torch.randn(M, K, generator=g).bfloat16().float()
-    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().float()
-    b = (0.1 * torch.randn(N, generator=g)).bfloat16().float()
-    ref = x @ W.T + b
-    got32 = E.op_decode_cols(bf(x), bf(W), bf(b), cpb=cpb, out_f32=True)
-    assert rel_err(got32, ref) <= 2e-5                                   # fp32 accumulation: order only
-    got = E.op_decode_cols(bf(x), bf(W), bf(b), cpb=cpb)
-    assert rel_err(got, ref) <= 1.1 * BF16_1ULP
-    if N % 16 == 0:
-        r = torch.randn(M, N, generator=g).bfloat16().float()
-        want = (r + ref.bfloat16().float())                             # h = bf(h + bf(x W^T + b)): gpt_bigcode :694-755
-        res = E.op_decode_cols(bf(x), bf(W), bf(b), residual=bf(r), cpb=cpb)
-        assert rel_err(res, want) <= 1.1 * BF16_1ULP and mean_err(res, want) <= 6e-4
-
-
-@pytest.mark.parametrize("M,N,K", [(32, 2304, 2048), (7, 2304, 2048), (40, 512, 256), (16, 5632, 4608), (9, 640, 768)])
-def test_decode_cols_layernorm_prologue(M, N, K):
-    """LayerNorm computed INSIDE the GEMM block (two-pass statistics over the rows the block reads anyway)."""
-    g = torch.Generator().manual_seed(11 * M + N + K)
-    h = (1.5 * torch.randn(M, K, generator=g) + 0.3).bfloat16().float()
-    gam = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().float()
-    bet = (0.1 * torch.randn(K, generator=g)).bfloat16().float()
-    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().float()
-    b = (0.1 * torch.randn(N, generator=g)).bfloat16().float()
-    ref = _ln_ref(h, gam, bet) @ W.T + b
-    first = E.op_decode_cols(bf(h), bf(W), bf(b), gamma=bf(gam), beta=bf(bet), out_f32=True)
-    got = E.op_decode_cols(bf(h), bf(W), bf(b), gamma=bf(gam), beta=bf(bet), out_f32=True)
-    # the LayerNorm output is rounded to bf16 before the GEMM on both sides; a 1-ulp flip of one normalised value moves an
-    # output by <= 2^-8 |x| |W| ~ 1e-4 of the output scale
-    assert rel_err(got, ref) <= 1e-3 and mean_err(got, ref) <= 2e-5
-    # OPEN ISSUE of this opt-in kernel (csrc/decode_gemm.hip::launch_gemm_cols, profiles/cols_ln_first_launch_r02.log): on about
-    # half of the pool's GPUs the FIRST launch on new data, in a process that has already run other kernels, returns rows
-    # 16..31 of a few column blocks 2e-3 .. 8e-3 off (the launch above, on the same data, is then exact).  Recorded, not hidden:
-    # the first result must at least be that close, and a clean first launch is reported.
-    assert rel_err(first, ref) <= 2e-2
-    if rel_err(first, ref) > 1e-3:
-        import warnings
-        warnings.warn(f"in-block LayerNorm GEMM: first launch off by {rel_err(first, ref):.2e} (known open issue)")
-    rows = E.op_decode_cols(bf(h), bf(W), bf(b), gamma=bf(gam), beta=bf(bet))
-    assert rel_err(rows, ref) <= 1.2 * BF16_1ULP
-
-
-@pytest.mark.parametrize("M,N,K,act", [(32, 8192, 2048, "gelu_tanh"), (3, 1024, 256, "gelu_tanh"), (40, 1024, 768, "none"),
-                                       (16, 18432, 4608, "gelu_tanh")])
-def test_decode_skinny_ln_activation(M, N, K, act):
-    g = torch.Generator().manual_seed(5 * M + N + K)
-    h = (1.5 * torch.randn(M, K, generator=g) - 0.2).bfloat16().float()
-    gam = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().float()
-    bet = (0.1 * torch.randn(K, generator=g)).bfloat16().float()
-    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().float()
-    b = (0.1 * torch.randn(N, generator=g)).bfloat16().float()
-    y = (_ln_ref(h, gam, bet) @ W.T + b).bfloat16().float()               # the Linear output is rounded before the activation
-    if act == "gelu_tanh":
-        y = torch.nn.functional.gelu(y, approximate="tanh")
-    got = E.op_decode_skinny_ln(bf(h), bf(W), bf(gam), bf(bet), bias=bf(b), act=act)
-    assert rel_err(got, y) <= 2.2 * BF16_1ULP and mean_err(got, y) <= 6e-4
-
-
-@pytest.mark.parametrize("M,V,K", [(32, 49156, 2048), (2, 516, 256), (16, 49157, 4608)])
-def test_decode_skinny_ln_logits(M, V, K):
-    """lm_head form: ln_f prologue, no bias, float32 logits holding bf16-rounded values (HF casts bf16 logits to float)."""
-    g = torch.Generator().manual_seed(M + V + K)
-    h = (2.0 * torch.randn(M, K, generator=g)).bfloat16().float()
-    gam = (1 + 0.1 * torch.randn(K, generator=g)).bfloat16().float()
-    bet = (0.1 * torch.randn(K, generator=g)).bfloat16().float()
-    W = (0.02 * torch.randn(V, K, generator=g)).bfloat16().float()
-    ref = _ln_ref(h, gam, bet) @ W.T
-    got = E.op_decode_skinny_ln(bf(h), bf(W), bf(gam), bf(bet), out_f32=True)
-    assert got.dtype == torch.float32 and torch.equal(got, got.bfloat16().float())      # values are bf16-exact
-    assert rel_err(got, ref) <= 1.2 * BF16_1ULP

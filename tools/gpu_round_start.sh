@@ -1,28 +1,55 @@
 #!/usr/bin/env bash
-# One gpurun call that re-establishes the round's baseline on a fresh MI355X box (about 6 GPU-minutes):
-#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/gpu_round_start.sh r02'
-# Writes everything under gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
+# ONE parameterised script for the GPU box (replaces round 2's 41 one-shot scripts).  Usage, from the repo root on the box:
+#   bash tools/gpu_round_start.sh <tag> [steps...]      steps (default "pytest bench"), run in the order given:
+#     pytest      the whole GPU suite through the C ABI            -> gpurun_out/<tag>/pytest_gpu.log
+#     pytest:<k>  only tests matching -k <k>
+#     bench       the headline line (BASELINE config 2)            -> bench_n1.json
+#     bench8b     configs 4 and 5 per-GPU workloads (256 tokens)   -> bench_8b_*.json
+#     rocprof     rocprofv3 --kernel-trace --stats of the headline -> rocprof_kernel_stats.csv, rocprof_by_grid.csv
+#     pmc         FETCH_SIZE / WRITE_SIZE / MFMA-busy passes        -> pmc_*.json  (kernel-trace only: never with sys-trace)
+#     smoke       __graft_entry__.smoke()
+#     ctx         tools/ctx_sweep.py                                -> ctx_sweep.log
+#     skinny      tools/bench_skinny.py                             -> bench_skinny.log
+#     env:<K=V>   export K=V for the steps that follow (experiment switches)
+# Everything lands under gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
 set -u
-TAG="${1:-rXX}"
+TAG="${1:-rXX}"; shift || true
+STEPS=("$@"); [ ${#STEPS[@]} -eq 0 ] && STEPS=(pytest bench)
 OUT="gpurun_out/${TAG}"
 mkdir -p "$OUT"
 export TMPDIR=/tmp
+ROOT="${GRAFT_REPO_ROOT:-$PWD}"
 bash tools/box_info.sh > "$OUT/box.txt" 2>&1        # results have differed between the pool's GPUs: keep the identity
-
-# 1. parity: the whole GPU suite through the C ABI
-timeout 400 python -m pytest tests -m gpu -q 2>&1 | tail -40 > "$OUT/pytest_gpu.log"
-
-# 2. the headline line (BASELINE config 2) and the secondary ones
-timeout 300 python bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"
-timeout 300 python bench.py --model 8b --new-tokens 256 --steps 2 --no-cpu-baseline > "$OUT/bench_8b.json" 2> "$OUT/bench_8b.err"
-# BASELINE config 5's workload (first measurement: it went in after round 1's GPU minutes were spent)
-timeout 300 python bench.py --model 8b --weights fp8 --task text2svg --new-tokens 256 --steps 2 --no-cpu-baseline \
-    > "$OUT/bench_8b_fp8_text2svg.json" 2> "$OUT/bench_8b_fp8_text2svg.err"
-
-# 3. per-kernel time of the headline command (kernel trace only: never together with --pmc)
-( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$OUT/rocprof" -- \
-    python "$GRAFT_REPO_ROOT/bench.py" --no-cpu-baseline --steps 1 --warmup 1 --ttft-requests 2 \
-    > "$GRAFT_REPO_ROOT/$OUT/bench_under_rocprof.json" 2> "$GRAFT_REPO_ROOT/$OUT/rocprof.err" )
-python tools/rocprof_summary.py "$OUT/rocprof" "$OUT/rocprof_kernel_stats.csv" > "$OUT/rocprof_summary.log" 2>&1 || true
-find "$OUT/rocprof" -name '*kernel_trace.csv' -size +8M -delete 2>/dev/null   # keep the pull under 64 MiB
-tail -3 "$OUT/pytest_gpu.log"; cat "$OUT/bench_n1.json"
+for s in "${STEPS[@]}"; do
+  case "$s" in
+    env:*) export "${s#env:}"; echo "[env] ${s#env:}" ;;
+    pytest) timeout 600 python -m pytest tests -m gpu -q -x 2>&1 | tail -40 > "$OUT/pytest_gpu.log"; tail -3 "$OUT/pytest_gpu.log" ;;
+    pytest:*) timeout 600 python -m pytest tests -m gpu -q -x -k "${s#pytest:}" 2>&1 | tail -40 > "$OUT/pytest_gpu_k.log"; tail -5 "$OUT/pytest_gpu_k.log" ;;
+    bench) timeout 400 python bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"; cat "$OUT/bench_n1.json" ;;
+    bench8b)
+      timeout 300 python bench.py --model 8b --new-tokens 256 --steps 2 --no-cpu-baseline > "$OUT/bench_8b_im2svg.json" 2> "$OUT/bench_8b_im2svg.err"
+      timeout 300 python bench.py --model 8b --weights fp8 --task text2svg --new-tokens 256 --steps 2 --no-cpu-baseline \
+          > "$OUT/bench_8b_fp8_text2svg.json" 2> "$OUT/bench_8b_fp8_text2svg.err"
+      cat "$OUT/bench_8b_im2svg.json" "$OUT/bench_8b_fp8_text2svg.json" ;;
+    rocprof)
+      ( cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/rocprof" -- \
+          python "$ROOT/bench.py" --no-cpu-baseline --steps 1 --warmup 1 --ttft-requests 2 \
+          > "$ROOT/$OUT/bench_under_rocprof.json" 2> "$ROOT/$OUT/rocprof.err" )
+      python tools/rocprof_summary.py "$OUT/rocprof" "$OUT/rocprof_kernel_stats.csv" > "$OUT/rocprof_summary.log" 2>&1 || true
+      python tools/trace_by_grid.py "$OUT/rocprof" "$OUT/rocprof_by_grid.csv" > "$OUT/by_grid.log" 2>&1 || true
+      find "$OUT/rocprof" -name '*kernel_trace.csv' -size +8M -delete 2>/dev/null   # keep the pull under 64 MiB
+      head -14 "$OUT/rocprof_kernel_stats.csv" | cut -c1-160 ;;
+    pmc)
+      for ctr in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
+        ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$ROOT/$OUT/pmc_$ctr" -- \
+            python "$ROOT/bench.py" --no-cpu-baseline --steps 1 --warmup 0 --new-tokens 64 --ttft-requests 1 \
+            > /dev/null 2> "$ROOT/$OUT/pmc_$ctr.err" )
+        python tools/pmc_summary.py "$OUT/pmc_$ctr" "$OUT/pmc_$ctr.json" > /dev/null 2>&1 || true
+        find "$OUT/pmc_$ctr" -name '*.csv' -size +8M -delete 2>/dev/null
+      done ;;
+    smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee "$OUT/smoke.log" ;;
+    ctx) timeout 400 python tools/ctx_sweep.py 2>&1 | tee "$OUT/ctx_sweep.log" ;;
+    skinny) timeout 200 python tools/bench_skinny.py 2>&1 | tee "$OUT/bench_skinny.log" ;;
+    *) echo "unknown step $s" ;;
+  esac
+done
