@@ -876,7 +876,8 @@ class StarVectorForCausalLM(nn.Module):
             if bool((m[:, 1:] & ~m[:, :-1]).any()) or not bool(m[:, 0].all()):
                 raise NotImplementedError("only right-padded attention masks are built for the scoring forward")
         emb16, keep = inputs_embeds.to(torch.bfloat16), int(num_logits_to_keep or 0)
-        batcher = getattr(self.model.svg_transformer.transformer, "batcher", None)
+        lm = getattr(getattr(self.model, "svg_transformer", None), "transformer", None)
+        batcher = getattr(lm, "batcher", None)
         if batcher is not None and not _in_exclusive_job():
             # requests share the engine's decode loop: the scoring pass wants the engine to itself (it would fail with SV_ESTATE
             # while slots are live) -> queue it as an exclusive job, FIFO with the generation requests
