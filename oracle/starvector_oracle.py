@@ -138,18 +138,21 @@ def _ln(x: Tensor, w: Tensor, b: Tensor, eps: float) -> Tensor:
 # deterministic weights + inputs (shared by tests, smoke and bench; values are bf16-exact so the
 # fp32 oracle and the bf16 engine consume IDENTICAL numbers)
 # ----------------------------------------------------------------------------------------------
-def iter_weights(cfg: OracleConfig, seed: int = 1234, init: str = "parity"):
+def iter_weights(cfg: OracleConfig, seed: int = 1234, init: str = "parity", device=None):
     """Seeded random-init state_dict with the reference's key names and shapes, streamed as
     (name, float32 tensor) pairs so a loader never has to hold all 1.4 B parameters at once.
 
     init="parity": fan-in scaled normals so activations stay O(1) and greedy argmax has
     non-degenerate margins.  init="std002": N(0, 0.02) everywhere
     (throughput runs; values do not affect speed).  Values are bf16-exact.
+    device: where the tensors are drawn (default: the host, which is what every committed fixture was minted with; a GPU
+    generator draws OTHER values for the same seed -- used only where engine and oracle both consume the streamed tensors,
+    e.g. the full-depth 8B parity test, to avoid minutes of host RNG).
     """
-    g = torch.Generator().manual_seed(seed)
+    g = torch.Generator(device=device).manual_seed(seed) if device is not None else torch.Generator().manual_seed(seed)
 
     def nrm(*shape, std):
-        t = torch.empty(*shape, dtype=torch.float32).normal_(0.0, std, generator=g)
+        t = torch.empty(*shape, dtype=torch.float32, device=device).normal_(0.0, std, generator=g)
         return t.to(torch.bfloat16).to(torch.float32)
 
     def lin(name, out_f, in_f, gain=1.0):
@@ -159,10 +162,10 @@ def iter_weights(cfg: OracleConfig, seed: int = 1234, init: str = "parity"):
 
     def ln(name, *shape):
         if init == "std002":
-            yield name + ".weight", torch.ones(*shape)
-            yield name + ".bias", torch.zeros(*shape)
+            yield name + ".weight", torch.ones(*shape, device=device)
+            yield name + ".bias", torch.zeros(*shape, device=device)
             return
-        yield name + ".weight", (1.0 + 0.1 * torch.empty(*shape).normal_(0, 1, generator=g)).to(torch.bfloat16).to(torch.float32)
+        yield name + ".weight", (1.0 + 0.1 * torch.empty(*shape, device=device).normal_(0, 1, generator=g)).to(torch.bfloat16).to(torch.float32)
         yield name + ".bias", nrm(*shape, std=0.02)
 
     if cfg.arch == "v2":
@@ -193,7 +196,7 @@ def iter_weights(cfg: OracleConfig, seed: int = 1234, init: str = "parity"):
         Q = cfg.query_length
         yield from ln(P_ADP + "norm", Q)
         yield P_ADP + "norm.running_mean", nrm(Q, std=0.1)
-        yield P_ADP + "norm.running_var", (1.0 + 0.2 * torch.rand(Q, generator=g)).to(torch.bfloat16).to(torch.float32)
+        yield P_ADP + "norm.running_var", (1.0 + 0.2 * torch.rand(Q, generator=g, device=device)).to(torch.bfloat16).to(torch.float32)
 
     # wte is small (std 0.02): keeps the tied-head self-logit from dominating, so random-init greedy streams
     # are diverse instead of one repeated token
@@ -443,8 +446,8 @@ def _block(w, cfg: OracleConfig, p: str, h: Tensor, k_cache: Optional[Tensor], v
     q = q.view(B, S, H, dh).transpose(1, 2)                                      # [B,H,S,dh]
     s = torch.einsum("bhsd,bld->bhsl", q, k) * (dh ** -0.5)                      # scale_attn_weights
     # causal: query at absolute position L-S+i sees keys 0..L-S+i (all-ones padding mask)
-    qi = torch.arange(L - S, L).view(S, 1)
-    kj = torch.arange(L).view(1, L)
+    qi = torch.arange(L - S, L, device=h.device).view(S, 1)
+    kj = torch.arange(L, device=h.device).view(1, L)
     s = s.masked_fill(kj > qi, float("-inf"))
     pr = r(torch.softmax(s, dim=-1))                                             # softmax in fp32 (:156-159)
     o = r(torch.einsum("bhsl,bld->bhsd", pr, v).transpose(1, 2).reshape(B, S, D))
@@ -468,7 +471,7 @@ def _lm_logits(w, cfg: OracleConfig, h_last: Tensor, r) -> Tensor:
 def _rope(cfg: OracleConfig, positions: Tensor, r):
     """Starcoder2RotaryEmbedding: inv_freq = theta^(-2i/d); cos/sin over cat(freqs, freqs), cast to the model dtype."""
     dh = cfg.head_dim
-    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, dh, 2, dtype=torch.float32) / dh))
+    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, dh, 2, dtype=torch.float32, device=positions.device) / dh))
     fr = positions.to(torch.float32)[:, None] * inv[None, :]
     emb = torch.cat([fr, fr], dim=-1)
     return r(emb.cos()), r(emb.sin())
@@ -494,7 +497,7 @@ def _block_v2(w, cfg: OracleConfig, p: str, h: Tensor, k_cache, v_cache, r):
     k = r(x @ w[p + "self_attn.k_proj.weight"].T + w[p + "self_attn.k_proj.bias"]).view(B, S, Hkv, dh).transpose(1, 2)
     v = r(x @ w[p + "self_attn.v_proj.weight"].T + w[p + "self_attn.v_proj.bias"]).view(B, S, Hkv, dh).transpose(1, 2)
     past = 0 if k_cache is None else k_cache.shape[2]
-    cos, sin = _rope(cfg, torch.arange(past, past + S), r)
+    cos, sin = _rope(cfg, torch.arange(past, past + S, device=h.device), r)
     q = r(r(q * cos) + r(_rot_half(q) * sin))          # apply_rotary_pos_emb in model precision
     k = r(r(k * cos) + r(_rot_half(k) * sin))
     if k_cache is not None:
@@ -504,8 +507,8 @@ def _block_v2(w, cfg: OracleConfig, p: str, h: Tensor, k_cache, v_cache, r):
     kk = k.repeat_interleave(H // Hkv, dim=1)
     vv = v.repeat_interleave(H // Hkv, dim=1)
     s = (q @ kk.transpose(-1, -2)) * dh ** -0.5
-    qi = torch.arange(L - S, L).view(S, 1)
-    kj = torch.arange(L).view(1, L)
+    qi = torch.arange(L - S, L, device=h.device).view(S, 1)
+    kj = torch.arange(L, device=h.device).view(1, L)
     s = s.masked_fill(kj > qi, float("-inf"))
     if cfg.sliding_window:
         s = s.masked_fill(kj <= qi - cfg.sliding_window, float("-inf"))
@@ -605,7 +608,7 @@ def greedy_generate(w, cfg: OracleConfig, inputs_embeds: Tensor, max_length: int
     if budget <= 0:
         raise ValueError("max_length must exceed the prompt length (HF raises here)")
     logits, cache = decoder_prefill(w, cfg, inputs_embeds, mode)
-    unfinished = torch.ones(B, dtype=torch.bool)
+    unfinished = torch.ones(B, dtype=torch.bool, device=inputs_embeds.device)
     out: List[Tensor] = []
     all_logits: List[Tensor] = []
     stop = list(stop_ids) if stop_ids else None

@@ -1026,19 +1026,22 @@ __device__ __forceinline__ void sk_store(const SkinnyArgs& p, float* v, const fl
         const int r = r0 + 4 * g;
         const int n0 = nt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
         float* vv = v + 4 * g;
-        if (p.out_mode == SK_OUT_PARTIAL || p.out_mode == SK_OUT_F32) {
-            // (two separate destinations on purpose: one store through `cond ? ws + .. : out_f32 + ..` made hipcc 7.2 keep the
-            //  out_f32 base for both arms in the fp8 kernel)
-            float* dst;
-            if (p.out_mode == SK_OUT_PARTIAL) dst = p.ws + ((size_t)split * p.MT * 32 + mt * 32 + m) * p.ldws + n0;
-            else dst = p.out_f32 + ((size_t)mt * 32 + m) * p.ldo + n0;
-            if (p.out_mode == SK_OUT_F32 && p.round_bf16) {
-#pragma unroll
-                for (int i = 0; i < W; ++i) vv[i] = bfround(vv[i]);
-            }
+        auto store_f32 = [&](float* dst) {
             if constexpr (W == 4) *reinterpret_cast<float4*>(dst) = make_float4(vv[0], vv[1], vv[2], vv[3]);
             else if constexpr (W == 2) *reinterpret_cast<float2*>(dst) = make_float2(vv[0], vv[1]);
             else dst[0] = vv[0];
+        };
+        // TWO separate stores on purpose: written as one store through `cond ? ws + .. : out_f32 + ..` (or an if / else that only
+        // picks the pointer) hipcc 7.2 keeps the out_f32 base register for both arms and the slab store goes to a null pointer
+        // (seen twice: the fp8 kernel in round 2, this helper in round 3 -- a GPU memory fault at 0x1000).
+        if (p.out_mode == SK_OUT_PARTIAL) {
+            store_f32(p.ws + ((size_t)split * p.MT * 32 + mt * 32 + m) * p.ldws + n0);
+        } else if (p.out_mode == SK_OUT_F32) {
+            if (p.round_bf16) {
+#pragma unroll
+                for (int i = 0; i < W; ++i) vv[i] = bfround(vv[i]);
+            }
+            store_f32(p.out_f32 + ((size_t)mt * 32 + m) * p.ldo + n0);
         } else {   // SK_OUT_PACKED_ACT
 #pragma unroll
             for (int i = 0; i < W; ++i) {
