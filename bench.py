@@ -101,12 +101,35 @@ def main():
     dev_index = local_rank % max(n_dev, 1)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    import datetime
     import torch.distributed as dist
+    rccl_version = None
     if world > 1:
-        if shared:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)       # "nccl" is RCCL on ROCm
+        # Fail LOUDLY, never hang: a bounded rendezvous / collective timeout, and a first tiny all_reduce right away so that a
+        # broken xGMI / RCCL setup (e.g. a missing HSA_ENABLE_IPC_MODE_LEGACY=0: hipIpcGetMemHandle fails) surfaces here with a
+        # message instead of inside the timed region.
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        tmo = datetime.timedelta(seconds=int(os.environ.get("SV_DIST_TIMEOUT_S", "180")))
+        try:
+            if shared:
+                dist.init_process_group("gloo", timeout=tmo)
+            else:
+                dist.init_process_group("nccl", device_id=dev, timeout=tmo)       # "nccl" is RCCL on ROCm
+                try:
+                    rccl_version = ".".join(str(x) for x in torch.cuda.nccl.version())
+                except Exception:
+                    rccl_version = "unknown"
+            probe = torch.ones(1, device="cpu" if shared else dev)
+            dist.all_reduce(probe)
+            if not shared:
+                torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise RuntimeError(f"all_reduce probe returned {probe.item()} for world size {world}")
+        except Exception as e:
+            print(f"[bench rank {rank}] distributed setup FAILED ({'gloo' if shared else 'nccl/RCCL'}, world {world}, "
+                  f"MASTER_ADDR={os.environ.get('MASTER_ADDR')}:{os.environ.get('MASTER_PORT')}): {type(e).__name__}: {e}",
+                  file=sys.stderr, flush=True)
+            raise SystemExit(3)
 
     import starvector_amd as sva
     from starvector_amd.parallel import all_gather_token_streams
@@ -206,8 +229,14 @@ def main():
     launches = max(sk["launches_per_step"], 1.0)
     # average launch duration of the dominant kernel: its 97 launches of one step enqueued back to back between
     # one HIP event pair on the engine stream (dispatch to dispatch, the interval rocprofv3 reports per kernel)
-    sk_ms = prof.get("skinny_chain_ms_per_step", 0.0) or sk["ms_per_step"]
+    sk_chain_ms = prof.get("skinny_chain_ms_per_step", 0.0) or sk["ms_per_step"]
     sk_exec_ms = sk["ms_per_step"]                 # per-launch event deltas minus the empty event-pair time
+    # IN SITU the same launches sit between attention / row-update launches (cold L2, a different predecessor): what the step
+    # spends on them is the measured step minus the chain of everything else, also enqueued back to back between one event
+    # pair.  rocprofv3's per-kernel average (profiles/) lies between the two figures; `frac` uses the in-situ (larger) one.
+    step_ms = decode_ms / max(decode_steps, 1)
+    others_ms = prof.get("others_chain_ms_per_step", 0.0)
+    sk_ms = max(sk_chain_ms, step_ms - others_ms) if others_ms > 0 and step_ms > others_ms else sk_chain_ms
     achieved = W_BYTES_PER_STEP / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else None
     # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is
     # the one a separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` pass of this command left in profiles/ -- labelled
@@ -257,7 +286,8 @@ def main():
                        "global_batch": B_PER_GPU * world, "new_tokens": n_new,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        **({"dist_backend": ("gloo, ranks SHARE GPUs (functional run of the sharded path on a box with fewer GPUs than "
-                                            "ranks; not a scaling number)") if shared else "nccl (RCCL)"} if world > 1 else {}),
+                                            "ranks; not a scaling number)") if shared else f"nccl (RCCL {rccl_version})",
+                           "collectives_per_step": 1} if world > 1 else {}),
                        "hipgraph_decode": bool(graph)},
             "tokens_per_s_per_gpu": round(value / world, 1),
             "ttft_p50_ms": round(ttft_p50, 2) if ttft_p50 is not None else None,
@@ -268,6 +298,9 @@ def main():
                          "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": round(W_BYTES_PER_STEP / launches),
                          "avg_launch_us": round(sk_ms * 1e3 / launches, 2),
+                         "avg_launch_us_source": "in situ: (decode step - back-to-back chain of the step's other kernels) / launches",
+                         "avg_launch_us_gemm_chain": round(sk_chain_ms * 1e3 / launches, 2),
+                         "frac_gemm_chain": round(W_BYTES_PER_STEP / (sk_chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sk_chain_ms > 0 else None,
                          "avg_exec_us_event_deltas": round(sk_exec_ms * 1e3 / launches, 2)},
             "roofline_prefill_gemm": {"bound": "mfma",
                                       "kernel": "gemm_bf16_kernel / gemm256_kernel / gemm_tail_kernel (the 4 decoder GEMMs of a prefill layer)",

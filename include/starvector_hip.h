@@ -278,12 +278,13 @@ int  sv_beam_history(sv_engine* e, int32_t* host_parent, int32_t* host_tok, int3
  * [1] ms decode loop, [2] decode steps enqueued, [3] 1 if the step ran as a hipGraph replay */
 int  sv_last_timing(sv_engine* e, double* out4);
 /* HIP-event timing of one decode step by kernel class, on the cache state left by the last
- * sv_generate / sv_prefill (bench.py roofline leg).  out: 8 doubles, [2k] = ms per step in class k
+ * sv_generate / sv_prefill (bench.py roofline leg).  out: 10 doubles, [2k] = ms per step in class k
  * (event deltas minus the empty event-pair time), [2k+1] = launches per step; k = 0 skinny
  * weight-streaming GEMM, 1 paged decode attention, 2 residual+LayerNorm row update;
  * [6] = ms between two back-to-back events with no kernel; [7] = ms per step of the step's GEMM launches
- * enqueued back to back between ONE event pair (dispatch-to-dispatch, as rocprofv3 reports it). */
-int  sv_profile_decode_step(sv_engine* e, int32_t B, int32_t iters, double* out8, sv_stream stream);
+ * enqueued back to back between ONE event pair (dispatch-to-dispatch); [8] = the same for every OTHER kernel
+ * of the step (no GEMMs): step - [8] = what the GEMMs cost in situ; [9] reserved. */
+int  sv_profile_decode_step(sv_engine* e, int32_t B, int32_t iters, double* out10, sv_stream stream);
 
 /* ---- single operators (parity tests; all device pointers, bf16 unless noted) ------------------ */
 int  sv_op_layernorm(const void* x, const void* gamma, const void* beta, void* y, int32_t M, int32_t D,

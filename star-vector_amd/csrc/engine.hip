@@ -167,6 +167,7 @@ struct sv_engine {
     int MT = 0, ldws = 0, Vpad = 0;
     bf16_t *h_dec = nullptr, *hl = nullptr, *xp_a = nullptr, *xp_attn = nullptr, *xp_mlp = nullptr;
     bool only_skinny = false;       // profiling: enqueue only the weight-streaming GEMMs of a step
+    bool skip_skinny = false;       // profiling: enqueue everything BUT the weight-streaming GEMMs
     float *ws = nullptr, *ws2 = nullptr, *logits = nullptr, *sample_scratch = nullptr, *attn_part = nullptr;
     unsigned* attn_cnt = nullptr;
     float* am_val = nullptr; int32_t* am_idx = nullptr;
@@ -875,6 +876,7 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
         if (out_mode == SK_OUT_PARTIAL) { a.splitk = l.splitk; a.ws = ws; a.ldws = e->ldws; }
         else if (out_mode == SK_OUT_PACKED_ACT) { a.splitk = 1; a.bias = l.bias; a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16; }
         else { a.splitk = 1; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1; }
+        if (e->skip_skinny) return;
         prof_mark(e, PK_SKINNY, st);
         launch_gemm_skinny(a, st);
     };
@@ -1760,7 +1762,7 @@ extern "C" int sv_profile_decode_step(sv_engine* e, int32_t B, int32_t iters, do
     HIPCHECK(hipStreamWaitEvent(st, e->gen_event, 0));
     // positions may sit one past the budget after a full generate: step back so the probe stays in range
     add_i32_kernel<<<(B + 63) / 64, 64, 0, st>>>(e->positions, -1, B);
-    for (int k = 0; k < 2 * PK_COUNT; ++k) out[k] = 0.0;
+    for (int k = 0; k < 2 * PK_COUNT + 2; ++k) out[k] = 0.0;
     // event-pair overhead: two back-to-back events with nothing in between
     double overhead_ms = 0.0;
     {
@@ -1807,6 +1809,19 @@ extern "C" int sv_profile_decode_step(sv_engine* e, int32_t B, int32_t iters, do
         float ms = 0.f; HIPCHECK(hipEventElapsedTime(&ms, a, b));
         (void)hipEventDestroy(a); (void)hipEventDestroy(b);
         out[2 * PK_SAMPLE + 1] = (double)ms / iters;       // ms per step for the GEMM chain
+        // slot 8: the complement -- every other kernel of the step (row updates, attention) back to back, no GEMMs.  The step
+        // minus this chain is what the GEMMs cost IN SITU (bench.py's roofline.avg_launch_us)
+        HIPCHECK(hipEventCreate(&a)); HIPCHECK(hipEventCreate(&b));
+        e->skip_skinny = true;
+        decode_forward(e, B, st);
+        HIPCHECK(hipEventRecord(a, st));
+        for (int it = 0; it < iters; ++it) decode_forward(e, B, st);
+        HIPCHECK(hipEventRecord(b, st));
+        e->skip_skinny = false;
+        HIPCHECK(hipEventSynchronize(b));
+        HIPCHECK(hipEventElapsedTime(&ms, a, b));
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        out[2 * PK_COUNT] = (double)ms / iters;
     }
     add_i32_kernel<<<(B + 63) / 64, 64, 0, st>>>(e->positions, 1, B);
     HIPCHECK(hipStreamSynchronize(st));

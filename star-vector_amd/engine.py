@@ -290,12 +290,13 @@ class HipEngine:
 
     def profile_decode_step(self, B: int, iters: int = 5) -> Dict[str, Dict[str, float]]:
         """HIP-event time per decode step by kernel class (eager launches of the graph's kernels)."""
-        buf = (C.c_double * 8)()
+        buf = (C.c_double * 10)()
         check(self.lib.sv_profile_decode_step(self._h, B, iters, buf, _stream()), "sv_profile_decode_step")
         names = ["skinny_gemm", "attn_decode", "row_update_ln"]
         res = {n: {"ms_per_step": buf[2 * i], "launches_per_step": buf[2 * i + 1]} for i, n in enumerate(names)}
         res["event_pair_overhead_ms"] = buf[6]
         res["skinny_chain_ms_per_step"] = buf[7]
+        res["others_chain_ms_per_step"] = buf[8]
         return res
 
 

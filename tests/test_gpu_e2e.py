@@ -234,7 +234,8 @@ def _stream_equal_until_band(got, o_toks, margin, band):
         t = int(diff[0]) if diff.numel() else got.shape[1]
         if t < got.shape[1]:
             assert margin[b, t] <= band, (f"row {b} step {t}: engine token {int(got[b, t])} != oracle {int(o_toks[b, t])} "
-                                          f"at margin {float(margin[b, t]):.3e} (band {band:.3e})")
+                                          f"at margin {float(margin[b, t]):.3e} (band {band:.3e}); leading identical positions of "
+                                          f"the rows before it: {n} of {got.shape[1]}")
         n.append(t)
     return n
 
@@ -455,6 +456,17 @@ def test_starvector_8b_op_graph_against_reference_golden():
     eng.close()
 
 
+def _assert_stream_vs_hf(got, hf_tokens, w, cfg, g):
+    """HF's golden stream is the float32 oracle's stream (asserted); its float32 top-1/top-2 margins say where a correct bf16
+    implementation may legitimately pick the other token.  Returns the leading identical positions per row."""
+    o_emb = O.prepare_generation_inputs(w, cfg, g["image"], g["prompt_ids"])
+    n = hf_tokens.shape[1]
+    f_toks, f_lg = O.greedy_generate(w, cfg, o_emb, o_emb.shape[1] + n, return_logits=True)
+    assert torch.equal(f_toks, hf_tokens), "the float32 oracle no longer reproduces HF's golden stream"
+    top2 = f_lg.topk(2, -1).values
+    return _stream_equal_until_band(got, hf_tokens, top2[..., 0] - top2[..., 1], 2 * LOGIT_TOL * float(f_lg.abs().max()))
+
+
 def test_starcoder2_sliding_window():
     """StarCoder2 attends to the last `sliding_window` keys (4096 in bigcode/starcoder2-7b; 24 here).  Teacher-forced
     logits against the windowed oracle (pinned to HF by tests/golden/tiny_v2_window) for 80 steps: the window start
@@ -473,6 +485,10 @@ def test_starcoder2_sliding_window():
     got = eng.generate(emb, max_length=S0 + n_new, eos_token_id=-1, pad_token_id=0).cpu()
     same = sum(int(torch.equal(got[b], g["tokens"][b])) for b in range(B))
     print(f"[v2 window] {same}/{B} streams identical to HF's windowed generate")
+    # asserted, not only printed: the float32 oracle's stream IS HF's (pinned), and every engine stream equals it or leaves it
+    # AT a position where the float32 margin is inside the band (a bf16 near-tie; the oracle's own bf16 mode flips there too)
+    lead = _assert_stream_vs_hf(got, g["tokens"], w, cfg, g)
+    assert same == sum(1 for t in lead if t == n_new), f"identical streams {same} vs leading positions {lead} of {n_new}"
     eng.close()
     full = build_engine(dataclasses.replace(cfg, sliding_window=0), w, max_batch=4, max_seq_len=128)
     with pytest.raises(AssertionError):
@@ -489,6 +505,7 @@ def test_starcoder2_sliding_window():
     got8 = small.generate(emb, max_length=S0 + g["tokens_w8"].shape[1], eos_token_id=-1, pad_token_id=0).cpu()
     print(f"[v2 window] W=8: {sum(int(torch.equal(got8[b], g['tokens_w8'][b])) for b in range(B))}/{B} streams identical to HF's "
           "generate with the window inside the prompt pass")
+    _assert_stream_vs_hf(got8, g["tokens_w8"], w, cfg8, g)      # asserts: departures from HF's stream only at in-band near-ties
     small.close()
 
 
@@ -608,7 +625,7 @@ def test_starvector_8b_dims_one_layer_against_oracle():
     worst, scale, checked, near, o_toks, margin = _teacher_forced_check(eng, emb, w, cfg, n_new)
     print(f"[8b dims] {n_new} steps x {B} rows: logits max|err| {worst:.3e} (scale {scale:.3e}); {checked}/{B * n_new} positions "
           f"token-exact outside the band, {near} near-tie flips inside it")
-    assert checked >= 0.75 * B * n_new
+    assert checked >= 0.85 * B * n_new, f"only {checked}/{B * n_new} positions are margin-safe and token-exact"
     # a longer free run crosses the 640-token KV page boundary with RoPE positions: deterministic, graph == eager
     kw = dict(max_length=578 + 70, eos_token_id=-1, pad_token_id=0)
     a = eng.generate(emb, **kw).cpu()
