@@ -203,6 +203,9 @@ int  sv_preprocess_images(const uint8_t* const* dev_pixels, const int32_t* width
  *                             32-row tiles (33..64 rows: the weights are streamed once)} */
 int  sv_debug_resample_coeffs(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* taps, int32_t cap);
 int  sv_debug_skinny_plan(int32_t rows, int32_t N, int32_t K, int32_t splitk, int32_t fp8, int32_t* out2);
+/*   sv_debug_set_exp          the experiment bit mask of a live engine (what the environment variable SV_EXP sets at sv_create):
+ *                             in-process A/B runs of the round's experiments (tools/ab_exp.py) */
+int  sv_debug_set_exp(sv_engine* e, int32_t mask);
 int  sv_debug_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t act, int32_t* out5);
 
 /* Prompt pass over inputs_embeds [B,S0,hidden] bf16 (all-ones attention mask): fills the paged KV

@@ -105,6 +105,7 @@ PROTOTYPES = {
     "sv_beam_finalize": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(_F), _P]),
     "sv_beam_history": (_I, [_P, C.POINTER(_I), C.POINTER(_I), _I, C.POINTER(_I), C.POINTER(_I)]),
     "sv_last_timing": (_I, [_P, C.POINTER(C.c_double)]),
+    "sv_debug_set_exp": (_I, [_P, _I]),
     "sv_profile_decode_step": (_I, [_P, _I, _I, C.POINTER(C.c_double), _P]),
     "sv_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "sv_op_linear": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -355,10 +355,23 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     // StarCoder2 sliding window: only keys win0 <= j <= pos are visible; whole groups (and pages) below are skipped
     const int win0 = (p.window > 0 && L > p.window) ? L - p.window : 0;
     const int g0 = win0 >> 5;
-    int act = (ngroups - g0 + AD_GROUPS_PER_BLOCK - 1) / AD_GROUPS_PER_BLOCK;
+    const int gpb = p.groups_per_block > 0 ? p.groups_per_block : AD_GROUPS_PER_BLOCK;
+    int act = (ngroups - g0 + gpb - 1) / gpb;
     act = act > p.max_splits ? p.max_splits : act;      // host cap: B * act <= #CUs (one block per CU) and <= AD_SPLIT
     act = act < 1 ? 1 : act;
-    if (split >= act) return;
+    // XCD-aligned prefetch of the next GEMM's weights (common.h): participant slots of this XCD = (sequence group, split, wave)
+    const bool pf_on = p.pf.base != nullptr && (gridDim.x & 7) == 0 && split < p.max_splits;
+    const int pf_nslots = (gridDim.x >> 3) * p.max_splits * AD_WAVES;
+    const int pf_slot0 = ((bx >> 3) * p.max_splits + split) * AD_WAVES;
+    if (split >= act) {
+        if (pf_on) {      // an active-range split with no keys yet (short context): the whole block prefetches, then leaves
+            u32x4 t[4];
+            const int w = threadIdx.x >> 6;
+            sv_prefetch_issue<4>(p.pf, sv_xcc_id(), pf_slot0 + w, pf_nslots, threadIdx.x & 63, t);
+            sv_prefetch_sink<4>(t, p.counters);
+        }
+        return;
+    }
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* q_s = reinterpret_cast<bf16_t*>(smem);                       // [16][D]
@@ -384,7 +397,15 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     const int stride = act * AD_WAVES;
     int g = g0 + split + act * wave;
     KvFrags<D> fa, fb;
+    // waves 4..7 without a key group (contexts up to ~1000 tokens at 8 splits) carry the prefetch of their own slot and of wave
+    // w - 4's (busy with keys); the loads land in fa's registers, which such a wave never uses otherwise
+    const bool pf_wave = pf_on && g >= ngroups && wave >= 4;
     if (g < ngroups) load_group<D>(fa, pool, page_of(g), page_bytes, g, lane);
+    else if (pf_wave) {
+        const int xcd = sv_xcc_id();
+        sv_prefetch_issue<NKS>(p.pf, xcd, pf_slot0 + wave, pf_nslots, lane, &fa.k[0][0]);
+        sv_prefetch_issue<NKS>(p.pf, xcd, pf_slot0 + wave - 4, pf_nslots, lane, &fa.k[1][0]);
+    }
 
     // q / k_new / v_new of this sequence -> LDS (bf16): the fp32 split-K slabs of the c_attn GEMM, summed here in slab order + bias.
     // 4 columns per thread and every load issued before the first add: one memory round trip.
@@ -527,6 +548,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
         g = g2;
     }
 
+    if (pf_wave) sv_prefetch_sink<2 * NKS>(&fa.k[0][0], p.counters);
     // merge the waves of this block (LDS), in wave order
     float l_tot = l_run + __shfl_xor(l_run, 16, 64);
     l_tot += __shfl_xor(l_tot, 32, 64);

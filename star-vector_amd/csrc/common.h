@@ -57,6 +57,57 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// XCD-aligned weight prefetch.  The decode step alternates weight-streaming GEMMs with latency-bound kernels (paged attention,
+// row update) during which HBM is nearly idle; the small GEMMs that follow (c_attn, attention c_proj: ~1.1 MiB per XCD) are a
+// single HBM round trip per wave, i.e. mostly first-touch latency.  Waves with nothing to do in the latency-bound kernel read
+// the head of every consumer wave's weight stream with ordinary loads, so the lines sit in the L2 of the XCD THE CONSUMER BLOCK
+// WILL RUN ON: workgroups are dealt round-robin to the 8 XCDs in launch order (observed, a speed assumption only -- a wrong
+// guess costs the hint, never a result), so consumer block (nt, split) of a skinny GEMM with NT % 8 == 0 runs on XCD nt % 8,
+// and the prefetching wave takes the tiles of the XCD it runs on itself (HW_REG_XCC_ID).  Round 2's linear slicing parked the
+// lines in other XCDs' L2s / the Infinity Cache and bought nothing (profiles/prefetch_r02_ab.log).
+// A piece = the first `piece_units` KiB of one consumer wave's stream; a unit = 1 KiB = one wave-wide 16-byte load.
+// ------------------------------------------------------------------------------------------------
+struct PrefetchDesc {
+    const char* base;          // packed weight image (nullptr = off)
+    unsigned tile_bytes;       // bytes of one 32-column tile (K/16 KiB for bf16)
+    int n_tiles;               // column tiles of the consumer (its grid.x)
+    int pieces;                // consumer wave streams per tile (splitk * waves per block)
+    unsigned piece_stride;     // bytes between the starts of consecutive streams
+    int piece_units;           // KiB prefetched at the head of each stream
+};
+__device__ __forceinline__ int sv_xcc_id() {
+    unsigned v;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
+    return (int)(v & 7u);
+}
+// Issue up to NU loads: units slot, slot + nslots, ... of this XCD's share (units past the end re-read the first line).
+// The caller keeps `dst` alive until sv_prefetch_sink (the loads are ordinary loads: the compiler tracks them).
+template <int NU>
+__device__ __forceinline__ void sv_prefetch_issue(const PrefetchDesc& d, int xcd, int slot, int nslots, int lane, u32x4* dst) {
+    const int n_own = (d.n_tiles - xcd + 7) >> 3;                  // tiles xcd, xcd + 8, ...
+    const int total = n_own * d.pieces * d.piece_units;
+#pragma unroll
+    for (int k = 0; k < NU; ++k) {
+        const int u = slot + k * nslots;
+        size_t off = 0;
+        if (u < total) {                                            // wave-uniform
+            const int q = u / d.piece_units, kb = u - q * d.piece_units;
+            const int ti = q / d.pieces, pc = q - ti * d.pieces;
+            off = (size_t)(xcd + 8 * ti) * d.tile_bytes + (size_t)pc * d.piece_stride + (size_t)kb * 1024;
+        }
+        dst[k] = *reinterpret_cast<const u32x4*>(d.base + off + (size_t)lane * 16);
+    }
+}
+// Wait for the prefetch loads where the wave has time to (data-dependent, practically never taken store keeps them alive).
+template <int NU>
+__device__ __forceinline__ void sv_prefetch_sink(const u32x4* dst, unsigned* scratch_word) {
+    unsigned x = 0;
+#pragma unroll
+    for (int k = 0; k < NU; ++k) x ^= dst[k][0] ^ dst[k][1] ^ dst[k][2] ^ dst[k][3];
+    if (x == 0x9e3779b9u && scratch_word == reinterpret_cast<unsigned*>(1)) *scratch_word = x;      // never true
+}
+
 // activations used by the path's fused epilogues
 enum { ACT_NONE = 0, ACT_QUICKGELU = 1, ACT_SWISH = 2, ACT_GELU_TANH = 3 };
 

@@ -125,6 +125,19 @@ __global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
     __shared__ float redbuf[8];
     const int row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (row >= p.M) {
+        // spare CUs (the update itself keeps M blocks busy for a few microseconds of latency): XCD-aligned prefetch of the head of
+        // every consumer wave's weight stream of the GEMM that follows (common.h).  Two rounds of 8 loads per wave.
+        const int xcd = sv_xcc_id();
+        const int nslots = (p.pf_blocks >> 3) * 4;                       // participants per XCD: 4 waves per extra block
+        const int slot = ((row - p.M) >> 3) * 4 + wave;
+        u32x4 t[8];
+        sv_prefetch_issue<8>(p.pf, xcd, slot, nslots, lane, t);
+        sv_prefetch_sink<8>(t, reinterpret_cast<unsigned*>(p.xp_out));
+        sv_prefetch_issue<8>(p.pf, xcd, slot + 8 * nslots, nslots, lane, t);
+        sv_prefetch_sink<8>(t, reinterpret_cast<unsigned*>(p.xp_out));
+        return;
+    }
     const int D = p.D, NC = D >> 3;
     bf16_t* hr = p.h + (size_t)row * p.ldh;
 
@@ -234,7 +247,10 @@ __global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
 }
 
 void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st) {
-    row_update_ln_kernel<<<a.M, 256, a.D * sizeof(float), st>>>(a);
+    const int extra = (a.pf.base && (a.M & 7) == 0 && a.pf_blocks >= 8) ? (a.pf_blocks & ~7) : 0;
+    RowUpdateArgs b = a;
+    b.pf_blocks = extra;
+    row_update_ln_kernel<<<a.M + extra, 256, a.D * sizeof(float), st>>>(b);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -288,6 +288,10 @@ class HipEngine:
         check(self.lib.sv_last_timing(self._h, buf), "sv_last_timing")
         return {"ttft_ms": buf[0], "decode_ms": buf[1], "decode_steps": buf[2], "graph": bool(buf[3])}
 
+    def set_exp(self, mask: int) -> None:
+        """Experiment bit mask (SV_EXP) of the live engine: in-process A/B runs (tools/ab_exp.py)."""
+        check(self.lib.sv_debug_set_exp(self._h, int(mask)), "sv_debug_set_exp")
+
     def profile_decode_step(self, B: int, iters: int = 5) -> Dict[str, Dict[str, float]]:
         """HIP-event time per decode step by kernel class (eager launches of the graph's kernels)."""
         buf = (C.c_double * 10)()
