@@ -367,7 +367,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
         if (pf_on) {      // an active-range split with no keys yet (short context): the whole block prefetches, then leaves
             u32x4 t[4];
             const int w = threadIdx.x >> 6;
-            sv_prefetch_issue<4>(p.pf, sv_xcc_id(), pf_slot0 + w, pf_nslots, threadIdx.x & 63, t);
+            sv_prefetch_issue<4>(p.pf, bx & 7, pf_slot0 + w, pf_nslots, threadIdx.x & 63, t);
             sv_prefetch_sink<4>(t, p.counters);
         }
         return;
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     const bool pf_wave = pf_on && g >= ngroups && wave >= 4;
     if (g < ngroups) load_group<D>(fa, pool, page_of(g), page_bytes, g, lane);
     else if (pf_wave) {
-        const int xcd = sv_xcc_id();
+        const int xcd = bx & 7;                 // linear block id = bx + gridDim.x * split, gridDim.x % 8 == 0
         sv_prefetch_issue<NKS>(p.pf, xcd, pf_slot0 + wave, pf_nslots, lane, &fa.k[0][0]);
         sv_prefetch_issue<NKS>(p.pf, xcd, pf_slot0 + wave - 4, pf_nslots, lane, &fa.k[1][0]);
     }
@@ -548,7 +548,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
         g = g2;
     }
 
-    if (pf_wave) sv_prefetch_sink<2 * NKS>(&fa.k[0][0], p.counters);
+    if (pf_wave) sv_prefetch_sink<2 * NKS>(&fa.k[0][0], p.counters);       // (kept alive longer, the 8 vectors push the merge code into spills)
     // merge the waves of this block (LDS), in wave order
     float l_tot = l_run + __shfl_xor(l_run, 16, 64);
     l_tot += __shfl_xor(l_tot, 32, 64);

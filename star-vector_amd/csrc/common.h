@@ -62,10 +62,12 @@ __device__ __forceinline__ float wave_max(float v) {
 // row update) during which HBM is nearly idle; the small GEMMs that follow (c_attn, attention c_proj: ~1.1 MiB per XCD) are a
 // single HBM round trip per wave, i.e. mostly first-touch latency.  Waves with nothing to do in the latency-bound kernel read
 // the head of every consumer wave's weight stream with ordinary loads, so the lines sit in the L2 of the XCD THE CONSUMER BLOCK
-// WILL RUN ON: workgroups are dealt round-robin to the 8 XCDs in launch order (observed, a speed assumption only -- a wrong
-// guess costs the hint, never a result), so consumer block (nt, split) of a skinny GEMM with NT % 8 == 0 runs on XCD nt % 8,
-// and the prefetching wave takes the tiles of the XCD it runs on itself (HW_REG_XCC_ID).  Round 2's linear slicing parked the
-// lines in other XCDs' L2s / the Infinity Cache and bought nothing (profiles/prefetch_r02_ab.log).
+// WILL RUN ON: workgroups are dealt round-robin to the 8 XCDs in launch order, by the SAME rule in every launch of a replayed
+// graph (tools/diag/xcd_map.hip on MI355X: linear block id b runs on HW_REG_XCC_ID (b + 7) % 8, every kernel, every replay) -- a
+// speed assumption only, a wrong guess costs the hint, never a result.  So a prefetching block with linear id p and consumer
+// block (nt, split) of a skinny GEMM with NT % 8 == 0 share an XCD iff p % 8 == nt % 8: the prefetcher takes the tiles
+// congruent to ITS OWN block id (the hardware register would be off by that rotation: round 3's first attempt).
+// Round 2's linear slicing parked the lines in other XCDs' L2s / the Infinity Cache and bought nothing (profiles/prefetch_r02_ab.log).
 // A piece = the first `piece_units` KiB of one consumer wave's stream; a unit = 1 KiB = one wave-wide 16-byte load.
 // ------------------------------------------------------------------------------------------------
 struct PrefetchDesc {
@@ -76,11 +78,6 @@ struct PrefetchDesc {
     unsigned piece_stride;     // bytes between the starts of consecutive streams
     int piece_units;           // KiB prefetched at the head of each stream
 };
-__device__ __forceinline__ int sv_xcc_id() {
-    unsigned v;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v));
-    return (int)(v & 7u);
-}
 // Issue up to NU loads: units slot, slot + nslots, ... of this XCD's share (units past the end re-read the first line).
 // The caller keeps `dst` alive until sv_prefetch_sink (the loads are ordinary loads: the compiler tracks them).
 template <int NU>

@@ -170,7 +170,8 @@ struct sv_engine {
     bool skip_skinny = false;       // profiling: enqueue everything BUT the weight-streaming GEMMs
     int exp = 0;                    // SV_EXP bit mask, read once at sv_create (A/B switches of the round's experiments):
                                     //   1 attention's idle waves prefetch c_proj; 2 spare blocks of the row update prefetch the next GEMM;
-                                    //   4 decode attention: one 32-key group per block before another context split joins
+                                    //   4 decode attention: one 32-key group per block before another context split joins;
+                                    //   8 (at sv_create only) the round 1-2 split-K rule of the decode GEMMs
     float *ws = nullptr, *ws2 = nullptr, *logits = nullptr, *sample_scratch = nullptr, *attn_part = nullptr;
     unsigned* attn_cnt = nullptr;
     float* am_val = nullptr; int32_t* am_idx = nullptr;
@@ -273,12 +274,37 @@ static void reg_ln(sv_engine* e, const std::string& base, LNp* ln, size_t n) {
     reg_raw(e, base + "bias", &ln->b, n);
 }
 
-static int pick_splitk(int n_tiles, int KS) {
-    int want = (256 + n_tiles - 1) / n_tiles;
-    int s = 1;
-    while (s < want && s < 8) s <<= 1;
-    while (s > 1 && (KS % s) != 0) s >>= 1;
-    return s;
+// Split-K factor of a decode GEMM whose output goes to fp32 slabs (the consumer sums them in slab order).  Blocks are
+// one-per-CU-sized and a CU streams HBM at a capped rate, so what matters is how evenly NT * s equal blocks fall on the chip:
+// the time is ceil(NT * s / #CU) rounds of one block, i.e. the busiest CU's share -- NOT the average (8B down-projection at
+// split 2: 288 blocks = one full round + 32 blocks at 2 x 590 KB per busy CU: 45.8 us measured against 31 us for the bytes).
+// Pick the s <= 8 (the slab buffer and the consumers' limit) with the best fill, preferring fewer slabs on near-ties; each
+// block keeps >= 16 k-steps so that its 8 waves still have a stream to pipeline.  `legacy` = the round 1-2 rule (smallest
+// power of two that reaches one block per CU) kept for the A/B mask.
+static int pick_splitk(int n_tiles, int KS, int num_cus, bool fp8, bool legacy) {
+    // small GEMMs (StarVector-1B's c_attn / attention c_proj: < 40 KB per CU) are one latency-bound round trip per wave: the fill
+    // model does not describe them, and more slabs only cost their consumer -> the old rule
+    if (legacy || (long)n_tiles * KS < 24L * 1024) {
+        int want = (256 + n_tiles - 1) / n_tiles;
+        int s = 1;
+        while (s < want && s < 8) s <<= 1;
+        while (s > 1 && (KS % s) != 0) s >>= 1;
+        return s;
+    }
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 8; ++s) {
+        if (KS % s) continue;
+        const int per = KS / s;
+        if (s > 1 && per < 16) continue;
+        if (per % (fp8 ? 4 : 2)) continue;                       // the kernels cut a block's K over 2..16 waves (fp8: pairs of k-steps)
+        const long nb = (long)n_tiles * s;
+        const long rounds = (nb + num_cus - 1) / num_cus;
+        const double fill = (double)nb / (double)(rounds * num_cus);          // 1 = every CU equally loaded
+        const double cost = 1.0 / fill + 0.015 * s;                            // slabs cost the consumer a little
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    }
+    return best;
 }
 
 // StarVector-8B key names: HF SiglipVisionTransformer under model.image_encoder.visual_encoder.*
@@ -342,10 +368,6 @@ static void register_v2(sv_engine* e) {
         reg_linear(e, p + "self_attn.o_proj.", &L.c_proj, D, QD, 64, true);
         reg_linear(e, p + "mlp.c_fc.", &L.c_fc, F, D, 64, true);
         reg_linear(e, p + "mlp.c_proj.", &L.c_proj2, D, F, 64, true);
-        L.c_attn.splitk = pick_splitk(L.c_attn.Npad / 32, D / 16);
-        L.c_proj.splitk = pick_splitk(L.c_proj.Npad / 32, QD / 16);
-        L.c_fc.splitk = 1;
-        L.c_proj2.splitk = pick_splitk(L.c_proj2.Npad / 32, F / 16);
     }
     reg_ln(e, pd + "norm.", &e->ln_f, D);
 }
@@ -483,30 +505,32 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         reg_linear(e, p + "attn.c_proj.", &L.c_proj, D, D, 64, true);
         reg_linear(e, p + "mlp.c_fc.", &L.c_fc, F, D, 64, true);
         reg_linear(e, p + "mlp.c_proj.", &L.c_proj2, D, F, 64, true);
-        // slab pipeline (default): narrow outputs split K across blocks into fp32 slabs that the next
-        // kernel (attention / row update) sums in slab order
-        L.c_attn.splitk = pick_splitk(L.c_attn.Npad / 32, D / 16);
-        L.c_proj.splitk = pick_splitk(L.c_proj.Npad / 32, D / 16);
-        L.c_fc.splitk = 1;
-        L.c_proj2.splitk = pick_splitk(L.c_proj2.Npad / 32, F / 16);
     }
     reg_ln(e, pd + "ln_f.", &e->ln_f, D);
     }   // v1 registration
 
-    if (c.weight_dtype == SV_WEIGHT_FP8_E4M3) {
-        // decoder Linears + lm_head stream as fp8 at decode time; the fp8 kernel covers the slab pipeline only
-        e->lm_head.fp8 = true;
+    {
+        // decode-path split-K: narrow outputs split K across blocks into fp32 slabs that the next kernel (attention / row update)
+        // sums in slab order; c_fc keeps the whole K (its bias + GELU epilogue needs the finished sum)
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, c.device) == hipSuccess && prop.multiProcessorCount > 0) e->num_cus = prop.multiProcessorCount;
+        const bool fp8 = c.weight_dtype == SV_WEIGHT_FP8_E4M3;
+        const bool legacy = getenv("SV_EXP") && (atoi(getenv("SV_EXP")) & 8);          // A/B: the round 1-2 split rule
+        if (fp8) e->lm_head.fp8 = true;                  // decoder Linears + lm_head stream as fp8 at decode time
         for (DecLayer& L : e->dec) {
             Linear* ls[4] = {&L.c_attn, &L.c_proj, &L.c_fc, &L.c_proj2};
             for (Linear* l : ls) {
-                l->fp8 = true;
-                // the fp8 kernel wants an even number (>= 2 per wave pair) of k-steps per wave: shrink split-K until it fits
+                l->fp8 = fp8;
                 const int KS = l->Kpad / 16;
-                while (l->splitk > 1 && (KS % l->splitk != 0 || (KS / l->splitk) % 4 != 0)) --l->splitk;
-                if (((l->Kpad / 16) / l->splitk) % 4 != 0) {
-                    const int code = fail(SV_ENOTSUP, "fp8 weights: K=%d with split-K %d has no fp8 decode kernel", l->Kpad, l->splitk);
-                    sv_destroy(e);
-                    return code;
+                l->splitk = l == &L.c_fc ? 1 : pick_splitk(l->Npad / 32, KS, e->num_cus, fp8, legacy);
+                if (fp8) {
+                    // the fp8 kernel wants an even number (>= 2 per wave pair) of k-steps per wave: shrink split-K until it fits
+                    while (l->splitk > 1 && (KS % l->splitk != 0 || (KS / l->splitk) % 4 != 0)) --l->splitk;
+                    if ((KS / l->splitk) % 4 != 0) {
+                        const int code = fail(SV_ENOTSUP, "fp8 weights: K=%d with split-K %d has no fp8 decode kernel", l->Kpad, l->splitk);
+                        sv_destroy(e);
+                        return code;
+                    }
                 }
             }
         }
@@ -583,11 +607,6 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         hipError_t hr = hipStreamCreateWithFlags(&e->gen_stream, hipStreamNonBlocking);
         if (hr == hipSuccess) hr = hipEventCreateWithFlags(&e->gen_event, hipEventDisableTiming);
         if (hr != hipSuccess) rc = fail(SV_EHIP, "stream/event creation: %s", hipGetErrorString(hr));
-    }
-    {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, c.device) == hipSuccess && prop.multiProcessorCount > 0)
-            e->num_cus = prop.multiProcessorCount;
     }
     if (!rc && v2) {
         // rotary tables, computed in float like the reference's Starcoder2RotaryEmbedding and rounded to bf16
@@ -890,7 +909,7 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
         ru.pf_blocks = 0;
         if ((e->exp & 2) && e->num_cus > B) {
             ru.pf = prefetch_desc(next, next_splitk, MT, 4);
-            ru.pf_blocks = e->num_cus - B;
+            ru.pf_blocks = 2 * (e->num_cus - B);             // light blocks (4 waves, 8 KiB each): two per spare CU
         }
         prof_mark(e, PK_ROWLN, st);
         launch_row_update_ln(ru, st);

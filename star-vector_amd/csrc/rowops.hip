@@ -127,14 +127,12 @@ __global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (row >= p.M) {
         // spare CUs (the update itself keeps M blocks busy for a few microseconds of latency): XCD-aligned prefetch of the head of
-        // every consumer wave's weight stream of the GEMM that follows (common.h).  Two rounds of 8 loads per wave.
-        const int xcd = sv_xcc_id();
+        // every consumer wave's weight stream of the GEMM that follows (common.h).  One round of 8 loads per wave: the extra
+        // blocks must not outlive the update.  M % 8 == 0, so block `row` shares its XCD with consumer tiles nt = row (mod 8).
         const int nslots = (p.pf_blocks >> 3) * 4;                       // participants per XCD: 4 waves per extra block
         const int slot = ((row - p.M) >> 3) * 4 + wave;
         u32x4 t[8];
-        sv_prefetch_issue<8>(p.pf, xcd, slot, nslots, lane, t);
-        sv_prefetch_sink<8>(t, reinterpret_cast<unsigned*>(p.xp_out));
-        sv_prefetch_issue<8>(p.pf, xcd, slot + 8 * nslots, nslots, lane, t);
+        sv_prefetch_issue<8>(p.pf, row & 7, slot, nslots, lane, t);
         sv_prefetch_sink<8>(t, reinterpret_cast<unsigned*>(p.xp_out));
         return;
     }

@@ -108,7 +108,9 @@ def test_starvector_8b_full_depth_against_gpu_oracle(weights):
     drawn on the GPU (seconds instead of minutes of host RNG) and handed to BOTH the engine and the float32 oracle."""
     cfg = dataclasses.replace(O.OracleConfig.starvector_8b(), eos_token_id=-1)
     B, n_new = 2, 17
-    eng = sva.HipEngine(sva.EngineConfig.starvector_8b(max_batch=2, max_seq_len=578 + 72, weight_dtype=weights))
+    ec = sva.EngineConfig.starvector_8b(max_batch=2, max_seq_len=578 + 72)
+    ec.weight_dtype = weights
+    eng = sva.HipEngine(ec)
     w_dev = {}
     for name, tns in O.iter_weights(cfg, seed=91, init="parity", device=dev()):
         eng.load_weight(name, tns.to(torch.bfloat16))
