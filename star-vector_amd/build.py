@@ -14,7 +14,11 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libstarvector_hip.so")
 SOURCES = ["gemm.hip", "rowops.hip", "attention.hip", "sampling.hip", "beam.hip", "preprocess.hip", "engine.hip"]
 HEADERS = ["common.h", "kernels.h", "beam.h", "warp.h", os.path.join("..", "..", "include", "starvector_hip.h")]
+# -amdgpu-kernarg-preload-count: leading scalar / pointer kernel parameters arrive in SGPRs with the dispatch (gfx950) instead
+# of through a scalar load at the top of every kernel (the decode step is 172 dependent launches)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + os.environ.get("SV_HIPCC_FLAGS", "").split()
+if not os.environ.get("SV_NO_KERNARG_PRELOAD"):          # A/B switch of the build (profiles/kernarg_preload_r03_ab.log)
+    FLAGS += ["-mllvm", "-amdgpu-kernarg-preload-count=16"]
 
 
 def _hipcc() -> str:

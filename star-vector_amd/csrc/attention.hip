@@ -335,43 +335,36 @@ __device__ __forceinline__ void load_group(KvFrags<D>& f, const char* pool, int 
         f.v[t] = *reinterpret_cast<const u32x4*>(page + (size_t)64 * D * 2 + ((size_t)((half * NDV + t) * 64 + lane)) * 16);
 }
 
+// Leading scalar parameters: what the first loads (position, block table, KV fragments, c_attn slabs) need; they arrive
+// preloaded in SGPRs with the dispatch (see gemm_skinny_kernel), the struct is read later.
+struct AttnDecodeKernarg { const int32_t* positions; const int32_t* block_table; char* pool_layer; const float* ws; size_t kv_head_stride;
+                           int max_pages, n_kv, max_splits, window; AttnDecodeArgs p; };          // the kernarg segment
 template <int D>
-__global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeArgs p) {
+__global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_t* positions_, const int32_t* block_table_, char* pool_layer_,
+                                                                     const float* ws_, size_t kv_head_stride_, int max_pages_, int n_kv_,
+                                                                     int max_splits_, int window_, AttnDecodeArgs p_unused) {
     constexpr int NKS = D / 32;          // k-steps of S^T (over head_dim)
     constexpr int NDV = D / 16;          // dv tiles of O^T
     constexpr int PART = 32 + 16 * D;    // floats per partial: m[16], l[16], O[16][D]
     const int bx = blockIdx.x;               // (sequence, KV head)
-    const int b = bx / p.n_kv;
-    const int kvh = bx % p.n_kv;
+    const int b = bx / n_kv_;
+    const int kvh = bx % n_kv_;
     const int split = blockIdx.y;
     // the first 64 entries of this sequence's block-table row (4096 tokens) are requested together with the position: the
     // page of a key group is then a cross-lane read instead of a second dependent global round trip (position -> table -> KV)
-    const int32_t* table = p.block_table + (size_t)b * p.max_pages;
+    const int32_t* table = block_table_ + (size_t)b * max_pages_;
     const int tl = threadIdx.x & 63;
-    const int tpre = tl < p.max_pages ? table[tl] : 0;
-    const int pos = p.positions[b];
+    const int tpre = tl < max_pages_ ? table[tl] : 0;
+    const int pos = positions_[b];
     const int L = pos + 1;
     const int ngroups = (L + 31) >> 5;
     // StarCoder2 sliding window: only keys win0 <= j <= pos are visible; whole groups (and pages) below are skipped
-    const int win0 = (p.window > 0 && L > p.window) ? L - p.window : 0;
+    const int win0 = (window_ > 0 && L > window_) ? L - window_ : 0;
     const int g0 = win0 >> 5;
-    const int gpb = p.groups_per_block > 0 ? p.groups_per_block : AD_GROUPS_PER_BLOCK;
-    int act = (ngroups - g0 + gpb - 1) / gpb;
-    act = act > p.max_splits ? p.max_splits : act;      // host cap: B * act <= #CUs (one block per CU) and <= AD_SPLIT
+    int act = (ngroups - g0 + AD_GROUPS_PER_BLOCK - 1) / AD_GROUPS_PER_BLOCK;
+    act = act > max_splits_ ? max_splits_ : act;      // host cap: B * act <= #CUs (one block per CU) and <= AD_SPLIT
     act = act < 1 ? 1 : act;
-    // XCD-aligned prefetch of the next GEMM's weights (common.h): participant slots of this XCD = (sequence group, split, wave)
-    const bool pf_on = p.pf.base != nullptr && (gridDim.x & 7) == 0 && split < p.max_splits;
-    const int pf_nslots = (gridDim.x >> 3) * p.max_splits * AD_WAVES;
-    const int pf_slot0 = ((bx >> 3) * p.max_splits + split) * AD_WAVES;
-    if (split >= act) {
-        if (pf_on) {      // an active-range split with no keys yet (short context): the whole block prefetches, then leaves
-            u32x4 t[4];
-            const int w = threadIdx.x >> 6;
-            sv_prefetch_issue<4>(p.pf, bx & 7, pf_slot0 + w, pf_nslots, threadIdx.x & 63, t);
-            sv_prefetch_sink<4>(t, p.counters);
-        }
-        return;
-    }
+    if (split >= act) return;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* q_s = reinterpret_cast<bf16_t*>(smem);                       // [16][D]
@@ -383,10 +376,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int H = p.H;                       // all query heads of the model
-    const int G = H / p.n_kv;                // query heads sharing this KV head (<= 16): the MFMA N side
-    const int HD = G * D;                    // output columns owned by this block
-    char* const pool = p.pool_layer + (size_t)kvh * p.kv_head_stride;
+    char* const pool = pool_layer_ + (size_t)kvh * kv_head_stride_;
 
     const int page_bytes = kv_page_bytes(D);
     auto page_of = [&](int grp) -> int {                   // grp is wave-uniform
@@ -397,15 +387,13 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
     const int stride = act * AD_WAVES;
     int g = g0 + split + act * wave;
     KvFrags<D> fa, fb;
-    // waves 4..7 without a key group (contexts up to ~1000 tokens at 8 splits) carry the prefetch of their own slot and of wave
-    // w - 4's (busy with keys); the loads land in fa's registers, which such a wave never uses otherwise
-    const bool pf_wave = pf_on && g >= ngroups && wave >= 4;
     if (g < ngroups) load_group<D>(fa, pool, page_of(g), page_bytes, g, lane);
-    else if (pf_wave) {
-        const int xcd = bx & 7;                 // linear block id = bx + gridDim.x * split, gridDim.x % 8 == 0
-        sv_prefetch_issue<NKS>(p.pf, xcd, pf_slot0 + wave, pf_nslots, lane, &fa.k[0][0]);
-        sv_prefetch_issue<NKS>(p.pf, xcd, pf_slot0 + wave - 4, pf_nslots, lane, &fa.k[1][0]);
-    }
+
+    // the KV stream is in flight: now the rest of the arguments (common.h sv_late_args)
+    const AttnDecodeArgs p = sv_late_args<AttnDecodeArgs>(offsetof(AttnDecodeKernarg, p));
+    const int H = p.H;                       // all query heads of the model
+    const int G = H / n_kv_;                 // query heads sharing this KV head (<= 16): the MFMA N side
+    const int HD = G * D;                    // output columns owned by this block
 
     // q / k_new / v_new of this sequence -> LDS (bf16): the fp32 split-K slabs of the c_attn GEMM, summed here in slab order + bias.
     // 4 columns per thread and every load issued before the first add: one memory round trip.
@@ -423,7 +411,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
 #pragma unroll
                 for (int sp = 0; sp < 8; ++sp)
                     if (sp < p.splitk)
-                        acc4[sp] = *reinterpret_cast<const float4*>(p.ws + ((size_t)sp * p.rows_ws + b) * p.ldws + col);
+                        acc4[sp] = *reinterpret_cast<const float4*>(ws_ + ((size_t)sp * p.rows_ws + b) * p.ldws + col);
                 float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int sp = 0; sp < 8; ++sp)
@@ -548,7 +536,6 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(AttnDecodeAr
         g = g2;
     }
 
-    if (pf_wave) sv_prefetch_sink<2 * NKS>(&fa.k[0][0], p.counters);       // (kept alive longer, the 8 vectors push the merge code into spills)
     // merge the waves of this block (LDS), in wave order
     float l_tot = l_run + __shfl_xor(l_run, 16, 64);
     l_tot += __shfl_xor(l_tot, 32, 64);
@@ -690,9 +677,11 @@ void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
     const size_t smem = attn_decode_smem(a.head_dim);
     dim3 grid(a.B * a.n_kv, AD_SPLIT);
     if (a.head_dim == 128)
-        attn_decode_kernel<128><<<grid, AD_WAVES * 64, smem, st>>>(a);
+        attn_decode_kernel<128><<<grid, AD_WAVES * 64, smem, st>>>(a.positions, a.block_table, a.pool_layer, a.ws, a.kv_head_stride,
+                                                                    a.max_pages, a.n_kv, a.max_splits, a.window, a);
     else
-        attn_decode_kernel<64><<<grid, AD_WAVES * 64, smem, st>>>(a);
+        attn_decode_kernel<64><<<grid, AD_WAVES * 64, smem, st>>>(a.positions, a.block_table, a.pool_layer, a.ws, a.kv_head_stride,
+                                                                   a.max_pages, a.n_kv, a.max_splits, a.window, a);
 }
 
 }  // namespace sv

@@ -58,51 +58,25 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// XCD-aligned weight prefetch.  The decode step alternates weight-streaming GEMMs with latency-bound kernels (paged attention,
-// row update) during which HBM is nearly idle; the small GEMMs that follow (c_attn, attention c_proj: ~1.1 MiB per XCD) are a
-// single HBM round trip per wave, i.e. mostly first-touch latency.  Waves with nothing to do in the latency-bound kernel read
-// the head of every consumer wave's weight stream with ordinary loads, so the lines sit in the L2 of the XCD THE CONSUMER BLOCK
-// WILL RUN ON: workgroups are dealt round-robin to the 8 XCDs in launch order, by the SAME rule in every launch of a replayed
-// graph (tools/diag/xcd_map.hip on MI355X: linear block id b runs on HW_REG_XCC_ID (b + 7) % 8, every kernel, every replay) -- a
-// speed assumption only, a wrong guess costs the hint, never a result.  So a prefetching block with linear id p and consumer
-// block (nt, split) of a skinny GEMM with NT % 8 == 0 share an XCD iff p % 8 == nt % 8: the prefetcher takes the tiles
-// congruent to ITS OWN block id (the hardware register would be off by that rotation: round 3's first attempt).
-// Round 2's linear slicing parked the lines in other XCDs' L2s / the Infinity Cache and bought nothing (profiles/prefetch_r02_ab.log).
-// A piece = the first `piece_units` KiB of one consumer wave's stream; a unit = 1 KiB = one wave-wide 16-byte load.
+// Late argument block.  A decode kernel's leading scalar / pointer parameters are preloaded into SGPRs with the dispatch
+// (-amdgpu-kernarg-preload-count): enough to issue its first global loads at once.  The rest of its arguments travel as a
+// by-value struct placed right after them in the kernarg segment; read through an ordinary `p.field` the compiler hoists the
+// scalar loads to the top of the kernel and waits for them BEFORE the first global load (a cold K$ miss at every launch, 172
+// launches per decode step).  sv_late_args reads the struct through the kernarg pointer laundered by an empty asm, so the
+// scalar loads are issued where this is called -- after the kernel's first loads are in flight.
 // ------------------------------------------------------------------------------------------------
-struct PrefetchDesc {
-    const char* base;          // packed weight image (nullptr = off)
-    unsigned tile_bytes;       // bytes of one 32-column tile (K/16 KiB for bf16)
-    int n_tiles;               // column tiles of the consumer (its grid.x)
-    int pieces;                // consumer wave streams per tile (splitk * waves per block)
-    unsigned piece_stride;     // bytes between the starts of consecutive streams
-    int piece_units;           // KiB prefetched at the head of each stream
-};
-// Issue up to NU loads: units slot, slot + nslots, ... of this XCD's share (units past the end re-read the first line).
-// The caller keeps `dst` alive until sv_prefetch_sink (the loads are ordinary loads: the compiler tracks them).
-template <int NU>
-__device__ __forceinline__ void sv_prefetch_issue(const PrefetchDesc& d, int xcd, int slot, int nslots, int lane, u32x4* dst) {
-    const int n_own = (d.n_tiles - xcd + 7) >> 3;                  // tiles xcd, xcd + 8, ...
-    const int total = n_own * d.pieces * d.piece_units;
+template <typename T>
+__device__ __forceinline__ T sv_late_args(unsigned byte_offset) {
+    typedef const char __attribute__((address_space(4))) * kaptr_t;
+    typedef const uint32_t __attribute__((address_space(4))) * kaw_t;
+    kaptr_t ka = (kaptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka) : : "memory");
+    kaw_t w = (kaw_t)(ka + byte_offset);
+    constexpr int N = (int)((sizeof(T) + 3) / 4);
+    union U { T t; uint32_t w[N]; __device__ U() {} } u;          // T: a plain argument struct
 #pragma unroll
-    for (int k = 0; k < NU; ++k) {
-        const int u = slot + k * nslots;
-        size_t off = 0;
-        if (u < total) {                                            // wave-uniform
-            const int q = u / d.piece_units, kb = u - q * d.piece_units;
-            const int ti = q / d.pieces, pc = q - ti * d.pieces;
-            off = (size_t)(xcd + 8 * ti) * d.tile_bytes + (size_t)pc * d.piece_stride + (size_t)kb * 1024;
-        }
-        dst[k] = *reinterpret_cast<const u32x4*>(d.base + off + (size_t)lane * 16);
-    }
-}
-// Wait for the prefetch loads where the wave has time to (data-dependent, practically never taken store keeps them alive).
-template <int NU>
-__device__ __forceinline__ void sv_prefetch_sink(const u32x4* dst, unsigned* scratch_word) {
-    unsigned x = 0;
-#pragma unroll
-    for (int k = 0; k < NU; ++k) x ^= dst[k][0] ^ dst[k][1] ^ dst[k][2] ^ dst[k][3];
-    if (x == 0x9e3779b9u && scratch_word == reinterpret_cast<unsigned*>(1)) *scratch_word = x;      // never true
+    for (int i = 0; i < N; ++i) u.w[i] = w[i];                    // constant address space, uniform address: scalar loads
+    return u.t;
 }
 
 // activations used by the path's fused epilogues

@@ -169,9 +169,9 @@ struct sv_engine {
     bool only_skinny = false;       // profiling: enqueue only the weight-streaming GEMMs of a step
     bool skip_skinny = false;       // profiling: enqueue everything BUT the weight-streaming GEMMs
     int exp = 0;                    // SV_EXP bit mask, read once at sv_create (A/B switches of the round's experiments):
-                                    //   1 attention's idle waves prefetch c_proj; 2 spare blocks of the row update prefetch the next GEMM;
-                                    //   4 decode attention: one 32-key group per block before another context split joins;
                                     //   8 (at sv_create only) the round 1-2 split-K rule of the decode GEMMs
+                                    //   (1, 2: XCD-aligned weight prefetch by attention's idle waves / spare row-update blocks; 4: one key
+                                    //    group per attention block -- all measured slower, profiles/prefetch_r03_*.log, removed)
     float *ws = nullptr, *ws2 = nullptr, *logits = nullptr, *sample_scratch = nullptr, *attn_part = nullptr;
     unsigned* attn_cnt = nullptr;
     float* am_val = nullptr; int32_t* am_idx = nullptr;
@@ -870,23 +870,6 @@ static int prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hi
     return 0;
 }
 
-// XCD-aligned L2 prefetch of a decode GEMM's weights by the latency-bound kernel in front of it (common.h): the head
-// (`max_units` KiB) of every consumer wave's stream.  Off (base = nullptr) where the consumer's block -> XCD map is not nt % 8.
-static PrefetchDesc prefetch_desc(const Linear& l, int splitk, int MT, int max_units) {
-    PrefetchDesc d;
-    memset(&d, 0, sizeof(d));
-    if (l.fp8 || !l.Wp) return d;
-    int waves = 0, two = 0;
-    skinny_plan(l.Npad, l.Kpad, splitk, 0, MT, &waves, &two);
-    const int KS = l.Kpad / 16, NT = l.Npad / 32;
-    if (waves < 1 || (splitk > 1 && (NT & 7)) || KS % (splitk * waves)) return d;
-    const int kspw = KS / (splitk * waves);
-    d.base = reinterpret_cast<const char*>(l.Wp);
-    d.tile_bytes = (unsigned)KS * 1024u; d.n_tiles = NT; d.pieces = splitk * waves; d.piece_stride = (unsigned)kspw * 1024u;
-    d.piece_units = kspw < max_units ? kspw : max_units;
-    return d;
-}
-
 // One autoregressive step: consumes cur_tok / positions, leaves logits in e->logits.  7 launches per layer + 2:
 //   row update (embedding | + bias + residual of the previous down-proj, LN1) | c_attn -> fp32 slabs | attention (sums the
 //   slabs, + bias) | c_proj -> slabs | row update (+ bias, + residual, LN2) | c_fc (bias + GELU epilogue) | down-proj -> slabs
@@ -903,14 +886,8 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
     ru.ldws = e->ldws; ru.rows_ws = MT * 32;
     ru.ws = nullptr; ru.wte = e->wte; ru.wpe = e->wpe; ru.tokens = e->cur_tok; ru.positions = e->positions;
     ru.g = e->dec[0].ln1.g; ru.b = e->dec[0].ln1.b;
-    auto row_update = [&](const Linear& next, int next_splitk) {
+    auto row_update = [&]() {
         if (e->only_skinny) return;
-        memset(&ru.pf, 0, sizeof(ru.pf));
-        ru.pf_blocks = 0;
-        if ((e->exp & 2) && e->num_cus > B) {
-            ru.pf = prefetch_desc(next, next_splitk, MT, 4);
-            ru.pf_blocks = 2 * (e->num_cus - B);             // light blocks (4 waves, 8 KiB each): two per spare CU
-        }
         prof_mark(e, PK_ROWLN, st);
         launch_row_update_ln(ru, st);
     };
@@ -928,7 +905,7 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
     };
     for (int i = 0; i < c.n_layer; ++i) {
         DecLayer& L = e->dec[i];
-        row_update(L.c_attn, L.c_attn.splitk);                   // embedding or the previous layer's down-proj -> LN1(h)
+        row_update();                                            // embedding or the previous layer's down-proj -> LN1(h)
         skinny(e->xp_a, L.c_attn, SK_OUT_PARTIAL, wsA);
         if (!e->only_skinny) {
             AttnDecodeArgs ad;
@@ -941,20 +918,18 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
             ad.part = e->attn_part; ad.counters = e->attn_cnt;
             ad.max_splits = attn_max_splits(e);
             ad.n_kv = e->nkv; ad.kv_head_stride = e->kv_head_stride; ad.rope_cos = e->rope_cos; ad.rope_sin = e->rope_sin;
-            if (e->exp & 1) ad.pf = prefetch_desc(L.c_proj, L.c_proj.splitk, MT, 4);
-            if (e->exp & 4) ad.groups_per_block = 1;
             prof_mark(e, PK_ATTN, st);
             launch_attn_decode(ad, st);
         }
         skinny(e->xp_attn, L.c_proj, SK_OUT_PARTIAL, wsB);
         ru.ws = wsB; ru.splitk = L.c_proj.splitk; ru.bias = L.c_proj.bias; ru.g = L.ln2.g; ru.b = L.ln2.b;
-        row_update(L.c_fc, 1);                                   // + bias + residual, LN2
+        row_update();                                            // + bias + residual, LN2
         skinny(e->xp_a, L.c_fc, SK_OUT_PACKED_ACT, nullptr);
         skinny(e->xp_mlp, L.c_proj2, SK_OUT_PARTIAL, wsB);
         const LNp& nxt = (i + 1 < c.n_layer) ? e->dec[i + 1].ln1 : e->ln_f;
         ru.ws = wsB; ru.splitk = L.c_proj2.splitk; ru.bias = L.c_proj2.bias; ru.g = nxt.g; ru.b = nxt.b;
     }
-    row_update(e->lm_head, 1);                                   // + bias + residual, ln_f
+    row_update();                                                // + bias + residual, ln_f
     skinny(e->xp_a, e->lm_head, SK_OUT_F32, nullptr);
     prof_mark(e, PK_SAMPLE, st);      // closes the lm_head interval; whatever follows is sampling
 }

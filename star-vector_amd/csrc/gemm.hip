@@ -1065,8 +1065,12 @@ __device__ __forceinline__ void sk_store(const SkinnyArgs& p, float* v, const fl
     }
 }
 
+// Leading scalar parameters = the few values the first address computation needs: they are PRELOADED into SGPRs by the command
+// processor (build flag -amdgpu-kernarg-preload-count; only scalar / pointer parameters qualify, not a by-value struct), so the
+// weight stream is requested without first waiting for a scalar load of the argument block (a cold K$ miss at every launch).
+struct SkinnyKernarg { const void* W; const bf16_t* x; int K; int splitk; SkinnyArgs p; };      // the kernarg segment of the skinny kernels
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* Wp_, const bf16_t* xp_, int K_, int splitk_, SkinnyArgs p_unused) {
     constexpr int CH = 4;                            // k-steps per register chunk (two chunks = 8 KiB of W in flight per wave)
     constexpr int NB = 2;
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
@@ -1077,27 +1081,28 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(SkinnyArgs p) {
     const int nt = blockIdx.x;
     const int split = blockIdx.y;
     const int mt = blockIdx.z;
-    const int KS = p.K >> 4;
-    const int ks_per_split = KS / p.splitk;
+    const int KS = K_ >> 4;
+    const int ks_per_split = KS / splitk_;
     const int ks_per_wave = ks_per_split / WAVES;
     const int ks0 = split * ks_per_split + wave * ks_per_wave;
     const int m = lane & 31;
     const int half = lane >> 5;
 
-    const u32x4* wptr = reinterpret_cast<const u32x4*>(p.Wp) + ((size_t)nt * KS + ks0) * 64 + lane;
-    const u32x4* xptr = reinterpret_cast<const u32x4*>(p.xp) + ((size_t)mt * KS + ks0) * 64 + lane;
+    const u32x4* wptr = reinterpret_cast<const u32x4*>(Wp_) + ((size_t)nt * KS + ks0) * 64 + lane;
+    const u32x4* xptr = reinterpret_cast<const u32x4*>(xp_) + ((size_t)mt * KS + ks0) * 64 + lane;
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
     constexpr int RPW = 16 / WAVES;
-    float bias_d[RPW];
-    sk_bias<RPW>(p, bias_d, wave * RPW, nt, half);
     SkChunk<CH> ck[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b)
         if (b * CH < ks_per_wave) sk_load<CH>(ck[b], wptr, xptr, b * CH, ks_per_wave);
+    const SkinnyArgs p = sv_late_args<SkinnyArgs>(offsetof(SkinnyKernarg, p));       // the stream is in flight: now the rest
+    float bias_d[RPW];
+    sk_bias<RPW>(p, bias_d, wave * RPW, nt, half);
 
     for (int ks = 0; ks < ks_per_wave; ks += NB * CH) {
 #pragma unroll
@@ -1147,7 +1152,7 @@ int init_gemm_kernels() {
 
 template <int W>
 static void launch_sk(const SkinnyArgs& a, dim3 grid, hipStream_t st) {
-    gemm_skinny_kernel<W><<<grid, W * 64, skinny_smem(W), st>>>(a);
+    gemm_skinny_kernel<W><<<grid, W * 64, skinny_smem(W), st>>>(a.Wp, a.xp, a.K, a.splitk, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1160,7 +1165,7 @@ static void launch_sk(const SkinnyArgs& a, dim3 grid, hipStream_t st) {
 // as the bf16 kernel has (one CU streams ~25 GB/s whatever the element size: it is the bytes in flight that count).
 // ------------------------------------------------------------------------------------------------
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_fp8_kernel(SkinnyArgs p) {
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_fp8_kernel(const uint8_t* Wq_, const bf16_t* xp_, int K_, int splitk_, SkinnyArgs p_unused) {
     constexpr int CH = 8;
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(sk_smem);          // [WAVES][16][64]
@@ -1168,26 +1173,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_fp8_kernel(SkinnyArgs 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = blockIdx.x, split = blockIdx.y, mt = blockIdx.z;
-    const int KS = p.K >> 4;
-    const int ks_per_split = KS / p.splitk;
+    const int KS = K_ >> 4;
+    const int ks_per_split = KS / splitk_;
     const int ks_per_wave = ks_per_split / WAVES;          // even (launcher)
     const int ks0 = split * ks_per_split + wave * ks_per_wave;
     const int m = lane & 31, half = lane >> 5;
 
-    const u32x4* wq = reinterpret_cast<const u32x4*>(p.Wq) + ((size_t)nt * (KS >> 1) + (ks0 >> 1)) * 64 + lane;
-    const u32x4* xptr = reinterpret_cast<const u32x4*>(p.xp) + ((size_t)mt * KS + ks0) * 64 + lane;
+    const u32x4* wq = reinterpret_cast<const u32x4*>(Wq_) + ((size_t)nt * (KS >> 1) + (ks0 >> 1)) * 64 + lane;
+    const u32x4* xptr = reinterpret_cast<const u32x4*>(xp_) + ((size_t)mt * KS + ks0) * 64 + lane;
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float4 sc4[4];
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) sc4[rg] = *reinterpret_cast<const float4*>(p.wscale + nt * 32 + rg * 8 + half * 4);
-
     constexpr int RPW = 16 / WAVES;                       // WAVES in {2, 4, 8}
-    float bias_d[RPW];
-    sk_bias<RPW>(p, bias_d, wave * RPW, nt, half);
-
     struct Chunk { u32x4 w[CH / 2]; u32x4 x[CH]; };
     Chunk ca, cb;
     auto load = [&](Chunk& c, int ks) {
@@ -1216,6 +1214,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_fp8_kernel(SkinnyArgs 
     };
     load(ca, 0);
     if (CH < ks_per_wave) load(cb, CH);
+    // scales and bias need the argument block (a scalar load): requested after the stream is in flight
+    const SkinnyArgs p = sv_late_args<SkinnyArgs>(offsetof(SkinnyKernarg, p));
+    float4 sc4[4];
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg) sc4[rg] = *reinterpret_cast<const float4*>(p.wscale + nt * 32 + rg * 8 + half * 4);
+    float bias_d[RPW];
+    sk_bias<RPW>(p, bias_d, wave * RPW, nt, half);
     for (int ks = 0; ks < ks_per_wave; ks += 2 * CH) {
         compute(ca, ks);
         if (ks + 2 * CH < ks_per_wave) load(ca, ks + 2 * CH);
@@ -1271,9 +1276,9 @@ static bool launch_gemm_skinny_fp8(const SkinnyArgs& a, hipStream_t st) {
     const int per_split = (a.K / 16) / a.splitk;
     (void)per_split;
     const int waves = skinny_waves_fp8(a.K / 16, a.splitk);
-    if (waves == 8) gemm_skinny_fp8_kernel<8><<<grid, 512, 8 * 16 * 64 * 4, st>>>(a);
-    else if (waves == 4) gemm_skinny_fp8_kernel<4><<<grid, 256, 4 * 16 * 64 * 4, st>>>(a);
-    else if (waves == 2) gemm_skinny_fp8_kernel<2><<<grid, 128, 2 * 16 * 64 * 4, st>>>(a);
+    if (waves == 8) gemm_skinny_fp8_kernel<8><<<grid, 512, 8 * 16 * 64 * 4, st>>>(a.Wq, a.xp, a.K, a.splitk, a);
+    else if (waves == 4) gemm_skinny_fp8_kernel<4><<<grid, 256, 4 * 16 * 64 * 4, st>>>(a.Wq, a.xp, a.K, a.splitk, a);
+    else if (waves == 2) gemm_skinny_fp8_kernel<2><<<grid, 128, 2 * 16 * 64 * 4, st>>>(a.Wq, a.xp, a.K, a.splitk, a);
     else return false;
     return true;
 }
@@ -1288,7 +1293,7 @@ static bool launch_gemm_skinny_fp8(const SkinnyArgs& a, hipStream_t st) {
 // fp8 (e4m3, widened in registers, per-column scale on the accumulator) weights.  NBUF register chunks of CH k-steps ring.
 // ------------------------------------------------------------------------------------------------
 template <int WAVES, bool FP8>
-__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(SkinnyArgs p) {
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(const void* W_, const bf16_t* xp_, int K_, int splitk_, SkinnyArgs p_unused) {
     constexpr int CH = 4;
     constexpr int NBUF = FP8 ? 3 : 2;
     constexpr int WCH = FP8 ? CH / 2 : CH;                 // 16-byte weight loads per chunk and lane
@@ -1298,15 +1303,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(SkinnyArgs 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = blockIdx.x, split = blockIdx.y, mt0 = blockIdx.z * 2;
-    const int KS = p.K >> 4;
-    const int ks_per_split = KS / p.splitk;
+    const int KS = K_ >> 4;
+    const int ks_per_split = KS / splitk_;
     const int ks_per_wave = ks_per_split / WAVES;          // fp8: even (launcher)
     const int ks0 = split * ks_per_split + wave * ks_per_wave;
     const int m = lane & 31, half = lane >> 5;
 
-    const u32x4* wptr = FP8 ? reinterpret_cast<const u32x4*>(p.Wq) + ((size_t)nt * (KS >> 1) + (ks0 >> 1)) * 64 + lane
-                            : reinterpret_cast<const u32x4*>(p.Wp) + ((size_t)nt * KS + ks0) * 64 + lane;
-    const u32x4* xptr0 = reinterpret_cast<const u32x4*>(p.xp) + ((size_t)mt0 * KS + ks0) * 64 + lane;
+    const u32x4* wptr = FP8 ? reinterpret_cast<const u32x4*>(W_) + ((size_t)nt * (KS >> 1) + (ks0 >> 1)) * 64 + lane
+                            : reinterpret_cast<const u32x4*>(W_) + ((size_t)nt * KS + ks0) * 64 + lane;
+    const u32x4* xptr0 = reinterpret_cast<const u32x4*>(xp_) + ((size_t)mt0 * KS + ks0) * 64 + lane;
     const u32x4* xptr1 = xptr0 + (size_t)KS * 64;
 
     f32x16 acc0, acc1;
@@ -1314,9 +1319,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(SkinnyArgs 
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
 
     constexpr int RPW = 16 / WAVES;                       // WAVES in {4, 8}
-    float bias_d[RPW];
-    sk_bias<RPW>(p, bias_d, wave * RPW, nt, half);
-
     struct Chunk { u32x4 w[WCH]; u32x4 x0[CH]; u32x4 x1[CH]; };
     Chunk c[NBUF];
     auto load = [&](Chunk& k, int ks) {                    // ks multiple of CH; the last chunk of a wave may be ragged
@@ -1354,6 +1356,9 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(SkinnyArgs 
 #pragma unroll
     for (int b = 0; b < NBUF; ++b)
         if (b * CH < ks_per_wave) load(c[b], b * CH);
+    const SkinnyArgs p = sv_late_args<SkinnyArgs>(offsetof(SkinnyKernarg, p));       // the stream is in flight: now the rest
+    float bias_d[RPW];
+    sk_bias<RPW>(p, bias_d, wave * RPW, nt, half);
     for (int ks = 0; ks < ks_per_wave; ks += NBUF * CH) {
 #pragma unroll
         for (int b = 0; b < NBUF; ++b) {
@@ -1404,13 +1409,13 @@ static bool launch_gemm_skinny_mt2(const SkinnyArgs& a, hipStream_t st) {
     // the SAME number of waves (= the same per-wave k ranges and reduction order) as the one-tile kernel of this GEMM
     const int waves = a.Wq ? skinny_waves_fp8(a.K / 16, a.splitk) : skinny_waves(a.Npad, a.K / 16, a.splitk);
     if (waves == 8) {
-        if (a.Wq) gemm_skinny_mt2_kernel<8, true><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(a);
-        else gemm_skinny_mt2_kernel<8, false><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(a);
+        if (a.Wq) gemm_skinny_mt2_kernel<8, true><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(a.Wq, a.xp, a.K, a.splitk, a);
+        else gemm_skinny_mt2_kernel<8, false><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(a.Wp, a.xp, a.K, a.splitk, a);
         return true;
     }
     if (waves == 4) {
-        if (a.Wq) gemm_skinny_mt2_kernel<4, true><<<grid, 256, 2 * 4 * 16 * 64 * 4, st>>>(a);
-        else gemm_skinny_mt2_kernel<4, false><<<grid, 256, 2 * 4 * 16 * 64 * 4, st>>>(a);
+        if (a.Wq) gemm_skinny_mt2_kernel<4, true><<<grid, 256, 2 * 4 * 16 * 64 * 4, st>>>(a.Wq, a.xp, a.K, a.splitk, a);
+        else gemm_skinny_mt2_kernel<4, false><<<grid, 256, 2 * 4 * 16 * 64 * 4, st>>>(a.Wp, a.xp, a.K, a.splitk, a);
         return true;
     }
     return false;       // 16-wave (narrow outputs) and 1/2-wave (tiny K) shapes keep one row tile per block

@@ -79,7 +79,6 @@ struct RowUpdateArgs {
     const bf16_t* g; const bf16_t* b; float eps;           // LayerNorm applied to the updated row
     bf16_t* xp_out;                                        // packed LN output
     int M, D;
-    PrefetchDesc pf; int pf_blocks;                        // blocks [M, M + pf_blocks) warm the L2 for the next GEMM (0 = off)
 };
 void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st);
 
@@ -136,8 +135,6 @@ struct AttnDecodeArgs {
     size_t kv_head_stride;                                 // bytes between the page pools of consecutive KV heads
     const float* rope_cos; const float* rope_sin;          // [positions][D/2] rotary tables (nullptr: no RoPE)
     int window;                                            // sliding window: keys pos - window < j <= pos (0 = all)
-    int groups_per_block;                                  // 32-key groups a block takes before another split joins (0 = 4)
-    PrefetchDesc pf;                                       // idle waves warm the L2 for the next GEMM (attention c_proj); base = nullptr: off
 };
 // in-place rotary embedding of the q and k heads of a prefill c_attn output (rotate_half convention)
 void launch_rope_prefill(bf16_t* qkv, int row_stride, int rows, int S0, int n_heads, int head_dim,

@@ -119,25 +119,19 @@ void launch_layernorm_rows_packed(const bf16_t* x, int ldx, const bf16_t* g, con
 //   then           : xp = LN(h)   written in fragment order for the next skinny GEMM
 // the split-K slabs are summed in slab order -> bitwise deterministic.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
+// (leading scalar parameters: preloaded into SGPRs with the dispatch, see gemm_skinny_kernel)
+struct RowUpdateKernarg { const float* ws; const bf16_t* bias; bf16_t* h; const bf16_t* g; const bf16_t* b;
+                          int splitk, ldws, rows_ws, ldh, D, M; RowUpdateArgs p; };               // the kernarg segment
+__global__ __launch_bounds__(256) void row_update_ln_kernel(const float* ws_, const bf16_t* bias_, bf16_t* h_, const bf16_t* g_,
+                                                            const bf16_t* b_, int splitk_, int ldws_, int rows_ws_, int ldh_, int D_,
+                                                            int M_, RowUpdateArgs p_unused) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* hrow = reinterpret_cast<float*>(smem_raw);          // [D]
     __shared__ float redbuf[8];
     const int row = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (row >= p.M) {
-        // spare CUs (the update itself keeps M blocks busy for a few microseconds of latency): XCD-aligned prefetch of the head of
-        // every consumer wave's weight stream of the GEMM that follows (common.h).  One round of 8 loads per wave: the extra
-        // blocks must not outlive the update.  M % 8 == 0, so block `row` shares its XCD with consumer tiles nt = row (mod 8).
-        const int nslots = (p.pf_blocks >> 3) * 4;                       // participants per XCD: 4 waves per extra block
-        const int slot = ((row - p.M) >> 3) * 4 + wave;
-        u32x4 t[8];
-        sv_prefetch_issue<8>(p.pf, row & 7, slot, nslots, lane, t);
-        sv_prefetch_sink<8>(t, reinterpret_cast<unsigned*>(p.xp_out));
-        return;
-    }
-    const int D = p.D, NC = D >> 3;
-    bf16_t* hr = p.h + (size_t)row * p.ldh;
+    const int D = D_, NC = D >> 3;
+    bf16_t* hr = h_ + (size_t)row * ldh_;
 
     // gamma / beta do not depend on anything this kernel computes: request them first, so that the last phase does not
     // start with a global round trip (the kernel is a chain of latencies: slabs -> mean -> variance -> normalise)
@@ -149,16 +143,20 @@ __global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
         for (int i = 0; i < RU_PRE; ++i) {
             const int c = tid + i * 256;
             if (c < NC) {
-                gpre[i] = *reinterpret_cast<const uint4*>(p.g + c * 8);
-                bpre[i] = *reinterpret_cast<const uint4*>(p.b + c * 8);
+                gpre[i] = *reinterpret_cast<const uint4*>(g_ + c * 8);
+                bpre[i] = *reinterpret_cast<const uint4*>(b_ + c * 8);
             }
         }
     }
 
+    // the rest of the arguments (common.h sv_late_args): the embedding mode needs its tables at once, the slab mode only reads
+    // eps / the output pointer at the end -> after its loads are in flight
+    RowUpdateArgs p;
+    if (ws_ == nullptr) p = sv_late_args<RowUpdateArgs>(offsetof(RowUpdateKernarg, p));
     float s = 0.f;
     for (int c = tid; c < NC; c += 256) {
         float f[8];
-        if (p.ws == nullptr) {
+        if (ws_ == nullptr) {
             const int tok = p.tokens[row], pos = p.positions[row];
             float a[8], w[8];
             unpack8(*reinterpret_cast<const uint4*>(p.wte + (size_t)tok * D + c * 8), a);
@@ -176,20 +174,20 @@ __global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
             for (int e = 0; e < 8; ++e) v[e] = 0.f;
             // bias / residual and up to 4 slabs are requested together, then summed in slab order (a load per iteration,
             // each waited for, is one L2 round trip per slab)
-            const uint4 bq = *reinterpret_cast<const uint4*>(p.bias + c * 8);
+            const uint4 bq = *reinterpret_cast<const uint4*>(bias_ + c * 8);
             const uint4 hq = *reinterpret_cast<const uint4*>(hr + c * 8);
-            for (int base = 0; base < p.splitk; base += 4) {
+            for (int base = 0; base < splitk_; base += 4) {
                 float4 a[4], b4[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const int sp = base + j < p.splitk ? base + j : p.splitk - 1;
-                    const float* src = p.ws + ((size_t)sp * p.rows_ws + row) * p.ldws + c * 8;
+                    const int sp = base + j < splitk_ ? base + j : splitk_ - 1;
+                    const float* src = ws_ + ((size_t)sp * rows_ws_ + row) * ldws_ + c * 8;
                     a[j] = *reinterpret_cast<const float4*>(src);
                     b4[j] = *reinterpret_cast<const float4*>(src + 4);
                 }
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (base + j < p.splitk) {
+                    if (base + j < splitk_) {
                         v[0] += a[j].x; v[1] += a[j].y; v[2] += a[j].z; v[3] += a[j].w;
                         v[4] += b4[j].x; v[5] += b4[j].y; v[6] += b4[j].z; v[7] += b4[j].w;
                     }
@@ -205,6 +203,7 @@ __global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) { hrow[c * 8 + e] = f[e]; s += f[e]; }
     }
+    if (ws_ != nullptr) p = sv_late_args<RowUpdateArgs>(offsetof(RowUpdateKernarg, p));
     s = wave_sum(s);
     if (lane == 0) redbuf[wave] = s;
     __syncthreads();
@@ -236,8 +235,8 @@ __global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
     }
     for (int c = tid; c < NC; c += 256) {
         float f[8], gg[8], bb[8];
-        unpack8(*reinterpret_cast<const uint4*>(p.g + c * 8), gg);
-        unpack8(*reinterpret_cast<const uint4*>(p.b + c * 8), bb);
+        unpack8(*reinterpret_cast<const uint4*>(g_ + c * 8), gg);
+        unpack8(*reinterpret_cast<const uint4*>(b_ + c * 8), bb);
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = (hrow[c * 8 + e] - mean) * rstd * gg[e] + bb[e];
         *reinterpret_cast<uint4*>(p.xp_out + xp_index(row >> 5, KS, row & 31, c * 8)) = pack8(f);
@@ -245,10 +244,7 @@ __global__ __launch_bounds__(256) void row_update_ln_kernel(RowUpdateArgs p) {
 }
 
 void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st) {
-    const int extra = (a.pf.base && (a.M & 7) == 0 && a.pf_blocks >= 8) ? (a.pf_blocks & ~7) : 0;
-    RowUpdateArgs b = a;
-    b.pf_blocks = extra;
-    row_update_ln_kernel<<<a.M + extra, 256, a.D * sizeof(float), st>>>(b);
+    row_update_ln_kernel<<<a.M, 256, a.D * sizeof(float), st>>>(a.ws, a.bias, a.h, a.g, a.b, a.splitk, a.ldws, a.rows_ws, a.ldh, a.D, a.M, a);
 }
 
 // ------------------------------------------------------------------------------------------------

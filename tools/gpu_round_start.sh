@@ -12,6 +12,7 @@
 #     skinny      tools/bench_skinny.py                             -> bench_skinny.log
 #     xcd         tools/diag/xcd_map.hip: block -> XCD placement inside a replayed graph  -> xcd_map.log
 #     ab:<args>   tools/ab_exp.py <args> (in-process A/B of SV_EXP masks)           -> ab_exp.log
+#     rebuild:<K=V>  rebuild the library on the box with K=V in the environment (build-flag A/B, e.g. SV_NO_KERNARG_PRELOAD=1)
 #     env:<K=V>   export K=V for the steps that follow (experiment switches)
 # Everything lands under gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
 set -u
@@ -52,6 +53,7 @@ for s in "${STEPS[@]}"; do
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee "$OUT/smoke.log" ;;
     ctx) timeout 400 python tools/ctx_sweep.py 2>&1 | tee "$OUT/ctx_sweep.log" ;;
     skinny) timeout 200 python tools/bench_skinny.py 2>&1 | tee "$OUT/bench_skinny.log" ;;
+    rebuild:*) env ${s#rebuild:} python star-vector_amd/build.py --force 2>&1 | tail -1 ;;
     xcd) hipcc --offload-arch=gfx950 -O2 -o /tmp/xcd_map tools/diag/xcd_map.hip 2>/dev/null && /tmp/xcd_map 2>&1 | tee "$OUT/xcd_map.log" | tail -8 ;;
     ab:*) timeout 600 python tools/ab_exp.py ${s#ab:} 2>&1 | grep -v amdgpu.ids | tee -a "$OUT/ab_exp.log" ;;
     *) echo "unknown step $s" ;;
