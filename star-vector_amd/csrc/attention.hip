@@ -338,11 +338,11 @@ __device__ __forceinline__ void load_group(KvFrags<D>& f, const char* pool, int 
 // Leading scalar parameters: what the first loads (position, block table, KV fragments, c_attn slabs) need; they arrive
 // preloaded in SGPRs with the dispatch (see gemm_skinny_kernel), the struct is read later.
 struct AttnDecodeKernarg { const int32_t* positions; const int32_t* block_table; char* pool_layer; const float* ws; size_t kv_head_stride;
-                           int max_pages, n_kv, max_splits, window; AttnDecodeArgs p; };          // the kernarg segment
+                           int max_pages, n_kv, max_splits, window, gpb; AttnDecodeArgs p; };     // the kernarg segment
 template <int D>
 __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_t* positions_, const int32_t* block_table_, char* pool_layer_,
                                                                      const float* ws_, size_t kv_head_stride_, int max_pages_, int n_kv_,
-                                                                     int max_splits_, int window_, AttnDecodeArgs p_unused) {
+                                                                     int max_splits_, int window_, int gpb_, AttnDecodeArgs p_unused) {
     constexpr int NKS = D / 32;          // k-steps of S^T (over head_dim)
     constexpr int NDV = D / 16;          // dv tiles of O^T
     constexpr int PART = 32 + 16 * D;    // floats per partial: m[16], l[16], O[16][D]
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
     // StarCoder2 sliding window: only keys win0 <= j <= pos are visible; whole groups (and pages) below are skipped
     const int win0 = (window_ > 0 && L > window_) ? L - window_ : 0;
     const int g0 = win0 >> 5;
-    int act = (ngroups - g0 + AD_GROUPS_PER_BLOCK - 1) / AD_GROUPS_PER_BLOCK;
+    int act = (ngroups - g0 + gpb_ - 1) / gpb_;         // gpb_: 32-key groups a block takes before another context split joins
     act = act > max_splits_ ? max_splits_ : act;      // host cap: B * act <= #CUs (one block per CU) and <= AD_SPLIT
     act = act < 1 ? 1 : act;
     if (split >= act) return;
@@ -675,13 +675,16 @@ int init_attention_kernels() {
 
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
     const size_t smem = attn_decode_smem(a.head_dim);
-    dim3 grid(a.B * a.n_kv, AD_SPLIT);
+    // grid.y = the engine's split cap, not AD_SPLIT: the splits above it never work, and dispatching 8-wave blocks that exit
+    // at once is not free (B = 32: 256 of 512 blocks)
+    dim3 grid(a.B * a.n_kv, a.max_splits < 1 ? 1 : (a.max_splits > AD_SPLIT ? AD_SPLIT : a.max_splits));
+    const int gpb = a.groups_per_block > 0 ? a.groups_per_block : AD_GROUPS_PER_BLOCK;
     if (a.head_dim == 128)
         attn_decode_kernel<128><<<grid, AD_WAVES * 64, smem, st>>>(a.positions, a.block_table, a.pool_layer, a.ws, a.kv_head_stride,
-                                                                    a.max_pages, a.n_kv, a.max_splits, a.window, a);
+                                                                    a.max_pages, a.n_kv, a.max_splits, a.window, gpb, a);
     else
         attn_decode_kernel<64><<<grid, AD_WAVES * 64, smem, st>>>(a.positions, a.block_table, a.pool_layer, a.ws, a.kv_head_stride,
-                                                                   a.max_pages, a.n_kv, a.max_splits, a.window, a);
+                                                                   a.max_pages, a.n_kv, a.max_splits, a.window, gpb, a);
 }
 
 }  // namespace sv

@@ -918,6 +918,7 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
             ad.part = e->attn_part; ad.counters = e->attn_cnt;
             ad.max_splits = attn_max_splits(e);
             ad.n_kv = e->nkv; ad.kv_head_stride = e->kv_head_stride; ad.rope_cos = e->rope_cos; ad.rope_sin = e->rope_sin;
+            ad.groups_per_block = (e->exp & 16) ? 2 : (e->exp & 32) ? 6 : (e->exp & 64) ? 8 : 0;      // A/B: context splits per length
             prof_mark(e, PK_ATTN, st);
             launch_attn_decode(ad, st);
         }

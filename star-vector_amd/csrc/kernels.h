@@ -135,6 +135,7 @@ struct AttnDecodeArgs {
     size_t kv_head_stride;                                 // bytes between the page pools of consecutive KV heads
     const float* rope_cos; const float* rope_sin;          // [positions][D/2] rotary tables (nullptr: no RoPE)
     int window;                                            // sliding window: keys pos - window < j <= pos (0 = all)
+    int groups_per_block;                                  // 32-key groups a block takes before another context split joins (0 = 4)
 };
 // in-place rotary embedding of the q and k heads of a prefill c_attn output (rotate_half convention)
 void launch_rope_prefill(bf16_t* qkv, int row_stride, int rows, int S0, int n_heads, int head_dim,
