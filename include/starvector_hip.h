@@ -306,6 +306,12 @@ int  sv_op_linear_skinny_fp8(const void* x, const void* W, const void* bias, voi
  * (the c_fc form, N %% 8 == 0); out_f32 != 0: float32 rows of x W^T holding bf16-rounded values, bias ignored (the lm_head form) */
 int  sv_op_linear_skinny_epi(const void* x, const void* W, const void* bias, void* y, int32_t M, int32_t N, int32_t K,
                              int32_t act, int32_t out_f32, sv_stream stream);
+/* the two kernels of the 6-launch decode layer (csrc/decode_cols.hip; gpt_bigcode/modeling_gpt_bigcode.py:694-755) as one op, M <= 32:
+ *   h2 = bf16(h + bf16(x[M,Kp] . Wp[D,Kp]^T + bp))                      attention output projection, whole K per block, in place
+ *   y  = act(bf16(LayerNorm(h2; gamma, beta, eps) . Wf[F,D]^T + bf))    c_fc on the raw h2, ln_2 folded into weights / epilogue */
+int  sv_op_decode_proj_fold(const void* x, const void* Wp, const void* bp, const void* h, const void* gamma, const void* beta, float eps,
+                            const void* Wf, const void* bf, void* h2_out, void* y_out, int32_t M, int32_t D, int32_t Kp, int32_t F,
+                            int32_t act, sv_stream stream);
 /* micro-benchmark of the big-M MFMA GEMM alone (pseudo-random operands): average microseconds per launch */
 int  sv_bench_linear(int32_t M, int32_t N, int32_t K, int32_t act, int32_t residual, int32_t iters, double* avg_us,
                      sv_stream stream);

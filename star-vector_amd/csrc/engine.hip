@@ -115,6 +115,10 @@ struct Linear {
     float* wscale = nullptr;   //   per-output-row scale [Npad]
     int N = 0, K = 0, Npad = 0, Kpad = 0;
     int splitk = 1;       // decode-path split-K factor (fp32 slabs summed by the consumer)
+    int cpb = 8;          // output columns per block of the slab-free output projection (decode_cols.hip)
+    bf16_t* Wf = nullptr; // LayerNorm-folded image W' = bf16(W * gamma) (decode_cols.hip; c_fc only), with
+    float* c1 = nullptr;  //   c1[n] = sum_k W'[n][k]
+    float* c2 = nullptr;  //   c2[n] = sum_k beta[k] W[n][k] + bias[n]
 };
 struct LNp { bf16_t* g = nullptr; bf16_t* b = nullptr; };
 struct VitLayer { LNp ln1, ln2; Linear in_proj, out_proj, c_fc, c_proj; };
@@ -166,10 +170,17 @@ struct sv_engine {
     // decode workspaces
     int MT = 0, ldws = 0, Vpad = 0;
     bf16_t *h_dec = nullptr, *hl = nullptr, *xp_a = nullptr, *xp_attn = nullptr, *xp_mlp = nullptr;
+    bf16_t* h_xp = nullptr;         // residual stream of the decode step in fragment order (6-launch layer)
+    float2* cols_stats = nullptr;   // [MT*32][cols_nblocks] per-block partial LayerNorm statistics of the output projection
+    int cols_nblocks = 0;
+    bool fold6 = false;             // 6 launches per layer: slab-free attention output projection + ln_2 folded into c_fc
+    bool fold_ready = false;
     bool only_skinny = false;       // profiling: enqueue only the weight-streaming GEMMs of a step
     bool skip_skinny = false;       // profiling: enqueue everything BUT the weight-streaming GEMMs
     int exp = 0;                    // SV_EXP bit mask, read once at sv_create (A/B switches of the round's experiments):
+                                    //   1 row update as one wave per row; 2 the 7-launch layer (no LayerNorm fold);
                                     //   8 (at sv_create only) the round 1-2 split-K rule of the decode GEMMs
+                                    //   (16 / 32 / 64: 2 / 6 / 8 key groups per attention block: 1186 / 1169 / 1175 vs 1171 us, removed)
                                     //   (1, 2: XCD-aligned weight prefetch by attention's idle waves / spare row-update blocks; 4: one key
                                     //    group per attention block -- all measured slower, profiles/prefetch_r03_*.log, removed)
     float *ws = nullptr, *ws2 = nullptr, *logits = nullptr, *sample_scratch = nullptr, *attn_part = nullptr;
@@ -442,6 +453,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
 
     if (int ar = init_attention_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
     if (int ar = init_gemm_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
+    if (int ar = init_cols_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
 
     sv_engine* e = new sv_engine();
     e->cfg = c;
@@ -557,6 +569,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     e->ldws = round_up(e->QKV, 32);
     if (e->ldws < D) e->ldws = D;
     A(dalloc(e, &e->h_dec, R * D));
+    A(dalloc(e, &e->h_xp, R * D));
     A(dalloc(e, &e->hl, R * D));
     A(dalloc(e, &e->xp_a, R * D));
     A(dalloc(e, &e->xp_attn, R * D));
@@ -629,6 +642,14 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
             rc = fail(SV_EHIP, "rope table upload failed");
     }
     if (getenv("SV_EXP")) e->exp = atoi(getenv("SV_EXP"));
+    // 6 launches per layer (decode_cols.hip): bf16 weights, at most one 32-row tile per launch; SV_EXP bit 2 = A/B, the 7-launch layer
+    e->fold6 = c.weight_dtype == SV_WEIGHT_BF16 && e->MT == 1 && (c.n_head * dh) % 32 == 0 && D % 32 == 0;
+    if (!rc && e->fold6) {
+        const int cpb = cols_pick_cpb(D);
+        for (DecLayer& L : e->dec) L.c_proj.cpb = cpb;
+        e->cols_nblocks = (D + cpb - 1) / cpb;
+        rc = dalloc(e, &e->cols_stats, (size_t)R * e->cols_nblocks);
+    }
     if (rc) { sv_destroy(e); return rc; }
     *out = e;
     return 0;
@@ -694,6 +715,7 @@ extern "C" int sv_load_weight(sv_engine* e, const char* name, const void* dev_pt
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(st));   // the caller may free its tensor right after this returns
     s.loaded = true;
+    e->fold_ready = false;                // a (re)loaded tensor invalidates the LayerNorm-folded images (rebuilt by sv_weights_complete)
     return 0;
 }
 
@@ -701,6 +723,23 @@ extern "C" int sv_weights_complete(sv_engine* e) {
     if (!e) return fail(SV_EINVAL, "null engine");
     for (auto& kv : e->slots)
         if (kv.second.required && !kv.second.loaded) return fail(SV_ENOENT, "missing weight '%s'", kv.first.c_str());
+    if (e->fold6 && !e->fold_ready) {
+        // every tensor is in: build the LayerNorm-folded c_fc images (W' = bf16(W * gamma_2), c1, c2) once
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (!e->fold_ready) {
+            HIPCHECK(hipSetDevice(e->cfg.device));
+            for (DecLayer& L : e->dec) {
+                Linear& l = L.c_fc;
+                if (!l.Wf) SVCHECK(dalloc(e, &l.Wf, (size_t)l.Npad * l.Kpad, false));
+                if (!l.c1) SVCHECK(dalloc(e, &l.c1, (size_t)l.Npad, true));
+                if (!l.c2) SVCHECK(dalloc(e, &l.c2, (size_t)l.Npad, true));
+                launch_fold_prepare(l.Wp, L.ln2.g, L.ln2.b, l.bias, l.Wf, l.c1, l.c2, l.N, l.Npad, l.Kpad, nullptr);
+            }
+            HIPCHECK(hipGetLastError());
+            HIPCHECK(hipDeviceSynchronize());
+            e->fold_ready = true;
+        }
+    }
     return 0;
 }
 
@@ -870,10 +909,12 @@ static int prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hi
     return 0;
 }
 
-// One autoregressive step: consumes cur_tok / positions, leaves logits in e->logits.  7 launches per layer + 2:
+// One autoregressive step: consumes cur_tok / positions, leaves logits in e->logits.  6 launches per layer + 2 (bf16 weights,
+// <= 32 rows):
 //   row update (embedding | + bias + residual of the previous down-proj, LN1) | c_attn -> fp32 slabs | attention (sums the
-//   slabs, + bias) | c_proj -> slabs | row update (+ bias, + residual, LN2) | c_fc (bias + GELU epilogue) | down-proj -> slabs
-//   ... | row update (ln_f) | lm_head
+//   slabs, + bias) | c_proj over the whole K: h += ..., partial row statistics | c_fc on the raw h (ln_2 folded, bias + GELU
+//   epilogue) | down-proj -> slabs ... | row update (ln_f) | lm_head
+// fp8 weights / more than one row tile: 7 launches per layer (c_proj -> slabs | row update (+ bias, + residual, LN2) | c_fc).
 static void decode_forward(sv_engine* e, int B, hipStream_t st) {
     const sv_config& c = e->cfg;
     const int D = c.hidden, dh = e->dh, F = c.n_inner, MT = (B + 31) / 32;
@@ -882,12 +923,15 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
     float* wsB = e->ws2;
     RowUpdateArgs ru;
     memset(&ru, 0, sizeof(ru));
-    ru.h = e->h_dec; ru.ldh = D; ru.M = B; ru.D = D; ru.eps = c.ln_eps; ru.xp_out = e->xp_a;
+    const bool fold6 = e->fold6 && e->fold_ready && !(e->exp & 2);
+    ru.h = fold6 ? e->h_xp : e->h_dec; ru.ldh = fold6 ? 0 : D;        // 6-launch layer: the residual stream lives in fragment order
+    ru.M = B; ru.D = D; ru.eps = c.ln_eps; ru.xp_out = e->xp_a;
     ru.ldws = e->ldws; ru.rows_ws = MT * 32;
     ru.ws = nullptr; ru.wte = e->wte; ru.wpe = e->wpe; ru.tokens = e->cur_tok; ru.positions = e->positions;
     ru.g = e->dec[0].ln1.g; ru.b = e->dec[0].ln1.b;
     auto row_update = [&]() {
         if (e->only_skinny) return;
+        ru.one_wave = (e->exp & 1) ? 1 : 0;
         prof_mark(e, PK_ROWLN, st);
         launch_row_update_ln(ru, st);
     };
@@ -918,14 +962,30 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
             ad.part = e->attn_part; ad.counters = e->attn_cnt;
             ad.max_splits = attn_max_splits(e);
             ad.n_kv = e->nkv; ad.kv_head_stride = e->kv_head_stride; ad.rope_cos = e->rope_cos; ad.rope_sin = e->rope_sin;
-            ad.groups_per_block = (e->exp & 16) ? 2 : (e->exp & 32) ? 6 : (e->exp & 64) ? 8 : 0;      // A/B: context splits per length
             prof_mark(e, PK_ATTN, st);
             launch_attn_decode(ad, st);
         }
-        skinny(e->xp_attn, L.c_proj, SK_OUT_PARTIAL, wsB);
-        ru.ws = wsB; ru.splitk = L.c_proj.splitk; ru.bias = L.c_proj.bias; ru.g = L.ln2.g; ru.b = L.ln2.b;
-        row_update();                                            // + bias + residual, LN2
-        skinny(e->xp_a, L.c_fc, SK_OUT_PACKED_ACT, nullptr);
+        if (fold6) {
+            // attention output projection over the whole K per block: h += bf(x W^T + b) in place (+ partial row statistics), then
+            // c_fc on the raw h with ln_2 folded into its weights / epilogue: no slabs, no row-update launch (decode_cols.hip)
+            ColsArgs ca;
+            memset(&ca, 0, sizeof(ca));
+            ca.xp = e->xp_attn; ca.Wp = L.c_proj.Wp; ca.bias = L.c_proj.bias; ca.MT = MT; ca.N = L.c_proj.N; ca.K = L.c_proj.Kpad;
+            ca.cpb = L.c_proj.cpb; ca.h_xp = e->h_xp; ca.out_KS = D / 16; ca.stats = e->cols_stats; ca.nblocks = e->cols_nblocks;
+            if (!e->skip_skinny) { prof_mark(e, PK_SKINNY, st); launch_gemm_cols(ca, st); }
+            SkinnyArgs a;
+            memset(&a, 0, sizeof(a));
+            a.xp = e->h_xp; a.Wp = L.c_fc.Wf; a.MT = MT; a.Npad = L.c_fc.Npad; a.K = L.c_fc.Kpad; a.N = L.c_fc.N; a.splitk = 1;
+            a.out_mode = SK_OUT_PACKED_ACT; a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16;
+            a.fold_c1 = L.c_fc.c1; a.fold_c2 = L.c_fc.c2; a.fold_stats = e->cols_stats; a.fold_nparts = e->cols_nblocks;
+            a.fold_D = D; a.fold_eps = c.ln_eps;
+            if (!e->skip_skinny) { prof_mark(e, PK_SKINNY, st); launch_gemm_skinny(a, st); }
+        } else {
+            skinny(e->xp_attn, L.c_proj, SK_OUT_PARTIAL, wsB);
+            ru.ws = wsB; ru.splitk = L.c_proj.splitk; ru.bias = L.c_proj.bias; ru.g = L.ln2.g; ru.b = L.ln2.b;
+            row_update();                                        // + bias + residual, LN2
+            skinny(e->xp_a, L.c_fc, SK_OUT_PACKED_ACT, nullptr);
+        }
         skinny(e->xp_mlp, L.c_proj2, SK_OUT_PARTIAL, wsB);
         const LNp& nxt = (i + 1 < c.n_layer) ? e->dec[i + 1].ln1 : e->ln_f;
         ru.ws = wsB; ru.splitk = L.c_proj2.splitk; ru.bias = L.c_proj2.bias; ru.g = nxt.g; ru.b = nxt.b;
@@ -2044,6 +2104,57 @@ extern "C" int sv_op_linear_skinny_epi(const void* x, const void* W, const void*
     launch_gemm_skinny(a, st);
     if (out_f32) HIPCHECK(hipMemcpy2DAsync(y, (size_t)N * 4, of, (size_t)Npad * 4, (size_t)N * 4, M, hipMemcpyDeviceToDevice, st));
     else unpack_rows_kernel<<<(M * (N / 8) + 255) / 256, 256, 0, st>>>(oxp, (bf16_t*)y, N, M, N);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(st));
+    return 0;
+}
+
+// The 6-launch layer's two kernels as one op (decode_cols.hip): h2 = bf16(h + bf16(x Wp^T + bp)) by the slab-free output projection
+// (whole K per block, partial row statistics), then y = act(bf16(LN(h2; gamma, beta) Wf^T + bf)) by the decode GEMM on the RAW h2
+// with the LayerNorm folded into its weights / epilogue.  Row-major in / out; M <= 32.
+extern "C" int sv_op_decode_proj_fold(const void* x, const void* Wp_, const void* bp, const void* h, const void* gamma, const void* beta,
+                                      float eps, const void* Wf_, const void* bf_, void* h2_out, void* y_out, int32_t M, int32_t D,
+                                      int32_t Kp, int32_t F, int32_t act, sv_stream stream) {
+    if (!x || !Wp_ || !h || !gamma || !beta || !Wf_ || !h2_out || !y_out || M < 1 || M > 32 || D < 32 || D % 32 || Kp < 32 || Kp % 32 ||
+        F < 8 || F % 8)
+        return fail(SV_EINVAL, "sv_op_decode_proj_fold: bad argument (M <= 32, D %% 32 == 0, Kp %% 32 == 0, F %% 8 == 0)");
+    if (int ar = init_cols_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
+    if (int ar = init_gemm_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
+    hipStream_t st = (hipStream_t)stream;
+    TmpBufs tmp;
+    const int Fpad = round_up(F, 32), cpb = cols_pick_cpb(D), nblocks = (D + cpb - 1) / cpb;
+    bf16_t *Wpp, *Wfp, *Wff, *xp, *hxp, *yxp;
+    float *c1, *c2; float2* stats;
+    SVCHECK(tmp.get(&Wpp, (size_t)D * Kp));
+    SVCHECK(tmp.get(&Wfp, (size_t)Fpad * D));
+    SVCHECK(tmp.get(&Wff, (size_t)Fpad * D));
+    SVCHECK(tmp.get(&xp, (size_t)32 * Kp));
+    SVCHECK(tmp.get(&hxp, (size_t)32 * D));
+    SVCHECK(tmp.get(&yxp, (size_t)32 * Fpad));
+    SVCHECK(tmp.get(&c1, (size_t)Fpad));
+    SVCHECK(tmp.get(&c2, (size_t)Fpad));
+    SVCHECK(tmp.get(&stats, (size_t)32 * nblocks));
+    HIPCHECK(hipMemsetAsync(xp, 0, (size_t)32 * Kp * 2, st));
+    HIPCHECK(hipMemsetAsync(hxp, 0, (size_t)32 * D * 2, st));
+    HIPCHECK(hipMemsetAsync(stats, 0, (size_t)32 * nblocks * sizeof(float2), st));
+    launch_pack_weight(Wp_, 0, Wpp, D, Kp, D, Kp, st);
+    launch_pack_weight(Wf_, 0, Wfp, F, D, Fpad, D, st);
+    pack_rows_kernel<<<(M * (Kp / 8) + 255) / 256, 256, 0, st>>>((const bf16_t*)x, Kp, xp, M, Kp);
+    pack_rows_kernel<<<(M * (D / 8) + 255) / 256, 256, 0, st>>>((const bf16_t*)h, D, hxp, M, D);
+    launch_fold_prepare(Wfp, (const bf16_t*)gamma, (const bf16_t*)beta, (const bf16_t*)bf_, Wff, c1, c2, F, Fpad, D, st);
+    ColsArgs ca;
+    memset(&ca, 0, sizeof(ca));
+    ca.xp = xp; ca.Wp = Wpp; ca.bias = (const bf16_t*)bp; ca.MT = 1; ca.N = D; ca.K = Kp; ca.cpb = cpb; ca.h_xp = hxp; ca.out_KS = D / 16;
+    ca.stats = stats; ca.nblocks = nblocks;
+    if (launch_gemm_cols(ca, st)) return fail(SV_ENOTSUP, "sv_op_decode_proj_fold: no kernel for this shape");
+    SkinnyArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xp = hxp; a.Wp = Wff; a.MT = 1; a.Npad = Fpad; a.K = D; a.N = F; a.splitk = 1; a.out_mode = SK_OUT_PACKED_ACT; a.act = act;
+    a.out_xp = yxp; a.out_KS = Fpad / 16; a.fold_c1 = c1; a.fold_c2 = c2; a.fold_stats = stats; a.fold_nparts = nblocks; a.fold_D = D;
+    a.fold_eps = eps;
+    launch_gemm_skinny(a, st);
+    unpack_rows_kernel<<<(M * (D / 8) + 255) / 256, 256, 0, st>>>(hxp, (bf16_t*)h2_out, D, M, D);
+    unpack_rows_kernel<<<(M * (F / 8) + 255) / 256, 256, 0, st>>>(yxp, (bf16_t*)y_out, F, M, F);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(st));
     return 0;

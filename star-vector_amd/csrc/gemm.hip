@@ -1003,22 +1003,27 @@ __device__ __forceinline__ void sk_load(SkChunk<CH>& c, const u32x4* wptr, const
 
 // the bias of this lane's RPW output columns, requested BEFORE the weight stream (the epilogue must not start with a round trip)
 template <int RPW>
-__device__ __forceinline__ void sk_bias(const SkinnyArgs& p, float* bias_d, int r0, int nt, int half) {
+__device__ __forceinline__ void sk_bias(const SkinnyArgs& p, float* bias_d, int r0, int nt, int half, float* fc1 = nullptr) {
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
         bias_d[i] = 0.f;
-        if (p.out_mode == SK_OUT_PACKED_ACT && p.bias) {
-            const int r = r0 + i;
-            const int n = nt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-            if (n < p.N) bias_d[i] = bf2f(p.bias[n]);
+        if (fc1) fc1[i] = 0.f;
+        const int r = r0 + i;
+        const int n = nt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+        if (p.out_mode == SK_OUT_PACKED_ACT && n < p.N) {
+            if (fc1 && p.fold_c1) { fc1[i] = p.fold_c1[n]; bias_d[i] = p.fold_c2[n]; }
+            else if (p.bias) bias_d[i] = bf2f(p.bias[n]);
         }
     }
 }
 // shared tail of the skinny kernels: v[i] = the reduced accumulator row r0 + i of lane (m, half), i.e. output
 // column n(r) = nt*32 + 8*(r >> 2) + 4*half + (r & 3) of row mt*32 + m; RPW consecutive rows r (RPW in {1, 2, 4, 8, 16})
+// fold: LayerNorm applied algebraically (decode_cols.hip): x = rstd * (acc - mean * c1[n]) + c2[n]; fc1 / fc2 = this lane's RPW
+// values of c1 / c2, (mean, rstd) = the statistics of row m
+struct SkFold { bool on; float mean, rstd; };
 template <int RPW>
 __device__ __forceinline__ void sk_store(const SkinnyArgs& p, float* v, const float* bias_d, int r0, int nt, int mt, int split, int m,
-                                         int half) {
+                                         int half, const SkFold fold = SkFold{false, 0.f, 1.f}, const float* fc1 = nullptr) {
     constexpr int G = RPW >= 4 ? RPW / 4 : 1;          // groups of (up to) 4 consecutive columns
     constexpr int W = RPW >= 4 ? 4 : RPW;
 #pragma unroll
@@ -1047,7 +1052,9 @@ __device__ __forceinline__ void sk_store(const SkinnyArgs& p, float* v, const fl
             for (int i = 0; i < W; ++i) {
                 float x = 0.f;
                 if (n0 + i < p.N) {
-                    x = bfround(vv[i] + bias_d[4 * g + i]);
+                    // (fold: bias_d carries c2 = sum_k beta_k W[n][k] + bias[n])
+                    x = fold.on ? bfround(fold.rstd * (vv[i] - fold.mean * fc1[4 * g + i]) + bias_d[4 * g + i])
+                                : bfround(vv[i] + bias_d[4 * g + i]);
                     if (p.act != ACT_NONE) x = sv_act(x, p.act);
                 }
                 vv[i] = x;
@@ -1101,8 +1108,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
     for (int b = 0; b < NB; ++b)
         if (b * CH < ks_per_wave) sk_load<CH>(ck[b], wptr, xptr, b * CH, ks_per_wave);
     const SkinnyArgs p = sv_late_args<SkinnyArgs>(offsetof(SkinnyKernarg, p));       // the stream is in flight: now the rest
-    float bias_d[RPW];
-    sk_bias<RPW>(p, bias_d, wave * RPW, nt, half);
+    float bias_d[RPW], fc1[RPW];
+    sk_bias<RPW>(p, bias_d, wave * RPW, nt, half, fc1);
+    // LayerNorm fold: this thread's share of the producer's per-block row statistics (row tid & 31, every (2 WAVES)-th part)
+    const bool fold_on = p.fold_c1 != nullptr;
+    float2 fst = make_float2(0.f, 0.f);
+    if (fold_on) {
+        const float2* sp = p.fold_stats + (size_t)(tid & 31) * p.fold_nparts;
+        for (int q = tid >> 5; q < p.fold_nparts; q += 2 * WAVES) { const float2 t = sp[q]; fst.x += t.x; fst.y += t.y; }
+    }
 
     for (int ks = 0; ks < ks_per_wave; ks += NB * CH) {
 #pragma unroll
@@ -1117,6 +1131,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
 
     // ---- K reduction across the waves of the block (wave order), every wave finishes RPW accumulator rows ----
     float v[RPW];
+    float2* fst_s = reinterpret_cast<float2*>(sk_smem + (size_t)WAVES * 16 * 64 * 4);      // [2 * WAVES][32] partial row statistics
+    if (fold_on) fst_s[tid] = fst;                                                          // tid = slice * 32 + row
     if constexpr (WAVES > 1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
@@ -1130,13 +1146,25 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
             v[i] = t;
         }
     } else {
+        if (fold_on) __syncthreads();
 #pragma unroll
         for (int i = 0; i < 16; ++i) v[i] = acc[i];
     }
-    sk_store<RPW>(p, v, bias_d, wave * RPW, nt, mt, split, m, half);
+    SkFold fold{false, 0.f, 1.f};
+    if (fold_on) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2 * WAVES; ++q) { const float2 t = fst_s[q * 32 + m]; s1 += t.x; s2 += t.y; }      // slice order
+        const float invD = 1.0f / (float)p.fold_D;
+        const float mean = s1 * invD;
+        float var = s2 * invD - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        fold = SkFold{true, mean, rsqrtf(var + p.fold_eps)};
+    }
+    sk_store<RPW>(p, v, bias_d, wave * RPW, nt, mt, split, m, half, fold, fc1);
 }
 
-static size_t skinny_smem(int waves) { return (size_t)waves * 16 * 64 * 4 + 16; }
+static size_t skinny_smem(int waves) { return (size_t)waves * 16 * 64 * 4 + (size_t)2 * waves * 32 * 8 + 16; }
 
 static int init_mt2_attrs();
 int init_gemm_kernels() {

@@ -53,6 +53,11 @@ struct SkinnyArgs {
     bf16_t* out_xp; int out_KS;      // PACKED_ACT: fragment-order buffer with out_KS = Npad/16 k-steps
     float* out_f32; int ldo;         // F32: [MT*32][ldo]; rounded to bf16 values if round_bf16
     int round_bf16;
+    // LayerNorm fold (decode_cols.hip; PACKED_ACT, MT == 1): xp is the RAW residual stream, Wp the folded image W' = bf16(W * gamma);
+    // epilogue x = rstd[m] * (acc - mean[m] * c1[n]) + c2[n].  Row statistics = fold_nparts partial (sum, sum of squares) per row
+    const float* fold_c1; const float* fold_c2;            // [Npad] (nullptr: off)
+    const float2* fold_stats; int fold_nparts;             // [32][fold_nparts]
+    int fold_D; float fold_eps;                            // LayerNorm width and epsilon
 };
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st);
 // host arithmetic of the launch: waves per block (how K is cut inside a block = the summation order of a row) and whether a
@@ -61,6 +66,22 @@ void skinny_plan(int Npad, int K, int splitk, int fp8, int MT, int* waves, int* 
 int init_gemm_kernels();        // hipFuncSetAttribute for the large-LDS variants (0 = ok)
 
 void launch_cvt_bf16_hw(const float* x, bf16_t* y, size_t n, hipStream_t st);
+
+// ---- attention output projection without slabs + LayerNorm fold (decode_cols.hip) ------------------
+struct ColsArgs {
+    const bf16_t* xp;                // packed activations [MT][K/16][64][8]
+    const bf16_t* Wp;                // packed weight [Npad/32][K/16][64][8] (the image the 32-column kernels read)
+    const bf16_t* bias;              // [N] or nullptr
+    int MT, N, K;                    // K multiple of 32
+    int cpb;                         // output columns per block (4, 8 or 16): cols_pick_cpb(N)
+    bf16_t* h_xp; int out_KS;        // residual stream in fragment order, N = 16 * out_KS columns: h = bf(h + bf(x W^T + b)), in place
+    float2* stats; int nblocks;      // [MT*32][nblocks] per-block partial (sum, sum of squares) of the new rows (nullptr: off)
+};
+int cols_pick_cpb(int N);
+int launch_gemm_cols(const ColsArgs& a, hipStream_t st);        // 0 = ok, -1 = unsupported shape
+int init_cols_kernels();
+void launch_fold_prepare(const bf16_t* Wp, const bf16_t* gamma, const bf16_t* beta, const bf16_t* bias, bf16_t* Wf, float* c1, float* c2,
+                         int N, int Npad, int K, hipStream_t st);
 
 // ---- row kernels ---------------------------------------------------------------------------------
 void launch_layernorm_rows(const bf16_t* x, int ldx, const bf16_t* g, const bf16_t* b, bf16_t* y, int ldy,
@@ -73,12 +94,13 @@ void launch_layernorm_rows_packed(const bf16_t* x, int ldx, const bf16_t* g, con
 struct RowUpdateArgs {
     const float* ws; int splitk; int ldws; int rows_ws;   // partials [splitk][rows_ws][ldws] (or nullptr)
     const bf16_t* bias;
-    bf16_t* h; int ldh;                                    // residual stream [M][D] (in/out)
+    bf16_t* h; int ldh;                                    // residual stream [M][D] (in/out); ldh == 0: fragment order (xp layout)
     const bf16_t* wte; const bf16_t* wpe;                  // embedding mode (ws == nullptr)
     const int32_t* tokens; const int32_t* positions;       // [M]
     const bf16_t* g; const bf16_t* b; float eps;           // LayerNorm applied to the updated row
     bf16_t* xp_out;                                        // packed LN output
     int M, D;
+    int one_wave;                                          // experiment: one wave per row (registers + shuffles) instead of a 4-wave block
 };
 void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st);
 

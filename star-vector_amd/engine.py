@@ -446,6 +446,21 @@ def op_linear_skinny_epi(x, W, bias=None, act="none", out_f32=False):
     return y
 
 
+def op_decode_proj_fold(x, Wp, bp, h, gamma, beta, Wf, bf_, act="gelu_tanh", eps=1e-5):
+    """The 6-launch decode layer's two kernels (csrc/decode_cols.hip): returns (h2 bf16 [M, D], y bf16 [M, F])."""
+    lib = _lib.load()
+    t = lambda v, n: _need(v, torch.bfloat16, n)
+    x, Wp, h, gamma, beta, Wf = t(x, "x"), t(Wp, "Wp"), t(h, "h"), t(gamma, "gamma"), t(beta, "beta"), t(Wf, "Wf")
+    bp = t(bp, "bp") if bp is not None else None
+    bf_ = t(bf_, "bf") if bf_ is not None else None
+    M, Kp = x.shape; D = Wp.shape[0]; F = Wf.shape[0]
+    h2 = torch.empty(M, D, dtype=torch.bfloat16, device=x.device)
+    y = torch.empty(M, F, dtype=torch.bfloat16, device=x.device)
+    check(lib.sv_op_decode_proj_fold(_ptr(x), _ptr(Wp), _ptr(bp), _ptr(h), _ptr(gamma), _ptr(beta), float(eps), _ptr(Wf), _ptr(bf_),
+                                     _ptr(h2), _ptr(y), M, D, Kp, F, _lib.ACT[act], _stream()), "sv_op_decode_proj_fold")
+    return h2, y
+
+
 def bench_decode_linear(M: int, N: int, K: int, splitk: int = 1, mode: int = 0, iters: int = 100) -> float:
     """Average microseconds per launch of one decode GEMM (mode 0 fp32 slabs, 1 bias + GELU, 2 fp32 logits)."""
     lib = _lib.load()

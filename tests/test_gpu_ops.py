@@ -362,3 +362,31 @@ def test_preprocess_images_batched_stateless_bit_exact():
         assert np.array_equal(sig[i].cpu().numpy().view(np.int32), P.preprocess_siglip(imgs[i]).view(np.int32)), i
     with pytest.raises(ValueError):
         E.op_preprocess_images([], 224, P.CLIP_MEAN, P.CLIP_STD)
+
+
+@pytest.mark.parametrize("M,D,Kp,F", [(32, 2048, 2048, 8192), (5, 256, 256, 512), (17, 4608, 4608, 1024), (32, 128, 64, 96), (1, 512, 1024, 2048)])
+def test_decode_output_projection_and_folded_layernorm(M, D, Kp, F):
+    """The 6-launch decode layer (csrc/decode_cols.hip): the attention output projection over the whole K per block finishes the
+    residual add in place (bit for bit the reference's bf16 cast points), and c_fc consumes the RAW residual stream with ln_2 folded
+    into its weights and epilogue -- against LayerNorm -> Linear -> GELU in float32 with the reference's roundings."""
+    g = torch.Generator().manual_seed(M + D + Kp + F)
+    x = torch.randn(M, Kp, generator=g).bfloat16().float()
+    Wp = (torch.randn(D, Kp, generator=g) / Kp ** 0.5).bfloat16().float()
+    bp = (0.1 * torch.randn(D, generator=g)).bfloat16().float()
+    h = (1.5 * torch.randn(M, D, generator=g) + 0.3).bfloat16().float()                 # a non-zero row mean: the fold subtracts mean * c1
+    gam = (1 + 0.1 * torch.randn(D, generator=g)).bfloat16().float()
+    bet = (0.1 * torch.randn(D, generator=g)).bfloat16().float()
+    Wf = (torch.randn(F, D, generator=g) / D ** 0.5).bfloat16().float()
+    bf_ = (0.1 * torch.randn(F, generator=g)).bfloat16().float()
+    h2_ref = (h + (x @ Wp.T + bp).bfloat16().float()).bfloat16().float()
+    h2, y = E.op_decode_proj_fold(bf(x), bf(Wp), bf(bp), bf(h), bf(gam), bf(bet), bf(Wf), bf(bf_))
+    assert rel_err(h2, h2_ref) <= 1.1 * BF16_1ULP                                       # one bf16 rounding of the sum
+    # c_fc against the reference chain evaluated on the ENGINE's h2 (so that only the fold is measured)
+    h2e = h2.float().cpu()
+    xln = torch.nn.functional.layer_norm(h2e, (D,), gam, bet, 1e-5)
+    y_ref = torch.nn.functional.gelu((xln.bfloat16().float() @ Wf.T + bf_).bfloat16().float(), approximate="tanh")
+    y_f32 = torch.nn.functional.gelu(xln @ Wf.T + bf_, approximate="tanh")               # no rounding of LN(h): what the fold approximates
+    e_ref, e_f32 = rel_err(y, y_ref), rel_err(y, y_f32)
+    assert min(e_ref, e_f32) <= 3 * BF16_1ULP and mean_err(y, y_f32) <= 2e-3, (e_ref, e_f32)
+    h2b, yb = E.op_decode_proj_fold(bf(x), bf(Wp), bf(bp), bf(h), bf(gam), bf(bet), bf(Wf), bf(bf_))
+    assert torch.equal(h2, h2b) and torch.equal(y, yb)                                   # deterministic (fixed-order statistics)
