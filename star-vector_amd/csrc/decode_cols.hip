@@ -136,7 +136,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_cols_resid_kernel(const bf16_
         if (tid < 32) {
             float s1 = 0.f, s2 = 0.f;
             for (int c = 0; c < cpb_; ++c) { const float v = tile[tid * 17 + c]; s1 += v; s2 += v * v; }
-            p.stats[((size_t)mt * 32 + tid) * p.nblocks + j] = make_float2(s1, s2);
+            p.stats[((size_t)mt * p.nblocks + j) * 32 + tid] = make_float2(s1, s2);       // [block][row]: 256 contiguous bytes
         }
     }
 }

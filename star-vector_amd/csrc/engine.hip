@@ -178,7 +178,8 @@ struct sv_engine {
     bool only_skinny = false;       // profiling: enqueue only the weight-streaming GEMMs of a step
     bool skip_skinny = false;       // profiling: enqueue everything BUT the weight-streaming GEMMs
     int exp = 0;                    // SV_EXP bit mask, read once at sv_create (A/B switches of the round's experiments):
-                                    //   1 row update as one wave per row; 2 the 7-launch layer (no LayerNorm fold);
+                                    //   2 the 7-launch layer (no LayerNorm fold);
+                                    //   (1: was the row update as one wave per row: 0.218 vs 0.131 ms per step, removed)
                                     //   8 (at sv_create only) the round 1-2 split-K rule of the decode GEMMs
                                     //   (16 / 32 / 64: 2 / 6 / 8 key groups per attention block: 1186 / 1169 / 1175 vs 1171 us, removed)
                                     //   (1, 2: XCD-aligned weight prefetch by attention's idle waves / spare row-update blocks; 4: one key
@@ -931,7 +932,6 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
     ru.g = e->dec[0].ln1.g; ru.b = e->dec[0].ln1.b;
     auto row_update = [&]() {
         if (e->only_skinny) return;
-        ru.one_wave = (e->exp & 1) ? 1 : 0;
         prof_mark(e, PK_ROWLN, st);
         launch_row_update_ln(ru, st);
     };

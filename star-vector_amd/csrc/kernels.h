@@ -56,7 +56,7 @@ struct SkinnyArgs {
     // LayerNorm fold (decode_cols.hip; PACKED_ACT, MT == 1): xp is the RAW residual stream, Wp the folded image W' = bf16(W * gamma);
     // epilogue x = rstd[m] * (acc - mean[m] * c1[n]) + c2[n].  Row statistics = fold_nparts partial (sum, sum of squares) per row
     const float* fold_c1; const float* fold_c2;            // [Npad] (nullptr: off)
-    const float2* fold_stats; int fold_nparts;             // [32][fold_nparts]
+    const float2* fold_stats; int fold_nparts;             // [fold_nparts][32]
     int fold_D; float fold_eps;                            // LayerNorm width and epsilon
 };
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st);
@@ -75,7 +75,7 @@ struct ColsArgs {
     int MT, N, K;                    // K multiple of 32
     int cpb;                         // output columns per block (4, 8 or 16): cols_pick_cpb(N)
     bf16_t* h_xp; int out_KS;        // residual stream in fragment order, N = 16 * out_KS columns: h = bf(h + bf(x W^T + b)), in place
-    float2* stats; int nblocks;      // [MT*32][nblocks] per-block partial (sum, sum of squares) of the new rows (nullptr: off)
+    float2* stats; int nblocks;      // [MT][nblocks][32] per-block partial (sum, sum of squares) of the new rows (nullptr: off)
 };
 int cols_pick_cpb(int N);
 int launch_gemm_cols(const ColsArgs& a, hipStream_t st);        // 0 = ok, -1 = unsupported shape
@@ -100,7 +100,6 @@ struct RowUpdateArgs {
     const bf16_t* g; const bf16_t* b; float eps;           // LayerNorm applied to the updated row
     bf16_t* xp_out;                                        // packed LN output
     int M, D;
-    int one_wave;                                          // experiment: one wave per row (registers + shuffles) instead of a 4-wave block
 };
 void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st);
 

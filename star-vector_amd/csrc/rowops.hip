@@ -246,140 +246,8 @@ __global__ __launch_bounds__(256) void row_update_ln_kernel(const float* ws_, co
     }
 }
 
-// One WAVE per row (experiment, SV_EXP bit 1): the whole row lives in the wave's registers (NCH chunks of 8 columns per lane), so
-// the two LayerNorm reductions are wave shuffles -- no LDS staging of the row, no block barriers, a quarter of the waves to
-// launch.  Same arithmetic and summation grouping per column as the block kernel; the row statistics are summed in another
-// order (lane-local partials first), so the result may differ from the block kernel's in the last bit of a few outputs.
-template <int NCH>
-__global__ __launch_bounds__(64) void row_update_ln_wave_kernel(const float* ws_, const bf16_t* bias_, bf16_t* h_, const bf16_t* g_,
-                                                                const bf16_t* b_, int splitk_, int ldws_, int rows_ws_, int ldh_, int D_,
-                                                                int M_, RowUpdateArgs p_unused) {
-    const int row = blockIdx.x, lane = threadIdx.x;
-    const int D = D_, NC = D >> 3;
-    auto hchunk = [&](int c) -> bf16_t* {
-        return ldh_ ? h_ + (size_t)row * ldh_ + c * 8 : h_ + xp_index(row >> 5, D >> 4, row & 31, c * 8);
-    };
-    uint4 gq[NCH], bq[NCH];
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = lane + i * 64;
-        if (c < NC) {
-            gq[i] = *reinterpret_cast<const uint4*>(g_ + c * 8);
-            bq[i] = *reinterpret_cast<const uint4*>(b_ + c * 8);
-        }
-    }
-    RowUpdateArgs p;
-    if (ws_ == nullptr) p = sv_late_args<RowUpdateArgs>(offsetof(RowUpdateKernarg, p));
-    float f[NCH][8];
-    float s = 0.f;
-    if (ws_ == nullptr) {
-        const int tok = p.tokens[row], pos = p.positions[row];
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = lane + i * 64;
-            if (c < NC) {
-                float a[8], w[8];
-                unpack8(*reinterpret_cast<const uint4*>(p.wte + (size_t)tok * D + c * 8), a);
-                if (p.wpe) {
-                    unpack8(*reinterpret_cast<const uint4*>(p.wpe + (size_t)pos * D + c * 8), w);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[i][e] = bfround(a[e] + w[e]);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) f[i][e] = a[e];
-                }
-            }
-        }
-    } else {
-        // every load of the row (bias, residual, all slabs) is requested before the first add: one memory round trip
-        uint4 biq[NCH], hq[NCH];
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            const int c = lane + i * 64;
-            if (c < NC) {
-                biq[i] = *reinterpret_cast<const uint4*>(bias_ + c * 8);
-                hq[i] = *reinterpret_cast<const uint4*>(hchunk(c));
-            }
-        }
-        float v[NCH][8];
-#pragma unroll
-        for (int i = 0; i < NCH; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
-        for (int base = 0; base < splitk_; base += 4) {                       // slab order, four slabs in flight per chunk
-            float4 a0[NCH][4], a1[NCH][4];
-#pragma unroll
-            for (int i = 0; i < NCH; ++i) {
-                const int c = lane + i * 64;
-                if (c < NC) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int sp = base + j < splitk_ ? base + j : splitk_ - 1;
-                        const float* src = ws_ + ((size_t)sp * rows_ws_ + row) * ldws_ + c * 8;
-                        a0[i][j] = *reinterpret_cast<const float4*>(src);
-                        a1[i][j] = *reinterpret_cast<const float4*>(src + 4);
-                    }
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < NCH; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (base + j < splitk_) {
-                        v[i][0] += a0[i][j].x; v[i][1] += a0[i][j].y; v[i][2] += a0[i][j].z; v[i][3] += a0[i][j].w;
-                        v[i][4] += a1[i][j].x; v[i][5] += a1[i][j].y; v[i][6] += a1[i][j].z; v[i][7] += a1[i][j].w;
-                    }
-        }
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            float bb[8], hh[8];
-            unpack8(biq[i], bb);
-            unpack8(hq[i], hh);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) f[i][e] = bfround(hh[e] + bfround(v[i][e] + bb[e]));
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = lane + i * 64;
-        if (c < NC) {
-            *reinterpret_cast<uint4*>(hchunk(c)) = pack8(f[i]);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += f[i][e];
-        }
-    }
-    if (ws_ != nullptr) p = sv_late_args<RowUpdateArgs>(offsetof(RowUpdateKernarg, p));
-    const float mean = wave_sum(s) / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = lane + i * 64;
-        if (c < NC) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mean; q += d * d; }
-        }
-    }
-    const float rstd = rsqrtf(wave_sum(q) / (float)D + p.eps);
-    const int KS = D >> 4;
-#pragma unroll
-    for (int i = 0; i < NCH; ++i) {
-        const int c = lane + i * 64;
-        if (c < NC) {
-            float o[8], gg[8], bb[8];
-            unpack8(gq[i], gg);
-            unpack8(bq[i], bb);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f[i][e] - mean) * rstd * gg[e] + bb[e];
-            *reinterpret_cast<uint4*>(p.xp_out + xp_index(row >> 5, KS, row & 31, c * 8)) = pack8(o);
-        }
-    }
-}
-
 void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st) {
-    if (a.one_wave && a.D <= 4 * 512)
-        row_update_ln_wave_kernel<4><<<a.M, 64, 0, st>>>(a.ws, a.bias, a.h, a.g, a.b, a.splitk, a.ldws, a.rows_ws, a.ldh, a.D, a.M, a);
-    else
-        row_update_ln_kernel<<<a.M, 256, a.D * sizeof(float), st>>>(a.ws, a.bias, a.h, a.g, a.b, a.splitk, a.ldws, a.rows_ws, a.ldh, a.D, a.M, a);
+    row_update_ln_kernel<<<a.M, 256, a.D * sizeof(float), st>>>(a.ws, a.bias, a.h, a.g, a.b, a.splitk, a.ldws, a.rows_ws, a.ldh, a.D, a.M, a);
 }
 
 // ------------------------------------------------------------------------------------------------
