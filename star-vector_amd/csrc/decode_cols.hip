@@ -85,12 +85,25 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_cols_resid_kernel(const bf16_
     load(ga, 0);
     if (G < nc) load(gb, G);
 
-    // epilogue operands (they depend on nothing): thread e finishes (row, column) = (e / cpb, e % cpb)
+    // epilogue operands (they depend on nothing).  cpb = 8 or 16 (the shapes the engine uses): thread t < 32 * cpb / 8 finishes
+    // 8 consecutive columns of one row = one 16-byte piece of the fragment-order residual stream -> 16-byte loads / stores and
+    // the row statistics without another LDS pass; other cpb: one thread per element.
+    const bool vec = (cpb_ & 7) == 0 && (N_ & 7) == 0;
+    const int v_row = tid & 31, v_ch = tid >> 5;                       // vec: (row, 8-column chunk of the block)
+    const int v_n = j * cpb_ + 8 * v_ch;
+    const bool v_on = vec && tid < 4 * cpb_ && v_n < N_;               // 32 * (cpb / 8) threads
+    uint4 v_res = make_uint4(0u, 0u, 0u, 0u), v_bias = make_uint4(0u, 0u, 0u, 0u);
+    size_t v_idx = 0;
     const int e_row = tid / cpb_, e_cr = tid - e_row * cpb_;
     const int e_n = j * cpb_ + e_cr;
-    const bool e_on = tid < 32 * cpb_ && e_n < N_;
+    const bool e_on = !vec && tid < 32 * cpb_ && e_n < N_;
     float e_bias = 0.f, e_res = 0.f;
     size_t e_idx = 0;
+    if (v_on) {
+        if (bias_) v_bias = *reinterpret_cast<const uint4*>(bias_ + v_n);
+        v_idx = xp_index(mt, out_KS_, v_row, v_n);
+        v_res = *reinterpret_cast<const uint4*>(h_xp_ + v_idx);
+    }
     if (e_on) {
         if (bias_) e_bias = bf2f(bias_[e_n]);
         e_idx = xp_index(mt, out_KS_, e_row, e_n);
@@ -123,6 +136,38 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_cols_resid_kernel(const bf16_
         tile[(16 * hb + (ln & 15)) * 17 + 4 * (ln >> 4) + q] = s;
     }
     __syncthreads();
+    if (vec) {
+        if (v_on) {
+            float rr[8], bb[8], hn[8];
+            unpack8(v_res, rr);
+            unpack8(v_bias, bb);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                hn[e] = bfround(rr[e] + bfround(tile[v_row * 17 + 8 * v_ch + e] + bb[e]));      // h = bf(h + bf(x W^T + b))
+                s1 += hn[e]; s2 += hn[e] * hn[e];
+            }
+            *reinterpret_cast<uint4*>(h_xp_ + v_idx) = pack8(hn);
+            if (p.stats) {
+                // per-row partial LayerNorm statistics of the block's columns of the NEW h (column order: deterministic);
+                // cpb = 16: the two chunks of a row are 32 threads apart -> combined through the tile
+                if (cpb_ == 8) {
+                    p.stats[((size_t)mt * p.nblocks + j) * 32 + v_row] = make_float2(s1, s2);       // [block][row]: 256 contiguous bytes
+                } else {
+                    red[2 * tid] = s1; red[2 * tid + 1] = s2;           // red is free again: [chunk][row][2]
+                }
+            }
+        }
+        if (p.stats && cpb_ != 8) {
+            __syncthreads();
+            if (tid < 32) {
+                float s1 = 0.f, s2 = 0.f;
+                for (int c = 0; c < cpb_ / 8; ++c) { s1 += red[2 * (c * 32 + tid)]; s2 += red[2 * (c * 32 + tid) + 1]; }
+                p.stats[((size_t)mt * p.nblocks + j) * 32 + tid] = make_float2(s1, s2);
+            }
+        }
+        return;
+    }
     float hnew = 0.f;
     if (e_on) {
         hnew = bfround(e_res + bfround(tile[e_row * 17 + e_cr] + e_bias));      // h = bf(h + bf(x W^T + b))

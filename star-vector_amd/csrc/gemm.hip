@@ -1076,7 +1076,9 @@ __device__ __forceinline__ void sk_store(const SkinnyArgs& p, float* v, const fl
 // processor (build flag -amdgpu-kernarg-preload-count; only scalar / pointer parameters qualify, not a by-value struct), so the
 // weight stream is requested without first waiting for a scalar load of the argument block (a cold K$ miss at every launch).
 struct SkinnyKernarg { const void* W; const bf16_t* x; int KS; int ks_per_split; SkinnyArgs p; };      // the kernarg segment of the skinny kernels
-template <int WAVES>
+// FOLD: the LayerNorm-folded c_fc (decode_cols.hip) -- its own instantiation, so that the statistics registers do not cost the
+// other GEMMs their second block per CU (<= 128 VGPRs)
+template <int WAVES, bool FOLD = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* Wp_, const bf16_t* xp_, int KS_, int ks_per_split_, SkinnyArgs p_unused) {
     constexpr int CH = 4;                            // k-steps per register chunk (two chunks = 8 KiB of W in flight per wave)
     constexpr int NB = 2;
@@ -1109,15 +1111,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
         if (b * CH < ks_per_wave) sk_load<CH>(ck[b], wptr, xptr, b * CH, ks_per_wave);
     const SkinnyArgs p = sv_late_args<SkinnyArgs>(offsetof(SkinnyKernarg, p));       // the stream is in flight: now the rest
     float bias_d[RPW], fc1[RPW];
-    sk_bias<RPW>(p, bias_d, wave * RPW, nt, half, fc1);
-    // LayerNorm fold: this thread's share of the producer's per-block row statistics (row tid & 31, every (2 WAVES)-th part)
-    const bool fold_on = p.fold_c1 != nullptr;
-    float2 fst = make_float2(0.f, 0.f);
+    sk_bias<RPW>(p, bias_d, wave * RPW, nt, half, FOLD ? fc1 : nullptr);
+    // LayerNorm fold: this thread's share of the producer's per-block row statistics (row tid & 31, every (2 WAVES)-th part).
+    // [part][row]: the 32 rows of a part are 256 contiguous bytes.  ALL loads are issued here, behind the first weight chunks, and
+    // only summed after the K loop (a load-add-load-add loop in front of it was 16 dependent round trips: +4 us per launch).
+    constexpr bool fold_on = FOLD;
+    constexpr int FST = FOLD ? 16 : 1;                                    // parts per thread in flight: covers 2 * WAVES * 16 parts per batch
+    float2 ft[FST];
     if (fold_on) {
-        // [part][row]: the 32 rows of a part are 256 contiguous bytes (a [row][part] layout made every lane fetch its own line:
-        // +6.7 us per layer, the first measurement of this pipeline)
         const float2* sp = p.fold_stats + (tid & 31);
-        for (int q = tid >> 5; q < p.fold_nparts; q += 2 * WAVES) { const float2 t = sp[(size_t)q * 32]; fst.x += t.x; fst.y += t.y; }
+#pragma unroll
+        for (int i = 0; i < FST; ++i) {
+            const int q = (tid >> 5) + i * 2 * WAVES;
+            ft[i] = q < p.fold_nparts ? sp[(size_t)q * 32] : make_float2(0.f, 0.f);
+        }
     }
 
     for (int ks = 0; ks < ks_per_wave; ks += NB * CH) {
@@ -1134,7 +1141,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
     // ---- K reduction across the waves of the block (wave order), every wave finishes RPW accumulator rows ----
     float v[RPW];
     float2* fst_s = reinterpret_cast<float2*>(sk_smem + (size_t)WAVES * 16 * 64 * 4);      // [2 * WAVES][32] partial row statistics
-    if (fold_on) fst_s[tid] = fst;                                                          // tid = slice * 32 + row
+    if (fold_on) {
+        float2 fst = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int i = 0; i < FST; ++i) { fst.x += ft[i].x; fst.y += ft[i].y; }
+        const float2* sp = p.fold_stats + (tid & 31);
+        for (int q = (tid >> 5) + FST * 2 * WAVES; q < p.fold_nparts; q += 2 * WAVES) {      // (more than 2 * WAVES * 16 parts: rare)
+            const float2 t = sp[(size_t)q * 32];
+            fst.x += t.x; fst.y += t.y;
+        }
+        fst_s[tid] = fst;                                                                   // tid = slice * 32 + row
+    }
     if constexpr (WAVES > 1) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
@@ -1171,7 +1188,8 @@ static size_t skinny_smem(int waves) { return (size_t)waves * 16 * 64 * 4 + (siz
 static int init_mt2_attrs();
 int init_gemm_kernels() {
     // 16-wave blocks reduce through 64 KiB of LDS: above the default dynamic-LDS limit
-    int r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    int r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (!r) r = init_mt2_attrs();
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<bf16_t>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
@@ -1182,7 +1200,8 @@ int init_gemm_kernels() {
 
 template <int W>
 static void launch_sk(const SkinnyArgs& a, dim3 grid, hipStream_t st) {
-    gemm_skinny_kernel<W><<<grid, W * 64, skinny_smem(W), st>>>(a.Wp, a.xp, a.K / 16, (a.K / 16) / a.splitk, a);
+    if (a.fold_c1) gemm_skinny_kernel<W, true><<<grid, W * 64, skinny_smem(W), st>>>(a.Wp, a.xp, a.K / 16, (a.K / 16) / a.splitk, a);
+    else gemm_skinny_kernel<W, false><<<grid, W * 64, skinny_smem(W), st>>>(a.Wp, a.xp, a.K / 16, (a.K / 16) / a.splitk, a);
 }
 
 // ------------------------------------------------------------------------------------------------

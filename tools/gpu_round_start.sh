@@ -54,6 +54,13 @@ for s in "${STEPS[@]}"; do
     ctx) timeout 400 python tools/ctx_sweep.py 2>&1 | tee "$OUT/ctx_sweep.log" ;;
     skinny) timeout 200 python tools/bench_skinny.py 2>&1 | tee "$OUT/bench_skinny.log" ;;
     rebuild:*) env ${s#rebuild:} python star-vector_amd/build.py --force 2>&1 | tail -1 ;;
+    prof:*)   # rocprofv3 kernel trace of an arbitrary python command line, grouped by (kernel, grid): prof:<name>:<script and args>
+      rest="${s#prof:}"; name="${rest%%:*}"; cmd="${rest#*:}"
+      ( cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$ROOT/$OUT/rocprof_$name" -- \
+          python $ROOT/$cmd > "$ROOT/$OUT/prof_$name.out" 2> "$ROOT/$OUT/prof_$name.err" )
+      python tools/trace_by_grid.py "$OUT/rocprof_$name" "$OUT/rocprof_${name}_by_grid.csv" > /dev/null 2>&1 || true
+      find "$OUT/rocprof_$name" -name '*kernel_trace.csv' -size +8M -delete 2>/dev/null
+      head -14 "$OUT/rocprof_${name}_by_grid.csv" | cut -c1-150 ;;
     xcd) hipcc --offload-arch=gfx950 -O2 -o /tmp/xcd_map tools/diag/xcd_map.hip 2>/dev/null && /tmp/xcd_map 2>&1 | tee "$OUT/xcd_map.log" | tail -8 ;;
     ab:*) timeout 600 python tools/ab_exp.py ${s#ab:} 2>&1 | grep -v amdgpu.ids | tee -a "$OUT/ab_exp.log" ;;
     *) echo "unknown step $s" ;;
