@@ -8,13 +8,15 @@
 //   * gemm_cols_resid_kernel: a block owns `cpb` <= 16 output columns over the WHOLE K (K = hidden: 128 KiB of activations per
 //     block come out of L2 next to 32 KiB of weights -- affordable for this projection, not for the K = 4 * hidden down
 //     projection, which keeps its slabs), so no cross-block reduction exists and the epilogue finishes the op in place:
-//     h = bf16(h + bf16(x W^T + b)) in fragment order, plus the block's per-row partial (sum, sum of squares) of the new h.
+//     h = bf16(h + bf16(x W^T + b)) in fragment order.
 //   * the consumer c_fc reads the RAW residual stream as its MFMA operand; ln_2 is applied algebraically in its epilogue:
 //         LN(h) W^T + bias = rstd * (h W'^T - mean * c1) + c2,   W' = bf16(W * gamma),  c1[n] = sum_k W'[n][k],
 //         c2[n] = sum_k beta[k] W[n][k] + bias[n]
-//     (fold_prepare_kernel builds W', c1, c2 once per engine).  The row statistics are the cols kernel's partials, summed in
-//     block order inside every c_fc block (deterministic).  No per-element LayerNorm arithmetic anywhere: round 2's "LayerNorm
-//     inside the GEMM block" cost 2.5 us of VALU per block and lost.
+//     (fold_prepare_kernel builds W', c1, c2 once per engine).  The row statistics (sum, sum of squares) are accumulated from
+//     the activation fragments on their way to the MFMA inside every c_fc block (a few packed VALU operations per fragment under
+//     the weight stream; first version: per-block partials left by the producer, 64 KB re-read by every consumer block -- +1.4 us).
+//     Nothing is normalised or rewritten: round 2's "LayerNorm inside the GEMM block" had to rewrite the operand before the
+//     MFMA (two passes + packing), cost 2.5 us of VALU per block and lost.
 //
 // Cast points: the reference rounds LN(h) to bf16 before the GEMM; here the normalised activations are never materialised (the
 // products (h_k - mean) * gamma_k * W[n][k] are formed from the bf16-rounded W' instead): same error budget, different
@@ -109,8 +111,6 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_cols_resid_kernel(const bf16_
         e_idx = xp_index(mt, out_KS_, e_row, e_n);
         e_res = bf2f(h_xp_[e_idx]);
     }
-    const ColsArgs p = sv_late_args<ColsArgs>(offsetof(ColsKernarg, p));      // (the stream is in flight: the rest of the arguments)
-
     for (int ci = 0; ci < nc; ci += 2 * G) {
         compute(ga, ci);
         if (ci + 2 * G < nc) load(ga, ci + 2 * G);
@@ -141,49 +141,13 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_cols_resid_kernel(const bf16_
             float rr[8], bb[8], hn[8];
             unpack8(v_res, rr);
             unpack8(v_bias, bb);
-            float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                hn[e] = bfround(rr[e] + bfround(tile[v_row * 17 + 8 * v_ch + e] + bb[e]));      // h = bf(h + bf(x W^T + b))
-                s1 += hn[e]; s2 += hn[e] * hn[e];
-            }
+            for (int e = 0; e < 8; ++e) hn[e] = bfround(rr[e] + bfround(tile[v_row * 17 + 8 * v_ch + e] + bb[e]));      // h = bf(h + bf(x W^T + b))
             *reinterpret_cast<uint4*>(h_xp_ + v_idx) = pack8(hn);
-            if (p.stats) {
-                // per-row partial LayerNorm statistics of the block's columns of the NEW h (column order: deterministic);
-                // cpb = 16: the two chunks of a row are 32 threads apart -> combined through the tile
-                if (cpb_ == 8) {
-                    p.stats[((size_t)mt * p.nblocks + j) * 32 + v_row] = make_float2(s1, s2);       // [block][row]: 256 contiguous bytes
-                } else {
-                    red[2 * tid] = s1; red[2 * tid + 1] = s2;           // red is free again: [chunk][row][2]
-                }
-            }
-        }
-        if (p.stats && cpb_ != 8) {
-            __syncthreads();
-            if (tid < 32) {
-                float s1 = 0.f, s2 = 0.f;
-                for (int c = 0; c < cpb_ / 8; ++c) { s1 += red[2 * (c * 32 + tid)]; s2 += red[2 * (c * 32 + tid) + 1]; }
-                p.stats[((size_t)mt * p.nblocks + j) * 32 + tid] = make_float2(s1, s2);
-            }
         }
         return;
     }
-    float hnew = 0.f;
-    if (e_on) {
-        hnew = bfround(e_res + bfround(tile[e_row * 17 + e_cr] + e_bias));      // h = bf(h + bf(x W^T + b))
-        h_xp_[e_idx] = f2bf(hnew);
-    }
-    if (p.stats) {
-        // per-row partial LayerNorm statistics of the block's columns of the NEW h (column order: deterministic)
-        __syncthreads();                                                        // every thread has read its tile value
-        if (tid < 32 * cpb_) tile[e_row * 17 + e_cr] = e_on ? hnew : 0.f;
-        __syncthreads();
-        if (tid < 32) {
-            float s1 = 0.f, s2 = 0.f;
-            for (int c = 0; c < cpb_; ++c) { const float v = tile[tid * 17 + c]; s1 += v; s2 += v * v; }
-            p.stats[((size_t)mt * p.nblocks + j) * 32 + tid] = make_float2(s1, s2);       // [block][row]: 256 contiguous bytes
-        }
-    }
+    if (e_on) h_xp_[e_idx] = f2bf(bfround(e_res + bfround(tile[e_row * 17 + e_cr] + e_bias)));
 }
 
 static size_t cols_smem(int waves) { return (size_t)waves * 512 * 4 + (32 * 17 + 16) * 4 + 64; }

@@ -171,8 +171,6 @@ struct sv_engine {
     int MT = 0, ldws = 0, Vpad = 0;
     bf16_t *h_dec = nullptr, *hl = nullptr, *xp_a = nullptr, *xp_attn = nullptr, *xp_mlp = nullptr;
     bf16_t* h_xp = nullptr;         // residual stream of the decode step in fragment order (6-launch layer)
-    float2* cols_stats = nullptr;   // [MT*32][cols_nblocks] per-block partial LayerNorm statistics of the output projection
-    int cols_nblocks = 0;
     bool fold6 = false;             // 6 launches per layer: slab-free attention output projection + ln_2 folded into c_fc
     bool fold_ready = false;
     bool only_skinny = false;       // profiling: enqueue only the weight-streaming GEMMs of a step
@@ -648,8 +646,6 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     if (!rc && e->fold6) {
         const int cpb = cols_pick_cpb(D);
         for (DecLayer& L : e->dec) L.c_proj.cpb = cpb;
-        e->cols_nblocks = (D + cpb - 1) / cpb;
-        rc = dalloc(e, &e->cols_stats, (size_t)R * e->cols_nblocks);
     }
     if (rc) { sv_destroy(e); return rc; }
     *out = e;
@@ -971,14 +967,13 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
             ColsArgs ca;
             memset(&ca, 0, sizeof(ca));
             ca.xp = e->xp_attn; ca.Wp = L.c_proj.Wp; ca.bias = L.c_proj.bias; ca.MT = MT; ca.N = L.c_proj.N; ca.K = L.c_proj.Kpad;
-            ca.cpb = L.c_proj.cpb; ca.h_xp = e->h_xp; ca.out_KS = D / 16; ca.stats = e->cols_stats; ca.nblocks = e->cols_nblocks;
+            ca.cpb = L.c_proj.cpb; ca.h_xp = e->h_xp; ca.out_KS = D / 16;
             if (!e->skip_skinny) { prof_mark(e, PK_SKINNY, st); launch_gemm_cols(ca, st); }
             SkinnyArgs a;
             memset(&a, 0, sizeof(a));
             a.xp = e->h_xp; a.Wp = L.c_fc.Wf; a.MT = MT; a.Npad = L.c_fc.Npad; a.K = L.c_fc.Kpad; a.N = L.c_fc.N; a.splitk = 1;
             a.out_mode = SK_OUT_PACKED_ACT; a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16;
-            a.fold_c1 = L.c_fc.c1; a.fold_c2 = L.c_fc.c2; a.fold_stats = e->cols_stats; a.fold_nparts = e->cols_nblocks;
-            a.fold_D = D; a.fold_eps = c.ln_eps;
+            a.fold_c1 = L.c_fc.c1; a.fold_c2 = L.c_fc.c2; a.fold_D = D; a.fold_eps = c.ln_eps;
             if (!e->skip_skinny) { prof_mark(e, PK_SKINNY, st); launch_gemm_skinny(a, st); }
         } else {
             skinny(e->xp_attn, L.c_proj, SK_OUT_PARTIAL, wsB);
@@ -2122,9 +2117,9 @@ extern "C" int sv_op_decode_proj_fold(const void* x, const void* Wp_, const void
     if (int ar = init_gemm_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
     hipStream_t st = (hipStream_t)stream;
     TmpBufs tmp;
-    const int Fpad = round_up(F, 32), cpb = cols_pick_cpb(D), nblocks = (D + cpb - 1) / cpb;
+    const int Fpad = round_up(F, 32), cpb = cols_pick_cpb(D);
     bf16_t *Wpp, *Wfp, *Wff, *xp, *hxp, *yxp;
-    float *c1, *c2; float2* stats;
+    float *c1, *c2;
     SVCHECK(tmp.get(&Wpp, (size_t)D * Kp));
     SVCHECK(tmp.get(&Wfp, (size_t)Fpad * D));
     SVCHECK(tmp.get(&Wff, (size_t)Fpad * D));
@@ -2133,10 +2128,8 @@ extern "C" int sv_op_decode_proj_fold(const void* x, const void* Wp_, const void
     SVCHECK(tmp.get(&yxp, (size_t)32 * Fpad));
     SVCHECK(tmp.get(&c1, (size_t)Fpad));
     SVCHECK(tmp.get(&c2, (size_t)Fpad));
-    SVCHECK(tmp.get(&stats, (size_t)32 * nblocks));
     HIPCHECK(hipMemsetAsync(xp, 0, (size_t)32 * Kp * 2, st));
     HIPCHECK(hipMemsetAsync(hxp, 0, (size_t)32 * D * 2, st));
-    HIPCHECK(hipMemsetAsync(stats, 0, (size_t)32 * nblocks * sizeof(float2), st));
     launch_pack_weight(Wp_, 0, Wpp, D, Kp, D, Kp, st);
     launch_pack_weight(Wf_, 0, Wfp, F, D, Fpad, D, st);
     pack_rows_kernel<<<(M * (Kp / 8) + 255) / 256, 256, 0, st>>>((const bf16_t*)x, Kp, xp, M, Kp);
@@ -2145,12 +2138,11 @@ extern "C" int sv_op_decode_proj_fold(const void* x, const void* Wp_, const void
     ColsArgs ca;
     memset(&ca, 0, sizeof(ca));
     ca.xp = xp; ca.Wp = Wpp; ca.bias = (const bf16_t*)bp; ca.MT = 1; ca.N = D; ca.K = Kp; ca.cpb = cpb; ca.h_xp = hxp; ca.out_KS = D / 16;
-    ca.stats = stats; ca.nblocks = nblocks;
     if (launch_gemm_cols(ca, st)) return fail(SV_ENOTSUP, "sv_op_decode_proj_fold: no kernel for this shape");
     SkinnyArgs a;
     memset(&a, 0, sizeof(a));
     a.xp = hxp; a.Wp = Wff; a.MT = 1; a.Npad = Fpad; a.K = D; a.N = F; a.splitk = 1; a.out_mode = SK_OUT_PACKED_ACT; a.act = act;
-    a.out_xp = yxp; a.out_KS = Fpad / 16; a.fold_c1 = c1; a.fold_c2 = c2; a.fold_stats = stats; a.fold_nparts = nblocks; a.fold_D = D;
+    a.out_xp = yxp; a.out_KS = Fpad / 16; a.fold_c1 = c1; a.fold_c2 = c2; a.fold_D = D;
     a.fold_eps = eps;
     launch_gemm_skinny(a, st);
     unpack_rows_kernel<<<(M * (D / 8) + 255) / 256, 256, 0, st>>>(hxp, (bf16_t*)h2_out, D, M, D);

@@ -1112,45 +1112,41 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
     const SkinnyArgs p = sv_late_args<SkinnyArgs>(offsetof(SkinnyKernarg, p));       // the stream is in flight: now the rest
     float bias_d[RPW], fc1[RPW];
     sk_bias<RPW>(p, bias_d, wave * RPW, nt, half, FOLD ? fc1 : nullptr);
-    // LayerNorm fold: this thread's share of the producer's per-block row statistics (row tid & 31, every (2 WAVES)-th part).
-    // [part][row]: the 32 rows of a part are 256 contiguous bytes.  ALL loads are issued here, behind the first weight chunks, and
-    // only summed after the K loop (a load-add-load-add loop in front of it was 16 dependent round trips: +4 us per launch).
+    // LayerNorm fold: the row statistics come out of the activation stream itself -- lane (m, half) sees 8 values of row m per
+    // k-step on their way to the MFMA, so (sum, sum of squares) of the wave's K range are a few packed VALU operations per
+    // fragment, hidden under the weight stream (nothing is normalised or rewritten: the statistics are only needed in the
+    // epilogue).  No producer-side partials, no extra global reads.
     constexpr bool fold_on = FOLD;
-    constexpr int FST = FOLD ? 16 : 1;                                    // parts per thread in flight: covers 2 * WAVES * 16 parts per batch
-    float2 ft[FST];
-    if (fold_on) {
-        const float2* sp = p.fold_stats + (tid & 31);
+    float fs1 = 0.f, fs2 = 0.f;
+    auto fold_acc = [&](const u32x4& xv) {
 #pragma unroll
-        for (int i = 0; i < FST; ++i) {
-            const int q = (tid >> 5) + i * 2 * WAVES;
-            ft[i] = q < p.fold_nparts ? sp[(size_t)q * 32] : make_float2(0.f, 0.f);
+        for (int w = 0; w < 4; ++w) {
+            const float a = __uint_as_float(xv[w] << 16), b = __uint_as_float(xv[w] & 0xffff0000u);
+            fs1 += a + b;
+            fs2 = fmaf(a, a, fmaf(b, b, fs2));
         }
-    }
+    };
 
     for (int ks = 0; ks < ks_per_wave; ks += NB * CH) {
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
 #pragma unroll
             for (int u = 0; u < CH; ++u)
-                if (ks + b * CH + u < ks_per_wave)
+                if (ks + b * CH + u < ks_per_wave) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(ck[b].w[u]), as_frag4(ck[b].x[u]), acc, 0, 0, 0);
+                    if constexpr (FOLD) fold_acc(ck[b].x[u]);
+                }
             if (ks + (b + NB) * CH < ks_per_wave) sk_load<CH>(ck[b], wptr, xptr, ks + (b + NB) * CH, ks_per_wave);
         }
     }
 
     // ---- K reduction across the waves of the block (wave order), every wave finishes RPW accumulator rows ----
     float v[RPW];
-    float2* fst_s = reinterpret_cast<float2*>(sk_smem + (size_t)WAVES * 16 * 64 * 4);      // [2 * WAVES][32] partial row statistics
-    if (fold_on) {
-        float2 fst = make_float2(0.f, 0.f);
-#pragma unroll
-        for (int i = 0; i < FST; ++i) { fst.x += ft[i].x; fst.y += ft[i].y; }
-        const float2* sp = p.fold_stats + (tid & 31);
-        for (int q = (tid >> 5) + FST * 2 * WAVES; q < p.fold_nparts; q += 2 * WAVES) {      // (more than 2 * WAVES * 16 parts: rare)
-            const float2 t = sp[(size_t)q * 32];
-            fst.x += t.x; fst.y += t.y;
-        }
-        fst_s[tid] = fst;                                                                   // tid = slice * 32 + row
+    float2* fst_s = reinterpret_cast<float2*>(sk_smem + (size_t)WAVES * 16 * 64 * 4);      // [WAVES][32] partial row statistics
+    if constexpr (FOLD) {
+        fs1 += __shfl_xor(fs1, 32, 64);                          // the two 8-column halves of a k-step
+        fs2 += __shfl_xor(fs2, 32, 64);
+        if (half == 0) fst_s[wave * 32 + m] = make_float2(fs1, fs2);
     }
     if constexpr (WAVES > 1) {
 #pragma unroll
@@ -1173,7 +1169,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
     if (fold_on) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int q = 0; q < 2 * WAVES; ++q) { const float2 t = fst_s[q * 32 + m]; s1 += t.x; s2 += t.y; }      // slice order
+        for (int q = 0; q < WAVES; ++q) { const float2 t = fst_s[q * 32 + m]; s1 += t.x; s2 += t.y; }          // wave (= K) order
         const float invD = 1.0f / (float)p.fold_D;
         const float mean = s1 * invD;
         float var = s2 * invD - mean * mean;
@@ -1183,7 +1179,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
     sk_store<RPW>(p, v, bias_d, wave * RPW, nt, mt, split, m, half, fold, fc1);
 }
 
-static size_t skinny_smem(int waves) { return (size_t)waves * 16 * 64 * 4 + (size_t)2 * waves * 32 * 8 + 16; }
+static size_t skinny_smem(int waves) { return (size_t)waves * 16 * 64 * 4 + (size_t)waves * 32 * 8 + 16; }
 
 static int init_mt2_attrs();
 int init_gemm_kernels() {

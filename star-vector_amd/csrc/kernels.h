@@ -53,11 +53,10 @@ struct SkinnyArgs {
     bf16_t* out_xp; int out_KS;      // PACKED_ACT: fragment-order buffer with out_KS = Npad/16 k-steps
     float* out_f32; int ldo;         // F32: [MT*32][ldo]; rounded to bf16 values if round_bf16
     int round_bf16;
-    // LayerNorm fold (decode_cols.hip; PACKED_ACT, MT == 1): xp is the RAW residual stream, Wp the folded image W' = bf16(W * gamma);
-    // epilogue x = rstd[m] * (acc - mean[m] * c1[n]) + c2[n].  Row statistics = fold_nparts partial (sum, sum of squares) per row
+    // LayerNorm fold (decode_cols.hip; split-K 1): xp is the RAW residual stream, Wp the folded image W' = bf16(W * gamma);
+    // epilogue x = rstd[m] * (acc - mean[m] * c1[n]) + c2[n], the row statistics accumulated from the activation stream in the kernel
     const float* fold_c1; const float* fold_c2;            // [Npad] (nullptr: off)
-    const float2* fold_stats; int fold_nparts;             // [fold_nparts][32]
-    int fold_D; float fold_eps;                            // LayerNorm width and epsilon
+    int fold_D; float fold_eps;                            // LayerNorm width (= K) and epsilon
 };
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st);
 // host arithmetic of the launch: waves per block (how K is cut inside a block = the summation order of a row) and whether a
@@ -75,7 +74,6 @@ struct ColsArgs {
     int MT, N, K;                    // K multiple of 32
     int cpb;                         // output columns per block (4, 8 or 16): cols_pick_cpb(N)
     bf16_t* h_xp; int out_KS;        // residual stream in fragment order, N = 16 * out_KS columns: h = bf(h + bf(x W^T + b)), in place
-    float2* stats; int nblocks;      // [MT][nblocks][32] per-block partial (sum, sum of squares) of the new rows (nullptr: off)
 };
 int cols_pick_cpb(int N);
 int launch_gemm_cols(const ColsArgs& a, hipStream_t st);        // 0 = ok, -1 = unsupported shape
