@@ -397,22 +397,6 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
 
     // q / k_new / v_new of this sequence -> LDS (bf16): the fp32 split-K slabs of the c_attn GEMM, summed here in slab order + bias.
     // 4 columns per thread and every load issued before the first add: one memory round trip.
-    // LayerNorm fold (decode_cols.hip): the slabs are sums over the RAW residual row times W' = bf16(W gamma); ln_1 is applied here,
-    // x = rstd * (sum - mean * c1[col]) + c2[col], from the row's (sum, sum of squares) the GEMM left per K slice.
-    float f_mean = 0.f, f_rstd = 1.f;
-    const bool fold = p.fold_c1 != nullptr;
-    if (fold) {
-        float s1 = 0.f, s2 = 0.f;
-        for (int sp = 0; sp < p.splitk; ++sp) {                     // slice order
-            const float2 t = p.fold_stats[(size_t)sp * p.rows_ws + b];
-            s1 += t.x; s2 += t.y;
-        }
-        const float invD = 1.0f / (float)p.fold_D;
-        f_mean = s1 * invD;
-        float var = s2 * invD - f_mean * f_mean;
-        var = var > 0.f ? var : 0.f;
-        f_rstd = rsqrtf(var + p.fold_eps);
-    }
     for (int c4 = tid; c4 < (16 * D + 2 * D) / 4; c4 += AD_WAVES * 64) {
         const int n = c4 * 4;                    // LDS slot: q rows [0,16*D) (rows >= G are zero), k_new, v_new
         int col;                                 // column of the c_attn output: q heads | k heads | v heads
@@ -423,14 +407,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
         if (col >= 0) {
             {
                 float4 acc4[8];
-                uint2 bb = make_uint2(0u, 0u);
-                float4 k1 = make_float4(0.f, 0.f, 0.f, 0.f), k2 = k1;
-                if (fold) {
-                    k1 = *reinterpret_cast<const float4*>(p.fold_c1 + col);
-                    k2 = *reinterpret_cast<const float4*>(p.fold_c2 + col);
-                } else {
-                    bb = *reinterpret_cast<const uint2*>(p.bias + col);
-                }
+                const uint2 bb = *reinterpret_cast<const uint2*>(p.bias + col);
 #pragma unroll
                 for (int sp = 0; sp < 8; ++sp)
                     if (sp < p.splitk)
@@ -439,13 +416,8 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
 #pragma unroll
                 for (int sp = 0; sp < 8; ++sp)
                     if (sp < p.splitk) { a.x += acc4[sp].x; a.y += acc4[sp].y; a.z += acc4[sp].z; a.w += acc4[sp].w; }
-                if (fold) {
-                    o.x = pack2bf(f_rstd * (a.x - f_mean * k1.x) + k2.x, f_rstd * (a.y - f_mean * k1.y) + k2.y);
-                    o.y = pack2bf(f_rstd * (a.z - f_mean * k1.z) + k2.z, f_rstd * (a.w - f_mean * k1.w) + k2.w);
-                } else {
-                    o.x = pack2bf(a.x + __uint_as_float(bb.x << 16), a.y + __uint_as_float(bb.x & 0xffff0000u));
-                    o.y = pack2bf(a.z + __uint_as_float(bb.y << 16), a.w + __uint_as_float(bb.y & 0xffff0000u));
-                }
+                o.x = pack2bf(a.x + __uint_as_float(bb.x << 16), a.y + __uint_as_float(bb.x & 0xffff0000u));
+                o.y = pack2bf(a.z + __uint_as_float(bb.y << 16), a.w + __uint_as_float(bb.y & 0xffff0000u));
             }
         }
         *reinterpret_cast<uint2*>(q_s + n) = o;

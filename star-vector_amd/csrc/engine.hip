@@ -171,13 +171,12 @@ struct sv_engine {
     int MT = 0, ldws = 0, Vpad = 0;
     bf16_t *h_dec = nullptr, *hl = nullptr, *xp_a = nullptr, *xp_attn = nullptr, *xp_mlp = nullptr;
     bf16_t* h_xp = nullptr;         // residual stream of the decode step in fragment order (6-launch layer)
-    bool fold6 = false;             // slab-free output projections + LayerNorms folded into their consumer GEMMs (decode_cols.hip)
+    bool fold6 = false;             // 6 launches per layer: slab-free attention output projection + ln_2 folded into c_fc
     bool fold_ready = false;
-    float2* slice_stats = nullptr;  // [8][MT*32] (sum, sum of squares) of every row over each K slice of the folded c_attn
     bool only_skinny = false;       // profiling: enqueue only the weight-streaming GEMMs of a step
     bool skip_skinny = false;       // profiling: enqueue everything BUT the weight-streaming GEMMs
     int exp = 0;                    // SV_EXP bit mask, read once at sv_create (A/B switches of the round's experiments):
-                                    //   2 the 7-launch layer (no LayerNorm fold); 4 the 6-launch layer (down projection keeps slabs + row update);
+                                    //   2 the 7-launch layer (no LayerNorm fold);
                                     //   (1: was the row update as one wave per row: 0.218 vs 0.131 ms per step, removed)
                                     //   8 (at sv_create only) the round 1-2 split-K rule of the decode GEMMs
                                     //   (16 / 32 / 64: 2 / 6 / 8 key groups per attention block: 1186 / 1169 / 1175 vs 1171 us, removed)
@@ -646,8 +645,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     e->fold6 = c.weight_dtype == SV_WEIGHT_BF16 && e->MT == 1 && (c.n_head * dh) % 32 == 0 && D % 32 == 0;
     if (!rc && e->fold6) {
         const int cpb = cols_pick_cpb(D);
-        for (DecLayer& L : e->dec) { L.c_proj.cpb = cpb; L.c_proj2.cpb = cpb; }
-        rc = dalloc(e, &e->slice_stats, (size_t)8 * R);
+        for (DecLayer& L : e->dec) L.c_proj.cpb = cpb;
     }
     if (rc) { sv_destroy(e); return rc; }
     *out = e;
@@ -727,18 +725,13 @@ extern "C" int sv_weights_complete(sv_engine* e) {
         std::lock_guard<std::mutex> lk(e->mu);
         if (!e->fold_ready) {
             HIPCHECK(hipSetDevice(e->cfg.device));
-            auto fold = [&](Linear& l, const LNp& ln, const bf16_t* bias) -> int {
+            for (DecLayer& L : e->dec) {
+                Linear& l = L.c_fc;
                 if (!l.Wf) SVCHECK(dalloc(e, &l.Wf, (size_t)l.Npad * l.Kpad, false));
                 if (!l.c1) SVCHECK(dalloc(e, &l.c1, (size_t)l.Npad, true));
                 if (!l.c2) SVCHECK(dalloc(e, &l.c2, (size_t)l.Npad, true));
-                launch_fold_prepare(l.Wp, ln.g, ln.b, bias, l.Wf, l.c1, l.c2, l.N, l.Npad, l.Kpad, nullptr);
-                return 0;
-            };
-            for (DecLayer& L : e->dec) {
-                SVCHECK(fold(L.c_attn, L.ln1, L.c_attn.bias));          // ln_1 -> c_attn (applied by the attention kernel to the summed slabs)
-                SVCHECK(fold(L.c_fc, L.ln2, L.c_fc.bias));              // ln_2 -> c_fc
+                launch_fold_prepare(l.Wp, L.ln2.g, L.ln2.b, l.bias, l.Wf, l.c1, l.c2, l.N, l.Npad, l.Kpad, nullptr);
             }
-            SVCHECK(fold(e->lm_head, e->ln_f, nullptr));                 // ln_f -> lm_head (no bias)
             HIPCHECK(hipGetLastError());
             HIPCHECK(hipDeviceSynchronize());
             e->fold_ready = true;
@@ -950,54 +943,8 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
         prof_mark(e, PK_SKINNY, st);
         launch_gemm_skinny(a, st);
     };
-    const bool fold5 = fold6 && !(e->exp & 4);             // SV_EXP bit 4 = A/B: keep the down-projection's slabs + row update (6 launches)
-    auto cols = [&](const bf16_t* xp, const Linear& l) {         // h += bf(x W^T + b) in place, whole K per block
-        ColsArgs ca;
-        memset(&ca, 0, sizeof(ca));
-        ca.xp = xp; ca.Wp = l.Wp; ca.bias = l.bias; ca.MT = MT; ca.N = l.N; ca.K = l.Kpad; ca.cpb = l.cpb; ca.h_xp = e->h_xp; ca.out_KS = D / 16;
-        if (e->skip_skinny) return;
-        prof_mark(e, PK_SKINNY, st);
-        launch_gemm_cols(ca, st);
-    };
-    auto folded = [&](const Linear& l, int out_mode, int splitk, float* ws) {      // a GEMM on the raw residual stream, LayerNorm folded
-        SkinnyArgs a;
-        memset(&a, 0, sizeof(a));
-        a.xp = e->h_xp; a.Wp = l.Wf; a.MT = MT; a.Npad = l.Npad; a.K = l.Kpad; a.N = l.N; a.splitk = splitk; a.out_mode = out_mode;
-        a.fold_c1 = l.c1; a.fold_c2 = l.c2; a.fold_D = D; a.fold_eps = c.ln_eps;
-        if (out_mode == SK_OUT_PARTIAL) { a.ws = ws; a.ldws = e->ldws; a.fold_stats_out = e->slice_stats; }
-        else if (out_mode == SK_OUT_PACKED_ACT) { a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16; }
-        else { a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1; }
-        if (e->skip_skinny) return;
-        prof_mark(e, PK_SKINNY, st);
-        launch_gemm_skinny(a, st);
-    };
     for (int i = 0; i < c.n_layer; ++i) {
         DecLayer& L = e->dec[i];
-        if (fold5) {
-            // 5 launches: c_attn on the raw h (ln_1 folded, slabs + slice statistics) | attention (sums the slabs, applies ln_1) |
-            // output projection in place | c_fc on the raw h (ln_2 folded, GELU) | down projection in place
-            if (i == 0) row_update();                            // token embedding -> h (fragment order)
-            folded(L.c_attn, SK_OUT_PARTIAL, L.c_attn.splitk, wsA);
-            if (!e->only_skinny) {
-                AttnDecodeArgs ad;
-                memset(&ad, 0, sizeof(ad));
-                ad.ws = wsA; ad.splitk = L.c_attn.splitk; ad.ldws = e->ldws; ad.rows_ws = MT * 32; ad.bias = L.c_attn.bias;
-                ad.fold_c1 = L.c_attn.c1; ad.fold_c2 = L.c_attn.c2; ad.fold_stats = e->slice_stats; ad.fold_D = D; ad.fold_eps = c.ln_eps;
-                ad.pool_layer = e->kv_pool + (size_t)i * e->layer_stride; ad.block_table = e->block_table;
-                ad.max_pages = e->pages_per_seq; ad.positions = e->positions; ad.out_xp = e->xp_attn; ad.out_KS = D / 16;
-                ad.window = c.sliding_window;
-                ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
-                ad.part = e->attn_part; ad.counters = e->attn_cnt;
-                ad.max_splits = attn_max_splits(e);
-                ad.n_kv = e->nkv; ad.kv_head_stride = e->kv_head_stride; ad.rope_cos = e->rope_cos; ad.rope_sin = e->rope_sin;
-                prof_mark(e, PK_ATTN, st);
-                launch_attn_decode(ad, st);
-            }
-            cols(e->xp_attn, L.c_proj);
-            folded(L.c_fc, SK_OUT_PACKED_ACT, 1, nullptr);
-            cols(e->xp_mlp, L.c_proj2);
-            continue;
-        }
         row_update();                                            // embedding or the previous layer's down-proj -> LN1(h)
         skinny(e->xp_a, L.c_attn, SK_OUT_PARTIAL, wsA);
         if (!e->only_skinny) {
@@ -1015,9 +962,19 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
             launch_attn_decode(ad, st);
         }
         if (fold6) {
-            // 6 launches (A/B): output projection in place, then c_fc on the raw h with ln_2 folded; the down projection keeps its slabs
-            cols(e->xp_attn, L.c_proj);
-            folded(L.c_fc, SK_OUT_PACKED_ACT, 1, nullptr);
+            // attention output projection over the whole K per block: h += bf(x W^T + b) in place (+ partial row statistics), then
+            // c_fc on the raw h with ln_2 folded into its weights / epilogue: no slabs, no row-update launch (decode_cols.hip)
+            ColsArgs ca;
+            memset(&ca, 0, sizeof(ca));
+            ca.xp = e->xp_attn; ca.Wp = L.c_proj.Wp; ca.bias = L.c_proj.bias; ca.MT = MT; ca.N = L.c_proj.N; ca.K = L.c_proj.Kpad;
+            ca.cpb = L.c_proj.cpb; ca.h_xp = e->h_xp; ca.out_KS = D / 16;
+            if (!e->skip_skinny) { prof_mark(e, PK_SKINNY, st); launch_gemm_cols(ca, st); }
+            SkinnyArgs a;
+            memset(&a, 0, sizeof(a));
+            a.xp = e->h_xp; a.Wp = L.c_fc.Wf; a.MT = MT; a.Npad = L.c_fc.Npad; a.K = L.c_fc.Kpad; a.N = L.c_fc.N; a.splitk = 1;
+            a.out_mode = SK_OUT_PACKED_ACT; a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16;
+            a.fold_c1 = L.c_fc.c1; a.fold_c2 = L.c_fc.c2; a.fold_D = D; a.fold_eps = c.ln_eps;
+            if (!e->skip_skinny) { prof_mark(e, PK_SKINNY, st); launch_gemm_skinny(a, st); }
         } else {
             skinny(e->xp_attn, L.c_proj, SK_OUT_PARTIAL, wsB);
             ru.ws = wsB; ru.splitk = L.c_proj.splitk; ru.bias = L.c_proj.bias; ru.g = L.ln2.g; ru.b = L.ln2.b;
@@ -1028,12 +985,8 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
         const LNp& nxt = (i + 1 < c.n_layer) ? e->dec[i + 1].ln1 : e->ln_f;
         ru.ws = wsB; ru.splitk = L.c_proj2.splitk; ru.bias = L.c_proj2.bias; ru.g = nxt.g; ru.b = nxt.b;
     }
-    if (fold5) {
-        folded(e->lm_head, SK_OUT_F32, 1, nullptr);              // lm_head on the raw h, ln_f folded
-    } else {
-        row_update();                                            // + bias + residual, ln_f
-        skinny(e->xp_a, e->lm_head, SK_OUT_F32, nullptr);
-    }
+    row_update();                                                // + bias + residual, ln_f
+    skinny(e->xp_a, e->lm_head, SK_OUT_F32, nullptr);
     prof_mark(e, PK_SAMPLE, st);      // closes the lm_head interval; whatever follows is sampling
 }
 

@@ -1010,9 +1010,9 @@ __device__ __forceinline__ void sk_bias(const SkinnyArgs& p, float* bias_d, int 
         if (fc1) fc1[i] = 0.f;
         const int r = r0 + i;
         const int n = nt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-        if (n < p.N) {
-            if (fc1 && p.fold_c1) { if (p.out_mode != SK_OUT_PARTIAL) { fc1[i] = p.fold_c1[n]; bias_d[i] = p.fold_c2[n]; } }
-            else if (p.out_mode == SK_OUT_PACKED_ACT && p.bias) bias_d[i] = bf2f(p.bias[n]);
+        if (p.out_mode == SK_OUT_PACKED_ACT && n < p.N) {
+            if (fc1 && p.fold_c1) { fc1[i] = p.fold_c1[n]; bias_d[i] = p.fold_c2[n]; }
+            else if (p.bias) bias_d[i] = bf2f(p.bias[n]);
         }
     }
 }
@@ -1042,10 +1042,6 @@ __device__ __forceinline__ void sk_store(const SkinnyArgs& p, float* v, const fl
         if (p.out_mode == SK_OUT_PARTIAL) {
             store_f32(p.ws + ((size_t)split * p.MT * 32 + mt * 32 + m) * p.ldws + n0);
         } else if (p.out_mode == SK_OUT_F32) {
-            if (fold.on) {                                       // lm_head on the raw h: ln_f folded (c2 = sum_k beta_k W[n][k])
-#pragma unroll
-                for (int i = 0; i < W; ++i) vv[i] = fold.rstd * (vv[i] - fold.mean * fc1[4 * g + i]) + bias_d[4 * g + i];
-            }
             if (p.round_bf16) {
 #pragma unroll
                 for (int i = 0; i < W; ++i) vv[i] = bfround(vv[i]);
@@ -1174,17 +1170,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int q = 0; q < WAVES; ++q) { const float2 t = fst_s[q * 32 + m]; s1 += t.x; s2 += t.y; }          // wave (= K) order
-        if (p.out_mode == SK_OUT_PARTIAL) {
-            // split-K: the statistics of this K slice go out next to the slabs (one writer per slice and row tile: column tile 0)
-            if (nt == 0 && wave == 0 && half == 0 && p.fold_stats_out)
-                p.fold_stats_out[((size_t)split * p.MT + mt) * 32 + m] = make_float2(s1, s2);
-            s1 = 0.f; s2 = 0.f;          // (no correction here: the consumer applies it to the summed slabs)
-        }
         const float invD = 1.0f / (float)p.fold_D;
         const float mean = s1 * invD;
         float var = s2 * invD - mean * mean;
         var = var > 0.f ? var : 0.f;
-        fold = SkFold{p.out_mode != SK_OUT_PARTIAL, mean, rsqrtf(var + p.fold_eps)};
+        fold = SkFold{true, mean, rsqrtf(var + p.fold_eps)};
     }
     sk_store<RPW>(p, v, bias_d, wave * RPW, nt, mt, split, m, half, fold, fc1);
 }

@@ -57,8 +57,6 @@ struct SkinnyArgs {
     // epilogue x = rstd[m] * (acc - mean[m] * c1[n]) + c2[n], the row statistics accumulated from the activation stream in the kernel
     const float* fold_c1; const float* fold_c2;            // [Npad] (nullptr: off)
     int fold_D; float fold_eps;                            // LayerNorm width (= K) and epsilon
-    float2* fold_stats_out;                                // PARTIAL + fold: [splitk][MT*32] (sum, sum of squares) of each row over the
-                                                           //   block's K slice, written by the blocks of column tile 0 (the consumer folds)
 };
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st);
 // host arithmetic of the launch: waves per block (how K is cut inside a block = the summation order of a row) and whether a
@@ -157,10 +155,6 @@ struct AttnDecodeArgs {
     const float* rope_cos; const float* rope_sin;          // [positions][D/2] rotary tables (nullptr: no RoPE)
     int window;                                            // sliding window: keys pos - window < j <= pos (0 = all)
     int groups_per_block;                                  // 32-key groups a block takes before another context split joins (0 = 4)
-    // LayerNorm fold (decode_cols.hip): the slabs are raw-h sums against W' = bf16(W gamma); x = rstd (sum - mean c1) + c2 here
-    const float* fold_c1; const float* fold_c2;            // [QKV] (nullptr: off; then `bias` is added instead)
-    const float2* fold_stats;                              // [splitk][rows_ws] (sum, sum of squares) of the row over each K slice
-    int fold_D; float fold_eps;
 };
 // in-place rotary embedding of the q and k heads of a prefill c_attn output (rotate_half convention)
 void launch_rope_prefill(bf16_t* qkv, int row_stride, int rows, int S0, int n_heads, int head_dim,
