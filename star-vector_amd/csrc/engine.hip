@@ -936,7 +936,12 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
         memset(&a, 0, sizeof(a));
         a.xp = xp; a.Wp = l.Wp; a.Wq = l.Wq; a.wscale = l.wscale; a.MT = MT; a.Npad = l.Npad; a.K = l.Kpad; a.N = l.N;
         a.out_mode = out_mode;
-        if (out_mode == SK_OUT_PARTIAL) { a.splitk = l.splitk; a.ws = ws; a.ldws = e->ldws; }
+        if (out_mode == SK_OUT_PARTIAL) {
+            a.splitk = l.splitk; a.ws = ws; a.ldws = e->ldws;
+            const int NT = l.Npad / 32;
+            a.xcd_remap = ((e->exp & 16) && MT == 1 && !l.fp8 && l.splitk > 1 && 8 % l.splitk == 0 && (NT * l.splitk) % 8 == 0 &&
+                           NT % (8 / l.splitk) == 0) ? 1 : 0;
+        }
         else if (out_mode == SK_OUT_PACKED_ACT) { a.splitk = 1; a.bias = l.bias; a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16; }
         else { a.splitk = 1; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1; }
         if (e->skip_skinny) return;

@@ -1075,11 +1075,11 @@ __device__ __forceinline__ void sk_store(const SkinnyArgs& p, float* v, const fl
 // Leading scalar parameters = the few values the first address computation needs: they are PRELOADED into SGPRs by the command
 // processor (build flag -amdgpu-kernarg-preload-count; only scalar / pointer parameters qualify, not a by-value struct), so the
 // weight stream is requested without first waiting for a scalar load of the argument block (a cold K$ miss at every launch).
-struct SkinnyKernarg { const void* W; const bf16_t* x; int KS; int ks_per_split; SkinnyArgs p; };      // the kernarg segment of the skinny kernels
+struct SkinnyKernarg { const void* W; const bf16_t* x; int KS; int ks_per_split; int flags; SkinnyArgs p; };      // the kernarg segment of the skinny kernels
 // FOLD: the LayerNorm-folded c_fc (decode_cols.hip) -- its own instantiation, so that the statistics registers do not cost the
 // other GEMMs their second block per CU (<= 128 VGPRs)
 template <int WAVES, bool FOLD = false>
-__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* Wp_, const bf16_t* xp_, int KS_, int ks_per_split_, SkinnyArgs p_unused) {
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* Wp_, const bf16_t* xp_, int KS_, int ks_per_split_, int flags_, SkinnyArgs p_unused) {
     constexpr int CH = 4;                            // k-steps per register chunk (two chunks = 8 KiB of W in flight per wave)
     constexpr int NB = 2;
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
@@ -1087,9 +1087,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = blockIdx.x;
-    const int split = blockIdx.y;
+    int nt = blockIdx.x;
+    int split = blockIdx.y;
     const int mt = blockIdx.z;
+    if (flags_ & 1) {
+        // XCD-aware (tile, K slice) assignment of a split-K launch (speed only, results identical): blocks are dealt round-robin to
+        // the 8 XCDs, so in launch order every XCD meets all K slices and pulls the WHOLE activation matrix into its L2
+        // (down projection: 8 x 512 KB).  Here XCD x works on K slice x % splitk only -> 1 / splitk of it (launcher: splitk | 8).
+        const int S = gridDim.y, L = blockIdx.x + gridDim.x * blockIdx.y;
+        const int xcd = L & 7, i = L >> 3;
+        const int tpg = (gridDim.x * S) >> 3;             // tiles per XCD
+        split = xcd % S;
+        nt = (xcd / S) * tpg + i;
+    }
     const int KS = KS_;                                    // k-steps of the whole K and of this block's split (host-computed:
     const int ks_per_split = ks_per_split_;                //  no integer division in front of the first load)
     const int ks_per_wave = ks_per_split / WAVES;
@@ -1196,8 +1206,8 @@ int init_gemm_kernels() {
 
 template <int W>
 static void launch_sk(const SkinnyArgs& a, dim3 grid, hipStream_t st) {
-    if (a.fold_c1) gemm_skinny_kernel<W, true><<<grid, W * 64, skinny_smem(W), st>>>(a.Wp, a.xp, a.K / 16, (a.K / 16) / a.splitk, a);
-    else gemm_skinny_kernel<W, false><<<grid, W * 64, skinny_smem(W), st>>>(a.Wp, a.xp, a.K / 16, (a.K / 16) / a.splitk, a);
+    if (a.fold_c1) gemm_skinny_kernel<W, true><<<grid, W * 64, skinny_smem(W), st>>>(a.Wp, a.xp, a.K / 16, (a.K / 16) / a.splitk, a.xcd_remap, a);
+    else gemm_skinny_kernel<W, false><<<grid, W * 64, skinny_smem(W), st>>>(a.Wp, a.xp, a.K / 16, (a.K / 16) / a.splitk, a.xcd_remap, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1210,7 +1220,7 @@ static void launch_sk(const SkinnyArgs& a, dim3 grid, hipStream_t st) {
 // as the bf16 kernel has (one CU streams ~25 GB/s whatever the element size: it is the bytes in flight that count).
 // ------------------------------------------------------------------------------------------------
 template <int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_fp8_kernel(const uint8_t* Wq_, const bf16_t* xp_, int KS_, int ks_per_split_, SkinnyArgs p_unused) {
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_fp8_kernel(const uint8_t* Wq_, const bf16_t* xp_, int KS_, int ks_per_split_, int flags_, SkinnyArgs p_unused) {
     constexpr int CH = 8;
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(sk_smem);          // [WAVES][16][64]
@@ -1321,9 +1331,9 @@ static bool launch_gemm_skinny_fp8(const SkinnyArgs& a, hipStream_t st) {
     const int per_split = (a.K / 16) / a.splitk;
     (void)per_split;
     const int waves = skinny_waves_fp8(a.K / 16, a.splitk);
-    if (waves == 8) gemm_skinny_fp8_kernel<8><<<grid, 512, 8 * 16 * 64 * 4, st>>>(a.Wq, a.xp, a.K / 16, (a.K / 16) / a.splitk, a);
-    else if (waves == 4) gemm_skinny_fp8_kernel<4><<<grid, 256, 4 * 16 * 64 * 4, st>>>(a.Wq, a.xp, a.K / 16, (a.K / 16) / a.splitk, a);
-    else if (waves == 2) gemm_skinny_fp8_kernel<2><<<grid, 128, 2 * 16 * 64 * 4, st>>>(a.Wq, a.xp, a.K / 16, (a.K / 16) / a.splitk, a);
+    if (waves == 8) gemm_skinny_fp8_kernel<8><<<grid, 512, 8 * 16 * 64 * 4, st>>>(a.Wq, a.xp, a.K / 16, (a.K / 16) / a.splitk, a.xcd_remap, a);
+    else if (waves == 4) gemm_skinny_fp8_kernel<4><<<grid, 256, 4 * 16 * 64 * 4, st>>>(a.Wq, a.xp, a.K / 16, (a.K / 16) / a.splitk, a.xcd_remap, a);
+    else if (waves == 2) gemm_skinny_fp8_kernel<2><<<grid, 128, 2 * 16 * 64 * 4, st>>>(a.Wq, a.xp, a.K / 16, (a.K / 16) / a.splitk, a.xcd_remap, a);
     else return false;
     return true;
 }
@@ -1338,7 +1348,7 @@ static bool launch_gemm_skinny_fp8(const SkinnyArgs& a, hipStream_t st) {
 // fp8 (e4m3, widened in registers, per-column scale on the accumulator) weights.  NBUF register chunks of CH k-steps ring.
 // ------------------------------------------------------------------------------------------------
 template <int WAVES, bool FP8>
-__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(const void* W_, const bf16_t* xp_, int KS_, int ks_per_split_, SkinnyArgs p_unused) {
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(const void* W_, const bf16_t* xp_, int KS_, int ks_per_split_, int flags_, SkinnyArgs p_unused) {
     constexpr int CH = 4;
     constexpr int NBUF = FP8 ? 3 : 2;
     constexpr int WCH = FP8 ? CH / 2 : CH;                 // 16-byte weight loads per chunk and lane
@@ -1454,13 +1464,13 @@ static bool launch_gemm_skinny_mt2(const SkinnyArgs& a, hipStream_t st) {
     // the SAME number of waves (= the same per-wave k ranges and reduction order) as the one-tile kernel of this GEMM
     const int waves = a.Wq ? skinny_waves_fp8(a.K / 16, a.splitk) : skinny_waves(a.Npad, a.K / 16, a.splitk);
     if (waves == 8) {
-        if (a.Wq) gemm_skinny_mt2_kernel<8, true><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(a.Wq, a.xp, a.K / 16, (a.K / 16) / a.splitk, a);
-        else gemm_skinny_mt2_kernel<8, false><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(a.Wp, a.xp, a.K / 16, (a.K / 16) / a.splitk, a);
+        if (a.Wq) gemm_skinny_mt2_kernel<8, true><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(a.Wq, a.xp, a.K / 16, (a.K / 16) / a.splitk, a.xcd_remap, a);
+        else gemm_skinny_mt2_kernel<8, false><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(a.Wp, a.xp, a.K / 16, (a.K / 16) / a.splitk, a.xcd_remap, a);
         return true;
     }
     if (waves == 4) {
-        if (a.Wq) gemm_skinny_mt2_kernel<4, true><<<grid, 256, 2 * 4 * 16 * 64 * 4, st>>>(a.Wq, a.xp, a.K / 16, (a.K / 16) / a.splitk, a);
-        else gemm_skinny_mt2_kernel<4, false><<<grid, 256, 2 * 4 * 16 * 64 * 4, st>>>(a.Wp, a.xp, a.K / 16, (a.K / 16) / a.splitk, a);
+        if (a.Wq) gemm_skinny_mt2_kernel<4, true><<<grid, 256, 2 * 4 * 16 * 64 * 4, st>>>(a.Wq, a.xp, a.K / 16, (a.K / 16) / a.splitk, a.xcd_remap, a);
+        else gemm_skinny_mt2_kernel<4, false><<<grid, 256, 2 * 4 * 16 * 64 * 4, st>>>(a.Wp, a.xp, a.K / 16, (a.K / 16) / a.splitk, a.xcd_remap, a);
         return true;
     }
     return false;       // 16-wave (narrow outputs) and 1/2-wave (tiny K) shapes keep one row tile per block

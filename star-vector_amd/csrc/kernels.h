@@ -53,6 +53,7 @@ struct SkinnyArgs {
     bf16_t* out_xp; int out_KS;      // PACKED_ACT: fragment-order buffer with out_KS = Npad/16 k-steps
     float* out_f32; int ldo;         // F32: [MT*32][ldo]; rounded to bf16 values if round_bf16
     int round_bf16;
+    int xcd_remap;                   // 1: XCD-aware (tile, K slice) assignment of a split-K launch (needs splitk | 8, (Npad/32 * splitk) % 8 == 0)
     // LayerNorm fold (decode_cols.hip; split-K 1): xp is the RAW residual stream, Wp the folded image W' = bf16(W * gamma);
     // epilogue x = rstd[m] * (acc - mean[m] * c1[n]) + c2[n], the row statistics accumulated from the activation stream in the kernel
     const float* fold_c1; const float* fold_c2;            // [Npad] (nullptr: off)
