@@ -941,7 +941,7 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
             const int NT = l.Npad / 32;
             // XCD-aware (tile, K slice) assignment: every XCD pulls one K slice of the activations into its L2, not all of them
             // (profiles/skinny_r03_xcd_slice_remap_ab.log: 1121 -> 1110 us per step, tokens identical); SV_EXP bit 16 = off (A/B)
-            a.xcd_remap = (!(e->exp & 16) && MT == 1 && !l.fp8 && l.splitk > 1 && 8 % l.splitk == 0 && (NT * l.splitk) % 8 == 0 &&
+            a.xcd_remap = (!(e->exp & 16) && MT == 1 && l.splitk > 1 && 8 % l.splitk == 0 && (NT * l.splitk) % 8 == 0 &&
                            NT % (8 / l.splitk) == 0) ? 1 : 0;
         }
         else if (out_mode == SK_OUT_PACKED_ACT) { a.splitk = 1; a.bias = l.bias; a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16; }

@@ -1227,7 +1227,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_fp8_kernel(const uint8
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = blockIdx.x, split = blockIdx.y, mt = blockIdx.z;
+    int nt = blockIdx.x, split = blockIdx.y;
+    const int mt = blockIdx.z;
+    if (flags_ & 1) {                                          // XCD-aware (tile, K slice) assignment: see gemm_skinny_kernel
+        const int S = gridDim.y, L = blockIdx.x + gridDim.x * blockIdx.y;
+        const int xcd = L & 7, tpg = (gridDim.x * S) >> 3;
+        split = xcd % S;
+        nt = (xcd / S) * tpg + (L >> 3);
+    }
     const int KS = KS_;                                    // k-steps of the whole K and of this block's split (host-computed:
     const int ks_per_split = ks_per_split_;                //  no integer division in front of the first load)
     const int ks_per_wave = ks_per_split / WAVES;          // even (launcher)
