@@ -152,8 +152,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_cols_resid_kernel(const bf16_
 
 static size_t cols_smem(int waves) { return (size_t)waves * 512 * 4 + (32 * 17 + 16) * 4 + 64; }
 
-// blocks = ceil(N / cpb) close to a multiple of the 256 CUs, cpb a power of two <= 16
-int cols_pick_cpb(int N) {
+// Every block re-reads its row tile's whole activation operand (32 x K bf16) from L2 next to cpb x K weights from HBM, so narrow
+// blocks multiply L2 traffic: 4 columns per block at K = 4608 is 340 MB of L2 reads for 42 MB of weights (measured: +18 us per
+// layer on StarVector-8B, profiles/fold6_r03_8b_ab.log).  K <= 2048: blocks = ceil(N / cpb) closest to a multiple of the 256 CUs
+// (the activations are 128 KiB, the fill matters more); above that the widest block.
+int cols_pick_cpb(int N, int K) {
+    if (K > 2048) return 16;
     int best = 8;
     double best_fill = 0.0;
     for (int cpb = 16; cpb >= 4; cpb >>= 1) {

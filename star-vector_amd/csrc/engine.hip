@@ -641,10 +641,14 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
             rc = fail(SV_EHIP, "rope table upload failed");
     }
     if (getenv("SV_EXP")) e->exp = atoi(getenv("SV_EXP"));
-    // 6 launches per layer (decode_cols.hip): bf16 weights, at most one 32-row tile per launch; SV_EXP bit 2 = A/B, the 7-launch layer
-    e->fold6 = c.weight_dtype == SV_WEIGHT_BF16 && e->MT == 1 && (c.n_head * dh) % 32 == 0 && D % 32 == 0;
+    // 6 launches per layer (decode_cols.hip): bf16 weights, at most one 32-row tile per launch; SV_EXP bit 2 = A/B, the 7-launch layer.
+    // Hidden sizes above 2048 keep the 7-launch layer: every block of the whole-K projection re-reads 32 x K activations from L2,
+    // and at StarVector-8B's K = 4608 that costs what the removed row update saved and a little more (4227 vs 4178 us per step,
+    // profiles/fold6_r03_8b_ab.log); SV_EXP bit 4 = A/B, the 6-launch layer at any size.
+    e->fold6 = c.weight_dtype == SV_WEIGHT_BF16 && e->MT == 1 && (c.n_head * dh) % 32 == 0 && D % 32 == 0 &&
+               (c.n_head * dh <= 2048 || (e->exp & 4));
     if (!rc && e->fold6) {
-        const int cpb = cols_pick_cpb(D);
+        const int cpb = cols_pick_cpb(D, c.n_head * dh);
         for (DecLayer& L : e->dec) L.c_proj.cpb = cpb;
     }
     if (rc) { sv_destroy(e); return rc; }
@@ -2124,7 +2128,7 @@ extern "C" int sv_op_decode_proj_fold(const void* x, const void* Wp_, const void
     if (int ar = init_gemm_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
     hipStream_t st = (hipStream_t)stream;
     TmpBufs tmp;
-    const int Fpad = round_up(F, 32), cpb = cols_pick_cpb(D);
+    const int Fpad = round_up(F, 32), cpb = cols_pick_cpb(D, Kp);
     bf16_t *Wpp, *Wfp, *Wff, *xp, *hxp, *yxp;
     float *c1, *c2;
     SVCHECK(tmp.get(&Wpp, (size_t)D * Kp));

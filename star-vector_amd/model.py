@@ -865,32 +865,56 @@ class StarVectorForCausalLM(nn.Module):
         completion_embeds = self.model._get_embeddings(input_ids)
         inputs_embeds = torch.cat([vision_embeds.repeat(num_generations, 1, 1).to(completion_embeds.dtype),
                                    completion_embeds], dim=1)
+        lead = None
         if attention_mask is not None and not bool((attention_mask == 1).all()):
             # Right padding (completions padded after their EOS, what a GRPO trainer passes): under the causal mask a real
             # position never sees a later key and HF's positions (cumsum(mask) - 1) equal the plain index for it, so the
             # logits of every real position are those of the unmasked run.  Rows at padded positions are unspecified (HF's
             # differ there too from any unpadded run; the caller multiplies them away with the same mask).
+            # Left padding: HF masks the padded keys and numbers positions by cumsum(mask) - 1, i.e. a left-padded row IS the same
+            # row with its padding removed (pinned against HF for generation, oracle/make_golden.py::run_padding_case) -> rows are
+            # grouped by their number of leading pads, scored without them, and their logits put back at the real positions.
             m = attention_mask.to(torch.bool)
             if m.shape != inputs_embeds.shape[:2]:
                 raise ValueError(f"attention_mask {tuple(m.shape)} does not cover inputs_embeds {tuple(inputs_embeds.shape[:2])}")
-            if bool((m[:, 1:] & ~m[:, :-1]).any()) or not bool(m[:, 0].all()):
-                raise NotImplementedError("only right-padded attention masks are built for the scoring forward")
+            lead = (m.cumsum(1) == 0).sum(1)                                  # leading pads per row
+            idx = torch.arange(m.shape[1], device=m.device).unsqueeze(0)
+            real = idx >= lead.unsqueeze(1)
+            if bool((m[:, 1:] & ~m[:, :-1] & real[:, :-1]).any()):            # a 1 after a 0 behind the leading pads
+                raise NotImplementedError("attention masks with holes are not built for the scoring forward (left / right padding only)")
+            if not bool(lead.any()):
+                lead = None
         emb16, keep = inputs_embeds.to(torch.bfloat16), int(num_logits_to_keep or 0)
         lm = getattr(getattr(self.model, "svg_transformer", None), "transformer", None)
         batcher = getattr(lm, "batcher", None)
-        if batcher is not None and not _in_exclusive_job():
-            # requests share the engine's decode loop: the scoring pass wants the engine to itself (it would fail with SV_ESTATE
-            # while slots are live) -> queue it as an exclusive job, FIFO with the generation requests
-            def call():
-                _EXCLUSIVE.active = True
-                try:
-                    return self.engine.forward_logits(emb16, keep)
-                finally:
-                    _EXCLUSIVE.active = False
-            logits = batcher.run_exclusive(call)
-        else:
+
+        def score(e16):
+            if batcher is not None and not _in_exclusive_job():
+                # requests share the engine's decode loop: the scoring pass wants the engine to itself (it would fail with SV_ESTATE
+                # while slots are live) -> queue it as an exclusive job, FIFO with the generation requests
+                def call():
+                    _EXCLUSIVE.active = True
+                    try:
+                        return self.engine.forward_logits(e16, keep)
+                    finally:
+                        _EXCLUSIVE.active = False
+                return batcher.run_exclusive(call)
             with (getattr(self.engine, "call_lock", None) or contextlib.nullcontext()):
-                logits = self.engine.forward_logits(emb16, keep)
+                return self.engine.forward_logits(e16, keep)
+
+        if lead is None:
+            logits = score(emb16)
+        else:
+            S = emb16.shape[1]
+            if keep and int(lead.max()) + keep > S:
+                raise ValueError(f"num_logits_to_keep ({keep}) reaches into the left padding of a row ({int(lead.max())} pads of {S})")
+            logits = None
+            for pads in sorted(set(lead.tolist())):
+                rows = (lead == pads).nonzero().flatten()
+                lg = score(emb16[rows, pads:].contiguous())                   # [rows, keep or S - pads, V]
+                if logits is None:
+                    logits = torch.zeros(emb16.shape[0], keep or S, lg.shape[-1], dtype=lg.dtype, device=lg.device)
+                logits[rows.to(lg.device), (0 if keep else pads):] = lg
         try:
             from transformers.modeling_outputs import CausalLMOutputWithCrossAttentions
             return CausalLMOutputWithCrossAttentions(loss=None, logits=logits, past_key_values=None, hidden_states=None,

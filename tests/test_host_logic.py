@@ -271,7 +271,7 @@ def test_config_from_checkpoint_reads_sizes_off_the_tensors():
         config_from_checkpoint({"vocab_size": 49152}, {pd + "wte.weight": (100, 2048)})
 
 
-def test_scoring_forward_accepts_right_padded_masks_only():
+def test_scoring_forward_padded_masks():
     """starvector_arch.py:161-184 with the mask a GRPO trainer passes (completions padded after EOS)."""
     import types
     from starvector_amd.model import StarVectorForCausalLM
@@ -285,22 +285,38 @@ def test_scoring_forward_accepts_right_padded_masks_only():
 
         def forward_logits(self, emb, keep):
             self.seen = (tuple(emb.shape), keep)
-            return torch.zeros(emb.shape[0], keep or emb.shape[1], 7)
+            self.calls.append((tuple(emb.shape), keep))
+            # "logit" = the embedding value of the position it belongs to, so placement can be checked
+            pos = emb[:, -(keep or emb.shape[1]):, 0].float()
+            return pos.unsqueeze(-1).expand(-1, -1, 7).contiguous()
 
     m = StarVectorForCausalLM.__new__(StarVectorForCausalLM)
     torch.nn.Module.__init__(m)
     eng = Eng()
+    eng.calls = []
     object.__setattr__(m, "engine", eng)
     object.__setattr__(m, "model", types.SimpleNamespace(_get_embeddings=eng.embed_tokens))
     vis = torch.ones(1, 3, 4, dtype=torch.bfloat16)
     ids = torch.tensor([[5, 6, 7, 0], [5, 6, 0, 0]])
     right = torch.tensor([[1, 1, 1, 1, 1, 1, 1], [1, 1, 1, 1, 1, 0, 0]])
     out = m.forward(vis, ids, 2, right, 4)
-    assert out.logits.shape == (2, 4, 7) and eng.seen == ((2, 7, 4), 4)
-    with pytest.raises(NotImplementedError):
-        m.forward(vis, ids, 2, torch.tensor([[1] * 7, [0, 1, 1, 1, 1, 1, 1]]), 4)        # left padding
+    assert out.logits.shape == (2, 4, 7) and eng.seen == ((2, 7, 4), 4) and len(eng.calls) == 1
+    # left padding: the row is scored without its pads (HF: masked keys, positions cumsum(mask) - 1) in its own engine pass
+    eng.calls.clear()
+    out = m.forward(vis, ids, 2, torch.tensor([[1] * 7, [0, 0, 1, 1, 1, 1, 1]]), 4)
+    assert sorted(eng.calls) == [((1, 5, 4), 4), ((1, 7, 4), 4)]
+    assert out.logits.shape == (2, 4, 7)
+    assert out.logits[0, :, 0].tolist() == [5, 6, 7, 0] and out.logits[1, :, 0].tolist() == [5, 6, 0, 0]
+    eng.calls.clear()
+    out = m.forward(vis, ids, 2, torch.tensor([[0, 1, 1, 1, 1, 1, 0], [0, 1, 1, 1, 1, 1, 1]]), None)    # all positions, left + right pads
+    assert eng.calls == [((2, 6, 4), 0)] and out.logits.shape == (2, 7, 7)
+    assert out.logits[0, :, 0].tolist() == [0, 1, 1, 5, 6, 7, 0]          # column 0 = the pad: left at zero
+    with pytest.raises(ValueError):
+        m.forward(vis, ids, 2, torch.tensor([[1] * 7, [0, 0, 0, 0, 1, 1, 1]]), 4)        # the kept logits reach into the pads
     with pytest.raises(NotImplementedError):
         m.forward(vis, ids, 2, torch.tensor([[1] * 7, [1, 1, 0, 1, 1, 1, 1]]), 4)        # a hole
+    with pytest.raises(NotImplementedError):
+        m.forward(vis, ids, 2, torch.tensor([[1] * 7, [0, 1, 0, 1, 1, 1, 1]]), 4)        # a hole behind a left pad
     with pytest.raises(ValueError):
         m.forward(vis, ids, 2, torch.ones(2, 4, dtype=torch.long)[:, :3] * torch.tensor([[1, 1, 0]]), 4)
 
