@@ -585,9 +585,25 @@ def run_forward_case(write):
     d_pad = float((masked - ref.detach())[~mask.bool()].abs().max())
     print(f"[tiny_forward] right-padded mask: max|diff| at real positions {d_real:.2e} (at padded ones {d_pad:.2e}: unspecified)")
     assert d_real < 1e-5
+    # left-padded mask: the reference's pinned transformers (4.49; the vendored snapshot gpt_bigcode/modeling_gpt_bigcode.py:980-983)
+    # masks the padded keys and numbers positions by cumsum(mask) - 1 inside the model's forward -> a row's real positions equal the
+    # row scored ALONE without its pads (what the mirror's forward does for such rows), and an unpadded row is untouched.  The
+    # transformers installed here (5.x) builds that numbering in generate() only, so the 4.49 rule is passed in as position_ids.
+    lmask = torch.ones(emb.shape[:2], dtype=torch.long)
+    lmask[0, :2] = 0
+    pos = lmask.cumsum(-1) - 1
+    pos.masked_fill_(lmask == 0, 1)
+    lpad = lm(inputs_embeds=emb, attention_mask=lmask, position_ids=pos).logits.detach()
+    alone = O.decoder_forward_logits(w, cfg, emb[:1, 2:], 0)
+    d_left = float((lpad[0, 2:] - alone[0]).abs().max())
+    d_other = float((lpad[1] - ref.detach()[1]).abs().max())
+    print(f"[tiny_forward] left-padded mask: max|HF masked row - oracle on the row without pads| {d_left:.2e}; "
+          f"unpadded row vs unmasked run {d_other:.2e}")
+    assert d_left < 1e-5 and d_other < 1e-5
     if write:
         from safetensors.torch import save_file
-        save_file({"image": image, "ids": ids, "logits_keep5": ref[:, -5:].contiguous(), "meta": torch.tensor([1234, 2, 9])},
+        save_file({"image": image, "ids": ids, "logits_keep5": ref[:, -5:].contiguous(), "meta": torch.tensor([1234, 2, 9]),
+                   "logits_leftpad2_row0_keep5": lpad[0, -5:].contiguous()},
                   os.path.join(GOLD, "tiny_forward.safetensors"))
         print("  wrote tests/golden/tiny_forward.safetensors")
 
@@ -637,6 +653,9 @@ def main():
     torch.set_num_threads(host_cores())
     if "--only-window" in sys.argv:                 # re-mint tests/golden/tiny_v2_window.safetensors alone
         run_window_case(write)
+        return
+    if "--only-forward" in sys.argv:                # re-mint tests/golden/tiny_forward.safetensors alone
+        run_forward_case(write)
         return
     run_fitted_case("tiny_b3", O.OracleConfig.tiny(), seed=1234, batch=3, n_new=24, write=write)
     import dataclasses

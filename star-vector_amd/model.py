@@ -871,8 +871,9 @@ class StarVectorForCausalLM(nn.Module):
             # position never sees a later key and HF's positions (cumsum(mask) - 1) equal the plain index for it, so the
             # logits of every real position are those of the unmasked run.  Rows at padded positions are unspecified (HF's
             # differ there too from any unpadded run; the caller multiplies them away with the same mask).
-            # Left padding: HF masks the padded keys and numbers positions by cumsum(mask) - 1, i.e. a left-padded row IS the same
-            # row with its padding removed (pinned against HF for generation, oracle/make_golden.py::run_padding_case) -> rows are
+            # Left padding: the pinned transformers (4.49; gpt_bigcode/modeling_gpt_bigcode.py:980-983) masks the padded keys and
+            # numbers positions by cumsum(mask) - 1 inside the model's forward, i.e. a left-padded row IS the same row with its
+            # padding removed (pinned against HF: oracle/make_golden.py::run_forward_case, tests/golden/tiny_forward) -> rows are
             # grouped by their number of leading pads, scored without them, and their logits put back at the real positions.
             m = attention_mask.to(torch.bool)
             if m.shape != inputs_embeds.shape[:2]:

@@ -263,3 +263,7 @@ def test_scoring_forward_matches_hf(golden_dir):
     full = O.decoder_forward_logits(w, cfg, emb, 0)
     assert full.shape[1] == emb.shape[1] and float((full[:, -5:] - got).abs().max()) <= 1e-5
     assert float((full[:, -1] - O.decoder_prefill(w, cfg, emb)[0]).abs().max()) <= 1e-6     # last row == the prefill logits
+    # HF's run of the batch with row 0 left-padded by 2 (mask 0 0 1 ... 1, positions cumsum(mask) - 1 as transformers 4.49 numbers
+    # them): the row alone without its pads -- what the mirror's forward computes for left-padded rows
+    alone = O.decoder_forward_logits(w, cfg, emb[:1, 2:], 5)
+    assert float((alone[0] - g["logits_leftpad2_row0_keep5"]).abs().max()) <= 1e-5
