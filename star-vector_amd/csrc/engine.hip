@@ -115,6 +115,7 @@ struct Linear {
     float* wscale = nullptr;   //   per-output-row scale [Npad]
     int N = 0, K = 0, Npad = 0, Kpad = 0;
     int splitk = 1;       // decode-path split-K factor (fp32 slabs summed by the consumer)
+    int col_tiles = 1;    // column tiles per block of the two-row-tile decode kernel (33..64 rows; pick_decode_plan)
     int cpb = 8;          // output columns per block of the slab-free output projection (decode_cols.hip)
     bf16_t* Wf = nullptr; // LayerNorm-folded image W' = bf16(W * gamma) (decode_cols.hip; c_fc only), with
     float* c1 = nullptr;  //   c1[n] = sum_k W'[n][k]
@@ -315,6 +316,39 @@ static int pick_splitk(int n_tiles, int KS, int num_cus, bool fp8, bool legacy) 
         if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
     }
     return best;
+}
+
+// 33..64 rows (two row tiles per block): at that height every block re-reads 2 (bf16) / 4 (fp8) activation bytes per weight byte out
+// of L2 and the L2 -> CU side bounds the launch (tools/diag/mem_mix.hip), so a block may carry TWO column tiles per loaded activation
+// fragment.  (column tiles per block, split-K) are picked together: modelled time = the busiest CU's bytes (weights + activations
+// over its blocks) relative to an even spread, plus the slab cost.  Only shapes the two-row-tile kernel takes are candidates.
+static void pick_decode_plan(const Linear& l, int MT, int num_cus, bool fp8, bool legacy, bool whole_k, int* splitk, int* col_tiles) {
+    const int tiles = l.Npad / 32, KS = l.Kpad / 16;
+    *col_tiles = 1;
+    if (MT != 2 || legacy || (long)tiles * KS < 24L * 1024) {
+        *splitk = whole_k ? 1 : pick_splitk(tiles, KS, num_cus, fp8, legacy);
+        return;
+    }
+    const double wb = fp8 ? 512.0 : 1024.0, ab = 1024.0 * MT;
+    const double ideal = (double)tiles * KS * (wb + ab) / num_cus;
+    double best_cost = 1e30;
+    int best_s = 0, best_nt = 1;
+    for (int nt = 1; nt <= 2; ++nt)
+        for (int s = 1; s <= (whole_k ? 1 : 8); ++s) {
+            if (KS % s) continue;
+            const int per = KS / s;
+            if (s > 1 && per < 16) continue;
+            int waves = 0, two = 0;
+            skinny_plan(l.Npad, l.Kpad, s, fp8 ? 1 : 0, MT, &waves, &two);
+            if (!two || (nt == 2 && waves != 8)) continue;
+            const long nb = (long)((tiles + nt - 1) / nt) * s;
+            const long rounds = (nb + num_cus - 1) / num_cus;
+            const double cost = (double)rounds * per * (nt * wb + ab) / ideal + 0.015 * s;
+            if (cost < best_cost - 1e-9) { best_cost = cost; best_s = s; best_nt = nt; }
+        }
+    if (!best_s) { *splitk = whole_k ? 1 : pick_splitk(tiles, KS, num_cus, fp8, legacy); return; }
+    *splitk = best_s;
+    *col_tiles = best_nt;
 }
 
 // StarVector-8B key names: HF SiglipVisionTransformer under model.image_encoder.visual_encoder.*
@@ -528,12 +562,14 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         const bool fp8 = c.weight_dtype == SV_WEIGHT_FP8_E4M3;
         const bool legacy = getenv("SV_EXP") && (atoi(getenv("SV_EXP")) & 8);          // A/B: the round 1-2 split rule
         if (fp8) e->lm_head.fp8 = true;                  // decoder Linears + lm_head stream as fp8 at decode time
+        { int sk1 = 1; pick_decode_plan(e->lm_head, (c.max_batch + 31) / 32, e->num_cus, fp8, legacy, true, &sk1, &e->lm_head.col_tiles); }
+        const bool plan_log = getenv("SV_GEMM_AUTOTUNE_LOG") && atoi(getenv("SV_GEMM_AUTOTUNE_LOG"));
         for (DecLayer& L : e->dec) {
             Linear* ls[4] = {&L.c_attn, &L.c_proj, &L.c_fc, &L.c_proj2};
             for (Linear* l : ls) {
                 l->fp8 = fp8;
                 const int KS = l->Kpad / 16;
-                l->splitk = l == &L.c_fc ? 1 : pick_splitk(l->Npad / 32, KS, e->num_cus, fp8, legacy);
+                pick_decode_plan(*l, (c.max_batch + 31) / 32, e->num_cus, fp8, legacy, l == &L.c_fc, &l->splitk, &l->col_tiles);
                 if (fp8) {
                     // the fp8 kernel wants an even number (>= 2 per wave pair) of k-steps per wave: shrink split-K until it fits
                     while (l->splitk > 1 && (KS % l->splitk != 0 || (KS / l->splitk) % 4 != 0)) --l->splitk;
@@ -543,8 +579,14 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
                         return code;
                     }
                 }
+                if (plan_log && &L == &e->dec[0])
+                    fprintf(stderr, "[starvector_hip] decode plan N=%d K=%d rows<=%d %s: split-K %d, column tiles per block %d\n", l->Npad, l->Kpad,
+                            32 * ((c.max_batch + 31) / 32), fp8 ? "fp8" : "bf16", l->splitk, l->col_tiles);
             }
         }
+        if (plan_log)
+            fprintf(stderr, "[starvector_hip] decode plan lm_head N=%d K=%d: column tiles per block %d\n", e->lm_head.Npad, e->lm_head.Kpad,
+                    e->lm_head.col_tiles);
     }
 
     // ---- workspaces ----
@@ -939,7 +981,7 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
         SkinnyArgs a;
         memset(&a, 0, sizeof(a));
         a.xp = xp; a.Wp = l.Wp; a.Wq = l.Wq; a.wscale = l.wscale; a.MT = MT; a.Npad = l.Npad; a.K = l.Kpad; a.N = l.N;
-        a.out_mode = out_mode;
+        a.out_mode = out_mode; a.col_tiles = l.col_tiles;
         if (out_mode == SK_OUT_PARTIAL) {
             a.splitk = l.splitk; a.ws = ws; a.ldws = e->ldws;
             const int NT = l.Npad / 32;

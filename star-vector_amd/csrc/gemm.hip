@@ -1001,6 +1001,18 @@ __device__ __forceinline__ void sk_load(SkChunk<CH>& c, const u32x4* wptr, const
         if (ks + u < ks_end) c.x[u] = xptr[(size_t)(ks + u) * 64];                                 // wave-uniform guard
 }
 
+// the same without guards: the chunk lies inside the wave's k range.  The steady-state loops use this one on purpose: with the
+// wave-uniform guards of sk_load every load sits behind a branch, the compiler's wait-count analysis merges "loaded" and "not
+// loaded" paths and falls back to s_waitcnt vmcnt(0) in front of EVERY chunk's MFMAs -- the wave then waits for the loads it has
+// just issued (two chunks "in flight" were one round trip per chunk pair; found in round 3 from the ISA).
+template <int CH>
+__device__ __forceinline__ void sk_load_full(SkChunk<CH>& c, const u32x4* wptr, const u32x4* xptr, int ks) {
+#pragma unroll
+    for (int u = 0; u < CH; ++u) c.w[u] = __builtin_nontemporal_load(wptr + (size_t)(ks + u) * 64);
+#pragma unroll
+    for (int u = 0; u < CH; ++u) c.x[u] = xptr[(size_t)(ks + u) * 64];
+}
+
 // the bias of this lane's RPW output columns, requested BEFORE the weight stream (the epilogue must not start with a round trip)
 template <int RPW>
 __device__ __forceinline__ void sk_bias(const SkinnyArgs& p, float* bias_d, int r0, int nt, int half, float* fc1 = nullptr) {
@@ -1014,6 +1026,17 @@ __device__ __forceinline__ void sk_bias(const SkinnyArgs& p, float* bias_d, int 
             if (fc1 && p.fold_c1) { fc1[i] = p.fold_c1[n]; bias_d[i] = p.fold_c2[n]; }
             else if (p.bias) bias_d[i] = bf2f(p.bias[n]);
         }
+    }
+}
+// The epilogue operands must have LANDED before the k loop starts: a load that stays pending across the loop makes the compiler's
+// wait-count analysis give up on the loop (an unbounded distance to the oldest pending load) and put s_waitcnt vmcnt(0) at the
+// top of every iteration.  An empty asm that "uses" the values forces the wait here, once, in the prologue.
+template <int RPW>
+__device__ __forceinline__ void sk_settle(float* a, float* b = nullptr) {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        asm volatile("" : "+v"(a[i]));
+        if (b) asm volatile("" : "+v"(b[i]));
     }
 }
 // shared tail of the skinny kernels: v[i] = the reduced accumulator row r0 + i of lane (m, half), i.e. output
@@ -1116,12 +1139,8 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
 
     constexpr int RPW = 16 / WAVES;
     SkChunk<CH> ck[NB];
-#pragma unroll
-    for (int b = 0; b < NB; ++b)
-        if (b * CH < ks_per_wave) sk_load<CH>(ck[b], wptr, xptr, b * CH, ks_per_wave);
-    const SkinnyArgs p = sv_late_args<SkinnyArgs>(offsetof(SkinnyKernarg, p));       // the stream is in flight: now the rest
+    SkinnyArgs p;
     float bias_d[RPW], fc1[RPW];
-    sk_bias<RPW>(p, bias_d, wave * RPW, nt, half, FOLD ? fc1 : nullptr);
     // LayerNorm fold: the row statistics come out of the activation stream itself -- lane (m, half) sees 8 values of row m per
     // k-step on their way to the MFMA, so (sum, sum of squares) of the wave's K range are a few packed VALU operations per
     // fragment, hidden under the weight stream (nothing is normalised or rewritten: the statistics are only needed in the
@@ -1136,18 +1155,52 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
             fs2 = fmaf(a, a, fmaf(b, b, fs2));
         }
     };
-
-    for (int ks = 0; ks < ks_per_wave; ks += NB * CH) {
+    auto late = [&]() {                                     // the stream is in flight: now the rest of the arguments + the bias
+        p = sv_late_args<SkinnyArgs>(offsetof(SkinnyKernarg, p));
+        sk_bias<RPW>(p, bias_d, wave * RPW, nt, half, FOLD ? fc1 : nullptr);
+        sk_settle<RPW>(bias_d, FOLD ? fc1 : nullptr);
+    };
+    auto guarded = [&](int ks) {                            // the ragged end of the range (and short ranges): guard per k-step
+        for (; ks < ks_per_wave; ks += NB * CH) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
+            for (int b = 0; b < NB; ++b) {
 #pragma unroll
-            for (int u = 0; u < CH; ++u)
-                if (ks + b * CH + u < ks_per_wave) {
+                for (int u = 0; u < CH; ++u)
+                    if (ks + b * CH + u < ks_per_wave) {
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(ck[b].w[u]), as_frag4(ck[b].x[u]), acc, 0, 0, 0);
+                        if constexpr (FOLD) fold_acc(ck[b].x[u]);
+                    }
+                if (ks + (b + NB) * CH < ks_per_wave) sk_load<CH>(ck[b], wptr, xptr, ks + (b + NB) * CH, ks_per_wave);
+            }
+        }
+    };
+    if (ks_per_wave >= 2 * NB * CH) {
+        // long ranges (StarVector-8B: 36 .. 48 k-steps per wave): a branch-free steady state, so that the MFMAs of chunk b wait for
+        // chunk b only (s_waitcnt vmcnt(8): the other chunk's loads stay in flight) -- same k order, same results
+#pragma unroll
+        for (int b = 0; b < NB; ++b) sk_load_full<CH>(ck[b], wptr, xptr, b * CH);
+        late();
+        int ks = 0;
+        for (; ks + 2 * NB * CH <= ks_per_wave; ks += NB * CH) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
                     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(ck[b].w[u]), as_frag4(ck[b].x[u]), acc, 0, 0, 0);
                     if constexpr (FOLD) fold_acc(ck[b].x[u]);
                 }
-            if (ks + (b + NB) * CH < ks_per_wave) sk_load<CH>(ck[b], wptr, xptr, ks + (b + NB) * CH, ks_per_wave);
+                __builtin_amdgcn_sched_barrier(0);          // keep "compute chunk b, refill chunk b" in this order: the scheduler
+                sk_load_full<CH>(ck[b], wptr, xptr, ks + (b + NB) * CH);     // otherwise hoists the other chunk's MFMAs above the refill
+                __builtin_amdgcn_sched_barrier(0);          // and the wave drains to 2 outstanding loads every iteration
+            }
         }
+        guarded(ks);
+    } else {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            if (b * CH < ks_per_wave) sk_load<CH>(ck[b], wptr, xptr, b * CH, ks_per_wave);
+        late();
+        guarded(0);
     }
 
     // ---- K reduction across the waves of the block (wave order), every wave finishes RPW accumulator rows ----
@@ -1250,18 +1303,20 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_fp8_kernel(const uint8
     constexpr int RPW = 16 / WAVES;                       // WAVES in {2, 4, 8}
     struct Chunk { u32x4 w[CH / 2]; u32x4 x[CH]; };
     Chunk ca, cb;
-    auto load = [&](Chunk& c, int ks) {
+    auto load = [&](Chunk& c, int ks, auto full) {         // FULL: no guards (exact wait counts in the steady state, see sk_load_full)
+        constexpr bool FULL = decltype(full)::value;
 #pragma unroll
         for (int u2 = 0; u2 < CH / 2; ++u2)
-            if (ks + 2 * u2 < ks_per_wave) c.w[u2] = __builtin_nontemporal_load(wq + (size_t)((ks >> 1) + u2) * 64);
+            if (FULL || ks + 2 * u2 < ks_per_wave) c.w[u2] = __builtin_nontemporal_load(wq + (size_t)((ks >> 1) + u2) * 64);
 #pragma unroll
         for (int u = 0; u < CH; ++u)
-            if (ks + u < ks_per_wave) c.x[u] = xptr[(size_t)(ks + u) * 64];
+            if (FULL || ks + u < ks_per_wave) c.x[u] = xptr[(size_t)(ks + u) * 64];
     };
-    auto compute = [&](Chunk& c, int ks) {
+    auto compute = [&](Chunk& c, int ks, auto full) {
+        constexpr bool FULL = decltype(full)::value;
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            if (ks + u < ks_per_wave) {
+            if (FULL || ks + u < ks_per_wave) {
                 const uint32_t lo = c.w[u >> 1][(u & 1) * 2], hi = c.w[u >> 1][(u & 1) * 2 + 1];
                 const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
                 const f32x2 a2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
@@ -1274,20 +1329,47 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_fp8_kernel(const uint8
             }
         }
     };
-    load(ca, 0);
-    if (CH < ks_per_wave) load(cb, CH);
-    // scales and bias need the argument block (a scalar load): requested after the stream is in flight
-    const SkinnyArgs p = sv_late_args<SkinnyArgs>(offsetof(SkinnyKernarg, p));
+    SkinnyArgs p;
     float4 sc4[4];
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) sc4[rg] = *reinterpret_cast<const float4*>(p.wscale + nt * 32 + rg * 8 + half * 4);
     float bias_d[RPW];
-    sk_bias<RPW>(p, bias_d, wave * RPW, nt, half);
-    for (int ks = 0; ks < ks_per_wave; ks += 2 * CH) {
-        compute(ca, ks);
-        if (ks + 2 * CH < ks_per_wave) load(ca, ks + 2 * CH);
-        if (ks + CH < ks_per_wave) compute(cb, ks + CH);
-        if (ks + 3 * CH < ks_per_wave) load(cb, ks + 3 * CH);
+    auto late = [&]() {     // scales and bias need the argument block (a scalar load): requested after the stream is in flight
+        p = sv_late_args<SkinnyArgs>(offsetof(SkinnyKernarg, p));
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) sc4[rg] = *reinterpret_cast<const float4*>(p.wscale + nt * 32 + rg * 8 + half * 4);
+        sk_bias<RPW>(p, bias_d, wave * RPW, nt, half);
+        sk_settle<RPW>(bias_d);
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) asm volatile("" : "+v"(sc4[rg].x), "+v"(sc4[rg].y), "+v"(sc4[rg].z), "+v"(sc4[rg].w));
+    };
+    auto guarded = [&](int ks) {
+        for (; ks < ks_per_wave; ks += 2 * CH) {
+            compute(ca, ks, std::false_type{});
+            if (ks + 2 * CH < ks_per_wave) load(ca, ks + 2 * CH, std::false_type{});
+            if (ks + CH < ks_per_wave) compute(cb, ks + CH, std::false_type{});
+            if (ks + 3 * CH < ks_per_wave) load(cb, ks + 3 * CH, std::false_type{});
+        }
+    };
+    if (ks_per_wave >= 4 * CH) {                            // long ranges: branch-free steady state
+        load(ca, 0, std::true_type{});
+        load(cb, CH, std::true_type{});
+        late();
+        int ks = 0;
+        for (; ks + 4 * CH <= ks_per_wave; ks += 2 * CH) {
+            compute(ca, ks, std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            load(ca, ks + 2 * CH, std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            compute(cb, ks + CH, std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);
+            load(cb, ks + 3 * CH, std::true_type{});
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        guarded(ks);
+    } else {
+        load(ca, 0, std::false_type{});
+        if (CH < ks_per_wave) load(cb, CH, std::false_type{});
+        late();
+        guarded(0);
     }
     // per-column scale (accumulator row r <-> column 8 (r >> 2) + 4 half + (r & 3)), then the K reduction across waves
 #pragma unroll
@@ -1354,110 +1436,184 @@ static bool launch_gemm_skinny_fp8(const SkinnyArgs& a, hipStream_t st) {
 // Scope = what the slab pipeline launches: fp32 slabs, packed activations with bias + activation, fp32 logits; bf16 or
 // fp8 (e4m3, widened in registers, per-column scale on the accumulator) weights.  NBUF register chunks of CH k-steps ring.
 // ------------------------------------------------------------------------------------------------
-template <int WAVES, bool FP8>
-__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(const void* W_, const bf16_t* xp_, int KS_, int ks_per_split_, int flags_, SkinnyArgs p_unused) {
+// NT = column tiles per block (1 or 2).  Every block of a launch re-reads the SAME activation fragments out of L2 -- at 64 rows
+// that is 2 (bf16 weights) or 4 (fp8) bytes per weight byte, and the L2 -> CU side, not HBM, bounds the launch
+// (tools/diag/mem_mix.hip, profiles/mem_mix_r03.log: the same traffic without MFMA streams weights at 6.3 / 5.0 / 3.7 TB/s with
+// 1 / 2 / 4 shared-operand bytes per weight byte).  NT = 2: a wave feeds the activation fragments it has loaded to the
+// weight fragments of TWO adjacent column tiles -> half the re-reads per weight byte; per-column arithmetic unchanged (same k
+// ranges per wave, same reduction order), so the results stay bit-identical to NT = 1 and to the one-tile kernels.
+template <int WAVES, bool FP8, int NT>
+__global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(const void* W_, const bf16_t* xp_, int KS_, int ks_per_split_, int n_tiles_, SkinnyArgs p_unused) {
     constexpr int CH = 4;
-    constexpr int NBUF = FP8 ? 3 : 2;
-    constexpr int WCH = FP8 ? CH / 2 : CH;                 // 16-byte weight loads per chunk and lane
+    constexpr int NBUF = (FP8 && NT == 1) ? 3 : 2;
+    constexpr int WCH = FP8 ? CH / 2 : CH;                 // 16-byte weight loads per chunk, lane and column tile
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     float (*red)[WAVES][16][64] = reinterpret_cast<float (*)[WAVES][16][64]>(sk_smem);          // [2][WAVES][16][64]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nt = blockIdx.x, split = blockIdx.y, mt0 = blockIdx.z * 2;
+    const int nt0 = blockIdx.x * NT, split = blockIdx.y, mt0 = blockIdx.z * 2;
     const int KS = KS_;                                    // k-steps of the whole K and of this block's split (host-computed:
     const int ks_per_split = ks_per_split_;                //  no integer division in front of the first load)
     const int ks_per_wave = ks_per_split / WAVES;          // fp8: even (launcher)
     const int ks0 = split * ks_per_split + wave * ks_per_wave;
     const int m = lane & 31, half = lane >> 5;
 
-    const u32x4* wptr = FP8 ? reinterpret_cast<const u32x4*>(W_) + ((size_t)nt * (KS >> 1) + (ks0 >> 1)) * 64 + lane
-                            : reinterpret_cast<const u32x4*>(W_) + ((size_t)nt * KS + ks0) * 64 + lane;
+    const u32x4* wptr[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        int nt = nt0 + j;
+        nt = nt < n_tiles_ ? nt : n_tiles_ - 1;             // odd tile count: the last block streams its only tile twice, stores it once
+        wptr[j] = FP8 ? reinterpret_cast<const u32x4*>(W_) + ((size_t)nt * (KS >> 1) + (ks0 >> 1)) * 64 + lane
+                      : reinterpret_cast<const u32x4*>(W_) + ((size_t)nt * KS + ks0) * 64 + lane;
+    }
     const u32x4* xptr0 = reinterpret_cast<const u32x4*>(xp_) + ((size_t)mt0 * KS + ks0) * 64 + lane;
     const u32x4* xptr1 = xptr0 + (size_t)KS * 64;
 
-    f32x16 acc0, acc1;
+    f32x16 acc[NT][2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[j][0][r] = 0.f; acc[j][1][r] = 0.f; }
 
     constexpr int RPW = 16 / WAVES;                       // WAVES in {4, 8}
-    struct Chunk { u32x4 w[WCH]; u32x4 x0[CH]; u32x4 x1[CH]; };
+    struct Chunk { u32x4 w[NT][WCH]; u32x4 x0[CH]; u32x4 x1[CH]; };
     Chunk c[NBUF];
-    auto load = [&](Chunk& k, int ks) {                    // ks multiple of CH; the last chunk of a wave may be ragged
+    // FULL = the chunk lies inside the wave's range: no guards, i.e. no branches around the loads -> exact s_waitcnt counts in the
+    // steady-state loop (see sk_load_full)
+    auto load = [&](Chunk& k, int ks, auto full) {         // ks multiple of CH; the last chunk of a wave may be ragged
+        constexpr bool FULL = decltype(full)::value;
 #pragma unroll
-        for (int u = 0; u < WCH; ++u)
-            if (ks + (FP8 ? 2 * u : u) < ks_per_wave)       // wave-uniform
-                k.w[u] = __builtin_nontemporal_load(wptr + (size_t)(FP8 ? (ks >> 1) + u : ks + u) * 64);
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int u = 0; u < WCH; ++u)
+                if (FULL || ks + (FP8 ? 2 * u : u) < ks_per_wave)       // wave-uniform
+                    k.w[j][u] = __builtin_nontemporal_load(wptr[j] + (size_t)(FP8 ? (ks >> 1) + u : ks + u) * 64);
 #pragma unroll
         for (int u = 0; u < CH; ++u)
-            if (ks + u < ks_per_wave) {
+            if (FULL || ks + u < ks_per_wave) {
                 k.x0[u] = xptr0[(size_t)(ks + u) * 64];
                 k.x1[u] = xptr1[(size_t)(ks + u) * 64];
             }
     };
-    auto compute = [&](Chunk& k, int ks) {
+    auto compute = [&](Chunk& k, int ks, auto full) {
+        constexpr bool FULL = decltype(full)::value;
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            if (ks + u >= ks_per_wave) continue;            // wave-uniform
-            u32x4 wf;
-            if constexpr (FP8) {
-                const uint32_t lo = k.w[u >> 1][(u & 1) * 2], hi = k.w[u >> 1][(u & 1) * 2 + 1];
-                const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
-                const f32x2 a2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
-                wf[0] = (__float_as_uint(a0[0]) >> 16) | (__float_as_uint(a0[1]) & 0xffff0000u);
-                wf[1] = (__float_as_uint(a1[0]) >> 16) | (__float_as_uint(a1[1]) & 0xffff0000u);
-                wf[2] = (__float_as_uint(a2[0]) >> 16) | (__float_as_uint(a2[1]) & 0xffff0000u);
-                wf[3] = (__float_as_uint(a3[0]) >> 16) | (__float_as_uint(a3[1]) & 0xffff0000u);
-            } else {
-                wf = k.w[u];
+            if (!FULL && ks + u >= ks_per_wave) continue;   // wave-uniform
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                u32x4 wf;
+                if constexpr (FP8) {
+                    const uint32_t lo = k.w[j][u >> 1][(u & 1) * 2], hi = k.w[j][u >> 1][(u & 1) * 2 + 1];
+                    const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
+                    const f32x2 a2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
+                    wf[0] = (__float_as_uint(a0[0]) >> 16) | (__float_as_uint(a0[1]) & 0xffff0000u);
+                    wf[1] = (__float_as_uint(a1[0]) >> 16) | (__float_as_uint(a1[1]) & 0xffff0000u);
+                    wf[2] = (__float_as_uint(a2[0]) >> 16) | (__float_as_uint(a2[1]) & 0xffff0000u);
+                    wf[3] = (__float_as_uint(a3[0]) >> 16) | (__float_as_uint(a3[1]) & 0xffff0000u);
+                } else {
+                    wf = k.w[j][u];
+                }
+                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wf), as_frag4(k.x0[u]), acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wf), as_frag4(k.x1[u]), acc[j][1], 0, 0, 0);
             }
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wf), as_frag4(k.x0[u]), acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wf), as_frag4(k.x1[u]), acc1, 0, 0, 0);
         }
     };
+    SkinnyArgs p;
+    float bias_d[NT][RPW];
+    float4 sc4[NT][4];
+    auto late = [&]() {                                     // the stream is in flight: now the rest of the arguments, bias, scales
+        p = sv_late_args<SkinnyArgs>(offsetof(SkinnyKernarg, p));
 #pragma unroll
-    for (int b = 0; b < NBUF; ++b)
-        if (b * CH < ks_per_wave) load(c[b], b * CH);
-    const SkinnyArgs p = sv_late_args<SkinnyArgs>(offsetof(SkinnyKernarg, p));       // the stream is in flight: now the rest
-    float bias_d[RPW];
-    sk_bias<RPW>(p, bias_d, wave * RPW, nt, half);
-    for (int ks = 0; ks < ks_per_wave; ks += NBUF * CH) {
+        for (int j = 0; j < NT; ++j) {
+            const int nt = nt0 + j < n_tiles_ ? nt0 + j : n_tiles_ - 1;
+            sk_bias<RPW>(p, bias_d[j], wave * RPW, nt, half);
+            sk_settle<RPW>(bias_d[j]);
+            if constexpr (FP8) {
+                // per-column scale (accumulator row r <-> column 8 (r >> 2) + 4 half + (r & 3))
 #pragma unroll
-        for (int b = 0; b < NBUF; ++b) {
-            if (ks + b * CH < ks_per_wave) compute(c[b], ks + b * CH);
-            if (ks + (b + NBUF) * CH < ks_per_wave) load(c[b], ks + (b + NBUF) * CH);
+                for (int rg = 0; rg < 4; ++rg) {
+                    sc4[j][rg] = *reinterpret_cast<const float4*>(p.wscale + nt * 32 + rg * 8 + half * 4);
+                    asm volatile("" : "+v"(sc4[j][rg].x), "+v"(sc4[j][rg].y), "+v"(sc4[j][rg].z), "+v"(sc4[j][rg].w));
+                }
+            }
         }
+    };
+    auto guarded = [&](int ks) {
+        for (; ks < ks_per_wave; ks += NBUF * CH) {
+#pragma unroll
+            for (int b = 0; b < NBUF; ++b) {
+                if (ks + b * CH < ks_per_wave) compute(c[b], ks + b * CH, std::false_type{});
+                if (ks + (b + NBUF) * CH < ks_per_wave) load(c[b], ks + (b + NBUF) * CH, std::false_type{});
+            }
+        }
+    };
+    if (ks_per_wave >= 2 * NBUF * CH) {
+        // long ranges: branch-free steady state (chunk b's MFMAs wait for chunk b only; the other chunks' loads stay in flight)
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b) load(c[b], b * CH, std::true_type{});
+        late();
+        int ks = 0;
+        for (; ks + 2 * NBUF * CH <= ks_per_wave; ks += NBUF * CH) {
+#pragma unroll
+            for (int b = 0; b < NBUF; ++b) {
+                compute(c[b], ks + b * CH, std::true_type{});
+                __builtin_amdgcn_sched_barrier(0);
+                load(c[b], ks + (b + NBUF) * CH, std::true_type{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        guarded(ks);
+    } else {
+#pragma unroll
+        for (int b = 0; b < NBUF; ++b)
+            if (b * CH < ks_per_wave) load(c[b], b * CH, std::false_type{});
+        late();
+        guarded(0);
     }
-    if constexpr (FP8) {
-        // per-column scale (accumulator row r <-> column 8 (r >> 2) + 4 half + (r & 3)) before the reduction, as the one-tile kernel
 #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const float4 sc = *reinterpret_cast<const float4*>(p.wscale + nt * 32 + rg * 8 + half * 4);
-            acc0[rg * 4 + 0] *= sc.x; acc0[rg * 4 + 1] *= sc.y; acc0[rg * 4 + 2] *= sc.z; acc0[rg * 4 + 3] *= sc.w;
-            acc1[rg * 4 + 0] *= sc.x; acc1[rg * 4 + 1] *= sc.y; acc1[rg * 4 + 2] *= sc.z; acc1[rg * 4 + 3] *= sc.w;
+    for (int j = 0; j < NT; ++j) {
+        if constexpr (FP8) {
+            // per-column scale before the reduction, as the one-tile kernel
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float4 sc = sc4[j][rg];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    acc[j][mi][rg * 4 + 0] *= sc.x; acc[j][mi][rg * 4 + 1] *= sc.y; acc[j][mi][rg * 4 + 2] *= sc.z; acc[j][mi][rg * 4 + 3] *= sc.w;
+                }
+            }
         }
-    }
+        if (j > 0) __syncthreads();                        // the previous tile's reduction has been read
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { red[0][wave][r][lane] = acc0[r]; red[1][wave][r][lane] = acc1[r]; }
-    __syncthreads();
+        for (int r = 0; r < 16; ++r) { red[0][wave][r][lane] = acc[j][0][r]; red[1][wave][r][lane] = acc[j][1][r]; }
+        __syncthreads();
+        if (nt0 + j < n_tiles_) {                           // block-uniform
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        float v[RPW];
+            for (int mi = 0; mi < 2; ++mi) {
+                float v[RPW];
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int r = wave * RPW + i;
-            float t = red[mi][0][r][lane];
+                for (int i = 0; i < RPW; ++i) {
+                    const int r = wave * RPW + i;
+                    float t = red[mi][0][r][lane];
 #pragma unroll
-            for (int w = 1; w < WAVES; ++w) t += red[mi][w][r][lane];
-            v[i] = t;
+                    for (int w = 1; w < WAVES; ++w) t += red[mi][w][r][lane];
+                    v[i] = t;
+                }
+                sk_store<RPW>(p, v, bias_d[j], wave * RPW, nt0 + j, mt0 + mi, split, m, half);
+            }
         }
-        sk_store<RPW>(p, v, bias_d, wave * RPW, nt, mt0 + mi, split, m, half);
     }
 }
 
 static int init_mt2_attrs() {
-    int r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 16 * 64 * 4);
-    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 16 * 64 * 4);
+    int r = 0;
+    auto set = [&](const void* f, int bytes) { if (!r) r = (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
+    set(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, true, 1>), 2 * 8 * 16 * 64 * 4);
+    set(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, false, 1>), 2 * 8 * 16 * 64 * 4);
+    set(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, true, 2>), 2 * 8 * 16 * 64 * 4);
+    set(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, false, 2>), 2 * 8 * 16 * 64 * 4);
     return r;
 }
 // two-row-tile launch: false when the shape / mode is outside the kernel's scope (the caller falls back to one tile per block)
@@ -1466,18 +1622,29 @@ static bool launch_gemm_skinny_mt2(const SkinnyArgs& a, hipStream_t st) {
     if (!(a.out_mode == SK_OUT_PARTIAL || ((a.out_mode == SK_OUT_PACKED_ACT || a.out_mode == SK_OUT_F32) && a.splitk == 1)))
         return false;
     if (a.Wq && !a.wscale) return false;
-    const dim3 grid(a.Npad / 32, a.splitk, a.MT / 2);
     if ((a.K / 16) % a.splitk) return false;
+    const int n_tiles = a.Npad / 32, KS = a.K / 16, per = KS / a.splitk;
     // the SAME number of waves (= the same per-wave k ranges and reduction order) as the one-tile kernel of this GEMM
-    const int waves = a.Wq ? skinny_waves_fp8(a.K / 16, a.splitk) : skinny_waves(a.Npad, a.K / 16, a.splitk);
+    const int waves = a.Wq ? skinny_waves_fp8(KS, a.splitk) : skinny_waves(a.Npad, KS, a.splitk);
+    const void* W = a.Wq ? (const void*)a.Wq : (const void*)a.Wp;
     if (waves == 8) {
-        if (a.Wq) gemm_skinny_mt2_kernel<8, true><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(a.Wq, a.xp, a.K / 16, (a.K / 16) / a.splitk, a.xcd_remap, a);
-        else gemm_skinny_mt2_kernel<8, false><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(a.Wp, a.xp, a.K / 16, (a.K / 16) / a.splitk, a.xcd_remap, a);
+        // the engine picks (column tiles, split-K) together (engine.hip, pick_decode_plan); on its own (col_tiles = 0: the op-level
+        // entry points) the launcher takes two column tiles when half the blocks still cover the chip
+        if (a.col_tiles == 2 || (a.col_tiles == 0 && n_tiles * a.splitk >= 512)) {
+            const dim3 grid((n_tiles + 1) / 2, a.splitk, a.MT / 2);
+            if (a.Wq) gemm_skinny_mt2_kernel<8, true, 2><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(W, a.xp, KS, per, n_tiles, a);
+            else gemm_skinny_mt2_kernel<8, false, 2><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(W, a.xp, KS, per, n_tiles, a);
+            return true;
+        }
+        const dim3 grid(n_tiles, a.splitk, a.MT / 2);
+        if (a.Wq) gemm_skinny_mt2_kernel<8, true, 1><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(W, a.xp, KS, per, n_tiles, a);
+        else gemm_skinny_mt2_kernel<8, false, 1><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(W, a.xp, KS, per, n_tiles, a);
         return true;
     }
     if (waves == 4) {
-        if (a.Wq) gemm_skinny_mt2_kernel<4, true><<<grid, 256, 2 * 4 * 16 * 64 * 4, st>>>(a.Wq, a.xp, a.K / 16, (a.K / 16) / a.splitk, a.xcd_remap, a);
-        else gemm_skinny_mt2_kernel<4, false><<<grid, 256, 2 * 4 * 16 * 64 * 4, st>>>(a.Wp, a.xp, a.K / 16, (a.K / 16) / a.splitk, a.xcd_remap, a);
+        const dim3 grid(n_tiles, a.splitk, a.MT / 2);
+        if (a.Wq) gemm_skinny_mt2_kernel<4, true, 1><<<grid, 256, 2 * 4 * 16 * 64 * 4, st>>>(W, a.xp, KS, per, n_tiles, a);
+        else gemm_skinny_mt2_kernel<4, false, 1><<<grid, 256, 2 * 4 * 16 * 64 * 4, st>>>(W, a.xp, KS, per, n_tiles, a);
         return true;
     }
     return false;       // 16-wave (narrow outputs) and 1/2-wave (tiny K) shapes keep one row tile per block

@@ -10,6 +10,7 @@
 #     smoke       __graft_entry__.smoke()
 #     ctx         tools/ctx_sweep.py                                -> ctx_sweep.log
 #     skinny      tools/bench_skinny.py                             -> bench_skinny.log
+#     memmix      tools/diag/mem_mix.hip: weight stream + shared-operand re-reads without MFMA (what bounds the decode GEMMs) -> mem_mix.log
 #     xcd         tools/diag/xcd_map.hip: block -> XCD placement inside a replayed graph  -> xcd_map.log
 #     ab:<args>   tools/ab_exp.py <args> (in-process A/B of SV_EXP masks)           -> ab_exp.log
 #     rebuild:<K=V>  rebuild the library on the box with K=V in the environment (build-flag A/B, e.g. SV_NO_KERNARG_PRELOAD=1)
@@ -61,6 +62,7 @@ for s in "${STEPS[@]}"; do
       python tools/trace_by_grid.py "$OUT/rocprof_$name" "$OUT/rocprof_${name}_by_grid.csv" > /dev/null 2>&1 || true
       find "$OUT/rocprof_$name" -name '*kernel_trace.csv' -size +8M -delete 2>/dev/null
       head -14 "$OUT/rocprof_${name}_by_grid.csv" | cut -c1-150 ;;
+    memmix) hipcc --offload-arch=gfx950 -O3 -o /tmp/mem_mix tools/diag/mem_mix.hip 2>/dev/null && timeout 120 /tmp/mem_mix 2>&1 | tee "$OUT/mem_mix.log" | tail -30 ;;
     xcd) hipcc --offload-arch=gfx950 -O2 -o /tmp/xcd_map tools/diag/xcd_map.hip 2>/dev/null && /tmp/xcd_map 2>&1 | tee "$OUT/xcd_map.log" | tail -8 ;;
     ab:*) timeout 600 python tools/ab_exp.py ${s#ab:} 2>&1 | grep -v amdgpu.ids | tee -a "$OUT/ab_exp.log" ;;
     *) echo "unknown step $s" ;;
