@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SV_ABI_VERSION 5
+#define SV_ABI_VERSION 6
 #define SV_WEIGHT_BF16 0
 #define SV_WEIGHT_FP8_E4M3 1
 
@@ -207,6 +207,11 @@ int  sv_debug_skinny_plan(int32_t rows, int32_t N, int32_t K, int32_t splitk, in
  *                             in-process A/B runs of the round's experiments (tools/ab_exp.py) */
 int  sv_debug_set_exp(sv_engine* e, int32_t mask);
 int  sv_debug_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t act, int32_t* out5);
+/*   sv_debug_set_col_tiles    column tiles per block (1..3; 0 = the launcher's own choice) the OP-LEVEL decode GEMM entry points
+ *                             (sv_op_linear_skinny*, 33..64 rows) launch with from now on, process-wide: lets the parity tests put
+ *                             every variant of the two-row-tile kernel next to the one-tile kernels (all bit-identical).  An engine's
+ *                             decode loop is not affected (it carries its own plan per Linear). */
+int  sv_debug_set_col_tiles(int32_t col_tiles);
 
 /* Prompt pass over inputs_embeds [B,S0,hidden] bf16 (all-ones attention mask): fills the paged KV
  * cache and writes the last-row logits [B, vocab] fp32 (bf16-rounded values, as the reference's

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libstarvector_hip.so")
 HEADER_PATH = os.path.normpath(os.path.join(HERE, "..", "include", "starvector_hip.h"))
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 SV_DTYPE_BF16, SV_DTYPE_F32 = 0, 1
 SV_NORM_LAYER, SV_NORM_BATCH = 0, 1
 SV_ARCH_V1, SV_ARCH_V2 = 0, 1
@@ -106,6 +106,7 @@ PROTOTYPES = {
     "sv_beam_history": (_I, [_P, C.POINTER(_I), C.POINTER(_I), _I, C.POINTER(_I), C.POINTER(_I)]),
     "sv_last_timing": (_I, [_P, C.POINTER(C.c_double)]),
     "sv_debug_set_exp": (_I, [_P, _I]),
+    "sv_debug_set_col_tiles": (_I, [_I]),
     "sv_profile_decode_step": (_I, [_P, _I, _I, C.POINTER(C.c_double), _P]),
     "sv_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "sv_op_linear": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

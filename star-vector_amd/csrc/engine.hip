@@ -319,8 +319,8 @@ static int pick_splitk(int n_tiles, int KS, int num_cus, bool fp8, bool legacy) 
 }
 
 // 33..64 rows (two row tiles per block): at that height every block re-reads 2 (bf16) / 4 (fp8) activation bytes per weight byte out
-// of L2 and the L2 -> CU side bounds the launch (tools/diag/mem_mix.hip), so a block may carry TWO column tiles per loaded activation
-// fragment.  (column tiles per block, split-K) are picked together: modelled time = the busiest CU's bytes (weights + activations
+// of L2 and the L2 -> CU side bounds the launch (tools/diag/mem_mix.hip), so a block may carry two or three column tiles per loaded
+// activation fragment.  (column tiles per block, split-K) are picked together: modelled time = the busiest CU's bytes (weights + activations
 // over its blocks) relative to an even spread, plus the slab cost.  Only shapes the two-row-tile kernel takes are candidates.
 static void pick_decode_plan(const Linear& l, int MT, int num_cus, bool fp8, bool legacy, bool whole_k, int* splitk, int* col_tiles) {
     const int tiles = l.Npad / 32, KS = l.Kpad / 16;
@@ -333,14 +333,14 @@ static void pick_decode_plan(const Linear& l, int MT, int num_cus, bool fp8, boo
     const double ideal = (double)tiles * KS * (wb + ab) / num_cus;
     double best_cost = 1e30;
     int best_s = 0, best_nt = 1;
-    for (int nt = 1; nt <= 2; ++nt)
+    for (int nt = 1; nt <= 3; ++nt)
         for (int s = 1; s <= (whole_k ? 1 : 8); ++s) {
             if (KS % s) continue;
             const int per = KS / s;
             if (s > 1 && per < 16) continue;
             int waves = 0, two = 0;
             skinny_plan(l.Npad, l.Kpad, s, fp8 ? 1 : 0, MT, &waves, &two);
-            if (!two || (nt == 2 && waves != 8)) continue;
+            if (!two || (nt >= 2 && waves != 8)) continue;
             const long nb = (long)((tiles + nt - 1) / nt) * s;
             const long rounds = (nb + num_cus - 1) / num_cus;
             const double cost = (double)rounds * per * (nt * wb + ab) / ideal + 0.015 * s;
@@ -1751,6 +1751,12 @@ extern "C" int sv_debug_skinny_plan(int32_t rows, int32_t N, int32_t K, int32_t 
     int waves = 0, two = 0;
     skinny_plan(round_up(N, 32), K, splitk, fp8, (rows + 31) / 32, &waves, &two);
     out2[0] = waves; out2[1] = two;
+    return 0;
+}
+
+extern "C" int sv_debug_set_col_tiles(int32_t col_tiles) {
+    if (col_tiles < 0 || col_tiles > 3) return fail(SV_EINVAL, "sv_debug_set_col_tiles: 0..3");
+    g_op_col_tiles = col_tiles;
     return 0;
 }
 

@@ -1436,7 +1436,7 @@ static bool launch_gemm_skinny_fp8(const SkinnyArgs& a, hipStream_t st) {
 // Scope = what the slab pipeline launches: fp32 slabs, packed activations with bias + activation, fp32 logits; bf16 or
 // fp8 (e4m3, widened in registers, per-column scale on the accumulator) weights.  NBUF register chunks of CH k-steps ring.
 // ------------------------------------------------------------------------------------------------
-// NT = column tiles per block (1 or 2).  Every block of a launch re-reads the SAME activation fragments out of L2 -- at 64 rows
+// NT = column tiles per block (1, 2 or 3).  Every block of a launch re-reads the SAME activation fragments out of L2 -- at 64 rows
 // that is 2 (bf16 weights) or 4 (fp8) bytes per weight byte, and the L2 -> CU side, not HBM, bounds the launch
 // (tools/diag/mem_mix.hip, profiles/mem_mix_r03.log: the same traffic without MFMA streams weights at 6.3 / 5.0 / 3.7 TB/s with
 // 1 / 2 / 4 shared-operand bytes per weight byte).  NT = 2: a wave feeds the activation fragments it has loaded to the
@@ -1444,7 +1444,7 @@ static bool launch_gemm_skinny_fp8(const SkinnyArgs& a, hipStream_t st) {
 // ranges per wave, same reduction order), so the results stay bit-identical to NT = 1 and to the one-tile kernels.
 template <int WAVES, bool FP8, int NT>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(const void* W_, const bf16_t* xp_, int KS_, int ks_per_split_, int n_tiles_, SkinnyArgs p_unused) {
-    constexpr int CH = 4;
+    constexpr int CH = NT >= 3 ? 2 : 4;                    // k-steps per register chunk (three column tiles: 2, to stay under 256 VGPRs)
     constexpr int NBUF = (FP8 && NT == 1) ? 3 : 2;
     constexpr int WCH = FP8 ? CH / 2 : CH;                 // 16-byte weight loads per chunk, lane and column tile
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
@@ -1607,6 +1607,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(const void*
     }
 }
 
+int g_op_col_tiles = 0;
 static int init_mt2_attrs() {
     int r = 0;
     auto set = [&](const void* f, int bytes) { if (!r) r = (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
@@ -1614,6 +1615,8 @@ static int init_mt2_attrs() {
     set(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, false, 1>), 2 * 8 * 16 * 64 * 4);
     set(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, true, 2>), 2 * 8 * 16 * 64 * 4);
     set(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, false, 2>), 2 * 8 * 16 * 64 * 4);
+    set(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, true, 3>), 2 * 8 * 16 * 64 * 4);
+    set(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, false, 3>), 2 * 8 * 16 * 64 * 4);
     return r;
 }
 // two-row-tile launch: false when the shape / mode is outside the kernel's scope (the caller falls back to one tile per block)
@@ -1630,7 +1633,14 @@ static bool launch_gemm_skinny_mt2(const SkinnyArgs& a, hipStream_t st) {
     if (waves == 8) {
         // the engine picks (column tiles, split-K) together (engine.hip, pick_decode_plan); on its own (col_tiles = 0: the op-level
         // entry points) the launcher takes two column tiles when half the blocks still cover the chip
-        if (a.col_tiles == 2 || (a.col_tiles == 0 && n_tiles * a.splitk >= 512)) {
+        const int ct = a.col_tiles ? a.col_tiles : g_op_col_tiles;
+        if (ct == 3) {
+            const dim3 grid((n_tiles + 2) / 3, a.splitk, a.MT / 2);
+            if (a.Wq) gemm_skinny_mt2_kernel<8, true, 3><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(W, a.xp, KS, per, n_tiles, a);
+            else gemm_skinny_mt2_kernel<8, false, 3><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(W, a.xp, KS, per, n_tiles, a);
+            return true;
+        }
+        if (ct == 2 || (ct == 0 && n_tiles * a.splitk >= 512)) {
             const dim3 grid((n_tiles + 1) / 2, a.splitk, a.MT / 2);
             if (a.Wq) gemm_skinny_mt2_kernel<8, true, 2><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(W, a.xp, KS, per, n_tiles, a);
             else gemm_skinny_mt2_kernel<8, false, 2><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(W, a.xp, KS, per, n_tiles, a);

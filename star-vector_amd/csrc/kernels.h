@@ -53,7 +53,7 @@ struct SkinnyArgs {
     bf16_t* out_xp; int out_KS;      // PACKED_ACT: fragment-order buffer with out_KS = Npad/16 k-steps
     float* out_f32; int ldo;         // F32: [MT*32][ldo]; rounded to bf16 values if round_bf16
     int round_bf16;
-    int col_tiles;                   // two-row-tile kernel (33..64 rows): column tiles per block, 1 or 2; 0 = the launcher's default
+    int col_tiles;                   // two-row-tile kernel (33..64 rows): column tiles per block, 1..3; 0 = the launcher's default
     int xcd_remap;                   // 1: XCD-aware (tile, K slice) assignment of a split-K launch (needs splitk | 8, (Npad/32 * splitk) % 8 == 0)
     // LayerNorm fold (decode_cols.hip; split-K 1): xp is the RAW residual stream, Wp the folded image W' = bf16(W * gamma);
     // epilogue x = rstd[m] * (acc - mean[m] * c1[n]) + c2[n], the row statistics accumulated from the activation stream in the kernel
@@ -64,6 +64,7 @@ void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st);
 // host arithmetic of the launch: waves per block (how K is cut inside a block = the summation order of a row) and whether a
 // block carries two row tiles; a function of the GEMM only for the former (sv_debug_skinny_plan, CPU tests)
 void skinny_plan(int Npad, int K, int splitk, int fp8, int MT, int* waves, int* two_row_tiles);
+extern int g_op_col_tiles;       // sv_debug_set_col_tiles: what SkinnyArgs.col_tiles == 0 means (0 = the launcher's default)
 
 int init_gemm_kernels();        // hipFuncSetAttribute for the large-LDS variants (0 = ok)
 

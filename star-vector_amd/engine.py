@@ -411,6 +411,11 @@ def op_linear(x, W, bias=None, residual=None, act="none", out_f32=False):
     return y
 
 
+def set_op_col_tiles(col_tiles: int) -> None:
+    """Column tiles per block (1..3, 0 = default) of the op-level decode GEMMs at 33..64 rows (sv_debug_set_col_tiles)."""
+    check(_lib.load().sv_debug_set_col_tiles(int(col_tiles)))
+
+
 def op_linear_skinny(x, W, bias=None, splitk=1):
     lib = _lib.load()
     x = _need(x, torch.bfloat16, "x"); W = _need(W, torch.bfloat16, "W")

@@ -130,6 +130,15 @@ def test_linear_skinny_two_row_tiles_per_block_is_bitwise_the_one_tile_kernel(M,
     two = E.op_linear_skinny(bf(x), bf(W), bf(b), splitk=sk)
     two8, sc = E.op_linear_skinny_fp8(bf(x), bf(W), bf(b), splitk=sk)
     assert rel_err(two, x @ W.T + b) <= 1e-5
+    # one, two or three column tiles per block (the engine picks per Linear; ragged last block when N / 32 is not a multiple):
+    # the same bits every time
+    try:
+        for ct in (1, 2, 3):
+            E.set_op_col_tiles(ct)
+            assert torch.equal(E.op_linear_skinny(bf(x), bf(W), bf(b), splitk=sk), two), ct
+            assert torch.equal(E.op_linear_skinny_fp8(bf(x), bf(W), bf(b), splitk=sk)[0], two8), ct
+    finally:
+        E.set_op_col_tiles(0)
     # each row tile alone (<= 32 rows: the one-tile-per-block kernel) gives the same bits as inside the two-tile launch: batch
     # composition cannot change a row
     for lo, hi in ((0, 32), (32, M)):
