@@ -984,6 +984,19 @@ void launch_gemm(const GemmArgs& a0, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) { return pack2bf(lo, hi); }   // common.h: v_cvt_pk_bf16_f32
 
+// 8 e4m3 bytes (one lane's share of a k-step) -> the bf16 MFMA operand.  gfx950 converts two fp8 to a packed bf16 pair in ONE
+// instruction (v_cvt_scalef32_pk_bf16_fp8, scale 1.0: exact, every e4m3 value is a bf16 value); round 2 went through float
+// (v_cvt_pk_f32_fp8 + shift / and-or per pair: 12 VALU instructions per k-step against these 4, next to 2 MFMAs of 8 passes).
+typedef __bf16 sv_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u32x4 fp8x8_to_bf16x8(uint32_t lo, uint32_t hi) {
+    const sv_bf16x2 a0 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, false), a1 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(lo, 1.0f, true);
+    const sv_bf16x2 a2 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, false), a3 = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(hi, 1.0f, true);
+    union { sv_bf16x2 b; uint32_t u; } c0, c1, c2, c3;
+    c0.b = a0; c1.b = a1; c2.b = a2; c3.b = a3;
+    u32x4 wf = {c0.u, c1.u, c2.u, c3.u};
+    return wf;
+}
+
 // one chunk of the weight / activation stream held in registers
 template <int CH>
 struct SkChunk {
@@ -1505,13 +1518,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(const void*
             for (int j = 0; j < NT; ++j) {
                 u32x4 wf;
                 if constexpr (FP8) {
-                    const uint32_t lo = k.w[j][u >> 1][(u & 1) * 2], hi = k.w[j][u >> 1][(u & 1) * 2 + 1];
-                    const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
-                    const f32x2 a2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
-                    wf[0] = (__float_as_uint(a0[0]) >> 16) | (__float_as_uint(a0[1]) & 0xffff0000u);
-                    wf[1] = (__float_as_uint(a1[0]) >> 16) | (__float_as_uint(a1[1]) & 0xffff0000u);
-                    wf[2] = (__float_as_uint(a2[0]) >> 16) | (__float_as_uint(a2[1]) & 0xffff0000u);
-                    wf[3] = (__float_as_uint(a3[0]) >> 16) | (__float_as_uint(a3[1]) & 0xffff0000u);
+                    wf = fp8x8_to_bf16x8(k.w[j][u >> 1][(u & 1) * 2], k.w[j][u >> 1][(u & 1) * 2 + 1]);
                 } else {
                     wf = k.w[j][u];
                 }

@@ -74,12 +74,232 @@ void launch_argmax(const float* logits, int ld, int V, int32_t* out, float* pval
     argmax_merge_kernel<<<(B + 63) / 64, 64, 0, st>>>(pval, pidx, out, B);
 }
 
+// ------------------------------------------------------------------------------------------------
+// TopK (k <= 256) -> TopP -> multinomial without the two 32-step bisections of warp.h (each step = a sweep of the row's 48 register
+// values per thread + a block reduction: 126 us per step at V = 49157, 3 % of StarVector-8B's decode step).  Selection instead:
+//   1. one sweep of the row: mx = the maximum, m_t = every thread's own maximum (thread t owns the scores t, t + 1024, ...)
+//   2. T0 = the k-th largest of the 1024 thread maxima: an 8-bit MSB-first radix select (4 passes: LDS histogram of one key per
+//      thread, one wave scans the 256 bins).  The k largest thread maxima are k distinct elements >= T0, so the k-th largest
+//      element of the ROW is >= T0: everything >= T0 is a candidate, and there are ~k of them (not 49157)
+//   3. a second sweep compacts the candidates (key, index) into LDS (block scan of the per-thread counts, thread order = a fixed
+//      order); more than TK_CAP of them, or more than 4 in one thread -> general path
+//   4. exact k-th largest among the n candidates by counting ranks (n^2 / 1024 LDS reads per thread, n ~ 60): kth = the key with
+//      #(greater) < k <= #(greater or equal) -- ties at the k-th value are all kept, like HF's `scores < kth` removal
+//   5. softmax over the survivors; TopP: F(c) = the mass of survivors with p <= p_c, v0 = the smallest p_c with F(c) > 1 - top_p,
+//      keep p >= v0 (the maximum always: min_tokens_to_keep = 1) -- warp.h's rule, evaluated on the ~k survivors
+//   6. one multinomial draw over the kept tokens in INDEX order: the token with the largest index whose exclusive prefix mass is
+//      <= u (the same counter-based uniform as the general path)
+// Deterministic (fixed summation orders).  Returns -1 when the row is outside its scope (no finite score, too many candidates).
+// ------------------------------------------------------------------------------------------------
+#define TK_CAP 2048
+struct TopkSmem {
+    uint32_t key[TK_CAP];
+    int idx[TK_CAP];
+    float p[TK_CAP];
+    int hist[256];
+    int wtot[SP_THREADS / 64];
+    uint32_t sel_key;
+    int sel_need;
+    int pick;
+};
+__device__ __forceinline__ TopkSmem& topk_smem() {
+    __shared__ TopkSmem s;
+    return s;
+}
+
+template <class F>
+__device__ int sample_row_topk(F lg, int V, int k, float top_p, uint64_t seed, uint32_t step, uint32_t rowid, float* red) {
+    TopkSmem& sm = topk_smem();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float mt = -INFINITY;
+    // sweep 1 (strided: thread t owns i = t mod 1024), 8 independent loads per round trip
+    constexpr int UNR = 8;
+    for (int i0 = tid; i0 < V; i0 += UNR * SP_THREADS) {
+        float x[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int i = i0 + u * SP_THREADS;
+            x[u] = lg(i < V ? i : V - 1);                           // (clamped: the duplicate cannot raise the maximum)
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) mt = fmaxf(mt, x[u]);
+    }
+    const float mx = wp_block_max(mt, red);
+    if (!(mx > -INFINITY) || !(mx < INFINITY)) return -1;             // no finite score / NaN / +inf: the general path reports it
+
+    // ---- 2. T0 = k-th largest thread maximum ----
+    const uint32_t mkey = wp_key(mt);
+    uint32_t prefix = 0u;
+    int need = k;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) sm.hist[tid] = 0;
+        __syncthreads();
+        if (pass == 0 || (mkey >> (shift + 8)) == prefix) atomicAdd(&sm.hist[(mkey >> shift) & 255u], 1);
+        __syncthreads();
+        if (tid < 64) {                                              // lane l owns bins 255 - 4l .. 252 - 4l (descending keys)
+            const int b0 = 255 - 4 * tid;
+            const int h0 = sm.hist[b0], h1 = sm.hist[b0 - 1], h2 = sm.hist[b0 - 2], h3 = sm.hist[b0 - 3];
+            const int sum4 = h0 + h1 + h2 + h3;
+            int inc = sum4;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o, 64);
+                if (tid >= o) inc += t;
+            }
+            int above = inc - sum4;                                   // keys in the bins above this lane's four
+            if (above < need && need <= inc) {
+                int d = b0;
+                if (need > above + h0) {
+                    above += h0; d = b0 - 1;
+                    if (need > above + h1) {
+                        above += h1; d = b0 - 2;
+                        if (need > above + h2) { above += h2; d = b0 - 3; }
+                    }
+                }
+                sm.sel_key = (prefix << 8) | (uint32_t)d;
+                sm.sel_need = need - above;
+            }
+        }
+        __syncthreads();
+        prefix = sm.sel_key;
+        need = sm.sel_need;
+    }
+    const uint32_t t0 = prefix;
+
+    // ---- 3. candidates >= T0 into LDS (sweep 2: a thread meets ~0.06 of them; more than TK_PER -> general path) ----
+    constexpr int TK_PER = 4;
+    uint32_t ck[TK_PER];
+    int ci[TK_PER];
+    int cnt = 0;
+    for (int i0 = tid; i0 < V; i0 += UNR * SP_THREADS) {
+        uint32_t x[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int i = i0 + u * SP_THREADS;
+            x[u] = i < V ? wp_key(lg(i)) : 0u;                      // key 0 < every real key (t0 >= the key of a finite score)
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            if (x[u] >= t0) {
+#pragma unroll
+                for (int q = 0; q < TK_PER; ++q)
+                    if (cnt == q) { ck[q] = x[u]; ci[q] = i0 + u * SP_THREADS; }
+                ++cnt;
+            }
+        }
+    }
+    int inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    if (lane == 63) sm.wtot[wave] = inc;
+    if (tid == 0) sm.pick = -1;
+    const float over = wp_block_max(cnt > TK_PER ? 1.f : 0.f, red);  // (syncs inside: wtot / pick are visible after it)
+    int off = inc - cnt, n = 0;
+#pragma unroll
+    for (int w = 0; w < SP_THREADS / 64; ++w) {
+        const int t = sm.wtot[w];
+        off += w < wave ? t : 0;
+        n += t;
+    }
+    if (over > 0.f || n > TK_CAP || n < k) return -1;                 // block-uniform
+#pragma unroll
+    for (int q = 0; q < TK_PER; ++q)
+        if (q < cnt) { sm.key[off + q] = ck[q]; sm.idx[off + q] = ci[q]; }
+    __syncthreads();
+
+    // ---- 4. the exact k-th largest key ----
+    for (int c = tid; c < n; c += SP_THREADS) {
+        const uint32_t kc = sm.key[c];
+        int gt = 0, ge = 0;
+        for (int j = 0; j < n; ++j) {
+            const uint32_t kj = sm.key[j];
+            gt += kj > kc ? 1 : 0;
+            ge += kj >= kc ? 1 : 0;
+        }
+        if (gt < k && k <= ge) sm.sel_key = kc;                       // every writer writes the same key
+    }
+    __syncthreads();
+    const uint32_t kth = sm.sel_key;
+
+    // ---- 5. softmax over the survivors, TopP ----
+    float e[(TK_CAP + SP_THREADS - 1) / SP_THREADS];
+    float zs = 0.f;
+#pragma unroll
+    for (int q = 0; q < (TK_CAP + SP_THREADS - 1) / SP_THREADS; ++q) {
+        const int c = tid + q * SP_THREADS;
+        e[q] = (c < n && sm.key[c] >= kth) ? __expf(wp_unkey(sm.key[c]) - mx) : 0.f;
+        zs += e[q];
+    }
+    const float invZ = 1.0f / wp_block_sum(zs, red);
+#pragma unroll
+    for (int q = 0; q < (TK_CAP + SP_THREADS - 1) / SP_THREADS; ++q) {
+        const int c = tid + q * SP_THREADS;
+        e[q] *= invZ;
+        if (c < n) sm.p[c] = e[q];
+    }
+    __syncthreads();
+    if (top_p < 1.0f) {
+        const float cut = 1.0f - top_p;
+        float v0c = INFINITY;
+#pragma unroll
+        for (int q = 0; q < (TK_CAP + SP_THREADS - 1) / SP_THREADS; ++q) {
+            const int c = tid + q * SP_THREADS;
+            if (c < n && e[q] > 0.f) {
+                float f = 0.f;
+                for (int j = 0; j < n; ++j) { const float pj = sm.p[j]; f += pj <= e[q] ? pj : 0.f; }
+                if (f > cut) v0c = fminf(v0c, e[q]);
+            }
+        }
+        const float v0 = -wp_block_max(-v0c, red);                    // (syncs inside: every F loop has finished)
+#pragma unroll
+        for (int q = 0; q < (TK_CAP + SP_THREADS - 1) / SP_THREADS; ++q) {
+            const int c = tid + q * SP_THREADS;
+            if (c < n) {
+                const bool keep = e[q] > 0.f && (e[q] >= v0 || sm.key[c] == wp_key(mx));
+                e[q] = keep ? e[q] : 0.f;
+                sm.p[c] = e[q];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- 6. multinomial over the kept tokens, index order ----
+    float ts = 0.f;
+#pragma unroll
+    for (int q = 0; q < (TK_CAP + SP_THREADS - 1) / SP_THREADS; ++q) ts += e[q];
+    const float total = wp_block_sum(ts, red);
+    const uint64_t h = wp_splitmix64(seed ^ wp_splitmix64(((uint64_t)step << 32) | rowid));
+    const float u = (float)((h >> 40) * (1.0 / 16777216.0)) * total;
+#pragma unroll
+    for (int q = 0; q < (TK_CAP + SP_THREADS - 1) / SP_THREADS; ++q) {
+        const int c = tid + q * SP_THREADS;
+        if (c < n && e[q] > 0.f) {
+            const int ic = sm.idx[c];
+            float pre = 0.f;
+            for (int j = 0; j < n; ++j) pre += sm.idx[j] < ic ? sm.p[j] : 0.f;
+            if (pre <= u) atomicMax(&sm.pick, ic);
+        }
+    }
+    __syncthreads();
+    const int tok = sm.pick;
+    __syncthreads();                                                  // sm is reused by the caller's next row (beam-free: one row per block)
+    return tok;
+}
+
 // one multinomial draw from softmax(warped scores) of a row, by the whole 1024-thread block; `lg(i)` = the row's score after
 // processors and temperature.  The random number is a pure function of (seed, step, row).  Every thread returns the token.
 template <class F>
 __device__ int sample_row(F lg, int V, int top_k, float top_p, uint64_t seed, uint32_t step, uint32_t rowid, float* red,
                           float* scan, int* result) {
     const int tid = threadIdx.x;
+    if (top_k > 0 && top_k <= 256 && top_k < V) {                                        // the reference's default: top_k = 50
+        const int t = sample_row_topk(lg, V, top_k, top_p, seed, step, rowid, red);
+        if (t >= 0) return t;                                                            // -1: outside its scope (block-uniform)
+    }
     const WarpStats w = row_warp_stats(lg, V, top_k, top_p, 1, red);                     // TopK -> TopP thresholds
     // multinomial over the survivors, in index order: per-thread contiguous ranges + block scan
     const int per = (V + SP_THREADS - 1) / SP_THREADS;

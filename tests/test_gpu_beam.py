@@ -265,6 +265,43 @@ def test_sampler_top_k_then_top_p_distribution():
     assert bool((only == lg.argmax()).all())
 
 
+def test_sampler_top_k_selection_at_full_vocabulary():
+    """The top-k sampler's selection path (radix select over the thread maxima -> a few dozen candidates in LDS -> exact ranks)
+    at StarVector's vocabulary, against the oracle's warped distribution: random scores, scores with ties across the k-th value
+    (all ties survive, like HF's `scores < kth` removal), and rows the selection hands back to the general path (every score
+    equal: 49157 candidates; a cluster of > 4 candidates in one thread's stride)."""
+    from starvector_amd import engine as E
+    g = torch.Generator().manual_seed(23)
+    V, rows_n, calls = 49157, 2000, 10                                # 20000 draws per case: (seed, step, row) index the stream
+    cases = {
+        "random": 3.0 * torch.randn(1, V, generator=g),
+        "ties": (2.0 * torch.randn(1, V, generator=g)).mul(2).round().div(2),          # half-integer grid: many equal scores
+        "flat": torch.zeros(1, V),
+    }
+    clustered = -5.0 + 0.01 * torch.randn(1, V, generator=g)
+    clustered[0, 7::1024] = 4.0 + 0.1 * torch.arange(len(clustered[0, 7::1024]))       # 49 candidates, all in thread 7's stride
+    cases["one thread's stride"] = clustered
+
+    def draw(lg, T, tp, tk, seed):
+        rows = lg.repeat(rows_n, 1).to(dev()).contiguous()
+        return torch.cat([E.op_sample_top_p(rows, T, tp, seed=seed, step=st, top_k=tk).cpu().long() for st in range(calls)])
+
+    for name, lg in cases.items():
+        # (equal probabilities across the top-p cut are kept or dropped TOGETHER here, one by one in sort order by HF: the tie
+        #  cases are compared with top_p = 1 only)
+        for (T, tk, tp) in ([(1.0, 50, 0.95), (0.7, 8, 1.0)] if name in ("random", "one thread's stride") else [(1.0, 50, 1.0), (0.7, 8, 1.0)]):
+            probs = O.top_p_filtered_probs(lg, T, tp, top_k=tk)[0]
+            s = draw(lg, T, tp, tk, 11)
+            emp = torch.bincount(s, minlength=V).float() / len(s)
+            assert float(emp[probs == 0].sum()) == 0.0, (name, T, tk, tp)                # never outside top-k / the nucleus
+            if name != "flat":                                                           # L1 noise of 20000 draws over <= 100 ids: ~0.06
+                assert float((emp - probs).abs().sum()) < 0.1, (name, T, tk, tp, float((emp - probs).abs().sum()))
+            assert torch.equal(s, draw(lg, T, tp, tk, 11))                               # deterministic
+    # flat scores: top-k keeps every tie = the whole vocabulary (the selection hands the row to the general path)
+    s = draw(cases["flat"], 1.0, 1.0, 50, 2)
+    assert len(torch.unique(s)) > 0.75 * len(s) * (1 - len(s) / (2 * V))                # ~ uniform over 49157 ids
+
+
 def test_beam_sample_scorer_distribution():
     """Beam-sample draws K = 2*num_beams continuations WITHOUT replacement from softmax(accumulated warped scores) and
     keeps the num_beams best.  Device: Gumbel-top-k with a counter-based RNG; oracle: torch.multinomial (pinned to HF
