@@ -1330,14 +1330,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_fp8_kernel(const uint8
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
             if (FULL || ks + u < ks_per_wave) {
-                const uint32_t lo = c.w[u >> 1][(u & 1) * 2], hi = c.w[u >> 1][(u & 1) * 2 + 1];
-                const f32x2 a0 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), a1 = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
-                const f32x2 a2 = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), a3 = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
-                u32x4 wf;
-                wf[0] = (__float_as_uint(a0[0]) >> 16) | (__float_as_uint(a0[1]) & 0xffff0000u);
-                wf[1] = (__float_as_uint(a1[0]) >> 16) | (__float_as_uint(a1[1]) & 0xffff0000u);
-                wf[2] = (__float_as_uint(a2[0]) >> 16) | (__float_as_uint(a2[1]) & 0xffff0000u);
-                wf[3] = (__float_as_uint(a3[0]) >> 16) | (__float_as_uint(a3[1]) & 0xffff0000u);
+                const u32x4 wf = fp8x8_to_bf16x8(c.w[u >> 1][(u & 1) * 2], c.w[u >> 1][(u & 1) * 2 + 1]);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wf), as_frag4(c.x[u]), acc, 0, 0, 0);
             }
         }
