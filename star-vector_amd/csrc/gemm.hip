@@ -979,8 +979,10 @@ void launch_gemm(const GemmArgs& a0, hipStream_t st) {
 //   * outputs: fp32 slabs (c_attn, both c_proj); bias + activation -> fragment-order bf16 (c_fc);
 //     fp32 logits rounded to bf16 values (lm_head).
 //   Round 1-2 variants that were measured and lost (LayerNorm prologue, ticket-merged split-K with fused residual
-//   epilogues, the row update inside the consumer launch, two column tiles per wave, four register chunks in
-//   flight, full-K blocks) are in git history and in profiles/SUMMARY_r02.md, not in the library.
+//   epilogues, the row update inside the consumer launch, two column tiles per wave at <= 32 rows, four register
+//   chunks in flight, full-K blocks) are in git history and in profiles/SUMMARY_r02.md, not in the library.  (Column
+//   tiles per block came back in round 3 for 33..64 rows, where the activation re-reads do bound the launch:
+//   gemm_skinny_mt2_kernel.)
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) { return pack2bf(lo, hi); }   // common.h: v_cvt_pk_bf16_f32
 
