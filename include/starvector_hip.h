@@ -207,6 +207,11 @@ int  sv_debug_skinny_plan(int32_t rows, int32_t N, int32_t K, int32_t splitk, in
  *                             in-process A/B runs of the round's experiments (tools/ab_exp.py) */
 int  sv_debug_set_exp(sv_engine* e, int32_t mask);
 int  sv_debug_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t act, int32_t* out5);
+/*   sv_debug_decode_plan      what sv_create decides for a decoder Linear W [N][K] when the engine decodes `rows` (<= 64) rows at a
+ *                             time on a GPU with `num_cus` CUs: out2 = {split-K factor (1 when whole_k: c_fc / lm_head keep the whole
+ *                             K for their epilogue), column tiles per block of the two-row-tile kernel (1 for rows <= 32)} -- plain
+ *                             host arithmetic (engine.hip: pick_splitk / pick_decode_plan), pinned by the CPU tests */
+int  sv_debug_decode_plan(int32_t rows, int32_t N, int32_t K, int32_t fp8, int32_t whole_k, int32_t num_cus, int32_t* out2);
 /*   sv_debug_set_col_tiles    column tiles per block (1..3; 0 = the launcher's own choice) the OP-LEVEL decode GEMM entry points
  *                             (sv_op_linear_skinny*, 33..64 rows) launch with from now on, process-wide: lets the parity tests put
  *                             every variant of the two-row-tile kernel next to the one-tile kernels (all bit-identical).  An engine's

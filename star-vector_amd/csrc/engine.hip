@@ -1754,6 +1754,18 @@ extern "C" int sv_debug_skinny_plan(int32_t rows, int32_t N, int32_t K, int32_t 
     return 0;
 }
 
+extern "C" int sv_debug_decode_plan(int32_t rows, int32_t N, int32_t K, int32_t fp8, int32_t whole_k, int32_t num_cus, int32_t* out2) {
+    if (!out2 || rows < 1 || rows > 64 || N < 1 || K < 16 || K % 16 || num_cus < 1)
+        return fail(SV_EINVAL, "sv_debug_decode_plan: bad argument");
+    Linear l;
+    l.N = N; l.K = K; l.Npad = round_up(N, 32); l.Kpad = K;
+    int sk = 1, ct = 1;
+    pick_decode_plan(l, (rows + 31) / 32, num_cus, fp8 != 0, false, whole_k != 0, &sk, &ct);
+    if (fp8) while (sk > 1 && ((K / 16) % sk != 0 || ((K / 16) / sk) % 4 != 0)) --sk;          // as sv_create does
+    out2[0] = sk; out2[1] = ct;
+    return 0;
+}
+
 extern "C" int sv_debug_set_col_tiles(int32_t col_tiles) {
     if (col_tiles < 0 || col_tiles > 3) return fail(SV_EINVAL, "sv_debug_set_col_tiles: 0..3");
     g_op_col_tiles = col_tiles;

@@ -94,3 +94,42 @@ def test_decode_gemm_wave_split_depends_on_the_gemm_only(lib):
     assert _skinny(lib, 32, 1024, 1024, 2)[0] == 16                                                   # narrow output: 16 waves, one tile
     out = (C.c_int32 * 2)()
     assert lib.sv_debug_skinny_plan(32, 64, 100, 1, 0, out) == -22                                    # K % 16
+
+
+def _decode_plan(lib, rows, N, K, fp8=0, whole_k=0, cus=256):
+    out = (C.c_int32 * 2)()
+    assert lib.sv_debug_decode_plan(rows, N, K, fp8, whole_k, cus, out) == 0
+    return out[0], out[1]
+
+
+def test_decode_plan_split_k_and_column_tiles(lib):
+    """sv_create's per-Linear decode plan on a 256-CU GPU (DESIGN.md sections 3c / 3d): split-K by CU fill, and at 33..64 rows the
+    column tiles per block picked together with it.  <= 32 rows never share activation fragments across column tiles (one tile per
+    block); whole-K Linears (c_fc, lm_head) never split."""
+    # StarVector-1B (hidden 2048): small GEMMs keep the round 1-2 rule (smallest power of two reaching one block per CU)
+    assert _decode_plan(lib, 32, 2304, 2048) == (4, 1) and _decode_plan(lib, 32, 2048, 2048) == (4, 1)
+    assert _decode_plan(lib, 32, 2048, 8192) == (4, 1)
+    assert _decode_plan(lib, 32, 8192, 2048, whole_k=1) == (1, 1) and _decode_plan(lib, 32, 49156, 2048, whole_k=1) == (1, 1)
+    # StarVector-8B at 16 rows (config 4), bf16: fill rule
+    assert _decode_plan(lib, 16, 5632, 4608) == (4, 1)
+    assert _decode_plan(lib, 16, 4608, 4608) == (3, 1) and _decode_plan(lib, 16, 4608, 18432) == (3, 1)
+    assert _decode_plan(lib, 16, 18432, 4608, whole_k=1) == (1, 1)
+    # StarVector-8B at 64 rows, fp8 weights (config 5): (split-K, column tiles) together
+    assert _decode_plan(lib, 64, 5632, 4608, fp8=1) == (3, 3)
+    assert _decode_plan(lib, 64, 4608, 4608, fp8=1) == (3, 2)
+    assert _decode_plan(lib, 64, 18432, 4608, fp8=1, whole_k=1) == (1, 3)            # 576 tiles -> 192 blocks: one round
+    assert _decode_plan(lib, 64, 4608, 18432, fp8=1) == (4, 3)
+    assert _decode_plan(lib, 64, 49157, 4608, fp8=1, whole_k=1) == (1, 3)
+    # the same at bf16
+    assert _decode_plan(lib, 64, 5632, 4608) == (4, 3) and _decode_plan(lib, 64, 4608, 18432) == (4, 3)
+    # every plan is launchable: K splits evenly, fp8 keeps pairs of k-steps per wave
+    for rows in (16, 32, 64):
+        for fp8 in (0, 1):
+            for N, K in ((5632, 4608), (4608, 4608), (4608, 18432), (2304, 2048), (2048, 8192), (512, 256)):
+                sk, ct = _decode_plan(lib, rows, N, K, fp8=fp8)
+                assert 1 <= sk <= 8 and (K // 16) % sk == 0 and ct in (1, 2, 3)
+                assert ct == 1 or rows > 32
+                if fp8:
+                    assert ((K // 16) // sk) % 4 == 0
+    out = (C.c_int32 * 2)()
+    assert lib.sv_debug_decode_plan(65, 512, 256, 0, 0, 256, out) == -22
