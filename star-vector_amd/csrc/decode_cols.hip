@@ -37,12 +37,15 @@ namespace sv {
 // ------------------------------------------------------------------------------------------------
 struct ColsKernarg { const bf16_t* Wp; const bf16_t* xp; bf16_t* h_xp; const bf16_t* bias; int K, N, cpb, out_KS; ColsArgs p; };
 
-template <int WAVES, int G>
+// CT = 16-column MFMA tiles per block (1: cpb <= 16, 2: cpb <= 32).  18 columns per block make N = 4608 exactly 256 blocks (one
+// round on 256 CUs; 16 columns are 288 blocks = a second round for 32 of them).
+template <int WAVES, int G, int CT>
 __global__ __launch_bounds__(WAVES * 64) void gemm_cols_resid_kernel(const bf16_t* Wp_, const bf16_t* xp_, bf16_t* h_xp_, const bf16_t* bias_,
                                                                      int K_, int N_, int cpb_, int out_KS_, ColsArgs p_unused) {
+    constexpr int LDT = 16 * CT + 1;
     extern __shared__ __attribute__((aligned(16))) char dg_smem[];
-    float* red = reinterpret_cast<float*>(dg_smem);                     // [WAVES][512]
-    float* tile = red + WAVES * 512;                                     // [32][17]: finished x W^T, later the new h values
+    float* red = reinterpret_cast<float*>(dg_smem);                     // [WAVES][CT][512]
+    float* tile = red + WAVES * CT * 512;                                // [32][LDT]: finished x W^T
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
@@ -53,23 +56,33 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_cols_resid_kernel(const bf16_
     int nc = C - c0;
     nc = nc > cpw ? cpw : nc;
     nc = nc < 0 ? 0 : nc;
-    const int n = j * cpb_ + r;
-    const bool wvalid = r < cpb_ && n < N_;
-    const u32x4* wbase = reinterpret_cast<const u32x4*>(Wp_) +
-                         ((size_t)(n >> 5) * KS + (g >> 1)) * 64 + (n & 31) + 32 * (g & 1) + (size_t)c0 * 128;
+    bool wvalid[CT];
+    const u32x4* wbase[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) {
+        const int n = j * cpb_ + 16 * t + r;
+        wvalid[t] = 16 * t + r < cpb_ && n < N_;
+        const int nn = wvalid[t] ? n : 0;
+        wbase[t] = reinterpret_cast<const u32x4*>(Wp_) + ((size_t)(nn >> 5) * KS + (g >> 1)) * 64 + (nn & 31) + 32 * (g & 1) + (size_t)c0 * 128;
+    }
     const u32x4* xbase = reinterpret_cast<const u32x4*>(xp_) +
                          ((size_t)mt * KS + (g >> 1)) * 64 + r + 32 * (g & 1) + (size_t)c0 * 128;
 
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[CT][2];
+#pragma unroll
+    for (int t = 0; t < CT; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const u32x4 zero4 = {0u, 0u, 0u, 0u};
-    struct Grp { u32x4 w[G]; u32x4 x[G][2]; };
+    struct Grp { u32x4 w[CT][G]; u32x4 x[G][2]; };
     Grp ga, gb;
     auto load = [&](Grp& q, int ci) {
 #pragma unroll
         for (int u = 0; u < G; ++u) {
             if (ci + u < nc) {                                   // wave-uniform
-                q.w[u] = zero4;
-                if (wvalid) q.w[u] = __builtin_nontemporal_load(wbase + (size_t)(ci + u) * 128);
+#pragma unroll
+                for (int t = 0; t < CT; ++t) {
+                    q.w[t][u] = zero4;
+                    if (wvalid[t]) q.w[t][u] = __builtin_nontemporal_load(wbase[t] + (size_t)(ci + u) * 128);
+                }
                 q.x[u][0] = xbase[(size_t)(ci + u) * 128];
                 q.x[u][1] = xbase[(size_t)(ci + u) * 128 + 16];
             }
@@ -79,17 +92,19 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_cols_resid_kernel(const bf16_
 #pragma unroll
         for (int u = 0; u < G; ++u) {
             if (ci + u < nc) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag4(q.w[u]), as_frag4(q.x[u][0]), acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag4(q.w[u]), as_frag4(q.x[u][1]), acc1, 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < CT; ++t) {
+                    acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag4(q.w[t][u]), as_frag4(q.x[u][0]), acc[t][0], 0, 0, 0);
+                    acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag4(q.w[t][u]), as_frag4(q.x[u][1]), acc[t][1], 0, 0, 0);
+                }
             }
         }
     };
     load(ga, 0);
     if (G < nc) load(gb, G);
 
-    // epilogue operands (they depend on nothing).  cpb = 8 or 16 (the shapes the engine uses): thread t < 32 * cpb / 8 finishes
-    // 8 consecutive columns of one row = one 16-byte piece of the fragment-order residual stream -> 16-byte loads / stores and
-    // the row statistics without another LDS pass; other cpb: one thread per element.
+    // epilogue operands (they depend on nothing).  cpb a multiple of 8: thread t < 32 * cpb / 8 finishes 8 consecutive columns of
+    // one row = one 16-byte piece of the fragment-order residual stream -> 16-byte loads / stores; other cpb: one thread per element.
     const bool vec = (cpb_ & 7) == 0 && (N_ & 7) == 0;
     const int v_row = tid & 31, v_ch = tid >> 5;                       // vec: (row, 8-column chunk of the block)
     const int v_n = j * cpb_ + 8 * v_ch;
@@ -118,22 +133,24 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_cols_resid_kernel(const bf16_
         if (ci + 3 * G < nc) load(gb, ci + 3 * G);
     }
 
-    // ---- K reduction across the waves (wave order), then one thread per output element ----
+    // ---- K reduction across the waves (wave order), then one thread per output element / 8-column piece ----
     {
-        float* my = red + wave * 512;
+        float* my = red + wave * (CT * 512);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            my[q * 64 + lane] = acc0[q];
-            my[(4 + q) * 64 + lane] = acc1[q];
-        }
+        for (int t = 0; t < CT; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                my[t * 512 + q * 64 + lane] = acc[t][0][q];
+                my[t * 512 + (4 + q) * 64 + lane] = acc[t][1][q];
+            }
     }
     __syncthreads();
-    if (tid < 512) {
-        float s = red[tid];
+    for (int idx = tid; idx < CT * 512; idx += WAVES * 64) {
+        float s = red[idx];
 #pragma unroll
-        for (int w = 1; w < WAVES; ++w) s += red[w * 512 + tid];
-        const int hb = tid >> 8, q = (tid >> 6) & 3, ln = tid & 63;
-        tile[(16 * hb + (ln & 15)) * 17 + 4 * (ln >> 4) + q] = s;
+        for (int w = 1; w < WAVES; ++w) s += red[w * (CT * 512) + idx];
+        const int t = idx >> 9, hb = (idx >> 8) & 1, q = (idx >> 6) & 3, ln = idx & 63;
+        tile[(16 * hb + (ln & 15)) * LDT + 16 * t + 4 * (ln >> 4) + q] = s;
     }
     __syncthreads();
     if (vec) {
@@ -142,22 +159,32 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_cols_resid_kernel(const bf16_
             unpack8(v_res, rr);
             unpack8(v_bias, bb);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) hn[e] = bfround(rr[e] + bfround(tile[v_row * 17 + 8 * v_ch + e] + bb[e]));      // h = bf(h + bf(x W^T + b))
+            for (int e = 0; e < 8; ++e) hn[e] = bfround(rr[e] + bfround(tile[v_row * LDT + 8 * v_ch + e] + bb[e]));      // h = bf(h + bf(x W^T + b))
             *reinterpret_cast<uint4*>(h_xp_ + v_idx) = pack8(hn);
         }
         return;
     }
-    if (e_on) h_xp_[e_idx] = f2bf(bfround(e_res + bfround(tile[e_row * 17 + e_cr] + e_bias)));
+    if (e_on) h_xp_[e_idx] = f2bf(bfround(e_res + bfround(tile[e_row * LDT + e_cr] + e_bias)));
 }
 
-static size_t cols_smem(int waves) { return (size_t)waves * 512 * 4 + (32 * 17 + 16) * 4 + 64; }
+static size_t cols_smem(int waves, int ct) { return (size_t)waves * ct * 512 * 4 + (32 * (16 * ct + 1) + 16) * 4 + 64; }
 
 // Every block re-reads its row tile's whole activation operand (32 x K bf16) from L2 next to cpb x K weights from HBM, so narrow
 // blocks multiply L2 traffic: 4 columns per block at K = 4608 is 340 MB of L2 reads for 42 MB of weights (measured: +18 us per
 // layer on StarVector-8B, profiles/fold6_r03_8b_ab.log).  K <= 2048: blocks = ceil(N / cpb) closest to a multiple of the 256 CUs
-// (the activations are 128 KiB, the fill matters more); above that the widest block.
+// (the activations are 128 KiB, the fill matters more), cpb a power of two <= 16; above that the (cpb <= 32) with the least bytes
+// through the busiest CU: rounds of 256 blocks x (cpb + 32 rows) -- N = 4608: 18 columns = exactly 256 blocks.
 int cols_pick_cpb(int N, int K) {
-    if (K > 2048) return 16;
+    if (K > 2048) {
+        int best = 16;
+        long best_cost = -1;
+        for (int cpb = 8; cpb <= 32; ++cpb) {
+            const long nb = (N + cpb - 1) / cpb, rounds = (nb + 255) / 256;
+            const long cost = rounds * (cpb + 32);
+            if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = cpb; }
+        }
+        return best;
+    }
     int best = 8;
     double best_fill = 0.0;
     for (int cpb = 16; cpb >= 4; cpb >>= 1) {
@@ -170,15 +197,21 @@ int cols_pick_cpb(int N, int K) {
 }
 
 int launch_gemm_cols(const ColsArgs& a, hipStream_t st) {
-    if (a.K % 32 || a.cpb < 1 || a.cpb > 16 || !a.h_xp) return -1;
+    if (a.K % 32 || a.cpb < 1 || a.cpb > 32 || !a.h_xp) return -1;
     dim3 grid((a.N + a.cpb - 1) / a.cpb, a.MT);
-    gemm_cols_resid_kernel<16, 2><<<grid, 16 * 64, cols_smem(16), st>>>(a.Wp, a.xp, a.h_xp, a.bias, a.K, a.N, a.cpb, a.out_KS, a);
+    if (a.cpb > 16)
+        gemm_cols_resid_kernel<16, 2, 2><<<grid, 16 * 64, cols_smem(16, 2), st>>>(a.Wp, a.xp, a.h_xp, a.bias, a.K, a.N, a.cpb, a.out_KS, a);
+    else
+        gemm_cols_resid_kernel<16, 2, 1><<<grid, 16 * 64, cols_smem(16, 1), st>>>(a.Wp, a.xp, a.h_xp, a.bias, a.K, a.N, a.cpb, a.out_KS, a);
     return 0;
 }
 
 int init_cols_kernels() {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_cols_resid_kernel<16, 2>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)cols_smem(16));
+    int r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_cols_resid_kernel<16, 2, 1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)cols_smem(16, 1));
+    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_cols_resid_kernel<16, 2, 2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)cols_smem(16, 2));
+    return r;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -685,8 +685,8 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     if (getenv("SV_EXP")) e->exp = atoi(getenv("SV_EXP"));
     // 6 launches per layer (decode_cols.hip): bf16 weights, at most one 32-row tile per launch; SV_EXP bit 2 = A/B, the 7-launch layer.
     // Hidden sizes above 2048 keep the 7-launch layer: every block of the whole-K projection re-reads 32 x K activations from L2,
-    // and at StarVector-8B's K = 4608 that costs what the removed row update saved and a little more (4227 vs 4178 us per step,
-    // profiles/fold6_r03_8b_ab.log); SV_EXP bit 4 = A/B, the 6-launch layer at any size.
+    // and at StarVector-8B's K = 4608 that costs what the removed row update saves (16 columns per block: 4227 vs 4178 us per
+    // step; 18 columns = 256 blocks: 3933 vs 3932, profiles/fold6_r03_8b_ab.log); SV_EXP bit 4 = A/B, the 6-launch layer at any size.
     e->fold6 = c.weight_dtype == SV_WEIGHT_BF16 && e->MT == 1 && (c.n_head * dh) % 32 == 0 && D % 32 == 0 &&
                (c.n_head * dh <= 2048 || (e->exp & 4));
     if (!rc && e->fold6) {

@@ -76,7 +76,7 @@ struct ColsArgs {
     const bf16_t* Wp;                // packed weight [Npad/32][K/16][64][8] (the image the 32-column kernels read)
     const bf16_t* bias;              // [N] or nullptr
     int MT, N, K;                    // K multiple of 32
-    int cpb;                         // output columns per block (4, 8 or 16): cols_pick_cpb(N, K)
+    int cpb;                         // output columns per block (<= 32): cols_pick_cpb(N, K)
     bf16_t* h_xp; int out_KS;        // residual stream in fragment order, N = 16 * out_KS columns: h = bf(h + bf(x W^T + b)), in place
 };
 int cols_pick_cpb(int N, int K);

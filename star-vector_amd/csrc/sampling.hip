@@ -119,7 +119,7 @@ __device__ int sample_row_topk(F lg, int V, int k, float top_p, uint64_t seed, u
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const int i = i0 + u * SP_THREADS;
-            x[u] = lg(i < V ? i : V - 1);                           // (clamped: the duplicate cannot raise the maximum)
+            x[u] = i < V ? lg(i) : -INFINITY;
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) mt = fmaxf(mt, x[u]);
