@@ -807,6 +807,14 @@ static int attn_max_splits(const sv_engine* e) {
     return ms < 1 ? 1 : (ms > 8 ? 8 : ms);
 }
 
+// 32-key groups a block takes before another context split joins.  Where the engine's rows x KV heads already give every CU a block
+// (StarVector-8B at 64 rows: 256 (row, KV head) pairs), a context of <= 8 groups stays in ONE block (one group per wave: no partial
+// results, no ticket, no merge); otherwise 4 (measured best where the splits are what fills the chip,
+// profiles/attention_r03_groups_per_block_ab.log).  A constant of the engine like the split cap (same reason).
+static int attn_groups_per_block(const sv_engine* e) {
+    return (e->cfg.max_batch < 64 ? e->cfg.max_batch : 64) * e->nkv >= e->num_cus ? 8 : 0;
+}
+
 static int vision_forward(sv_engine* e, const bf16_t* img, int B, bf16_t* out, hipStream_t st) {
     const sv_config& c = e->cfg;
     const int Dv = c.vit_width, T = e->T, NP = e->NP, M = B * T, Fv = e->vit_F;
@@ -1010,6 +1018,7 @@ static void decode_forward(sv_engine* e, int B, hipStream_t st) {
             ad.B = B; ad.H = c.n_head; ad.head_dim = dh; ad.scale = 1.0f / sqrtf((float)dh);
             ad.part = e->attn_part; ad.counters = e->attn_cnt;
             ad.max_splits = attn_max_splits(e);
+            ad.groups_per_block = attn_groups_per_block(e);
             ad.n_kv = e->nkv; ad.kv_head_stride = e->kv_head_stride; ad.rope_cos = e->rope_cos; ad.rope_sin = e->rope_sin;
             prof_mark(e, PK_ATTN, st);
             launch_attn_decode(ad, st);

@@ -656,6 +656,35 @@ def test_starvector_8b_dims_one_layer_against_oracle():
     eng.close()
 
 
+def test_starvector_8b_dims_64_row_engine_short_contexts():
+    """A 64-row engine at StarVector-8B's dimensions (BASELINE config 5: text2svg, short prompts): rows x KV heads = 256 fill the chip,
+    so a context of up to 8 key groups stays in one attention block (no partial results / merge) and longer ones split; the decode
+    GEMMs run the two-row-tile kernel with the engine's (split-K, column tiles) plan.  Text-only prompt of 250 tokens + 12 new tokens:
+    the context crosses 256 -> the attention switches from one block to two splits on the way.  Teacher-forced against the oracle."""
+    torch.set_num_threads(host_cores())
+    cfg = dataclasses.replace(O.OracleConfig.starvector_8b(), n_layer=1, vit_layers=1, eos_token_id=-1)
+    w = O.make_weights(cfg, seed=79)
+    B, n_new, S0 = 3, 12, 250
+    eng = build_engine(cfg, w, max_batch=64, max_seq_len=320)
+    ids = torch.randint(0, 4000, (B, S0), generator=torch.Generator().manual_seed(80))
+    emb = eng.embed_tokens(ids.to(dev()))
+    assert emb.shape == (B, S0, 4608)
+    worst, scale, checked, near, o_toks, margin = _teacher_forced_check(eng, emb, w, cfg, n_new)
+    print(f"[8b dims, 64-row engine] {n_new} steps x {B} rows: logits max|err| {worst:.3e} (scale {scale:.3e}); "
+          f"{checked}/{B * n_new} positions token-exact outside the band, {near} near-tie flips inside it")
+    assert checked >= 0.8 * B * n_new, f"only {checked}/{B * n_new} positions are margin-safe and token-exact"
+    # a row does not depend on the batch around it (same splits, same plan: constants of the engine), graph == eager
+    kw = dict(max_length=S0 + n_new, eos_token_id=-1, pad_token_id=0)
+    a = eng.generate(emb, **kw).cpu()
+    assert torch.equal(a[2], eng.generate(emb[2:3].contiguous(), **kw).cpu()[0])
+    os.environ["SV_NO_GRAPH"] = "1"
+    try:
+        assert torch.equal(a, eng.generate(emb, **kw).cpu())
+    finally:
+        os.environ.pop("SV_NO_GRAPH", None)
+    eng.close()
+
+
 def test_starvector_8b_full_size_properties():
     """BASELINE config 4 shapes (siglip_384 + starcoder2-7b: 7.2 B parameters, 36 query / 4 KV heads, D 4608):
     the CPU oracle cannot run this size in test time, so the full size is covered by size-independent properties -
