@@ -212,6 +212,11 @@ int  sv_debug_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t act, int32_t* o
  *                             K for their epilogue), column tiles per block of the two-row-tile kernel (1 for rows <= 32)} -- plain
  *                             host arithmetic (engine.hip: pick_splitk / pick_decode_plan), pinned by the CPU tests */
 int  sv_debug_decode_plan(int32_t rows, int32_t N, int32_t K, int32_t fp8, int32_t whole_k, int32_t num_cus, int32_t* out2);
+/*   sv_debug_attn_plan        the decode attention's context-split constants of an engine: out2 = {the most blocks a sequence's context
+ *                             is split over (so that rows x KV heads x splits covers the CUs, <= 8), 32-key groups a block takes
+ *                             before another split joins (8 where rows x KV heads alone cover the CUs, else 4)} -- functions of the
+ *                             engine's max_batch / KV heads only, never of the call's batch (a row's bits do not depend on its batch) */
+int  sv_debug_attn_plan(int32_t max_batch, int32_t n_kv_head, int32_t num_cus, int32_t* out2);
 /*   sv_debug_set_col_tiles    column tiles per block (1..3; 0 = the launcher's own choice) the OP-LEVEL decode GEMM entry points
  *                             (sv_op_linear_skinny*, 33..64 rows) launch with from now on, process-wide: lets the parity tests put
  *                             every variant of the two-row-tile kernel next to the one-tile kernels (all bit-identical).  An engine's

@@ -107,6 +107,7 @@ PROTOTYPES = {
     "sv_last_timing": (_I, [_P, C.POINTER(C.c_double)]),
     "sv_debug_set_exp": (_I, [_P, _I]),
     "sv_debug_set_col_tiles": (_I, [_I]),
+    "sv_debug_attn_plan": (_I, [_I, _I, _I, C.POINTER(_I)]),
     "sv_debug_decode_plan": (_I, [_I, _I, _I, _I, _I, _I, C.POINTER(_I)]),
     "sv_profile_decode_step": (_I, [_P, _I, _I, C.POINTER(C.c_double), _P]),
     "sv_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),

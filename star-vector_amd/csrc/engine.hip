@@ -801,19 +801,21 @@ static void gemm(const bf16_t* A, int lda, const Linear& l, const bf16_t* R, int
 // Context splits of the decode attention: a constant of the engine (sized for the engine's max_batch), NOT of the batch of the
 // call, so that a sequence's partial results are merged in the same grouping whatever shares the batch with it: a row is
 // bit-identical alone, inside a batch and inside a continuous batch at any context length.
-static int attn_max_splits(const sv_engine* e) {
-    const int rows = (e->cfg.max_batch < 32 ? e->cfg.max_batch : 32) * e->nkv;
-    const int ms = e->num_cus / (rows < 1 ? 1 : rows);
+static int attn_max_splits_of(int max_batch, int nkv, int num_cus) {
+    const int rows = (max_batch < 32 ? max_batch : 32) * nkv;
+    const int ms = num_cus / (rows < 1 ? 1 : rows);
     return ms < 1 ? 1 : (ms > 8 ? 8 : ms);
 }
+static int attn_max_splits(const sv_engine* e) { return attn_max_splits_of(e->cfg.max_batch, e->nkv, e->num_cus); }
 
 // 32-key groups a block takes before another context split joins.  Where the engine's rows x KV heads already give every CU a block
 // (StarVector-8B at 64 rows: 256 (row, KV head) pairs), a context of <= 8 groups stays in ONE block (one group per wave: no partial
 // results, no ticket, no merge); otherwise 4 (measured best where the splits are what fills the chip,
 // profiles/attention_r03_groups_per_block_ab.log).  A constant of the engine like the split cap (same reason).
-static int attn_groups_per_block(const sv_engine* e) {
-    return (e->cfg.max_batch < 64 ? e->cfg.max_batch : 64) * e->nkv >= e->num_cus ? 8 : 0;
+static int attn_groups_per_block_of(int max_batch, int nkv, int num_cus) {
+    return (max_batch < 64 ? max_batch : 64) * nkv >= num_cus ? 8 : 4;
 }
+static int attn_groups_per_block(const sv_engine* e) { return attn_groups_per_block_of(e->cfg.max_batch, e->nkv, e->num_cus); }
 
 static int vision_forward(sv_engine* e, const bf16_t* img, int B, bf16_t* out, hipStream_t st) {
     const sv_config& c = e->cfg;
@@ -1772,6 +1774,13 @@ extern "C" int sv_debug_decode_plan(int32_t rows, int32_t N, int32_t K, int32_t 
     pick_decode_plan(l, (rows + 31) / 32, num_cus, fp8 != 0, false, whole_k != 0, &sk, &ct);
     if (fp8) while (sk > 1 && ((K / 16) % sk != 0 || ((K / 16) / sk) % 4 != 0)) --sk;          // as sv_create does
     out2[0] = sk; out2[1] = ct;
+    return 0;
+}
+
+extern "C" int sv_debug_attn_plan(int32_t max_batch, int32_t n_kv_head, int32_t num_cus, int32_t* out2) {
+    if (!out2 || max_batch < 1 || n_kv_head < 1 || num_cus < 1) return fail(SV_EINVAL, "sv_debug_attn_plan: bad argument");
+    out2[0] = attn_max_splits_of(max_batch, n_kv_head, num_cus);
+    out2[1] = attn_groups_per_block_of(max_batch, n_kv_head, num_cus);
     return 0;
 }
 

@@ -133,3 +133,20 @@ def test_decode_plan_split_k_and_column_tiles(lib):
                     assert ((K // 16) // sk) % 4 == 0
     out = (C.c_int32 * 2)()
     assert lib.sv_debug_decode_plan(65, 512, 256, 0, 0, 256, out) == -22
+
+
+def test_decode_attention_split_constants(lib):
+    """Context splits of the decode attention are constants of the engine (DESIGN.md sections 3 / 3d): enough blocks to cover the
+    256 CUs, never more than 8 per sequence; where rows x KV heads cover the chip on their own a block takes 8 key groups."""
+    def plan(max_batch, nkv, cus=256):
+        out = (C.c_int32 * 2)()
+        assert lib.sv_debug_attn_plan(max_batch, nkv, cus, out) == 0
+        return out[0], out[1]
+    assert plan(32, 1) == (8, 4)          # StarVector-1B, batch 32 (multi-query): 32 rows x 8 splits = 256 blocks
+    assert plan(1, 1) == (8, 4) and plan(4, 1) == (8, 4)
+    assert plan(64, 1) == (8, 4)          # the split cap is sized for 32 rows: the same grouping as the 32-row engine
+    assert plan(16, 4) == (4, 4)          # StarVector-8B, batch 16: 64 (row, KV head) pairs x 4
+    assert plan(64, 4) == (2, 8)          # StarVector-8B, batch 64: 256 pairs cover the chip -> contexts <= 256 tokens stay in one block
+    assert plan(32, 4) == (2, 4)
+    out = (C.c_int32 * 2)()
+    assert lib.sv_debug_attn_plan(0, 1, 256, out) == -22
