@@ -815,7 +815,9 @@ static int attn_max_splits(const sv_engine* e) { return attn_max_splits_of(e->cf
 static int attn_groups_per_block_of(int max_batch, int nkv, int num_cus) {
     return (max_batch < 64 ? max_batch : 64) * nkv >= num_cus ? 8 : 4;
 }
-static int attn_groups_per_block(const sv_engine* e) { return attn_groups_per_block_of(e->cfg.max_batch, e->nkv, e->num_cus); }
+static int attn_groups_per_block(const sv_engine* e) {
+    return (e->exp & 64) ? 4 : attn_groups_per_block_of(e->cfg.max_batch, e->nkv, e->num_cus);       // SV_EXP bit 64: A/B, always 4
+}
 
 static int vision_forward(sv_engine* e, const bf16_t* img, int B, bf16_t* out, hipStream_t st) {
     const sv_config& c = e->cfg;
