@@ -292,7 +292,10 @@ def main():
             "tokens_per_s_per_gpu": round(value / world, 1),
             "ttft_p50_ms": round(ttft_p50, 2) if ttft_p50 is not None else None,
             "decode_us_per_step": round(decode_ms / max(decode_steps, 1) * 1e3, 1),
-            "roofline": {"bound": "hbm", "kernel": f"decoder weight-streaming GEMMs: gemm_skinny_kernel (+ gemm_cols_resid_kernel for the attention output projection), {int(launches)} launches/step",
+            "roofline": {"bound": "hbm", "kernel": "decoder weight-streaming GEMMs: " + (
+                             "gemm_skinny_mt2_kernel (two row tiles, up to three column tiles per block)" if B_PER_GPU > 32 else
+                             "gemm_skinny_kernel" if (is8b or args.weights != "bf16") else
+                             "gemm_skinny_kernel (+ gemm_cols_resid_kernel for the attention output projection)") + f", {int(launches)} launches/step",
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,
                          "traffic_source": traffic_source,
