@@ -16,19 +16,21 @@ Prints ONE JSON line (rank 0).  value = generated SVG tokens / second over ALL G
 """
 from __future__ import annotations
 
-import argparse
-import json
 import os
-import statistics
-import sys
-import time
 
-import torch
+# Before ANYTHING touches the HIP / HSA runtime (it reads its flags once, at initialisation): the host driver of this pool only
+# supports dmabuf IPC, and without this RCCL's hipIpcGetMemHandle fails (a setdefault after torch.cuda.* is too late).
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import argparse   # noqa: E402
+import json       # noqa: E402
+import socket     # noqa: E402
+import statistics  # noqa: E402
+import sys        # noqa: E402
+import time       # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-
-from oracle.hostinfo import host_cores  # noqa: E402  (cpu_baseline leg only)
 
 PROMPT_IDS = [7, 11]          # '<svg' is 2 ids under the (gated, offline) StarCoder tokenizer: synthetic stand-ins
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -37,8 +39,9 @@ HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 def decoder_weight_bytes(cfg) -> int:
     """Algorithmic bytes of the dominant kernel per decode step: every decoder Linear weight + the tied lm_head,
     bf16, streamed once (2,240,876,544 B for StarVector-1B)."""
-    qkv = cfg.n_head * cfg.head_dim + 2 * cfg.n_kv_head * cfg.head_dim
-    per_layer = cfg.hidden * (qkv + cfg.n_head * cfg.head_dim + 2 * cfg.n_inner)
+    head_dim = cfg.hidden // cfg.n_head
+    qkv = cfg.n_head * head_dim + 2 * cfg.n_kv_head * head_dim
+    per_layer = cfg.hidden * (qkv + cfg.n_head * head_dim + 2 * cfg.n_inner)
     return 2 * (cfg.n_layer * per_layer + cfg.vocab * cfg.hidden)
 
 
@@ -61,11 +64,17 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(w, cfg, O):
-    """The oracle (CPU float32 restatement of the reference modules, BASELINE config 1) timed on this
-    box's host cores, bounded sample: one image, prefill + 12 greedy decode steps."""
+def cpu_baseline():
+    """The oracle (CPU float32 restatement of the reference modules, BASELINE config 1) timed on this box's host cores, bounded
+    sample: one image, prefill + 12 greedy decode steps.  The ONLY place bench.py touches oracle/ (test infrastructure): its own
+    N(0, 0.02) weights of the same architecture -- values do not change a dense float32 forward's time."""
+    import torch
+    from oracle import starvector_oracle as O
+    from oracle.hostinfo import host_cores
+    cfg = O.OracleConfig()
     torch.set_num_threads(host_cores())
     cores = torch.get_num_threads()
+    w = O.make_weights(cfg, seed=1234, init="std002")
     img = O.synthetic_images(1, cfg.image_size, seed=3)
     prompt = torch.tensor([PROMPT_IDS], dtype=torch.long)
     t0 = time.perf_counter()
@@ -85,14 +94,42 @@ def cpu_baseline(w, cfg, O):
             "ttft_s": round(t2 - t0, 3)}
 
 
+_CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)      # data/util.py:33-38 (ImageTrainProcessor's Normalize)
+_CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def synthetic_images(torch, n, size, seed):
+    """Random-pixel images through the reference's normalisation: row i depends on (seed, i) only."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(n, 3, size, size, generator=g)
+    mean, std = torch.tensor(_CLIP_MEAN).view(1, 3, 1, 1), torch.tensor(_CLIP_STD).view(1, 3, 1, 1)
+    return ((x - mean) / std).to(torch.bfloat16)
+
+
+def self_launch_command(gpus: int, argv, port=None):
+    """`python bench.py --gpus N` without a launcher: the command line this process replaces itself with -- one rank per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve), a free port."""
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # called bare (`python bench.py --gpus 8`): become the launcher the contract names instead of giving up
+        cmd = self_launch_command(args.gpus, sys.argv[1:])
+        print("[bench] no launcher in the environment: re-executing as " + " ".join(cmd), file=sys.stderr, flush=True)
+        os.execvpe(cmd[0], cmd, os.environ)
+    import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s): they must agree (one process per GPU)")
     # One process per GPU.  With fewer GPUs than ranks (the 1-GPU development box) the ranks share devices and rendezvous
     # over gloo: a FUNCTIONAL run of the very same sharded path (full replica per rank, rank shard of the global batch, one
     # all_gather of token streams); its rate is not a scaling number and the line says so ("dist_backend").
@@ -108,7 +145,6 @@ def main():
         # Fail LOUDLY, never hang: a bounded rendezvous / collective timeout, and a first tiny all_reduce right away so that a
         # broken xGMI / RCCL setup (e.g. a missing HSA_ENABLE_IPC_MODE_LEGACY=0: hipIpcGetMemHandle fails) surfaces here with a
         # message instead of inside the timed region.
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         tmo = datetime.timedelta(seconds=int(os.environ.get("SV_DIST_TIMEOUT_S", "180")))
         try:
             if shared:
@@ -133,34 +169,26 @@ def main():
 
     import starvector_amd as sva
     from starvector_amd.parallel import all_gather_token_streams
-    from oracle import starvector_oracle as O        # weight factory + synthetic inputs + cpu_baseline only
 
     is8b = args.model == "8b"
-    cfg = O.OracleConfig.starvector_8b() if is8b else O.OracleConfig()
     t2s = args.task == "text2svg"
     B_PER_GPU = (64 if t2s else 16) if is8b else 32
-    W_BYTES_PER_STEP = decoder_weight_bytes(cfg) // (2 if args.weights == "fp8" else 1)
     n_new = args.new_tokens
     CAPTION_TOKENS = 32
-    S0 = CAPTION_TOKENS + 1 if t2s else cfg.query_length + len(PROMPT_IDS)
+    PAD_ID = 0 if is8b else 49152            # llm/starcoder2.py:47 / llm/starcoder.py:40-53 ([PAD] appended to the 49152-entry vocabulary)
+    ec = sva.EngineConfig.starvector_8b(max_batch=B_PER_GPU, max_seq_len=16) if is8b else sva.EngineConfig(max_batch=B_PER_GPU)
+    S0 = CAPTION_TOKENS + 1 if t2s else ec.query_length + len(PROMPT_IDS)
+    ec.max_seq_len = S0 + n_new
+    cfg = ec                                  # the shapes of the path come from the product's own config (StarVectorConfig's defaults)
+    W_BYTES_PER_STEP = decoder_weight_bytes(cfg) // (2 if args.weights == "fp8" else 1)
     t_setup = time.time()
-    ec = (sva.EngineConfig.starvector_8b(max_batch=B_PER_GPU, max_seq_len=S0 + n_new) if is8b
-          else sva.EngineConfig(max_batch=B_PER_GPU, max_seq_len=S0 + n_new))
     if args.weights == "fp8":
         ec.weight_dtype = "fp8_e4m3"
     eng = sva.HipEngine(ec, device=dev_index)
     keep_cpu = (world == 1 and rank == 0 and not args.no_cpu_baseline and not is8b and not t2s)   # 8B fp32 on CPU: 29 GB, skipped
-    w = {}
-    for name, t in O.iter_weights(cfg, seed=1234, init="std002"):      # streamed: fp32 -> bf16 + fragment
-        eng.load_weight(name, t)                                       # packing on device, one tensor at a time
-        if keep_cpu:
-            w[name] = t
-    eng.load_state_dict({})                                            # completeness check
-    if keep_cpu:
-        w[O.K_LMH] = w[O.P_DEC + "wte.weight"]
+    eng.load_random_weights(seed=1234, std=0.02)   # drawn on the GPU, one tensor at a time, same values on every rank
     # this rank's shard of the global batch (seeded per global row -> identical under any sharding)
-    images = O.synthetic_images(B_PER_GPU * world, cfg.image_size, seed=0)[rank * B_PER_GPU:(rank + 1) * B_PER_GPU]
-    images = images.to(torch.bfloat16).to(dev)
+    images = synthetic_images(torch, B_PER_GPU * world, cfg.image_size, seed=0)[rank * B_PER_GPU:(rank + 1) * B_PER_GPU].to(dev)
     prompt = torch.tensor([PROMPT_IDS] * B_PER_GPU, dtype=torch.long, device=dev)
     if t2s:
         # starvector_base.py:297-330: caption ids + <svg-start>; seeded per global row like the images
@@ -177,13 +205,13 @@ def main():
             vis = eng.adapter(enc)                             # a6
             emb = torch.cat([vis, eng.embed_tokens(prompt)], 1)    # a1, a7
         new = eng.generate(emb, max_length=S0 + max_new, eos_token_id=-1,      # EOS disabled:
-                           pad_token_id=cfg.pad_token_id,                      # fixed-length workload
+                           pad_token_id=PAD_ID,                                # fixed-length workload
                            do_sample=is8b, temperature=1.0, top_p=0.95, top_k=50 if is8b else 0,
                            seed=1)       # config 4 samples: top-p 0.95 after HF 4.49's implicit top-k 50
         out = new if t2s else torch.cat([prompt, new], 1)      # starvector_base.py:256 (text2svg returns the new ids, :329-330)
         if world > 1:
             # ONE collective: int32 [B, 1 + width] per rank (column 0 = the row's length); the width is known up front
-            out = all_gather_token_streams(out.cpu() if shared else out, cfg.pad_token_id, B_PER_GPU * world,
+            out = all_gather_token_streams(out.cpu() if shared else out, PAD_ID, B_PER_GPU * world,
                                            width=(0 if t2s else len(PROMPT_IDS)) + max_new)
         return out, new.shape[1]
 
@@ -206,10 +234,14 @@ def main():
         decode_ms += tm["decode_ms"]; decode_steps += tm["decode_steps"]; graph = graph and tm["graph"]
     sync_all()
     dt = time.perf_counter() - t0
+    per_rank_tps = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # every rank's own clock over the same K steps (a straggler is visible in the line); the job's time is the MAX
+        mine = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank_tps = [round(n_tok * B_PER_GPU / float(x.item()), 1) for x in every]
+        dt = max(float(x.item()) for x in every)
     total_tokens = n_tok * B_PER_GPU * world
     value = total_tokens / dt
 
@@ -257,6 +289,7 @@ def main():
     Mp = B_PER_GPU * S0
     D, F = cfg.hidden, cfg.n_inner
     qkv = D + 2 * (D // cfg.n_head) * cfg.n_kv_head
+    head_dim = D // cfg.n_head
     gemms = [("c_attn", qkv, D, "none", False), ("c_proj", D, D, "none", True),
              ("c_fc", F, D, "gelu_tanh", False), ("down_proj", D, F, "none", True)]
     pf_us, pf_flop, per_gemm = 0.0, 0.0, {}
@@ -275,7 +308,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.weights == "bf16" else "bf16 activations / fp8-e4m3 decoder weights (not the reference precision)",
-            "data": f"synthetic: random-pixel {cfg.image_size}x{cfg.image_size} images (CLIP-normalised), random-init weights N(0,0.02) seed 1234",
+            "data": f"synthetic: random-pixel {cfg.image_size}x{cfg.image_size} images (CLIP-normalised), random-init weights N(0,0.02) seed 1234 drawn on the GPU",
             "config": {"workload": (f"StarVector-{args.model.upper()} text2svg (no image encoder), batch {B_PER_GPU}/GPU, {args.weights} decoder weights, "
                                     f"{'top-k 50 + top-p 0.95' if is8b else 'greedy'}, prompt rows {S0} ({CAPTION_TOKENS} caption ids + <svg-start>), "
                                     f"{n_new} new tokens/seq, EOS disabled") if t2s else
@@ -287,7 +320,8 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        **({"dist_backend": ("gloo, ranks SHARE GPUs (functional run of the sharded path on a box with fewer GPUs than "
                                             "ranks; not a scaling number)") if shared else f"nccl (RCCL {rccl_version})",
-                           "collectives_per_step": 1} if world > 1 else {}),
+                           "collectives_per_step": 1, "rccl_version": rccl_version,
+                           "tokens_per_s_by_rank": per_rank_tps} if world > 1 else {}),
                        "hipgraph_decode": bool(graph)},
             "tokens_per_s_per_gpu": round(value / world, 1),
             "ttft_p50_ms": round(ttft_p50, 2) if ttft_p50 is not None else None,
@@ -316,13 +350,13 @@ def main():
                 "achieved": round((W_BYTES_PER_STEP + kvb) / (us * 1e-6) / 1e9, 1) if us > 0 else None, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round((W_BYTES_PER_STEP + kvb) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us > 0 else None,
                 "launches_per_step": int(sum(v["launches_per_step"] for v in prof.values() if isinstance(v, dict))) + 2})(
-                    B_PER_GPU * (S0 + n_new / 2.0) * cfg.n_layer * 2 * cfg.n_kv_head * cfg.head_dim * 2,
+                    B_PER_GPU * (S0 + n_new / 2.0) * cfg.n_layer * 2 * cfg.n_kv_head * head_dim * 2,
                     decode_ms / max(decode_steps, 1) * 1e3),
             "decode_step_profile_ms": {k: round(v["ms_per_step"], 4) for k, v in prof.items() if isinstance(v, dict)},
             "setup_s": round(t_setup, 1),
         }
         if keep_cpu:
-            res["cpu_baseline"] = cpu_baseline(w, cfg, O)
+            res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
     eng.close()
     if world > 1:

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define SV_ABI_VERSION 6
+#define SV_ABI_VERSION 7
 #define SV_WEIGHT_BF16 0
 #define SV_WEIGHT_FP8_E4M3 1
 
@@ -161,6 +161,11 @@ int  sv_load_weight(sv_engine* e, const char* name, const void* dev_ptr, int32_t
 /* 0 when every tensor the path needs has been loaded; otherwise SV_ENOENT and sv_last_error() names
  * the first missing key. */
 int  sv_weights_complete(sv_engine* e);
+/* The tensors an engine of this configuration expects, sorted by name: reference state_dict key (train/util.py:71 names), element
+ * count, whether sv_weights_complete insists on it (the tied lm_head is optional) and whether it has been loaded.
+ * sv_weight_count returns the number of entries (>= 0) or a negative error code. */
+int  sv_weight_count(sv_engine* e);
+int  sv_weight_info(sv_engine* e, int32_t index, char* name, int32_t name_cap, int64_t* numel, int32_t* required, int32_t* loaded);
 
 /* image [B,3,S,S] bf16 (device) -> out [B, T, vit_width] bf16, T = (S/patch)^2 + 1 */
 int  sv_encode_image(sv_engine* e, const void* dev_image, int32_t B, void* dev_out, sv_stream stream);
@@ -210,7 +215,7 @@ int  sv_debug_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t act, int32_t* o
 /*   sv_debug_decode_plan      what sv_create decides for a decoder Linear W [N][K] when the engine decodes `rows` (<= 64) rows at a
  *                             time on a GPU with `num_cus` CUs: out2 = {split-K factor (1 when whole_k: c_fc / lm_head keep the whole
  *                             K for their epilogue), column tiles per block of the two-row-tile kernel (1 for rows <= 32)} -- plain
- *                             host arithmetic (engine.hip: pick_splitk / pick_decode_plan), pinned by the CPU tests */
+ *                             host arithmetic (engine_core.hip: pick_splitk / pick_decode_plan), pinned by the CPU tests */
 int  sv_debug_decode_plan(int32_t rows, int32_t N, int32_t K, int32_t fp8, int32_t whole_k, int32_t num_cus, int32_t* out2);
 /*   sv_debug_attn_plan        the decode attention's context-split constants of an engine: out2 = {the most blocks a sequence's context
  *                             is split over (so that rows x KV heads x splits covers the CUs, <= 8), 32-key groups a block takes
@@ -222,6 +227,16 @@ int  sv_debug_attn_plan(int32_t max_batch, int32_t n_kv_head, int32_t num_cus, i
  *                             every variant of the two-row-tile kernel next to the one-tile kernels (all bit-identical).  An engine's
  *                             decode loop is not affected (it carries its own plan per Linear). */
 int  sv_debug_set_col_tiles(int32_t col_tiles);
+/* The decode attention (gpt_bigcode/modeling_gpt_bigcode.py:151-285, llm/starcoder2.py:22-27 sliding window) on
+ * its own, over the engine's real paged KV pool, block table and context-split plan.  Test surface: the caller chooses q / K / V.
+ *   sv_debug_kv_load     dev_kv bf16 [B][S][2*n_kv*head_dim] (k heads | v heads, K as cached = after RoPE) -> pages of `layer`;
+ *                        positions[b] = S for every row, or dev_lens[b] (int32 [B], <= S; NULL = S): a ragged batch
+ *   sv_debug_attn_decode dev_qkv_f32 fp32 [B][n_head*head_dim + 2*n_kv*head_dim] (the new token's c_attn output, before RoPE) ->
+ *                        dev_out bf16 [B][n_head*head_dim]; appends the new K/V row at positions[b]; advance != 0: positions += 1 */
+int  sv_debug_kv_load(sv_engine* e, int32_t layer, const void* dev_kv, int32_t B, int32_t S, const int32_t* dev_lens,
+                      sv_stream stream);
+int  sv_debug_attn_decode(sv_engine* e, int32_t layer, const float* dev_qkv_f32, int32_t B, void* dev_out, int32_t advance,
+                          sv_stream stream);
 
 /* Prompt pass over inputs_embeds [B,S0,hidden] bf16 (all-ones attention mask): fills the paged KV
  * cache and writes the last-row logits [B, vocab] fp32 (bf16-rounded values, as the reference's

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libstarvector_hip.so")
 HEADER_PATH = os.path.normpath(os.path.join(HERE, "..", "include", "starvector_hip.h"))
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 SV_DTYPE_BF16, SV_DTYPE_F32 = 0, 1
 SV_NORM_LAYER, SV_NORM_BATCH = 0, 1
 SV_ARCH_V1, SV_ARCH_V2 = 0, 1
@@ -79,6 +79,8 @@ PROTOTYPES = {
     "sv_destroy": (_I, [_P]),
     "sv_load_weight": (_I, [_P, C.c_char_p, _P, _I, _I, C.POINTER(C.c_int64), _P]),
     "sv_weights_complete": (_I, [_P]),
+    "sv_weight_count": (_I, [_P]),
+    "sv_weight_info": (_I, [_P, _I, C.c_char_p, _I, C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(_I)]),
     "sv_encode_image": (_I, [_P, _P, _I, _P, _P]),
     "sv_adapter": (_I, [_P, _P, _I, _P, _P]),
     "sv_embed_tokens": (_I, [_P, _P, _I, _P, _P]),
@@ -108,6 +110,8 @@ PROTOTYPES = {
     "sv_debug_set_exp": (_I, [_P, _I]),
     "sv_debug_set_col_tiles": (_I, [_I]),
     "sv_debug_attn_plan": (_I, [_I, _I, _I, C.POINTER(_I)]),
+    "sv_debug_kv_load": (_I, [_P, _I, _P, _I, _I, _P, _P]),
+    "sv_debug_attn_decode": (_I, [_P, _I, _P, _I, _P, _I, _P]),
     "sv_debug_decode_plan": (_I, [_I, _I, _I, _I, _I, _I, C.POINTER(_I)]),
     "sv_profile_decode_step": (_I, [_P, _I, _I, C.POINTER(C.c_double), _P]),
     "sv_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),

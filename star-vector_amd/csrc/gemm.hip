@@ -886,8 +886,8 @@ struct TuneKey {
 };
 static std::mutex g_tune_mu;
 static std::map<TuneKey, int> g_tune;          // bit 0: 256^2 kernel, bit 1: peel, bit 2: tail as a row of 128^2 tiles
-static void* g_tune_scratch = nullptr;         // grow-only scratch output of the timing runs (no hipFree = no device sync per shape)
-static size_t g_tune_scratch_bytes = 0;
+struct TuneScratch { void* p = nullptr; size_t bytes = 0; };
+static std::map<int, TuneScratch> g_tune_scratch;      // per device: grow-only scratch output of the timing runs (no hipFree per shape = no device sync)
 
 static int autotune_gemm(const GemmArgs& a, hipStream_t st, const GemmPlan& model) {
     const int fallback = (model.main_256 ? 1 : 0) | (model.peel ? 2 : 0) | (model.tail_by_tiles ? 4 : 0);
@@ -895,13 +895,16 @@ static int autotune_gemm(const GemmArgs& a, hipStream_t st, const GemmPlan& mode
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return fallback; }
     const size_t esz = a.out_f32 ? 4 : 2;
     const size_t need = (size_t)a.M * a.ldc * esz;
-    if (need > g_tune_scratch_bytes) {                  // (the caller holds g_tune_mu)
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess) { (void)hipGetLastError(); return fallback; }
+    TuneScratch& ts = g_tune_scratch[dev_id];           // (the caller holds g_tune_mu)
+    if (need > ts.bytes) {
         void* bigger = nullptr;
         if (hipMalloc(&bigger, need + need / 2) != hipSuccess) { (void)hipGetLastError(); return fallback; }
-        if (g_tune_scratch) (void)hipFree(g_tune_scratch);
-        g_tune_scratch = bigger; g_tune_scratch_bytes = need + need / 2;
+        if (ts.p) (void)hipFree(ts.p);
+        ts.p = bigger; ts.bytes = need + need / 2;
     }
-    void* scratch = g_tune_scratch;
+    void* scratch = ts.p;
     hipEvent_t e0, e1;
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fallback;
     GemmArgs t = a;
@@ -1609,7 +1612,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(const void*
     }
 }
 
-int g_op_col_tiles = 0;
+std::atomic<int> g_op_col_tiles{0};     // op-level entry points only (SkinnyArgs.col_tiles == 0); engines always pass their plan
 static int init_mt2_attrs() {
     int r = 0;
     auto set = [&](const void* f, int bytes) { if (!r) r = (int)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); };
@@ -1633,9 +1636,9 @@ static bool launch_gemm_skinny_mt2(const SkinnyArgs& a, hipStream_t st) {
     const int waves = a.Wq ? skinny_waves_fp8(KS, a.splitk) : skinny_waves(a.Npad, KS, a.splitk);
     const void* W = a.Wq ? (const void*)a.Wq : (const void*)a.Wp;
     if (waves == 8) {
-        // the engine picks (column tiles, split-K) together (engine.hip, pick_decode_plan); on its own (col_tiles = 0: the op-level
+        // the engine picks (column tiles, split-K) together (engine_core.hip, pick_decode_plan); on its own (col_tiles = 0: the op-level
         // entry points) the launcher takes two column tiles when half the blocks still cover the chip
-        const int ct = a.col_tiles ? a.col_tiles : g_op_col_tiles;
+        const int ct = a.col_tiles ? a.col_tiles : g_op_col_tiles.load(std::memory_order_relaxed);
         if (ct == 3) {
             const dim3 grid((n_tiles + 2) / 3, a.splitk, a.MT / 2);
             if (a.Wq) gemm_skinny_mt2_kernel<8, true, 3><<<grid, 512, 2 * 8 * 16 * 64 * 4, st>>>(W, a.xp, KS, per, n_tiles, a);

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "common.h"
 
 namespace sv {
@@ -64,7 +65,7 @@ void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st);
 // host arithmetic of the launch: waves per block (how K is cut inside a block = the summation order of a row) and whether a
 // block carries two row tiles; a function of the GEMM only for the former (sv_debug_skinny_plan, CPU tests)
 void skinny_plan(int Npad, int K, int splitk, int fp8, int MT, int* waves, int* two_row_tiles);
-extern int g_op_col_tiles;       // sv_debug_set_col_tiles: what SkinnyArgs.col_tiles == 0 means (0 = the launcher's default)
+extern std::atomic<int> g_op_col_tiles;       // sv_debug_set_col_tiles: what SkinnyArgs.col_tiles == 0 means (0 = the launcher's default)
 
 int init_gemm_kernels();        // hipFuncSetAttribute for the large-LDS variants (0 = ok)
 

@@ -4,7 +4,7 @@ from __future__ import annotations
 import ctypes as C
 import threading
 from dataclasses import dataclass
-from typing import Dict, Iterable, List, Optional, Sequence
+from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
 import torch
 
@@ -132,6 +132,39 @@ class HipEngine:
                 skipped.append(k)
         if strict and skipped:
             raise KeyError(f"unexpected keys in state_dict: {skipped[:5]}{'...' if len(skipped) > 5 else ''}")
+        check(self.lib.sv_weights_complete(self._h), "sv_weights_complete")
+
+    def expected_weights(self) -> List[Tuple[str, int, bool, bool]]:
+        """(reference state_dict key, element count, required, loaded) for every tensor this engine expects, sorted by name."""
+        n = self.lib.sv_weight_count(self._h)
+        if n < 0:
+            check(n, "sv_weight_count")
+        out = []
+        name = C.create_string_buffer(512)
+        numel, req, loaded = C.c_int64(0), C.c_int32(0), C.c_int32(0)
+        for i in range(n):
+            check(self.lib.sv_weight_info(self._h, i, name, 512, C.byref(numel), C.byref(req), C.byref(loaded)), "sv_weight_info")
+            out.append((name.value.decode(), int(numel.value), bool(req.value), bool(loaded.value)))
+        return out
+
+    def load_random_weights(self, seed: int = 1234, std: float = 0.02) -> None:
+        """Random-init weights of this architecture, drawn ON THE GPU one tensor at a time (throughput runs; there is no network for
+        checkpoints): Linear / embedding / position tensors and biases N(0, std), LayerNorm / BatchNorm scales (and running_var) 1,
+        their biases (and running_mean) 0.  Each tensor has its own generator seeded by (seed, crc32(name)): the values do not depend
+        on the enumeration order or on what else is loaded."""
+        import zlib
+        for name, numel, required, _ in self.expected_weights():
+            if not required:
+                continue                                   # the tied lm_head: the engine packs wte for it
+            norm = ".ln_" in name or "norm" in name        # ln_1 / ln_2 / ln_pre / ln_vision / ln_f, layer_norm*, *layernorm, norm
+            if norm and (name.endswith(".weight") or name.endswith("running_var")):
+                t = torch.ones(numel, dtype=torch.bfloat16, device=self._dev)
+            elif norm and (name.endswith(".bias") or name.endswith("running_mean")):
+                t = torch.zeros(numel, dtype=torch.bfloat16, device=self._dev)
+            else:
+                g = torch.Generator(device=self._dev).manual_seed((int(seed) << 32) ^ zlib.crc32(name.encode()))
+                t = torch.empty(numel, dtype=torch.float32, device=self._dev).normal_(0.0, std, generator=g).to(torch.bfloat16)
+            self.load_weight(name, t)
         check(self.lib.sv_weights_complete(self._h), "sv_weights_complete")
 
     # ---- forward entry points -----------------------------------------------------------------
@@ -291,6 +324,30 @@ class HipEngine:
     def set_exp(self, mask: int) -> None:
         """Experiment bit mask (SV_EXP) of the live engine: in-process A/B runs (tools/ab_exp.py)."""
         check(self.lib.sv_debug_set_exp(self._h, int(mask)), "sv_debug_set_exp")
+
+    def debug_kv_load(self, layer: int, kv: torch.Tensor, lens: Optional[torch.Tensor] = None) -> None:
+        """Test surface of the decode attention (include/starvector_hip.h, sv_debug_kv_load): kv [B, S, 2 * n_kv_head * head_dim]
+        bf16 (k heads | v heads, K as cached) becomes tokens 0..S-1 of `layer`'s paged KV; every row's position is set to S, or to
+        lens[b] (int32 [B], <= S) for a ragged batch."""
+        kv = _need(kv, torch.bfloat16, "kv")
+        B, S, _ = kv.shape
+        if lens is not None:
+            lens = _need(lens, torch.int32, "lens")
+            if lens.numel() != B or int(lens.max()) > S or int(lens.min()) < 0:
+                raise ValueError("lens must be int32 [B] with 0 <= lens[b] <= S")
+        check(self.lib.sv_debug_kv_load(self._h, int(layer), _ptr(kv) if S > 0 else C.c_void_p(0), B, S, _ptr(lens), _stream()),
+              "sv_debug_kv_load")
+        torch.cuda.current_stream().synchronize()          # the caller may free `kv` right away
+
+    def debug_attn_decode(self, layer: int, qkv: torch.Tensor, advance: bool = True) -> torch.Tensor:
+        """One launch of the decode attention of `layer` for the new token whose c_attn output is qkv [B, QKV] float32 (before
+        RoPE); returns [B, n_head * head_dim] bf16 and (advance) steps the positions, so repeated calls walk the sequence."""
+        qkv = _need(qkv, torch.float32, "qkv")
+        B = qkv.shape[0]
+        out = torch.empty(B, self.cfg.hidden, dtype=torch.bfloat16, device=qkv.device)     # n_head * head_dim == hidden
+        check(self.lib.sv_debug_attn_decode(self._h, int(layer), _ptr(qkv), B, _ptr(out), int(bool(advance)), _stream()),
+              "sv_debug_attn_decode")
+        return out
 
     def profile_decode_step(self, B: int, iters: int = 5) -> Dict[str, Dict[str, float]]:
         """HIP-event time per decode step by kernel class (eager launches of the graph's kernels)."""

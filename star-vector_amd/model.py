@@ -879,6 +879,9 @@ class StarVectorForCausalLM(nn.Module):
             if m.shape != inputs_embeds.shape[:2]:
                 raise ValueError(f"attention_mask {tuple(m.shape)} does not cover inputs_embeds {tuple(inputs_embeds.shape[:2])}")
             lead = (m.cumsum(1) == 0).sum(1)                                  # leading pads per row
+            if bool((lead >= m.shape[1]).any()):
+                empty = (lead >= m.shape[1]).nonzero().flatten().tolist()
+                raise ValueError(f"attention_mask rows {empty} are all zeros: a row needs at least one real position to be scored")
             idx = torch.arange(m.shape[1], device=m.device).unsqueeze(0)
             real = idx >= lead.unsqueeze(1)
             if bool((m[:, 1:] & ~m[:, :-1] & real[:, :-1]).any()):            # a 1 after a 0 behind the leading pads

@@ -776,3 +776,51 @@ def test_non_finite_logits_are_an_error_not_a_memory_fault():
     emb = torch.cat([good.adapter(good.encode_image(img)), good.embed_tokens(torch.tensor([[7, 11]] * 2, device=dev()))], 1)
     assert good.generate(emb, max_length=S0 + 12, eos_token_id=-1, pad_token_id=0).shape == (2, 12)
     good.close()
+
+
+def test_from_pretrained_reference_format_directory_matches_hf_generate(tmp_path):
+    """scripts/quickstart.py:9-19 end to end on a checkpoint DIRECTORY in the reference's format (config.json + sharded safetensors under
+    train/util.py:71's key names, written by tests/ckpt_util.py): `StarVectorForCausalLM.from_pretrained` -> `.cuda().eval()` ->
+    `generate_im2svg`.  The weights are tests/golden/tiny_b3's (designed greedy stream), so the NEW token ids must equal HF generate's,
+    token for token, through the public API; then the quickstart's own kwargs (beam-sample, repetition penalty) run on the same model."""
+    import starvector_amd as sva
+    from starvector_amd.model import ByteTokenizer
+    from tests.ckpt_util import write_reference_checkpoint
+    g = _golden("tiny_b3")
+    seed, B, n_new = [int(x) for x in g["meta"]]
+    cfg = O.OracleConfig.tiny()
+    w = O.apply_fixture_weights(O.make_weights(cfg, seed=seed), cfg, g)
+    d = str(tmp_path / "starvector-tiny-im2svg")
+    write_reference_checkpoint(d, cfg, w, n_shards=2, torch_dtype="bfloat16")
+    prompt_ids = g["prompt_ids"][0].tolist()
+
+    class Tok(ByteTokenizer):                       # the golden's prompt ids stand for '<svg' (the StarCoder tokenizer is gated / offline)
+        def encode(self, text, add_special_tokens=False):
+            return list(prompt_ids) if text == "<svg" else super().encode(text, add_special_tokens)
+
+    with pytest.raises(FileNotFoundError, match="tokenizer"):
+        sva.StarVectorForCausalLM.from_pretrained(d)                       # no tokenizer files, no silent stand-in
+    model = sva.StarVectorForCausalLM.from_pretrained(d, torch_dtype="auto", tokenizer=Tok(cfg.vocab - 4))
+    model.cuda()
+    model.eval()
+    batch = {"image": g["image"].to(torch.float16).to(dev())}              # the quickstart hands the image over as float16
+    S0 = model.model.query_length + len(prompt_ids)
+    res = model.model.generate_im2svg_grpo(batch, max_length=S0 + n_new, num_beams=1, use_nucleus_sampling=False)
+    assert res["outputs"].shape == (B, len(prompt_ids) + n_new)
+    assert torch.equal(res["outputs"][:, :len(prompt_ids)].cpu(), g["prompt_ids"])
+    assert torch.equal(res["outputs"][:, len(prompt_ids):].cpu(), g["tokens"]), "from_pretrained + generate != HF generate on the golden"
+    svgs = model.generate_im2svg(batch, max_length=S0 + n_new, num_beams=1, use_nucleus_sampling=False)
+    assert isinstance(svgs, list) and len(svgs) == B and all(isinstance(s, str) for s in svgs)
+    # the quickstart's literal call: one un-batched image, the reference's defaults (num_beams 2 + nucleus sampling) and its kwargs
+    one = {"image": g["image"][0].to(torch.float16).to(dev())}
+    raw_svg = model.generate_im2svg(one, max_length=S0 + 12, temperature=1.5, length_penalty=-1, repetition_penalty=3.1)[0]
+    assert isinstance(raw_svg, str)
+    # a float16 checkpoint (configs/generation/hf/starvector-1b/im2svg.yaml:16) loads too: converted at the boundary, with a warning
+    d16 = str(tmp_path / "starvector-tiny-fp16")
+    write_reference_checkpoint(d16, cfg, w, n_shards=1, torch_dtype="float16")
+    m16 = sva.StarVectorForCausalLM.from_pretrained(d16, tokenizer=Tok(cfg.vocab - 4))
+    r16 = m16.model.generate_im2svg_grpo(batch, max_length=S0 + n_new, num_beams=1, use_nucleus_sampling=False)
+    # fp16 storage only flushes the few weights below its subnormal range (|w| < 6e-8); the designed margins are 0.25 x the logit scale
+    assert torch.equal(r16["outputs"].cpu(), res["outputs"].cpu())
+    model.engine.close()
+    m16.engine.close()

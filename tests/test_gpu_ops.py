@@ -399,3 +399,35 @@ def test_decode_output_projection_and_folded_layernorm(M, D, Kp, F):
     assert min(e_ref, e_f32) <= 3 * BF16_1ULP and mean_err(y, y_f32) <= 2e-3, (e_ref, e_f32)
     h2b, yb = E.op_decode_proj_fold(bf(x), bf(Wp), bf(bp), bf(h), bf(gam), bf(bet), bf(Wf), bf(bf_))
     assert torch.equal(h2, h2b) and torch.equal(y, yb)                                   # deterministic (fixed-order statistics)
+
+
+@pytest.mark.parametrize("ratio", [30.0, 100.0])
+def test_folded_layernorm_with_a_large_common_offset_per_row(ratio):
+    """the 6-launch layer applies ln_2 with single-pass statistics (var = E[x^2] - mean^2) and the epilogue
+    rstd * (acc - mean * c1) + c2 -- both subtractions cancel when a row's |mean| is far above its standard deviation.  Rows with
+    mean / std = 30 and 100 (the most a bf16 residual stream can carry: at 256 the bf16 grid spacing IS the standard deviation), both
+    signs, against LayerNorm -> Linear -> GELU evaluated in float64 on the engine's own h2.  float32 loses (mean/std)^2 * 6e-8 of the
+    variance (6e-4 at 100) and (mean/std) * 6e-8 of the projection: far below one bf16 rounding, which is what is asserted."""
+    M, D, Kp, F = 32, 2048, 2048, 8192
+    g = torch.Generator().manual_seed(int(ratio))
+    x = torch.zeros(M, Kp)                                                               # h2 = h: the offset reaches c_fc unchanged
+    Wp = (torch.randn(D, Kp, generator=g) / Kp ** 0.5).bfloat16().float()
+    bp = torch.zeros(D)
+    sign = torch.where(torch.arange(M) % 2 == 0, 1.0, -1.0)[:, None]
+    h = (torch.randn(M, D, generator=g) + sign * ratio * (0.5 + torch.rand(M, 1, generator=g))).bfloat16().float()
+    gam = (1 + 0.1 * torch.randn(D, generator=g)).bfloat16().float()
+    bet = (0.1 * torch.randn(D, generator=g)).bfloat16().float()
+    Wf = (torch.randn(F, D, generator=g) / D ** 0.5).bfloat16().float()
+    bf_ = (0.1 * torch.randn(F, generator=g)).bfloat16().float()
+    h2, y = E.op_decode_proj_fold(bf(x), bf(Wp), bf(bp), bf(h), bf(gam), bf(bet), bf(Wf), bf(bf_))
+    assert torch.equal(h2.float().cpu(), h)
+    h64 = h.double()
+    got_ratio = float((h64.mean(1).abs() / h64.std(1)).min())
+    assert got_ratio >= 0.45 * ratio
+    xln = torch.nn.functional.layer_norm(h64, (D,), gam.double(), bet.double(), 1e-5)
+    y64 = torch.nn.functional.gelu(xln @ Wf.double().T + bf_.double(), approximate="tanh").float()
+    y_cast = torch.nn.functional.gelu((xln.float().bfloat16().float() @ Wf.T + bf_).bfloat16().float(), approximate="tanh")
+    e64, ecast = rel_err(y, y64), rel_err(y, y_cast)
+    print(f"[fold, row mean/std >= {got_ratio:.0f}] max err vs float64 LN-Linear-GELU {e64:.3e}, vs the bf16-cast-point chain {ecast:.3e}, "
+          f"mean err {mean_err(y, y64):.3e}")
+    assert min(e64, ecast) <= 3 * BF16_1ULP and mean_err(y, y64) <= 2e-3, (e64, ecast)

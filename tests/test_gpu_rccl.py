@@ -35,3 +35,22 @@ def test_bench_two_ranks_over_rccl():
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 64 and res["scaling"] == "weak"
     assert res["config"]["dist_backend"].startswith("nccl (RCCL") and res["config"]["collectives_per_step"] == 1
     assert res["value"] > 0 and res["config"]["hipgraph_decode"]
+
+
+def test_bench_bare_invocation_launches_itself_two_ranks_share_the_gpu():
+    """`python bench.py --gpus 2` with NO launcher in the environment (what a driver without torchrun would type) must become the
+    torch.distributed.run job itself.  On this 1-GPU box the two ranks share the device and rendezvous over gloo: the sharded path, the
+    single all_gather and the line's multi-rank fields run for real; with >= 2 GPUs the same command goes over RCCL."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SV_DIST_TIMEOUT_S"] = "120"
+    if torch.cuda.device_count() < 2:
+        env["SV_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--new-tokens", "8",
+           "--ttft-requests", "1", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, f"bare bench.py --gpus 2 failed (rc {r.returncode}):\n{r.stderr[-3000:]}"
+    assert "re-executing as" in r.stderr
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 64 and res["config"]["collectives_per_step"] == 1
+    assert len(res["config"]["tokens_per_s_by_rank"]) == 2 and min(res["config"]["tokens_per_s_by_rank"]) > 0
+    assert res["value"] > 0

@@ -319,6 +319,8 @@ def test_scoring_forward_padded_masks():
         m.forward(vis, ids, 2, torch.tensor([[1] * 7, [0, 1, 0, 1, 1, 1, 1]]), 4)        # a hole behind a left pad
     with pytest.raises(ValueError):
         m.forward(vis, ids, 2, torch.ones(2, 4, dtype=torch.long)[:, :3] * torch.tensor([[1, 1, 0]]), 4)
+    with pytest.raises(ValueError, match="all zeros"):
+        m.forward(vis, ids, 2, torch.tensor([[1] * 7, [0] * 7]), 4)                      # a row with no real position
 
 
 def test_simple_starvector_processor_is_hf_style():
@@ -422,3 +424,70 @@ def test_padded_prompts_run_as_slots_of_one_decode_loop():
     assert cut.shape == (4, 4) and torch.equal(cut, out[:, :4])                             # row 0's stop ends every row
     with pytest.raises(ValueError):
         lm.generate(inputs_embeds=emb, attention_mask=torch.tensor([[1, 1, 1, 1, 1, 0]] * 4), max_length=12)
+
+
+def test_reference_format_checkpoint_directory_round_trip(tmp_path):
+    """A checkpoint directory as the reference's `from_pretrained` reads it (scripts/quickstart.py:9, starvector_arch.py:96-145; HF
+    `save_pretrained`: config.json + sharded safetensors + index, tensors under train/util.py:71's names) -> the mirror's config.  The
+    numbers the reference takes from the HF sub-models it instantiates (vocabulary after resize_token_embeddings, positions, MLP
+    width) come off the saved tensors.  The GPU half (load + generate) is tests/test_gpu_e2e.py::test_from_pretrained_*."""
+    import json
+    from safetensors import safe_open
+    from oracle import starvector_oracle as O
+    from starvector_amd.model import config_from_checkpoint, StarVectorForCausalLM
+    from starvector_amd._lib import StarVectorHipError
+    from tests.ckpt_util import write_reference_checkpoint
+    cfg = O.OracleConfig.tiny()
+    w = O.make_weights(cfg, seed=5)
+    d = str(tmp_path / "ckpt")
+    write_reference_checkpoint(d, cfg, w, n_shards=3, torch_dtype="float16")
+    files = sorted(os.listdir(d))
+    assert files == ["config.json", "model-00001-of-00003.safetensors", "model-00002-of-00003.safetensors",
+                     "model-00003-of-00003.safetensors", "model.safetensors.index.json"]
+    shapes = {}
+    for fn in files:
+        if fn.endswith(".safetensors"):
+            with safe_open(os.path.join(d, fn), "pt") as f:
+                for k in f.keys():
+                    shapes[k] = tuple(f.get_slice(k).get_shape())
+    assert set(shapes) == set(w) - {O.K_LMH}                              # the tied head is not saved
+    assert set(json.load(open(os.path.join(d, "model.safetensors.index.json")))["weight_map"]) == set(shapes)
+    c = config_from_checkpoint(json.load(open(os.path.join(d, "config.json"))), shapes)
+    ec = c.engine_config()
+    assert (ec.vocab, ec.n_positions, ec.n_inner, ec.hidden, ec.n_layer, ec.n_head) == (cfg.vocab, cfg.n_positions, cfg.n_inner,
+                                                                                        cfg.hidden, cfg.n_layer, cfg.n_head)
+    assert (ec.image_size, ec.patch_size, ec.vit_width, ec.vit_layers, ec.vit_heads, ec.arch) == (56, 14, 128, 2, 2, "v1")
+    assert c.added_tokens == 4 and ec.max_batch == 4
+    # hub names cannot be fetched here and say so; a directory without tokenizer files must not silently get the byte tokenizer
+    with pytest.raises(FileNotFoundError, match="hub download"):
+        StarVectorForCausalLM.from_pretrained("starvector/starvector-1b-im2svg")
+    if not torch.cuda.is_available():
+        with pytest.raises((StarVectorHipError, FileNotFoundError)):      # no GPU: the engine refuses (never a CPU model)
+            StarVectorForCausalLM.from_pretrained(d)
+
+
+def test_bench_self_launch_command_and_environment():
+    """`python bench.py --gpus N` with no launcher re-executes itself under torch.distributed.run exactly as the driver's contract
+    spells the command (one rank per GPU, rendezvous on 127.0.0.1), and the HSA IPC flag is set before torch is imported."""
+    import importlib.util
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("_bench_mod", os.path.join(root, "bench.py"))
+    src = open(os.path.join(root, "bench.py")).read()
+    assert src.index('os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")') < src.index("import torch")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cmd = mod.self_launch_command(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], port=29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[3:9] == ["--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1", "--master-port", "29511"]
+    assert cmd[9] == os.path.join(root, "bench.py") and cmd[10:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    free = mod.self_launch_command(2, [])
+    assert 1024 < int(free[8]) < 65536
+    # a launcher whose world size disagrees with --gpus is refused before any GPU work
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "must agree" in (r.stderr + r.stdout)
+    # the product benchmark does not need test infrastructure to describe the model: oracle/ is imported inside cpu_baseline only
+    body = src[src.index("def main():"):]
+    assert "from oracle" not in body and "import oracle" not in body

@@ -13,7 +13,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import starvector_amd as sva  # noqa: E402
-from oracle import starvector_oracle as O  # noqa: E402
+from bench import synthetic_images  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("masks", nargs="*", type=int, default=[0, 1, 2, 3])
@@ -22,17 +22,14 @@ ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--batch", type=int, default=32)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
-cfg = O.OracleConfig()
 B = a.batch
 eng = sva.HipEngine(sva.EngineConfig(max_batch=B, max_seq_len=259 + a.new_tokens + 8))
-for name, t in O.iter_weights(cfg, seed=1234, init="std002"):
-    eng.load_weight(name, t)
-eng.load_state_dict({})
-img = O.synthetic_images(B, 224, seed=0).to(torch.bfloat16).to(dev)
+eng.load_random_weights(seed=1234)
+img = synthetic_images(torch, B, 224, seed=0).to(dev)
 prompt = torch.tensor([[7, 11]] * B, dtype=torch.long, device=dev)
 emb = torch.cat([eng.adapter(eng.encode_image(img)), eng.embed_tokens(prompt)], 1)
 S0 = emb.shape[1]
-kw = dict(max_length=S0 + a.new_tokens, eos_token_id=-1, pad_token_id=cfg.pad_token_id)
+kw = dict(max_length=S0 + a.new_tokens, eos_token_id=-1, pad_token_id=49152)
 ref = None
 for rep in range(a.reps + 1):                      # rep 0 = warm-up (graph capture, tuning)
     for m in a.masks:
