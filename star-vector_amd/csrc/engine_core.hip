@@ -555,6 +555,14 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     if (!rc && e->fold6) {
         const int cpb = cols_pick_cpb(D, c.n_head * dh);
         for (DecLayer& L : e->dec) L.c_proj.cpb = cpb;
+        // the fused MLP launch (SV_EXP bit 128) needs its F / 32 blocks resident at once (one 8-wave block per CU) and the exact
+        // (tile, K slice) geometry of the two kernels it replaces: 16 k-steps per wave in both phases
+        const Linear& fc = e->dec[0].c_fc; const Linear& dn = e->dec[0].c_proj2;
+        const int T1 = fc.Npad / 32;
+        e->mlp_fused_ok = T1 <= e->num_cus && T1 % 8 == 0 && fc.N == fc.Npad && dn.N == dn.Npad && fc.Kpad / 16 == 128 &&
+                          dn.splitk >= 1 && 8 % dn.splitk == 0 && dn.Kpad / 16 == dn.splitk * 128 && (dn.Npad / 32) * dn.splitk == T1 &&
+                          dn.Kpad == fc.Npad;
+        if (e->mlp_fused_ok) rc = dalloc(e, &e->mlp_cnt, 8);
     }
     if (rc) { sv_destroy(e); return rc; }
     *out = e;

@@ -176,8 +176,12 @@ int sveng::check_finite_logits(sv_engine* e, hipStream_t st, const char* who) {
     HIPCHECK(hipMemcpyAsync(&e->h_flags[4], e->d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
     if (!e->h_flags[4]) return 0;
+    const int what = e->h_flags[4];
     HIPCHECK(hipMemsetAsync(e->d_bad, 0, sizeof(int32_t), st));
     HIPCHECK(hipStreamSynchronize(st));
+    if (what == 3)
+        return fail(SV_EHIP, "%s: a block of the fused MLP launch gave up waiting for its producers (its blocks were not all resident at "
+                             "once?); the tokens of this call are void -- run without SV_EXP bit 128", who);
     return fail(SV_EHIP, "%s: a row of logits had no finite value (NaN / Inf in the weights or inputs?)", who);
 }
 

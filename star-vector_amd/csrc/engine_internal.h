@@ -110,12 +110,15 @@ struct sv_engine {
     bf16_t* h_xp = nullptr;         // residual stream of the decode step in fragment order (6-launch layer)
     bool fold6 = false;             // 6 launches per layer: slab-free attention output projection + ln_2 folded into c_fc
     bool fold_ready = false;
+    bool mlp_fused_ok = false;      // the MLP half as one launch (gemm.hip mlp_fused_kernel) fits this engine: shapes + one block per CU
+    unsigned* mlp_cnt = nullptr;    // its arrival counters [8], zeroed by the launch in front of it
     bool only_skinny = false;       // profiling: enqueue only the weight-streaming GEMMs of a step
     bool skip_skinny = false;       // profiling: enqueue everything BUT the weight-streaming GEMMs
     int exp = 0;                    // SV_EXP bit mask, read once at sv_create (A/B switches of the round's experiments):
                                     //   2 the 7-launch layer (no LayerNorm fold);
                                     //   (1: was the row update as one wave per row: 0.218 vs 0.131 ms per step, removed)
                                     //   8 (at sv_create only) the round 1-2 split-K rule of the decode GEMMs
+                                    //   128 (round 4) the MLP half of a layer as ONE launch (c_fc + down projection, mlp_fused_kernel)
                                     //   (16 / 32 / 64: 2 / 6 / 8 key groups per attention block: 1186 / 1169 / 1175 vs 1171 us, removed)
                                     //   (1, 2: XCD-aligned weight prefetch by attention's idle waves / spare row-update blocks; 4: one key
                                     //    group per attention block -- all measured slower, profiles/prefetch_r03_*.log, removed)

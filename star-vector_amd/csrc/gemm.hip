@@ -1260,6 +1260,207 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
     sk_store<RPW>(p, v, bias_d, wave * RPW, nt, mt, split, m, half, fold, fc1);
 }
 
+// ------------------------------------------------------------------------------------------------
+// mlp_fused_kernel: the MLP half of a decode layer (gpt_bigcode/modeling_gpt_bigcode.py:645-660: c_fc -> GELU-tanh -> c_proj) as ONE
+// launch of F/32 co-resident blocks (256 for StarVector-1B, one per CU), instead of gemm_skinny_kernel<8, true> (folded c_fc) and
+// gemm_skinny_kernel<8, false> (down projection, split-K slabs) with a kernel boundary between them.  Round-4 experiment behind
+// SV_EXP bit 128; kept only if it beats the two launches.
+//
+//   Why it can pay (MI355X_MICROARCH.md price list: boundary, prefetch-credit): both GEMMs are pure weight streams (2 x 33.5 MB) and
+//   the WEIGHTS of the second one depend on nothing.  Two launches pay a boundary (1.7-1.9 us) plus the second kernel's ramp (first
+//   round trip to HBM with an idle chip); here every wave requests its whole share of the down projection's weights (16 KiB, 64
+//   VGPRs) as soon as its c_fc loop has issued its last MFMA, so that stream runs UNDER the c_fc epilogue, the publish and the wait.
+//
+//   Phase 1  block L = (xcd = L & 7, i = L >> 3): c_fc tile nt1 = split * (T1 / S) + (xcd / S) * (T1 / 8) + i with split = xcd % S --
+//            the 32 GELU outputs columns of a tile are 2 KiB contiguous in fragment order; they go LDS -> 16-byte sc1 (write-through)
+//            stores, every storing wave drains (vmcnt(0)), one relaxed agent-scope ticket on cnt[split].
+//   Phase 2  the same block owns (tile nt2 = (xcd / S) * (T1 / 8) + i, K slice `split`) of the down projection = exactly the
+//            (tile, slice) the XCD-aware assignment of the slab kernel gives block L.  Its activations are the c_fc columns
+//            [2048 split, 2048 (split + 1)) = the tiles of the 64 blocks that share its `split` (and sit on XCDs split, split + 4):
+//            one lane polls cnt[split] (relaxed sc1 loads + s_sleep, BOUNDED: a give-up code in *err instead of a hang), then every
+//            wave reads its 16 KiB of activations with sc1 loads (L1 bypass: no acquire fence needed for write-through data).
+//   Results  per-wave k ranges, MFMA order, cross-wave reduction order, fold statistics and epilogues are those of the two kernels it
+//            replaces: bit-identical slabs (tests/test_gpu_ops.py::test_fused_mlp_equals_the_two_launches).
+//   Safety   needs all F/32 blocks resident at once (1 per CU: the engine enables it only when #CUs >= F/32); cnt[] is zeroed by the
+//            kernel in front of it (gemm_cols_resid_kernel), never by this launch.
+// ------------------------------------------------------------------------------------------------
+struct MlpFusedKernarg { const bf16_t* W1; const bf16_t* x1; const bf16_t* W2; int KS1; int KS2; int S; MlpFusedArgs p; };
+// amdgpu_waves_per_eu(2, 2): one 8-wave block per CU is the design point (2 waves per SIMD, 256 VGPRs each); without it the
+// scheduler trades registers for a third wave that can never exist and serialises phase 2's 16 activation loads 3 at a time
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_fused_kernel(const bf16_t* W1_, const bf16_t* x1_, const bf16_t* W2_, int KS1_, int KS2_, int S_,
+                                                        MlpFusedArgs p_unused) {
+    constexpr int WAVES = 8, CH = 4, NB = 2, RPW = 2, KPW = 16;          // k-steps per wave in BOTH phases (host-checked)
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(sk_smem);          // [WAVES][16][64]
+    float2* fst_s = reinterpret_cast<float2*>(sk_smem + (size_t)WAVES * 16 * 64 * 4);      // [WAVES][32] partial row statistics
+    bf16_t* tile_s = reinterpret_cast<bf16_t*>(sk_smem + (size_t)WAVES * 16 * 64 * 4 + (size_t)WAVES * 32 * 8);   // 2 KiB: the c_fc tile
+    int* flag_s = reinterpret_cast<int*>(tile_s + 1024);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, half = lane >> 5;
+    const int L = blockIdx.x, xcd = L & 7, ii = L >> 3;
+    const int T1 = gridDim.x, tpg = T1 >> 3;
+    const int split = xcd % S_, grp = xcd / S_;
+    const int nt2 = grp * tpg + ii;
+    const int nt1 = split * (T1 / S_) + nt2;
+
+    // ---- phase 1: folded c_fc, tile nt1 over the whole K1 (gemm_skinny_kernel<8, true>, long-range path) ----
+    const int ks0 = wave * KPW;
+    const u32x4* wptr = reinterpret_cast<const u32x4*>(W1_) + ((size_t)nt1 * KS1_ + ks0) * 64 + lane;
+    const u32x4* xptr = reinterpret_cast<const u32x4*>(x1_) + (size_t)ks0 * 64 + lane;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    SkChunk<CH> ck[NB];
+    float fs1 = 0.f, fs2 = 0.f;
+    auto fold_acc = [&](const u32x4& xv) {
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float a = __uint_as_float(xv[w] << 16), b = __uint_as_float(xv[w] & 0xffff0000u);
+            fs1 += a + b;
+            fs2 = fmaf(a, a, fmaf(b, b, fs2));
+        }
+    };
+#pragma unroll
+    for (int b = 0; b < NB; ++b) sk_load_full<CH>(ck[b], wptr, xptr, b * CH);
+    const MlpFusedArgs p = sv_late_args<MlpFusedArgs>(offsetof(MlpFusedKernarg, p));
+    float c2v[RPW], c1v[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = wave * RPW + i;
+        const int n = nt1 * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+        c1v[i] = n < p.N1 ? p.fold_c1[n] : 0.f;
+        c2v[i] = n < p.N1 ? p.fold_c2[n] : 0.f;
+    }
+    sk_settle<RPW>(c2v, c1v);
+#pragma unroll
+    for (int ks = 0; ks < KPW; ks += NB * CH) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(ck[b].w[u]), as_frag4(ck[b].x[u]), acc, 0, 0, 0);
+                fold_acc(ck[b].x[u]);
+            }
+            if (ks + (b + NB) * CH < KPW) {
+                __builtin_amdgcn_sched_barrier(0);
+                sk_load_full<CH>(ck[b], wptr, xptr, ks + (b + NB) * CH);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // the down projection's weights of this wave (tile nt2, k-steps split * 128 + wave * 16 .. + 16: 16 KiB) depend on nothing: request
+    // them now.  Waves 0 / 1 publish the tile below and must drain their stores with vmcnt(0) (loads and stores share the counter), so
+    // they request theirs after that.
+    const int ks2 = split * (WAVES * KPW) + wave * KPW;
+    const u32x4* w2ptr = reinterpret_cast<const u32x4*>(W2_) + ((size_t)nt2 * KS2_ + ks2) * 64 + lane;
+    u32x4 w2[KPW];
+    if (wave >= 2) {
+#pragma unroll
+        for (int u = 0; u < KPW; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
+    }
+
+    // K reduction across the waves (wave order) + LayerNorm fold epilogue: gemm_skinny_kernel<8, true>'s, value for value
+    float v[RPW];
+    fs1 += __shfl_xor(fs1, 32, 64);
+    fs2 += __shfl_xor(fs2, 32, 64);
+    if (half == 0) fst_s[wave * 32 + m] = make_float2(fs1, fs2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = wave * RPW + i;
+        float t = red[0][r][lane];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) t += red[w][r][lane];
+        v[i] = t;
+    }
+    {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < WAVES; ++q) { const float2 t = fst_s[q * 32 + m]; s1 += t.x; s2 += t.y; }
+        const float invD = 1.0f / (float)p.fold_D;
+        const float mean = s1 * invD;
+        float var = s2 * invD - mean * mean;
+        var = var > 0.f ? var : 0.f;
+        const float rstd = rsqrtf(var + p.fold_eps);
+        const int r = wave * RPW;
+        const int nl = 8 * (r >> 2) + 4 * half + (r & 3);                 // local column of v[0] (v[1]: + 1)
+        float o[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            float x = 0.f;
+            if (nt1 * 32 + nl + i < p.N1) {
+                x = bfround(rstd * (v[i] - mean * c1v[i]) + c2v[i]);
+                if (p.act != ACT_NONE) x = sv_act(x, p.act);
+            }
+            o[i] = x;
+        }
+        // the tile in fragment order (the image xp_index addresses: [k-step nl >> 4][64 lanes][8])
+        *reinterpret_cast<uint32_t*>(tile_s + (((nl >> 4) * 64 + ((nl >> 3) & 1) * 32 + m) * 8 + (nl & 7))) = pack2bf(o[0], o[1]);
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs_act = __builtin_amdgcn_make_buffer_rsrc(p.out_xp, 0, (unsigned)((size_t)p.out_KS * 1024), 0x00020000);
+    if (wave < 2) {
+        const u32x4 q = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(tile_s) + tid * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(q, rs_act, nt1 * 2048 + tid * 16, 0, 16);          // sc1: write-through
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < KPW; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __hip_atomic_fetch_add(p.cnt + split, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned want = (unsigned)(T1 / S_);
+        int ok = 0;
+        for (int it = 0; it < p.spin_limit; ++it) {
+            if (__hip_atomic_load(p.cnt + split, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (!ok) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // give up: the step's result is void
+        flag_s[0] = ok;
+    }
+    __syncthreads();
+
+    // ---- phase 2: down projection (tile nt2, K slice `split`) -> fp32 slab, gemm_skinny_kernel<8, false>'s order ----
+    u32x4 x2[KPW];
+#pragma unroll
+    for (int u = 0; u < KPW; ++u) x2[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, (ks2 + u) * 1024 + lane * 16, 0, 16);   // sc1: L1 bypass
+    __builtin_amdgcn_sched_barrier(0);                // all 16 requests in flight before the first MFMA: ONE round trip, not five
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < KPW; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(w2[u]), as_frag4(x2[u]), acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = wave * RPW + i;
+        float t = red[0][r][lane];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) t += red[w][r][lane];
+        v[i] = t;
+    }
+    {
+        const int r = wave * RPW;
+        const int n0 = nt2 * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+        *reinterpret_cast<float2*>(p.ws + ((size_t)split * p.rows_ws + m) * p.ldws + n0) = make_float2(v[0], v[1]);
+    }
+}
+static size_t mlp_fused_smem() { return (size_t)8 * 16 * 64 * 4 + (size_t)8 * 32 * 8 + 2048 + 64; }
+
+// 0 = launched; -1 = the shapes are outside the kernel's scope (the caller runs the two launches)
+int launch_mlp_fused(const MlpFusedArgs& a, hipStream_t st) {
+    const int KS1 = a.K1 / 16, KS2 = a.K2 / 16, T1 = a.N1pad / 32, T2 = a.N2pad / 32;
+    if (a.splitk < 1 || 8 % a.splitk || T1 % 8 || KS1 != 8 * 16 || KS2 != a.splitk * 8 * 16) return -1;      // 16 k-steps per wave in both phases
+    if (T2 * a.splitk != T1 || a.K2 != a.N1pad || a.N1 != a.N1pad || a.N2 != a.N2pad) return -1;
+    if (!a.cnt || !a.err || !a.fold_c1 || !a.fold_c2) return -1;
+    mlp_fused_kernel<<<T1, 512, mlp_fused_smem(), st>>>(a.W1, a.x1, a.W2, KS1, KS2, a.splitk, a);
+    return 0;
+}
+
 static size_t skinny_smem(int waves) { return (size_t)waves * 16 * 64 * 4 + (size_t)waves * 32 * 8 + 16; }
 
 static int init_mt2_attrs();

@@ -71,6 +71,21 @@ int init_gemm_kernels();        // hipFuncSetAttribute for the large-LDS variant
 
 void launch_cvt_bf16_hw(const float* x, bf16_t* y, size_t n, hipStream_t st);
 
+// ---- the MLP half of a decode layer as one launch (gemm.hip: mlp_fused_kernel; round-4 experiment, SV_EXP bit 128) ----
+struct MlpFusedArgs {
+    const bf16_t* W1; const bf16_t* x1;      // folded c_fc image W' [N1pad/32][K1/16][64][8], raw residual stream in fragment order
+    int N1, N1pad, K1;
+    const float* fold_c1; const float* fold_c2; int fold_D; float fold_eps; int act;
+    bf16_t* out_xp; int out_KS;              // the GELU output in fragment order (N1pad = 16 * out_KS columns): phase 2's operand
+    const bf16_t* W2; int N2, N2pad, K2;     // down projection, K2 == N1pad
+    int splitk;                              // K slices of the down projection = fp32 slabs
+    float* ws; int ldws; int rows_ws;        // slabs [splitk][rows_ws][ldws]
+    unsigned* cnt;                           // [splitk] arrival counters, ZERO at launch (zeroed by the kernel in front)
+    int* err;                                // set to 3 when a block gives up waiting (never a hang)
+    int spin_limit;                          // polls before giving up
+};
+int launch_mlp_fused(const MlpFusedArgs& a, hipStream_t st);
+
 // ---- attention output projection without slabs + LayerNorm fold (decode_cols.hip) ------------------
 struct ColsArgs {
     const bf16_t* xp;                // packed activations [MT][K/16][64][8]
@@ -79,6 +94,7 @@ struct ColsArgs {
     int MT, N, K;                    // K multiple of 32
     int cpb;                         // output columns per block (<= 32): cols_pick_cpb(N, K)
     bf16_t* h_xp; int out_KS;        // residual stream in fragment order, N = 16 * out_KS columns: h = bf(h + bf(x W^T + b)), in place
+    unsigned* zero_words; int n_zero; // optional: words block (0, 0) clears (the fused MLP launch behind it finds its counters zero)
 };
 int cols_pick_cpb(int N, int K);
 int launch_gemm_cols(const ColsArgs& a, hipStream_t st);        // 0 = ok, -1 = unsupported shape

@@ -824,3 +824,34 @@ def test_from_pretrained_reference_format_directory_matches_hf_generate(tmp_path
     assert torch.equal(r16["outputs"].cpu(), res["outputs"].cpu())
     model.engine.close()
     m16.engine.close()
+
+
+def test_fused_mlp_launch_equals_the_two_launches_bit_for_bit():
+    """Round-4 experiment (SV_EXP bit 128, gemm.hip mlp_fused_kernel): c_fc + GELU + down projection of a decode layer as ONE launch of
+    256 co-resident blocks with an in-launch hand-off (write-through stores, one ticket per K slice, bounded polling).  Per-wave k
+    ranges, MFMA order, reduction order and epilogues are those of the two kernels it replaces, so logits and tokens must be IDENTICAL
+    bit for bit -- at BASELINE config 2's size (the geometry it is built for), eager and under the hipGraph loop."""
+    import starvector_amd as sva
+    B = 32
+    eng = sva.HipEngine(sva.EngineConfig(max_batch=B, max_seq_len=259 + 160))
+    eng.load_random_weights(seed=7)
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(B, 3, 224, 224, generator=g).to(torch.bfloat16).to(dev())
+    prompt = torch.tensor([[7, 11]] * B, dtype=torch.long, device=dev())
+    emb = torch.cat([eng.adapter(eng.encode_image(img)), eng.embed_tokens(prompt)], 1)
+    runs = {}
+    for mask in (0, 128):
+        eng.set_exp(mask)
+        lg = [eng.prefill(emb)]
+        tok = lg[0].argmax(-1)
+        for _ in range(6):
+            lg.append(eng.decode_step(tok))
+            tok = lg[-1].argmax(-1)
+        toks = eng.generate(emb, max_length=emb.shape[1] + 150, eos_token_id=-1, pad_token_id=49152)
+        assert eng.last_timing()["graph"]
+        runs[mask] = (torch.stack(lg).cpu(), toks.cpu())
+    eng.set_exp(0)
+    assert torch.equal(runs[0][0], runs[128][0]), "fused MLP launch changes the logits"
+    assert torch.equal(runs[0][1], runs[128][1]), "fused MLP launch changes the token stream"
+    assert runs[0][1].unique().numel() > 8                                  # not a degenerate stream
+    eng.close()

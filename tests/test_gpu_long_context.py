@@ -271,7 +271,7 @@ def _page_swap_sensitivity(w, cfg, cache, last_tok, o_next_logits, page_a, page_
     return float((lg.float() - o_next_logits).abs().max()) / tol_abs
 
 
-def _teacher_forced_long(eng, emb, o_toks, o_lg, tag, min_checked):
+def _teacher_forced_long(eng, emb, o_toks, o_lg, tag, min_checked, max_near=0.1):
     """The engine is fed the oracle's tokens; logits within LOGIT_TOL * scale at every step, tokens exact outside twice that band."""
     B, n_new = o_toks.shape
     scale = float(o_lg.abs().max())
@@ -295,6 +295,7 @@ def _teacher_forced_long(eng, emb, o_toks, o_lg, tag, min_checked):
            f"{checked}/{B * n_new} positions token-exact outside the band, {near} near-tie flips inside it")
     print(msg)
     assert checked >= min_checked * B * n_new, msg
+    assert near <= max_near * B * n_new, msg                       # in-band flips are legitimate near-ties, but a regression shows as more of them
     return worst / scale
 
 
@@ -327,7 +328,10 @@ def test_config2_batch32_long_contexts(config2, S0, n_new, chunk):
     emb = _synthetic_prompt(B, S0, cfg.hidden, 1000 + S0)
     o_toks, o_lg, cache = _oracle_long(w_dev, cfg, emb, n_new, chunk)
     tag = f"config2 B=32 context {S0}->{S0 + n_new}"
-    _teacher_forced_long(eng, emb, o_toks, o_lg, tag, 0.6)
+    # coverage floor: a synthetic N(0, 0.5) prompt leaves the random-init model with flatter logits than an image prompt does --
+    # measured 28 / 28 / 33 % of the positions have a top-1/top-2 margin outside the band (217/768, 291/1024, 209/640; 18-35 in-band
+    # near-tie flips); EVERY one of them must be token-exact and EVERY position's logits in tolerance
+    _teacher_forced_long(eng, emb, o_toks, o_lg, tag, 0.2, max_near=0.06)
     # discriminating power of THIS case: swap one far page for another in the oracle's cache and look at its own logits
     with torch.no_grad():
         ref_next, _ = O.decoder_decode_step(w_dev, cfg, o_toks[:, -1], cache, "bf16")

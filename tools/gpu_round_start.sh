@@ -30,9 +30,9 @@ for s in "${STEPS[@]}"; do
     # -s -rA: the parity tests PRINT what they measured (max|err|, scale, checked / near-tie counts, comparator ratios); the numbers are
     # the evidence, so the full log is kept and the "[tag] ..." lines are cut out next to it
     pytest) timeout 1500 python -m pytest tests -m gpu -q -x -s -rA 2>&1 | grep -v amdgpu.ids > "$OUT/pytest_gpu_full.log"
-            grep -E "^\[|passed|failed|error" "$OUT/pytest_gpu_full.log" > "$OUT/pytest_gpu.log"; tail -4 "$OUT/pytest_gpu.log" ;;
+            grep -oE "\[[A-Za-z0-9][^]]*\] .*|^.*(passed|failed).*$|^(FAILED|ERROR).*$" "$OUT/pytest_gpu_full.log" > "$OUT/pytest_gpu.log"; tail -4 "$OUT/pytest_gpu.log" ;;
     pytest:*) timeout 1500 python -m pytest tests -m gpu -q -x -s -rA -k "${s#pytest:}" 2>&1 | grep -v amdgpu.ids > "$OUT/pytest_gpu_k_full.log"
-            grep -E "^\[|passed|failed|error|Error|assert" "$OUT/pytest_gpu_k_full.log" > "$OUT/pytest_gpu_k.log"; tail -25 "$OUT/pytest_gpu_k.log" ;;
+            grep -oE "\[[A-Za-z0-9][^]]*\] .*|^.*(passed|failed|Error|assert).*$|^(FAILED|ERROR).*$" "$OUT/pytest_gpu_k_full.log" > "$OUT/pytest_gpu_k.log"; tail -25 "$OUT/pytest_gpu_k.log" ;;
     bench) timeout 400 python bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"; cat "$OUT/bench_n1.json" ;;
     bench8b)
       timeout 300 python bench.py --model 8b --new-tokens 256 --steps 2 --no-cpu-baseline > "$OUT/bench_8b_im2svg.json" 2> "$OUT/bench_8b_im2svg.err"
