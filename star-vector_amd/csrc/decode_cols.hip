@@ -133,7 +133,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_cols_resid_kernel(const bf16_
         if (ci + 3 * G < nc) load(gb, ci + 3 * G);
     }
 
-    if (j == 0 && mt == 0 && tid < 8) {
+    if (j == 0 && mt == 0) {
         // ColsArgs::zero_words: counters of the launch BEHIND this one (mlp_fused_kernel); read late, off the critical path
         const ColsArgs pl = sv_late_args<ColsArgs>(offsetof(ColsKernarg, p));
         if (pl.zero_words && tid < pl.n_zero) pl.zero_words[tid] = 0u;

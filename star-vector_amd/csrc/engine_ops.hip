@@ -119,6 +119,20 @@ extern "C" int sv_debug_attn_decode(sv_engine* e, int32_t layer, const float* de
     return 0;
 }
 
+// SV_MLP_TRACE=1 at sv_create: wall-clock stamps (100 MHz ticks) of the fused MLP launch of the middle layer of the LAST decode step,
+// host_out [blocks][8] = {start, c_fc loop done, tile published, slice complete, end, XCC id, 0, 0}; returns the number of blocks
+extern "C" int sv_debug_mlp_trace(sv_engine* e, int64_t* host_out, int32_t capacity_blocks) {
+    if (!e || !host_out) return fail(SV_EINVAL, "sv_debug_mlp_trace: null argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->mlp_trace) return fail(SV_ESTATE, "sv_debug_mlp_trace: the engine was not created with SV_MLP_TRACE=1 (or the fused MLP launch does not fit it)");
+    const int T1 = e->dec[0].c_fc.Npad / 32;
+    if (capacity_blocks < T1) return fail(SV_EINVAL, "sv_debug_mlp_trace: capacity %d < %d blocks", capacity_blocks, T1);
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(host_out, e->mlp_trace, (size_t)T1 * 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return T1;
+}
+
 extern "C" int sv_debug_set_col_tiles(int32_t col_tiles) {
     if (col_tiles < 0 || col_tiles > 3) return fail(SV_EINVAL, "sv_debug_set_col_tiles: 0..3");
     g_op_col_tiles = col_tiles;
@@ -320,6 +334,16 @@ extern "C" int sv_bench_linear(int32_t M, int32_t N, int32_t K, int32_t act, int
     fill_random_bf16(bias, (size_t)N, 3u, 64, st);
     fill_random_bf16(C, (size_t)M * N, 4u, 4096, st);
     launch_pack_weight(Wsrc, 0, Wp, N, K, Npad, K, st);
+    if (const char* fill = getenv("SV_BENCH_FILL")) {
+        // evidence for the ceiling claim (cdna guide rule 25): the SAME kernel on zero-filled operands clocks ~20 % higher (DVFS), so a
+        // quoted TF/s must say which fill it ran on.  "zero": everything zero; default: uniform random in [-1, 1)
+        if (!strcmp(fill, "zero")) {
+            HIPCHECK(hipMemsetAsync(A, 0, (size_t)M * K * 2, st));
+            HIPCHECK(hipMemsetAsync(Wp, 0, (size_t)Npad * K * 2, st));
+            HIPCHECK(hipMemsetAsync(C, 0, (size_t)M * N * 2, st));
+            HIPCHECK(hipMemsetAsync(bias, 0, (size_t)N * 2, st));
+        }
+    }
     GemmArgs g;
     g.A = A; g.lda = K; g.Wp = Wp; g.bias = bias; g.R = residual ? C : nullptr; g.ldr = N; g.C = C; g.ldc = N;
     g.M = M; g.N = N; g.K = K; g.act = act; g.out_f32 = 0;

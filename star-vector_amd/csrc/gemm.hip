@@ -1273,11 +1273,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
 //
 //   Phase 1  block L = (xcd = L & 7, i = L >> 3): c_fc tile nt1 = split * (T1 / S) + (xcd / S) * (T1 / 8) + i with split = xcd % S --
 //            the 32 GELU outputs columns of a tile are 2 KiB contiguous in fragment order; they go LDS -> 16-byte sc1 (write-through)
-//            stores, every storing wave drains (vmcnt(0)), one relaxed agent-scope ticket on cnt[split].
+//            stores, every storing wave drains (vmcnt(0)), then the block raises ITS flag word cnt[nt1] (a write-through store).
 //   Phase 2  the same block owns (tile nt2 = (xcd / S) * (T1 / 8) + i, K slice `split`) of the down projection = exactly the
 //            (tile, slice) the XCD-aware assignment of the slab kernel gives block L.  Its activations are the c_fc columns
 //            [2048 split, 2048 (split + 1)) = the tiles of the 64 blocks that share its `split` (and sit on XCDs split, split + 4):
-//            one lane polls cnt[split] (relaxed sc1 loads + s_sleep, BOUNDED: a give-up code in *err instead of a hang), then every
+//            wave 0 polls the slice's 64 flags, one load per poll (relaxed sc1 loads + s_sleep, BOUNDED: a give-up code in *err instead of
+//            a hang), then every
 //            wave reads its 16 KiB of activations with sc1 loads (L1 bypass: no acquire fence needed for write-through data).
 //   Results  per-wave k ranges, MFMA order, cross-wave reduction order, fold statistics and epilogues are those of the two kernels it
 //            replaces: bit-identical slabs (tests/test_gpu_ops.py::test_fused_mlp_equals_the_two_launches).
@@ -1303,6 +1304,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int split = xcd % S_, grp = xcd / S_;
     const int nt2 = grp * tpg + ii;
     const int nt1 = split * (T1 / S_) + nt2;
+    const long long t_start = wall_clock64();             // 100 MHz; only stored when the trace buffer is on (tools/mlp_trace.py)
 
     // ---- phase 1: folded c_fc, tile nt1 over the whole K1 (gemm_skinny_kernel<8, true>, long-range path) ----
     const int ks0 = wave * KPW;
@@ -1349,6 +1351,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
         }
     }
+    const long long t_loop1 = wall_clock64();
     // the down projection's weights of this wave (tile nt2, k-steps split * 128 + wave * 16 .. + 16: 16 KiB) depend on nothing: request
     // them now.  Waves 0 / 1 publish the tile below and must drain their stores with vmcnt(0) (loads and stores share the counter), so
     // they request theirs after that.
@@ -1410,20 +1413,30 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int u = 0; u < KPW; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
     }
     __syncthreads();
-    if (tid == 0) {
-        __hip_atomic_fetch_add(p.cnt + split, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned want = (unsigned)(T1 / S_);
+    // Hand-off WITHOUT a shared counter (first version: one ticket per K slice, 64 arrivals + 64 pollers on one word, all four words in one
+    // cache line -- the fused launch took 25.5 us against 17.8 for the two launches, profiles/mlp_fused_r04_ab.log; the price list's
+    // "broadcast + fan-in on one counter under streaming load: 13-14 us").  Every producer owns ONE flag word (a plain write-through
+    // store, no read-modify-write); a consumer's wave 0 reads the 64 flags of its slice with ONE load per poll, lane j <- flag j.
+    const int per_slice = T1 / S_;                         // 64 (launcher)
+    const long long t_pub = wall_clock64();
+    if (tid == 0) __hip_atomic_store(p.cnt + nt1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave == 0) {
         int ok = 0;
         for (int it = 0; it < p.spin_limit; ++it) {
-            if (__hip_atomic_load(p.cnt + split, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) { ok = 1; break; }
-            __builtin_amdgcn_s_sleep(4);
+            unsigned f = 1u;
+            if (lane < per_slice) f = __hip_atomic_load(p.cnt + split * per_slice + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__all(f != 0u)) { ok = 1; break; }
+            __builtin_amdgcn_s_sleep(16);
         }
-        if (!ok) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // give up: the step's result is void
-        flag_s[0] = ok;
+        if (lane == 0) {
+            if (!ok) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // give up: the step's result is void
+            flag_s[0] = ok;
+        }
     }
     __syncthreads();
 
     // ---- phase 2: down projection (tile nt2, K slice `split`) -> fp32 slab, gemm_skinny_kernel<8, false>'s order ----
+    const long long t_go = wall_clock64();
     u32x4 x2[KPW];
 #pragma unroll
     for (int u = 0; u < KPW; ++u) x2[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, (ks2 + u) * 1024 + lane * 16, 0, 16);   // sc1: L1 bypass
@@ -1448,6 +1461,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int n0 = nt2 * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
         *reinterpret_cast<float2*>(p.ws + ((size_t)split * p.rows_ws + m) * p.ldws + n0) = make_float2(v[0], v[1]);
     }
+    if (p.trace && tid == 0) {                              // block L: start | c_fc loop done | tile published | slice complete | end  (wave 0's clock)
+        long long* q = p.trace + (size_t)L * 8;
+        q[0] = t_start; q[1] = t_loop1; q[2] = t_pub; q[3] = t_go; q[4] = wall_clock64(); { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); q[5] = (long long)(xcc & 0xf); }
+    }
 }
 static size_t mlp_fused_smem() { return (size_t)8 * 16 * 64 * 4 + (size_t)8 * 32 * 8 + 2048 + 64; }
 
@@ -1455,6 +1472,7 @@ static size_t mlp_fused_smem() { return (size_t)8 * 16 * 64 * 4 + (size_t)8 * 32
 int launch_mlp_fused(const MlpFusedArgs& a, hipStream_t st) {
     const int KS1 = a.K1 / 16, KS2 = a.K2 / 16, T1 = a.N1pad / 32, T2 = a.N2pad / 32;
     if (a.splitk < 1 || 8 % a.splitk || T1 % 8 || KS1 != 8 * 16 || KS2 != a.splitk * 8 * 16) return -1;      // 16 k-steps per wave in both phases
+    if (T1 / a.splitk > 64) return -1;                                                                       // one poll load covers a slice's flags
     if (T2 * a.splitk != T1 || a.K2 != a.N1pad || a.N1 != a.N1pad || a.N2 != a.N2pad) return -1;
     if (!a.cnt || !a.err || !a.fold_c1 || !a.fold_c2) return -1;
     mlp_fused_kernel<<<T1, 512, mlp_fused_smem(), st>>>(a.W1, a.x1, a.W2, KS1, KS2, a.splitk, a);

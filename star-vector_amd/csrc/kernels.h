@@ -80,9 +80,10 @@ struct MlpFusedArgs {
     const bf16_t* W2; int N2, N2pad, K2;     // down projection, K2 == N1pad
     int splitk;                              // K slices of the down projection = fp32 slabs
     float* ws; int ldws; int rows_ws;        // slabs [splitk][rows_ws][ldws]
-    unsigned* cnt;                           // [splitk] arrival counters, ZERO at launch (zeroed by the kernel in front)
+    unsigned* cnt;                           // [N1pad / 32] one flag word per producer block, ZERO at launch (zeroed by the kernel in front)
     int* err;                                // set to 3 when a block gives up waiting (never a hang)
     int spin_limit;                          // polls before giving up
+    long long* trace;                        // optional [N1pad / 32][8] wall-clock stamps per block (tools/mlp_trace.py); nullptr in production
 };
 int launch_mlp_fused(const MlpFusedArgs& a, hipStream_t st);
 

@@ -325,6 +325,15 @@ class HipEngine:
         """Experiment bit mask (SV_EXP) of the live engine: in-process A/B runs (tools/ab_exp.py)."""
         check(self.lib.sv_debug_set_exp(self._h, int(mask)), "sv_debug_set_exp")
 
+    def debug_mlp_trace(self) -> torch.Tensor:
+        """[blocks, 8] int64 wall-clock stamps (100 MHz) of the last fused MLP launch of the middle layer (engine created with
+        SV_MLP_TRACE=1 in the environment; include/starvector_hip.h, sv_debug_mlp_trace)."""
+        buf = (C.c_int64 * (1024 * 8))()
+        n = self.lib.sv_debug_mlp_trace(self._h, buf, 1024)
+        if n < 0:
+            check(n, "sv_debug_mlp_trace")
+        return torch.tensor(list(buf[: n * 8]), dtype=torch.int64).view(n, 8)
+
     def debug_kv_load(self, layer: int, kv: torch.Tensor, lens: Optional[torch.Tensor] = None) -> None:
         """Test surface of the decode attention (include/starvector_hip.h, sv_debug_kv_load): kv [B, S, 2 * n_kv_head * head_dim]
         bf16 (k heads | v heads, K as cached) becomes tokens 0..S-1 of `layer`'s paged KV; every row's position is set to S, or to
