@@ -133,10 +133,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_cols_resid_kernel(const bf16_
         if (ci + 3 * G < nc) load(gb, ci + 3 * G);
     }
 
-    if (j == 0 && mt == 0) {
-        // ColsArgs::zero_words: counters of the launch BEHIND this one (mlp_fused_kernel); read late, off the critical path
+    if (mt == 0) {
+        // ColsArgs::poison: the activation buffer of the launch BEHIND this one (mlp_fused_kernel) gets its "not written yet" pattern,
+        // every block its share; the arguments are read late, off the critical path
         const ColsArgs pl = sv_late_args<ColsArgs>(offsetof(ColsKernarg, p));
-        if (pl.zero_words && tid < pl.n_zero) pl.zero_words[tid] = 0u;
+        if (pl.poison) {
+            const unsigned share = ((pl.poison_bytes / 16 + gridDim.x - 1) / gridDim.x) * 16;
+            const unsigned lo = j * share, hi = min(lo + share, pl.poison_bytes);
+            const u32x4 ff = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            for (unsigned off = lo + tid * 16; off < hi; off += WAVES * 64 * 16)
+                *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(pl.poison) + off) = ff;
+        }
     }
     // ---- K reduction across the waves (wave order), then one thread per output element / 8-column piece ----
     {

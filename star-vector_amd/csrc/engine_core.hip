@@ -562,8 +562,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         e->mlp_fused_ok = T1 <= e->num_cus && T1 % 8 == 0 && fc.N == fc.Npad && dn.N == dn.Npad && fc.Kpad / 16 == 128 &&
                           dn.splitk >= 1 && 8 % dn.splitk == 0 && dn.Kpad / 16 == dn.splitk * 128 && (dn.Npad / 32) * dn.splitk == T1 &&
                           dn.Kpad == fc.Npad;
-        if (e->mlp_fused_ok) rc = dalloc(e, &e->mlp_cnt, (size_t)T1);
-        if (!rc && e->mlp_fused_ok && getenv("SV_MLP_TRACE")) rc = dalloc(e, &e->mlp_trace, (size_t)T1 * 8);
+        if (e->mlp_fused_ok && getenv("SV_MLP_TRACE")) rc = dalloc(e, &e->mlp_trace, (size_t)T1 * 8);
     }
     if (rc) { sv_destroy(e); return rc; }
     *out = e;

@@ -276,7 +276,7 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
             ca.xp = e->xp_attn; ca.Wp = L.c_proj.Wp; ca.bias = L.c_proj.bias; ca.MT = MT; ca.N = L.c_proj.N; ca.K = L.c_proj.Kpad;
             ca.cpb = L.c_proj.cpb; ca.h_xp = e->h_xp; ca.out_KS = D / 16;
             const bool fused = (e->exp & 128) && e->mlp_fused_ok;                       // round-4 experiment: c_fc + down projection in one launch
-            if (fused) { ca.zero_words = e->mlp_cnt; ca.n_zero = L.c_fc.Npad / 32; }
+            if (fused) { ca.poison = e->xp_mlp; ca.poison_bytes = (unsigned)((size_t)(F / 16) * 1024); }
             if (!e->skip_skinny) { prof_mark(e, PK_SKINNY, st); launch_gemm_cols(ca, st); }
             if (fused) {
                 MlpFusedArgs ma;
@@ -285,7 +285,7 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
                 ma.fold_c1 = L.c_fc.c1; ma.fold_c2 = L.c_fc.c2; ma.fold_D = D; ma.fold_eps = c.ln_eps; ma.act = ACT_GELU_TANH;
                 ma.out_xp = e->xp_mlp; ma.out_KS = F / 16;
                 ma.W2 = L.c_proj2.Wp; ma.N2 = L.c_proj2.N; ma.N2pad = L.c_proj2.Npad; ma.K2 = L.c_proj2.Kpad; ma.splitk = L.c_proj2.splitk;
-                ma.ws = wsB; ma.ldws = e->ldws; ma.rows_ws = MT * 32; ma.cnt = e->mlp_cnt; ma.err = e->d_bad; ma.spin_limit = 1 << 16;
+                ma.ws = wsB; ma.ldws = e->ldws; ma.rows_ws = MT * 32; ma.err = e->d_bad; ma.spin_limit = 1 << 16;
                 ma.trace = (i == c.n_layer / 2) ? e->mlp_trace : nullptr;        // one layer in the middle of the step
                 if (!e->skip_skinny) { prof_mark(e, PK_SKINNY, st); (void)launch_mlp_fused(ma, st); }
                 const LNp& nx = (i + 1 < c.n_layer) ? e->dec[i + 1].ln1 : e->ln_f;

@@ -112,7 +112,6 @@ struct sv_engine {
     bool fold_ready = false;
     bool mlp_fused_ok = false;      // the MLP half as one launch (gemm.hip mlp_fused_kernel) fits this engine: shapes + one block per CU
     long long* mlp_trace = nullptr; // SV_MLP_TRACE=1: wall-clock stamps of the LAST fused MLP launch, [F / 32][8] (sv_debug_mlp_trace)
-    unsigned* mlp_cnt = nullptr;    // its producer flags [F / 32], zeroed by the launch in front of it
     bool only_skinny = false;       // profiling: enqueue only the weight-streaming GEMMs of a step
     bool skip_skinny = false;       // profiling: enqueue everything BUT the weight-streaming GEMMs
     int exp = 0;                    // SV_EXP bit mask, read once at sv_create (A/B switches of the round's experiments):

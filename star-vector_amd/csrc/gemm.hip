@@ -1272,18 +1272,18 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
 //   VGPRs) as soon as its c_fc loop has issued its last MFMA, so that stream runs UNDER the c_fc epilogue, the publish and the wait.
 //
 //   Phase 1  block L = (xcd = L & 7, i = L >> 3): c_fc tile nt1 = split * (T1 / S) + (xcd / S) * (T1 / 8) + i with split = xcd % S --
-//            the 32 GELU outputs columns of a tile are 2 KiB contiguous in fragment order; they go LDS -> 16-byte sc1 (write-through)
-//            stores, every storing wave drains (vmcnt(0)), then the block raises ITS flag word cnt[nt1] (a write-through store).
+//            the 32 GELU output columns of a tile are 2 KiB contiguous in fragment order; they go LDS -> 16-byte sc1 (write-through)
+//            stores.  No flag, no counter, nothing to drain.
 //   Phase 2  the same block owns (tile nt2 = (xcd / S) * (T1 / 8) + i, K slice `split`) of the down projection = exactly the
-//            (tile, slice) the XCD-aware assignment of the slab kernel gives block L.  Its activations are the c_fc columns
-//            [2048 split, 2048 (split + 1)) = the tiles of the 64 blocks that share its `split` (and sit on XCDs split, split + 4):
-//            wave 0 polls the slice's 64 flags, one load per poll (relaxed sc1 loads + s_sleep, BOUNDED: a give-up code in *err instead of
-//            a hang), then every
-//            wave reads its 16 KiB of activations with sc1 loads (L1 bypass: no acquire fence needed for write-through data).
+//            (tile, slice) the XCD-aware assignment of the slab kernel gives block L.  Wave w needs the c_fc columns of its 16 k-steps
+//            = the tiles of 8 producer blocks; it reads them with sc1 loads (L1 bypass) and recognises "not written yet" by the data
+//            itself: the launch in front fills the buffer with the bf16 pair 0xFFFF'FFFF (two NaNs -- never a finite GELU output), a
+//            k-step that still shows the pattern is re-requested after an s_sleep, BOUNDED (a give-up code in *err, never a hang).
 //   Results  per-wave k ranges, MFMA order, cross-wave reduction order, fold statistics and epilogues are those of the two kernels it
 //            replaces: bit-identical slabs (tests/test_gpu_ops.py::test_fused_mlp_equals_the_two_launches).
-//   Safety   needs all F/32 blocks resident at once (1 per CU: the engine enables it only when #CUs >= F/32); cnt[] is zeroed by the
-//            kernel in front of it (gemm_cols_resid_kernel), never by this launch.
+//   Safety   needs all F/32 blocks resident at once (1 per CU: the engine enables it only when #CUs >= F/32); the pattern is written by
+//            the kernel in front of it (gemm_cols_resid_kernel, ColsArgs::poison), never by this launch; a NaN activation (a numeric
+//            failure upstream) ends in the give-up code, i.e. in an error from sv_generate, as non-finite logits do.
 // ------------------------------------------------------------------------------------------------
 struct MlpFusedKernarg { const bf16_t* W1; const bf16_t* x1; const bf16_t* W2; int KS1; int KS2; int S; MlpFusedArgs p; };
 // amdgpu_waves_per_eu(2, 2): one 8-wave block per CU is the design point (2 waves per SIMD, 256 VGPRs each); without it the
@@ -1352,16 +1352,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     }
     const long long t_loop1 = wall_clock64();
-    // the down projection's weights of this wave (tile nt2, k-steps split * 128 + wave * 16 .. + 16: 16 KiB) depend on nothing: request
-    // them now.  Waves 0 / 1 publish the tile below and must drain their stores with vmcnt(0) (loads and stores share the counter), so
-    // they request theirs after that.
     const int ks2 = split * (WAVES * KPW) + wave * KPW;
     const u32x4* w2ptr = reinterpret_cast<const u32x4*>(W2_) + ((size_t)nt2 * KS2_ + ks2) * 64 + lane;
     u32x4 w2[KPW];
-    if (wave >= 2) {
-#pragma unroll
-        for (int u = 0; u < KPW; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
-    }
 
     // K reduction across the waves (wave order) + LayerNorm fold epilogue: gemm_skinny_kernel<8, true>'s, value for value
     float v[RPW];
@@ -1404,43 +1397,55 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         *reinterpret_cast<uint32_t*>(tile_s + (((nl >> 4) * 64 + ((nl >> 3) & 1) * 32 + m) * 8 + (nl & 7))) = pack2bf(o[0], o[1]);
     }
     __syncthreads();
+    // ---- hand-off, third version: NO flag and NO counter.  The launch in front of this one (gemm_cols_resid_kernel) fills the whole
+    // activation buffer with the bf16 pair 0xFFFF'FFFF (two NaNs: no finite GELU output has that pattern).  A producer only writes its
+    // 2 KiB tile (write-through 16-byte stores, nothing to wait for); a consumer WAVE polls the 16 KiB it needs itself -- the tiles of
+    // the 8 producers behind its 16 k-steps, not of all 64 producers of the slice -- and re-requests only the k-steps that still
+    // carry the pattern.  History (profiles/mlp_fused_r04_ab.log): one ticket word per K slice: 25.5 us per launch (64 arrivals + 64
+    // pollers per word); one flag word per producer polled by wave 0: 17.7 us = the two launches, with 6 us of "publish" (the store
+    // drained behind 24 MB of weight prefetch) and 4 us of "wait" on the critical path.
     const __amdgpu_buffer_rsrc_t rs_act = __builtin_amdgcn_make_buffer_rsrc(p.out_xp, 0, (unsigned)((size_t)p.out_KS * 1024), 0x00020000);
     if (wave < 2) {
         const u32x4 q = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(tile_s) + tid * 16);
         __builtin_amdgcn_raw_buffer_store_b128(q, rs_act, nt1 * 2048 + tid * 16, 0, 16);          // sc1: write-through
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int u = 0; u < KPW; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
     }
-    __syncthreads();
-    // Hand-off WITHOUT a shared counter (first version: one ticket per K slice, 64 arrivals + 64 pollers on one word, all four words in one
-    // cache line -- the fused launch took 25.5 us against 17.8 for the two launches, profiles/mlp_fused_r04_ab.log; the price list's
-    // "broadcast + fan-in on one counter under streaming load: 13-14 us").  Every producer owns ONE flag word (a plain write-through
-    // store, no read-modify-write); a consumer's wave 0 reads the 64 flags of its slice with ONE load per poll, lane j <- flag j.
-    const int per_slice = T1 / S_;                         // 64 (launcher)
     const long long t_pub = wall_clock64();
-    if (tid == 0) __hip_atomic_store(p.cnt + nt1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wave == 0) {
-        int ok = 0;
-        for (int it = 0; it < p.spin_limit; ++it) {
-            unsigned f = 1u;
-            if (lane < per_slice) f = __hip_atomic_load(p.cnt + split * per_slice + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (__all(f != 0u)) { ok = 1; break; }
-            __builtin_amdgcn_s_sleep(16);
-        }
-        if (lane == 0) {
-            if (!ok) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // give up: the step's result is void
-            flag_s[0] = ok;
-        }
-    }
-    __syncthreads();
+    // The down projection's weights of this wave (tile nt2, k-steps split * 128 + wave * 16 .. + 16: 16 KiB) depend on nothing.  They are
+    // requested 8 KiB at a time (what the steady state of the stand-alone kernels keeps in flight per wave): all 16 KiB at once put
+    // 24 MB of reads in front of every tile store and every poll of the chip.
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#pragma unroll
+    for (int u = 8; u < 12; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+#pragma unroll
+    for (int u = 12; u < 16; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
 
     // ---- phase 2: down projection (tile nt2, K slice `split`) -> fp32 slab, gemm_skinny_kernel<8, false>'s order ----
-    const long long t_go = wall_clock64();
     u32x4 x2[KPW];
 #pragma unroll
     for (int u = 0; u < KPW; ++u) x2[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, (ks2 + u) * 1024 + lane * 16, 0, 16);   // sc1: L1 bypass
-    __builtin_amdgcn_sched_barrier(0);                // all 16 requests in flight before the first MFMA: ONE round trip, not five
+    unsigned pending = 0xffffu;                              // k-steps whose activations are not (known to be) complete: wave-uniform
+    int gave_up = 1;
+    for (int it = 0; it < p.spin_limit; ++it) {
+        unsigned still = 0u;
+#pragma unroll
+        for (int u = 0; u < KPW; ++u) {
+            if (pending & (1u << u)) {
+                const bool bad = x2[u][0] == 0xffffffffu || x2[u][1] == 0xffffffffu || x2[u][2] == 0xffffffffu || x2[u][3] == 0xffffffffu;
+                if (__any(bad)) still |= 1u << u;
+            }
+        }
+        pending = still;
+        if (!pending) { gave_up = 0; break; }
+        __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+        for (int u = 0; u < KPW; ++u)
+            if (pending & (1u << u)) x2[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, (ks2 + u) * 1024 + lane * 16, 0, 16);
+    }
+    if (gave_up && lane == 0) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the step's result is void
+    const long long t_go = wall_clock64();
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
@@ -1472,9 +1477,8 @@ static size_t mlp_fused_smem() { return (size_t)8 * 16 * 64 * 4 + (size_t)8 * 32
 int launch_mlp_fused(const MlpFusedArgs& a, hipStream_t st) {
     const int KS1 = a.K1 / 16, KS2 = a.K2 / 16, T1 = a.N1pad / 32, T2 = a.N2pad / 32;
     if (a.splitk < 1 || 8 % a.splitk || T1 % 8 || KS1 != 8 * 16 || KS2 != a.splitk * 8 * 16) return -1;      // 16 k-steps per wave in both phases
-    if (T1 / a.splitk > 64) return -1;                                                                       // one poll load covers a slice's flags
     if (T2 * a.splitk != T1 || a.K2 != a.N1pad || a.N1 != a.N1pad || a.N2 != a.N2pad) return -1;
-    if (!a.cnt || !a.err || !a.fold_c1 || !a.fold_c2) return -1;
+    if (!a.err || !a.fold_c1 || !a.fold_c2) return -1;
     mlp_fused_kernel<<<T1, 512, mlp_fused_smem(), st>>>(a.W1, a.x1, a.W2, KS1, KS2, a.splitk, a);
     return 0;
 }

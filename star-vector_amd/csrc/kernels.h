@@ -76,11 +76,11 @@ struct MlpFusedArgs {
     const bf16_t* W1; const bf16_t* x1;      // folded c_fc image W' [N1pad/32][K1/16][64][8], raw residual stream in fragment order
     int N1, N1pad, K1;
     const float* fold_c1; const float* fold_c2; int fold_D; float fold_eps; int act;
-    bf16_t* out_xp; int out_KS;              // the GELU output in fragment order (N1pad = 16 * out_KS columns): phase 2's operand
+    bf16_t* out_xp; int out_KS;              // the GELU output in fragment order (N1pad = 16 * out_KS columns): phase 2's operand;
+                                             // filled with 0xFFFF'FFFF by the launch in front (ColsArgs::poison)
     const bf16_t* W2; int N2, N2pad, K2;     // down projection, K2 == N1pad
     int splitk;                              // K slices of the down projection = fp32 slabs
     float* ws; int ldws; int rows_ws;        // slabs [splitk][rows_ws][ldws]
-    unsigned* cnt;                           // [N1pad / 32] one flag word per producer block, ZERO at launch (zeroed by the kernel in front)
     int* err;                                // set to 3 when a block gives up waiting (never a hang)
     int spin_limit;                          // polls before giving up
     long long* trace;                        // optional [N1pad / 32][8] wall-clock stamps per block (tools/mlp_trace.py); nullptr in production
@@ -95,7 +95,8 @@ struct ColsArgs {
     int MT, N, K;                    // K multiple of 32
     int cpb;                         // output columns per block (<= 32): cols_pick_cpb(N, K)
     bf16_t* h_xp; int out_KS;        // residual stream in fragment order, N = 16 * out_KS columns: h = bf(h + bf(x W^T + b)), in place
-    unsigned* zero_words; int n_zero; // optional: words block (0, 0) clears (the fused MLP launch behind it finds its counters zero)
+    void* poison; unsigned poison_bytes; // optional: a buffer the blocks fill with 0xFF bytes (the fused MLP launch behind this one
+                                     // recognises unwritten activations by that pattern); a multiple of 16 bytes
 };
 int cols_pick_cpb(int N, int K);
 int launch_gemm_cols(const ColsArgs& a, hipStream_t st);        // 0 = ok, -1 = unsupported shape
