@@ -1355,6 +1355,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int ks2 = split * (WAVES * KPW) + wave * KPW;
     const u32x4* w2ptr = reinterpret_cast<const u32x4*>(W2_) + ((size_t)nt2 * KS2_ + ks2) * 64 + lane;
     u32x4 w2[KPW];
+    // The down projection's weights of this wave (tile nt2, k-steps split * 128 + wave * 16 .. + 16: 16 KiB) depend on nothing: the first
+    // half is requested NOW, so that the HBM stream does not pause while the block reduces and publishes (third version: requested after
+    // the publish -- HBM idle for 2.5 us); 8 KiB per wave in flight is what the steady state of the stand-alone kernels keeps (all
+    // 16 KiB at once put 24 MB of reads in front of every tile store of the chip: second version, 6 us from loop end to publish).
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
 
     // K reduction across the waves (wave order) + LayerNorm fold epilogue: gemm_skinny_kernel<8, true>'s, value for value
     float v[RPW];
@@ -1410,17 +1416,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         __builtin_amdgcn_raw_buffer_store_b128(q, rs_act, nt1 * 2048 + tid * 16, 0, 16);          // sc1: write-through
     }
     const long long t_pub = wall_clock64();
-    // The down projection's weights of this wave (tile nt2, k-steps split * 128 + wave * 16 .. + 16: 16 KiB) depend on nothing.  They are
-    // requested 8 KiB at a time (what the steady state of the stand-alone kernels keeps in flight per wave): all 16 KiB at once put
-    // 24 MB of reads in front of every tile store and every poll of the chip.
+    // second half of the weights (the first half has landed during the reduction), then -- once half of THAT is in -- the activations:
+    // their producers publish at about the same time as this block, and a request that finds the pattern costs a whole extra round trip
 #pragma unroll
-    for (int u = 0; u < 8; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
+    for (int u = 8; u < 16; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#pragma unroll
-    for (int u = 8; u < 12; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-#pragma unroll
-    for (int u = 12; u < 16; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
 
     // ---- phase 2: down projection (tile nt2, K slice `split`) -> fp32 slab, gemm_skinny_kernel<8, false>'s order ----
     u32x4 x2[KPW];
