@@ -474,6 +474,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     if (e->ldws < D) e->ldws = D;
     A(dalloc(e, &e->h_dec, R * D));
     A(dalloc(e, &e->h_xp, R * D));
+    A(dalloc(e, &e->h_xp2, R * D));
     A(dalloc(e, &e->hl, R * D));
     A(dalloc(e, &e->xp_a, R * D));
     A(dalloc(e, &e->xp_attn, R * D));
@@ -562,6 +563,8 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         e->mlp_fused_ok = T1 <= e->num_cus && T1 % 8 == 0 && fc.N == fc.Npad && dn.N == dn.Npad && fc.Kpad / 16 == 128 &&
                           dn.splitk >= 1 && 8 % dn.splitk == 0 && dn.Kpad / 16 == dn.splitk * 128 && (dn.Npad / 32) * dn.splitk == T1 &&
                           dn.Kpad == fc.Npad;
+        const Linear& cp = e->dec[0].c_proj;
+        e->proj_fused_ok = e->mlp_fused_ok && cp.cpb == 8 && cp.Kpad == 2048 && cp.N == D && D == 8 * T1 && e->MT == 1;
         if (e->mlp_fused_ok && getenv("SV_MLP_TRACE")) rc = dalloc(e, &e->mlp_trace, (size_t)T1 * 8);
     }
     if (rc) { sv_destroy(e); return rc; }

@@ -1288,6 +1288,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
 struct MlpFusedKernarg { const bf16_t* W1; const bf16_t* x1; const bf16_t* W2; int KS1; int KS2; int S; MlpFusedArgs p; };
 // amdgpu_waves_per_eu(2, 2): one 8-wave block per CU is the design point (2 waves per SIMD, 256 VGPRs each); without it the
 // scheduler trades registers for a third wave that can never exist and serialises phase 2's 16 activation loads 3 at a time
+// PROJ: the attention output projection (decode_cols.hip: gemm_cols_resid_kernel, 8 columns per block) runs as PHASE 0 of the same launch
+// (SV_EXP bit 256): block L finishes h_new[:, 8 L .. 8 L + 8) = bf(h_old + bf(x_attn W_c^T + b)) and publishes it (write-through) into
+// the OTHER buffer of a residual-stream ping-pong, pre-filled with the "not written yet" pattern; phase 1 then reads its activations --
+// the whole new residual stream, all 256 producers -- by the same in-band polling as phase 2, with its c_fc weights already in
+// registers (requested at the very start of the launch, behind phase 0's own loads).  One boundary and one cold start less per layer.
+template <bool PROJ>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_fused_kernel(const bf16_t* W1_, const bf16_t* x1_, const bf16_t* W2_, int KS1_, int KS2_, int S_,
                                                         MlpFusedArgs p_unused) {
     constexpr int WAVES = 8, CH = 4, NB = 2, RPW = 2, KPW = 16;          // k-steps per wave in BOTH phases (host-checked)
@@ -1305,6 +1311,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int nt2 = grp * tpg + ii;
     const int nt1 = split * (T1 / S_) + nt2;
     const long long t_start = wall_clock64();             // 100 MHz; only stored when the trace buffer is on (tools/mlp_trace.py)
+    long long t_p0 = 0;                                   // PROJ: phase 0's piece published
 
     // ---- phase 1: folded c_fc, tile nt1 over the whole K1 (gemm_skinny_kernel<8, true>, long-range path) ----
     const int ks0 = wave * KPW;
@@ -1313,7 +1320,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    SkChunk<CH> ck[NB];
     float fs1 = 0.f, fs2 = 0.f;
     auto fold_acc = [&](const u32x4& xv) {
 #pragma unroll
@@ -1323,31 +1329,142 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             fs2 = fmaf(a, a, fmaf(b, b, fs2));
         }
     };
-#pragma unroll
-    for (int b = 0; b < NB; ++b) sk_load_full<CH>(ck[b], wptr, xptr, b * CH);
-    const MlpFusedArgs p = sv_late_args<MlpFusedArgs>(offsetof(MlpFusedKernarg, p));
+    MlpFusedArgs p;
     float c2v[RPW], c1v[RPW];
+    auto late = [&]() {
+        p = sv_late_args<MlpFusedArgs>(offsetof(MlpFusedKernarg, p));
 #pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        const int r = wave * RPW + i;
-        const int n = nt1 * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-        c1v[i] = n < p.N1 ? p.fold_c1[n] : 0.f;
-        c2v[i] = n < p.N1 ? p.fold_c2[n] : 0.f;
-    }
-    sk_settle<RPW>(c2v, c1v);
+        for (int i = 0; i < RPW; ++i) {
+            const int r = wave * RPW + i;
+            const int n = nt1 * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+            c1v[i] = n < p.N1 ? p.fold_c1[n] : 0.f;
+            c2v[i] = n < p.N1 ? p.fold_c2[n] : 0.f;
+        }
+    };
+    // in-band polling (see the hand-off note below): 16 k-steps of activations through sc1 loads; a k-step that still shows the
+    // pattern 0xFFFF'FFFF anywhere in the wave is re-requested after an s_sleep.  Returns true when it gave up.
+    auto poll16 = [&](u32x4 (&xx)[KPW], const __amdgpu_buffer_rsrc_t& rs, int ks_first, int limit) -> bool {
 #pragma unroll
-    for (int ks = 0; ks < KPW; ks += NB * CH) {
+        for (int u = 0; u < KPW; ++u) xx[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (ks_first + u) * 1024 + lane * 16, 0, 16);   // sc1: L1 bypass
+        unsigned pending = 0xffffu;                          // k-steps not (known to be) complete: wave-uniform
+        for (int it = 0; it < limit; ++it) {
+            unsigned still = 0u;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(ck[b].w[u]), as_frag4(ck[b].x[u]), acc, 0, 0, 0);
-                fold_acc(ck[b].x[u]);
+            for (int u = 0; u < KPW; ++u) {
+                if (pending & (1u << u)) {
+                    const bool bad = xx[u][0] == 0xffffffffu || xx[u][1] == 0xffffffffu || xx[u][2] == 0xffffffffu || xx[u][3] == 0xffffffffu;
+                    if (__any(bad)) still |= 1u << u;
+                }
             }
-            if (ks + (b + NB) * CH < KPW) {
-                __builtin_amdgcn_sched_barrier(0);
-                sk_load_full<CH>(ck[b], wptr, xptr, ks + (b + NB) * CH);
-                __builtin_amdgcn_sched_barrier(0);
+            pending = still;
+            if (!pending) return false;
+            __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+            for (int u = 0; u < KPW; ++u)
+                if (pending & (1u << u)) xx[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (ks_first + u) * 1024 + lane * 16, 0, 16);
+        }
+        return true;
+    };
+    if constexpr (PROJ) {
+        // ---- phase 0: the attention output projection, columns 8 L .. 8 L + 8 over the whole K0 (gemm_cols_resid_kernel<16, 2, 1> with cpb = 8:
+        // wave w plays its waves 2 w and 2 w + 1 -- same chunk ranges, same MFMA order, same 16-way reduction order: bit-identical) ----
+        float* red_v = reinterpret_cast<float*>(sk_smem);                 // [16 virtual waves][512] (aliases `red`: 32 KiB)
+        float* ctile = reinterpret_cast<float*>(flag_s + 4);                // [32][17] finished x W^T
+        const int r16 = lane & 15, g4 = lane >> 4;
+        const int n0c = L * 8 + r16;
+        const bool wvalid = r16 < 8;
+        const int nn = wvalid ? n0c : 0;
+        // the kernarg struct is needed at once here (K0, the operands): read it first; it is a scalar load behind NO earlier global load
+        late();
+        const int KS0 = p.K0 >> 4;
+        u32x4 cw[2][4], cx[2][4][2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int c0 = (2 * wave + h2) * 4;                             // chunks of 32 k: 4 per virtual wave (K0 = 2048, launcher)
+            const u32x4* wb = reinterpret_cast<const u32x4*>(p.Wc) + ((size_t)(nn >> 5) * KS0 + (g4 >> 1)) * 64 + (nn & 31) + 32 * (g4 & 1) + (size_t)c0 * 128;
+            const u32x4* xb = reinterpret_cast<const u32x4*>(p.x0) + (size_t)(g4 >> 1) * 64 + r16 + 32 * (g4 & 1) + (size_t)c0 * 128;
+            const u32x4 zero4 = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                cw[h2][u] = zero4;
+                if (wvalid) cw[h2][u] = __builtin_nontemporal_load(wb + (size_t)u * 128);
+                cx[h2][u][0] = xb[(size_t)u * 128];
+                cx[h2][u][1] = xb[(size_t)u * 128 + 16];
+            }
+        }
+        // old residual piece + bias of the 32 finishing threads (row tid, the block's 8 columns): they depend on nothing either
+        uint4 v_res = make_uint4(0u, 0u, 0u, 0u), v_bias = make_uint4(0u, 0u, 0u, 0u);
+        const size_t v_idx = xp_index(0, p.N0 >> 4, tid & 31, L * 8);
+        if (tid < 32) {
+            if (p.bias_c) v_bias = *reinterpret_cast<const uint4*>(p.bias_c + L * 8);
+            v_res = *reinterpret_cast<const uint4*>(p.h_old + v_idx);
+        }
+        // phase 1's weights (16 KiB per wave) queue up behind phase 0's loads NOW: they stream while phase 0 computes and publishes
+        u32x4 w1[KPW];
+#pragma unroll
+        for (int u = 0; u < KPW; ++u) w1[u] = __builtin_nontemporal_load(wptr + (size_t)u * 64);
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag4(cw[h2][u]), as_frag4(cx[h2][u][0]), a0, 0, 0, 0);
+                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag4(cw[h2][u]), as_frag4(cx[h2][u][1]), a1, 0, 0, 0);
+            }
+            float* my = red_v + (2 * wave + h2) * 512;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { my[q * 64 + lane] = a0[q]; my[(4 + q) * 64 + lane] = a1[q]; }
+        }
+        __syncthreads();
+        {
+            float s = red_v[tid];
+#pragma unroll
+            for (int w = 1; w < 16; ++w) s += red_v[w * 512 + tid];
+            const int hb = (tid >> 8) & 1, q = (tid >> 6) & 3, ln = tid & 63;
+            ctile[(16 * hb + (ln & 15)) * 17 + 4 * (ln >> 4) + q] = s;
+        }
+        __syncthreads();
+        const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x1_), 0, (unsigned)((size_t)KS1_ * 1024), 0x00020000);
+        if (tid < 32) {
+            float rr[8], bb[8], hn[8];
+            unpack8(v_res, rr);
+            unpack8(v_bias, bb);
+#pragma unroll
+            for (int e2 = 0; e2 < 8; ++e2) hn[e2] = bfround(rr[e2] + bfround(ctile[tid * 17 + e2] + bb[e2]));      // h = bf(h + bf(x W^T + b))
+            const uint4 o = pack8(hn);
+            const u32x4 ov = {o.x, o.y, o.z, o.w};
+            __builtin_amdgcn_raw_buffer_store_b128(ov, rs_h, (int)(v_idx * 2), 0, 16);                                 // sc1: write-through
+        }
+        t_p0 = wall_clock64();
+        __syncthreads();                                     // `red` is reused by phase 1's reduction
+        // ---- phase 1 proper: the wave's 16 k-steps of the NEW residual stream (32 producers behind them), weights already here ----
+        u32x4 x1v[KPW];
+        if (poll16(x1v, rs_h, ks0, p.spin_limit) && lane == 0) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int u = 0; u < KPW; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(w1[u]), as_frag4(x1v[u]), acc, 0, 0, 0);
+            fold_acc(x1v[u]);
+        }
+    } else {
+        SkChunk<CH> ck[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) sk_load_full<CH>(ck[b], wptr, xptr, b * CH);
+        late();
+        sk_settle<RPW>(c2v, c1v);
+#pragma unroll
+        for (int ks = 0; ks < KPW; ks += NB * CH) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(ck[b].w[u]), as_frag4(ck[b].x[u]), acc, 0, 0, 0);
+                    fold_acc(ck[b].x[u]);
+                }
+                if (ks + (b + NB) * CH < KPW) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    sk_load_full<CH>(ck[b], wptr, xptr, ks + (b + NB) * CH);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
     }
@@ -1424,27 +1541,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // ---- phase 2: down projection (tile nt2, K slice `split`) -> fp32 slab, gemm_skinny_kernel<8, false>'s order ----
     u32x4 x2[KPW];
-#pragma unroll
-    for (int u = 0; u < KPW; ++u) x2[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, (ks2 + u) * 1024 + lane * 16, 0, 16);   // sc1: L1 bypass
-    unsigned pending = 0xffffu;                              // k-steps whose activations are not (known to be) complete: wave-uniform
-    int gave_up = 1;
-    for (int it = 0; it < p.spin_limit; ++it) {
-        unsigned still = 0u;
-#pragma unroll
-        for (int u = 0; u < KPW; ++u) {
-            if (pending & (1u << u)) {
-                const bool bad = x2[u][0] == 0xffffffffu || x2[u][1] == 0xffffffffu || x2[u][2] == 0xffffffffu || x2[u][3] == 0xffffffffu;
-                if (__any(bad)) still |= 1u << u;
-            }
-        }
-        pending = still;
-        if (!pending) { gave_up = 0; break; }
-        __builtin_amdgcn_s_sleep(8);
-#pragma unroll
-        for (int u = 0; u < KPW; ++u)
-            if (pending & (1u << u)) x2[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, (ks2 + u) * 1024 + lane * 16, 0, 16);
-    }
-    if (gave_up && lane == 0) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the step's result is void
+    if (poll16(x2, rs_act, ks2, p.spin_limit) && lane == 0) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the step's result is void
     const long long t_go = wall_clock64();
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -1468,18 +1565,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     if (p.trace && tid == 0) {                              // block L: start | c_fc loop done | tile published | slice complete | end  (wave 0's clock)
         long long* q = p.trace + (size_t)L * 8;
-        q[0] = t_start; q[1] = t_loop1; q[2] = t_pub; q[3] = t_go; q[4] = wall_clock64(); { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); q[5] = (long long)(xcc & 0xf); }
+        q[0] = t_start; q[1] = t_loop1; q[2] = t_pub; q[3] = t_go; q[4] = wall_clock64(); q[6] = t_p0; { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); q[5] = (long long)(xcc & 0xf); }
     }
 }
-static size_t mlp_fused_smem() { return (size_t)8 * 16 * 64 * 4 + (size_t)8 * 32 * 8 + 2048 + 64; }
+static size_t mlp_fused_smem() { return (size_t)8 * 16 * 64 * 4 + (size_t)8 * 32 * 8 + 2048 + 16 + 32 * 17 * 4 + 64; }
 
-// 0 = launched; -1 = the shapes are outside the kernel's scope (the caller runs the two launches)
+// 0 = launched; -1 = the shapes are outside the kernel's scope (the caller runs the separate launches)
 int launch_mlp_fused(const MlpFusedArgs& a, hipStream_t st) {
     const int KS1 = a.K1 / 16, KS2 = a.K2 / 16, T1 = a.N1pad / 32, T2 = a.N2pad / 32;
     if (a.splitk < 1 || 8 % a.splitk || T1 % 8 || KS1 != 8 * 16 || KS2 != a.splitk * 8 * 16) return -1;      // 16 k-steps per wave in both phases
     if (T2 * a.splitk != T1 || a.K2 != a.N1pad || a.N1 != a.N1pad || a.N2 != a.N2pad) return -1;
     if (!a.err || !a.fold_c1 || !a.fold_c2) return -1;
-    mlp_fused_kernel<<<T1, 512, mlp_fused_smem(), st>>>(a.W1, a.x1, a.W2, KS1, KS2, a.splitk, a);
+    if (a.Wc) {
+        // phase 0: 8 columns per block over K0 = 2048 (4 chunks of 32 per virtual wave), N0 = K1 = the residual width, one block per 8 columns
+        if (a.K0 != 2048 || a.N0 != a.K1 || a.N0 != 8 * T1 || !a.x0 || !a.h_old) return -1;
+        mlp_fused_kernel<true><<<T1, 512, mlp_fused_smem(), st>>>(a.W1, a.x1, a.W2, KS1, KS2, a.splitk, a);
+    } else {
+        mlp_fused_kernel<false><<<T1, 512, mlp_fused_smem(), st>>>(a.W1, a.x1, a.W2, KS1, KS2, a.splitk, a);
+    }
     return 0;
 }
 
