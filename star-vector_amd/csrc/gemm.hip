@@ -1399,10 +1399,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (p.bias_c) v_bias = *reinterpret_cast<const uint4*>(p.bias_c + L * 8);
             v_res = *reinterpret_cast<const uint4*>(p.h_old + v_idx);
         }
-        // phase 1's weights (16 KiB per wave) queue up behind phase 0's loads NOW: they stream while phase 0 computes and publishes
         u32x4 w1[KPW];
-#pragma unroll
-        for (int u = 0; u < KPW; ++u) w1[u] = __builtin_nontemporal_load(wptr + (size_t)u * 64);
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
             f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
@@ -1415,6 +1412,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int q = 0; q < 4; ++q) { my[q * 64 + lane] = a0[q]; my[(4 + q) * 64 + lane] = a1[q]; }
         }
+        // phase 1's weights (16 KiB per wave) are requested only NOW, with phase 0's own operands on chip: requested at the start of the
+        // launch (first version) the 33 MB of them queued in front of the phase-0 loads of every wave that started a little later, and
+        // phase 0 published at 7.0 us instead of ~3.  They stream under the reduction, the publish and the first poll.
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < KPW; ++u) w1[u] = __builtin_nontemporal_load(wptr + (size_t)u * 64);
+        __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
         {
             float s = red_v[tid];
@@ -1438,6 +1442,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         t_p0 = wall_clock64();
         __syncthreads();                                     // `red` is reused by phase 1's reduction
         // ---- phase 1 proper: the wave's 16 k-steps of the NEW residual stream (32 producers behind them), weights already here ----
+        // the other 255 blocks publish within about a microsecond of this one: a request sent right now would mostly find the pattern and
+        // cost a second round trip -- wait for three quarters of the weight stream first (it has to land anyway)
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         u32x4 x1v[KPW];
         if (poll16(x1v, rs_h, ks0, p.spin_limit) && lane == 0) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
