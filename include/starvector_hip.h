@@ -234,8 +234,9 @@ int  sv_debug_set_col_tiles(int32_t col_tiles);
  *   sv_debug_attn_decode dev_qkv_f32 fp32 [B][n_head*head_dim + 2*n_kv*head_dim] (the new token's c_attn output, before RoPE) ->
  *                        dev_out bf16 [B][n_head*head_dim]; appends the new K/V row at positions[b]; advance != 0: positions += 1 */
 /*   sv_debug_mlp_trace   (engine created with SV_MLP_TRACE=1) 100 MHz wall-clock stamps of the fused MLP launch (SV_EXP bit 128) of the
- *                        middle layer of the last decode step: host_out [blocks][8] = {start, c_fc loop done, tile published, slice
- *                        complete, end, XCC id, 0, 0}; returns the block count or a negative error code */
+ *                        middle layer of the last decode step: host_out [blocks][16] = {start, c_fc loop done, tile published, slice
+ *                        complete, end, XCC id, (bit 256) phase-0 piece published, arguments read, phase-0 operands used, phase-0
+ *                        reduced, x1 complete, 0...}; returns the block count or a negative error code */
 int  sv_debug_mlp_trace(sv_engine* e, int64_t* host_out, int32_t capacity_blocks);
 int  sv_debug_kv_load(sv_engine* e, int32_t layer, const void* dev_kv, int32_t B, int32_t S, const int32_t* dev_lens,
                       sv_stream stream);

@@ -565,7 +565,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
                           dn.Kpad == fc.Npad;
         const Linear& cp = e->dec[0].c_proj;
         e->proj_fused_ok = e->mlp_fused_ok && cp.cpb == 8 && cp.Kpad == 2048 && cp.N == D && D == 8 * T1 && e->MT == 1;
-        if (e->mlp_fused_ok && getenv("SV_MLP_TRACE")) rc = dalloc(e, &e->mlp_trace, (size_t)T1 * 8);
+        if (e->mlp_fused_ok && getenv("SV_MLP_TRACE")) rc = dalloc(e, &e->mlp_trace, (size_t)T1 * 16);
     }
     if (rc) { sv_destroy(e); return rc; }
     *out = e;

@@ -326,13 +326,13 @@ class HipEngine:
         check(self.lib.sv_debug_set_exp(self._h, int(mask)), "sv_debug_set_exp")
 
     def debug_mlp_trace(self) -> torch.Tensor:
-        """[blocks, 8] int64 wall-clock stamps (100 MHz) of the last fused MLP launch of the middle layer (engine created with
+        """[blocks, 16] int64 wall-clock stamps (100 MHz) of the last fused MLP launch of the middle layer (engine created with
         SV_MLP_TRACE=1 in the environment; include/starvector_hip.h, sv_debug_mlp_trace)."""
-        buf = (C.c_int64 * (1024 * 8))()
+        buf = (C.c_int64 * (1024 * 16))()
         n = self.lib.sv_debug_mlp_trace(self._h, buf, 1024)
         if n < 0:
             check(n, "sv_debug_mlp_trace")
-        return torch.tensor(list(buf[: n * 8]), dtype=torch.int64).view(n, 8)
+        return torch.tensor(list(buf[: n * 16]), dtype=torch.int64).view(n, 16)
 
     def debug_kv_load(self, layer: int, kv: torch.Tensor, lens: Optional[torch.Tensor] = None) -> None:
         """Test surface of the decode attention (include/starvector_hip.h, sv_debug_kv_load): kv [B, S, 2 * n_kv_head * head_dim]

@@ -36,7 +36,7 @@ for rep in range(3):
           f"wait for the slice {float((us[:,3]-us[:,2]).median()):.2f} (max {float((us[:,3]-us[:,2]).max()):.2f})  phase 2 {float((us[:,4]-us[:,3]).median()):.2f}")
     xcc = tr[:, 5].long()
     if MASK & 256:
-        p0 = (tr[:, 6] - t0) / 100.0
-        print(f"  phase 0 (projection) piece published {q(p0)}")
+        for k, n in ((7, "arguments read"), (8, "phase-0 operands used"), (9, "phase-0 reduced"), (6, "phase-0 piece published"), (10, "x1 complete")):
+            print(f"  {n:24s} {q((tr[:, k] - t0) / 100.0)}")
     print("  per XCC id: blocks", [int((xcc == x).sum()) for x in range(8)], " median end", [round(float(us[xcc == x, 4].median()), 2) if int((xcc == x).sum()) else None for x in range(8)])
 eng.close()
