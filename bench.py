@@ -184,6 +184,9 @@ def main():
     t_setup = time.time()
     if args.weights == "fp8":
         ec.weight_dtype = "fp8_e4m3"
+    # one process per GPU is the deployment this benchmark measures: the engine owns its device (all-blocks-resident fused launches on);
+    # ranks SHARING a GPU (the functional gloo run on a 1-GPU box) must not claim that
+    ec.exclusive_device = not shared and os.environ.get("SV_SHARED_GPU", "") != "1"
     eng = sva.HipEngine(ec, device=dev_index)
     keep_cpu = (world == 1 and rank == 0 and not args.no_cpu_baseline and not is8b and not t2s)   # 8B fp32 on CPU: 29 GB, skipped
     eng.load_random_weights(seed=1234, std=0.02)   # drawn on the GPU, one tensor at a time, same values on every rank
@@ -322,7 +325,7 @@ def main():
                                             "ranks; not a scaling number)") if shared else f"nccl (RCCL {rccl_version})",
                            "collectives_per_step": 1, "rccl_version": rccl_version,
                            "tokens_per_s_by_rank": per_rank_tps} if world > 1 else {}),
-                       "hipgraph_decode": bool(graph)},
+                       "hipgraph_decode": bool(graph), "exclusive_device": bool(ec.exclusive_device)},
             "tokens_per_s_per_gpu": round(value / world, 1),
             "ttft_p50_ms": round(ttft_p50, 2) if ttft_p50 is not None else None,
             "decode_us_per_step": round(decode_ms / max(decode_steps, 1) * 1e3, 1),

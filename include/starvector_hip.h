@@ -91,6 +91,13 @@ typedef struct sv_config {
                                   lm_head are quantised at load to OCP e4m3 with one scale per output row (BASELINE config 5,
                                   "fp8 weights"): the decode step streams half the bytes; activations, accumulation and every
                                   other tensor stay as they are.  Not a reference numerics mode: see DESIGN.md. */
+    int32_t exclusive_device;  /* != 0: this engine is the only thing launching kernels on its GPU while it decodes (the deployment the
+                                  path is built for: one process per GPU).  Enables the decode launches that need ALL their
+                                  workgroups resident at once (mlp_fused_kernel: the MLP half of a layer as one launch, 256 blocks, one
+                                  per CU, in-launch hand-off).  Results are bit-identical either way.  With ANOTHER process or engine
+                                  decoding on the same GPU such a launch can find its blocks only partly resident: the waiting
+                                  blocks then give up after a bounded spin and the call fails (never a hang, never wrong tokens) --
+                                  leave it 0 there.  Default 0. */
 } sv_config;
 
 /* Streaming: called on the host with the tokens that became final since the last call -- tokens [batch][n_cols] int32
@@ -234,9 +241,8 @@ int  sv_debug_set_col_tiles(int32_t col_tiles);
  *   sv_debug_attn_decode dev_qkv_f32 fp32 [B][n_head*head_dim + 2*n_kv*head_dim] (the new token's c_attn output, before RoPE) ->
  *                        dev_out bf16 [B][n_head*head_dim]; appends the new K/V row at positions[b]; advance != 0: positions += 1 */
 /*   sv_debug_mlp_trace   (engine created with SV_MLP_TRACE=1) 100 MHz wall-clock stamps of the fused MLP launch (SV_EXP bit 128) of the
- *                        middle layer of the last decode step: host_out [blocks][16] = {start, c_fc loop done, tile published, slice
- *                        complete, end, XCC id, (bit 256) phase-0 piece published, arguments read, phase-0 operands used, phase-0
- *                        reduced, x1 complete, 0...}; returns the block count or a negative error code */
+ *                        middle layer of the last decode step: host_out [blocks][8] = {start, c_fc loop done, tile published, slice
+ *                        complete, end, XCC id, 0, 0}; returns the block count or a negative error code */
 int  sv_debug_mlp_trace(sv_engine* e, int64_t* host_out, int32_t capacity_blocks);
 int  sv_debug_kv_load(sv_engine* e, int32_t layer, const void* dev_kv, int32_t B, int32_t S, const int32_t* dev_lens,
                       sv_stream stream);

@@ -27,7 +27,7 @@ class SvConfig(C.Structure):
         ("vocab", C.c_int32), ("n_positions", C.c_int32), ("max_batch", C.c_int32),
         ("max_seq_len", C.c_int32), ("ln_eps", C.c_float), ("device", C.c_int32),
         ("arch", C.c_int32), ("n_kv_head", C.c_int32), ("rope_theta", C.c_float), ("vit_mlp", C.c_int32),
-        ("vit_eps", C.c_float), ("sliding_window", C.c_int32), ("weight_dtype", C.c_int32),
+        ("vit_eps", C.c_float), ("sliding_window", C.c_int32), ("weight_dtype", C.c_int32), ("exclusive_device", C.c_int32),
     ]
 
 

@@ -291,7 +291,7 @@ extern "C" void sv_config_default_1b(sv_config* c) {
     c->vocab = 49156; c->n_positions = 8192; c->max_batch = 32; c->max_seq_len = 2048; c->ln_eps = 1e-5f;
     c->device = 0;
     c->arch = SV_ARCH_V1; c->n_kv_head = 1; c->rope_theta = 0.f; c->vit_mlp = 4096; c->vit_eps = 1e-5f;
-    c->sliding_window = 0; c->weight_dtype = SV_WEIGHT_BF16;
+    c->sliding_window = 0; c->weight_dtype = SV_WEIGHT_BF16; c->exclusive_device = 0;
 }
 
 extern "C" void sv_config_default_8b(sv_config* c) {
@@ -301,7 +301,7 @@ extern "C" void sv_config_default_8b(sv_config* c) {
     c->vocab = 49152 + 5; c->n_positions = 16384; c->max_batch = 16; c->max_seq_len = 4096; c->ln_eps = 1e-5f;
     c->device = 0;
     c->arch = SV_ARCH_V2; c->n_kv_head = 4; c->rope_theta = 1e6f; c->vit_mlp = 4096; c->vit_eps = 1e-6f;
-    c->sliding_window = 4096; c->weight_dtype = SV_WEIGHT_BF16;
+    c->sliding_window = 4096; c->weight_dtype = SV_WEIGHT_BF16; c->exclusive_device = 0;
 }
 
 extern "C" int sv_destroy(sv_engine* e) {
@@ -474,7 +474,6 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     if (e->ldws < D) e->ldws = D;
     A(dalloc(e, &e->h_dec, R * D));
     A(dalloc(e, &e->h_xp, R * D));
-    A(dalloc(e, &e->h_xp2, R * D));
     A(dalloc(e, &e->hl, R * D));
     A(dalloc(e, &e->xp_a, R * D));
     A(dalloc(e, &e->xp_attn, R * D));
@@ -563,9 +562,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         e->mlp_fused_ok = T1 <= e->num_cus && T1 % 8 == 0 && fc.N == fc.Npad && dn.N == dn.Npad && fc.Kpad / 16 == 128 &&
                           dn.splitk >= 1 && 8 % dn.splitk == 0 && dn.Kpad / 16 == dn.splitk * 128 && (dn.Npad / 32) * dn.splitk == T1 &&
                           dn.Kpad == fc.Npad;
-        const Linear& cp = e->dec[0].c_proj;
-        e->proj_fused_ok = e->mlp_fused_ok && cp.cpb == 8 && cp.Kpad == 2048 && cp.N == D && D == 8 * T1 && e->MT == 1;
-        if (e->mlp_fused_ok && getenv("SV_MLP_TRACE")) rc = dalloc(e, &e->mlp_trace, (size_t)T1 * 16);
+        if (e->mlp_fused_ok && getenv("SV_MLP_TRACE")) rc = dalloc(e, &e->mlp_trace, (size_t)T1 * 8);
     }
     if (rc) { sv_destroy(e); return rc; }
     *out = e;

@@ -258,18 +258,8 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
         prof_mark(e, PK_SKINNY, st);
         launch_gemm_skinny(a, st);
     };
-    // SV_EXP bit 256: projection + MLP in one launch; the residual stream ping-pongs between two buffers (the launch reads hx[i & 1] and
-    // writes hx[(i & 1) ^ 1]); the row update at the head of layer i works on hx[i & 1] and fills the other buffer + the GELU buffer
-    // with the "not written yet" pattern
-    const bool pm = fold6 && (e->exp & 256) && e->mlp_fused_ok && e->proj_fused_ok;
-    bf16_t* hx[2] = {e->h_xp, e->h_xp2};
     for (int i = 0; i < c.n_layer; ++i) {
         DecLayer& L = e->dec[i];
-        if (pm) {
-            ru.h = hx[i & 1];
-            ru.poison0 = hx[(i & 1) ^ 1]; ru.poison0_bytes = (unsigned)((size_t)(D / 16) * 1024);
-            ru.poison1 = e->xp_mlp; ru.poison1_bytes = (unsigned)((size_t)(F / 16) * 1024);
-        }
         row_update();                                            // embedding or the previous layer's down-proj -> LN1(h)
         skinny(e->xp_a, L.c_attn, SK_OUT_PARTIAL, wsA);
         if (!e->only_skinny) {
@@ -285,26 +275,23 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
             memset(&ca, 0, sizeof(ca));
             ca.xp = e->xp_attn; ca.Wp = L.c_proj.Wp; ca.bias = L.c_proj.bias; ca.MT = MT; ca.N = L.c_proj.N; ca.K = L.c_proj.Kpad;
             ca.cpb = L.c_proj.cpb; ca.h_xp = e->h_xp; ca.out_KS = D / 16;
-            const bool fused = pm || ((e->exp & 128) && e->mlp_fused_ok);               // round-4 experiment: c_fc + down projection in one launch
-            if (fused && !pm) { ca.poison = e->xp_mlp; ca.poison_bytes = (unsigned)((size_t)(F / 16) * 1024); }
-            if (!e->skip_skinny && !pm) { prof_mark(e, PK_SKINNY, st); launch_gemm_cols(ca, st); }
+            // c_fc + down projection in ONE launch (gemm.hip mlp_fused_kernel): on when the engine owns its GPU (sv_config.exclusive_device);
+            // SV_EXP bit 128 forces it on, bit 512 off (in-process A/B, tools/ab_exp.py)
+            const bool fused = e->mlp_fused_ok && !(e->exp & 512) && (c.exclusive_device || (e->exp & 128));
+            if (fused) { ca.poison = e->xp_mlp; ca.poison_bytes = (unsigned)((size_t)(F / 16) * 1024); }
+            if (!e->skip_skinny) { prof_mark(e, PK_SKINNY, st); launch_gemm_cols(ca, st); }
             if (fused) {
                 MlpFusedArgs ma;
                 memset(&ma, 0, sizeof(ma));
-                ma.W1 = L.c_fc.Wf; ma.x1 = pm ? hx[(i & 1) ^ 1] : e->h_xp;
-                if (pm) {
-                    ma.Wc = L.c_proj.Wp; ma.x0 = e->xp_attn; ma.bias_c = L.c_proj.bias; ma.h_old = hx[i & 1]; ma.N0 = L.c_proj.N; ma.K0 = L.c_proj.Kpad;
-                } ma.N1 = L.c_fc.N; ma.N1pad = L.c_fc.Npad; ma.K1 = L.c_fc.Kpad;
+                ma.W1 = L.c_fc.Wf; ma.x1 = e->h_xp; ma.N1 = L.c_fc.N; ma.N1pad = L.c_fc.Npad; ma.K1 = L.c_fc.Kpad;
                 ma.fold_c1 = L.c_fc.c1; ma.fold_c2 = L.c_fc.c2; ma.fold_D = D; ma.fold_eps = c.ln_eps; ma.act = ACT_GELU_TANH;
                 ma.out_xp = e->xp_mlp; ma.out_KS = F / 16;
                 ma.W2 = L.c_proj2.Wp; ma.N2 = L.c_proj2.N; ma.N2pad = L.c_proj2.Npad; ma.K2 = L.c_proj2.Kpad; ma.splitk = L.c_proj2.splitk;
                 ma.ws = wsB; ma.ldws = e->ldws; ma.rows_ws = MT * 32; ma.err = e->d_bad; ma.spin_limit = 1 << 16;
-                if (e->only_skinny) { ma.err = e->d_bad + 1; ma.spin_limit = 1; }     // profiling leg without the row updates: never wait, never flag
                 ma.trace = (i == c.n_layer / 2) ? e->mlp_trace : nullptr;        // one layer in the middle of the step
                 if (!e->skip_skinny) { prof_mark(e, PK_SKINNY, st); (void)launch_mlp_fused(ma, st); }
                 const LNp& nx = (i + 1 < c.n_layer) ? e->dec[i + 1].ln1 : e->ln_f;
                 ru.ws = wsB; ru.splitk = L.c_proj2.splitk; ru.bias = L.c_proj2.bias; ru.g = nx.g; ru.b = nx.b;
-                if (pm) ru.h = hx[(i & 1) ^ 1];                  // the stream now lives in the other buffer (also for the final ln_f update)
                 continue;
             }
             SkinnyArgs a;
@@ -323,7 +310,6 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
         const LNp& nxt = (i + 1 < c.n_layer) ? e->dec[i + 1].ln1 : e->ln_f;
         ru.ws = wsB; ru.splitk = L.c_proj2.splitk; ru.bias = L.c_proj2.bias; ru.g = nxt.g; ru.b = nxt.b;
     }
-    ru.poison0 = nullptr; ru.poison1 = nullptr;
     row_update();                                                // + bias + residual, ln_f
     skinny(e->xp_a, e->lm_head, SK_OUT_F32, nullptr);
     prof_mark(e, PK_SAMPLE, st);      // closes the lm_head interval; whatever follows is sampling

@@ -108,8 +108,6 @@ struct sv_engine {
     int MT = 0, ldws = 0, Vpad = 0;
     bf16_t *h_dec = nullptr, *hl = nullptr, *xp_a = nullptr, *xp_attn = nullptr, *xp_mlp = nullptr;
     bf16_t* h_xp = nullptr;         // residual stream of the decode step in fragment order (6-launch layer)
-    bf16_t* h_xp2 = nullptr;        // its second buffer: SV_EXP bit 256 ping-pongs the stream (the fused launch writes the OTHER buffer)
-    bool proj_fused_ok = false;     // the attention output projection fits phase 0 of the fused launch (8 columns per block, K = 2048)
     bool fold6 = false;             // 6 launches per layer: slab-free attention output projection + ln_2 folded into c_fc
     bool fold_ready = false;
     bool mlp_fused_ok = false;      // the MLP half as one launch (gemm.hip mlp_fused_kernel) fits this engine: shapes + one block per CU
@@ -120,8 +118,8 @@ struct sv_engine {
                                     //   2 the 7-launch layer (no LayerNorm fold);
                                     //   (1: was the row update as one wave per row: 0.218 vs 0.131 ms per step, removed)
                                     //   8 (at sv_create only) the round 1-2 split-K rule of the decode GEMMs
-                                    //   128 (round 4) the MLP half of a layer as ONE launch (c_fc + down projection, mlp_fused_kernel)
-                                    //   256 (round 4) ... with the attention output projection as its phase 0 (4 launches per layer)
+                                    //   128 / 512 (round 4) the MLP half of a layer as ONE launch (mlp_fused_kernel) forced on / off; default:
+                                    //       on iff sv_config.exclusive_device
                                     //   (16 / 32 / 64: 2 / 6 / 8 key groups per attention block: 1186 / 1169 / 1175 vs 1171 us, removed)
                                     //   (1, 2: XCD-aligned weight prefetch by attention's idle waves / spare row-update blocks; 4: one key
                                     //    group per attention block -- all measured slower, profiles/prefetch_r03_*.log, removed)

@@ -120,8 +120,7 @@ extern "C" int sv_debug_attn_decode(sv_engine* e, int32_t layer, const float* de
 }
 
 // SV_MLP_TRACE=1 at sv_create: wall-clock stamps (100 MHz ticks) of the fused MLP launch of the middle layer of the LAST decode step,
-// host_out [blocks][16] = {start, c_fc loop done, tile published, slice complete, end, XCC id, phase-0 piece published, arguments read,
-// phase-0 operands used, phase-0 reduced, x1 complete, 0...}; returns the number of blocks
+// host_out [blocks][8] = {start, c_fc loop done, tile published, slice complete, end, XCC id, 0, 0}; returns the number of blocks
 extern "C" int sv_debug_mlp_trace(sv_engine* e, int64_t* host_out, int32_t capacity_blocks) {
     if (!e || !host_out) return fail(SV_EINVAL, "sv_debug_mlp_trace: null argument");
     std::lock_guard<std::mutex> lk(e->mu);
@@ -130,7 +129,7 @@ extern "C" int sv_debug_mlp_trace(sv_engine* e, int64_t* host_out, int32_t capac
     if (capacity_blocks < T1) return fail(SV_EINVAL, "sv_debug_mlp_trace: capacity %d < %d blocks", capacity_blocks, T1);
     HIPCHECK(hipSetDevice(e->cfg.device));
     HIPCHECK(hipDeviceSynchronize());
-    HIPCHECK(hipMemcpy(host_out, e->mlp_trace, (size_t)T1 * 16 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    HIPCHECK(hipMemcpy(host_out, e->mlp_trace, (size_t)T1 * 8 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return T1;
 }
 

@@ -1261,55 +1261,41 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
 }
 
 // ------------------------------------------------------------------------------------------------
-// mlp_fused_kernel: the MLP half of a decode layer (gpt_bigcode/modeling_gpt_bigcode.py:645-660: c_fc -> GELU-tanh -> c_proj), and with
-// PROJ the attention output projection in front of it (:694-755 residual add), as ONE launch of F/32 co-resident blocks (256 for
-// StarVector-1B, one 8-wave block per CU) instead of gemm_skinny_kernel<8, true> (folded c_fc) + gemm_skinny_kernel<8, false> (down
-// projection, split-K slabs) [+ gemm_cols_resid_kernel] with kernel boundaries between them.  Round-4 experiment: SV_EXP bit 128 (MLP),
-// bit 256 (projection + MLP); DESIGN.md section 3e, history with traces in profiles/mlp_fused_r04_ab.log.
+// mlp_fused_kernel: the MLP half of a decode layer (gpt_bigcode/modeling_gpt_bigcode.py:645-660: c_fc -> GELU-tanh -> c_proj) as ONE
+// launch of F/32 co-resident blocks (256 for StarVector-1B, one per CU), instead of gemm_skinny_kernel<8, true> (folded c_fc) and
+// gemm_skinny_kernel<8, false> (down projection, split-K slabs) with a kernel boundary between them.  Round-4 experiment behind
+// SV_EXP bit 128; kept only if it beats the two launches.
 //
-//   Why it can pay (MI355X_MICROARCH.md price list: boundary, prefetch-credit): the GEMMs are pure weight streams and the WEIGHTS of
-//   the next one depend on nothing.  Separate launches pay a boundary (1.7-1.9 us) plus the next kernel's cold start; here the next
-//   phase's weights are requested while the block reduces, publishes and waits.
+//   Why it can pay (MI355X_MICROARCH.md price list: boundary, prefetch-credit): both GEMMs are pure weight streams (2 x 33.5 MB) and
+//   the WEIGHTS of the second one depend on nothing.  Two launches pay a boundary (1.7-1.9 us) plus the second kernel's ramp (first
+//   round trip to HBM with an idle chip); here every wave requests its whole share of the down projection's weights (16 KiB, 64
+//   VGPRs) as soon as its c_fc loop has issued its last MFMA, so that stream runs UNDER the c_fc epilogue, the publish and the wait.
 //
-//   Phase 0  (PROJ) block L finishes h_new[:, 8 L .. 8 L + 8) = bf(h_old + bf(x_attn W_c^T + b)): gemm_cols_resid_kernel<16, 2, 1> with
-//            cpb = 8, wave w playing its waves 2 w and 2 w + 1 (same chunk ranges, MFMA order, 16-way reduction order).  h_new is the
-//            OTHER buffer of a residual-stream ping-pong.
-//   Phase 1  block L = (xcd = L & 7, i = L >> 3): c_fc tile nt1 = split * (T1 / S) + (xcd / S) * (T1 / 8) + i with split = xcd % S; the 32
-//            GELU output columns of a tile are 2 KiB contiguous in fragment order.
-//   Phase 2  the same block owns (tile nt2 = (xcd / S) * (T1 / 8) + i, K slice `split`) of the down projection = exactly the (tile, slice)
-//            the XCD-aware assignment of the slab kernel gives block L.
-//   Hand-off in-band, no flag and no counter: an earlier launch fills the destination buffers with the bf16 pair 0xFFFF'FFFF (two NaNs:
-//            never a finite activation); producers write their piece with write-through (sc1) 16-byte stores and wait for nothing; a
-//            consumer WAVE reads the 16 k-steps it needs with sc1 loads (L1 bypass) and re-requests, after an s_sleep, only the k-steps
-//            that still show the pattern -- BOUNDED (a give-up code in *err, never a hang).  Phase 2 depends on 8 producers per wave,
-//            phase 1 (PROJ) on 32.
-//   Critical-path waves: a wave that issues more loads than the CU's miss queue takes (~64 KiB per CU) BLOCKS AT ISSUE until the
-//            queue drains -- a "prefetch" in front of the reduction delayed the publish by 1.3-3.7 us (versions 4 / stage B 1-2).  So
-//            after every phase all waves park their partial sums in LDS, ONE barrier, and then only waves 0-1 (phase 0: wave 0) reduce,
-//            run the epilogue and publish, while the other waves go straight to requesting the next phase's weights (and may block
-//            there, harmlessly); the publishing waves request theirs after the store.
-//   Results  per-wave k ranges, MFMA order, the order in which partial sums are added, fold statistics and epilogues are those of the
-//            kernels it replaces (WHO adds them changed, not the order): bit-identical (tests/test_gpu_e2e.py::
-//            test_fused_mlp_launch_equals_the_two_launches_bit_for_bit).
+//   Phase 1  block L = (xcd = L & 7, i = L >> 3): c_fc tile nt1 = split * (T1 / S) + (xcd / S) * (T1 / 8) + i with split = xcd % S --
+//            the 32 GELU output columns of a tile are 2 KiB contiguous in fragment order; they go LDS -> 16-byte sc1 (write-through)
+//            stores.  No flag, no counter, nothing to drain.
+//   Phase 2  the same block owns (tile nt2 = (xcd / S) * (T1 / 8) + i, K slice `split`) of the down projection = exactly the
+//            (tile, slice) the XCD-aware assignment of the slab kernel gives block L.  Wave w needs the c_fc columns of its 16 k-steps
+//            = the tiles of 8 producer blocks; it reads them with sc1 loads (L1 bypass) and recognises "not written yet" by the data
+//            itself: the launch in front fills the buffer with the bf16 pair 0xFFFF'FFFF (two NaNs -- never a finite GELU output), a
+//            k-step that still shows the pattern is re-requested after an s_sleep, BOUNDED (a give-up code in *err, never a hang).
+//   Results  per-wave k ranges, MFMA order, cross-wave reduction order, fold statistics and epilogues are those of the two kernels it
+//            replaces: bit-identical slabs (tests/test_gpu_ops.py::test_fused_mlp_equals_the_two_launches).
 //   Safety   needs all F/32 blocks resident at once (1 per CU: the engine enables it only when #CUs >= F/32); the pattern is written by
-//            an EARLIER launch (bit 128: gemm_cols_resid_kernel; bit 256: row_update_ln_kernel), never by this one; a NaN pair with the
-//            pattern (only from corrupted inputs; arithmetic NaNs are 0x7FC0) ends in the give-up code, i.e. an error from sv_generate.
+//            the kernel in front of it (gemm_cols_resid_kernel, ColsArgs::poison), never by this launch; a NaN activation (a numeric
+//            failure upstream) ends in the give-up code, i.e. in an error from sv_generate, as non-finite logits do.
 // ------------------------------------------------------------------------------------------------
 struct MlpFusedKernarg { const bf16_t* W1; const bf16_t* x1; const bf16_t* W2; int KS1; int KS2; int S; MlpFusedArgs p; };
 // amdgpu_waves_per_eu(2, 2): one 8-wave block per CU is the design point (2 waves per SIMD, 256 VGPRs each); without it the
-// scheduler trades registers for a third wave that can never exist and serialises the 16 activation loads of a poll 3 at a time
-template <bool PROJ>
+// scheduler trades registers for a third wave that can never exist and serialises phase 2's 16 activation loads 3 at a time
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void mlp_fused_kernel(const bf16_t* W1_, const bf16_t* x1_, const bf16_t* W2_, int KS1_, int KS2_, int S_,
                                                         MlpFusedArgs p_unused) {
-    constexpr int WAVES = 8, CH = 4, NB = 2, KPW = 16;                    // k-steps per wave in BOTH MLP phases (host-checked)
+    constexpr int WAVES = 8, CH = 4, NB = 2, RPW = 2, KPW = 16;          // k-steps per wave in BOTH phases (host-checked)
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
-    // LDS: R0 = partial sums of phase 0 and phase 2, R1 = of phase 1 (two regions: a wave may already park phase-(n+1) partials while
-    // wave 0 / 1 still reduce phase n), row statistics, the c_fc tile image, the projection tile
-    float (*red0)[16][64] = reinterpret_cast<float (*)[16][64]>(sk_smem);                       // [8][16][64] = 32 KiB
-    float (*red1)[16][64] = reinterpret_cast<float (*)[16][64]>(sk_smem + 32768);               // 32 KiB
-    float2* fst_s = reinterpret_cast<float2*>(sk_smem + 65536);                                 // [8][32] partial row statistics
-    char* tile_s = sk_smem + 65536 + 2048;                                                      // 2 KiB: the c_fc tile in fragment order
-    float* ctile = reinterpret_cast<float*>(sk_smem + 65536 + 4096);                            // [32][17] finished x_attn W_c^T
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(sk_smem);          // [WAVES][16][64]
+    float2* fst_s = reinterpret_cast<float2*>(sk_smem + (size_t)WAVES * 16 * 64 * 4);      // [WAVES][32] partial row statistics
+    bf16_t* tile_s = reinterpret_cast<bf16_t*>(sk_smem + (size_t)WAVES * 16 * 64 * 4 + (size_t)WAVES * 32 * 8);   // 2 KiB: the c_fc tile
+    int* flag_s = reinterpret_cast<int*>(tile_s + 1024);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = lane & 31, half = lane >> 5;
@@ -1319,16 +1305,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int nt2 = grp * tpg + ii;
     const int nt1 = split * (T1 / S_) + nt2;
     const long long t_start = wall_clock64();             // 100 MHz; only stored when the trace buffer is on (tools/mlp_trace.py)
-    long long t_p0 = 0, t_late = 0, t_ops0 = 0, t_red0 = 0, t_x1 = 0;   // PROJ: arguments read | phase-0 operands used | reduced | piece published | x1 complete
 
+    // ---- phase 1: folded c_fc, tile nt1 over the whole K1 (gemm_skinny_kernel<8, true>, long-range path) ----
     const int ks0 = wave * KPW;
     const u32x4* wptr = reinterpret_cast<const u32x4*>(W1_) + ((size_t)nt1 * KS1_ + ks0) * 64 + lane;
     const u32x4* xptr = reinterpret_cast<const u32x4*>(x1_) + (size_t)ks0 * 64 + lane;
-    const int ks2 = split * (WAVES * KPW) + wave * KPW;
-    const u32x4* w2ptr = reinterpret_cast<const u32x4*>(W2_) + ((size_t)nt2 * KS2_ + ks2) * 64 + lane;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    SkChunk<CH> ck[NB];
     float fs1 = 0.f, fs2 = 0.f;
     auto fold_acc = [&](const u32x4& xv) {
 #pragma unroll
@@ -1338,281 +1323,174 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             fs2 = fmaf(a, a, fmaf(b, b, fs2));
         }
     };
-    MlpFusedArgs p;
-    // fold constants of the 8 accumulator rows a publishing wave (0 / 1) finishes: rows 8 wave + i -> column nt1 * 32 + 8 (r >> 2) + 4 half + (r & 3)
-    float c1v[8], c2v[8];
-    auto late = [&]() {
-        p = sv_late_args<MlpFusedArgs>(offsetof(MlpFusedKernarg, p));
-        if (wave < 2) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int r = wave * 8 + i;
-                const int n = nt1 * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-                c1v[i] = n < p.N1 ? p.fold_c1[n] : 0.f;
-                c2v[i] = n < p.N1 ? p.fold_c2[n] : 0.f;
+    for (int b = 0; b < NB; ++b) sk_load_full<CH>(ck[b], wptr, xptr, b * CH);
+    const MlpFusedArgs p = sv_late_args<MlpFusedArgs>(offsetof(MlpFusedKernarg, p));
+    float c2v[RPW], c1v[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = wave * RPW + i;
+        const int n = nt1 * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+        c1v[i] = n < p.N1 ? p.fold_c1[n] : 0.f;
+        c2v[i] = n < p.N1 ? p.fold_c2[n] : 0.f;
+    }
+    sk_settle<RPW>(c2v, c1v);
+#pragma unroll
+    for (int ks = 0; ks < KPW; ks += NB * CH) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(ck[b].w[u]), as_frag4(ck[b].x[u]), acc, 0, 0, 0);
+                fold_acc(ck[b].x[u]);
             }
-        }
-    };
-    // in-band polling: 16 k-steps of activations through sc1 loads; a k-step that still shows the pattern anywhere in the wave is
-    // re-requested after an s_sleep.  Returns true when it gave up.
-    auto poll16 = [&](u32x4 (&xx)[KPW], const __amdgpu_buffer_rsrc_t& rs, int ks_first, int limit) -> bool {
-#pragma unroll
-        for (int u = 0; u < KPW; ++u) xx[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (ks_first + u) * 1024 + lane * 16, 0, 16);   // sc1: L1 bypass
-        unsigned pending = 0xffffu;                          // k-steps not (known to be) complete: wave-uniform
-        for (int it = 0; it < limit; ++it) {
-            unsigned still = 0u;
-#pragma unroll
-            for (int u = 0; u < KPW; ++u) {
-                if (pending & (1u << u)) {
-                    const bool bad = xx[u][0] == 0xffffffffu || xx[u][1] == 0xffffffffu || xx[u][2] == 0xffffffffu || xx[u][3] == 0xffffffffu;
-                    if (__any(bad)) still |= 1u << u;
-                }
-            }
-            pending = still;
-            if (!pending) return false;
-            __builtin_amdgcn_s_sleep(8);
-#pragma unroll
-            for (int u = 0; u < KPW; ++u)
-                if (pending & (1u << u)) xx[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, (ks_first + u) * 1024 + lane * 16, 0, 16);
-        }
-        return true;
-    };
-    u32x4 wn[KPW];                                            // the NEXT phase's weights of this wave (16 KiB): W1 during phase 0, W2 during phase 1
-    auto request = [&](const u32x4* src) {
-#pragma unroll
-        for (int u = 0; u < KPW; ++u) wn[u] = __builtin_nontemporal_load(src + (size_t)u * 64);
-    };
-
-    if constexpr (PROJ) {
-        // ---- phase 0: the attention output projection, columns 8 L .. 8 L + 8 over the whole K0 ----
-        float* red_v = &red0[0][0][0];                                      // [16 virtual waves][512]
-        const int r16 = lane & 15, g4 = lane >> 4;
-        const int n0c = L * 8 + r16;
-        const bool wvalid = r16 < 8;
-        const int nn = wvalid ? n0c : 0;
-        late();                                            // K0 and the operands are needed at once here: a scalar load behind no global load
-        t_late = wall_clock64();
-        const int KS0 = p.K0 >> 4;
-        u32x4 cw[2][4], cx[2][4][2];
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            const int c0 = (2 * wave + h2) * 4;                             // chunks of 32 k: 4 per virtual wave (K0 = 2048, launcher)
-            const u32x4* wb = reinterpret_cast<const u32x4*>(p.Wc) + ((size_t)(nn >> 5) * KS0 + (g4 >> 1)) * 64 + (nn & 31) + 32 * (g4 & 1) + (size_t)c0 * 128;
-            const u32x4* xb = reinterpret_cast<const u32x4*>(p.x0) + (size_t)(g4 >> 1) * 64 + r16 + 32 * (g4 & 1) + (size_t)c0 * 128;
-            const u32x4 zero4 = {0u, 0u, 0u, 0u};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                cw[h2][u] = zero4;
-                if (wvalid) cw[h2][u] = __builtin_nontemporal_load(wb + (size_t)u * 128);
-                cx[h2][u][0] = xb[(size_t)u * 128];
-                cx[h2][u][1] = xb[(size_t)u * 128 + 16];
-            }
-        }
-        // old residual piece + bias of wave 0's 32 finishing lanes (row = lane, the block's 8 columns): they depend on nothing either
-        uint4 v_res = make_uint4(0u, 0u, 0u, 0u), v_bias = make_uint4(0u, 0u, 0u, 0u);
-        const size_t v_idx = xp_index(0, p.N0 >> 4, tid & 31, L * 8);
-        if (tid < 32) {
-            if (p.bias_c) v_bias = *reinterpret_cast<const uint4*>(p.bias_c + L * 8);
-            v_res = *reinterpret_cast<const uint4*>(p.h_old + v_idx);
-        }
-#pragma unroll
-        for (int h2 = 0; h2 < 2; ++h2) {
-            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                a0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag4(cw[h2][u]), as_frag4(cx[h2][u][0]), a0, 0, 0, 0);
-                a1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag4(cw[h2][u]), as_frag4(cx[h2][u][1]), a1, 0, 0, 0);
-            }
-            float* my = red_v + (2 * wave + h2) * 512;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { my[q * 64 + lane] = a0[q]; my[(4 + q) * 64 + lane] = a1[q]; }
-        }
-        t_ops0 = wall_clock64();
-        __syncthreads();
-        const __amdgpu_buffer_rsrc_t rs_h = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(x1_), 0, (unsigned)((size_t)KS1_ * 1024), 0x00020000);
-        if (wave == 0) {
-            // wave 0 alone: the 16-way reduction of the 512 tile elements (8 per lane), the epilogue of its 32 rows, the publish
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                const int idx = lane + 64 * k;
-                float s = red_v[idx];
-#pragma unroll
-                for (int w = 1; w < 16; ++w) s += red_v[w * 512 + idx];
-                const int hb = (idx >> 8) & 1, q = (idx >> 6) & 3, ln = idx & 63;
-                ctile[(16 * hb + (ln & 15)) * 17 + 4 * (ln >> 4) + q] = s;
-            }
-            t_red0 = wall_clock64();
-            if (lane < 32) {
-                float rr[8], bb[8], hn[8];
-                unpack8(v_res, rr);
-                unpack8(v_bias, bb);
-#pragma unroll
-                for (int e2 = 0; e2 < 8; ++e2) hn[e2] = bfround(rr[e2] + bfround(ctile[lane * 17 + e2] + bb[e2]));      // h = bf(h + bf(x W^T + b))
-                const uint4 o = pack8(hn);
-                const u32x4 ov = {o.x, o.y, o.z, o.w};
-                __builtin_amdgcn_raw_buffer_store_b128(ov, rs_h, (int)(v_idx * 2), 0, 16);                             // sc1: write-through
-            }
-            t_p0 = wall_clock64();
-        }
-        // phase 1's weights: the other waves request them at once (and may block at issue), wave 0 after its publish
-        request(wptr);
-        // the other 255 blocks publish within about a microsecond of this one: a poll sent right now would mostly find the pattern and
-        // cost a second round trip -- wait for three quarters of the weight stream first (it has to land anyway)
-        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        u32x4 x1v[KPW];
-        if (poll16(x1v, rs_h, ks0, p.spin_limit) && lane == 0) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        t_x1 = wall_clock64();
-#pragma unroll
-        for (int u = 0; u < KPW; ++u) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wn[u]), as_frag4(x1v[u]), acc, 0, 0, 0);
-            fold_acc(x1v[u]);
-        }
-    } else {
-        // ---- phase 1 streamed: folded c_fc, tile nt1 over the whole K1 (gemm_skinny_kernel<8, true>, long-range path) ----
-        SkChunk<CH> ck[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) sk_load_full<CH>(ck[b], wptr, xptr, b * CH);
-        late();
-        if (wave < 2) sk_settle<8>(c2v, c1v);
-#pragma unroll
-        for (int ks = 0; ks < KPW; ks += NB * CH) {
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-#pragma unroll
-                for (int u = 0; u < CH; ++u) {
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(ck[b].w[u]), as_frag4(ck[b].x[u]), acc, 0, 0, 0);
-                    fold_acc(ck[b].x[u]);
-                }
-                if (ks + (b + NB) * CH < KPW) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    sk_load_full<CH>(ck[b], wptr, xptr, ks + (b + NB) * CH);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+            if (ks + (b + NB) * CH < KPW) {
+                __builtin_amdgcn_sched_barrier(0);
+                sk_load_full<CH>(ck[b], wptr, xptr, ks + (b + NB) * CH);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
     const long long t_loop1 = wall_clock64();
+    const int ks2 = split * (WAVES * KPW) + wave * KPW;
+    const u32x4* w2ptr = reinterpret_cast<const u32x4*>(W2_) + ((size_t)nt2 * KS2_ + ks2) * 64 + lane;
+    u32x4 w2[KPW];
+    // The down projection's weights of this wave (tile nt2, k-steps split * 128 + wave * 16 .. + 16: 16 KiB) depend on nothing: the first
+    // half is requested NOW, so that the HBM stream does not pause while the block reduces and publishes (third version: requested after
+    // the publish -- HBM idle for 2.5 us); 8 KiB per wave in flight is what the steady state of the stand-alone kernels keeps (all
+    // 16 KiB at once put 24 MB of reads in front of every tile store of the chip: second version, 6 us from loop end to publish).
+#pragma unroll
+    for (int u = 0; u < 8; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
 
-    // ---- phase 1 -> 2: every wave parks its partial sums + statistics, ONE barrier; waves 0 / 1 finish 8 accumulator rows each (the
-    // summation order over the waves is gemm_skinny_kernel<8, true>'s), apply the folded LayerNorm + GELU and publish k-step `wave`
-    // of the tile; the others request their down-projection weights at once ----
+    // K reduction across the waves (wave order) + LayerNorm fold epilogue: gemm_skinny_kernel<8, true>'s, value for value
+    float v[RPW];
     fs1 += __shfl_xor(fs1, 32, 64);
     fs2 += __shfl_xor(fs2, 32, 64);
     if (half == 0) fst_s[wave * 32 + m] = make_float2(fs1, fs2);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red1[wave][r][lane] = acc[r];
-    __builtin_amdgcn_sched_barrier(0);
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
     __syncthreads();
-    const __amdgpu_buffer_rsrc_t rs_act = __builtin_amdgcn_make_buffer_rsrc(p.out_xp, 0, (unsigned)((size_t)p.out_KS * 1024), 0x00020000);
-    long long t_pub = 0;
-    if (wave < 2) {
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = wave * RPW + i;
+        float t = red[0][r][lane];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) t += red[w][r][lane];
+        v[i] = t;
+    }
+    {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int q = 0; q < WAVES; ++q) { const float2 tq = fst_s[q * 32 + m]; s1 += tq.x; s2 += tq.y; }
+        for (int q = 0; q < WAVES; ++q) { const float2 t = fst_s[q * 32 + m]; s1 += t.x; s2 += t.y; }
         const float invD = 1.0f / (float)p.fold_D;
         const float mean = s1 * invD;
         float var = s2 * invD - mean * mean;
         var = var > 0.f ? var : 0.f;
         const float rstd = rsqrtf(var + p.fold_eps);
-        uint32_t pr[4];
+        const int r = wave * RPW;
+        const int nl = 8 * (r >> 2) + 4 * half + (r & 3);                 // local column of v[0] (v[1]: + 1)
+        float o[RPW];
 #pragma unroll
-        for (int i = 0; i < 8; i += 2) {
-            float o[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = wave * 8 + i + j;
-                float tsum = red1[0][r][lane];
-#pragma unroll
-                for (int w = 1; w < WAVES; ++w) tsum += red1[w][r][lane];
-                const int n = nt1 * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-                float x = 0.f;
-                if (n < p.N1) {
-                    x = bfround(rstd * (tsum - mean * c1v[i + j]) + c2v[i + j]);
-                    if (p.act != ACT_NONE) x = sv_act(x, p.act);
-                }
-                o[j] = x;
+        for (int i = 0; i < RPW; ++i) {
+            float x = 0.f;
+            if (nt1 * 32 + nl + i < p.N1) {
+                x = bfround(rstd * (v[i] - mean * c1v[i]) + c2v[i]);
+                if (p.act != ACT_NONE) x = sv_act(x, p.act);
             }
-            pr[i >> 1] = pack2bf(o[0], o[1]);
+            o[i] = x;
         }
-        // rows 8 wave + i are the tile's columns 16 wave + 8 (i >> 2) + 4 half + (i & 3): this wave's k-step of the fragment image; a lane
-        // holds two 4-column groups of row m, the 16-byte piece of lane (m, half') is columns 8 half' .. + 8 -> through this wave's own 1 KiB
-        char* kst = tile_s + wave * 1024;
-#pragma unroll
-        for (int gq = 0; gq < 2; ++gq)                     // group gq: columns 8 gq + 4 half + 0..3 -> piece (m, half' = gq), bytes 8 half ..
-            *reinterpret_cast<uint2*>(kst + (gq * 32 + m) * 16 + 8 * half) = make_uint2(pr[2 * gq], pr[2 * gq + 1]);
-        const u32x4 piece = *reinterpret_cast<const u32x4*>(kst + lane * 16);          // same wave: LDS operations of a wave are ordered
-        __builtin_amdgcn_raw_buffer_store_b128(piece, rs_act, nt1 * 2048 + wave * 1024 + lane * 16, 0, 16);          // sc1: write-through
-        t_pub = wall_clock64();
+        // the tile in fragment order (the image xp_index addresses: [k-step nl >> 4][64 lanes][8])
+        *reinterpret_cast<uint32_t*>(tile_s + (((nl >> 4) * 64 + ((nl >> 3) & 1) * 32 + m) * 8 + (nl & 7))) = pack2bf(o[0], o[1]);
     }
-    request(w2ptr);
-    // about half a round trip before the poll: the 8 producers behind this wave publish at about the same time as this block
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __syncthreads();
+    // ---- hand-off, third version: NO flag and NO counter.  The launch in front of this one (gemm_cols_resid_kernel) fills the whole
+    // activation buffer with the bf16 pair 0xFFFF'FFFF (two NaNs: no finite GELU output has that pattern).  A producer only writes its
+    // 2 KiB tile (write-through 16-byte stores, nothing to wait for); a consumer WAVE polls the 16 KiB it needs itself -- the tiles of
+    // the 8 producers behind its 16 k-steps, not of all 64 producers of the slice -- and re-requests only the k-steps that still
+    // carry the pattern.  History (profiles/mlp_fused_r04_ab.log): one ticket word per K slice: 25.5 us per launch (64 arrivals + 64
+    // pollers per word); one flag word per producer polled by wave 0: 17.7 us = the two launches, with 6 us of "publish" (the store
+    // drained behind 24 MB of weight prefetch) and 4 us of "wait" on the critical path.
+    const __amdgpu_buffer_rsrc_t rs_act = __builtin_amdgcn_make_buffer_rsrc(p.out_xp, 0, (unsigned)((size_t)p.out_KS * 1024), 0x00020000);
+    if (wave < 2) {
+        const u32x4 q = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(tile_s) + tid * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(q, rs_act, nt1 * 2048 + tid * 16, 0, 16);          // sc1: write-through
+    }
+    const long long t_pub = wall_clock64();
+    // second half of the weights (the first half has landed during the reduction), then -- once half of THAT is in -- the activations:
+    // their producers publish at about the same time as this block, and a request that finds the pattern costs a whole extra round trip
+#pragma unroll
+    for (int u = 8; u < 16; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 
     // ---- phase 2: down projection (tile nt2, K slice `split`) -> fp32 slab, gemm_skinny_kernel<8, false>'s order ----
     u32x4 x2[KPW];
-    if (poll16(x2, rs_act, ks2, p.spin_limit) && lane == 0) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the step's result is void
+#pragma unroll
+    for (int u = 0; u < KPW; ++u) x2[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, (ks2 + u) * 1024 + lane * 16, 0, 16);   // sc1: L1 bypass
+    unsigned pending = 0xffffu;                              // k-steps whose activations are not (known to be) complete: wave-uniform
+    int gave_up = 1;
+    for (int it = 0; it < p.spin_limit; ++it) {
+        unsigned still = 0u;
+#pragma unroll
+        for (int u = 0; u < KPW; ++u) {
+            if (pending & (1u << u)) {
+                const bool bad = x2[u][0] == 0xffffffffu || x2[u][1] == 0xffffffffu || x2[u][2] == 0xffffffffu || x2[u][3] == 0xffffffffu;
+                if (__any(bad)) still |= 1u << u;
+            }
+        }
+        pending = still;
+        if (!pending) { gave_up = 0; break; }
+        __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+        for (int u = 0; u < KPW; ++u)
+            if (pending & (1u << u)) x2[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, (ks2 + u) * 1024 + lane * 16, 0, 16);
+    }
+    if (gave_up && lane == 0) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the step's result is void
     const long long t_go = wall_clock64();
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-    for (int u = 0; u < KPW; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wn[u]), as_frag4(x2[u]), acc, 0, 0, 0);
+    for (int u = 0; u < KPW; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(w2[u]), as_frag4(x2[u]), acc, 0, 0, 0);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) red0[wave][r][lane] = acc[r];
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
     __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = wave * RPW + i;
+        float t = red[0][r][lane];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) t += red[w][r][lane];
+        v[i] = t;
+    }
     {
-        float v[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = wave * 2 + i;
-            float tsum = red0[0][r][lane];
-#pragma unroll
-            for (int w = 1; w < WAVES; ++w) tsum += red0[w][r][lane];
-            v[i] = tsum;
-        }
-        const int r = wave * 2;
+        const int r = wave * RPW;
         const int n0 = nt2 * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
         *reinterpret_cast<float2*>(p.ws + ((size_t)split * p.rows_ws + m) * p.ldws + n0) = make_float2(v[0], v[1]);
     }
-    if (p.trace && tid == 0) {                              // block L, wave 0's clock
-        long long* q = p.trace + (size_t)L * 16;
-        q[0] = t_start; q[1] = t_loop1; q[2] = t_pub; q[3] = t_go; q[4] = wall_clock64();
-        { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); q[5] = (long long)(xcc & 0xf); }
-        q[6] = t_p0; q[7] = t_late; q[8] = t_ops0; q[9] = t_red0; q[10] = t_x1;
+    if (p.trace && tid == 0) {                              // block L: start | c_fc loop done | tile published | slice complete | end  (wave 0's clock)
+        long long* q = p.trace + (size_t)L * 8;
+        q[0] = t_start; q[1] = t_loop1; q[2] = t_pub; q[3] = t_go; q[4] = wall_clock64(); { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); q[5] = (long long)(xcc & 0xf); }
     }
 }
-static size_t mlp_fused_smem() { return (size_t)65536 + 2048 + 2048 + 32 * 17 * 4 + 64; }
+static size_t mlp_fused_smem() { return (size_t)8 * 16 * 64 * 4 + (size_t)8 * 32 * 8 + 2048 + 64; }
 
-static int init_mlp_fused_attrs() {          // 70 KiB of dynamic LDS: above the default limit
-    int r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_fused_smem());
-    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_fused_smem());
-    return r;
-}
-// 0 = launched; -1 = the shapes are outside the kernel's scope (the caller runs the separate launches)
+// 0 = launched; -1 = the shapes are outside the kernel's scope (the caller runs the two launches)
 int launch_mlp_fused(const MlpFusedArgs& a, hipStream_t st) {
     const int KS1 = a.K1 / 16, KS2 = a.K2 / 16, T1 = a.N1pad / 32, T2 = a.N2pad / 32;
     if (a.splitk < 1 || 8 % a.splitk || T1 % 8 || KS1 != 8 * 16 || KS2 != a.splitk * 8 * 16) return -1;      // 16 k-steps per wave in both phases
     if (T2 * a.splitk != T1 || a.K2 != a.N1pad || a.N1 != a.N1pad || a.N2 != a.N2pad) return -1;
     if (!a.err || !a.fold_c1 || !a.fold_c2) return -1;
-    if (a.Wc) {
-        // phase 0: 8 columns per block over K0 = 2048 (4 chunks of 32 per virtual wave), N0 = K1 = the residual width, one block per 8 columns
-        if (a.K0 != 2048 || a.N0 != a.K1 || a.N0 != 8 * T1 || !a.x0 || !a.h_old) return -1;
-        mlp_fused_kernel<true><<<T1, 512, mlp_fused_smem(), st>>>(a.W1, a.x1, a.W2, KS1, KS2, a.splitk, a);
-    } else {
-        mlp_fused_kernel<false><<<T1, 512, mlp_fused_smem(), st>>>(a.W1, a.x1, a.W2, KS1, KS2, a.splitk, a);
-    }
+    mlp_fused_kernel<<<T1, 512, mlp_fused_smem(), st>>>(a.W1, a.x1, a.W2, KS1, KS2, a.splitk, a);
     return 0;
 }
 
 static size_t skinny_smem(int waves) { return (size_t)waves * 16 * 64 * 4 + (size_t)waves * 32 * 8 + 16; }
 
 static int init_mt2_attrs();
-static int init_mlp_fused_attrs();
 int init_gemm_kernels() {
     // 16-wave blocks reduce through 64 KiB of LDS: above the default dynamic-LDS limit
     int r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (!r) r = init_mt2_attrs();
-    if (!r) r = init_mlp_fused_attrs();
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<bf16_t>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<float>),

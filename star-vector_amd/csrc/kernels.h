@@ -84,9 +84,6 @@ struct MlpFusedArgs {
     int* err;                                // set to 3 when a block gives up waiting (never a hang)
     int spin_limit;                          // polls before giving up
     long long* trace;                        // optional [N1pad / 32][8] wall-clock stamps per block (tools/mlp_trace.py); nullptr in production
-    // phase 0 (SV_EXP bit 256; Wc == nullptr: off): the attention output projection h_new = bf(h_old + bf(x0 Wc^T + bias_c)), N0 = K1
-    // columns, 8 per block; h_new IS x1 (phase 1's operand): the other buffer of the residual ping-pong, pre-filled with the pattern
-    const bf16_t* Wc; const bf16_t* x0; const bf16_t* bias_c; const bf16_t* h_old; int N0, K0;
 };
 int launch_mlp_fused(const MlpFusedArgs& a, hipStream_t st);
 
@@ -124,9 +121,6 @@ struct RowUpdateArgs {
     const bf16_t* g; const bf16_t* b; float eps;           // LayerNorm applied to the updated row
     bf16_t* xp_out;                                        // packed LN output
     int M, D;
-    // optional (SV_EXP bit 256): buffers the blocks fill with 0xFF bytes -- the "not written yet" pattern of the fused projection + MLP
-    // launch later in the layer (the other residual buffer, the GELU output); multiples of 16 bytes
-    void* poison0; unsigned poison0_bytes; void* poison1; unsigned poison1_bytes;
 };
 void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st);
 

@@ -209,17 +209,6 @@ __global__ __launch_bounds__(THREADS) void row_update_ln_kernel(const float* ws_
         for (int e = 0; e < 8; ++e) { hrow[c * 8 + e] = f[e]; s += f[e]; }
     }
     if (ws_ != nullptr) p = sv_late_args<RowUpdateArgs>(offsetof(RowUpdateKernarg, p));
-    if (p.poison0) {
-        // RowUpdateArgs::poison*: every block fills its share (stores only: nothing waits for them inside this kernel)
-        const u32x4 ff = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-        auto fill = [&](void* base, unsigned bytes) {
-            const unsigned share = ((bytes / 16 + gridDim.x - 1) / gridDim.x) * 16;
-            const unsigned lo = blockIdx.x * share, hi = min(lo + share, bytes);
-            for (unsigned off = lo + tid * 16; off < hi; off += THREADS * 16) *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(base) + off) = ff;
-        };
-        fill(p.poison0, p.poison0_bytes);
-        if (p.poison1) fill(p.poison1, p.poison1_bytes);
-    }
     s = wave_sum(s);
     if (lane == 0) redbuf[wave] = s;
     __syncthreads();

@@ -38,6 +38,8 @@ class EngineConfig:
     vit_eps: float = 1e-6
     sliding_window: int = 0          # v2: keys visible to a query (4096 for bigcode/starcoder2-7b); 0 = all
     weight_dtype: str = "bf16"       # "fp8_e4m3": decoder weights + lm_head quantised at load (per-row scales), BASELINE config 5
+    exclusive_device: bool = False   # this engine alone launches kernels on its GPU while decoding (one process per GPU): enables the
+                                     # all-blocks-resident fused launches (include/starvector_hip.h sv_config.exclusive_device); same tokens
 
     @property
     def query_length(self) -> int:
@@ -84,7 +86,7 @@ class HipEngine:
                      _lib.SV_ARCH_V2 if cfg.arch == "v2" else _lib.SV_ARCH_V1, cfg.n_kv_head, cfg.rope_theta,
                      cfg.vit_mlp, cfg.vit_eps if cfg.arch == "v2" else cfg.ln_eps,
                      int(cfg.sliding_window) if cfg.arch == "v2" else 0,
-                     {"bf16": 0, "fp8_e4m3": 1}[cfg.weight_dtype])
+                     {"bf16": 0, "fp8_e4m3": 1}[cfg.weight_dtype], int(bool(getattr(cfg, "exclusive_device", False))))
         h = C.c_void_p()
         check(self.lib.sv_create(C.byref(c), C.byref(h)), "sv_create")
         self._h = h
@@ -326,13 +328,13 @@ class HipEngine:
         check(self.lib.sv_debug_set_exp(self._h, int(mask)), "sv_debug_set_exp")
 
     def debug_mlp_trace(self) -> torch.Tensor:
-        """[blocks, 16] int64 wall-clock stamps (100 MHz) of the last fused MLP launch of the middle layer (engine created with
+        """[blocks, 8] int64 wall-clock stamps (100 MHz) of the last fused MLP launch of the middle layer (engine created with
         SV_MLP_TRACE=1 in the environment; include/starvector_hip.h, sv_debug_mlp_trace)."""
-        buf = (C.c_int64 * (1024 * 16))()
+        buf = (C.c_int64 * (1024 * 8))()
         n = self.lib.sv_debug_mlp_trace(self._h, buf, 1024)
         if n < 0:
             check(n, "sv_debug_mlp_trace")
-        return torch.tensor(list(buf[: n * 16]), dtype=torch.int64).view(n, 16)
+        return torch.tensor(list(buf[: n * 8]), dtype=torch.int64).view(n, 8)
 
     def debug_kv_load(self, layer: int, kv: torch.Tensor, lens: Optional[torch.Tensor] = None) -> None:
         """Test surface of the decode attention (include/starvector_hip.h, sv_debug_kv_load): kv [B, S, 2 * n_kv_head * head_dim]

@@ -67,7 +67,7 @@ def test_binding_arity_and_struct_fields_match_header():
 
 def test_struct_layouts():
     from starvector_amd._lib import SvConfig, SvSampling
-    assert C.sizeof(SvConfig) == 23 * 4
+    assert C.sizeof(SvConfig) == 24 * 4
     assert SvSampling.stop_ids.offset % 8 == 0 and SvSampling.seed.offset % 8 == 0
 
 
@@ -77,7 +77,7 @@ def test_default_config_is_starvector_1b(lib):
     lib.sv_config_default_1b(C.byref(c))
     assert (c.image_size, c.patch_size, c.vit_width, c.vit_layers, c.vit_heads) == (224, 14, 1024, 23, 16)
     assert (c.hidden, c.n_layer, c.n_head, c.n_inner, c.vocab, c.n_positions) == (2048, 24, 16, 8192, 49156, 8192)
-    assert (c.arch, c.n_kv_head) == (0, 1)
+    assert (c.arch, c.n_kv_head, c.exclusive_device) == (0, 1, 0)
     lib.sv_config_default_8b(C.byref(c))                   # siglip_384 + starcoder2-7b
     assert (c.image_size, c.patch_size, c.vit_layers, c.hidden, c.n_layer, c.n_head, c.n_kv_head, c.n_inner, c.vocab) == \
         (384, 16, 24, 4608, 32, 36, 4, 18432, 49157)

@@ -19,9 +19,7 @@ eng.load_random_weights(seed=1234)
 img = synthetic_images(torch, B, 224, seed=0).to(dev)
 prompt = torch.tensor([[7, 11]] * B, dtype=torch.long, device=dev)
 emb = torch.cat([eng.adapter(eng.encode_image(img)), eng.embed_tokens(prompt)], 1)
-MASK = int(sys.argv[1]) if len(sys.argv) > 1 else 128
-eng.set_exp(MASK)
-print(f"SV_EXP mask {MASK}")
+eng.set_exp(128)
 for rep in range(3):
     eng.generate(emb, max_length=emb.shape[1] + 128, eos_token_id=-1, pad_token_id=49152)
     tr = eng.debug_mlp_trace().double()
@@ -35,8 +33,5 @@ for rep in range(3):
     print(f"  segments (median): loop {float((us[:,1]-us[:,0]).median()):.2f}  reduce+publish {float((us[:,2]-us[:,1]).median()):.2f}  "
           f"wait for the slice {float((us[:,3]-us[:,2]).median()):.2f} (max {float((us[:,3]-us[:,2]).max()):.2f})  phase 2 {float((us[:,4]-us[:,3]).median()):.2f}")
     xcc = tr[:, 5].long()
-    if MASK & 256:
-        for k, n in ((7, "arguments read"), (8, "phase-0 operands used"), (9, "phase-0 reduced"), (6, "phase-0 piece published"), (10, "x1 complete")):
-            print(f"  {n:24s} {q((tr[:, k] - t0) / 100.0)}")
     print("  per XCC id: blocks", [int((xcc == x).sum()) for x in range(8)], " median end", [round(float(us[xcc == x, 4].median()), 2) if int((xcc == x).sum()) else None for x in range(8)])
 eng.close()
