@@ -243,6 +243,10 @@ int  sv_debug_set_col_tiles(int32_t col_tiles);
 /*   sv_debug_mlp_trace   (engine created with SV_MLP_TRACE=1) 100 MHz wall-clock stamps of the fused MLP launch (SV_EXP bit 128) of the
  *                        middle layer of the last decode step: host_out [blocks][8] = {start, c_fc loop done, tile published, slice
  *                        complete, end, XCC id, 0, 0}; returns the block count or a negative error code */
+/*   sv_debug_attn_trace  (engine created with SV_ATTN_TRACE=1) the same for the decode attention launch of the middle layer: host_out
+ *                        [rows * kv heads * context splits][16] = {start, first KV group requested, q in LDS, key groups processed,
+ *                        partial stored + drained, ticket drawn, end (0 unless the merging block), active splits, key groups, 0...} */
+int  sv_debug_attn_trace(sv_engine* e, int64_t* host_out, int32_t capacity_rows);
 int  sv_debug_mlp_trace(sv_engine* e, int64_t* host_out, int32_t capacity_blocks);
 int  sv_debug_kv_load(sv_engine* e, int32_t layer, const void* dev_kv, int32_t B, int32_t S, const int32_t* dev_lens,
                       sv_stream stream);

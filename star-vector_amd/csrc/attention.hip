@@ -346,6 +346,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
     constexpr int NKS = D / 32;          // k-steps of S^T (over head_dim)
     constexpr int NDV = D / 16;          // dv tiles of O^T
     constexpr int PART = 32 + 16 * D;    // floats per partial: m[16], l[16], O[16][D]
+    const long long t_start = wall_clock64();         // 100 MHz; stored only when the trace buffer is on (tools/attn_trace.py)
     const int bx = blockIdx.x;               // (sequence, KV head)
     const int b = bx / n_kv_;
     const int kvh = bx % n_kv_;
@@ -388,6 +389,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
     int g = g0 + split + act * wave;
     KvFrags<D> fa, fb;
     if (g < ngroups) load_group<D>(fa, pool, page_of(g), page_bytes, g, lane);
+    const long long t_kvreq = wall_clock64();          // position + table landed, first KV group requested
 
     // the KV stream is in flight: now the rest of the arguments (common.h sv_late_args)
     const AttnDecodeArgs p = sv_late_args<AttnDecodeArgs>(offsetof(AttnDecodeKernarg, p));
@@ -449,6 +451,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
         *reinterpret_cast<bf16_t*>(page + off) = kv_new[tid];
     }
 
+    const long long t_q = wall_clock64();              // q / k_new / v_new summed from the slabs and in LDS
     const int hd = lane & 15, c = lane >> 4;
     bf16x8 qf[NKS];
 #pragma unroll
@@ -536,6 +539,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
         g = g2;
     }
 
+    const long long t_loop = wall_clock64();           // this wave's key groups processed
     // merge the waves of this block (LDS), in wave order
     float l_tot = l_run + __shfl_xor(l_run, 16, 64);
     l_tot += __shfl_xor(l_tot, 32, 64);
@@ -587,7 +591,13 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
             __builtin_amdgcn_raw_buffer_store_b128(v, rs, my_off + (32 + idx) * 4, 0, 16);   // write-through
         }
     }
-    if (act == 1) return;
+    auto stamp = [&](long long t_part, long long t_tick, long long t_end) {
+        if (p.trace && tid == 0) {
+            long long* q = p.trace + ((size_t)bx * gridDim.y + split) * 16;
+            q[0] = t_start; q[1] = t_kvreq; q[2] = t_q; q[3] = t_loop; q[4] = t_part; q[5] = t_tick; q[6] = t_end; q[7] = act; q[8] = ngroups;
+        }
+    };
+    if (act == 1) { stamp(0, 0, wall_clock64()); return; }
     if (tid < 8) {
         // m[16] | l[16] of this block's partial: 8 x 16 bytes
         const bool is_l = tid >= 4;
@@ -613,12 +623,14 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
     // agent-scope ticket; the last arriver reads the partials with sc1 loads (L1 bypass)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    const long long t_part = wall_clock64();           // partial stored and drained
     if (tid == 0) {
         const unsigned t = __hip_atomic_fetch_add(p.counters + bx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         flag_s[0] = (t == (unsigned)(act - 1)) ? 1 : 0;
     }
     __syncthreads();
-    if (!flag_s[0]) return;
+    const long long t_tick = wall_clock64();           // ticket drawn
+    if (!flag_s[0]) { stamp(t_part, t_tick, 0); return; }
     const int seq_off = (int)((size_t)bx * AD_SPLIT * PART * 4);
     // merge: every load (statistics of all splits for this thread's head + its O columns) is issued before
     // the first use -> one memory round trip
@@ -654,6 +666,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
         *reinterpret_cast<uint2*>(p.out_xp + xp_index(b >> 5, p.out_KS, b & 31, col0 + idx)) = o;
     }
     if (tid == 0) __hip_atomic_store(p.counters + bx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    stamp(t_part, t_tick, wall_clock64());
 }
 
 size_t attn_decode_part_floats(int head_dim) { return (size_t)AD_SPLIT * (32 + 16 * (size_t)head_dim); }

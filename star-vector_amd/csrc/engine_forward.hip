@@ -265,6 +265,7 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
         if (!e->only_skinny) {
             AttnDecodeArgs ad;
             attn_decode_args(e, i, B, wsA, L.c_attn.splitk, L.c_attn.bias, e->xp_attn, ad);
+            if (i == c.n_layer / 2) ad.trace = e->attn_trace;             // SV_ATTN_TRACE=1: one layer in the middle of the step
             prof_mark(e, PK_ATTN, st);
             launch_attn_decode(ad, st);
         }

@@ -111,6 +111,7 @@ struct sv_engine {
     bool fold6 = false;             // 6 launches per layer: slab-free attention output projection + ln_2 folded into c_fc
     bool fold_ready = false;
     bool mlp_fused_ok = false;      // the MLP half as one launch (gemm.hip mlp_fused_kernel) fits this engine: shapes + one block per CU
+    long long* attn_trace = nullptr;// SV_ATTN_TRACE=1: wall-clock stamps of the decode attention of the middle layer, [rows * kv heads * splits][16]
     long long* mlp_trace = nullptr; // SV_MLP_TRACE=1: wall-clock stamps of the LAST fused MLP launch, [F / 32][8] (sv_debug_mlp_trace)
     bool only_skinny = false;       // profiling: enqueue only the weight-streaming GEMMs of a step
     bool skip_skinny = false;       // profiling: enqueue everything BUT the weight-streaming GEMMs

@@ -133,6 +133,21 @@ extern "C" int sv_debug_mlp_trace(sv_engine* e, int64_t* host_out, int32_t capac
     return T1;
 }
 
+// SV_ATTN_TRACE=1 at sv_create: wall-clock stamps (100 MHz ticks) of the decode attention launch of the middle layer of the LAST decode step,
+// host_out [rows * kv heads * splits][16] = {start, first KV group requested, q in LDS, key groups processed, partial stored + drained, ticket
+// drawn, end (0: not the merging block), active splits, key groups, 0...}; an all-zero row = an inactive split.  Returns the number of rows.
+extern "C" int sv_debug_attn_trace(sv_engine* e, int64_t* host_out, int32_t capacity_rows) {
+    if (!e || !host_out) return fail(SV_EINVAL, "sv_debug_attn_trace: null argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    if (!e->attn_trace) return fail(SV_ESTATE, "sv_debug_attn_trace: the engine was not created with SV_ATTN_TRACE=1");
+    const int rows = e->cached_B * e->nkv * attn_max_splits_of(e->cfg.max_batch, e->nkv, e->num_cus);
+    if (rows < 1 || capacity_rows < rows) return fail(SV_EINVAL, "sv_debug_attn_trace: capacity %d < %d rows", capacity_rows, rows);
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    HIPCHECK(hipDeviceSynchronize());
+    HIPCHECK(hipMemcpy(host_out, e->attn_trace, (size_t)rows * 16 * sizeof(int64_t), hipMemcpyDeviceToHost));
+    return rows;
+}
+
 extern "C" int sv_debug_set_col_tiles(int32_t col_tiles) {
     if (col_tiles < 0 || col_tiles > 3) return fail(SV_EINVAL, "sv_debug_set_col_tiles: 0..3");
     g_op_col_tiles = col_tiles;

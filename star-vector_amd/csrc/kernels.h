@@ -178,6 +178,7 @@ struct AttnDecodeArgs {
     const float* rope_cos; const float* rope_sin;          // [positions][D/2] rotary tables (nullptr: no RoPE)
     int window;                                            // sliding window: keys pos - window < j <= pos (0 = all)
     int groups_per_block;                                  // 32-key groups a block takes before another context split joins (0 = 4)
+    long long* trace;                                      // optional [B * n_kv * max_splits][16] wall-clock stamps (tools/attn_trace.py); nullptr in production
 };
 // in-place rotary embedding of the q and k heads of a prefill c_attn output (rotate_half convention)
 void launch_rope_prefill(bf16_t* qkv, int row_stride, int rows, int S0, int n_heads, int head_dim,

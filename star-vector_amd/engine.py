@@ -327,6 +327,16 @@ class HipEngine:
         """Experiment bit mask (SV_EXP) of the live engine: in-process A/B runs (tools/ab_exp.py)."""
         check(self.lib.sv_debug_set_exp(self._h, int(mask)), "sv_debug_set_exp")
 
+    def debug_attn_trace(self) -> torch.Tensor:
+        """[rows * kv heads * splits, 16] int64 wall-clock stamps (100 MHz) of the decode attention of the middle layer of the last
+        step (engine created with SV_ATTN_TRACE=1 in the environment; include/starvector_hip.h, sv_debug_attn_trace)."""
+        cap = 8192
+        buf = (C.c_int64 * (cap * 16))()
+        n = self.lib.sv_debug_attn_trace(self._h, buf, cap)
+        if n < 0:
+            check(n, "sv_debug_attn_trace")
+        return torch.tensor(list(buf[: n * 16]), dtype=torch.int64).view(n, 16)
+
     def debug_mlp_trace(self) -> torch.Tensor:
         """[blocks, 8] int64 wall-clock stamps (100 MHz) of the last fused MLP launch of the middle layer (engine created with
         SV_MLP_TRACE=1 in the environment; include/starvector_hip.h, sv_debug_mlp_trace)."""
