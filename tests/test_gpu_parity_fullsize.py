@@ -23,7 +23,7 @@ from tests.test_gpu_e2e import LOGIT_TOL
 pytestmark = pytest.mark.gpu
 
 
-def _teacher_forced_gpu(eng, emb, w_dev, cfg, n_new, tag, min_checked):
+def _teacher_forced_gpu(eng, emb, w_dev, cfg, n_new, tag, min_checked, max_near=None):
     """Oracle (float32 tensors on the GPU, bf16 cast points) greedy stream + logits; the engine is fed the oracle's tokens.
     Returns (o_toks cpu, margin cpu, band)."""
     S0 = emb.shape[1]
@@ -52,6 +52,8 @@ def _teacher_forced_gpu(eng, emb, w_dev, cfg, n_new, tag, min_checked):
            f"token-exact outside the band, {near} near-tie flips inside it; min margin {float(margin.min()):.3e}")
     print(msg)
     assert checked >= min_checked * B * n_new, msg
+    if max_near is not None:
+        assert near <= max_near, msg                                # in-band flips are legitimate near-ties; more of them = a regression
     return o_toks.cpu(), margin.cpu(), band
 
 
@@ -93,10 +95,13 @@ def test_config2_batch32_against_gpu_oracle():
     assert e1 <= 4e-2 and e2 <= 4e-2
     # coverage floor: with random-init weights ~80 % of the 2048 positions have a top-1/top-2 margin outside the band (measured:
     # 1634, min margin 0.0 -- exact ties exist); EVERY one of them must be token-exact and EVERY position's logits in tolerance
-    o_toks, margin, band = _teacher_forced_gpu(eng, emb, w_dev, cfg, n_new, "config2 B=32", 0.75)
+    # measured on the round-4 code (profiles/pytest_gpu_r04_final.log; the kernels are bit-deterministic, so these are properties of
+    # the code, not of the box): 1634 / 2048 positions outside the band, 8 in-band near-tie flips, 26 / 32 free-running rows follow the
+    # oracle to the end (the other six leave it AT an in-band near-tie: steps 1, 8, 15, 33, 42, 45).  Floors = measured minus a little.
+    o_toks, margin, band = _teacher_forced_gpu(eng, emb, w_dev, cfg, n_new, "config2 B=32", 0.78, max_near=16)
     got = eng.generate(emb, max_length=S0 + n_new, eos_token_id=-1, pad_token_id=cfg.pad_token_id).cpu()
     lead = _free_run_check(got, o_toks, margin, band, "config2 B=32")
-    assert sum(1 for t in lead if t == n_new) >= B // 2, f"only {sum(1 for t in lead if t == n_new)}/{B} rows follow the oracle to the end: {lead}"
+    assert sum(1 for t in lead if t == n_new) >= 24, f"only {sum(1 for t in lead if t == n_new)}/{B} rows follow the oracle to the end: {lead}"
     eng.close()
     del w_dev
     gc.collect(); torch.cuda.empty_cache()
