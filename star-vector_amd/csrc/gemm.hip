@@ -1262,14 +1262,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
 
 // ------------------------------------------------------------------------------------------------
 // mlp_fused_kernel: the MLP half of a decode layer (gpt_bigcode/modeling_gpt_bigcode.py:645-660: c_fc -> GELU-tanh -> c_proj) as ONE
-// launch of F/32 co-resident blocks (256 for StarVector-1B, one per CU), instead of gemm_skinny_kernel<8, true> (folded c_fc) and
-// gemm_skinny_kernel<8, false> (down projection, split-K slabs) with a kernel boundary between them.  Round-4 experiment behind
-// SV_EXP bit 128; kept only if it beats the two launches.
+// launch of F/32 co-resident blocks (256 for StarVector-1B, one 8-wave block per CU), instead of gemm_skinny_kernel<8, true> (folded
+// c_fc) and gemm_skinny_kernel<8, false> (down projection, split-K slabs) with a kernel boundary between them.  Round 4; on for an
+// engine that owns its GPU (sv_config.exclusive_device), SV_EXP bit 128 / 512 = forced on / off.  Measured in process on one MI355X,
+// BASELINE config 2: 1079 vs 1111 us per decode step, tokens bit-identical (every version's A/B and wall-clock
+// trace: profiles/mlp_fused_r04_ab.log).
 //
-//   Why it can pay (MI355X_MICROARCH.md price list: boundary, prefetch-credit): both GEMMs are pure weight streams (2 x 33.5 MB) and
-//   the WEIGHTS of the second one depend on nothing.  Two launches pay a boundary (1.7-1.9 us) plus the second kernel's ramp (first
-//   round trip to HBM with an idle chip); here every wave requests its whole share of the down projection's weights (16 KiB, 64
-//   VGPRs) as soon as its c_fc loop has issued its last MFMA, so that stream runs UNDER the c_fc epilogue, the publish and the wait.
+//   Why it pays (MI355X_MICROARCH.md price list: boundary, prefetch-credit): both GEMMs are pure weight streams (2 x 33.5 MB) and the
+//   WEIGHTS of the second one depend on nothing.  Two launches pay a boundary (1.7-1.9 us) plus the second kernel's cold start; here a
+//   wave requests the first half of its share of the down projection's weights as soon as its c_fc loop has issued its last MFMA, so
+//   HBM keeps streaming under the c_fc reduction, epilogue and publish.
 //
 //   Phase 1  block L = (xcd = L & 7, i = L >> 3): c_fc tile nt1 = split * (T1 / S) + (xcd / S) * (T1 / 8) + i with split = xcd % S --
 //            the 32 GELU output columns of a tile are 2 KiB contiguous in fragment order; they go LDS -> 16-byte sc1 (write-through)
@@ -1279,11 +1281,22 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
 //            = the tiles of 8 producer blocks; it reads them with sc1 loads (L1 bypass) and recognises "not written yet" by the data
 //            itself: the launch in front fills the buffer with the bf16 pair 0xFFFF'FFFF (two NaNs -- never a finite GELU output), a
 //            k-step that still shows the pattern is re-requested after an s_sleep, BOUNDED (a give-up code in *err, never a hang).
+//   What the traces taught (all of it in profiles/mlp_fused_r04_ab.log):
+//            * one arrival counter per K slice (64 arrivals + 64 pollers per word): 25.5 us per launch against 17.8 for two launches;
+//              one flag word per producer: 17.7 us (the publish store drained behind 24 MB of weight prefetch); in-band pattern: 14.9;
+//              + the first half of the weights requested before the reduction: 13.8 us -- this version.
+//            * a CU's miss queue takes ~64 KiB: a wave that requests more BLOCKS AT ISSUE until the queue drains, and a wave's loads
+//              return IN ORDER -- a poll queued behind 16 KiB of its own weight requests completes after them.  Requesting all 16 KiB
+//              at once, moving the reduction to two "critical-path" waves, and the attention output projection as a phase 0 in front
+//              (a residual-stream ping-pong, 4 launches per layer) were all built, bit-identical, and slower or equal: removed.
+//              Separating the weight stream from the polls needs a loader wave + LDS-DMA ring (another K partition): not built.
 //   Results  per-wave k ranges, MFMA order, cross-wave reduction order, fold statistics and epilogues are those of the two kernels it
-//            replaces: bit-identical slabs (tests/test_gpu_ops.py::test_fused_mlp_equals_the_two_launches).
-//   Safety   needs all F/32 blocks resident at once (1 per CU: the engine enables it only when #CUs >= F/32); the pattern is written by
-//            the kernel in front of it (gemm_cols_resid_kernel, ColsArgs::poison), never by this launch; a NaN activation (a numeric
-//            failure upstream) ends in the give-up code, i.e. in an error from sv_generate, as non-finite logits do.
+//            replaces: bit-identical slabs (tests/test_gpu_e2e.py::test_fused_mlp_launch_equals_the_two_launches_bit_for_bit).
+//   Safety   needs all F/32 blocks resident at once (one per CU): enabled only when #CUs >= F/32 AND the engine owns the device -- two
+//            processes decoding on one GPU could each hold part of the CUs and wait for blocks that cannot be scheduled (then both
+//            give up after the bounded spin and the call fails: never a hang, never wrong tokens).  The pattern is written by the
+//            kernel in front (gemm_cols_resid_kernel, ColsArgs::poison), never by this launch; a NaN pair with the pattern (corrupted
+//            inputs only: arithmetic NaNs are 0x7FC0) ends in the give-up code, i.e. an error from sv_generate.
 // ------------------------------------------------------------------------------------------------
 struct MlpFusedKernarg { const bf16_t* W1; const bf16_t* x1; const bf16_t* W2; int KS1; int KS2; int S; MlpFusedArgs p; };
 // amdgpu_waves_per_eu(2, 2): one 8-wave block per CU is the design point (2 waves per SIMD, 256 VGPRs each); without it the

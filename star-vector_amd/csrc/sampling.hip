@@ -428,8 +428,11 @@ __global__ __launch_bounds__(SP_THREADS) void cb_step_kernel(CbStepArgs p) {
     __shared__ float am_v[SP_THREADS / 64];
     __shared__ int am_i[SP_THREADS / 64];
     const int b = blockIdx.x;
-    const int s = p.slot_map ? p.slot_map[b] : b;
-    const CbSlot sl = p.slots[s];
+    // block-uniform by construction: say so, and the slot's fields travel as scalar loads into SGPRs instead of occupying ~30 VGPRs
+    // across sample_row (round 3: a by-value copy of the slot, 224 B of scratch per lane; now 80 B, all of it inside the general
+    // bisection path of sample_row, which holds 48 scores per thread under the 128-VGPR cap of a 1024-thread block)
+    const int s = __builtin_amdgcn_readfirstlane(p.slot_map ? p.slot_map[b] : b);
+    const CbSlot& sl = p.slots[s];                                  // a reference: the fields are read where they are used (uniform address)
     if (!sl.live) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* row = p.logits + (size_t)b * p.ld;
