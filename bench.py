@@ -205,8 +205,7 @@ def main():
             emb = eng.embed_tokens(prompt)                     # text2svg: no image encoder, no adapter
         else:
             enc = eng.encode_image(images)                     # a2-a5
-            vis = eng.adapter(enc)                             # a6
-            emb = torch.cat([vis, eng.embed_tokens(prompt)], 1)    # a1, a7
+            emb = eng.prepare_inputs(enc, prompt)              # a6 + a1 / a7: adapter rows and prompt rows written into one buffer
         new = eng.generate(emb, max_length=S0 + max_new, eos_token_id=-1,      # EOS disabled:
                            pad_token_id=PAD_ID,                                # fixed-length workload
                            do_sample=is8b, temperature=1.0, top_p=0.95, top_k=50 if is8b else 0,

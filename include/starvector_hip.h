@@ -180,6 +180,12 @@ int  sv_encode_image(sv_engine* e, const void* dev_image, int32_t B, void* dev_o
 int  sv_adapter(sv_engine* e, const void* dev_in, int32_t B, void* dev_out, sv_stream stream);
 /* ids [n] int64 (device) -> out [n, hidden] bf16 */
 int  sv_embed_tokens(sv_engine* e, const int64_t* dev_ids, int32_t n, void* dev_out, sv_stream stream);
+/* The same two ops writing STRAIGHT into the inputs_embeds buffer [B][S0][hidden] that sv_prefill / sv_generate read (starvector_base.py:
+ * 203-221 without the torch.cat): image b's visual rows -> rows 0 .. T-1 of its block; the P token rows of sequence b -> rows
+ * row0 .. row0 + P - 1 (row0 = T for im2svg).  dev_ids: int64 [B][P]. */
+int  sv_adapter_into(sv_engine* e, const void* dev_in, int32_t B, void* dev_embeds, int32_t S0, sv_stream stream);
+int  sv_embed_tokens_into(sv_engine* e, const int64_t* dev_ids, int32_t B, int32_t P, void* dev_embeds, int32_t S0, int32_t row0,
+                          sv_stream stream);
 
 /* Image pre-processing on device = `ImageTrainProcessor.__call__` (starvector/data/util.py:40-68):
  * dev_pixels uint8 [height][width][channels] (3 = RGB, 4 = RGBA composited on white) -> white pad to square -> Pillow's

@@ -84,6 +84,8 @@ PROTOTYPES = {
     "sv_encode_image": (_I, [_P, _P, _I, _P, _P]),
     "sv_adapter": (_I, [_P, _P, _I, _P, _P]),
     "sv_embed_tokens": (_I, [_P, _P, _I, _P, _P]),
+    "sv_adapter_into": (_I, [_P, _P, _I, _P, _I, _P]),
+    "sv_embed_tokens_into": (_I, [_P, _P, _I, _I, _P, _I, _I, _P]),
     "sv_preprocess_image": (_I, [_P, _I, _I, _I, _I, _I, C.POINTER(_F), C.POINTER(_F), _P, _P]),
     "sv_preprocess_workspace_bytes": (C.c_int64, [C.POINTER(_I), C.POINTER(_I), _I, _I, _I]),
     "sv_preprocess_images": (_I, [C.POINTER(_P), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _I, _I, _I, C.POINTER(_F),

@@ -81,15 +81,16 @@ static int vision_forward(sv_engine* e, const bf16_t* img, int B, bf16_t* out, h
     return 0;
 }
 
-static int adapter_forward(sv_engine* e, const bf16_t* in, int B, bf16_t* out, hipStream_t st) {
+// out_batch_stride (elements; 0 = T * D): image b's T visual rows go to out + b * stride, e.g. the head of its [S0][D] prompt block
+static int adapter_forward(sv_engine* e, const bf16_t* in, int B, bf16_t* out, hipStream_t st, size_t out_batch_stride = 0) {
     const sv_config& c = e->cfg;
     const int Dv = c.vit_width, D = c.hidden, T = e->T, M = B * T;
     gemm(in, Dv, e->ad_fc, nullptr, 0, e->a1, 2 * Dv, M, ACT_SWISH, 0, st);
     gemm(e->a1, 2 * Dv, e->ad_proj, nullptr, 0, e->a2, D, M, ACT_NONE, 0, st);
     if (c.adapter_norm == SV_NORM_LAYER)
-        launch_plane_layernorm(e->a2, e->ad_w, e->ad_b, out, B, T * D, c.ln_eps, st);
+        launch_plane_layernorm(e->a2, e->ad_w, e->ad_b, out, B, T * D, c.ln_eps, st, out_batch_stride);
     else
-        launch_token_batchnorm(e->a2, e->ad_w, e->ad_b, e->ad_rm, e->ad_rv, out, B, T, D, c.ln_eps, st);
+        launch_token_batchnorm(e->a2, e->ad_w, e->ad_b, e->ad_rm, e->ad_rv, out, B, T, D, c.ln_eps, st, out_batch_stride);
     return 0;
 }
 
@@ -353,6 +354,31 @@ extern "C" int sv_embed_tokens(sv_engine* e, const int64_t* dev_ids, int32_t n, 
     std::lock_guard<std::mutex> lk(e->mu);
     HIPCHECK(hipSetDevice(e->cfg.device));
     launch_gather_rows(e->wte, dev_ids, (bf16_t*)dev_out, n, e->cfg.hidden, (hipStream_t)stream);
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+
+// a1 (starvector_base.py:203-221) without the torch.cat: the adapter's visual rows and the prompt's token rows are written straight into
+// the caller's [B][T + P][D] inputs_embeds buffer (the one sv_prefill / sv_generate read)
+extern "C" int sv_adapter_into(sv_engine* e, const void* dev_in, int32_t B, void* dev_embeds, int32_t S0, sv_stream stream) {
+    SVCHECK(check_ready(e));
+    if (!dev_in || !dev_embeds || B < 1 || B > e->cfg.max_batch) return fail(SV_EINVAL, "sv_adapter_into: bad B=%d or null pointer", B);
+    if (S0 < e->T) return fail(SV_EINVAL, "sv_adapter_into: S0=%d is shorter than the %d visual rows", S0, e->T);
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    SVCHECK(adapter_forward(e, (const bf16_t*)dev_in, B, (bf16_t*)dev_embeds, (hipStream_t)stream, (size_t)S0 * e->cfg.hidden));
+    HIPCHECK(hipGetLastError());
+    return 0;
+}
+extern "C" int sv_embed_tokens_into(sv_engine* e, const int64_t* dev_ids, int32_t B, int32_t P, void* dev_embeds, int32_t S0, int32_t row0,
+                                    sv_stream stream) {
+    SVCHECK(check_ready(e));
+    if (!dev_ids || !dev_embeds || B < 1 || P < 0 || row0 < 0 || row0 + P > S0) return fail(SV_EINVAL, "sv_embed_tokens_into: bad argument (rows %d..%d of %d)", row0, row0 + P, S0);
+    if (P == 0) return 0;
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    const int D = e->cfg.hidden;
+    launch_gather_rows(e->wte, dev_ids, (bf16_t*)dev_embeds + (size_t)row0 * D, B * P, D, (hipStream_t)stream, P, (size_t)S0 * D);
     HIPCHECK(hipGetLastError());
     return 0;
 }

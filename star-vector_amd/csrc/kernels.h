@@ -130,15 +130,17 @@ void launch_vit_embed_lnpre(const bf16_t* patch_out, int ldp, const bf16_t* cls,
                             const bf16_t* g, const bf16_t* b, bf16_t* x, int B, int NP, int Dv, float eps,
                             hipStream_t st);
 void launch_dec_embed(const bf16_t* emb, const bf16_t* wpe, bf16_t* h, int B, int S0, int D, hipStream_t st);
-void launch_gather_rows(const bf16_t* table, const int64_t* ids, bf16_t* out, int n, int D, hipStream_t st);
+// per_seq > 0: row r goes to out + (r / per_seq) * seq_stride + (r % per_seq) * D (token rows written behind the visual rows of a prefill buffer)
+void launch_gather_rows(const bf16_t* table, const int64_t* ids, bf16_t* out, int n, int D, hipStream_t st, int per_seq = 0, size_t seq_stride = 0);
 void launch_gather_last_rows(const bf16_t* h, bf16_t* out, int B, int S0, int D, hipStream_t st);
 void launch_gather_tail_rows(const bf16_t* h, bf16_t* out, int B, int S0, int n_keep, int D, hipStream_t st);
 
 // ---- adapter norm -------------------------------------------------------------------------------
+// y_batch_stride (elements, 0 = planes back to back): the planes may be written straight into a [B][S0][D] prefill buffer
 void launch_plane_layernorm(const bf16_t* x, const bf16_t* g, const bf16_t* b, bf16_t* y, int B, int QD,
-                            float eps, hipStream_t st);
+                            float eps, hipStream_t st, size_t y_batch_stride = 0);
 void launch_token_batchnorm(const bf16_t* x, const bf16_t* w, const bf16_t* b, const bf16_t* rm,
-                            const bf16_t* rv, bf16_t* y, int B, int Q, int D, float eps, hipStream_t st);
+                            const bf16_t* rv, bf16_t* y, int B, int Q, int D, float eps, hipStream_t st, size_t y_batch_stride = 0);
 
 // ---- attention ----------------------------------------------------------------------------------
 struct AttnPrefillArgs {

@@ -393,23 +393,25 @@ void launch_dec_embed(const bf16_t* emb, const bf16_t* wpe, bf16_t* h, int B, in
 
 // wte lookup (starvector_v1.py:16-18): out[i][:] = table[ids[i]][:]
 __global__ void gather_rows_kernel(const bf16_t* __restrict__ table, const int64_t* __restrict__ ids,
-                                   bf16_t* __restrict__ out, int n, int D) {
+                                   bf16_t* __restrict__ out, int n, int D, int per_seq, size_t seq_stride) {
     const int NC = D >> 3;
     const size_t total = (size_t)n * NC;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % NC);
         const size_t r = i / NC;
-        *reinterpret_cast<uint4*>(out + r * D + c * 8) =
+        // row r = (sequence r / per_seq, position r % per_seq): sequences seq_stride elements apart (= per_seq * D: back to back)
+        *reinterpret_cast<uint4*>(out + (r / per_seq) * seq_stride + (r % per_seq) * (size_t)D + c * 8) =
             *reinterpret_cast<const uint4*>(table + (size_t)ids[r] * D + c * 8);
     }
 }
-void launch_gather_rows(const bf16_t* table, const int64_t* ids, bf16_t* out, int n, int D, hipStream_t st) {
+void launch_gather_rows(const bf16_t* table, const int64_t* ids, bf16_t* out, int n, int D, hipStream_t st, int per_seq, size_t seq_stride) {
+    if (per_seq < 1) { per_seq = n > 0 ? n : 1; seq_stride = (size_t)per_seq * D; }
     size_t total = (size_t)n * (D / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
-    gather_rows_kernel<<<blocks, 256, 0, st>>>(table, ids, out, n, D);
+    gather_rows_kernel<<<blocks, 256, 0, st>>>(table, ids, out, n, D, per_seq, seq_stride);
 }
 
 // last prompt row of every sequence (only that row feeds ln_f + lm_head in prefill)
@@ -453,12 +455,12 @@ void launch_gather_last_rows(const bf16_t* h, bf16_t* out, int B, int S0, int D,
 __global__ __launch_bounds__(1024) void plane_layernorm_kernel(const bf16_t* __restrict__ x,
                                                                const bf16_t* __restrict__ g,
                                                                const bf16_t* __restrict__ b,
-                                                               bf16_t* __restrict__ y, int QD, float eps) {
+                                                               bf16_t* __restrict__ y, int QD, float eps, size_t y_batch_stride) {
     __shared__ float red[16];
     __shared__ float stat[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bf16_t* xs = x + (size_t)blockIdx.x * QD;
-    bf16_t* ys = y + (size_t)blockIdx.x * QD;
+    bf16_t* ys = y + (size_t)blockIdx.x * y_batch_stride;         // (= QD: planes back to back; larger: straight into a prefill buffer)
     const int NC = QD >> 3;
     float s = 0.f;
     for (int c = tid; c < NC; c += 1024) {
@@ -510,8 +512,8 @@ __global__ __launch_bounds__(1024) void plane_layernorm_kernel(const bf16_t* __r
     }
 }
 void launch_plane_layernorm(const bf16_t* x, const bf16_t* g, const bf16_t* b, bf16_t* y, int B, int QD,
-                            float eps, hipStream_t st) {
-    plane_layernorm_kernel<<<B, 1024, 0, st>>>(x, g, b, y, QD, eps);
+                            float eps, hipStream_t st, size_t y_batch_stride) {
+    plane_layernorm_kernel<<<B, 1024, 0, st>>>(x, g, b, y, QD, eps, y_batch_stride ? y_batch_stride : (size_t)QD);
 }
 
 // adapter_norm="batch_norm": nn.BatchNorm1d(Q) in eval = per-token affine from running statistics
@@ -519,7 +521,7 @@ void launch_plane_layernorm(const bf16_t* x, const bf16_t* g, const bf16_t* b, b
 __global__ void token_batchnorm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                        const bf16_t* __restrict__ b, const bf16_t* __restrict__ rm,
                                        const bf16_t* __restrict__ rv, bf16_t* __restrict__ y, int B, int Q,
-                                       int D, float eps) {
+                                       int D, float eps, size_t y_batch_stride) {
     const int NC = D >> 3;
     const size_t total = (size_t)B * Q * NC;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -534,15 +536,15 @@ __global__ void token_batchnorm_kernel(const bf16_t* __restrict__ x, const bf16_
         unpack8(*reinterpret_cast<const uint4*>(x + row * D + c * 8), f);
 #pragma unroll
         for (int e = 0; e < 8; ++e) f[e] = (f[e] - mean) * inv * ww + bb;
-        *reinterpret_cast<uint4*>(y + row * D + c * 8) = pack8(f);
+        *reinterpret_cast<uint4*>(y + (row / Q) * y_batch_stride + (size_t)qi * D + c * 8) = pack8(f);
     }
 }
 void launch_token_batchnorm(const bf16_t* x, const bf16_t* w, const bf16_t* b, const bf16_t* rm,
-                            const bf16_t* rv, bf16_t* y, int B, int Q, int D, float eps, hipStream_t st) {
+                            const bf16_t* rv, bf16_t* y, int B, int Q, int D, float eps, hipStream_t st, size_t y_batch_stride) {
     size_t total = (size_t)B * Q * (D / 8);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 16384) blocks = 16384;
-    token_batchnorm_kernel<<<blocks, 256, 0, st>>>(x, w, b, rm, rv, y, B, Q, D, eps);
+    token_batchnorm_kernel<<<blocks, 256, 0, st>>>(x, w, b, rm, rv, y, B, Q, D, eps, y_batch_stride ? y_batch_stride : (size_t)Q * D);
 }
 
 }  // namespace sv

@@ -194,6 +194,20 @@ class HipEngine:
         check(self.lib.sv_embed_tokens(self._h, _ptr(ids), ids.numel(), _ptr(out), _stream()), "sv_embed_tokens")
         return out
 
+    def prepare_inputs(self, enc: torch.Tensor, prompt_ids: torch.Tensor) -> torch.Tensor:
+        """a1 (starvector_base.py:203-221) without the concatenation: adapter(enc) and the prompt's token embeddings are written straight
+        into one [B, T + P, hidden] inputs_embeds buffer (the reference builds it with torch.cat; same values, no ATen kernel)."""
+        enc = _need(enc, torch.bfloat16, "adapter input")
+        ids = _need(prompt_ids, torch.int64, "input_ids")
+        B, T = enc.shape[0], self.cfg.query_length
+        if enc.shape[1:] != (T, self.cfg.vit_width) or ids.dim() != 2 or ids.shape[0] != B:
+            raise ValueError(f"prepare_inputs: enc [B,{T},{self.cfg.vit_width}] and prompt_ids [B,P] expected")
+        P = ids.shape[1]
+        out = torch.empty(B, T + P, self.cfg.hidden, dtype=torch.bfloat16, device=enc.device)
+        check(self.lib.sv_adapter_into(self._h, _ptr(enc), B, _ptr(out), T + P, _stream()), "sv_adapter_into")
+        check(self.lib.sv_embed_tokens_into(self._h, _ptr(ids), B, P, _ptr(out), T + P, T, _stream()), "sv_embed_tokens_into")
+        return out
+
     def prefill(self, inputs_embeds: torch.Tensor) -> torch.Tensor:
         x = _need(inputs_embeds, torch.bfloat16, "inputs_embeds")
         B, S0, D = x.shape

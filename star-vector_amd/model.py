@@ -714,13 +714,20 @@ class StarVectorStarCoder(nn.Module):
         image = batch["image"].to(device).to(self.model_precision)
         if image.dim() == 3:                  # one un-batched image, what `processor(pil)["pixel_values"]` returns for v1
             image = image.unsqueeze(0)
-        embedded_image = self.image_projection(self.image_encoder(image))
-        embedded_att = torch.ones(embedded_image.size()[:-1], dtype=torch.long, device=device)
         if prompt is None:
             prompt = self.svg_transformer.prompt
         prompt_tokens = self._tokenize([prompt] * image.size(0), None, device, add_special_tokens=False)
+        # image_projection(image_encoder(image)) and _get_embeddings(prompt ids), written straight into ONE inputs_embeds buffer instead of
+        # two tensors + torch.cat (same values: tests/test_gpu_e2e.py; the separate module calls stay available and equal)
+        enc = self.image_encoder(image)
+        ids = prompt_tokens.input_ids.to(device)
+        prep = getattr(getattr(self.image_projection, "_engine", None), "prepare_inputs", None)
+        if prep is not None and not bool((prompt_tokens.attention_mask == 0).any()):
+            inputs_embeds = prep(enc, ids)
+        else:
+            inputs_embeds = torch.cat([self.image_projection(enc), self._get_embeddings(ids)], dim=1)
+        embedded_att = torch.ones(inputs_embeds.shape[0], inputs_embeds.shape[1] - ids.shape[1], dtype=torch.long, device=device)
         attention_mask = torch.cat([embedded_att, prompt_tokens.attention_mask], dim=1)
-        inputs_embeds = torch.cat([embedded_image, self._get_embeddings(prompt_tokens.input_ids)], dim=1)
         return inputs_embeds, attention_mask, prompt_tokens
 
     def _get_generation_kwargs(self, base_kwargs):                    # starvector_base.py:223-241

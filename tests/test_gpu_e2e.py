@@ -862,3 +862,21 @@ def test_fused_mlp_launch_equals_the_two_launches_bit_for_bit():
     toks = own.generate(emb2, max_length=emb2.shape[1] + 150, eos_token_id=-1, pad_token_id=49152).cpu()
     assert torch.equal(toks, runs[0][1])
     own.close()
+
+
+@pytest.mark.parametrize("norm", ["layer_norm", "batch_norm"])
+def test_prepare_inputs_writes_the_prefill_buffer_directly(norm):
+    """a1 (starvector_base.py:203-221): `prepare_inputs` = torch.cat([adapter(enc), wte(prompt ids)], 1) bit for bit, without the ATen
+    concatenation kernel (both adapter norms; the drop-in `_prepare_generation_inputs` goes through it)."""
+    cfg = dataclasses.replace(O.OracleConfig.tiny(), adapter_norm=norm)
+    w = O.make_weights(cfg, seed=77)
+    eng = build_engine(cfg, w, max_batch=4, max_seq_len=64)
+    img = O.synthetic_images(3, cfg.image_size, seed=5)
+    ids = torch.tensor([[7, 11, 13], [2, 3, 4], [500, 1, 9]], dtype=torch.long, device=dev())
+    enc = eng.encode_image(bf(img))
+    want = torch.cat([eng.adapter(enc), eng.embed_tokens(ids)], 1)
+    got = eng.prepare_inputs(enc, ids)
+    assert got.shape == want.shape and torch.equal(got, want)
+    with pytest.raises(ValueError):
+        eng.prepare_inputs(enc, ids[:2])
+    eng.close()
