@@ -331,6 +331,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "decoder weight-streaming GEMMs: " + (
                              "gemm_skinny_mt2_kernel (two row tiles, up to three column tiles per block)" if B_PER_GPU > 32 else
                              "gemm_skinny_kernel" if (is8b or args.weights != "bf16") else
+                             "gemm_skinny_kernel + gemm_cols_resid_kernel (attention output projection) + mlp_fused_kernel (c_fc and down projection in one launch)"
+                             if ec.exclusive_device else
                              "gemm_skinny_kernel (+ gemm_cols_resid_kernel for the attention output projection)") + f", {int(launches)} launches/step",
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4) if achieved else None, "traffic": traffic,

@@ -48,12 +48,13 @@ for s in "${STEPS[@]}"; do
       find "$OUT/rocprof" -name '*kernel_trace.csv' -size +8M -delete 2>/dev/null   # keep the pull under 64 MiB
       head -14 "$OUT/rocprof_kernel_stats.csv" | cut -c1-160 ;;
     pmc)
-      for ctr in FETCH_SIZE WRITE_SIZE SQ_VALU_MFMA_BUSY_CYCLES; do
-        ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$ROOT/$OUT/pmc_$ctr" -- \
+      for ctr in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+        tagc="${ctr%% *}"
+        ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d "$ROOT/$OUT/pmc_$tagc" -- \
             python "$ROOT/bench.py" --no-cpu-baseline --steps 1 --warmup 0 --new-tokens 64 --ttft-requests 1 \
-            > /dev/null 2> "$ROOT/$OUT/pmc_$ctr.err" )
-        python tools/pmc_summary.py "$OUT/pmc_$ctr" "$OUT/pmc_$ctr.json" > /dev/null 2>&1 || true
-        find "$OUT/pmc_$ctr" -name '*.csv' -size +8M -delete 2>/dev/null
+            > /dev/null 2> "$ROOT/$OUT/pmc_$tagc.err" )
+        python tools/pmc_summary.py "$OUT/pmc_$tagc" "$OUT/pmc_$tagc.json" > /dev/null 2>&1 || true
+        find "$OUT/pmc_$tagc" -name '*.csv' -size +8M -delete 2>/dev/null
       done ;;
     smoke) python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee "$OUT/smoke.log" ;;
     ctx) timeout 400 python tools/ctx_sweep.py 2>&1 | tee "$OUT/ctx_sweep.log" ;;

@@ -8,7 +8,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "star-vector_amd"))
-SRC = ["gemm", "decode_cols", "rowops", "attention", "sampling", "beam", "preprocess", "engine"]
+SRC = ["gemm", "decode_cols", "rowops", "attention", "sampling", "beam", "preprocess", "engine_core"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-mllvm", "-amdgpu-kernarg-preload-count=16"]
 print("# Kernel resources (hipcc -Rpass-analysis=kernel-resource-usage, gfx950, the build flags of star-vector_amd/build.py)\n")
 print("| source | kernel | VGPRs | AGPRs | SGPRs | scratch B/lane | static LDS B | occupancy waves/SIMD |")

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Average a rocprofv3 --pmc counter per kernel name from *counter_collection.csv."""
+"""Average a rocprofv3 --pmc counter per kernel name from *counter_collection.csv; when the pass also left a kernel trace, the
+average dispatch duration of each kernel is added as the pseudo-counter DURATION_NS (what MFMA-busy cycles are divided by)."""
 import csv
 import glob
 import json
@@ -21,6 +22,14 @@ def main():
                 except ValueError:
                     continue
                 agg[name][cname].append(val)
+    for fn in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        with open(fn) as f:
+            for r in csv.DictReader(f):
+                name = (r.get("Kernel_Name") or "").split("(")[0][-48:]
+                try:
+                    agg[name]["DURATION_NS"].append(float(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+                except (KeyError, ValueError):
+                    continue
     res = {k: {c: {"calls": len(v), "avg": sum(v) / len(v), "min": min(v), "max": max(v)} for c, v in cs.items()}
            for k, cs in agg.items()}
     with open(out, "w") as f:
