@@ -366,7 +366,19 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
     int act = (ngroups - g0 + gpb_ - 1) / gpb_;         // gpb_: 32-key groups a block takes before another context split joins
     act = act > max_splits_ ? max_splits_ : act;      // host cap: B * act <= #CUs (one block per CU) and <= AD_SPLIT
     act = act < 1 ? 1 : act;
-    if (split >= act) return;
+    // AttnDecodeArgs::poison: every block of the launch stores 16 bytes per thread of the pattern -- the inactive splits before they
+    // leave, the active ones once their KV stream is in flight (the arguments are read late in both cases: off the critical path)
+    auto poison = [&](const AttnDecodeArgs& q) {
+        if (q.poison) {
+            const unsigned off = ((blockIdx.y * gridDim.x + blockIdx.x) * (AD_WAVES * 64) + threadIdx.x) * 16u;
+            if (off < q.poison_bytes)
+                *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(q.poison) + off) = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        }
+    };
+    if (split >= act) {
+        poison(sv_late_args<AttnDecodeArgs>(offsetof(AttnDecodeKernarg, p)));
+        return;
+    }
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* q_s = reinterpret_cast<bf16_t*>(smem);                       // [16][D]
@@ -393,6 +405,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
 
     // the KV stream is in flight: now the rest of the arguments (common.h sv_late_args)
     const AttnDecodeArgs p = sv_late_args<AttnDecodeArgs>(offsetof(AttnDecodeKernarg, p));
+    poison(p);
     const int H = p.H;                       // all query heads of the model
     const int G = H / n_kv_;                 // query heads sharing this KV head (<= 16): the MFMA N side
     const int HD = G * D;                    // output columns owned by this block

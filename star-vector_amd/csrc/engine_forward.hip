@@ -263,10 +263,18 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
         DecLayer& L = e->dec[i];
         row_update();                                            // embedding or the previous layer's down-proj -> LN1(h)
         skinny(e->xp_a, L.c_attn, SK_OUT_PARTIAL, wsA);
+        // c_fc + down projection in ONE launch (gemm.hip mlp_fused_kernel): on when the engine owns its GPU (sv_config.exclusive_device);
+        // SV_EXP bit 128 forces it on, bit 512 off (in-process A/B, tools/ab_exp.py).  It recognises unwritten activations by a pattern
+        // that an EARLIER launch of the layer leaves in the buffer: the attention launch (16 bytes per thread: free in a latency-bound
+        // kernel), or -- grid too small, or the profiling leg without attention -- the projection kernel (+0.5 us there)
+        const bool fused = fold6 && e->mlp_fused_ok && !(e->exp & 512) && (c.exclusive_device || (e->exp & 128));
+        const size_t pat_bytes = (size_t)(F / 16) * 1024;
+        const bool attn_poisons = fused && !e->only_skinny && pat_bytes <= (size_t)B * e->nkv * attn_max_splits(e) * 512 * 16;
         if (!e->only_skinny) {
             AttnDecodeArgs ad;
             attn_decode_args(e, i, B, wsA, L.c_attn.splitk, L.c_attn.bias, e->xp_attn, ad);
             if (i == c.n_layer / 2) ad.trace = e->attn_trace;             // SV_ATTN_TRACE=1: one layer in the middle of the step
+            if (attn_poisons) { ad.poison = e->xp_mlp; ad.poison_bytes = (unsigned)pat_bytes; }
             prof_mark(e, PK_ATTN, st);
             launch_attn_decode(ad, st);
         }
@@ -277,10 +285,7 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
             memset(&ca, 0, sizeof(ca));
             ca.xp = e->xp_attn; ca.Wp = L.c_proj.Wp; ca.bias = L.c_proj.bias; ca.MT = MT; ca.N = L.c_proj.N; ca.K = L.c_proj.Kpad;
             ca.cpb = L.c_proj.cpb; ca.h_xp = e->h_xp; ca.out_KS = D / 16;
-            // c_fc + down projection in ONE launch (gemm.hip mlp_fused_kernel): on when the engine owns its GPU (sv_config.exclusive_device);
-            // SV_EXP bit 128 forces it on, bit 512 off (in-process A/B, tools/ab_exp.py)
-            const bool fused = e->mlp_fused_ok && !(e->exp & 512) && (c.exclusive_device || (e->exp & 128));
-            if (fused) { ca.poison = e->xp_mlp; ca.poison_bytes = (unsigned)((size_t)(F / 16) * 1024); }
+            if (fused && !attn_poisons) { ca.poison = e->xp_mlp; ca.poison_bytes = (unsigned)pat_bytes; }
             if (!e->skip_skinny) { prof_mark(e, PK_SKINNY, st); launch_gemm_cols(ca, st); }
             if (fused) {
                 MlpFusedArgs ma;

@@ -182,6 +182,9 @@ struct AttnDecodeArgs {
     int window;                                            // sliding window: keys pos - window < j <= pos (0 = all)
     int groups_per_block;                                  // 32-key groups a block takes before another context split joins (0 = 4)
     long long* trace;                                      // optional [B * n_kv * max_splits][16] wall-clock stamps (tools/attn_trace.py); nullptr in production
+    void* poison; unsigned poison_bytes;                   // optional: a buffer the launch fills with 0xFF bytes, 16 per thread, before anything else (the
+                                                           // "not written yet" pattern of the fused MLP launch later in the layer): this kernel is bound by
+                                                           // latencies, a store per thread costs it nothing -- in gemm_cols_resid_kernel it cost 0.5 us
 };
 // in-place rotary embedding of the q and k heads of a prefill c_attn output (rotate_half convention)
 void launch_rope_prefill(bf16_t* qkv, int row_stride, int rows, int S0, int n_heads, int head_dim,
