@@ -304,10 +304,9 @@ void launch_kv_write_prefill(const bf16_t* qkv, int row_stride, int k_off, int v
 // (<= 64 KiB of KV each); the grid is (B, AD_SPLIT) so the captured hipGraph is static and the inactive
 // splits exit at once.  Active blocks own the 32-key
 // groups g = split + act*(wave + 8*i), prefetch the next group's fragments while the MFMAs of the
-// current one run, and (act > 1) leave a partial (m, l, O) in HBM; split 0's block merges the partials in
-// split order (bitwise deterministic).  Hand-off IN BAND (round 4): write-through (sc1) partial stores,
-// the merger polls the slots themselves with sc1 loads (an invalid slot holds the float pattern
-// 0xFFFF'FFFF): no ticket, no drain, no fences, placement independent.
+// current one run, and (act > 1) leave a partial (m, l, O) in HBM; an arrival ticket elects the last
+// block, which merges the partials in split order (bitwise deterministic).  Hand-off = write-through
+// (sc1) partial stores + drained ticket + sc1 loads in the merger: no fences, placement independent.
 // ------------------------------------------------------------------------------------------------
 #define AD_WAVES 8
 #define AD_SPLIT 16
@@ -386,6 +385,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
     float* m_s = reinterpret_cast<float*>(kv_new + 2 * D);               // [AD_WAVES][16]
     float* l_s = m_s + AD_WAVES * 16;                                    // [AD_WAVES][16]
     float* O_s = l_s + AD_WAVES * 16;                                    // [AD_WAVES][16][D]
+    int* flag_s = reinterpret_cast<int*>(O_s + AD_WAVES * 16 * D);       // [4]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -565,129 +565,120 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
         *reinterpret_cast<float4*>(O_s + ((size_t)(wave * 16 + hd)) * D + 16 * t + 4 * c) =
             make_float4(accO[t][0], accO[t][1], accO[t][2], accO[t][3]);
     __syncthreads();
-    // each thread owns 4 consecutive outputs (same head; 16 * D <= 2048 = 4 per thread): 16-byte stores for the partial / 8-byte for the result
+    // each thread owns 4 consecutive outputs (same head): 16-byte stores for the partial / 8-byte for the result
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         p.part, 0, (unsigned)((size_t)p.B * p.n_kv * AD_SPLIT * PART * sizeof(float)), 0x00020000);
     const int my_off = (int)(((size_t)bx * AD_SPLIT + split) * PART * 4);            // bytes
     const int col0 = kvh * G * D;            // this block's first output column ((kvh*G + h)*D + dv = col0 + idx)
+    for (int idx = tid * 4; idx < 16 * D; idx += AD_WAVES * 64 * 4) {
+        const int h = idx / D, dv = idx % D;
+        float M = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < AD_WAVES; ++w) M = fmaxf(M, m_s[w * 16 + h]);
+        float num[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < AD_WAVES; ++w) {
+            const float mw = m_s[w * 16 + h];
+            const float f = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+            const float4 o = *reinterpret_cast<const float4*>(O_s + ((size_t)(w * 16 + h)) * D + dv);
+            num[0] += f * o.x; num[1] += f * o.y; num[2] += f * o.z; num[3] += f * o.w;
+        }
+        if (act == 1) {
+            if (idx < HD) {
+                float den = 0.f;
+#pragma unroll
+                for (int w = 0; w < AD_WAVES; ++w) {
+                    const float mw = m_s[w * 16 + h];
+                    den += ((mw == -INFINITY) ? 0.f : __expf(mw - M)) * l_s[w * 16 + h];
+                }
+                const float inv = 1.0f / den;
+                uint2 o;
+                o.x = pack2bf(num[0] * inv, num[1] * inv);
+                o.y = pack2bf(num[2] * inv, num[3] * inv);
+                *reinterpret_cast<uint2*>(p.out_xp + xp_index(b >> 5, p.out_KS, b & 31, col0 + idx)) = o;
+            }
+        } else {
+            u32x4 v;
+            v[0] = __float_as_uint(num[0]); v[1] = __float_as_uint(num[1]);
+            v[2] = __float_as_uint(num[2]); v[3] = __float_as_uint(num[3]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, my_off + (32 + idx) * 4, 0, 16);   // write-through
+        }
+    }
     auto stamp = [&](long long t_part, long long t_tick, long long t_end) {
         if (p.trace && tid == 0) {
             long long* q = p.trace + ((size_t)bx * gridDim.y + split) * 16;
             q[0] = t_start; q[1] = t_kvreq; q[2] = t_q; q[3] = t_loop; q[4] = t_part; q[5] = t_tick; q[6] = t_end; q[7] = act; q[8] = ngroups;
         }
     };
-    const int idx = tid * 4;
-    const bool own = idx < 16 * D;
-    const int h = own ? idx / D : 0, dv = own ? idx % D : 0;
-    // this block's partial for the thread's 4 outputs: (M, den) of head h over the 8 waves, num[4] -- in wave order
-    float M = -INFINITY;
+    if (act == 1) { stamp(0, 0, wall_clock64()); return; }
+    if (tid < 8) {
+        // m[16] | l[16] of this block's partial: 8 x 16 bytes
+        const bool is_l = tid >= 4;
+        u32x4 v;
 #pragma unroll
-    for (int w = 0; w < AD_WAVES; ++w) M = fmaxf(M, m_s[w * 16 + h]);
-    float num[4] = {0.f, 0.f, 0.f, 0.f}, den = 0.f;
+        for (int j = 0; j < 4; ++j) {
+            const int h = (tid & 3) * 4 + j;
+            float M = -INFINITY;
 #pragma unroll
-    for (int w = 0; w < AD_WAVES; ++w) {
-        const float mw = m_s[w * 16 + h];
-        const float f = (mw == -INFINITY) ? 0.f : __expf(mw - M);
-        const float4 o = *reinterpret_cast<const float4*>(O_s + ((size_t)(w * 16 + h)) * D + dv);
-        num[0] += f * o.x; num[1] += f * o.y; num[2] += f * o.z; num[3] += f * o.w;
-        den += f * l_s[w * 16 + h];
-    }
-    if (act == 1) {
-        if (own && idx < HD) {
-            const float inv = 1.0f / den;
-            uint2 o;
-            o.x = pack2bf(num[0] * inv, num[1] * inv);
-            o.y = pack2bf(num[2] * inv, num[3] * inv);
-            *reinterpret_cast<uint2*>(p.out_xp + xp_index(b >> 5, p.out_KS, b & 31, col0 + idx)) = o;
-        }
-        stamp(0, 0, wall_clock64());
-        return;
-    }
-    // ---- more than one context split: the partials meet in split 0's block.  Hand-off IN BAND (round 4; the ticket version spent 3.0 us
-    // on "store the partial with write-through stores AND wait for them to drain", 0.6 us on the ticket and 1.5 us re-reading, at every
-    // layer: profiles/attn_trace_r04.log): a partial slot holds the float pattern 0xFFFF'FFFF (a NaN no partial contains) whenever it is
-    // not valid -- the engine fills the buffer once, the merging block restores the pattern after it has read a slot.  Blocks of splits
-    // >= 1 store (m, l, O) write-through and EXIT (nothing to drain, no ticket); split 0's block keeps its own partial in registers,
-    // polls the other act - 1 slots with sc1 loads (each thread its own 4 outputs + the statistics of its head; a slot that still shows
-    // the pattern is re-requested after an s_sleep, bounded) and merges in split order: bitwise the arithmetic of the ticket version.
-    if (split != 0) {
-        if (own) {
-            u32x4 v;
-            v[0] = __float_as_uint(num[0]); v[1] = __float_as_uint(num[1]); v[2] = __float_as_uint(num[2]); v[3] = __float_as_uint(num[3]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs, my_off + (32 + idx) * 4, 0, 16);   // write-through
-            if (dv == 0) {          // one thread per head: m | l
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(M), rs, my_off + h * 4, 0, 16);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(den), rs, my_off + (16 + h) * 4, 0, 16);
+            for (int w = 0; w < AD_WAVES; ++w) M = fmaxf(M, m_s[w * 16 + h]);
+            float den = 0.f;
+#pragma unroll
+            for (int w = 0; w < AD_WAVES; ++w) {
+                const float mw = m_s[w * 16 + h];
+                den += ((mw == -INFINITY) ? 0.f : __expf(mw - M)) * l_s[w * 16 + h];
             }
+            v[j] = __float_as_uint(is_l ? den : M);
         }
-        stamp(wall_clock64(), 0, 0);
-        return;
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, my_off + tid * 16, 0, 16);
     }
-    const long long t_part = wall_clock64();
+
+    // hand-off without fences: write-through (sc1) partial, every storing wave drains, one relaxed
+    // agent-scope ticket; the last arriver reads the partials with sc1 loads (L1 bypass)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const long long t_part = wall_clock64();           // partial stored and drained
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(p.counters + bx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag_s[0] = (t == (unsigned)(act - 1)) ? 1 : 0;
+    }
+    __syncthreads();
+    const long long t_tick = wall_clock64();           // ticket drawn
+    if (!flag_s[0]) { stamp(t_part, t_tick, 0); return; }
     const int seq_off = (int)((size_t)bx * AD_SPLIT * PART * 4);
-    u32x4 ov[AD_SPLIT];
-    float ms[AD_SPLIT], ls[AD_SPLIT];
-    ov[0][0] = __float_as_uint(num[0]); ov[0][1] = __float_as_uint(num[1]); ov[0][2] = __float_as_uint(num[2]); ov[0][3] = __float_as_uint(num[3]);
-    ms[0] = M; ls[0] = den;
-    unsigned pend = own ? ((1u << act) - 2u) : 0u;          // splits 1 .. act - 1 (per thread)
+    // merge: every load (statistics of all splits for this thread's head + its O columns) is issued before
+    // the first use -> one memory round trip
+    for (int idx = tid * 4; idx < HD; idx += AD_WAVES * 64 * 4) {
+        const int h = idx / D;
+        u32x4 ov[AD_SPLIT];
+        float ms[AD_SPLIT], ls[AD_SPLIT];
 #pragma unroll
-    for (int s2 = 1; s2 < AD_SPLIT; ++s2) { ov[s2] = u32x4{0u, 0u, 0u, 0u}; ms[s2] = -INFINITY; ls[s2] = 0.f; }
-    int gave_up = 1;
-    for (int it = 0; it < (1 << 16); ++it) {
-#pragma unroll
-        for (int s2 = 1; s2 < AD_SPLIT; ++s2) {
-            if (pend & (1u << s2)) {
+        for (int s2 = 0; s2 < AD_SPLIT; ++s2) {
+            ov[s2] = u32x4{0u, 0u, 0u, 0u};
+            ms[s2] = -INFINITY; ls[s2] = 0.f;
+            if (s2 < act) {
                 ms[s2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, seq_off + (s2 * PART + h) * 4, 0, 16));
                 ls[s2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, seq_off + (s2 * PART + 16 + h) * 4, 0, 16));
                 ov[s2] = __builtin_amdgcn_raw_buffer_load_b128(rs, seq_off + (s2 * PART + 32 + idx) * 4, 0, 16);
             }
         }
-        unsigned still = 0u;
+        float M = -INFINITY;
 #pragma unroll
-        for (int s2 = 1; s2 < AD_SPLIT; ++s2) {
-            if (pend & (1u << s2)) {
-                const bool bad = __float_as_uint(ms[s2]) == 0xffffffffu || __float_as_uint(ls[s2]) == 0xffffffffu || ov[s2][0] == 0xffffffffu ||
-                                 ov[s2][1] == 0xffffffffu || ov[s2][2] == 0xffffffffu || ov[s2][3] == 0xffffffffu;
-                if (bad) still |= 1u << s2;
-            }
-        }
-        pend = still;
-        if (!__any(pend != 0u)) { gave_up = 0; break; }
-        __builtin_amdgcn_s_sleep(8);
-    }
-    if (gave_up && lane == 0 && p.err) __hip_atomic_store(p.err, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // the step's result is void
-    const long long t_tick = wall_clock64();
-    __syncthreads();                                       // the m | l words of a head are read by the D / 4 threads of that head and rewritten
-                                                           // by one of them: nobody restores the pattern before everybody has its values
-    if (own) {
-        // restore the pattern in the slots this thread has read (plain stores: the next launch is a kernel boundary away)
-#pragma unroll
-        for (int s2 = 1; s2 < AD_SPLIT; ++s2) {
-            if (s2 < act) {
-                float* slot = p.part + ((size_t)bx * AD_SPLIT + s2) * PART;
-                *reinterpret_cast<u32x4*>(slot + 32 + idx) = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-                if (dv == 0) { reinterpret_cast<uint32_t*>(slot)[h] = 0xffffffffu; reinterpret_cast<uint32_t*>(slot)[16 + h] = 0xffffffffu; }
-            }
-        }
-    }
-    if (own && idx < HD) {
-        float Mx = -INFINITY;
-#pragma unroll
-        for (int s2 = 0; s2 < AD_SPLIT; ++s2) Mx = fmaxf(Mx, ms[s2]);
-        float nm[4] = {0.f, 0.f, 0.f, 0.f}, dn = 0.f;
+        for (int s2 = 0; s2 < AD_SPLIT; ++s2) M = fmaxf(M, ms[s2]);
+        float num[4] = {0.f, 0.f, 0.f, 0.f}, den = 0.f;
 #pragma unroll
         for (int s2 = 0; s2 < AD_SPLIT; ++s2) {
-            const float f = (s2 < act && ms[s2] != -INFINITY) ? __expf(ms[s2] - Mx) : 0.f;
-            nm[0] += f * __uint_as_float(ov[s2][0]); nm[1] += f * __uint_as_float(ov[s2][1]);
-            nm[2] += f * __uint_as_float(ov[s2][2]); nm[3] += f * __uint_as_float(ov[s2][3]);
-            dn += f * ls[s2];
+            const float f = (s2 < act && ms[s2] != -INFINITY) ? __expf(ms[s2] - M) : 0.f;
+            num[0] += f * __uint_as_float(ov[s2][0]); num[1] += f * __uint_as_float(ov[s2][1]);
+            num[2] += f * __uint_as_float(ov[s2][2]); num[3] += f * __uint_as_float(ov[s2][3]);
+            den += f * ls[s2];
         }
-        const float inv = 1.0f / dn;
+        const float inv = 1.0f / den;
         uint2 o;
-        o.x = pack2bf(nm[0] * inv, nm[1] * inv);
-        o.y = pack2bf(nm[2] * inv, nm[3] * inv);
+        o.x = pack2bf(num[0] * inv, num[1] * inv);
+        o.y = pack2bf(num[2] * inv, num[3] * inv);
         *reinterpret_cast<uint2*>(p.out_xp + xp_index(b >> 5, p.out_KS, b & 31, col0 + idx)) = o;
     }
+    if (tid == 0) __hip_atomic_store(p.counters + bx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
     stamp(t_part, t_tick, wall_clock64());
 }
 

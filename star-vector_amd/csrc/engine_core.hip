@@ -482,9 +482,8 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     A(dalloc(e, &e->ws2, (size_t)8 * R * e->ldws));
     A(dalloc(e, &e->logits, R * e->Vpad));
     A(dalloc(e, &e->sample_scratch, R * 4));
-    A(dalloc(e, &e->attn_part, R * nkv * attn_decode_part_floats(dh), false));
-    // every partial slot starts "not valid": the float pattern 0xFFFF'FFFF (attention.hip, in-band hand-off of the context splits)
-    if (!rc && hipMemset(e->attn_part, 0xFF, R * nkv * attn_decode_part_floats(dh) * sizeof(float)) != hipSuccess) rc = fail(SV_EHIP, "hipMemset(attn_part) failed");
+    A(dalloc(e, &e->attn_part, R * nkv * attn_decode_part_floats(dh)));
+    A(dalloc(e, &e->attn_cnt, R * nkv));
     e->seen_words = e->Vpad / 32;
     A(dalloc(e, &e->seen, R * (size_t)e->seen_words));
     A(dalloc(e, &e->am_val, R * 8));

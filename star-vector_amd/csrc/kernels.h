@@ -172,9 +172,8 @@ struct AttnDecodeArgs {
     const int32_t* positions;                              // [B] index of the new token (= tokens already cached)
     bf16_t* out_xp; int out_KS;                            // packed [MT][H*D/16][64][8]
     int B, H, head_dim; float scale;
-    float* part;                                           // [B][splits][32 + 16*D] partial (m, l, O); every slot holds the float pattern 0xFFFF'FFFF
-                                                           //   between launches (the engine fills it once, the merging block restores it)
-    int* err;                                              // set to 4 when the merging block gives up waiting for a partial (never a hang)
+    float* part;                                           // [B][splits][32 + 16*D] partial (m, l, O)
+    unsigned* counters;                                    // [B] arrival tickets, zero between launches
     int max_splits;                                        // cap on active context splits (#CUs / (B*n_kv), <= 16)
     int n_kv;                                              // key/value heads (1 = MQA); grid.x = B * n_kv
     size_t kv_head_stride;                                 // bytes between the page pools of consecutive KV heads

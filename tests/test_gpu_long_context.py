@@ -226,6 +226,24 @@ def test_decode_attention_8b_geometry_sliding_window_4096(S, steps):
     eng.close()
 
 
+@pytest.mark.parametrize("H,nkv,S,steps", [(36, 4, 248, 20), (36, 4, 1010, 6), (16, 1, 24, 16), (16, 1, 2040, 6)])
+def test_decode_attention_full_64_row_batch_has_more_blocks_than_the_chip_has_cus(H, nkv, S, steps):
+    """A 64-row engine launches 64 * n_kv * max_splits = 512 blocks of 8 waves at one block per CU: the blocks of a sequence's context
+    splits are NOT all resident at once, so the split merge must not wait for a block that has not been dispatched (round 4's in-band
+    hand-off did, and gave every row NaNs at the first context with two active splits: 8B geometry 257, profiles/diag_8b_fp8_r04.log).
+    Walks across that first multi-split context for both geometries, and a context at the split cap."""
+    B = 64
+    W = 4096 if nkv > 1 else 0
+    eng = _attn_engine(H, nkv, B, 4096, window=W)
+    q, K, V = _peaked_case(B, H, nkv, S + steps, 3.0, 6400 + S)
+    g = torch.Generator(device=dev()).manual_seed(6401 + S)
+    qs = [torch.randn(B, H, 128, generator=g, device=dev()) * 3.0 for _ in range(steps)]
+    rope = _rope_tables(4096, 128, 1e6) if nkv > 1 else None
+    worst = _walk(eng, qs, K, V, S, steps, W, rope, f"64 rows, {H}/{nkv} heads, walk {S + 1}..{S + steps}")
+    print(f"[decode attention, 64 rows, {H} heads on {nkv}] walk {S + 1}..{S + steps}: worst |err| / max|ref| = {worst:.3e}")
+    eng.close()
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # end to end
 # ------------------------------------------------------------------------------------------------------------------
