@@ -111,9 +111,12 @@ PROTOTYPES = {
     "sv_last_timing": (_I, [_P, C.POINTER(C.c_double)]),
     "sv_debug_set_exp": (_I, [_P, _I]),
     "sv_debug_set_col_tiles": (_I, [_I]),
+    "sv_debug_set_gemm_form": (_I, [_I]),
     "sv_debug_attn_plan": (_I, [_I, _I, _I, C.POINTER(_I)]),
     "sv_debug_attn_trace": (_I, [_P, C.POINTER(C.c_int64), _I]),
     "sv_debug_mlp_trace": (_I, [_P, C.POINTER(C.c_int64), _I]),
+    "sv_debug_xcc_map": (_I, [_P, _I, _I, C.POINTER(_I)]),
+    "sv_debug_gemm_trace": (_I, [_I, _I, _I, _I, _I, C.POINTER(C.c_int64), _I]),
     "sv_debug_kv_load": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "sv_debug_attn_decode": (_I, [_P, _I, _P, _I, _P, _I, _P]),
     "sv_debug_decode_plan": (_I, [_I, _I, _I, _I, _I, _I, C.POINTER(_I)]),

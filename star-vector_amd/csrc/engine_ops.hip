@@ -13,6 +13,22 @@ struct TmpBufs {
     }
 };
 
+// a stream-K workspace for the single-operator surfaces below (an engine has its own)
+static int local_sk(TmpBufs& tmp, SkWorkspace* sk) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    HIPCHECK(hipGetDevice(&dev));
+    HIPCHECK(hipGetDeviceProperties(&prop, dev));
+    char* ws; unsigned* flags; int* err;
+    SVCHECK(tmp.get(&ws, (size_t)prop.multiProcessorCount * 262144));
+    SVCHECK(tmp.get(&flags, (size_t)prop.multiProcessorCount));
+    SVCHECK(tmp.get(&err, 4));
+    HIPCHECK(hipMemset(flags, 0, (size_t)prop.multiProcessorCount * 4));
+    HIPCHECK(hipMemset(err, 0, 16));
+    sk->ws = ws; sk->flags = flags; sk->err = err; sk->blocks = prop.multiProcessorCount; sk->epoch = 0;
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI: host-side decisions, callable without a GPU (CPU tests)
 // ------------------------------------------------------------------------------------------------
@@ -116,6 +132,13 @@ extern "C" int sv_debug_attn_decode(sv_engine* e, int32_t layer, const float* de
     if (advance) add_i32(e->positions, 1, B, st);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(st));          // `zero_bias` is freed on return
+    int32_t bad = 0;
+    HIPCHECK(hipMemcpy(&bad, e->d_bad, sizeof(bad), hipMemcpyDeviceToHost));
+    if (bad == 5) {
+        HIPCHECK(hipMemset(e->d_bad, 0, sizeof(int32_t)));
+        return fail(SV_EHIP, "sv_debug_attn_decode: a context split ran on another XCD than the block that merged it (SV_EXP=1024 selects the "
+                             "placement-independent hand-off)");
+    }
     return 0;
 }
 
@@ -146,6 +169,27 @@ extern "C" int sv_debug_attn_trace(sv_engine* e, int64_t* host_out, int32_t capa
     HIPCHECK(hipDeviceSynchronize());
     HIPCHECK(hipMemcpy(host_out, e->attn_trace, (size_t)rows * 16 * sizeof(int64_t), hipMemcpyDeviceToHost));
     return rows;
+}
+
+// host_out[blocks]: the XCC_ID each block of a 1-D launch of 8-wave blocks ran on (heavy = 1: with the decode attention's LDS footprint and
+// 10 us of residence, so that a grid above the CU count is dispatched in rounds).  Returns 1 when the engine uses the XCD-local hand-off.
+extern "C" int sv_debug_xcc_map(sv_engine* e, int32_t blocks, int32_t heavy, int32_t* host_out) {
+    if (!e || !host_out || blocks < 1 || blocks > (1 << 16)) return fail(SV_EINVAL, "sv_debug_xcc_map: bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    int32_t* d = nullptr;
+    HIPCHECK(hipMalloc((void**)&d, (size_t)blocks * 4));
+    int rc = launch_xcc_probe(d, blocks, heavy, nullptr);
+    if (!rc && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host_out, d, (size_t)blocks * 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = -1;
+    (void)hipFree(d);
+    if (rc) return fail(SV_EHIP, "sv_debug_xcc_map: probe launch failed");
+    return e->attn_xcd_local ? 1 : 0;
+}
+
+extern "C" int sv_debug_set_gemm_form(int32_t form) {
+    if (form < -1 || form > 2) return fail(SV_EINVAL, "sv_debug_set_gemm_form: -1 (tuned) or 0..2");
+    set_gemm_form(form);
+    return 0;
 }
 
 extern "C" int sv_debug_set_col_tiles(int32_t col_tiles) {
@@ -324,6 +368,11 @@ extern "C" int sv_op_linear(const void* x, const void* W, const void* bias, cons
     GemmArgs g;
     g.A = A; g.lda = lda; g.Wp = Wp; g.bias = (const bf16_t*)bias; g.R = (const bf16_t*)residual; g.ldr = N;
     g.C = y; g.ldc = N; g.M = M; g.N = N; g.K = Kpad; g.act = act; g.out_f32 = out_f32;
+    SkWorkspace sk;
+    if ((long)((M + 255) / 256) * ((N + 255) / 256) >= 64) {          // big enough for the stream-K form to be a candidate
+        SVCHECK(local_sk(tmp, &sk));
+        g.sk = &sk;
+    }
     launch_gemm(g, st);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(st));
@@ -362,11 +411,18 @@ extern "C" int sv_bench_linear(int32_t M, int32_t N, int32_t K, int32_t act, int
     GemmArgs g;
     g.A = A; g.lda = K; g.Wp = Wp; g.bias = bias; g.R = residual ? C : nullptr; g.ldr = N; g.C = C; g.ldc = N;
     g.M = M; g.N = N; g.K = K; g.act = act; g.out_f32 = 0;
+    SkWorkspace sk;
+    SVCHECK(local_sk(tmp, &sk));
+    g.sk = &sk;
+    // SV_BENCH_GEMM_FORM = 0 / 1 / 2: one fixed form (128^2 tiles, 256^2 tiles, 256^2 persistent stream-K) instead of the tuned choice
+    const char* form_s = getenv("SV_BENCH_GEMM_FORM");
+    const int form = form_s ? atoi(form_s) : -1;
+    auto run1 = [&]() { if (form >= 0) launch_gemm_fixed(g, form, 0, st); else launch_gemm(g, st); };
     hipEvent_t e0, e1;
     HIPCHECK(hipEventCreate(&e0)); HIPCHECK(hipEventCreate(&e1));
-    for (int i = 0; i < 2; ++i) launch_gemm(g, st);
+    for (int i = 0; i < 2; ++i) run1();
     HIPCHECK(hipEventRecord(e0, st));
-    for (int i = 0; i < iters; ++i) launch_gemm(g, st);
+    for (int i = 0; i < iters; ++i) run1();
     HIPCHECK(hipEventRecord(e1, st));
     HIPCHECK(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -375,6 +431,46 @@ extern "C" int sv_bench_linear(int32_t M, int32_t N, int32_t K, int32_t act, int
     *avg_us = (double)ms * 1e3 / iters;
     HIPCHECK(hipGetLastError());
     return 0;
+}
+
+// The 256^2 big-M kernel on its own over random operands, one launch with wall-clock stamps (100 MHz): host_out [blocks * 2][8] =
+// {start, K-tile 0 staged, K loop done, epilogue stored and drained, tile m, tile n, wave (0 / 7: one wave of each ping-pong group), 0}.
+// form 2 = the persistent stream-K kernel: host_out [blocks][8] = {start, ticks spent waiting for an accumulator, segments, end, share in
+// K-tiles, head K-tiles, tail K-tiles, 0}.  Returns the number of blocks (tools/gemm_trace.py: where the time of a prefill GEMM goes).
+extern "C" int sv_debug_gemm_trace(int32_t M, int32_t N, int32_t K, int32_t act, int32_t form, int64_t* host_out, int32_t capacity_blocks) {
+    if (!host_out || M < 256 || N < 256 || N % 8 || K < 64 || K % 64 || form < 1 || form > 2) return fail(SV_EINVAL, "sv_debug_gemm_trace: bad argument");
+    const int blocks = ((M + 255) / 256) * ((N + 255) / 256);
+    if (capacity_blocks < blocks) return fail(SV_EINVAL, "sv_debug_gemm_trace: capacity %d < %d blocks", capacity_blocks, blocks);
+    hipStream_t st = nullptr;
+    TmpBufs tmp;
+    const int Npad = round_up(N, 32);
+    bf16_t *Wp, *A, *C, *bias, *Wsrc;
+    long long* tr;
+    SVCHECK(tmp.get(&Wp, (size_t)Npad * K));
+    SVCHECK(tmp.get(&Wsrc, (size_t)N * K));
+    SVCHECK(tmp.get(&A, (size_t)M * K));
+    SVCHECK(tmp.get(&C, (size_t)M * N));
+    SVCHECK(tmp.get(&bias, (size_t)N));
+    SVCHECK(tmp.get(&tr, (size_t)blocks * 16));
+    fill_random_bf16(A, (size_t)M * K, 1u, 4096, st);
+    fill_random_bf16(Wsrc, (size_t)N * K, 2u, 4096, st);
+    fill_random_bf16(bias, (size_t)N, 3u, 64, st);
+    launch_pack_weight(Wsrc, 0, Wp, N, K, Npad, K, st);
+    HIPCHECK(hipMemsetAsync(tr, 0, (size_t)blocks * 16 * sizeof(long long), st));
+    GemmArgs g;
+    g.A = A; g.lda = K; g.Wp = Wp; g.bias = bias; g.R = nullptr; g.ldr = N; g.C = C; g.ldc = N;
+    g.M = M; g.N = N; g.K = K; g.act = act; g.out_f32 = 0;
+    SkWorkspace sk;
+    SVCHECK(local_sk(tmp, &sk));
+    g.sk = &sk;
+    if (form == 2 && !gemm_sk_eligible(g)) return fail(SV_EINVAL, "sv_debug_gemm_trace: the stream-K form does not take this shape");
+    for (int i = 0; i < 20; ++i) launch_gemm_fixed(g, form, 0, st);          // clocks and caches as in a running prefill
+    g.trace = tr;
+    launch_gemm_fixed(g, form, 0, st);
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(st));
+    HIPCHECK(hipMemcpy(host_out, tr, (size_t)blocks * 16 * sizeof(long long), hipMemcpyDeviceToHost));
+    return form == 2 ? sk.blocks : blocks;
 }
 
 extern "C" int sv_op_linear_skinny(const void* x, const void* W, const void* bias, void* y_f32, int32_t M, int32_t N,

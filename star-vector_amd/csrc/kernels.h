@@ -22,6 +22,9 @@ void launch_pack_weight_fp8(const void* src, int src_is_f32, bf16_t* dst_bf16, u
                             int Npad, int Kpad, hipStream_t st);
 
 // ---- big-M MFMA GEMM:  C[M][N] = epi( A[M][K] . W^T + bias ) (+ residual) ----------------------
+// workspace of the persistent stream-K form of the 256^2 kernel (gemm.hip gemm256sk_kernel): one per engine / caller, used by one stream
+// at a time.  ws: blocks x 256 KiB (an fp32 accumulator per block), flags: blocks words, err: set to 6 when a block gave up waiting
+struct SkWorkspace { void* ws = nullptr; unsigned* flags = nullptr; int* err = nullptr; int blocks = 0; unsigned epoch = 0; };
 struct GemmArgs {
     const bf16_t* A; int lda;        // activations, row-major bf16, K-contiguous
     const bf16_t* Wp;                // packed weight
@@ -31,8 +34,14 @@ struct GemmArgs {
     int M, N, K;                     // K = padded K (multiple of 64) shared by A and Wp
     int act; int out_f32;
     const float* cscale = nullptr;   // fp8 weights: per-output-column scale applied to the accumulator (or nullptr)
+    SkWorkspace* sk = nullptr;       // HOST pointer (never read on the device): the stream-K form is a candidate only with a workspace
+    long long* trace = nullptr;      // optional [blocks][8] wall-clock stamps of the 256^2 kernel (tools/gemm_trace.py); nullptr in production
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
+// one fixed configuration (kernel256: 0 = 128^2 tiles, 1 = 256^2; peel: the row remainder over a multiple of 256 in its own launch), no tuning
+void launch_gemm_fixed(const GemmArgs& a, int kernel256, int peel, hipStream_t st);     // kernel256 = 2: the persistent stream-K form
+bool gemm_sk_eligible(const GemmArgs& a);
+void set_gemm_form(int form);         // -1: tuned (default); 0 / 1 / 2: every big-M launch takes that form (2 where eligible, else 1)
 // what launch_gemm decides for a shape (host arithmetic only; tail_on: 0 never peel, 1 cost model, 2 always)
 struct GemmPlan { int peel, tail_rows, tail_by_tiles, main_256; double est_us; };
 GemmPlan gemm_plan(int M, int N, int K, int act, int tail_on);
@@ -173,7 +182,9 @@ struct AttnDecodeArgs {
     bf16_t* out_xp; int out_KS;                            // packed [MT][H*D/16][64][8]
     int B, H, head_dim; float scale;
     float* part;                                           // [B][splits][32 + 16*D] partial (m, l, O)
-    unsigned* counters;                                    // [B] arrival tickets, zero between launches
+    unsigned long long* counters;                          // [B * n_kv] arrival tickets (count | arrivals per XCD), zero between launches
+    int* err;                                              // set to 5 when a context split of the XCD-local form ran on another XCD
+    int xcd_local;                                         // 1: all splits of a sequence on one XCD, hand-off through its L2 (attention.hip)
     int max_splits;                                        // cap on active context splits (#CUs / (B*n_kv), <= 16)
     int n_kv;                                              // key/value heads (1 = MQA); grid.x = B * n_kv
     size_t kv_head_stride;                                 // bytes between the page pools of consecutive KV heads
@@ -189,6 +200,8 @@ struct AttnDecodeArgs {
 void launch_rope_prefill(bf16_t* qkv, int row_stride, int rows, int S0, int n_heads, int head_dim,
                          const float* cos_t, const float* sin_t, hipStream_t st);
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t st);
+// XCC_ID of every block of a 1-D launch of `blocks` 8-wave blocks (heavy = 1: with the decode attention's LDS footprint and 10 us of residence)
+int launch_xcc_probe(int32_t* out, int blocks, int heavy, hipStream_t st);
 size_t attn_decode_part_floats(int head_dim);            // floats of `part` per sequence
 int init_attention_kernels();   // returns a hipError_t value (0 = ok)
 

@@ -351,6 +351,15 @@ class HipEngine:
             check(n, "sv_debug_attn_trace")
         return torch.tensor(list(buf[: n * 16]), dtype=torch.int64).view(n, 16)
 
+    def debug_xcc_map(self, blocks: int, heavy: bool = False):
+        """(xcd_local, [blocks] list of XCC_IDs): where the blocks of a 1-D launch ran, and whether this engine's decode attention hands its
+        context splits over inside one XCD's L2 (include/starvector_hip.h, sv_debug_xcc_map)."""
+        buf = (C.c_int32 * blocks)()
+        n = self.lib.sv_debug_xcc_map(self._h, blocks, 1 if heavy else 0, buf)
+        if n < 0:
+            check(n, "sv_debug_xcc_map")
+        return bool(n), list(buf)
+
     def debug_mlp_trace(self) -> torch.Tensor:
         """[blocks, 8] int64 wall-clock stamps (100 MHz) of the last fused MLP launch of the middle layer (engine created with
         SV_MLP_TRACE=1 in the environment; include/starvector_hip.h, sv_debug_mlp_trace)."""
@@ -501,6 +510,12 @@ def op_linear(x, W, bias=None, residual=None, act="none", out_f32=False):
     r = _need(residual, torch.bfloat16, "residual") if residual is not None else None
     check(lib.sv_op_linear(_ptr(x), _ptr(W), _ptr(b), _ptr(r), _ptr(y), M, N, K, _lib.ACT[act], int(out_f32), _stream()))
     return y
+
+
+def set_gemm_form(form: int) -> None:
+    """-1: the tuned choice (default); 0 / 1 / 2: every big-M GEMM launch of the process takes 128^2 tiles / 256^2 tiles / the persistent
+    256^2 kernel with a stream-K remainder (sv_debug_set_gemm_form).  Same bits either way; test and A/B surface."""
+    check(_lib.load().sv_debug_set_gemm_form(int(form)))
 
 
 def set_op_col_tiles(col_tiles: int) -> None:

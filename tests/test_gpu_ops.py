@@ -83,6 +83,45 @@ def test_linear_big_m_kernels_agree_bitwise(M, N, K, act, res):
     assert rel_err(y, ref) <= 2.2 * BF16_1ULP and mean_err(y, ref) <= 6e-4
 
 
+@pytest.mark.parametrize("M,N,K,act,res", [(8288, 2304, 2048, "none", False),          # prefill c_attn: 297 tiles, one-and-a-bit rounds
+                                           (8288, 2048, 2048, "none", True),            # c_proj + residual: 264 tiles
+                                           (8288, 8192, 2048, "gelu_tanh", False),      # c_fc: 1056 tiles = 3 whole rounds + 288 slots
+                                           (8224, 3072, 1024, "quickgelu", False),      # ViT: 396 tiles, K = 16 K-tiles
+                                           (8192 + 256 * 3, 2048, 8192, "none", True),  # long K: shares of 130 K-tiles
+                                           (16384 + 40, 1024 + 8, 512, "none", False)]) # ragged N and M, 325 tiles, short K
+def test_linear_stream_k_form_has_the_bits_of_the_tile_kernels(M, N, K, act, res):
+    """The persistent 256^2 kernel hands the ACCUMULATOR of a split tile from the block that owns its first K-tiles to the block that owns
+    the rest, which continues the K loop: ascending-K order as in the one-block-per-tile kernels, so the three forms must agree bit for bit
+    (gemm.hip gemm256sk_kernel; forms through sv_debug_set_gemm_form).  Run twice: the second launch reuses the workspace (epoch flags)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    b = (0.1 * torch.randn(N, generator=g)).bfloat16()
+    r = torch.randn(M, N, generator=g).bfloat16() if res else None
+    outs = {}
+    try:
+        for form in (1, 2, 2, 0):
+            E.set_gemm_form(form)
+            y = E.op_linear(bf(x), bf(W), bf(b), bf(r) if res else None, act=act).cpu()
+            if form in outs:
+                assert torch.equal(y.view(torch.int16), outs[form].view(torch.int16)), "the stream-K form is not repeatable"
+            outs[form] = y
+    finally:
+        E.set_gemm_form(-1)
+    same12 = torch.equal(outs[1].view(torch.int16), outs[2].view(torch.int16))
+    same10 = torch.equal(outs[1].view(torch.int16), outs[0].view(torch.int16))
+    bad = (outs[1].view(torch.int16) != outs[2].view(torch.int16)).nonzero()
+    assert same12, f"stream-K differs from the 256^2 tile kernel at {bad.shape[0]} outputs, first {bad[:4].tolist()}"
+    assert same10
+    ref = x.float() @ W.float().T + b.float()
+    if act != "none":
+        ref = {"gelu_tanh": lambda t: torch.nn.functional.gelu(t, approximate="tanh"),
+               "quickgelu": lambda t: t * torch.sigmoid(1.702 * t)}[act](ref.bfloat16().float())
+    if res:
+        ref = ref.bfloat16().float() + r.float()
+    assert rel_err(outs[2], ref) <= 2.2 * BF16_1ULP
+
+
 def test_linear_transpose_detecting():
     """A = identity with an ASYMMETRIC weight: catches swapped row/column in the MFMA C layout."""
     K = N = 128
