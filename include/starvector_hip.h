@@ -240,9 +240,8 @@ int  sv_debug_attn_plan(int32_t max_batch, int32_t n_kv_head, int32_t num_cus, i
  *                             every variant of the two-row-tile kernel next to the one-tile kernels (all bit-identical).  An engine's
  *                             decode loop is not affected (it carries its own plan per Linear). */
 int  sv_debug_set_col_tiles(int32_t col_tiles);
-/*   sv_debug_set_gemm_form    process-wide: every big-M GEMM launch takes ONE form -- 0 = 128x128 tiles, 1 = 256x256 tiles, 2 = the persistent
-     256x256 kernel with a stream-K remainder where it is eligible (else 1); -1 = the tuned choice (default).  The forms give the same bits;
-     the tests compare them through this switch. */
+/*   sv_debug_set_gemm_form    process-wide: every big-M GEMM launch takes ONE form -- 0 = 128x128 tiles, 1 = 256x256 tiles (rows not peeled);
+     -1 = the tuned choice (default).  The forms give the same bits; the tests compare them through this switch. */
 int  sv_debug_set_gemm_form(int32_t form);
 /* The decode attention (gpt_bigcode/modeling_gpt_bigcode.py:151-285, llm/starcoder2.py:22-27 sliding window) on
  * its own, over the engine's real paged KV pool, block table and context-split plan.  Test surface: the caller chooses q / K / V.
@@ -264,9 +263,8 @@ int  sv_debug_mlp_trace(sv_engine* e, int64_t* host_out, int32_t capacity_blocks
      sv_create found block L on XCD L % 8), 0 when it uses the placement-independent hand-off. */
 int  sv_debug_xcc_map(sv_engine* e, int32_t blocks, int32_t heavy, int32_t* host_out);
 /*   sv_debug_gemm_trace  the 256x256 big-M GEMM kernel (prefill / ViT) on random operands of the given shape, one launch with wall-clock
-     stamps: form 1 (one block per tile) host_out [blocks * 2][8] = {start, K-tile 0 staged, K loop done, epilogue stored, tile m, tile n,
-     wave, 0}; form 2 (persistent, stream-K remainder) host_out [CUs][8] = {start, ticks waited for an accumulator, segments, end, share,
-     head, tail, 0} (tools/gemm_trace.py).  Needs no engine.  Returns the number of rows' blocks. */
+     stamps (form = 1): host_out [blocks * 2][8] = {start, K-tile 0 staged, K loop done, epilogue stored, tile m, tile n, wave, 0}
+     (tools/gemm_trace.py).  Needs no engine.  Returns the number of blocks. */
 int  sv_debug_gemm_trace(int32_t M, int32_t N, int32_t K, int32_t act, int32_t form, int64_t* host_out, int32_t capacity_blocks);
 int  sv_debug_kv_load(sv_engine* e, int32_t layer, const void* dev_kv, int32_t B, int32_t S, const int32_t* dev_lens,
                       sv_stream stream);

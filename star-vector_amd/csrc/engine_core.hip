@@ -484,12 +484,6 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     A(dalloc(e, &e->sample_scratch, R * 4));
     A(dalloc(e, &e->attn_part, R * nkv * attn_decode_part_floats(dh)));
     A(dalloc(e, &e->attn_cnt, R * nkv));
-    {   // stream-K workspace of the prefill / ViT GEMMs: 256 KiB per CU (an fp32 accumulator of a 256 x 256 tile) + a flag word per CU
-        char* skw = nullptr;
-        A(dalloc(e, &skw, (size_t)e->num_cus * 262144, false));
-        A(dalloc(e, &e->sk.flags, (size_t)e->num_cus));
-        e->sk.ws = skw; e->sk.blocks = e->num_cus;
-    }
     e->seen_words = e->Vpad / 32;
     A(dalloc(e, &e->seen, R * (size_t)e->seen_words));
     A(dalloc(e, &e->am_val, R * 8));
@@ -504,7 +498,6 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     A(dalloc(e, &e->d_done, 4));
     A(dalloc(e, &e->d_nemit, 4));
     A(dalloc(e, &e->d_bad, 4));       // raised by the selection kernels when a row has no finite logit
-    e->sk.err = e->d_bad;
     A(dalloc(e, &e->d_stop, 64));
 
     e->page_bytes = kv_page_bytes(dh);

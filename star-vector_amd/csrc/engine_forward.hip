@@ -20,17 +20,9 @@ void prof_mark(sv_engine* e, int kind, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
-// the stream-K workspace of the engine whose forward pass runs on this thread (set by the three passes below, under the engine's mutex)
-static thread_local SkWorkspace* t_sk = nullptr;
-struct SkScope {
-    explicit SkScope(sv_engine* e) { t_sk = &e->sk; }
-    ~SkScope() { t_sk = nullptr; }
-};
-
 static void gemm(const bf16_t* A, int lda, const Linear& l, const bf16_t* R, int ldr, void* C, int ldc, int M,
                  int act, int out_f32, hipStream_t st) {
     GemmArgs g;
-    g.sk = t_sk;
     g.A = A; g.lda = lda; g.Wp = l.Wp; g.bias = l.bias; g.R = R; g.ldr = ldr; g.C = C; g.ldc = ldc;
     g.M = M; g.N = l.N; g.K = l.Kpad; g.act = act; g.out_f32 = out_f32;
     g.cscale = l.fp8 ? l.wscale : nullptr;
@@ -59,7 +51,6 @@ static int attn_groups_per_block(const sv_engine* e) {
 }
 
 static int vision_forward(sv_engine* e, const bf16_t* img, int B, bf16_t* out, hipStream_t st) {
-    const SkScope sks(e);
     const sv_config& c = e->cfg;
     const int Dv = c.vit_width, T = e->T, NP = e->NP, M = B * T, Fv = e->vit_F;
     const float eps = e->v2 ? c.vit_eps : c.ln_eps;
@@ -92,7 +83,6 @@ static int vision_forward(sv_engine* e, const bf16_t* img, int B, bf16_t* out, h
 
 // out_batch_stride (elements; 0 = T * D): image b's T visual rows go to out + b * stride, e.g. the head of its [S0][D] prompt block
 static int adapter_forward(sv_engine* e, const bf16_t* in, int B, bf16_t* out, hipStream_t st, size_t out_batch_stride = 0) {
-    const SkScope sks(e);
     const sv_config& c = e->cfg;
     const int Dv = c.vit_width, D = c.hidden, T = e->T, M = B * T;
     gemm(in, Dv, e->ad_fc, nullptr, 0, e->a1, 2 * Dv, M, ACT_SWISH, 0, st);
@@ -150,7 +140,6 @@ static void lm_head_logits(sv_engine* e, int MT, const bf16_t* xp, hipStream_t s
 int sveng::prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hipStream_t st, int n_keep,
                            bf16_t* dev_scores, const int32_t* table) {
     if (!table) table = e->block_table;           // continuous batching prefills NEW requests through a table of their slots' pages
-    const SkScope sks(e);
     const sv_config& c = e->cfg;
     const int D = c.hidden, dh = e->dh, F = c.n_inner, M = B * S0, QKV = e->QKV, nkv = e->nkv;
     const int QD = c.n_head * dh;                      // width of the query block (= D for both model families)

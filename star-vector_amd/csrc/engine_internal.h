@@ -126,7 +126,6 @@ struct sv_engine {
                                     //    group per attention block -- all measured slower, profiles/prefetch_r03_*.log, removed)
     float *ws = nullptr, *ws2 = nullptr, *logits = nullptr, *sample_scratch = nullptr, *attn_part = nullptr;
     unsigned long long* attn_cnt = nullptr;
-    SkWorkspace sk;                 // the big-M GEMMs' stream-K workspace (gemm.hip gemm256sk_kernel): one accumulator per CU
     bool attn_xcd_local = false;    // the decode attention's context splits meet in one XCD's L2 (attention.hip); set by the probe in sv_create
     float* am_val = nullptr; int32_t* am_idx = nullptr;
     uint32_t* seen = nullptr; int seen_words = 0;      // repetition-penalty bitmap [rows][Vpad/32]

@@ -13,22 +13,6 @@ struct TmpBufs {
     }
 };
 
-// a stream-K workspace for the single-operator surfaces below (an engine has its own)
-static int local_sk(TmpBufs& tmp, SkWorkspace* sk) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    HIPCHECK(hipGetDevice(&dev));
-    HIPCHECK(hipGetDeviceProperties(&prop, dev));
-    char* ws; unsigned* flags; int* err;
-    SVCHECK(tmp.get(&ws, (size_t)prop.multiProcessorCount * 262144));
-    SVCHECK(tmp.get(&flags, (size_t)prop.multiProcessorCount));
-    SVCHECK(tmp.get(&err, 4));
-    HIPCHECK(hipMemset(flags, 0, (size_t)prop.multiProcessorCount * 4));
-    HIPCHECK(hipMemset(err, 0, 16));
-    sk->ws = ws; sk->flags = flags; sk->err = err; sk->blocks = prop.multiProcessorCount; sk->epoch = 0;
-    return 0;
-}
-
 // ------------------------------------------------------------------------------------------------
 // C ABI: host-side decisions, callable without a GPU (CPU tests)
 // ------------------------------------------------------------------------------------------------
@@ -187,7 +171,7 @@ extern "C" int sv_debug_xcc_map(sv_engine* e, int32_t blocks, int32_t heavy, int
 }
 
 extern "C" int sv_debug_set_gemm_form(int32_t form) {
-    if (form < -1 || form > 2) return fail(SV_EINVAL, "sv_debug_set_gemm_form: -1 (tuned) or 0..2");
+    if (form < -1 || form > 1) return fail(SV_EINVAL, "sv_debug_set_gemm_form: -1 (tuned), 0 or 1");
     set_gemm_form(form);
     return 0;
 }
@@ -368,11 +352,6 @@ extern "C" int sv_op_linear(const void* x, const void* W, const void* bias, cons
     GemmArgs g;
     g.A = A; g.lda = lda; g.Wp = Wp; g.bias = (const bf16_t*)bias; g.R = (const bf16_t*)residual; g.ldr = N;
     g.C = y; g.ldc = N; g.M = M; g.N = N; g.K = Kpad; g.act = act; g.out_f32 = out_f32;
-    SkWorkspace sk;
-    if ((long)((M + 255) / 256) * ((N + 255) / 256) >= 64) {          // big enough for the stream-K form to be a candidate
-        SVCHECK(local_sk(tmp, &sk));
-        g.sk = &sk;
-    }
     launch_gemm(g, st);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(st));
@@ -411,10 +390,7 @@ extern "C" int sv_bench_linear(int32_t M, int32_t N, int32_t K, int32_t act, int
     GemmArgs g;
     g.A = A; g.lda = K; g.Wp = Wp; g.bias = bias; g.R = residual ? C : nullptr; g.ldr = N; g.C = C; g.ldc = N;
     g.M = M; g.N = N; g.K = K; g.act = act; g.out_f32 = 0;
-    SkWorkspace sk;
-    SVCHECK(local_sk(tmp, &sk));
-    g.sk = &sk;
-    // SV_BENCH_GEMM_FORM = 0 / 1 / 2: one fixed form (128^2 tiles, 256^2 tiles, 256^2 persistent stream-K) instead of the tuned choice
+    // SV_BENCH_GEMM_FORM = 0 / 1: one fixed form (128^2 tiles, 256^2 tiles; rows not peeled) instead of the tuned choice
     const char* form_s = getenv("SV_BENCH_GEMM_FORM");
     const int form = form_s ? atoi(form_s) : -1;
     auto run1 = [&]() { if (form >= 0) launch_gemm_fixed(g, form, 0, st); else launch_gemm(g, st); };
@@ -435,10 +411,10 @@ extern "C" int sv_bench_linear(int32_t M, int32_t N, int32_t K, int32_t act, int
 
 // The 256^2 big-M kernel on its own over random operands, one launch with wall-clock stamps (100 MHz): host_out [blocks * 2][8] =
 // {start, K-tile 0 staged, K loop done, epilogue stored and drained, tile m, tile n, wave (0 / 7: one wave of each ping-pong group), 0}.
-// form 2 = the persistent stream-K kernel: host_out [blocks][8] = {start, ticks spent waiting for an accumulator, segments, end, share in
-// K-tiles, head K-tiles, tail K-tiles, 0}.  Returns the number of blocks (tools/gemm_trace.py: where the time of a prefill GEMM goes).
+// form: 1 (round 4's persistent stream-K kernel was form 2: profiles/gemm_trace_r04.log).  Returns the number of blocks (tools/gemm_trace.py:
+// where the time of a prefill GEMM goes).
 extern "C" int sv_debug_gemm_trace(int32_t M, int32_t N, int32_t K, int32_t act, int32_t form, int64_t* host_out, int32_t capacity_blocks) {
-    if (!host_out || M < 256 || N < 256 || N % 8 || K < 64 || K % 64 || form < 1 || form > 2) return fail(SV_EINVAL, "sv_debug_gemm_trace: bad argument");
+    if (!host_out || M < 256 || N < 256 || N % 8 || K < 64 || K % 64 || form != 1) return fail(SV_EINVAL, "sv_debug_gemm_trace: bad argument (form: 1)");
     const int blocks = ((M + 255) / 256) * ((N + 255) / 256);
     if (capacity_blocks < blocks) return fail(SV_EINVAL, "sv_debug_gemm_trace: capacity %d < %d blocks", capacity_blocks, blocks);
     hipStream_t st = nullptr;
@@ -460,17 +436,13 @@ extern "C" int sv_debug_gemm_trace(int32_t M, int32_t N, int32_t K, int32_t act,
     GemmArgs g;
     g.A = A; g.lda = K; g.Wp = Wp; g.bias = bias; g.R = nullptr; g.ldr = N; g.C = C; g.ldc = N;
     g.M = M; g.N = N; g.K = K; g.act = act; g.out_f32 = 0;
-    SkWorkspace sk;
-    SVCHECK(local_sk(tmp, &sk));
-    g.sk = &sk;
-    if (form == 2 && !gemm_sk_eligible(g)) return fail(SV_EINVAL, "sv_debug_gemm_trace: the stream-K form does not take this shape");
     for (int i = 0; i < 20; ++i) launch_gemm_fixed(g, form, 0, st);          // clocks and caches as in a running prefill
     g.trace = tr;
     launch_gemm_fixed(g, form, 0, st);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(st));
     HIPCHECK(hipMemcpy(host_out, tr, (size_t)blocks * 16 * sizeof(long long), hipMemcpyDeviceToHost));
-    return form == 2 ? sk.blocks : blocks;
+    return blocks;
 }
 
 extern "C" int sv_op_linear_skinny(const void* x, const void* W, const void* bias, void* y_f32, int32_t M, int32_t N,

@@ -709,295 +709,10 @@ static void launch_gemm256(const GemmArgs& a, hipStream_t st) {
     else gemm256_kernel<bf16_t><<<tiles_m * tiles_n, 512, 2 * G2_BUF, st>>>(a, tiles_m, tiles_n);
 }
 
-// ------------------------------------------------------------------------------------------------
-// big-M GEMM, the same 256x256x64 ping-pong tile as a PERSISTENT kernel with a stream-K remainder
-//
-//   tools/gemm_trace.py (profiles/gemm_trace_r04.log): a tile of gemm256_kernel costs 1.4 us of prologue + 32 x 1.64 us of K loop +
-//   4.6 us of epilogue (7.6 with GELU) at K = 2048, but the prefill shapes do not fill whole rounds of 256 CUs -- c_fc is 1056 tiles
-//   = 4.125 rounds, c_attn 1.16, c_proj 1.03 -- and the last, nearly empty round costs a whole K loop: 57-78 % of the CUs are alive on
-//   average over a launch.  Here one block per CU walks a list of SEGMENTS (tile, K-tile range):
-//     * the first (rounds - 1) x 256 tiles data-parallel, whole;
-//     * the remaining 256 + r tiles ("slots") cut into 256 equal shares of K-TILES: block c owns the units [u0, u1) of the slot
-//       sequence = the tail of one slot, maybe whole slots, the head of another.
-//   ASCENDING-K ORDER IS KEPT, so the result has the bits of the other big-M kernels: the block that owns the head [0, k1) of a slot
-//   computes it from a zero accumulator and leaves the ACCUMULATOR (fp32, register layout, 256 KiB) in a workspace; the block that
-//   owns the tail [k1, KT) loads it and CONTINUES the K loop.  Every block does its head FIRST and its tail LAST; a share is at least
-//   one whole K loop long, so the accumulator a tail needs was stored a K loop earlier by a block that waited for nothing: there is no
-//   idle wait, and no deadlock whatever the residency (a block only ever waits for the first segment of the block dispatched before it).
-//   Hand-off across XCDs: write-through (sc1) stores, drained, then a flag = the launch's epoch (no reset between launches).
-// ------------------------------------------------------------------------------------------------
-struct SkSched { int tiles_m, tiles_n, t_dp, share, extra; unsigned epoch; void* ws; unsigned* flags; int* err; };
-
-__global__ __launch_bounds__(512) void gemm256sk_kernel(GemmArgs p, SkSched sc) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const long long t_start = p.trace ? wall_clock64() : 0;
-    long long t_wait = 0, t_load = 0, t_k = 0, t_dump = 0, t_epi = 0;
-    const int c = blockIdx.x, P = gridDim.x;
-    const int KS = p.K >> 4;
-    const int KT = p.K >> 6;
-    const int NT_total = (p.N + 31) >> 5;
-    const int T = sc.tiles_m * sc.tiles_n;
-
-    // this block's share of the stream-K slots [t_dp, T), in K-tile units
-    const long u0 = (long)c * sc.share + (c < sc.extra ? c : sc.extra), u1 = u0 + sc.share + (c < sc.extra ? 1 : 0);
-    const int sa = (int)(u0 / KT), k0 = (int)(u0 % KT), sb = (int)(u1 / KT), k1 = (int)(u1 % KT);
-    const int n_dp = sc.t_dp > c ? (sc.t_dp - c + P - 1) / P : 0;
-    const int w_first = k0 > 0 ? sa + 1 : sa;
-    const int n_whole = sb > w_first ? sb - w_first : 0;
-    const int has_head = k1 > 0 ? 1 : 0, has_tail = k0 > 0 ? 1 : 0;
-    const int nseg = has_head + n_dp + n_whole + has_tail;
-
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(sc.ws, 0, (unsigned)((size_t)P * 8 * 32768), 0x00020000);
-    const int half = lane >> 5;
-
-    for (int s = 0; s < nseg; ++s) {
-        int vid, kb, ke, mode;                  // mode 0: whole tile; 1: head, the accumulator goes to the workspace; 2: tail, it comes from there
-        if (s < has_head) { vid = sc.t_dp + sb; kb = 0; ke = k1; mode = 1; }
-        else if (s < has_head + n_dp) { vid = c + (s - has_head) * P; kb = 0; ke = KT; mode = 0; }
-        else if (s < has_head + n_dp + n_whole) { vid = sc.t_dp + w_first + (s - has_head - n_dp); kb = 0; ke = KT; mode = 0; }
-        else { vid = sc.t_dp + sa; kb = k0; ke = KT; mode = 2; }
-        // XCD-aware tile order of gemm256_kernel over the virtual block id
-        const int q = T >> 3, rem = T & 7, xcd = vid & 7, loc = vid >> 3;
-        const int wg = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + loc;
-        const int band = wg / (4 * sc.tiles_n), r_in = wg - band * 4 * sc.tiles_n;
-        const int band_rows = min(4, sc.tiles_m - band * 4);
-        const int tm = band * 4 + r_in % band_rows, tn = r_in / band_rows;
-        const int m0 = tm * G2_T, n0 = tn * G2_T;
-
-        G2_BARRIER();                            // every wave is done with the LDS strips of the segment before
-
-        f32x16 acc[2][4];                        // [n-tile j][m-tile 2*i + mt2]
-        const long long ts0 = p.trace ? wall_clock64() : 0;
-        if (mode == 2) {
-            if (tid == 0) {
-                const long long w0 = wall_clock64();
-                int spins = 0;
-                while (__hip_atomic_load(sc.flags + (c - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sc.epoch) {
-                    __builtin_amdgcn_s_sleep(16);
-                    if (++spins > (1 << 22)) { *sc.err = 6; break; }        // seconds: the producer is gone
-                }
-                t_wait += wall_clock64() - w0;
-            }
-            G2_BARRIER();
-            const int base = ((c - 1) * 8 + wave) * 32768 + lane * 16;
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, base + ((a * 4 + b) * 4 + g) * 1024, 0, 16);
-                        acc[a][b][4 * g + 0] = __uint_as_float(v[0]); acc[a][b][4 * g + 1] = __uint_as_float(v[1]);
-                        acc[a][b][4 * g + 2] = __uint_as_float(v[2]); acc[a][b][4 * g + 3] = __uint_as_float(v[3]);
-                    }
-        } else {
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-        }
-
-        const bf16_t* xsrc[2][2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc) {
-                const int g = wave * 2 + pc;
-                const int r = g * 8 + (lane >> 3);
-                int grow = m0 + (r >> 6) * 128 + i * 64 + (r & 63);
-                grow = grow < p.M ? grow : p.M - 1;
-                const int ch = (lane & 7) ^ ((r >> 1) & 7);
-                xsrc[i][pc] = p.A + (size_t)grow * p.lda + ch * 8;
-            }
-        const bf16_t* wsrc[2][2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int pc = 0; pc < 2; ++pc) {
-                const int f = wave * 2 + pc;
-                int nt = (n0 >> 5) + (f >> 2) * 2 + j;
-                nt = nt < NT_total ? nt : NT_total - 1;
-                wsrc[j][pc] = p.Wp + (((size_t)nt * KS + (f & 3)) * 64 + lane) * 8;
-            }
-        auto stage = [&](int h, int kt, char* buf) {          // h: 0 X0, 1 W0, 2 W1, 3 X1
-            if (h == 0 || h == 3) {
-                const int i = h == 0 ? 0 : 1;
-                char* dst = buf + i * G2_HALF + wave * 2048;
-                lds_dma16(xsrc[i][0] + kt * 64, dst);
-                lds_dma16(xsrc[i][1] + kt * 64, dst + 1024);
-            } else {
-                const int j = h - 1;
-                char* dst = buf + 2 * G2_HALF + j * G2_HALF + wave * 2048;
-                lds_dma16(wsrc[j][0] + (size_t)kt * 4 * 512, dst);
-                lds_dma16(wsrc[j][1] + (size_t)kt * 4 * 512, dst + 1024);
-            }
-        };
-        int xoff[2][4];
-#pragma unroll
-        for (int mt2 = 0; mt2 < 2; ++mt2)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int r = wr * 64 + mt2 * 32 + (lane & 31);
-                xoff[mt2][ks] = r * 128 + (((2 * ks + (lane >> 5)) ^ ((r >> 1) & 7)) << 4);
-            }
-        const int woff = wc * 4096 + lane * 16;
-
-        bf16x8 x0[2][4], x1[2][4], w0[4], w1[4];
-        auto read_x = [&](bf16x8 (&x)[2][4], const char* hf) {
-#pragma unroll
-            for (int mt2 = 0; mt2 < 2; ++mt2)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) x[mt2][ks] = *reinterpret_cast<const bf16x8*>(hf + xoff[mt2][ks]);
-        };
-        auto read_w = [&](bf16x8 (&w)[4], const char* hf) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) w[ks] = *reinterpret_cast<const bf16x8*>(hf + woff + ks * 1024);
-        };
-        auto quad = [&](bf16x8 (&w)[4], bf16x8 (&x)[2][4], int j, int i) {
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int mt2 = 0; mt2 < 2; ++mt2)
-                    acc[j][2 * i + mt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], x[mt2][ks], acc[j][2 * i + mt2], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-        };
-
-        // the K loop of gemm256_kernel over the K-tiles [kb, ke) (see its hazard table)
-        const long long ts1 = p.trace ? wall_clock64() : 0;
-        stage(0, kb, smem); stage(1, kb, smem); stage(2, kb, smem); stage(3, kb, smem);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        G2_BARRIER();
-        if (wr == 1) G2_BARRIER();
-        read_x(x0, smem);
-#define G2_WAIT(n) do { if (more) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
-        for (int t = kb; t < ke; ++t) {
-            char* buf = smem + ((t - kb) & 1) * G2_BUF;
-            char* nbuf = smem + ((t - kb + 1) & 1) * G2_BUF;
-            const bool more = t + 1 < ke;
-            read_w(w0, buf + 2 * G2_HALF);
-            if (more) stage(0, t + 1, nbuf);
-            G2_BARRIER(); quad(w0, x0, 0, 0); G2_WAIT(2); G2_BARRIER();
-            read_w(w1, buf + 3 * G2_HALF);
-            if (more) stage(1, t + 1, nbuf);
-            G2_BARRIER(); quad(w1, x0, 1, 0); G2_WAIT(2); G2_BARRIER();
-            read_x(x1, buf + G2_HALF);
-            if (more) stage(2, t + 1, nbuf);
-            G2_BARRIER(); quad(w1, x1, 1, 1); G2_WAIT(2); G2_BARRIER();
-            if (more) { read_x(x0, nbuf); stage(3, t + 1, nbuf); }
-            G2_BARRIER(); quad(w0, x1, 0, 1); G2_WAIT(2); G2_BARRIER();
-        }
-#undef G2_WAIT
-        if (wr == 0) G2_BARRIER();
-        const long long ts2 = p.trace ? wall_clock64() : 0;
-        t_load += ts1 - ts0; t_k += ts2 - ts1;
-
-        if (mode == 1) {
-            // the accumulator as it is, 32 x 1 KiB per wave, write-through; drained by every wave, then the flag
-            const int base = (c * 8 + wave) * 32768 + lane * 16;
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        u32x4 v;
-                        v[0] = __float_as_uint(acc[a][b][4 * g + 0]); v[1] = __float_as_uint(acc[a][b][4 * g + 1]);
-                        v[2] = __float_as_uint(acc[a][b][4 * g + 2]); v[3] = __float_as_uint(acc[a][b][4 * g + 3]);
-                        __builtin_amdgcn_raw_buffer_store_b128(v, rs, base + ((a * 4 + b) * 4 + g) * 1024, 0, 16);
-                    }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            G2_BARRIER();
-            if (tid == 0) __hip_atomic_store(sc.flags + c, sc.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (p.trace) t_dump += wall_clock64() - ts2;
-            continue;
-        }
-
-        uint2 bq[2][4];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const int n = n0 + wc * 64 + j * 32 + rg * 8 + half * 4;
-                bq[j][rg] = (p.bias && n < p.N) ? *reinterpret_cast<const uint2*>(p.bias + n) : make_uint2(0u, 0u);
-            }
-        // epilogue through LDS (epi_flush_strip), two passes of 64 rows per wave; the launcher admits only shapes that take this path
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        G2_BARRIER();
-        char* strip = smem + wave * (64 * EPI_ROW_BYTES);
-        auto run = [&](auto tag) {
-            constexpr int ACT = decltype(tag)::value;
-#pragma unroll
-            for (int hp = 0; hp < 2; ++hp) {
-#pragma unroll
-                for (int mq = 0; mq < 2; ++mq) {
-                    const int mt = hp * 2 + mq;
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-#pragma unroll
-                        for (int rg = 0; rg < 4; ++rg) {
-                            const int n = n0 + wc * 64 + j * 32 + rg * 8 + half * 4;
-                            const float bj[4] = {__uint_as_float(bq[j][rg].x << 16), __uint_as_float(bq[j][rg].x & 0xffff0000u),
-                                                 __uint_as_float(bq[j][rg].y << 16), __uint_as_float(bq[j][rg].y & 0xffff0000u)};
-                            float cs[4] = {1.f, 1.f, 1.f, 1.f};
-                            if (p.cscale && n < p.N) {
-                                const float4 c4 = *reinterpret_cast<const float4*>(p.cscale + n);
-                                cs[0] = c4.x; cs[1] = c4.y; cs[2] = c4.z; cs[3] = c4.w;
-                            }
-                            float v[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                float x = acc[j][mt][rg * 4 + e] * cs[e] + bj[e];
-                                if constexpr (ACT != ACT_NONE) x = sv_act(bfround(x), ACT);
-                                v[e] = x;
-                            }
-                            epi_park4(strip, mq * 32 + (lane & 31), j * 32 + rg * 8 + half * 4, v);
-                        }
-                }
-                epi_flush_strip(strip, p, m0 + wr * 128 + hp * 64, n0 + wc * 64, lane);
-            }
-        };
-        switch (p.act) {
-            case ACT_QUICKGELU: run(std::integral_constant<int, ACT_QUICKGELU>{}); break;
-            case ACT_SWISH: run(std::integral_constant<int, ACT_SWISH>{}); break;
-            case ACT_GELU_TANH: run(std::integral_constant<int, ACT_GELU_TANH>{}); break;
-            default: run(std::integral_constant<int, ACT_NONE>{}); break;
-        }
-        if (p.trace) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); t_epi += wall_clock64() - ts2; }
-    }
-    if (p.trace && tid == 0) {      // tools/gemm_trace.py: {start, ticks waiting for a flag, segments, end, K-tiles done, ticks in K loops (with their prologues), ticks loading | dumping << 32, ticks in epilogues}
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        long long* qq = p.trace + (size_t)blockIdx.x * 8;
-        qq[0] = t_start; qq[1] = t_wait; qq[2] = nseg; qq[3] = wall_clock64(); qq[4] = (long long)(u1 - u0) + (long long)n_dp * KT;
-        qq[5] = t_k; qq[6] = t_load | (t_dump << 32); qq[7] = t_epi;
-    }
-}
-
-// the stream-K form needs a workspace (GemmArgs::sk), the LDS epilogue's shapes, at least one full round of tiles and a ragged last round
-bool gemm_sk_eligible(const GemmArgs& a) {
-    static const bool off = getenv("SV_GEMM_NO_STREAMK") != nullptr;          // A/B of a run: the stream-K form is never a candidate
-    if (off) return false;
-    if (!a.sk || !a.sk->ws || a.out_f32 || (a.N & 7) || (a.ldc & 7) || (a.R && (a.ldr & 7)) || a.K < 128) return false;
-    const int T = ((a.M + G2_T - 1) / G2_T) * ((a.N + G2_T - 1) / G2_T), P = a.sk->blocks;
-    return P > 0 && T >= P && T % P != 0;
-}
-static void launch_gemm256sk(const GemmArgs& a, hipStream_t st) {
-    SkSched sc;
-    sc.tiles_m = (a.M + G2_T - 1) / G2_T; sc.tiles_n = (a.N + G2_T - 1) / G2_T;
-    const int T = sc.tiles_m * sc.tiles_n, P = a.sk->blocks, KT = a.K >> 6;
-    sc.t_dp = (T / P - 1) * P;
-    const long units = (long)(T - sc.t_dp) * KT;
-    sc.share = (int)(units / P); sc.extra = (int)(units % P);
-    sc.epoch = ++a.sk->epoch;
-    sc.ws = a.sk->ws; sc.flags = a.sk->flags; sc.err = a.sk->err;
-    gemm256sk_kernel<<<P, 512, 2 * G2_BUF, st>>>(a, sc);
-}
+// (Round 4 tried this tile as a PERSISTENT kernel with a stream-K remainder -- one block per CU, a split tile's accumulator handed from the
+// block that owns its first K-tiles to the block that continues the K loop, so the bits stay those of this kernel.  The hand-off cost
+// 3 + 6 us per block, but blocks at different K offsets stop sharing A / W panels in their XCD's L2 and the K loop went from 1.64 to
+// 1.85-2.29 us per K-tile: slower than the tuned forms on every prefill shape.  profiles/gemm_trace_r04.log; the kernel is in git history.)
 
 // ------------------------------------------------------------------------------------------------
 // tail rows of a big-M GEMM.  32 x 259 prompt rows are 32 full 256-row tiles plus 96 rows; run as a 33rd tile row
@@ -1151,7 +866,6 @@ GemmPlan gemm_plan(int M, int N, int K, int act, int tail_on) {
 // multiple of 256 is peeled into the tail kernel.  Every configuration computes the same bits (same MFMA, operand roles
 // and ascending-k order: tests/test_gpu_ops.py::test_linear_big_m_kernels_agree_bitwise), so the choice is speed only.
 static void launch_gemm_config(const GemmArgs& a, hipStream_t st, int kernel256, bool peel, bool tail_by_tiles) {
-    if (kernel256 == 2) { launch_gemm256sk(a, st); return; }          // (the caller checked gemm_sk_eligible)
     auto tiles = [&](const GemmArgs& g, bool force128) {
         dim3 grid((g.N + GB_N - 1) / GB_N, (g.M + GB_M - 1) / GB_M);
         if (kernel256 && !force128) { launch_gemm256(g, st); return; }
@@ -1230,29 +944,17 @@ static int autotune_gemm(const GemmArgs& a, hipStream_t st, const GemmPlan& mode
             if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) { best_ms = ms; best = cfg; }
         }
     }
-    if (gemm_sk_eligible(t)) {              // bit 3: the persistent stream-K form of the 256^2 kernel (rows not peeled: its last tile row is partial)
-        launch_gemm_config(t, st, 2, false, false);
-        (void)hipEventRecord(e0, st);
-        for (int r = 0; r < 3; ++r) launch_gemm_config(t, st, 2, false, false);
-        (void)hipEventRecord(e1, st);
-        float ms = 0.f;
-        if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best_ms) { best_ms = ms; best = 8; }
-        else (void)hipGetLastError();
-    }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (getenv("SV_GEMM_AUTOTUNE_LOG"))
         fprintf(stderr, "[sv gemm autotune] M %d N %d K %d act %d res %d -> %s%s (%.1f us; model said %s%s)\n", a.M, a.N, a.K, a.act,
-                a.R ? 1 : 0, (best & 8) ? "256^2 persistent stream-K" : (best & 1) ? "256^2" : "128^2", (best & 2) ? " + peeled tail" : "", best_ms * 1000.f / 3.f,
+                a.R ? 1 : 0, (best & 1) ? "256^2" : "128^2", (best & 2) ? " + peeled tail" : "", best_ms * 1000.f / 3.f,
                 (fallback & 1) ? "256^2" : "128^2", (fallback & 2) ? " + peeled tail" : "");
     return best;
 }
 
-void launch_gemm_fixed(const GemmArgs& a, int kernel256, int peel, hipStream_t st) {
-    if (kernel256 == 2 && !gemm_sk_eligible(a)) kernel256 = 1;
-    launch_gemm_config(a, st, kernel256, peel != 0, false);
-}
+void launch_gemm_fixed(const GemmArgs& a, int kernel256, int peel, hipStream_t st) { launch_gemm_config(a, st, kernel256 != 0, peel != 0, false); }
 
-static std::atomic<int> g_gemm_form{-1};        // test surface (sv_debug_set_gemm_form): -1 = tuned, 0 / 1 / 2 = one fixed form
+static std::atomic<int> g_gemm_form{-1};        // test surface (sv_debug_set_gemm_form): -1 = tuned, 0 / 1 = one fixed form
 void set_gemm_form(int form) { g_gemm_form = form; }
 
 void launch_gemm(const GemmArgs& a0, hipStream_t st) {
@@ -1272,9 +974,7 @@ void launch_gemm(const GemmArgs& a0, hipStream_t st) {
             if (it != g_tune.end()) cfg = it->second;
             else { cfg = autotune_gemm(a, st, pl); g_tune[key] = cfg; }
         }
-        if ((cfg & 8) && gemm_sk_eligible(a)) launch_gemm_config(a, st, 2, false, false);
-        else if (cfg & 8) { const GemmPlan pl2 = gemm_plan(a.M, a.N, a.K, a.act, 1); launch_gemm_config(a, st, pl2.main_256, pl2.peel != 0, pl2.tail_by_tiles != 0); }
-        else launch_gemm_config(a, st, cfg & 1, (cfg & 2) != 0, (cfg & 4) != 0);
+        launch_gemm_config(a, st, cfg & 1, (cfg & 2) != 0, (cfg & 4) != 0);
         return;
     }
     const int tail = a.M % 256, main_rows = a.M - tail;
@@ -1832,7 +1532,6 @@ int init_gemm_kernels() {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<float>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
-    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256sk_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
     return r;
 }
 

@@ -22,9 +22,6 @@ void launch_pack_weight_fp8(const void* src, int src_is_f32, bf16_t* dst_bf16, u
                             int Npad, int Kpad, hipStream_t st);
 
 // ---- big-M MFMA GEMM:  C[M][N] = epi( A[M][K] . W^T + bias ) (+ residual) ----------------------
-// workspace of the persistent stream-K form of the 256^2 kernel (gemm.hip gemm256sk_kernel): one per engine / caller, used by one stream
-// at a time.  ws: blocks x 256 KiB (an fp32 accumulator per block), flags: blocks words, err: set to 6 when a block gave up waiting
-struct SkWorkspace { void* ws = nullptr; unsigned* flags = nullptr; int* err = nullptr; int blocks = 0; unsigned epoch = 0; };
 struct GemmArgs {
     const bf16_t* A; int lda;        // activations, row-major bf16, K-contiguous
     const bf16_t* Wp;                // packed weight
@@ -34,14 +31,12 @@ struct GemmArgs {
     int M, N, K;                     // K = padded K (multiple of 64) shared by A and Wp
     int act; int out_f32;
     const float* cscale = nullptr;   // fp8 weights: per-output-column scale applied to the accumulator (or nullptr)
-    SkWorkspace* sk = nullptr;       // HOST pointer (never read on the device): the stream-K form is a candidate only with a workspace
     long long* trace = nullptr;      // optional [blocks][8] wall-clock stamps of the 256^2 kernel (tools/gemm_trace.py); nullptr in production
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 // one fixed configuration (kernel256: 0 = 128^2 tiles, 1 = 256^2; peel: the row remainder over a multiple of 256 in its own launch), no tuning
-void launch_gemm_fixed(const GemmArgs& a, int kernel256, int peel, hipStream_t st);     // kernel256 = 2: the persistent stream-K form
-bool gemm_sk_eligible(const GemmArgs& a);
-void set_gemm_form(int form);         // -1: tuned (default); 0 / 1 / 2: every big-M launch takes that form (2 where eligible, else 1)
+void launch_gemm_fixed(const GemmArgs& a, int kernel256, int peel, hipStream_t st);
+void set_gemm_form(int form);         // -1: tuned (default); 0 / 1: every big-M launch takes that form, rows not peeled
 // what launch_gemm decides for a shape (host arithmetic only; tail_on: 0 never peel, 1 cost model, 2 always)
 struct GemmPlan { int peel, tail_rows, tail_by_tiles, main_256; double est_us; };
 GemmPlan gemm_plan(int M, int N, int K, int act, int tail_on);

@@ -26,23 +26,6 @@ def pct(v):
     return [round(v[0], 2), round(v[n // 2], 2), round(v[min(n - 1, int(n * 0.9))], 2), round(v[-1], 2)]
 
 
-def stream_k(M, N, K, act):
-    blocks = ((M + 255) // 256) * ((N + 255) // 256)
-    buf = (C.c_int64 * (blocks * 16))()
-    n = lib.sv_debug_gemm_trace(M, N, K, act, 2, buf, blocks)
-    if n < 0:
-        print(f"  persistent stream-K form: {lib.sv_last_error().decode()}")
-        return
-    rows = [list(buf[i * 8:(i + 1) * 8]) for i in range(n)]
-    t0 = min(r[0] for r in rows)
-    span = max(r[3] - t0 for r in rows) / 100.0
-    print(f"  persistent stream-K form ({n} blocks): launch span {span:.1f} us = {2.0 * M * N * K / span / 1e6:.0f} TF/s; per block: segments "
-          f"{pct([r[2] for r in rows])}, K-tiles {pct([r[4] for r in rows])}, busy {pct([(r[3] - r[0]) / 100.0 for r in rows])} us")
-    print(f"    K loops + prologues {pct([r[5] / 100.0 for r in rows])} us = per K-tile {pct([r[5] / 100.0 / r[4] for r in rows])}; accumulator load (with "
-          f"the flag wait {pct([r[1] / 100.0 for r in rows])}) {pct([(r[6] & 0xffffffff) / 100.0 for r in rows])}; accumulator dump "
-          f"{pct([(r[6] >> 32) / 100.0 for r in rows])}; epilogues {pct([r[7] / 100.0 for r in rows])}")
-
-
 for M, N, K, act in shapes:
     blocks = ((M + 255) // 256) * ((N + 255) // 256)
     buf = (C.c_int64 * (blocks * 16))()
@@ -82,4 +65,3 @@ for M, N, K, act in shapes:
         alive += d
         last = t
     print(f"  mean blocks alive over the span: {area / span:.1f} of 256")
-    stream_k(M, N, K, act)
