@@ -259,8 +259,7 @@ int  sv_debug_attn_trace(sv_engine* e, int64_t* host_out, int32_t capacity_rows)
 int  sv_debug_mlp_trace(sv_engine* e, int64_t* host_out, int32_t capacity_blocks);
 /*   sv_debug_xcc_map     the XCD (XCC_ID) each block of a 1-D launch of `blocks` 8-wave blocks ran on, into host_out[blocks]; heavy = 1 gives
      the blocks the decode attention's LDS footprint and 10 us of residence (a grid above the CU count then runs in rounds, like a 64-row
-     attention launch).  Returns 1 when this engine hands the decode attention's context splits over inside one XCD's L2 (the probe at
-     sv_create found block L on XCD L % 8), 0 when it uses the placement-independent hand-off. */
+     attention launch).  Evidence for the XCD-aware block -> tile mappings (block L runs on XCD (L + c) % 8): DESIGN.md sections 3c / 3f. */
 int  sv_debug_xcc_map(sv_engine* e, int32_t blocks, int32_t heavy, int32_t* host_out);
 /*   sv_debug_gemm_trace  the 256x256 big-M GEMM kernel (prefill / ViT) on random operands of the given shape, one launch with wall-clock
      stamps (form = 1): host_out [blocks * 2][8] = {start, K-tile 0 staged, K loop done, epilogue stored, tile m, tile n, wave, 0}

@@ -305,14 +305,12 @@ void launch_kv_write_prefill(const bf16_t* qkv, int row_stride, int k_off, int v
 // splits exit at once.  Active blocks own the 32-key
 // groups g = split + act*(wave + 8*i), prefetch the next group's fragments while the MFMAs of the
 // current one run, and (act > 1) leave a partial (m, l, O) in HBM; an arrival ticket elects the last
-// block, which merges the partials in split order (bitwise deterministic).  Nobody waits for anybody: a
-// launch may have more blocks than the chip has CUs (64 rows: 512).  Two hand-offs:
-//   * placement independent (XL = false): write-through (sc1) partial stores + drained ticket + sc1 loads in the merger;
-//   * XCD local (XL = true): a 1-D grid whose linear block id L goes to XCD L % 8 (the dispatcher's round robin), mapped so that
-//     ALL the context splits of a sequence run on ONE XCD and meet in its L2: plain stores (acknowledged by the L2, not by
-//     HBM), the merger's loads bypass only the L1.  Every arriver adds its own XCC_ID to the (device-scope) ticket; the
-//     merger checks that all of them were on its XCD and flags the call (AttnDecodeArgs::err = 5) otherwise -- the engine
-//     probes the mapping once at creation (engine_core.hip) and uses this form only where it holds.
+// block, which merges the partials in split order (bitwise deterministic).  Hand-off = write-through
+// (sc1) partial stores + drained ticket + sc1 loads in the merger: no fences, placement independent, and NOBODY WAITS: a launch may
+// have more blocks than the chip has CUs (64 rows: 512).  Round 4 measured two other hand-offs and removed both (profiles/
+// attn_trace_r04.log): an in-band one (split 0's block polls the others' partial slots: needs every block resident -> NaNs at 64 rows)
+// and an XCD-local one (all splits of a sequence on one XCD, partials through its L2: bit-identical, but no faster once the grid
+// dispatches every sequence's split 0 first -- the store acknowledgement was never an HBM round trip).
 // ------------------------------------------------------------------------------------------------
 #define AD_WAVES 8
 #define AD_SPLIT 16
@@ -341,41 +339,28 @@ __device__ __forceinline__ void load_group(KvFrags<D>& f, const char* pool, int 
         f.v[t] = *reinterpret_cast<const u32x4*>(page + (size_t)64 * D * 2 + ((size_t)((half * NDV + t) * 64 + lane)) * 16);
 }
 
-// Leading scalar parameters: what the first loads (position, block table, KV fragments, c_attn slabs) need; they arrive
-// preloaded in SGPRs with the dispatch (see gemm_skinny_kernel), the struct is read later.
-struct AttnDecodeKernarg { const int32_t* positions; const int32_t* block_table; char* pool_layer; const float* ws; size_t kv_head_stride;
-                           int max_pages, n_kv, max_splits, window, gpb; AttnDecodeArgs p; };     // the kernarg segment
 __device__ __forceinline__ unsigned xcc_id() {
     unsigned x;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
     return x & 15u;
 }
 
-// gpb_nb_: bits 0..7 = 32-key groups per block, bits 8.. = B * n_kv (the XCD-local grid is padded to a multiple of 8 of them)
-template <int D, bool XL>
+// Leading scalar parameters: what the first loads (position, block table, KV fragments, c_attn slabs) need; they arrive
+// preloaded in SGPRs with the dispatch (see gemm_skinny_kernel), the struct is read later.
+struct AttnDecodeKernarg { const int32_t* positions; const int32_t* block_table; char* pool_layer; const float* ws; size_t kv_head_stride;
+                           int max_pages, n_kv, max_splits, window, gpb; AttnDecodeArgs p; };     // the kernarg segment
+template <int D>
 __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_t* positions_, const int32_t* block_table_, char* pool_layer_,
                                                                      const float* ws_, size_t kv_head_stride_, int max_pages_, int n_kv_,
-                                                                     int max_splits_, int window_, int gpb_nb_, AttnDecodeArgs p_unused) {
+                                                                     int max_splits_, int window_, int gpb_, AttnDecodeArgs p_unused) {
     constexpr int NKS = D / 32;          // k-steps of S^T (over head_dim)
     constexpr int NDV = D / 16;          // dv tiles of O^T
     constexpr int PART = 32 + 16 * D;    // floats per partial: m[16], l[16], O[16][D]
     const long long t_start = wall_clock64();         // 100 MHz; stored only when the trace buffer is on (tools/attn_trace.py)
-    const int gpb_ = gpb_nb_ & 255;
-    const int nsplit = max_splits_ < 1 ? 1 : (max_splits_ > AD_SPLIT ? AD_SPLIT : max_splits_);       // context splits the grid holds
-    int bx, split;                           // (sequence, KV head), context split
-    if (XL) {
-        // block L runs on XCD L % 8; the j = L / 8 -th block of an XCD is split j % nsplit of that XCD's (j / nsplit)-th sequence
-        const int j = blockIdx.x >> 3, per_xcd = (int)(gridDim.x >> 3) / nsplit;
-        bx = (blockIdx.x & 7) * per_xcd + j / nsplit;
-        split = j % nsplit;
-    } else {
-        bx = blockIdx.x;
-        split = blockIdx.y;
-    }
-    const bool pad_block = XL && bx >= (gpb_nb_ >> 8);
-    if (pad_block) bx = 0;                   // reads below stay in range; the block leaves with the inactive splits
+    const int bx = blockIdx.x;               // (sequence, KV head)
     const int b = bx / n_kv_;
     const int kvh = bx % n_kv_;
+    const int split = blockIdx.y;
     // the first 64 entries of this sequence's block-table row (4096 tokens) are requested together with the position: the
     // page of a key group is then a cross-lane read instead of a second dependent global round trip (position -> table -> KV)
     const int32_t* table = block_table_ + (size_t)b * max_pages_;
@@ -399,7 +384,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
                 *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(q.poison) + off) = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         }
     };
-    if (split >= act || pad_block) {
+    if (split >= act) {
         poison(sv_late_args<AttnDecodeArgs>(offsetof(AttnDecodeKernarg, p)));
         return;
     }
@@ -626,13 +611,12 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
             u32x4 v;
             v[0] = __float_as_uint(num[0]); v[1] = __float_as_uint(num[1]);
             v[2] = __float_as_uint(num[2]); v[3] = __float_as_uint(num[3]);
-            if (XL) __builtin_amdgcn_raw_buffer_store_b128(v, rs, my_off + (32 + idx) * 4, 0, 0);    // to this XCD's L2
-            else __builtin_amdgcn_raw_buffer_store_b128(v, rs, my_off + (32 + idx) * 4, 0, 16);      // write-through
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, my_off + (32 + idx) * 4, 0, 16);   // write-through
         }
     }
     auto stamp = [&](long long t_part, long long t_tick, long long t_end) {
         if (p.trace && tid == 0) {
-            long long* q = p.trace + ((size_t)bx * nsplit + split) * 16;
+            long long* q = p.trace + ((size_t)bx * gridDim.y + split) * 16;
             q[0] = t_start; q[1] = t_kvreq; q[2] = t_q; q[3] = t_loop; q[4] = t_part; q[5] = t_tick; q[6] = t_end; q[7] = act; q[8] = ngroups;
         }
     };
@@ -655,22 +639,17 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
             }
             v[j] = __float_as_uint(is_l ? den : M);
         }
-        if (XL) __builtin_amdgcn_raw_buffer_store_b128(v, rs, my_off + tid * 16, 0, 0);
-        else __builtin_amdgcn_raw_buffer_store_b128(v, rs, my_off + tid * 16, 0, 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, my_off + tid * 16, 0, 16);
     }
 
-    // hand-off without fences: the partial is stored (write-through, or to the XCD's L2), every storing wave drains, one relaxed
-    // agent-scope ticket; the last arriver reads the partials past its L1 (and past the L2 when placement independent).
-    // The ticket: bits 0..7 count the arrivals, 7 bits per XCD above them count the arrivals by the XCD they ran on.
+    // hand-off without fences: write-through (sc1) partial, every storing wave drains, one relaxed
+    // agent-scope ticket; the last arriver reads the partials with sc1 loads (L1 bypass)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     const long long t_part = wall_clock64();           // partial stored and drained
     if (tid == 0) {
-        const unsigned sh = 8u + 7u * (XL ? (xcc_id() & 7u) : 0u);
-        const unsigned long long t = __hip_atomic_fetch_add(p.counters + bx, 1ull + (1ull << sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const bool last = (unsigned)(t & 255ull) == (unsigned)(act - 1);
-        flag_s[0] = last ? 1 : 0;
-        if (XL && last && (unsigned)((t >> sh) & 127ull) != (unsigned)(act - 1)) *p.err = 5;      // a split ran on another XCD: its partial is not in this L2
+        const unsigned t = __hip_atomic_fetch_add(p.counters + bx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        flag_s[0] = (t == (unsigned)(act - 1)) ? 1 : 0;
     }
     __syncthreads();
     const long long t_tick = wall_clock64();           // ticket drawn
@@ -687,15 +666,9 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
             ov[s2] = u32x4{0u, 0u, 0u, 0u};
             ms[s2] = -INFINITY; ls[s2] = 0.f;
             if (s2 < act) {
-                if (XL) {                    // sc0: past the L1, served by the L2 the producers wrote
-                    ms[s2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, seq_off + (s2 * PART + h) * 4, 0, 1));
-                    ls[s2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, seq_off + (s2 * PART + 16 + h) * 4, 0, 1));
-                    ov[s2] = __builtin_amdgcn_raw_buffer_load_b128(rs, seq_off + (s2 * PART + 32 + idx) * 4, 0, 1);
-                } else {
-                    ms[s2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, seq_off + (s2 * PART + h) * 4, 0, 16));
-                    ls[s2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, seq_off + (s2 * PART + 16 + h) * 4, 0, 16));
-                    ov[s2] = __builtin_amdgcn_raw_buffer_load_b128(rs, seq_off + (s2 * PART + 32 + idx) * 4, 0, 16);
-                }
+                ms[s2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, seq_off + (s2 * PART + h) * 4, 0, 16));
+                ls[s2] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, seq_off + (s2 * PART + 16 + h) * 4, 0, 16));
+                ov[s2] = __builtin_amdgcn_raw_buffer_load_b128(rs, seq_off + (s2 * PART + 32 + idx) * 4, 0, 16);
             }
         }
         float M = -INFINITY;
@@ -715,7 +688,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
         o.y = pack2bf(num[2] * inv, num[3] * inv);
         *reinterpret_cast<uint2*>(p.out_xp + xp_index(b >> 5, p.out_KS, b & 31, col0 + idx)) = o;
     }
-    if (tid == 0) __hip_atomic_store(p.counters + bx, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    if (tid == 0) __hip_atomic_store(p.counters + bx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
     stamp(t_part, t_tick, wall_clock64());
 }
 
@@ -728,28 +701,26 @@ static size_t attn_decode_smem(int D) {
 // dynamic LDS above the 64 KiB default needs an explicit opt-in.  Done once at engine creation (never
 // inside a stream capture)
 int init_attention_kernels() {
-    const void* fns[4] = {reinterpret_cast<const void*>(&attn_decode_kernel<128, false>), reinterpret_cast<const void*>(&attn_decode_kernel<128, true>),
-                          reinterpret_cast<const void*>(&attn_decode_kernel<64, false>), reinterpret_cast<const void*>(&attn_decode_kernel<64, true>)};
-    for (int i = 0; i < 4; ++i) {
-        const hipError_t r = hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_decode_smem(i < 2 ? 128 : 64));
-        if (r != hipSuccess) return (int)r;
-    }
-    return 0;
+    hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_decode_kernel<128>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_decode_smem(128));
+    if (r != hipSuccess) return (int)r;
+    r = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_decode_kernel<64>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)attn_decode_smem(64));
+    return (int)r;
 }
 
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t st) {
     const size_t smem = attn_decode_smem(a.head_dim);
     // grid.y = the engine's split cap, not AD_SPLIT: the splits above it never work, and dispatching 8-wave blocks that exit
     // at once is not free (B = 32: 256 of 512 blocks)
-    const int nb = a.B * a.n_kv, ns = a.max_splits < 1 ? 1 : (a.max_splits > AD_SPLIT ? AD_SPLIT : a.max_splits);
-    const int gpb = (a.groups_per_block > 0 ? a.groups_per_block : AD_GROUPS_PER_BLOCK) | (nb << 8);
-    // XCD local: a 1-D grid, (B * n_kv rounded up to 8) sequences x ns splits, so that every XCD holds whole sequences
-    const dim3 grid = a.xcd_local ? dim3(((nb + 7) / 8) * 8 * ns) : dim3(nb, ns);
-#define SV_AD_LAUNCH(DD, XX) attn_decode_kernel<DD, XX><<<grid, AD_WAVES * 64, smem, st>>>(a.positions, a.block_table, a.pool_layer, a.ws, \
-                                 a.kv_head_stride, a.max_pages, a.n_kv, a.max_splits, a.window, gpb, a)
-    if (a.head_dim == 128) { if (a.xcd_local) SV_AD_LAUNCH(128, true); else SV_AD_LAUNCH(128, false); }
-    else { if (a.xcd_local) SV_AD_LAUNCH(64, true); else SV_AD_LAUNCH(64, false); }
-#undef SV_AD_LAUNCH
+    dim3 grid(a.B * a.n_kv, a.max_splits < 1 ? 1 : (a.max_splits > AD_SPLIT ? AD_SPLIT : a.max_splits));
+    const int gpb = a.groups_per_block > 0 ? a.groups_per_block : AD_GROUPS_PER_BLOCK;
+    if (a.head_dim == 128)
+        attn_decode_kernel<128><<<grid, AD_WAVES * 64, smem, st>>>(a.positions, a.block_table, a.pool_layer, a.ws, a.kv_head_stride,
+                                                                    a.max_pages, a.n_kv, a.max_splits, a.window, gpb, a);
+    else
+        attn_decode_kernel<64><<<grid, AD_WAVES * 64, smem, st>>>(a.positions, a.block_table, a.pool_layer, a.ws, a.kv_head_stride,
+                                                                   a.max_pages, a.n_kv, a.max_splits, a.window, gpb, a);
 }
 
 // which XCD each block of a 1-D launch runs on (XCC_ID), with the footprint of the decode attention when asked: `lds_bytes` of dynamic

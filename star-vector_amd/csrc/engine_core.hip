@@ -547,22 +547,6 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     }
     if (getenv("SV_EXP")) e->exp = atoi(getenv("SV_EXP"));
     if (!rc && getenv("SV_ATTN_TRACE")) rc = dalloc(e, &e->attn_trace, R * (size_t)nkv * 16 * 16);
-    // XCD-local hand-off of the decode attention (attention.hip): used when this device dispatches block L of a 1-D launch to XCD L % 8
-    // -- probed here with the attention's own footprint, one launch that fits the chip and one that runs in rounds; SV_EXP bit 1024 = A/B,
-    // the placement-independent hand-off
-    if (!rc && !(e->exp & 1024)) {
-        const int nblk = 4 * e->num_cus;
-        int32_t* d_map = nullptr;
-        std::vector<int32_t> h((size_t)nblk);
-        bool ok = hipMalloc((void**)&d_map, (size_t)nblk * 4) == hipSuccess;
-        for (int heavy = 0; ok && heavy < 2; ++heavy) {
-            ok = launch_xcc_probe(d_map, heavy ? 2 * e->num_cus : nblk, heavy, nullptr) == 0 && hipDeviceSynchronize() == hipSuccess &&
-                 hipMemcpy(h.data(), d_map, (size_t)(heavy ? 2 * e->num_cus : nblk) * 4, hipMemcpyDeviceToHost) == hipSuccess;
-            for (int i = 0; ok && i < (heavy ? 2 * e->num_cus : nblk); ++i) ok = h[i] == h[i & 7] && (i >= 8 || i == 0 || h[i] != h[0]);
-        }
-        if (d_map) (void)hipFree(d_map);
-        e->attn_xcd_local = ok;
-    }
     // 6 launches per layer (decode_cols.hip): bf16 weights, at most one 32-row tile per launch; SV_EXP bit 2 = A/B, the 7-launch layer.
     // Hidden sizes above 2048 keep the 7-launch layer: every block of the whole-K projection re-reads 32 x K activations from L2,
     // and at StarVector-8B's K = 4608 that costs what the removed row update saves (16 columns per block: 4227 vs 4178 us per

@@ -209,7 +209,7 @@ void sveng::attn_decode_args(sv_engine* e, int layer, int B, const float* ws, in
     ad.max_pages = e->pages_per_seq; ad.positions = e->positions; ad.out_xp = out_xp; ad.out_KS = c.n_head * e->dh / 16;
     ad.window = c.sliding_window;
     ad.B = B; ad.H = c.n_head; ad.head_dim = e->dh; ad.scale = 1.0f / sqrtf((float)e->dh);
-    ad.part = e->attn_part; ad.counters = e->attn_cnt; ad.err = e->d_bad; ad.xcd_local = (e->attn_xcd_local && !(e->exp & 1024)) ? 1 : 0;
+    ad.part = e->attn_part; ad.counters = e->attn_cnt;
     ad.max_splits = attn_max_splits(e);
     ad.groups_per_block = attn_groups_per_block(e);
     ad.n_kv = e->nkv; ad.kv_head_stride = e->kv_head_stride; ad.rope_cos = e->rope_cos; ad.rope_sin = e->rope_sin;

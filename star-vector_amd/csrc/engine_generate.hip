@@ -179,9 +179,6 @@ int sveng::check_finite_logits(sv_engine* e, hipStream_t st, const char* who) {
     const int what = e->h_flags[4];
     HIPCHECK(hipMemsetAsync(e->d_bad, 0, sizeof(int32_t), st));
     HIPCHECK(hipStreamSynchronize(st));
-    if (what == 5)
-        return fail(SV_EHIP, "%s: a context split of the decode attention ran on another XCD than the block that merged it (the dispatch order "
-                             "probed at sv_create did not hold); the tokens of this call are void -- run with SV_EXP=1024", who);
     if (what == 3)
         return fail(SV_EHIP, "%s: a block of the fused MLP launch gave up waiting for its producers (its blocks were not all resident at "
                              "once?); the tokens of this call are void -- run without SV_EXP bit 128", who);

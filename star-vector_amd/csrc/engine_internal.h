@@ -125,8 +125,7 @@ struct sv_engine {
                                     //   (1, 2: XCD-aligned weight prefetch by attention's idle waves / spare row-update blocks; 4: one key
                                     //    group per attention block -- all measured slower, profiles/prefetch_r03_*.log, removed)
     float *ws = nullptr, *ws2 = nullptr, *logits = nullptr, *sample_scratch = nullptr, *attn_part = nullptr;
-    unsigned long long* attn_cnt = nullptr;
-    bool attn_xcd_local = false;    // the decode attention's context splits meet in one XCD's L2 (attention.hip); set by the probe in sv_create
+    unsigned* attn_cnt = nullptr;
     float* am_val = nullptr; int32_t* am_idx = nullptr;
     uint32_t* seen = nullptr; int seen_words = 0;      // repetition-penalty bitmap [rows][Vpad/32]
     int32_t *cur_tok = nullptr, *next_tok = nullptr, *unfinished = nullptr, *positions = nullptr,

@@ -116,13 +116,6 @@ extern "C" int sv_debug_attn_decode(sv_engine* e, int32_t layer, const float* de
     if (advance) add_i32(e->positions, 1, B, st);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(st));          // `zero_bias` is freed on return
-    int32_t bad = 0;
-    HIPCHECK(hipMemcpy(&bad, e->d_bad, sizeof(bad), hipMemcpyDeviceToHost));
-    if (bad == 5) {
-        HIPCHECK(hipMemset(e->d_bad, 0, sizeof(int32_t)));
-        return fail(SV_EHIP, "sv_debug_attn_decode: a context split ran on another XCD than the block that merged it (SV_EXP=1024 selects the "
-                             "placement-independent hand-off)");
-    }
     return 0;
 }
 
@@ -156,7 +149,7 @@ extern "C" int sv_debug_attn_trace(sv_engine* e, int64_t* host_out, int32_t capa
 }
 
 // host_out[blocks]: the XCC_ID each block of a 1-D launch of 8-wave blocks ran on (heavy = 1: with the decode attention's LDS footprint and
-// 10 us of residence, so that a grid above the CU count is dispatched in rounds).  Returns 1 when the engine uses the XCD-local hand-off.
+// 10 us of residence, so that a grid above the CU count is dispatched in rounds).
 extern "C" int sv_debug_xcc_map(sv_engine* e, int32_t blocks, int32_t heavy, int32_t* host_out) {
     if (!e || !host_out || blocks < 1 || blocks > (1 << 16)) return fail(SV_EINVAL, "sv_debug_xcc_map: bad argument");
     std::lock_guard<std::mutex> lk(e->mu);
@@ -167,7 +160,7 @@ extern "C" int sv_debug_xcc_map(sv_engine* e, int32_t blocks, int32_t heavy, int
     if (!rc && (hipDeviceSynchronize() != hipSuccess || hipMemcpy(host_out, d, (size_t)blocks * 4, hipMemcpyDeviceToHost) != hipSuccess)) rc = -1;
     (void)hipFree(d);
     if (rc) return fail(SV_EHIP, "sv_debug_xcc_map: probe launch failed");
-    return e->attn_xcd_local ? 1 : 0;
+    return 0;
 }
 
 extern "C" int sv_debug_set_gemm_form(int32_t form) {

@@ -177,9 +177,7 @@ struct AttnDecodeArgs {
     bf16_t* out_xp; int out_KS;                            // packed [MT][H*D/16][64][8]
     int B, H, head_dim; float scale;
     float* part;                                           // [B][splits][32 + 16*D] partial (m, l, O)
-    unsigned long long* counters;                          // [B * n_kv] arrival tickets (count | arrivals per XCD), zero between launches
-    int* err;                                              // set to 5 when a context split of the XCD-local form ran on another XCD
-    int xcd_local;                                         // 1: all splits of a sequence on one XCD, hand-off through its L2 (attention.hip)
+    unsigned* counters;                                    // [B * n_kv] arrival tickets, zero between launches
     int max_splits;                                        // cap on active context splits (#CUs / (B*n_kv), <= 16)
     int n_kv;                                              // key/value heads (1 = MQA); grid.x = B * n_kv
     size_t kv_head_stride;                                 // bytes between the page pools of consecutive KV heads

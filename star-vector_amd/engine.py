@@ -352,13 +352,11 @@ class HipEngine:
         return torch.tensor(list(buf[: n * 16]), dtype=torch.int64).view(n, 16)
 
     def debug_xcc_map(self, blocks: int, heavy: bool = False):
-        """(xcd_local, [blocks] list of XCC_IDs): where the blocks of a 1-D launch ran, and whether this engine's decode attention hands its
-        context splits over inside one XCD's L2 (include/starvector_hip.h, sv_debug_xcc_map)."""
+        """[blocks] list of XCC_IDs: where the blocks of a 1-D launch of 8-wave blocks ran (heavy: with the decode attention's LDS footprint and
+        10 us of residence, so that a grid above the CU count runs in rounds; include/starvector_hip.h, sv_debug_xcc_map)."""
         buf = (C.c_int32 * blocks)()
-        n = self.lib.sv_debug_xcc_map(self._h, blocks, 1 if heavy else 0, buf)
-        if n < 0:
-            check(n, "sv_debug_xcc_map")
-        return bool(n), list(buf)
+        check(self.lib.sv_debug_xcc_map(self._h, blocks, 1 if heavy else 0, buf), "sv_debug_xcc_map")
+        return list(buf)
 
     def debug_mlp_trace(self) -> torch.Tensor:
         """[blocks, 8] int64 wall-clock stamps (100 MHz) of the last fused MLP launch of the middle layer (engine created with

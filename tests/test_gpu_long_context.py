@@ -244,41 +244,17 @@ def test_decode_attention_full_64_row_batch_has_more_blocks_than_the_chip_has_cu
     eng.close()
 
 
-def test_xcd_map_and_the_two_hand_offs_of_the_context_splits_agree_bit_for_bit():
-    """The engine hands a sequence's context splits over inside ONE XCD's L2 when the probe at sv_create found block L of a 1-D launch on
-    XCD L % 8 (attention.hip, XL form).  Prints where the blocks of a launch that fits the chip and of one that runs in
-    rounds actually ran, checks the rule the engine relies on, and that the XCD-local and the placement-independent (SV_EXP bit 1024)
-    hand-offs give the same bits (same merge order) for 32 rows (256 blocks), 64 rows (512 blocks) and a batch that is not a multiple
-    of 8 (padded grid)."""
-    for B, H, nkv, S in [(32, 16, 1, 1500), (64, 36, 4, 700), (5, 16, 1, 3000), (13, 36, 4, 900)]:
-        W = 4096 if nkv > 1 else 0
-        eng = _attn_engine(H, nkv, B, 4096, window=W)
-        if B == 32:
-            for heavy, n in [(False, 1024), (True, 512)]:
-                local, m = eng.debug_xcc_map(n, heavy)
-                rule = all(m[i] == m[i & 7] for i in range(n)) and len(set(m[:8])) == 8
-                print(f"[xcd map] {n} blocks, {'attention footprint, 2 rounds' if heavy else 'light'}: first 16 -> {m[:16]}; block L on XCD "
-                      f"map[L % 8]: {rule}; engine uses the XCD-local hand-off: {local}")
-                assert local == rule or not local, "the engine uses the XCD-local hand-off although the dispatch rule does not hold"
-        q, K, V = _peaked_case(B, H, nkv, S + 1, 3.0, 31 + B)
-        rope = _rope_tables(4096, 128, 1e6) if nkv > 1 else None
-        outs = []
-        for mask in (0, 1024):
-            eng.set_exp(mask)
-            eng.debug_kv_load(0, _kv_rows(K, V, S))
-            qkv = torch.cat([q.reshape(B, H * 128), K[:, :, S].reshape(B, nkv * 128), V[:, :, S].reshape(B, nkv * 128)], -1).float().contiguous()
-            outs.append(eng.debug_attn_decode(0, qkv, advance=False).clone())
-        qb, kb = _r(q), _r(K[:, :, S])
-        Kc = K.clone()
-        if rope is not None:
-            qb, kb = _rot(qb, rope[0][S], rope[1][S]), _rot(kb, rope[0][S], rope[1][S])
-        Kc[:, :, S] = kb
-        ref = _ref_attention(qb, Kc, V, torch.full((B,), S, device=dev()), W)
-        err = float((outs[0].float() - ref).abs().max() / ref.abs().max())
-        print(f"[decode attention hand-off] B={B}, {H} heads on {nkv}, context {S + 1}: XCD-local == placement-independent: "
-              f"{bool(torch.equal(outs[0], outs[1]))}; |err| / max|ref| = {err:.3e}")
-        assert torch.equal(outs[0], outs[1]) and err <= 2e-2
-        eng.close()
+def test_blocks_of_a_launch_go_round_robin_to_the_xcds():
+    """The XCD-aware block -> tile mappings (slab GEMMs' (tile, K slice) assignment, the 256^2 GEMM's tile order) rest on the dispatcher dealing
+    block L of a launch to XCD (L + c) % 8.  Where the blocks of a launch that fits the chip and of one that runs in rounds (the decode
+    attention's footprint, 512 blocks) actually ran: `sv_debug_xcc_map`."""
+    eng = _attn_engine(16, 1, 32, 4096)
+    for heavy, n in [(False, 1024), (True, 512)]:
+        m = eng.debug_xcc_map(n, heavy)
+        rule = all(m[i] == m[i & 7] for i in range(n)) and len(set(m[:8])) == 8
+        print(f"[xcd map] {n} blocks, {'attention footprint, 2 rounds' if heavy else 'light'}: first 16 -> {m[:16]}; block L on XCD map[L % 8]: {rule}")
+        assert rule
+    eng.close()
 
 
 # ------------------------------------------------------------------------------------------------------------------
