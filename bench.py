@@ -280,8 +280,13 @@ def main():
     if os.path.exists(tfile) and not is8b and args.weights == "bf16" and not t2s:
         try:
             tj = json.load(open(tfile))
-            traffic = tj.get("skinny_gemm_bytes_per_launch")
-            traffic_source = ("static: profiles/hbm_traffic.json (" + tj.get("measured", "rocprofv3 --pmc pass, separate run") + ")")
+            # the figure belongs to ONE launch family (73 launches per step with the fused MLP launch, 97 without): quoted only for that one
+            if int(tj.get("launches_per_step", round(launches))) == int(round(launches)):
+                traffic = tj.get("skinny_gemm_bytes_per_launch")
+                traffic_source = ("static: profiles/hbm_traffic.json (" + tj.get("measured", "rocprofv3 --pmc pass, separate run") + ")")
+            else:
+                traffic_source = (f"profiles/hbm_traffic.json was measured on the {tj.get('launches_per_step')}-launch family; this engine runs "
+                                  f"{int(round(launches))} launches per step")
         except Exception:
             traffic = None
 
