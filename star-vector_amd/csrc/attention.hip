@@ -429,9 +429,7 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
         else if (n < 17 * D) col = H * D + kvh * D + (n - 16 * D);
         else col = H * D + p.n_kv * D + kvh * D + (n - 17 * D);
         uint2 o = make_uint2(0u, 0u);
-        if (col >= 0 && p.qkv_rows) {
-            o = *reinterpret_cast<const uint2*>(p.qkv_rows + (size_t)b * p.ld_qkv + col);          // finished rows: one 8-byte load
-        } else if (col >= 0) {
+        if (col >= 0) {
             {
                 float4 acc4[8];
                 const uint2 bb = *reinterpret_cast<const uint2*>(p.bias + col);

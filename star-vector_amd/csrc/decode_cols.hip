@@ -116,18 +116,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_cols_resid_kernel(const bf16_
     const bool e_on = !vec && tid < 32 * cpb_ && e_n < N_;
     float e_bias = 0.f, e_res = 0.f;
     size_t e_idx = 0;
-    // out_KS_ < 0: ROW mode (the c_attn of the 6-launch layer): h_xp_ is a row-major bf16 [32 * MT][-out_KS_] output, out = bf16(x W^T + b),
-    // no residual -- the decode attention reads finished q | k | v rows instead of summing split-K slabs
-    const bool rowmode = out_KS_ < 0;
     if (v_on) {
         if (bias_) v_bias = *reinterpret_cast<const uint4*>(bias_ + v_n);
-        v_idx = rowmode ? (size_t)(32 * mt + v_row) * (size_t)(-out_KS_) + v_n : xp_index(mt, out_KS_, v_row, v_n);
-        if (!rowmode) v_res = *reinterpret_cast<const uint4*>(h_xp_ + v_idx);
+        v_idx = xp_index(mt, out_KS_, v_row, v_n);
+        v_res = *reinterpret_cast<const uint4*>(h_xp_ + v_idx);
     }
     if (e_on) {
         if (bias_) e_bias = bf2f(bias_[e_n]);
-        e_idx = rowmode ? (size_t)(32 * mt + e_row) * (size_t)(-out_KS_) + e_n : xp_index(mt, out_KS_, e_row, e_n);
-        if (!rowmode) e_res = bf2f(h_xp_[e_idx]);
+        e_idx = xp_index(mt, out_KS_, e_row, e_n);
+        e_res = bf2f(h_xp_[e_idx]);
     }
     for (int ci = 0; ci < nc; ci += 2 * G) {
         compute(ga, ci);
@@ -174,18 +171,12 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_cols_resid_kernel(const bf16_
             unpack8(v_res, rr);
             unpack8(v_bias, bb);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float y = tile[v_row * LDT + 8 * v_ch + e] + bb[e];
-                hn[e] = rowmode ? y : bfround(rr[e] + bfround(y));                                                    // h = bf(h + bf(x W^T + b))
-            }
+            for (int e = 0; e < 8; ++e) hn[e] = bfround(rr[e] + bfround(tile[v_row * LDT + 8 * v_ch + e] + bb[e]));      // h = bf(h + bf(x W^T + b))
             *reinterpret_cast<uint4*>(h_xp_ + v_idx) = pack8(hn);
         }
         return;
     }
-    if (e_on) {
-        const float y = tile[e_row * LDT + e_cr] + e_bias;
-        h_xp_[e_idx] = f2bf(rowmode ? y : bfround(e_res + bfround(y)));
-    }
+    if (e_on) h_xp_[e_idx] = f2bf(bfround(e_res + bfround(tile[e_row * LDT + e_cr] + e_bias)));
 }
 
 static size_t cols_smem(int waves, int ct) { return (size_t)waves * ct * 512 * 4 + (32 * (16 * ct + 1) + 16) * 4 + 64; }
@@ -218,7 +209,7 @@ int cols_pick_cpb(int N, int K) {
 }
 
 int launch_gemm_cols(const ColsArgs& a, hipStream_t st) {
-    if (a.K % 32 || a.cpb < 1 || a.cpb > 32 || !a.h_xp) return -1;          // (row mode: h_xp = the row-major output, out_KS = -ld)
+    if (a.K % 32 || a.cpb < 1 || a.cpb > 32 || !a.h_xp) return -1;
     dim3 grid((a.N + a.cpb - 1) / a.cpb, a.MT);
     if (a.cpb > 16)
         gemm_cols_resid_kernel<16, 2, 2><<<grid, 16 * 64, cols_smem(16, 2), st>>>(a.Wp, a.xp, a.h_xp, a.bias, a.K, a.N, a.cpb, a.out_KS, a);

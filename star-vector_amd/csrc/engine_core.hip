@@ -556,13 +556,6 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     if (!rc && e->fold6) {
         const int cpb = cols_pick_cpb(D, c.n_head * dh);
         for (DecLayer& L : e->dec) L.c_proj.cpb = cpb;
-        // c_attn the same way (round 4): the columns per block that make one block per CU (N = 2304: 9 -> 256 blocks), finished bf16 rows
-        // for the attention launch instead of split-K slabs; SV_EXP bit 256 = A/B, the slab c_attn
-        e->cattn_cpb = (e->QKV + e->num_cus - 1) / e->num_cus;
-        if (e->cattn_cpb < 4) e->cattn_cpb = 4;
-        if (e->cattn_cpb > 16) e->cattn_cpb = 0;
-        e->ld_qkv = round_up(e->QKV, 8);
-        if (e->cattn_cpb) rc = dalloc(e, &e->qkv_rows, R * (size_t)e->ld_qkv);
         // the fused MLP launch (SV_EXP bit 128) needs its F / 32 blocks resident at once (one 8-wave block per CU) and the exact
         // (tile, K slice) geometry of the two kernels it replaces: 16 k-steps per wave in both phases
         const Linear& fc = e->dec[0].c_fc; const Linear& dn = e->dec[0].c_proj2;

@@ -262,17 +262,7 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
     for (int i = 0; i < c.n_layer; ++i) {
         DecLayer& L = e->dec[i];
         row_update();                                            // embedding or the previous layer's down-proj -> LN1(h)
-        // 6-launch layer: c_attn over the whole K per block (no slabs): the attention launch loads finished bf16 q | k | v rows
-        const bool cattn_rows = fold6 && e->cattn_cpb > 0 && !(e->exp & 256);
-        if (cattn_rows) {
-            ColsArgs cq;
-            memset(&cq, 0, sizeof(cq));
-            cq.xp = e->xp_a; cq.Wp = L.c_attn.Wp; cq.bias = L.c_attn.bias; cq.MT = MT; cq.N = L.c_attn.N; cq.K = L.c_attn.Kpad;
-            cq.cpb = e->cattn_cpb; cq.h_xp = e->qkv_rows; cq.out_KS = -e->ld_qkv;
-            if (!e->skip_skinny) { prof_mark(e, PK_SKINNY, st); launch_gemm_cols(cq, st); }
-        } else {
-            skinny(e->xp_a, L.c_attn, SK_OUT_PARTIAL, wsA);
-        }
+        skinny(e->xp_a, L.c_attn, SK_OUT_PARTIAL, wsA);
         // c_fc + down projection in ONE launch (gemm.hip mlp_fused_kernel): on when the engine owns its GPU (sv_config.exclusive_device);
         // SV_EXP bit 128 forces it on, bit 512 off (in-process A/B, tools/ab_exp.py).  It recognises unwritten activations by a pattern
         // that an EARLIER launch of the layer leaves in the buffer: the attention launch (16 bytes per thread: free in a latency-bound
@@ -283,7 +273,6 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
         if (!e->only_skinny) {
             AttnDecodeArgs ad;
             attn_decode_args(e, i, B, wsA, L.c_attn.splitk, L.c_attn.bias, e->xp_attn, ad);
-            if (cattn_rows) { ad.qkv_rows = e->qkv_rows; ad.ld_qkv = e->ld_qkv; }
             if (i == c.n_layer / 2) ad.trace = e->attn_trace;             // SV_ATTN_TRACE=1: one layer in the middle of the step
             if (attn_poisons) { ad.poison = e->xp_mlp; ad.poison_bytes = (unsigned)pat_bytes; }
             prof_mark(e, PK_ATTN, st);

@@ -126,7 +126,6 @@ struct sv_engine {
                                     //    group per attention block -- all measured slower, profiles/prefetch_r03_*.log, removed)
     float *ws = nullptr, *ws2 = nullptr, *logits = nullptr, *sample_scratch = nullptr, *attn_part = nullptr;
     unsigned* attn_cnt = nullptr;
-    bf16_t* qkv_rows = nullptr; int ld_qkv = 0, cattn_cpb = 0;   // 6-launch layer: c_attn over the whole K per block -> finished bf16 q | k | v rows (decode_cols.hip row mode)
     float* am_val = nullptr; int32_t* am_idx = nullptr;
     uint32_t* seen = nullptr; int seen_words = 0;      // repetition-penalty bitmap [rows][Vpad/32]
     int32_t *cur_tok = nullptr, *next_tok = nullptr, *unfinished = nullptr, *positions = nullptr,

@@ -98,8 +98,7 @@ struct ColsArgs {
     const bf16_t* bias;              // [N] or nullptr
     int MT, N, K;                    // K multiple of 32
     int cpb;                         // output columns per block (<= 32): cols_pick_cpb(N, K)
-    bf16_t* h_xp; int out_KS;        // residual stream in fragment order, N = 16 * out_KS columns: h = bf(h + bf(x W^T + b)), in place;
-                                     // out_KS < 0 = ROW mode: h_xp is a row-major bf16 [32 * MT][-out_KS] output, out = bf(x W^T + b), no residual
+    bf16_t* h_xp; int out_KS;        // residual stream in fragment order, N = 16 * out_KS columns: h = bf(h + bf(x W^T + b)), in place
     void* poison; unsigned poison_bytes; // optional: a buffer the blocks fill with 0xFF bytes (the fused MLP launch behind this one
                                      // recognises unwritten activations by that pattern); a multiple of 16 bytes
 };
@@ -177,8 +176,6 @@ struct AttnDecodeArgs {
     const int32_t* positions;                              // [B] index of the new token (= tokens already cached)
     bf16_t* out_xp; int out_KS;                            // packed [MT][H*D/16][64][8]
     int B, H, head_dim; float scale;
-    const bf16_t* qkv_rows; int ld_qkv;                    // non-null: the new token's q | k | v as finished bf16 rows [B][ld_qkv] (whole-K c_attn,
-                                                           //   decode_cols.hip row mode) instead of `splitk` fp32 slabs in `ws`
     float* part;                                           // [B][splits][32 + 16*D] partial (m, l, O)
     unsigned* counters;                                    // [B * n_kv] arrival tickets, zero between launches
     int max_splits;                                        // cap on active context splits (#CUs / (B*n_kv), <= 16)
