@@ -144,6 +144,14 @@ def test_argument_validation_precedes_any_device_work(lib):
         lib.sv_config_default_1b(C.byref(c))
         setattr(c, field, val)
         assert lib.sv_create(C.byref(c), C.byref(h)) == -22 and msg in err(), (field, err())
+    # the measurement / A-B surfaces validate before they touch the device as well
+    assert lib.sv_debug_set_gemm_form(2) == -22 and lib.sv_debug_set_gemm_form(-2) == -22
+    assert lib.sv_debug_set_gemm_form(1) == 0 and lib.sv_debug_set_gemm_form(-1) == 0
+    buf = (C.c_int64 * 16)()
+    assert lib.sv_debug_gemm_trace(100, 256, 256, 0, 1, buf, 1) == -22            # M < one tile
+    assert lib.sv_debug_gemm_trace(256, 256, 256, 0, 2, buf, 1) == -22 and "form" in err()
+    assert lib.sv_debug_gemm_trace(512, 512, 256, 0, 1, buf, 1) == -22 and "capacity" in err()
+    assert lib.sv_debug_xcc_map(None, 8, 0, None) == -22
     if not torch.cuda.is_available():
         c = SvConfig()
         lib.sv_config_default_1b(C.byref(c))
