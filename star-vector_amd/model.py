@@ -52,7 +52,7 @@ class StarVectorConfig:
                  # sub-model configs, and the batch/sequence capacity the KV pool is sized for
                  n_inner: Optional[int] = None, n_positions: Optional[int] = None, added_tokens: Optional[int] = None,
                  vit_width: int = 1024, vit_layers: int = 23, vit_heads: int = 16, patch_size: int = 14,
-                 max_batch: int = 32, **kwargs):
+                 max_batch: int = 32, exclusive_device: Optional[bool] = None, **kwargs):
         self.starcoder_model_name = starcoder_model_name
         self.image_encoder_type = image_encoder_type
         self.adapter_norm = adapter_norm
@@ -75,6 +75,9 @@ class StarVectorConfig:
         self.added_tokens = added_tokens if added_tokens is not None else (5 if v2 else 4)
         self.vit_width, self.vit_layers, self.vit_heads, self.patch_size = vit_width, vit_layers, vit_heads, patch_size
         self.max_batch = max_batch
+        # one process per GPU and nothing else decoding on it (the deployment the engine is built for): allows the launches whose blocks
+        # wait for each other (INTEGRATION.md "Deployment knob").  None = the environment decides (SV_EXCLUSIVE_DEVICE=1), default off
+        self.exclusive_device = (os.environ.get("SV_EXCLUSIVE_DEVICE", "0") == "1") if exclusive_device is None else bool(exclusive_device)
         for k, v in kwargs.items():
             setattr(self, k, v)
 
@@ -120,7 +123,8 @@ class StarVectorConfig:
                                 # window_size=(W, W), i.e. the query sees W + 1 keys, while its eager/sdpa mask (and later releases
                                 # everywhere) show W.  `window_semantics` picks which one the engine's window (= number of visible
                                 # keys) mirrors: "flash_attention_2" (default: what the reference runs) or "sdpa".
-                                sliding_window=self._visible_keys(g("sliding_window", 4096), g("window_semantics", "flash_attention_2")))
+                                sliding_window=self._visible_keys(g("sliding_window", 4096), g("window_semantics", "flash_attention_2")),
+                                exclusive_device=bool(self.exclusive_device))
         if self.image_encoder_type != "clip":
             raise NotImplementedError(f"image_encoder_type={self.image_encoder_type!r}: v1 is built for the clip branch")
         return EngineConfig(image_size=self.image_size, patch_size=self.patch_size, vit_width=self.vit_width,
@@ -128,7 +132,7 @@ class StarVectorConfig:
                             hidden=self.hidden_size, n_layer=self.num_hidden_layers, n_head=self.num_attention_heads,
                             n_inner=self.n_inner, vocab=self.vocab_size + self.added_tokens,
                             n_positions=self.n_positions, max_batch=self.max_batch,
-                            max_seq_len=min(self.max_length, self.n_positions))
+                            max_seq_len=min(self.max_length, self.n_positions), exclusive_device=bool(self.exclusive_device))
 
 
 def config_from_checkpoint(cfg_json: Dict, shapes: Dict[str, tuple]) -> StarVectorConfig:

@@ -32,6 +32,20 @@ def test_config_maps_to_engine_shapes():
         StarVectorConfig(torch_dtype="int8").engine_config()
 
 
+def test_exclusive_device_reaches_the_engine_config(monkeypatch):
+    """The deployment knob: off by default, on by the config field or -- for callers that only change their import line --
+    by SV_EXCLUSIVE_DEVICE=1 in the environment; an explicit field wins over the environment; both model families carry it."""
+    monkeypatch.delenv("SV_EXCLUSIVE_DEVICE", raising=False)
+    assert StarVectorConfig().engine_config().exclusive_device is False
+    assert StarVectorConfig(exclusive_device=True).engine_config().exclusive_device is True
+    monkeypatch.setenv("SV_EXCLUSIVE_DEVICE", "1")
+    assert StarVectorConfig().engine_config().exclusive_device is True
+    assert StarVectorConfig(exclusive_device=False).engine_config().exclusive_device is False
+    v2 = StarVectorConfig(starcoder_model_name="bigcode/starcoder2-7b", image_encoder_type="siglip_384", hidden_size=4608,
+                          num_hidden_layers=32, num_attention_heads=36, num_kv_heads=4, n_inner=18432, added_tokens=5)
+    assert v2.engine_config().exclusive_device is True
+
+
 def test_byte_tokenizer_surface():
     tok = ByteTokenizer(49152)
     assert len(tok) == 49156 and tok.pad_token_id == 49152 and tok.eos_token_id == 0
