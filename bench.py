@@ -256,6 +256,19 @@ def main():
         torch.cuda.synchronize()
         ttfts.append((time.perf_counter() - a) * 1e3)
     ttft_p50 = statistics.median(ttfts) if ttfts else None
+    # ... and where it goes: one pass with a HIP event in front of every launch group (sv_profile_ttft).  The events open small gaps
+    # between launches, so the stages sum to a little more than the unprofiled figure above -- both are printed.
+    ttft_stages = None
+    try:
+        tp = eng.profile_ttft(None if t2s else images, prompt, iters=3)
+        ttft_stages = {k: round(tp[k], 3) for k in eng.TTFT_STAGES}
+        ttft_stages["sum_of_stages"] = round(sum(tp[k] for k in eng.TTFT_STAGES), 3)
+        ttft_stages["first_to_last_event"] = round(tp["first_to_last_event_ms"], 3)
+        ttft_stages["launch_groups"] = tp["launches"]
+        ttft_stages["note"] = ("HIP-event deltas minus the empty event-pair time (%.4f ms), one batch of %d, mean of 3 passes; gemm_remainder_rows = "
+                               "the peeled remainder-row launches of the big-M GEMMs of all towers" % (tp["event_pair_overhead_ms"], B_PER_GPU))
+    except Exception as ex:                      # a measurement extra: never the reason a bench line is missing
+        ttft_stages = {"error": f"{type(ex).__name__}: {ex}"}
 
     # dominant kernel = skinny weight-streaming GEMM (97 launches / decode step): HIP-event time per step
     prof = eng.profile_decode_step(B_PER_GPU, iters=5)
@@ -332,6 +345,7 @@ def main():
                        "hipgraph_decode": bool(graph), "exclusive_device": bool(ec.exclusive_device)},
             "tokens_per_s_per_gpu": round(value / world, 1),
             "ttft_p50_ms": round(ttft_p50, 2) if ttft_p50 is not None else None,
+            "ttft_breakdown_ms": ttft_stages,
             "decode_us_per_step": round(decode_ms / max(decode_steps, 1) * 1e3, 1),
             "roofline": {"bound": "hbm", "kernel": "decoder weight-streaming GEMMs: " + (
                              "gemm_skinny_mt2_kernel (two row tiles, up to three column tiles per block)" if B_PER_GPU > 32 else

@@ -18,8 +18,12 @@
  *                                    incl. StoppingCriteriaSub (starvector_base.py:9-20)
  *   sv_load_weight         ingests the reference state_dict keys (train/util.py:71 naming;
  *                          SURVEY.md section 8b "Weight names")
- *   sv_op_*                single-operator entry points used by the parity tests (one per row of
- *                          SURVEY.md section 8a)
+ *
+ * This header is the PRODUCT ABI: what a reference-side binding needs -- engine life cycle, weights,
+ * the forward entry points, generate, continuous batching, the beam scorer, image pre-processing.  The test / measurement surface
+ * (sv_op_* single operators, sv_debug_* plans and traces, sv_bench_*, sv_profile_*) is compiled into the same library but declared
+ * in include/starvector_hip_debug.h: nothing there is needed to run the path, and three of its switches change which kernels a live
+ * engine launches (A/B measurements only).
  *
  * Conventions: every pointer named dev_* / documented "device" is a HIP device pointer owned by the
  * caller (PyTorch-ROCm tensor.data_ptr()); `stream` is a hipStream_t passed as void* (0 = default
@@ -207,69 +211,6 @@ int  sv_preprocess_images(const uint8_t* const* dev_pixels, const int32_t* width
                           const int32_t* channels, int32_t n, int32_t out_size, int32_t recipe, const float* mean3,
                           const float* std3, float* dev_out, void* dev_workspace, int64_t workspace_bytes, sv_stream stream);
 
-/* Host-side decisions of the library, callable WITHOUT a GPU (the CPU test suite pins them):
- *   sv_debug_resample_coeffs  the fixed-point table sv_preprocess_image feeds its two passes = Pillow's
- *                             precompute_coeffs + normalize_coeffs_8bpc (libImaging/Resample.c) for BICUBIC, box (0, in_size):
- *                             bounds [out_size][2] = (first input index, tap count), taps [out_size][cap]; returns ksize
- *                             (> 0) or SV_EINVAL when cap < ksize
- *   sv_debug_gemm_plan        what the big-M GEMM dispatch does with an M x N x K problem: out5 = {peel the row remainder,
- *                             remainder rows, remainder as a 128^2 tile row (else one wave per 32x32 tile), main part on the
- *                             256^2 kernel, modelled time in us}; every choice computes the same bits */
-/*   sv_debug_skinny_plan      how a decode GEMM (rows <= 64, W [N][K], split-K `splitk`, bf16 or fp8 weights) is launched:
- *                             out2 = {waves per block = how K is cut inside a block, i.e. the order in which a row's partial
- *                             sums are added -- a function of the GEMM only, never of `rows`; 1 when a block carries two
- *                             32-row tiles (33..64 rows: the weights are streamed once)} */
-int  sv_debug_resample_coeffs(int32_t in_size, int32_t out_size, int32_t* bounds, int32_t* taps, int32_t cap);
-int  sv_debug_skinny_plan(int32_t rows, int32_t N, int32_t K, int32_t splitk, int32_t fp8, int32_t* out2);
-/*   sv_debug_set_exp          the experiment bit mask of a live engine (what the environment variable SV_EXP sets at sv_create):
- *                             in-process A/B runs of the round's experiments (tools/ab_exp.py) */
-int  sv_debug_set_exp(sv_engine* e, int32_t mask);
-int  sv_debug_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t act, int32_t* out5);
-/*   sv_debug_decode_plan      what sv_create decides for a decoder Linear W [N][K] when the engine decodes `rows` (<= 64) rows at a
- *                             time on a GPU with `num_cus` CUs: out2 = {split-K factor (1 when whole_k: c_fc / lm_head keep the whole
- *                             K for their epilogue), column tiles per block of the two-row-tile kernel (1 for rows <= 32)} -- plain
- *                             host arithmetic (engine_core.hip: pick_splitk / pick_decode_plan), pinned by the CPU tests */
-int  sv_debug_decode_plan(int32_t rows, int32_t N, int32_t K, int32_t fp8, int32_t whole_k, int32_t num_cus, int32_t* out2);
-/*   sv_debug_attn_plan        the decode attention's context-split constants of an engine: out2 = {the most blocks a sequence's context
- *                             is split over (so that rows x KV heads x splits covers the CUs, <= 8), 32-key groups a block takes
- *                             before another split joins (8 where rows x KV heads alone cover the CUs, else 4)} -- functions of the
- *                             engine's max_batch / KV heads only, never of the call's batch (a row's bits do not depend on its batch) */
-int  sv_debug_attn_plan(int32_t max_batch, int32_t n_kv_head, int32_t num_cus, int32_t* out2);
-/*   sv_debug_set_col_tiles    column tiles per block (1..3; 0 = the launcher's own choice) the OP-LEVEL decode GEMM entry points
- *                             (sv_op_linear_skinny*, 33..64 rows) launch with from now on, process-wide: lets the parity tests put
- *                             every variant of the two-row-tile kernel next to the one-tile kernels (all bit-identical).  An engine's
- *                             decode loop is not affected (it carries its own plan per Linear). */
-int  sv_debug_set_col_tiles(int32_t col_tiles);
-/*   sv_debug_set_gemm_form    process-wide: every big-M GEMM launch takes ONE form -- 0 = 128x128 tiles, 1 = 256x256 tiles (rows not peeled);
-     -1 = the tuned choice (default).  The forms give the same bits; the tests compare them through this switch. */
-int  sv_debug_set_gemm_form(int32_t form);
-/* The decode attention (gpt_bigcode/modeling_gpt_bigcode.py:151-285, llm/starcoder2.py:22-27 sliding window) on
- * its own, over the engine's real paged KV pool, block table and context-split plan.  Test surface: the caller chooses q / K / V.
- *   sv_debug_kv_load     dev_kv bf16 [B][S][2*n_kv*head_dim] (k heads | v heads, K as cached = after RoPE) -> pages of `layer`;
- *                        positions[b] = S for every row, or dev_lens[b] (int32 [B], <= S; NULL = S): a ragged batch
- *   sv_debug_attn_decode dev_qkv_f32 fp32 [B][n_head*head_dim + 2*n_kv*head_dim] (the new token's c_attn output, before RoPE) ->
- *                        dev_out bf16 [B][n_head*head_dim]; appends the new K/V row at positions[b]; advance != 0: positions += 1 */
-/*   sv_debug_mlp_trace   (engine created with SV_MLP_TRACE=1) 100 MHz wall-clock stamps of the fused MLP launch (SV_EXP bit 128) of the
- *                        middle layer of the last decode step: host_out [blocks][8] = {start, c_fc loop done, tile published, slice
- *                        complete, end, XCC id, 0, 0}; returns the block count or a negative error code */
-/*   sv_debug_attn_trace  (engine created with SV_ATTN_TRACE=1) the same for the decode attention launch of the middle layer: host_out
- *                        [rows * kv heads * context splits][16] = {start, first KV group requested, q in LDS, key groups processed,
- *                        partial stored + drained, ticket drawn, end (0 unless the merging block), active splits, key groups, 0...} */
-int  sv_debug_attn_trace(sv_engine* e, int64_t* host_out, int32_t capacity_rows);
-int  sv_debug_mlp_trace(sv_engine* e, int64_t* host_out, int32_t capacity_blocks);
-/*   sv_debug_xcc_map     the XCD (XCC_ID) each block of a 1-D launch of `blocks` 8-wave blocks ran on, into host_out[blocks]; heavy = 1 gives
-     the blocks the decode attention's LDS footprint and 10 us of residence (a grid above the CU count then runs in rounds, like a 64-row
-     attention launch).  Evidence for the XCD-aware block -> tile mappings (block L runs on XCD (L + c) % 8): DESIGN.md sections 3c / 3f. */
-int  sv_debug_xcc_map(sv_engine* e, int32_t blocks, int32_t heavy, int32_t* host_out);
-/*   sv_debug_gemm_trace  the 256x256 big-M GEMM kernel (prefill / ViT) on random operands of the given shape, one launch with wall-clock
-     stamps (form = 1): host_out [blocks * 2][8] = {start, K-tile 0 staged, K loop done, epilogue stored, tile m, tile n, wave, 0}
-     (tools/gemm_trace.py).  Needs no engine.  Returns the number of blocks. */
-int  sv_debug_gemm_trace(int32_t M, int32_t N, int32_t K, int32_t act, int32_t form, int64_t* host_out, int32_t capacity_blocks);
-int  sv_debug_kv_load(sv_engine* e, int32_t layer, const void* dev_kv, int32_t B, int32_t S, const int32_t* dev_lens,
-                      sv_stream stream);
-int  sv_debug_attn_decode(sv_engine* e, int32_t layer, const float* dev_qkv_f32, int32_t B, void* dev_out, int32_t advance,
-                          sv_stream stream);
-
 /* Prompt pass over inputs_embeds [B,S0,hidden] bf16 (all-ones attention mask): fills the paged KV
  * cache and writes the last-row logits [B, vocab] fp32 (bf16-rounded values, as the reference's
  * bf16 lm_head produces). */
@@ -342,59 +283,6 @@ int  sv_beam_history(sv_engine* e, int32_t* host_parent, int32_t* host_tok, int3
 /* host wall-clock of the last sv_generate, 4 doubles: [0] ms prefill + first token (TTFT),
  * [1] ms decode loop, [2] decode steps enqueued, [3] 1 if the step ran as a hipGraph replay */
 int  sv_last_timing(sv_engine* e, double* out4);
-/* HIP-event timing of one decode step by kernel class, on the cache state left by the last
- * sv_generate / sv_prefill (bench.py roofline leg).  out: 10 doubles, [2k] = ms per step in class k
- * (event deltas minus the empty event-pair time), [2k+1] = launches per step; k = 0 skinny
- * weight-streaming GEMM, 1 paged decode attention, 2 residual+LayerNorm row update;
- * [6] = ms between two back-to-back events with no kernel; [7] = ms per step of the step's GEMM launches
- * enqueued back to back between ONE event pair (dispatch-to-dispatch); [8] = the same for every OTHER kernel
- * of the step (no GEMMs): step - [8] = what the GEMMs cost in situ; [9] reserved. */
-int  sv_profile_decode_step(sv_engine* e, int32_t B, int32_t iters, double* out10, sv_stream stream);
-
-/* ---- single operators (parity tests; all device pointers, bf16 unless noted) ------------------ */
-int  sv_op_layernorm(const void* x, const void* gamma, const void* beta, void* y, int32_t M, int32_t D,
-                     float eps, sv_stream stream);
-/* y[M,N] = act(x[M,K] . W[N,K]^T + bias) (+ residual); W/bias/residual reference layouts */
-int  sv_op_linear(const void* x, const void* W, const void* bias, const void* residual, void* y,
-                  int32_t M, int32_t N, int32_t K, int32_t act, int32_t out_f32, sv_stream stream);
-/* the decode-path (M<=32 per tile, weight-streaming) implementation of the same contraction */
-int  sv_op_linear_skinny(const void* x, const void* W, const void* bias, void* y_f32, int32_t M, int32_t N,
-                         int32_t K, int32_t splitk, sv_stream stream);
-/* the same contraction with the weight quantised to fp8 e4m3 (one scale per output row, as weight_dtype = SV_WEIGHT_FP8_E4M3
- * does at load): y = x . dequant(quant(W))^T + bias, fp32; scale_out [N] (device, optional) receives the row scales */
-int  sv_op_linear_skinny_fp8(const void* x, const void* W, const void* bias, void* y_f32, float* scale_out, int32_t M,
-                             int32_t N, int32_t K, int32_t splitk, sv_stream stream);
-/* the decode GEMM's fused epilogues on their own (split-K 1): out_f32 == 0: y[M,N] = act(bf16(x W^T + bias)) as bf16 rows
- * (the c_fc form, N %% 8 == 0); out_f32 != 0: float32 rows of x W^T holding bf16-rounded values, bias ignored (the lm_head form) */
-int  sv_op_linear_skinny_epi(const void* x, const void* W, const void* bias, void* y, int32_t M, int32_t N, int32_t K,
-                             int32_t act, int32_t out_f32, sv_stream stream);
-/* the two kernels of the 6-launch decode layer (csrc/decode_cols.hip; gpt_bigcode/modeling_gpt_bigcode.py:694-755) as one op, M <= 32:
- *   h2 = bf16(h + bf16(x[M,Kp] . Wp[D,Kp]^T + bp))                      attention output projection, whole K per block, in place
- *   y  = act(bf16(LayerNorm(h2; gamma, beta, eps) . Wf[F,D]^T + bf))    c_fc on the raw h2, ln_2 folded into weights / epilogue */
-int  sv_op_decode_proj_fold(const void* x, const void* Wp, const void* bp, const void* h, const void* gamma, const void* beta, float eps,
-                            const void* Wf, const void* bf, void* h2_out, void* y_out, int32_t M, int32_t D, int32_t Kp, int32_t F,
-                            int32_t act, sv_stream stream);
-/* micro-benchmark of the big-M MFMA GEMM alone (pseudo-random operands): average microseconds per launch */
-int  sv_bench_linear(int32_t M, int32_t N, int32_t K, int32_t act, int32_t residual, int32_t iters, double* avg_us,
-                     sv_stream stream);
-/* micro-benchmark of the decode GEMM kernel alone: average microseconds per launch over `iters` back-to-back launches (HIP
- * events); mode = 0 fp32 slabs (split-K `splitk`), 1 bias + GELU -> fragment order, 2 fp32 logits (modes 1, 2: splitk == 1) */
-int  sv_bench_decode_linear(int32_t M, int32_t N, int32_t K, int32_t splitk, int32_t mode, int32_t iters, double* avg_us,
-                            sv_stream stream);
-/* f32 -> bf16 through the hardware convert used inside the kernels (rounding-mode check) */
-int  sv_op_cvt_bf16_hw(const float* x, void* y, int64_t n, sv_stream stream);
-/* q,k,v token-major [B,S,H*D] / [B,S,Hkv*D]; out [B,S,H*D] */
-int  sv_op_attention(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t S,
-                     int32_t H, int32_t Hkv, int32_t head_dim, int32_t causal, float scale,
-                     sv_stream stream);
-int  sv_op_plane_layernorm(const void* x, const void* gamma, const void* beta, void* y, int32_t B,
-                           int32_t QD, float eps, sv_stream stream);
-int  sv_op_argmax(const float* logits, int32_t B, int32_t V, int32_t ld, int32_t* out, sv_stream stream);
-int  sv_op_sample_top_p(const float* logits, int32_t B, int32_t V, int32_t ld, float temperature,
-                        float top_p, uint64_t seed, int32_t step, int32_t* out, sv_stream stream);
-/* temperature -> top-k (0 = off) -> top-p -> one multinomial draw per row */
-int  sv_op_sample(const float* logits, int32_t B, int32_t V, int32_t ld, float temperature, int32_t top_k,
-                  float top_p, uint64_t seed, int32_t step, int32_t* out, sv_stream stream);
 
 #ifdef __cplusplus
 }

@@ -3,6 +3,14 @@
 The directory is named ``star-vector_amd`` (repo convention); import it as ``starvector_amd`` (the
 sibling shim package maps the importable name onto this directory).
 """
+import os as _os
+
+# Multi-process GPU work (generate_im2svg_dp: one process per GPU, RCCL all-gather) needs dmabuf IPC on hosts whose driver has no
+# legacy IPC -- without this RCCL's hipIpcGetMemHandle fails with "invalid argument".  The HSA runtime reads the variable ONCE, when
+# torch first initialises HIP, so it is set at import time (a setdefault: an explicit value from the launcher wins); if HIP is already
+# up in this process the variable must come from the launcher's environment instead (INTEGRATION.md section 3).
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 from ._lib import StarVectorHipError, LIB_PATH, HEADER_PATH  # noqa: F401
 from .engine import EngineConfig, HipEngine  # noqa: F401
 from .model import (  # noqa: F401

@@ -1,4 +1,5 @@
-"""ctypes binding of libstarvector_hip.so (include/starvector_hip.h).
+"""ctypes binding of libstarvector_hip.so (include/starvector_hip.h: the product ABI; include/starvector_hip_debug.h: the test and
+measurement surface of the same library).
 
 The product path has NO fallback: if the HIP library is missing or fails to load this module raises,
 and every public entry point of the package goes through it.
@@ -11,6 +12,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libstarvector_hip.so")
 HEADER_PATH = os.path.normpath(os.path.join(HERE, "..", "include", "starvector_hip.h"))
+DEBUG_HEADER_PATH = os.path.normpath(os.path.join(HERE, "..", "include", "starvector_hip_debug.h"))
 
 ABI_VERSION = 7
 SV_DTYPE_BF16, SV_DTYPE_F32 = 0, 1
@@ -70,7 +72,7 @@ _I = C.c_int32
 _F = C.c_float
 
 # name -> (restype, argtypes): exactly the prototypes of include/starvector_hip.h
-PROTOTYPES = {
+PRODUCT_PROTOTYPES = {
     "sv_abi_version": (_I, []),
     "sv_last_error": (C.c_char_p, []),
     "sv_config_default_1b": (None, [C.POINTER(SvConfig)]),
@@ -90,9 +92,6 @@ PROTOTYPES = {
     "sv_preprocess_workspace_bytes": (C.c_int64, [C.POINTER(_I), C.POINTER(_I), _I, _I, _I]),
     "sv_preprocess_images": (_I, [C.POINTER(_P), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), _I, _I, _I, C.POINTER(_F),
                                   C.POINTER(_F), _P, _P, C.c_int64, _P]),
-    "sv_debug_resample_coeffs": (_I, [_I, _I, C.POINTER(_I), C.POINTER(_I), _I]),
-    "sv_debug_gemm_plan": (_I, [_I, _I, _I, _I, C.POINTER(_I)]),
-    "sv_debug_skinny_plan": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),
     "sv_prefill": (_I, [_P, _P, _I, _I, _P, _P]),
     "sv_forward_logits": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "sv_decode_step": (_I, [_P, _P, _I, _P, _P]),
@@ -109,6 +108,13 @@ PROTOTYPES = {
     "sv_beam_finalize": (_I, [_P, C.POINTER(C.c_int64), C.POINTER(_I), C.POINTER(_F), _P]),
     "sv_beam_history": (_I, [_P, C.POINTER(_I), C.POINTER(_I), _I, C.POINTER(_I), C.POINTER(_I)]),
     "sv_last_timing": (_I, [_P, C.POINTER(C.c_double)]),
+}
+
+# the test / measurement surface: include/starvector_hip_debug.h (same library)
+DEBUG_PROTOTYPES = {
+    "sv_debug_resample_coeffs": (_I, [_I, _I, C.POINTER(_I), C.POINTER(_I), _I]),
+    "sv_debug_gemm_plan": (_I, [_I, _I, _I, _I, C.POINTER(_I)]),
+    "sv_debug_skinny_plan": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),
     "sv_debug_set_exp": (_I, [_P, _I]),
     "sv_debug_set_col_tiles": (_I, [_I]),
     "sv_debug_set_gemm_form": (_I, [_I]),
@@ -121,6 +127,7 @@ PROTOTYPES = {
     "sv_debug_attn_decode": (_I, [_P, _I, _P, _I, _P, _I, _P]),
     "sv_debug_decode_plan": (_I, [_I, _I, _I, _I, _I, _I, C.POINTER(_I)]),
     "sv_profile_decode_step": (_I, [_P, _I, _I, C.POINTER(C.c_double), _P]),
+    "sv_profile_ttft": (_I, [_P, _P, _I, _P, _I, _I, C.POINTER(C.c_double), _P]),
     "sv_op_layernorm": (_I, [_P, _P, _P, _P, _I, _I, _F, _P]),
     "sv_op_linear": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sv_op_linear_skinny": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -136,6 +143,8 @@ PROTOTYPES = {
     "sv_op_sample_top_p": (_I, [_P, _I, _I, _I, _F, _F, C.c_uint64, _I, _P, _P]),
     "sv_op_sample": (_I, [_P, _I, _I, _I, _F, _I, _F, C.c_uint64, _I, _P, _P]),
 }
+
+PROTOTYPES = {**PRODUCT_PROTOTYPES, **DEBUG_PROTOTYPES}
 
 _lib = None
 

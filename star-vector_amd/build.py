@@ -13,7 +13,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libstarvector_hip.so")
 SOURCES = ["gemm.hip", "decode_cols.hip", "rowops.hip", "attention.hip", "sampling.hip", "beam.hip", "preprocess.hip", "engine_core.hip", "engine_forward.hip", "engine_generate.hip", "engine_cb.hip", "engine_ops.hip"]
-HEADERS = ["common.h", "kernels.h", "beam.h", "warp.h", "engine_internal.h", os.path.join("..", "..", "include", "starvector_hip.h")]
+HEADERS = ["common.h", "kernels.h", "beam.h", "warp.h", "engine_internal.h", os.path.join("..", "..", "include", "starvector_hip.h"),
+           os.path.join("..", "..", "include", "starvector_hip_debug.h")]
 # -amdgpu-kernarg-preload-count: leading scalar / pointer kernel parameters arrive in SGPRs with the dispatch (gfx950) instead
 # of through a scalar load at the top of every kernel (the decode step is 172 dependent launches)
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"] + os.environ.get("SV_HIPCC_FLAGS", "").split()

@@ -645,11 +645,13 @@ static std::vector<std::pair<std::string, const Slot*>> sorted_slots(const sv_en
 }
 extern "C" int sv_weight_count(sv_engine* e) {
     if (!e) return fail(SV_EINVAL, "null engine");
+    std::lock_guard<std::mutex> lk(e->mu);
     return (int)e->slots.size();
 }
 extern "C" int sv_weight_info(sv_engine* e, int32_t index, char* name, int32_t name_cap, int64_t* numel, int32_t* required,
                               int32_t* loaded) {
     if (!e || !name || name_cap < 2 || !numel) return fail(SV_EINVAL, "sv_weight_info: bad argument");
+    std::lock_guard<std::mutex> lk(e->mu);          // sv_load_weight flips `loaded` under the same mutex
     const auto v = sorted_slots(e);
     if (index < 0 || index >= (int)v.size()) return fail(SV_EINVAL, "sv_weight_info: index %d out of range (0..%zu)", index, v.size());
     const std::string& n = v[index].first;
@@ -663,8 +665,11 @@ extern "C" int sv_weight_info(sv_engine* e, int32_t index, char* name, int32_t n
 
 extern "C" int sv_weights_complete(sv_engine* e) {
     if (!e) return fail(SV_EINVAL, "null engine");
-    for (auto& kv : e->slots)
-        if (kv.second.required && !kv.second.loaded) return fail(SV_ENOENT, "missing weight '%s'", kv.first.c_str());
+    {
+        std::lock_guard<std::mutex> lk(e->mu);      // (every caller checks readiness BEFORE it takes the engine mutex)
+        for (auto& kv : e->slots)
+            if (kv.second.required && !kv.second.loaded) return fail(SV_ENOENT, "missing weight '%s'", kv.first.c_str());
+    }
     if (e->fold6 && !e->fold_ready) {
         // every tensor is in: build the LayerNorm-folded c_fc images (W' = bf16(W * gamma_2), c1, c2) once
         std::lock_guard<std::mutex> lk(e->mu);

@@ -68,6 +68,7 @@ static int generate_beam(sv_engine* e, const void* dev_embeds, int B, int S0, co
     if (need > e->pages_per_seq) return fail(SV_EINVAL, "sequence length %d exceeds max_seq_len %d", S0 + max_new, c.max_seq_len);
 
     auto t0 = std::chrono::steady_clock::now();
+    HIPCHECK(hipMemsetAsync(e->d_bad, 0, sizeof(int32_t), st));         // a flag left by an earlier, failed call is not this call's
     BeamConfig bc;
     bc.B = B; bc.nb = nb; bc.V = c.vocab; bc.max_new = max_new; bc.eos = sp->eos_token_id; bc.pad = sp->pad_token_id;
     bc.early = sp->early_stopping; bc.length_penalty = sp->length_penalty;
@@ -149,6 +150,9 @@ static int generate_beam(sv_engine* e, const void* dev_embeds, int B, int S0, co
     const double gexec_used = gexec ? 1.0 : 0.0;
     if (gexec) (void)hipGraphExecDestroy(gexec);
     if (graph) (void)hipGraphDestroy(graph);
+    // the decode steps of a beam search run the fused MLP launch too: its give-up code must not come back as rc 0 with hypotheses
+    // built from void logits
+    SVCHECK(check_finite_logits(e, st, "sv_generate (beam search)"));
     if (!e->h_flags[0]) return fail(SV_EHIP, "beam search did not terminate within its budget");
     std::vector<int64_t> toks;
     std::vector<float> scores;
@@ -181,7 +185,8 @@ int sveng::check_finite_logits(sv_engine* e, hipStream_t st, const char* who) {
     HIPCHECK(hipStreamSynchronize(st));
     if (what == 3)
         return fail(SV_EHIP, "%s: a block of the fused MLP launch gave up waiting for its producers (its blocks were not all resident at "
-                             "once?); the tokens of this call are void -- run without SV_EXP bit 128", who);
+                             "once?  another process or engine on this GPU?); the tokens of this call are void -- create the engine with "
+                             "exclusive_device = 0 (SV_EXP bit 512) there", who);
     return fail(SV_EHIP, "%s: a row of logits had no finite value (NaN / Inf in the weights or inputs?)", who);
 }
 
@@ -210,6 +215,7 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
     }
 
     auto t0 = std::chrono::steady_clock::now();
+    HIPCHECK(hipMemsetAsync(e->d_bad, 0, sizeof(int32_t), st));         // a flag left by an earlier, failed call is not this call's
     SVCHECK(prefill_locked(e, dev_embeds, B, S0, S0 + max_new, st));
     // generation state
     fill_i32(e->positions, S0 - 1, B, st);     // finish_step adds 1

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../include/starvector_hip.h"
+#include "../../include/starvector_hip_debug.h"
 #include "kernels.h"
 #include "beam.h"
 
@@ -145,6 +146,7 @@ struct sv_engine {
     bf16_t* score_ws = nullptr;      // scoring forward: kept hidden rows, their ln_f, bf16 logits [rows][Vpad]
     size_t score_elems = 0;
     int cached_B = 0;
+    int dbg_pos_hi = 0;             // sv_debug_kv_load / sv_debug_attn_decode: upper bound of positions[] (host side), kept below max_seq_len
     int num_cus = 256;
     double timing[3] = {0, 0, 0};
     double timing_graph = 0;
@@ -171,7 +173,10 @@ struct sv_engine {
     size_t prof_used = 0;
 };
 
-enum { PK_SKINNY = 0, PK_ATTN = 1, PK_ROWLN = 2, PK_SAMPLE = 3, PK_COUNT = 4 };
+enum { PK_SKINNY = 0, PK_ATTN = 1, PK_ROWLN = 2, PK_SAMPLE = 3, PK_COUNT = 4,
+       // stages of the time to first token (sv_profile_ttft): never marked by decode_forward
+       PK_VIT_GEMM = 4, PK_VIT_ATTN, PK_VIT_ROWS, PK_AD_GEMM, PK_AD_NORM, PK_PF_GEMM, PK_GEMM_TAIL, PK_PF_ATTN, PK_PF_ROWS, PK_PF_LMHEAD,
+       PK_FIRST_SAMPLE, PK_END, PK_TTFT_FIRST = PK_VIT_GEMM, PK_TTFT_COUNT = PK_END - PK_VIT_GEMM };
 
 namespace sveng {
 // engine_core.hip: small utility kernels behind host wrappers, allocation, decode planning

@@ -85,6 +85,7 @@ extern "C" int sv_debug_kv_load(sv_engine* e, int32_t layer, const void* dev_kv,
     if (dev_lens) HIPCHECK(hipMemcpyAsync(e->positions, dev_lens, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     else fill_i32(e->positions, S, B, st);
     e->cached_B = B;
+    e->dbg_pos_hi = S;                          // dev_lens[b] <= S by contract
     HIPCHECK(hipGetLastError());
     return 0;
 }
@@ -101,6 +102,10 @@ extern "C" int sv_debug_attn_decode(sv_engine* e, int32_t layer, const float* de
     std::lock_guard<std::mutex> lk(e->mu);
     SVCHECK(cb_guard(e, "sv_debug_attn_decode"));
     if (B != e->cached_B) return fail(SV_ESTATE, "sv_debug_attn_decode: B=%d but the cache holds %d sequences", B, e->cached_B);
+    // the kernel appends the new K/V row at positions[b] and indexes the block table with it: repeated advancing calls must not walk
+    // past the sequence's allocation
+    if (e->dbg_pos_hi >= c.max_seq_len)
+        return fail(SV_EINVAL, "sv_debug_attn_decode: position %d would reach max_seq_len %d", e->dbg_pos_hi, c.max_seq_len);
     HIPCHECK(hipSetDevice(c.device));
     hipStream_t st = (hipStream_t)stream;
     TmpBufs tmp;
@@ -113,7 +118,7 @@ extern "C" int sv_debug_attn_decode(sv_engine* e, int32_t layer, const float* de
     attn_decode_args(e, layer, B, e->ws, 1, zero_bias, e->xp_attn, ad);
     launch_attn_decode(ad, st);
     unpack_rows(e->xp_attn, (bf16_t*)dev_out, c.n_head * e->dh, B, c.n_head * e->dh, st);
-    if (advance) add_i32(e->positions, 1, B, st);
+    if (advance) { add_i32(e->positions, 1, B, st); e->dbg_pos_hi += 1; }
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(st));          // `zero_bias` is freed on return
     return 0;

@@ -882,6 +882,7 @@ static void launch_gemm_config(const GemmArgs& a, hipStream_t st, int kernel256,
         t.R = a.R ? a.R + (size_t)main_rows * a.ldr : nullptr;
         t.C = a.out_f32 ? (void*)((float*)a.C + (size_t)main_rows * a.ldc) : (void*)((bf16_t*)a.C + (size_t)main_rows * a.ldc);
         t.M = tail;
+        if (a.tail_mark) a.tail_mark(a.tail_ctx, st);
         if (tail_by_tiles) tiles(t, true);
         else gemm_tail_kernel<<<dim3((a.N + 31) / 32, (tail + 31) / 32), 64, 0, st>>>(t);
         return;
@@ -926,6 +927,7 @@ static int autotune_gemm(const GemmArgs& a, hipStream_t st, const GemmPlan& mode
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return fallback;
     GemmArgs t = a;
     t.C = scratch;
+    t.tail_mark = nullptr;                       // the timing runs are not part of anybody's profile
     const int tail = a.M % 256, main_rows = a.M - tail;
     const bool can_peel = tail > 0 && tail <= 96 && main_rows >= 2048;
     const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
@@ -988,6 +990,7 @@ void launch_gemm(const GemmArgs& a0, hipStream_t st) {
         t.R = a.R ? a.R + (size_t)main_rows * a.ldr : nullptr;
         t.C = a.out_f32 ? (void*)((float*)a.C + (size_t)main_rows * a.ldc) : (void*)((bf16_t*)a.C + (size_t)main_rows * a.ldc);
         t.M = tail;
+        if (a.tail_mark) a.tail_mark(a.tail_ctx, st);
         if (tail_by_tiles) launch_gemm_tiles(t, st, true);
         else gemm_tail_kernel<<<dim3((a.N + 31) / 32, (tail + 31) / 32), 64, 0, st>>>(t);
         return;
@@ -1465,7 +1468,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int u = 0; u < KPW; ++u) x2[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, (ks2 + u) * 1024 + lane * 16, 0, 16);   // sc1: L1 bypass
     unsigned pending = 0xffffu;                              // k-steps whose activations are not (known to be) complete: wave-uniform
     int gave_up = 1;
-    for (int it = 0; it < p.spin_limit; ++it) {
+    // Bounded by WALL CLOCK, not by a poll count (65536 polls of ~2 us each per wave, per layer, per step turned a
+    // co-residency failure into minutes before the host saw it): a wave gives up after spin_ticks (5 ms) -- and at once when another
+    // wave or an earlier launch has already raised the flag (every later layer of a void step then falls through without waiting).
+    for (int it = 0;; ++it) {
         unsigned still = 0u;
 #pragma unroll
         for (int u = 0; u < KPW; ++u) {
@@ -1476,6 +1482,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         pending = still;
         if (!pending) { gave_up = 0; break; }
+        if ((it & 7) == 7 && (wall_clock64() - t_pub > (long long)p.spin_ticks ||
+                              __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) break;
         __builtin_amdgcn_s_sleep(8);
 #pragma unroll
         for (int u = 0; u < KPW; ++u)

@@ -32,6 +32,8 @@ struct GemmArgs {
     int act; int out_f32;
     const float* cscale = nullptr;   // fp8 weights: per-output-column scale applied to the accumulator (or nullptr)
     long long* trace = nullptr;      // optional [blocks][8] wall-clock stamps of the 256^2 kernel (tools/gemm_trace.py); nullptr in production
+    void (*tail_mark)(void* ctx, hipStream_t st) = nullptr;   // profiling hook: called right before the remainder-row launch of a peeled GEMM
+    void* tail_ctx = nullptr;        //   (sv_profile_ttft prices the tails apart from the tile launches); nullptr in production
 };
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 // one fixed configuration (kernel256: 0 = 128^2 tiles, 1 = 256^2; peel: the row remainder over a multiple of 256 in its own launch), no tuning
@@ -86,7 +88,8 @@ struct MlpFusedArgs {
     int splitk;                              // K slices of the down projection = fp32 slabs
     float* ws; int ldws; int rows_ws;        // slabs [splitk][rows_ws][ldws]
     int* err;                                // set to 3 when a block gives up waiting (never a hang)
-    int spin_limit;                          // polls before giving up
+    int spin_ticks;                          // wall-clock budget of a wave's wait in 100 MHz ticks (s_memrealtime): on expiry -- or when
+                                             // *err is already set by another wave / launch -- the wave gives up (code 3)
     long long* trace;                        // optional [N1pad / 32][8] wall-clock stamps per block (tools/mlp_trace.py); nullptr in production
 };
 int launch_mlp_fused(const MlpFusedArgs& a, hipStream_t st);

@@ -381,7 +381,7 @@ __global__ void finish_step_kernel(FinishArgs p) {
         }
         if (unf && (unsigned)nxt >= (unsigned)p.V) {     // no finite logit in this row: never index the embedding table with it
             nxt = 0;
-            if (p.bad) *p.bad = 1;
+            if (p.bad) atomicCAS(p.bad, 0, 1);          // 0 -> 1 only: a code already there (3 = the fused MLP launch gave up) survives
         }
         const int tok = unf ? nxt : p.pad;
         p.out_tokens[(size_t)b * p.ld_out + t] = tok;
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(SP_THREADS) void cb_step_kernel(CbStepArgs p) {
     if (tid != 0) return;
     if ((unsigned)tok >= (unsigned)p.V) {               // no finite logit: never index the embedding table with the sentinel
         tok = 0;
-        if (p.bad) *p.bad = 1;
+        if (p.bad) atomicCAS(p.bad, 0, 1);              // 0 -> 1 only (see finish_step_kernel)
     }
     const int t = sl.step;
     int32_t* out = p.out_tokens + (size_t)s * p.ld_out;

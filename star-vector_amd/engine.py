@@ -402,6 +402,24 @@ class HipEngine:
         res["others_chain_ms_per_step"] = buf[8]
         return res
 
+    TTFT_STAGES = ("encoder_gemm", "encoder_attention", "encoder_rows", "adapter_gemm", "adapter_norm_and_token_gather",
+                   "prefill_gemm", "gemm_remainder_rows", "prefill_attention", "prefill_rows", "lm_head", "first_token_select")
+
+    def profile_ttft(self, image: Optional[torch.Tensor], prompt_ids: torch.Tensor, iters: int = 3) -> Dict[str, float]:
+        """Where the time to first token goes (include/starvector_hip_debug.h, sv_profile_ttft): ms per stage of ONE pass
+        image -> encoder -> adapter -> prompt rows -> prompt pass -> lm_head -> first greedy token, HIP events in front of every
+        launch group.  image: bf16 [B,3,S,S] or None (text2svg); prompt_ids: int64 [B, P]."""
+        ids = _need(prompt_ids, torch.int64, "prompt_ids")
+        B, P = ids.shape
+        img = _need(image, torch.bfloat16, "image") if image is not None else None
+        buf = (C.c_double * 24)()
+        check(self.lib.sv_profile_ttft(self._h, _ptr(img), B, _ptr(ids), P, int(iters), buf, _stream()), "sv_profile_ttft")
+        res = {n: buf[2 * i] for i, n in enumerate(self.TTFT_STAGES)}
+        res["launches"] = {n: int(round(buf[2 * i + 1])) for i, n in enumerate(self.TTFT_STAGES)}
+        res["event_pair_overhead_ms"] = buf[22]
+        res["first_to_last_event_ms"] = buf[23]
+        return res
+
 
 def token_callback(on_tokens):
     """Wrap ``on_tokens(tokens [B, n] int64 cpu, first_col)`` as an `sv_token_callback`.  An exception cannot unwind through

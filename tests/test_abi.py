@@ -17,36 +17,60 @@ def lib():
     return _lib.load()
 
 
-def _declared_functions():
-    text = open(os.path.join(ROOT, "include", "starvector_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(sv_[a-z0-9_]+)\s*\(", text)))
+HEADERS = ("starvector_hip.h", "starvector_hip_debug.h")          # product ABI | test and measurement surface
+
+
+def _header_text(name):
+    text = open(os.path.join(ROOT, "include", name)).read()
+    return re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+
+def _declared_functions(name):
+    return sorted(set(re.findall(r"\b(sv_[a-z0-9_]+)\s*\(", _header_text(name))))
 
 
 def test_header_symbols_exported(lib):
-    names = _declared_functions()
-    assert len(names) >= 20
-    for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/starvector_hip.h but not exported"
+    for h in HEADERS:
+        names = _declared_functions(h)
+        assert len(names) >= 20
+        for n in names:
+            assert hasattr(lib, n), f"{n} declared in include/{h} but not exported"
 
 
 def test_binding_matches_header(lib):
     from starvector_amd import _lib
-    assert sorted(_lib.PROTOTYPES) == _declared_functions()
+    assert sorted(_lib.PRODUCT_PROTOTYPES) == _declared_functions("starvector_hip.h")
+    assert sorted(_lib.DEBUG_PROTOTYPES) == _declared_functions("starvector_hip_debug.h")
+
+
+def test_product_header_carries_no_test_surface():
+    """the product header is what a reference-side binding binds (SURVEY.md 8b's export list + continuous
+    batching, the beam scorer, pre-processing); plans, traces, micro-benchmarks, single operators and the A/B switches live in
+    the debug header, which includes the product one."""
+    prod = _declared_functions("starvector_hip.h")
+    assert not [n for n in prod if n.startswith(("sv_debug_", "sv_op_", "sv_bench_", "sv_profile_"))], prod
+    for need in ("sv_create", "sv_destroy", "sv_load_weight", "sv_encode_image", "sv_adapter", "sv_embed_tokens", "sv_prefill",
+                 "sv_decode_step", "sv_generate", "sv_cb_admit", "sv_beam_step", "sv_preprocess_images", "sv_last_error"):
+        assert need in prod, need
+    dbg = _declared_functions("starvector_hip_debug.h")
+    assert all(n.startswith(("sv_debug_", "sv_op_", "sv_bench_", "sv_profile_")) for n in dbg), dbg
+    assert '#include "starvector_hip.h"' in open(os.path.join(ROOT, "include", "starvector_hip_debug.h")).read()
 
 
 def test_binding_arity_and_struct_fields_match_header():
     """Every ctypes prototype has as many arguments as the C declaration, and the ctypes mirrors of the three structs list
     the header's fields in the header's order (an ABI drift here corrupts arguments silently)."""
     from starvector_amd import _lib
-    text = open(os.path.join(ROOT, "include", "starvector_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = _header_text("starvector_hip.h") + _header_text("starvector_hip_debug.h")
+    seen = set()
     for name, params in re.findall(r"\b(sv_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
         if name not in _lib.PROTOTYPES:
             continue                                            # typedef'd callback etc.
         params = params.strip()
         n = 0 if params in ("", "void") else len([p for p in params.split(",") if p.strip()])
         assert n == len(_lib.PROTOTYPES[name][1]), f"{name}: header has {n} parameters, binding {len(_lib.PROTOTYPES[name][1])}"
+        seen.add(name)
+    assert seen == set(_lib.PROTOTYPES), sorted(set(_lib.PROTOTYPES) - seen)
 
     def fields(struct):
         body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), text, flags=re.S).group(1)

@@ -4,9 +4,12 @@ and (b) the CPU oracle on the same seeded inputs; plus size-independent properti
 Stated tolerances (floating point path, bf16 storage / fp32 accumulation):
   * module outputs vs the float32 reference golden: max|err| <= 3e-2 * max|ref|  (bf16 has 8 mantissa bits;
     23+24 layers of bf16 rounding);
-  * logits vs the oracle's bf16 mode (same cast points): max|err| <= LOGIT_TOL * max|logit|, LOGIT_TOL = 2.5e-2
-    (about 3 bf16 ulps: the reference's own bf16 lm_head quantises logits at 2^-8 relative, so an absolute
-    1e-3 is below the resolution of O(1) bf16 logits; DESIGN.md section "Parity");
+  * logits vs the oracle's bf16 mode (same cast points): max|err| <= LOGIT_TOL * max|logit|, LOGIT_TOL = 1.7e-2
+    = the worst error measured over the whole suite on bf16 weights (1.40e-2 of the scale: BASELINE config 2 at B = 32,
+    contexts 259 .. 7800, profiles/pytest_gpu_r04_final.log) + 20 %; at |logit| ~ 4.5 that is two bf16 ulps (the
+    reference's own bf16 lm_head quantises logits at 2^-8 relative, so north_star's absolute 1e-3 is below the
+    resolution of O(1) bf16 logits; DESIGN.md section "Parity").  fp8 weights (not a reference numerics mode; checked
+    against oracle.fake_quantize_fp8): LOGIT_TOL_FP8 = 2.2e-2 = measured 1.77e-2 (StarVector-8B, full depth) + 20 %;
   * token ids: bit-exact wherever the oracle's top-1/top-2 margin exceeds twice the logit tolerance; a
     mismatch inside that band is a legitimate near-tie and is reported, anything outside fails."""
 import dataclasses
@@ -21,7 +24,8 @@ from oracle.hostinfo import host_cores
 from tests.gpu_util import bf, build_engine, dev, rel_err
 
 pytestmark = pytest.mark.gpu
-LOGIT_TOL = 2.5e-2
+LOGIT_TOL = 1.7e-2
+LOGIT_TOL_FP8 = 2.2e-2
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -879,4 +883,35 @@ def test_prepare_inputs_writes_the_prefill_buffer_directly(norm):
     assert got.shape == want.shape and torch.equal(got, want)
     with pytest.raises(ValueError):
         eng.prepare_inputs(enc, ids[:2])
+    eng.close()
+
+
+def test_ttft_stage_profile_accounts_for_the_pass():
+    """sv_profile_ttft (the bench line's `ttft_breakdown_ms`): every stage of image -> first token is priced, the
+    stages add up to the first-to-last-event span (minus the event-pair time of each interval), and the call leaves the engine
+    usable with the KV cache of that prompt (a decode step continues from it exactly as after sv_prefill)."""
+    cfg = dataclasses.replace(O.OracleConfig.tiny(), eos_token_id=-1)
+    w = O.make_weights(cfg, seed=31)
+    eng = build_engine(cfg, w, max_batch=4, max_seq_len=64)
+    img = bf(O.synthetic_images(3, cfg.image_size, seed=32))
+    ids = torch.tensor([[7, 11, 13]] * 3, dtype=torch.long, device=dev())
+    tp = eng.profile_ttft(img, ids, iters=2)
+    stages = {k: tp[k] for k in eng.TTFT_STAGES}
+    print(f"[ttft profile, tiny] {', '.join(f'{k} {v * 1e3:.0f} us' for k, v in stages.items())}; first to last event {tp['first_to_last_event_ms'] * 1e3:.0f} us")
+    assert all(v >= 0 for v in stages.values()) and stages["encoder_gemm"] > 0 and stages["prefill_gemm"] > 0 and stages["lm_head"] > 0
+    n_int = sum(tp["launches"].values())
+    assert n_int > 20
+    total = sum(stages.values())
+    span = tp["first_to_last_event_ms"]
+    assert total <= span + 1e-3 and total >= span - n_int * (tp["event_pair_overhead_ms"] + 2e-3), (total, span, n_int)
+    # the cache it leaves = sv_prefill's: the next decode step gives the same logits as after a plain prompt pass
+    emb = eng.prepare_inputs(eng.encode_image(img), ids)
+    tok = torch.tensor([5, 6, 7], device=dev())
+    eng.profile_ttft(img, ids, iters=1)
+    a = eng.decode_step(tok)
+    eng.prefill(emb)
+    assert torch.equal(a, eng.decode_step(tok))
+    # text2svg: no encoder / adapter stages
+    t2 = eng.profile_ttft(None, ids, iters=1)
+    assert t2["encoder_gemm"] == 0 and t2["adapter_gemm"] == 0 and t2["prefill_gemm"] > 0
     eng.close()

@@ -9,9 +9,9 @@ from safetensors.torch import load_file
 
 from oracle import starvector_oracle as O
 from tests.gpu_util import build_engine, dev, bf
+from tests.test_gpu_e2e import LOGIT_TOL
 
 pytestmark = pytest.mark.gpu
-LOGIT_TOL = 2.5e-2                   # as in tests/test_gpu_e2e.py
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 

@@ -35,6 +35,11 @@ def test_bench_two_ranks_over_rccl():
     assert res["n_gpus"] == 2 and res["config"]["global_batch"] == 64 and res["scaling"] == "weak"
     assert res["config"]["dist_backend"].startswith("nccl (RCCL") and res["config"]["collectives_per_step"] == 1
     assert res["value"] > 0 and res["config"]["hipgraph_decode"]
+    # one rank per GPU does the same work on the same clock: a straggler (a throttled GPU, a rank that fell back to a slower path)
+    # must be REPORTED by the first real multi-GPU run, not averaged away
+    by_rank = res["config"]["tokens_per_s_by_rank"]
+    assert len(by_rank) == 2 and min(by_rank) > 0
+    assert (max(by_rank) - min(by_rank)) / max(by_rank) < 0.05, f"per-rank throughput spread above 5 %: {by_rank}"
 
 
 def test_bench_bare_invocation_launches_itself_two_ranks_share_the_gpu():

@@ -505,3 +505,15 @@ def test_bench_self_launch_command_and_environment():
     # the product benchmark does not need test infrastructure to describe the model: oracle/ is imported inside cpu_baseline only
     body = src[src.index("def main():"):]
     assert "from oracle" not in body and "import oracle" not in body
+
+
+def test_import_sets_dmabuf_ipc_for_multi_process_gpu_work():
+    """generate_im2svg_dp users (one process per GPU, RCCL) get HSA_ENABLE_IPC_MODE_LEGACY=0 from the package
+    import itself, not only from bench.py -- as a default that an explicit launcher value overrides."""
+    import subprocess
+    import sys
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('HSA_ENABLE_IPC_MODE_LEGACY', None); "
+            "import starvector_amd; print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.strip() == "0"
+    code = code.replace("os.environ.pop('HSA_ENABLE_IPC_MODE_LEGACY', None)", "os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '1'")
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.strip() == "1"
