@@ -126,6 +126,10 @@ int  sv_op_linear_skinny_fp8(const void* x, const void* W, const void* bias, voi
  * (the c_fc form, N %% 8 == 0); out_f32 != 0: float32 rows of x W^T holding bf16-rounded values, bias ignored (the lm_head form) */
 int  sv_op_linear_skinny_epi(const void* x, const void* W, const void* bias, void* y, int32_t M, int32_t N, int32_t K,
                              int32_t act, int32_t out_f32, sv_stream stream);
+/* the lm_head form with the greedy selection folded into its epilogue (what a plain greedy sv_generate runs per decode step): y_f32 [M][N]
+ * (optional, device) = bf16-rounded fp32 logits, host_idx [M] (HOST) = arg-max column per row -- lowest index on ties, NaN never wins,
+ * 0x7fffffff when a row has no comparable score; M <= 32 */
+int  sv_op_lm_head_argmax(const void* x, const void* W, void* y_f32, int32_t* host_idx, int32_t M, int32_t N, int32_t K, sv_stream stream);
 /* the two kernels of the 6-launch decode layer (csrc/decode_cols.hip; gpt_bigcode/modeling_gpt_bigcode.py:694-755) as one op, M <= 32:
  *   h2 = bf16(h + bf16(x[M,Kp] . Wp[D,Kp]^T + bp))                      attention output projection, whole K per block, in place
  *   y  = act(bf16(LayerNorm(h2; gamma, beta, eps) . Wf[F,D]^T + bf))    c_fc on the raw h2, ln_2 folded into weights / epilogue */

@@ -133,6 +133,7 @@ DEBUG_PROTOTYPES = {
     "sv_op_linear_skinny": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sv_op_linear_skinny_fp8": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sv_op_linear_skinny_epi": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sv_op_lm_head_argmax": (_I, [_P, _P, _P, C.POINTER(_I), _I, _I, _I, _P]),
     "sv_op_decode_proj_fold": (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sv_bench_linear": (_I, [_I, _I, _I, _I, _I, _I, C.POINTER(C.c_double), _P]),
     "sv_bench_decode_linear": (_I, [_I, _I, _I, _I, _I, _I, C.POINTER(C.c_double), _P]),

@@ -488,6 +488,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     A(dalloc(e, &e->seen, R * (size_t)e->seen_words));
     A(dalloc(e, &e->am_val, R * 8));
     A(dalloc(e, &e->am_idx, R * 8));
+    A(dalloc(e, &e->amax, (size_t)64 * SV_AMAX_STRIDE));
     A(dalloc(e, &e->cur_tok, R));
     A(dalloc(e, &e->next_tok, R));
     A(dalloc(e, &e->unfinished, R));

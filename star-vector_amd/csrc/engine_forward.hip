@@ -275,7 +275,10 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
                            NT % (8 / l.splitk) == 0) ? 1 : 0;
         }
         else if (out_mode == SK_OUT_PACKED_ACT) { a.splitk = 1; a.bias = l.bias; a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16; }
-        else { a.splitk = 1; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1; }
+        else {
+            a.splitk = 1; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1;
+            if (e->greedy_fused) { a.amax = e->amax; a.amax_rows = B; }      // greedy selection inside the lm_head launch (sv_generate)
+        }
         if (e->skip_skinny) return;
         prof_mark(e, PK_SKINNY, st);
         launch_gemm_skinny(a, st);
@@ -316,6 +319,7 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
                 ma.out_xp = e->xp_mlp; ma.out_KS = F / 16;
                 ma.W2 = L.c_proj2.Wp; ma.N2 = L.c_proj2.N; ma.N2pad = L.c_proj2.Npad; ma.K2 = L.c_proj2.Kpad; ma.splitk = L.c_proj2.splitk;
                 ma.ws = wsB; ma.ldws = e->ldws; ma.rows_ws = MT * 32; ma.err = e->d_bad; ma.spin_ticks = 500000;     // 5 ms at 100 MHz
+                ma.order = (e->exp & 2048) ? 1 : 0;
                 ma.trace = (i == c.n_layer / 2) ? e->mlp_trace : nullptr;        // one layer in the middle of the step
                 // the launcher re-checks the shapes of THIS layer (sv_create looked at layer 0): a layer it refuses takes the two launches
                 // below -- never a silently skipped MLP

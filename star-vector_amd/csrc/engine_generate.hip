@@ -3,7 +3,9 @@
 #include "engine_internal.h"
 
 // sample from e->logits into next_tok, then the bookkeeping kernel
-static void sample_and_finish(sv_engine* e, int B, const sv_sampling& sp, int max_new, hipStream_t st) {
+// fused: the lm_head launch in front has already left every row's best (value, lowest index) in e->amax (gemm.hip, SkinnyArgs::amax):
+// no argmax launch, finish_step_kernel decodes the keys
+static void sample_and_finish(sv_engine* e, int B, const sv_sampling& sp, int max_new, hipStream_t st, bool fused = false) {
     const bool pen = sp.repetition_penalty > 0.f && sp.repetition_penalty != 1.0f;
     const uint32_t* seen = pen ? e->seen : nullptr;
     if (sp.min_new_tokens > 0 && sp.eos_token_id >= 0 && sp.eos_token_id < e->cfg.vocab)
@@ -14,12 +16,13 @@ static void sample_and_finish(sv_engine* e, int B, const sv_sampling& sp, int ma
         sa.top_p = sp.top_p; sa.top_k = sp.top_k; sa.seed = sp.seed; sa.step = e->d_step; sa.out = e->next_tok; sa.scratch = e->sample_scratch;
         sa.seen = seen; sa.seen_words = e->seen_words; sa.penalty = sp.repetition_penalty;
         launch_sample_top_p(sa, st);
-    } else {
+    } else if (!fused) {
         launch_argmax_partial(e->logits, e->Vpad, e->cfg.vocab, e->am_val, e->am_idx, B, seen, e->seen_words,
                               sp.repetition_penalty, st);
     }
     FinishArgs f;
     f.pval = sp.do_sample ? nullptr : e->am_val; f.pidx = sp.do_sample ? nullptr : e->am_idx;
+    f.amax = fused ? e->amax : nullptr;
     f.next = e->next_tok; f.cur_tok = e->cur_tok; f.unfinished = e->unfinished; f.positions = e->positions;
     f.out_tokens = e->out_tok; f.ld_out = e->out_ld; f.step = e->d_step; f.done = e->d_done; f.n_emitted = e->d_nemit;
     f.stop_ids = e->d_stop; f.n_stop = sp.n_stop; f.eos = sp.eos_token_id; f.pad = sp.pad_token_id; f.B = B;
@@ -230,6 +233,21 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
         HIPCHECK(hipMemcpyAsync(e->d_stop, sp->stop_ids, sp->n_stop * sizeof(int32_t), hipMemcpyHostToDevice, st));
     }
     sample_and_finish(e, B, *sp, max_new, st);       // first token from the prefill logits
+    // Plain greedy decode (no repetition penalty, no min_length hold, one row tile, bf16 lm_head with the K split over the waves of a
+    // block): the selection rides in the lm_head epilogue of every decode step -- one launch less per step, same tokens bit for bit.
+    // SV_EXP bit 1024 = the separate argmax launch (A/B).
+    bool fused_sel = false;
+    {
+        int waves = 1, two = 0;
+        skinny_plan(e->lm_head.Npad, e->lm_head.Kpad, 1, e->lm_head.fp8 ? 1 : 0, (B + 31) / 32, &waves, &two);
+        const bool pen = sp->repetition_penalty > 0.f && sp->repetition_penalty != 1.0f;
+        fused_sel = !sp->do_sample && !pen && sp->min_new_tokens <= 0 && B <= 32 && !e->lm_head.fp8 && waves > 1 && !two && !(e->exp & 1024);
+    }
+    struct FusedSel { sv_engine* e; ~FusedSel() { e->greedy_fused = false; } } fused_guard{e};
+    if (fused_sel) {
+        HIPCHECK(hipMemsetAsync(e->amax, 0, (size_t)64 * SV_AMAX_STRIDE * sizeof(unsigned long long), st));
+        e->greedy_fused = true;                      // read by decode_forward (capture and eager launches below); cleared on every exit
+    }
     HIPCHECK(hipMemcpyAsync(&e->h_flags[0], e->d_done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
     auto t1 = std::chrono::steady_clock::now();
@@ -271,7 +289,7 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
             hipError_t ce = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
             if (ce == hipSuccess) {
                 decode_forward(e, B, st);
-                sample_and_finish(e, B, *sp, max_new, st);
+                sample_and_finish(e, B, *sp, max_new, st, fused_sel);
                 ce = hipStreamEndCapture(st, &e->gen_graph);
                 if (ce == hipSuccess && e->gen_graph) ce = hipGraphInstantiate(&e->gen_gexec, e->gen_graph, nullptr, nullptr, 0);
             }
@@ -295,7 +313,7 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
                 HIPCHECK(hipGraphLaunch(gexec, st));
             } else {
                 decode_forward(e, B, st);
-                sample_and_finish(e, B, *sp, max_new, st);
+                sample_and_finish(e, B, *sp, max_new, st, fused_sel);
             }
         }
         steps += n;

@@ -120,6 +120,7 @@ struct sv_engine {
                                     //   2 the 7-launch layer (no LayerNorm fold);
                                     //   (1: was the row update as one wave per row: 0.218 vs 0.131 ms per step, removed)
                                     //   8 (at sv_create only) the round 1-2 split-K rule of the decode GEMMs
+                                    //   1024 (round 5) greedy selection as its own launch again (argmax_kernel), not folded into the lm_head epilogue
                                     //   128 / 512 (round 4) the MLP half of a layer as ONE launch (mlp_fused_kernel) forced on / off; default:
                                     //       on iff sv_config.exclusive_device
                                     //   (16 / 32 / 64: 2 / 6 / 8 key groups per attention block: 1186 / 1169 / 1175 vs 1171 us, removed)
@@ -128,6 +129,8 @@ struct sv_engine {
     float *ws = nullptr, *ws2 = nullptr, *logits = nullptr, *sample_scratch = nullptr, *attn_part = nullptr;
     unsigned* attn_cnt = nullptr;
     float* am_val = nullptr; int32_t* am_idx = nullptr;
+    unsigned long long* amax = nullptr;   // greedy selection folded into the lm_head launch: one 64-bit key per row, [64 * SV_AMAX_STRIDE]
+    bool greedy_fused = false;            //   on for the decode steps of the current sv_generate call (set and cleared by it)
     uint32_t* seen = nullptr; int seen_words = 0;      // repetition-penalty bitmap [rows][Vpad/32]
     int32_t *cur_tok = nullptr, *next_tok = nullptr, *unfinished = nullptr, *positions = nullptr,
             *out_tok = nullptr, *d_step = nullptr, *d_done = nullptr, *d_nemit = nullptr, *d_stop = nullptr, *d_bad = nullptr;

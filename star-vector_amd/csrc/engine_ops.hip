@@ -534,6 +534,44 @@ extern "C" int sv_op_linear_skinny_epi(const void* x, const void* W, const void*
     return 0;
 }
 
+// the lm_head form of the decode GEMM with the greedy selection folded into its epilogue (gemm.hip, SkinnyArgs::amax): y_f32 [M][N]
+// (optional) = the bf16-rounded fp32 logits x W^T, host_idx [M] = the arg-max column of every row as finish_step_kernel decodes it
+// (lowest index on ties, NaN never wins; 0x7fffffff for a row without a single comparable score).  M <= 32.
+extern "C" int sv_op_lm_head_argmax(const void* x, const void* W, void* y_f32, int32_t* host_idx, int32_t M, int32_t N, int32_t K,
+                                    sv_stream stream) {
+    if (!x || !W || !host_idx || M < 1 || M > 32 || N < 1 || K < 32 || K % 32) return fail(SV_EINVAL, "sv_op_lm_head_argmax: bad argument (M <= 32, K %% 32 == 0)");
+    if (int ar = init_gemm_kernels()) return fail(SV_EHIP, "hipFuncSetAttribute: %s", hipGetErrorString((hipError_t)ar));
+    hipStream_t st = (hipStream_t)stream;
+    TmpBufs tmp;
+    const int Npad = round_up(N, 32);
+    int waves = 1, two = 0;
+    skinny_plan(Npad, K, 1, 0, 1, &waves, &two);
+    if (waves < 2) return fail(SV_ENOTSUP, "sv_op_lm_head_argmax: K = %d leaves one wave per block (the fold needs the K split over waves)", K);
+    bf16_t *Wp, *xp;
+    float* of;
+    unsigned long long* keys;
+    SVCHECK(tmp.get(&Wp, (size_t)Npad * K));
+    SVCHECK(tmp.get(&xp, (size_t)32 * K));
+    SVCHECK(tmp.get(&of, (size_t)32 * Npad));
+    SVCHECK(tmp.get(&keys, (size_t)32 * SV_AMAX_STRIDE));
+    HIPCHECK(hipMemsetAsync(xp, 0, (size_t)32 * K * 2, st));
+    HIPCHECK(hipMemsetAsync(keys, 0, (size_t)32 * SV_AMAX_STRIDE * 8, st));
+    launch_pack_weight(W, 0, Wp, N, K, Npad, K, st);
+    pack_rows((const bf16_t*)x, K, xp, M, K, st);
+    SkinnyArgs a;
+    memset(&a, 0, sizeof(a));
+    a.xp = xp; a.Wp = Wp; a.MT = 1; a.Npad = Npad; a.K = K; a.splitk = 1; a.N = N;
+    a.out_mode = SK_OUT_F32; a.out_f32 = of; a.ldo = Npad; a.round_bf16 = 1; a.amax = keys; a.amax_rows = M;
+    launch_gemm_skinny(a, st);
+    if (y_f32) HIPCHECK(hipMemcpy2DAsync(y_f32, (size_t)N * 4, of, (size_t)Npad * 4, (size_t)N * 4, M, hipMemcpyDeviceToDevice, st));
+    std::vector<unsigned long long> h((size_t)32 * SV_AMAX_STRIDE);
+    HIPCHECK(hipMemcpyAsync(h.data(), keys, h.size() * 8, hipMemcpyDeviceToHost, st));
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(st));
+    for (int m = 0; m < M; ++m) host_idx[m] = sv_amax_index(h[(size_t)m * SV_AMAX_STRIDE]);
+    return 0;
+}
+
 // The 6-launch layer's two kernels as one op (decode_cols.hip): h2 = bf16(h + bf16(x Wp^T + bp)) by the slab-free output projection
 // (whole K per block, partial row statistics), then y = act(bf16(LN(h2; gamma, beta) Wf^T + bf)) by the decode GEMM on the RAW h2
 // with the LayerNorm folded into its weights / epilogue.  Row-major in / out; M <= 32.

@@ -1200,9 +1200,17 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
             fs2 = fmaf(a, a, fmaf(b, b, fs2));
         }
     };
+    unsigned long long amax_seen = 0ull;                    // the row's best key when this block started (a lower bound: a filter only)
     auto late = [&]() {                                     // the stream is in flight: now the rest of the arguments + the bias
         p = sv_late_args<SkinnyArgs>(offsetof(SkinnyKernarg, p));
         sk_bias<RPW>(p, bias_d, wave * RPW, nt, half, FOLD ? fc1 : nullptr);
+        if constexpr (!FOLD && WAVES > 1) {
+            if (p.out_mode == SK_OUT_F32 && p.amax && wave == 0 && half == 0 && mt * 32 + m < p.amax_rows) {
+                // L1-bypassing load: finish_step_kernel of the PREVIOUS step has re-armed the slot (a stale, higher key must never be seen)
+                amax_seen = __hip_atomic_load(p.amax + (size_t)(mt * 32 + m) * SV_AMAX_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("" : "+v"(amax_seen));         // settled before the k loop (see sk_settle)
+            }
+        }
         sk_settle<RPW>(bias_d, FOLD ? fc1 : nullptr);
     };
     auto guarded = [&](int ks) {                            // the ragged end of the range (and short ranges): guard per k-step
@@ -1285,6 +1293,34 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
         fold = SkFold{true, mean, rsqrtf(var + p.fold_eps)};
     }
     sk_store<RPW>(p, v, bias_d, wave * RPW, nt, mt, split, m, half, fold, fc1);
+    if constexpr (!FOLD && WAVES > 1) {
+        // Greedy selection folded into the lm_head launch: the logits this block has just rounded and stored are
+        // still in registers -- lane (m, half) of wave w holds RPW columns of row m.  Best (value, lowest column) of the lane, of the
+        // two halves (one shuffle), of the 8 waves (the statistics slots of the FOLD instantiation: unused here), then ONE atomic max
+        // per row and block on a 64-bit key -- and only where the block beats the row's maximum as it stood when the block started
+        // (`seen`, read with the late arguments while the weight stream was in flight): ~ln(1537) atomics per row instead of 1537.
+        // argmax_kernel + the slice merge (a 6 us launch of the step) become a decode in finish_step_kernel.  Bit-identical selection:
+        // same bf16-rounded values, columns < N only, NaN never wins, lowest index on ties (tests/test_gpu_ops.py).
+        if (p.out_mode == SK_OUT_F32 && p.amax) {
+            unsigned long long key = 0ull;
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const int r = wave * RPW + i;
+                const int n = nt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                if (n < p.N) { const unsigned long long k = sv_amax_key(v[i], (unsigned)n); key = k > key ? k : key; }
+            }
+            { const unsigned long long o = __shfl_xor(key, 32, 64); key = o > key ? o : key; }
+            unsigned long long* key_s = reinterpret_cast<unsigned long long*>(fst_s);            // [WAVES][32]
+            if (half == 0) key_s[wave * 32 + m] = key;
+            __syncthreads();
+            if (wave == 0 && half == 0 && mt * 32 + m < p.amax_rows) {
+#pragma unroll
+                for (int q = 1; q < WAVES; ++q) { const unsigned long long o = key_s[q * 32 + m]; key = o > key ? o : key; }
+                if (key > amax_seen)
+                    (void)__hip_atomic_fetch_max(p.amax + (size_t)(mt * 32 + m) * SV_AMAX_STRIDE, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1399,8 +1435,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // half is requested NOW, so that the HBM stream does not pause while the block reduces and publishes (third version: requested after
     // the publish -- HBM idle for 2.5 us); 8 KiB per wave in flight is what the steady state of the stand-alone kernels keeps (all
     // 16 KiB at once put 24 MB of reads in front of every tile store of the chip: second version, 6 us from loop end to publish).
+    // (p.order == 1, SV_EXP bit 2048, round-5 A/B: NOTHING is requested here -- reduce and publish first, with an empty queue, then the whole
+    //  16 KiB share at once; the polls queue behind it and return when it has landed, by which time the producers' tiles are visible)
+    if (p.order == 0) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
+        for (int u = 0; u < 8; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
+    }
 
     // K reduction across the waves (wave order) + LayerNorm fold epilogue: gemm_skinny_kernel<8, true>'s, value for value
     float v[RPW];
@@ -1458,9 +1498,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const long long t_pub = wall_clock64();
     // second half of the weights (the first half has landed during the reduction), then -- once half of THAT is in -- the activations:
     // their producers publish at about the same time as this block, and a request that finds the pattern costs a whole extra round trip
+    if (p.order == 0) {
 #pragma unroll
-    for (int u = 8; u < 16; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        for (int u = 8; u < 16; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
+    }
 
     // ---- phase 2: down projection (tile nt2, K slice `split`) -> fp32 slab, gemm_skinny_kernel<8, false>'s order ----
     u32x4 x2[KPW];

@@ -66,7 +66,22 @@ struct SkinnyArgs {
     // epilogue x = rstd[m] * (acc - mean[m] * c1[n]) + c2[n], the row statistics accumulated from the activation stream in the kernel
     const float* fold_c1; const float* fold_c2;            // [Npad] (nullptr: off)
     int fold_D; float fold_eps;                            // LayerNorm width (= K) and epsilon
+    // Greedy selection folded into the lm_head epilogue (F32 mode, one row tile, bf16 weights): every block leaves the best
+    // (value, lowest index) of its 32 columns per row in amax[row * SV_AMAX_STRIDE] through an atomic max on a 64-bit key
+    // (sv_amax_key); finish_step_kernel decodes and re-arms it.  nullptr: off.
+    unsigned long long* amax; int amax_rows;               // rows < amax_rows take part
 };
+#define SV_AMAX_STRIDE 16          // one 128-byte line per row: the rows' atomics do not share an L2 line
+// key = (order-preserving image of the float) << 32 | (0xFFFFFFFF - column): larger value wins, equal values -> LOWER column wins
+// (torch.argmax / HF _sample's tie-break, sampling.hip argmax_pair); 0 = "no finite-or-infinite score seen" (NaN never wins).
+__host__ __device__ inline unsigned long long sv_amax_key(float v, unsigned col) {
+    if (v != v) return 0ull;
+    if (v == 0.f) v = 0.f;                                 // -0.0 == +0.0 for the comparison the argmax kernel makes
+    union { float f; unsigned u; } c; c.f = v;
+    const unsigned o = (c.u & 0x80000000u) ? ~c.u : (c.u | 0x80000000u);
+    return ((unsigned long long)o << 32) | (unsigned long long)(0xFFFFFFFFu - col);
+}
+__host__ __device__ inline int sv_amax_index(unsigned long long key) { return key ? (int)(0xFFFFFFFFu - (unsigned)(key & 0xFFFFFFFFull)) : 0x7fffffff; }
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st);
 // host arithmetic of the launch: waves per block (how K is cut inside a block = the summation order of a row) and whether a
 // block carries two row tiles; a function of the GEMM only for the former (sv_debug_skinny_plan, CPU tests)
@@ -91,6 +106,8 @@ struct MlpFusedArgs {
     int spin_ticks;                          // wall-clock budget of a wave's wait in 100 MHz ticks (s_memrealtime): on expiry -- or when
                                              // *err is already set by another wave / launch -- the wave gives up (code 3)
     long long* trace;                        // optional [N1pad / 32][8] wall-clock stamps per block (tools/mlp_trace.py); nullptr in production
+    int order;                               // 0: the shipped order of the down projection's weight requests (half before the reduction, half
+                                             // after the publish); 1 (SV_EXP bit 2048, A/B): all of them after the publish
 };
 int launch_mlp_fused(const MlpFusedArgs& a, hipStream_t st);
 
@@ -219,6 +236,8 @@ void launch_sample_top_p(const SampleArgs& a, hipStream_t st);
 struct FinishArgs {
     const int32_t* next;          // [B] raw sampled ids (sampling path)
     const float* pval; const int32_t* pidx;   // greedy path: [B][8] slice winners merged here (or nullptr)
+    unsigned long long* amax;     // greedy path, selection folded into the lm_head launch: keys [B * SV_AMAX_STRIDE] (SkinnyArgs::amax),
+                                  // decoded and re-armed (zeroed) here; nullptr: off
     int32_t* cur_tok;             // [B] token fed to the next step
     int32_t* unfinished;          // [B]
     int32_t* positions;           // [B] (+1 each step)

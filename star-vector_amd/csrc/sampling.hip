@@ -372,7 +372,11 @@ __global__ void finish_step_kernel(FinishArgs p) {
     if (b < p.B) {
         const int unf = p.unfinished[b];
         int nxt;
-        if (p.pval) {                       // greedy: merge the AM_SPLIT slice winners of this row
+        if (p.amax) {                       // greedy, selection folded into the lm_head launch: decode the row's key, re-arm the slot
+            unsigned long long* slot = p.amax + (size_t)b * SV_AMAX_STRIDE;
+            nxt = sv_amax_index(__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (p.pval) {                // greedy: merge the AM_SPLIT slice winners of this row
             float best = -INFINITY;
             nxt = 0x7fffffff;
             for (int s = 0; s < AM_SPLIT; ++s) argmax_pair(best, nxt, p.pval[b * AM_SPLIT + s], p.pidx[b * AM_SPLIT + s]);

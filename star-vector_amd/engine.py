@@ -574,6 +574,18 @@ def op_linear_skinny_epi(x, W, bias=None, act="none", out_f32=False):
     return y
 
 
+def op_lm_head_argmax(x, W):
+    """The lm_head form of the decode GEMM with the greedy selection folded into its epilogue (what a plain greedy generate
+    runs per step): returns (logits float32 [M, N] holding bf16-rounded values, arg-max column per row as an int64 cpu tensor)."""
+    lib = _lib.load()
+    x = _need(x, torch.bfloat16, "x"); W = _need(W, torch.bfloat16, "W")
+    M, K = x.shape; N = W.shape[0]
+    y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+    idx = (C.c_int32 * M)()
+    check(lib.sv_op_lm_head_argmax(_ptr(x), _ptr(W), _ptr(y), idx, M, N, K, _stream()), "sv_op_lm_head_argmax")
+    return y, torch.tensor(list(idx), dtype=torch.int64)
+
+
 def op_decode_proj_fold(x, Wp, bp, h, gamma, beta, Wf, bf_, act="gelu_tanh", eps=1e-5):
     """The 6-launch decode layer's two kernels (csrc/decode_cols.hip): returns (h2 bf16 [M, D], y bf16 [M, F])."""
     lib = _lib.load()

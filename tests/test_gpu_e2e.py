@@ -9,7 +9,8 @@ Stated tolerances (floating point path, bf16 storage / fp32 accumulation, SURVEY
     contexts 259 .. 7800, profiles/pytest_gpu_r04_final.log) + 20 %; at |logit| ~ 4.5 that is two bf16 ulps (the
     reference's own bf16 lm_head quantises logits at 2^-8 relative, so north_star's absolute 1e-3 is below the
     resolution of O(1) bf16 logits; DESIGN.md section "Parity").  fp8 weights (not a reference numerics mode; checked
-    against oracle.fake_quantize_fp8): LOGIT_TOL_FP8 = 2.2e-2 = measured 1.77e-2 (StarVector-8B, full depth) + 20 %;
+    against oracle.fake_quantize_fp8): LOGIT_TOL_FP8 = 2.6e-2 = measured 2.13e-2 (StarVector-8B, full depth, 64 rows x 12 steps:
+    config 5 at its batch size, tests/test_gpu_configs45.py; 1.77e-2 at 2 rows) + 20 %;
   * token ids: bit-exact wherever the oracle's top-1/top-2 margin exceeds twice the logit tolerance; a
     mismatch inside that band is a legitimate near-tie and is reported, anything outside fails."""
 import dataclasses
@@ -25,7 +26,7 @@ from tests.gpu_util import bf, build_engine, dev, rel_err
 
 pytestmark = pytest.mark.gpu
 LOGIT_TOL = 1.7e-2
-LOGIT_TOL_FP8 = 2.2e-2
+LOGIT_TOL_FP8 = 2.6e-2
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -914,4 +915,48 @@ def test_ttft_stage_profile_accounts_for_the_pass():
     # text2svg: no encoder / adapter stages
     t2 = eng.profile_ttft(None, ids, iters=1)
     assert t2["encoder_gemm"] == 0 and t2["adapter_gemm"] == 0 and t2["prefill_gemm"] > 0
+    eng.close()
+
+
+def test_folded_greedy_selection_equals_the_argmax_launch_token_for_token():
+    """Round 5: a plain greedy sv_generate selects inside the lm_head launch (one launch less per decode step).  SV_EXP bit 1024 puts
+    the separate argmax launch back: the token streams must be IDENTICAL -- BASELINE config 2's size, graph and eager, a batch that is
+    not a multiple of anything (rows >= B of the row tile take no part), EOS / pad bookkeeping after a row finishes, and the modes
+    that must NOT take the folded path (repetition penalty, min_length hold, sampling) unchanged."""
+    import starvector_amd as sva
+    B = 32
+    eng = sva.HipEngine(sva.EngineConfig(max_batch=B, max_seq_len=259 + 200))
+    eng.load_random_weights(seed=11)
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(B, 3, 224, 224, generator=g).to(torch.bfloat16).to(dev())
+    prompt = torch.tensor([[7, 11]] * B, dtype=torch.long, device=dev())
+    emb = torch.cat([eng.adapter(eng.encode_image(img)), eng.embed_tokens(prompt)], 1)
+    S0 = emb.shape[1]
+    kw = dict(max_length=S0 + 180, eos_token_id=-1, pad_token_id=49152)
+    eng.set_exp(1024)
+    ref = eng.generate(emb, **kw).cpu()
+    eos = int(ref[3, 40])                                       # a token row 3 emits at step 40: that row finishes there
+    ref_eos = eng.generate(emb, max_length=S0 + 120, eos_token_id=eos, pad_token_id=49152).cpu()
+    ref13 = eng.generate(emb[:13].contiguous(), **kw).cpu()
+    ref_pen = eng.generate(emb, repetition_penalty=1.3, **kw).cpu()
+    eng.set_exp(0)
+    got = eng.generate(emb, **kw).cpu()
+    assert eng.last_timing()["graph"]
+    assert torch.equal(got, ref), "folded greedy selection changes the token stream"
+    assert ref.unique().numel() > 8
+    assert torch.equal(eng.generate(emb, max_length=S0 + 120, eos_token_id=eos, pad_token_id=49152).cpu(), ref_eos)
+    assert bool((ref_eos[3, 41:] == 49152).all()) and int(ref_eos[3, 40]) == eos
+    assert torch.equal(eng.generate(emb[:13].contiguous(), **kw).cpu(), ref13)
+    assert torch.equal(ref13, ref[:13])                         # a row does not depend on the batch around it
+    assert torch.equal(eng.generate(emb, repetition_penalty=1.3, **kw).cpu(), ref_pen)
+    os.environ["SV_NO_GRAPH"] = "1"
+    try:
+        assert torch.equal(eng.generate(emb, **kw).cpu(), ref)
+        assert not eng.last_timing()["graph"]
+    finally:
+        os.environ.pop("SV_NO_GRAPH", None)
+    # back-to-back calls re-arm the key slots: a second identical call, then a sampled one, then greedy again
+    assert torch.equal(eng.generate(emb, **kw).cpu(), ref)
+    eng.generate(emb, do_sample=True, temperature=1.0, top_p=0.9, top_k=50, seed=3, **kw)
+    assert torch.equal(eng.generate(emb, **kw).cpu(), ref)
     eng.close()

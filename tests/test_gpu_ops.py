@@ -266,6 +266,54 @@ def test_argmax_lowest_index_on_ties():
     assert got[2] == 100 and got[5] == 49155 and got[7] == 0
 
 
+@pytest.mark.parametrize("V", [49156, 49157, 96])
+def test_lm_head_with_folded_greedy_selection(V):
+    """Round 5: the greedy arg-max rides in the lm_head launch's epilogue -- per block the best (value, lowest
+    column) of its 32 columns, one 64-bit atomic max per row (gemm.hip, SkinnyArgs::amax) -- instead of argmax_kernel + a slice
+    merge.  Integer result, bit-exact against torch.argmax of the kernel's own logits: exact ties (duplicated weight rows) resolve
+    to the LOWEST index, the zero columns that pad the vocabulary to 32 never win (a row whose real logits are all negative), a
+    NaN row has no winner, -0.0 ties with +0.0 like the float comparison does."""
+    g = torch.Generator().manual_seed(60 + V)
+    M, K = 32, 2048 if V > 1000 else 64
+    x = torch.randn(M, K, generator=g).bfloat16()
+    W = (torch.randn(V, K, generator=g) / K ** 0.5).bfloat16()
+    W[V - 1] = W[7]                                   # an exact tie between column 7 and the last column (the 4 added tokens' tile)
+    W[V // 2] = W[3]
+    x[4] = x[4].abs()                                 # row 4: make column 9 the winner by a wide margin, and its duplicate V - 2 tie it
+    W[9] = 0.25
+    W[V - 2] = W[9]
+    x[5] = -x[4]                                      # row 5: the same two columns are the most NEGATIVE; zero rows 11 / 12 give logits +-0.0
+    W[11] = 0.0
+    W[12] = -0.0
+    x[6] = float("nan")                               # row 6: no comparable score at all
+    lg, idx = E.op_lm_head_argmax(bf(x), bf(W))
+    lg = lg.cpu()
+    ok = [m for m in range(M) if m != 6]
+    assert torch.equal(lg[ok], E.op_linear_skinny_epi(bf(x), bf(W), out_f32=True).cpu()[ok])        # the epilogue still stores the logits
+    ref = lg[ok].argmax(-1)                           # torch: lowest index among equal maxima
+    assert torch.equal(idx[ok], ref), (idx[ok], ref)
+    assert int(idx[6]) == 0x7fffffff                  # what finish_step_kernel turns into token 0 + the device flag
+    assert int(idx[4]) == 9 and float(lg[4, 9]) == float(lg[4, V - 2])
+    # every real logit of a row negative: the zero columns that pad the vocabulary to a multiple of 32 (logit 0) are no candidates
+    Wn = -W.abs()
+    xn = x.clone()
+    xn[6] = x[7]
+    xn[0] = x[0].abs()
+    lg2, idx2 = E.op_lm_head_argmax(bf(xn), bf(Wn))
+    lg2 = lg2.cpu()
+    assert float(lg2[0].max()) < 0.0
+    assert torch.equal(idx2, lg2.argmax(-1)) and int(idx2.max()) < V
+    # +0.0 and -0.0 tie (the float comparison of argmax_kernel): rows of zeros in W, everything else negative -> the LOWER column
+    Wz = Wn.clone()
+    Wz[12] = 0.0
+    Wz[11] = -0.0
+    xz = xn.clone()
+    xz[1] = -xn[0]                                    # row 1: 0 * negative = -0.0 in column 11 / 12 products; row 0: +0.0
+    lg3, idx3 = E.op_lm_head_argmax(bf(xz), bf(Wz))
+    assert int(idx3[0]) == 11 and float(lg3[0, 11]) == 0.0 and float(lg3[0, 12]) == 0.0
+    assert torch.equal(idx3, lg3.cpu().argmax(-1))
+
+
 def test_top_p_sampler_distribution():
     """Distributional parity with HF's temperature -> top-p -> multinomial (torch's RNG stream itself is
     not reproducible in a custom kernel)."""

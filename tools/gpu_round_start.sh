@@ -2,6 +2,7 @@
 # ONE parameterised script for the GPU box (replaces round 2's 41 one-shot scripts).  Usage, from the repo root on the box:
 #   bash tools/gpu_round_start.sh <tag> [steps...]      steps (default "pytest bench"), run in the order given:
 #     pytest      the whole GPU suite through the C ABI            -> gpurun_out/<tag>/pytest_gpu.log
+#     pytestall   the same without -x (every failure of a first run of new tests)
 #     pytest:<k>  only tests matching -k <k>
 #     bench       the headline line (BASELINE config 2)            -> bench_n1.json
 #     bench8b     configs 4 and 5 per-GPU workloads (256 tokens)   -> bench_8b_*.json
@@ -13,6 +14,7 @@
 #     memmix      tools/diag/mem_mix.hip: weight stream + shared-operand re-reads without MFMA (what bounds the decode GEMMs) -> mem_mix.log
 #     xcd         tools/diag/xcd_map.hip: block -> XCD placement inside a replayed graph  -> xcd_map.log
 #     ab:<args>   tools/ab_exp.py <args> (in-process A/B of SV_EXP masks)           -> ab_exp.log
+#     run:<name>:<script args>  python <script args> -> <name>.log
 #     rebuild:<K=V>  rebuild the library on the box with K=V in the environment (build-flag A/B, e.g. SV_NO_KERNARG_PRELOAD=1)
 #     env:<K=V>   export K=V for the steps that follow (experiment switches)
 # Everything lands under gpurun_out/<tag>/ ; copy what is to be judged into profiles/.
@@ -31,6 +33,8 @@ for s in "${STEPS[@]}"; do
     # the evidence, so the full log is kept and the "[tag] ..." lines are cut out next to it
     pytest) timeout 1500 python -m pytest tests -m gpu -q -x -s -rA 2>&1 | grep -v amdgpu.ids > "$OUT/pytest_gpu_full.log"
             grep -oE "\[[A-Za-z0-9][^]]*\] .*|^.*(passed|failed).*$|^(FAILED|ERROR).*$" "$OUT/pytest_gpu_full.log" > "$OUT/pytest_gpu.log"; tail -4 "$OUT/pytest_gpu.log" ;;
+    pytestall) timeout 2400 python -m pytest tests -m gpu -q -s -rA 2>&1 | grep -v amdgpu.ids > "$OUT/pytest_gpu_full.log"       # no -x: every failure of a first run
+            grep -oE "\[[A-Za-z0-9][^]]*\] .*|^.*(passed|failed).*$|^(FAILED|ERROR).*$" "$OUT/pytest_gpu_full.log" > "$OUT/pytest_gpu.log"; grep -E "^(FAILED|ERROR)|passed|failed" "$OUT/pytest_gpu.log" | tail -30 ;;
     pytest:*) timeout 1500 python -m pytest tests -m gpu -q -x -s -rA -k "${s#pytest:}" 2>&1 | grep -v amdgpu.ids > "$OUT/pytest_gpu_k_full.log"
             grep -oE "\[[A-Za-z0-9][^]]*\] .*|^.*(passed|failed|Error|assert).*$|^(FAILED|ERROR).*$" "$OUT/pytest_gpu_k_full.log" > "$OUT/pytest_gpu_k.log"; tail -25 "$OUT/pytest_gpu_k.log" ;;
     bench) timeout 400 python bench.py > "$OUT/bench_n1.json" 2> "$OUT/bench_n1.err"; cat "$OUT/bench_n1.json" ;;
@@ -67,6 +71,9 @@ for s in "${STEPS[@]}"; do
       python tools/trace_by_grid.py "$OUT/rocprof_$name" "$OUT/rocprof_${name}_by_grid.csv" > /dev/null 2>&1 || true
       find "$OUT/rocprof_$name" -name '*kernel_trace.csv' -size +8M -delete 2>/dev/null
       head -14 "$OUT/rocprof_${name}_by_grid.csv" | cut -c1-150 ;;
+    run:*)    # an arbitrary python script of the repo: run:<name>:<script and args>   -> <name>.log
+      rest="${s#run:}"; name="${rest%%:*}"; cmd="${rest#*:}"
+      timeout 600 python $cmd 2>&1 | grep -v amdgpu.ids | tee "$OUT/$name.log" | tail -40 ;;
     memmix) hipcc --offload-arch=gfx950 -O3 -o /tmp/mem_mix tools/diag/mem_mix.hip 2>/dev/null && timeout 120 /tmp/mem_mix 2>&1 | tee "$OUT/mem_mix.log" | tail -30 ;;
     xcd) hipcc --offload-arch=gfx950 -O2 -o /tmp/xcd_map tools/diag/xcd_map.hip 2>/dev/null && /tmp/xcd_map 2>&1 | tee "$OUT/xcd_map.log" | tail -8 ;;
     ab:*) timeout 600 python tools/ab_exp.py ${s#ab:} 2>&1 | grep -v amdgpu.ids | tee -a "$OUT/ab_exp.log" ;;

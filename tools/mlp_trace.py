@@ -19,7 +19,9 @@ eng.load_random_weights(seed=1234)
 img = synthetic_images(torch, B, 224, seed=0).to(dev)
 prompt = torch.tensor([[7, 11]] * B, dtype=torch.long, device=dev)
 emb = torch.cat([eng.adapter(eng.encode_image(img)), eng.embed_tokens(prompt)], 1)
-eng.set_exp(128)
+mask = int(sys.argv[1]) if len(sys.argv) > 1 else 128       # SV_EXP mask: 128 = the fused launch; + 2048 = round 5's request order
+eng.set_exp(mask)
+print(f"=== SV_EXP {mask}")
 for rep in range(3):
     eng.generate(emb, max_length=emb.shape[1] + 128, eos_token_id=-1, pad_token_id=49152)
     tr = eng.debug_mlp_trace().double()
