@@ -319,7 +319,7 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
                 ma.out_xp = e->xp_mlp; ma.out_KS = F / 16;
                 ma.W2 = L.c_proj2.Wp; ma.N2 = L.c_proj2.N; ma.N2pad = L.c_proj2.Npad; ma.K2 = L.c_proj2.Kpad; ma.splitk = L.c_proj2.splitk;
                 ma.ws = wsB; ma.ldws = e->ldws; ma.rows_ws = MT * 32; ma.err = e->d_bad; ma.spin_ticks = 500000;     // 5 ms at 100 MHz
-                ma.order = (e->exp & 2048) ? 1 : 0;
+                ma.loader = (e->exp & 4096) ? 0 : 1;
                 ma.trace = (i == c.n_layer / 2) ? e->mlp_trace : nullptr;        // one layer in the middle of the step
                 // the launcher re-checks the shapes of THIS layer (sv_create looked at layer 0): a layer it refuses takes the two launches
                 // below -- never a silently skipped MLP
