@@ -1613,20 +1613,36 @@ __global__ __launch_bounds__(576) void mlp_fused_ld_kernel(const bf16_t* W1_, co
         }
         const char* src = reinterpret_cast<const char*>(W2_) + (((size_t)nt2 * KS2_ + (size_t)split * (WAVES * KPW)) * 64 + lane) * 16;
         const unsigned ready_off = (unsigned)(size_t)(lptr_t)(&sy->ready[0]);    // LDS byte address of the flags
+        // DEPTH slots (15 KiB each) in flight: after issuing slot w wait until at most DEPTH - 1 slots are outstanding, i.e. slot
+        // w - (DEPTH - 1) has landed (loads return in order), and raise its flag.  The flags go out through asm stores: a C++ store
+        // to LDS makes hipcc drain the LDS-DMA queue first (it treats every pending global_load_lds as a possible alias:
+        // s_waitcnt vmcnt(0) -> one slot in flight -> half the fill rate).
+        auto flag = [&](int slot) {
+            if (lane == 0) asm volatile("ds_write_b32 %0, %1" :: "v"(ready_off + 4u * (unsigned)slot), "v"(1) : "memory");
+        };
+        auto stream = [&](auto depth_tag) {
+            constexpr int DEPTH = decltype(depth_tag)::value;
 #pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
+            for (int w = 0; w < WAVES; ++w) {
 #pragma unroll
-            for (int u = 0; u < LKS; ++u)
-                __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)(w * KPW + u) * 1024), (lptr_t)(w2_s + (w * LKS + u) * 1024), 16, 0, 2);   // nt
-            if (w >= 1) {
-                asm volatile("s_waitcnt vmcnt(15)" ::: "memory");                 // slot w - 1 has landed (two slots in flight at most)
-                // the flag goes out through an asm store: a C++ store to LDS makes hipcc drain the LDS-DMA queue first (it treats every
-                // pending global_load_lds as a possible alias: s_waitcnt vmcnt(0) -> one slot in flight -> half the fill rate)
-                if (lane == 0) asm volatile("ds_write_b32 %0, %1" :: "v"(ready_off + 4u * (unsigned)(w - 1)), "v"(1) : "memory");
+                for (int u = 0; u < LKS; ++u)
+                    __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)(w * KPW + u) * 1024), (lptr_t)(w2_s + (w * LKS + u) * 1024), 16, 0, 2);   // nt
+                if (w >= DEPTH - 1) {
+                    if constexpr (DEPTH == 2) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                    else if constexpr (DEPTH == 3) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(45)" ::: "memory");
+                    flag(w - (DEPTH - 1));
+                }
             }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) asm volatile("ds_write_b32 %0, %1" :: "v"(ready_off + 4u * (unsigned)(WAVES - 1)), "v"(1) : "memory");
+            if constexpr (DEPTH >= 4) { asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); flag(WAVES - 3); }
+            if constexpr (DEPTH >= 3) { asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); flag(WAVES - 2); }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            flag(WAVES - 1);
+        };
+        const int depth = (p.loader >> 8) & 7;
+        if (depth == 4) stream(std::integral_constant<int, 4>{});
+        else if (depth == 3) stream(std::integral_constant<int, 3>{});
+        else stream(std::integral_constant<int, 2>{});
         return;
     }
 
@@ -1652,6 +1668,7 @@ __global__ __launch_bounds__(576) void mlp_fused_ld_kernel(const bf16_t* W1_, co
     asm volatile("s_barrier" ::: "memory");                                       // (1) raw: the loads above stay in flight
     const MlpFusedArgs p = sv_late_args<MlpFusedArgs>(offsetof(MlpFusedKernarg, p));
     const long long budget = (long long)p.spin_ticks;
+    const int trigger = (p.loader >> 4) & 3;                 // when the loader may start: 0 last c_fc request issued, 1 one chunk to come, 2 loop done
     float c2v[RPW], c1v[RPW];
 #pragma unroll
     for (int i = 0; i < RPW; ++i) {
@@ -1674,11 +1691,14 @@ __global__ __launch_bounds__(576) void mlp_fused_ld_kernel(const bf16_t* W1_, co
                 __builtin_amdgcn_sched_barrier(0);
                 sk_load_full<CH>(ck[b], wptr, xptr, ks + (b + NB) * CH);
                 __builtin_amdgcn_sched_barrier(0);
-                if (ks + (b + NB) * CH + CH >= KPW && lane == 0)                   // that was this wave's last c_fc request
+                if (trigger == 0 && ks + (b + NB) * CH + CH >= KPW && lane == 0)   // that was this wave's last c_fc request
                     __hip_atomic_fetch_add(&sy->issued, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
+            if (trigger == 1 && ks + b * CH + 2 * CH == KPW && lane == 0)          // one chunk (4 KiB per wave) of c_fc still to come
+                __hip_atomic_fetch_add(&sy->issued, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
+    if (trigger == 2 && lane == 0) __hip_atomic_fetch_add(&sy->issued, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // c_fc stream consumed
     const long long t_loop1 = wall_clock64();
     const int ks2 = split * (WAVES * KPW) + wave * KPW;
     const u32x4* w2ptr = reinterpret_cast<const u32x4*>(W2_) + ((size_t)nt2 * KS2_ + ks2) * 64 + lane;

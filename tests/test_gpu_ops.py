@@ -296,6 +296,7 @@ def test_lm_head_with_folded_greedy_selection(V):
     assert int(idx[4]) == 9 and float(lg[4, 9]) == float(lg[4, V - 2])
     # every real logit of a row negative: the zero columns that pad the vocabulary to a multiple of 32 (logit 0) are no candidates
     Wn = -W.abs()
+    Wn[11] = Wn[10]; Wn[12] = Wn[13]                  # (no zero rows here: every real column is negative)
     xn = x.clone()
     xn[6] = x[7]
     xn[0] = x[0].abs()
