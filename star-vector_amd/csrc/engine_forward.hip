@@ -319,8 +319,6 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
                 ma.out_xp = e->xp_mlp; ma.out_KS = F / 16;
                 ma.W2 = L.c_proj2.Wp; ma.N2 = L.c_proj2.N; ma.N2pad = L.c_proj2.Npad; ma.K2 = L.c_proj2.Kpad; ma.splitk = L.c_proj2.splitk;
                 ma.ws = wsB; ma.ldws = e->ldws; ma.rows_ws = MT * 32; ma.err = e->d_bad; ma.spin_ticks = 500000;     // 5 ms at 100 MHz
-                // (round-5 sweep, tools/ab_exp.py: SV_EXP bits 13-14 = the loader's start trigger, bits 15-16 = slots in flight - 2)
-                ma.loader = (e->exp & 4096) ? 0 : (1 | (((e->exp >> 13) & 3) << 4) | ((2 + ((e->exp >> 15) & 3)) << 8));
                 ma.trace = (i == c.n_layer / 2) ? e->mlp_trace : nullptr;        // one layer in the middle of the step
                 // the launcher re-checks the shapes of THIS layer (sv_create looked at layer 0): a layer it refuses takes the two launches
                 // below -- never a silently skipped MLP

@@ -1344,7 +1344,11 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
 //              return IN ORDER -- a poll queued behind 16 KiB of its own weight requests completes after them.  Requesting all 16 KiB
 //              at once, moving the reduction to two "critical-path" waves, and the attention output projection as a phase 0 in front
 //              (a residual-stream ping-pong, 4 launches per layer) were all built, bit-identical, and slower or equal: removed.
-//              Separating the weight stream from the polls needs a loader wave + LDS-DMA ring (another K partition): not built.
+//              Round 5 BUILT the loader wave (a ninth wave per block streams the block's W2 share into LDS with global_load_lds, the
+//              consumers request nothing but polls after the publish): bit-identical, +2.0 ... +2.5 us per layer for every start
+//              trigger / depth tried -- polls issued at the publish find the pattern and every failed poll is a ~2 us round trip beside
+//              the CU's own fill stream; this form's polls ride behind the second half of the weights and arrive when the data is there.
+//              What is left over the 12.2 us that 67 MB + the phase-2 tail take is ~1 us.  profiles/mlp_fused_r05_loader_ab.log; removed.
 //   Results  per-wave k ranges, MFMA order, cross-wave reduction order, fold statistics and epilogues are those of the two kernels it
 //            replaces: bit-identical slabs (tests/test_gpu_e2e.py::test_fused_mlp_launch_equals_the_two_launches_bit_for_bit).
 //   Safety   needs all F/32 blocks resident at once (one per CU): enabled only when #CUs >= F/32 AND the engine owns the device -- two
@@ -1428,7 +1432,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // the publish -- HBM idle for 2.5 us); 8 KiB per wave in flight is what the steady state of the stand-alone kernels keeps (all
     // 16 KiB at once put 24 MB of reads in front of every tile store of the chip: second version, 6 us from loop end to publish).
     // (round 5 re-measured the alternative "reduce and publish with an empty queue, then the whole 16 KiB share": publish 0.9 us earlier, but the
-    //  MFMAs then wait 2.7 us for the weights -- 1100 vs 1066 us per step; removed.  What does separate the two is mlp_fused_ld_kernel below.)
+    //  MFMAs then wait 2.7 us for the weights -- 1100 vs 1066 us per step; removed.)
 #pragma unroll
     for (int u = 0; u < 8; ++u) w2[u] = __builtin_nontemporal_load(w2ptr + (size_t)u * 64);
 
@@ -1546,275 +1550,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         q[0] = t_start; q[1] = t_loop1; q[2] = t_pub; q[3] = t_go; q[4] = wall_clock64(); { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); q[5] = (long long)(xcc & 0xf); }
     }
 }
-// ------------------------------------------------------------------------------------------------
-// mlp_fused_ld_kernel (round 5; SV_EXP bit 4096 turns it OFF): the same launch with a NINTH wave per block whose only
-// job is the down projection's weights -- the "loader wave + LDS-DMA" form the header above says was missing.
-//   What the round-4 traces showed (profiles/mlp_fused_r04_ab.log): the eight waves of a block split K, so the c_fc tile can only be
-//   published when the SLOWEST wave has finished its loop and the reduction barrier has been passed; any weight request a wave issues
-//   in front of that barrier makes it block at issue (the CU's miss queue is full of the c_fc stream's tail) and delays the publish
-//   (7.9 us instead of 6.9), any request issued behind the publish leaves HBM idle for the ~2.5 us the reduction takes, and a wave's
-//   polls return IN ORDER behind its own weight loads.  One in-order queue per wave cannot serve both.
-//   Here  * waves 0-7 are EXACTLY the consumers of mlp_fused_kernel minus every W2 request but their last k-step (1 KiB per wave, so
-//           that 8 x 15 KiB of W2 + the 32 KiB reduction buffer fit the CU's 160 KiB of LDS): after the publish their queues hold
-//           nothing but the polls;
-//         * wave 8 starts when all eight consumers have ISSUED their last c_fc loads (an LDS counter), and streams the block's share
-//           of W2 -- 8 slots of 15 k-steps, `global_load_lds ... nt`, one fully coalesced 1 KiB per instruction, lane-linear in LDS
-//           = the MFMA A-fragment image -- at most two slots in flight (MI355X_MICROARCH.md, ldsdma-fill: one loader wave per CU
-//           sustains the CU's share of HBM); per slot it waits with a counted vmcnt and raises an LDS flag;
-//         * the consumers synchronise among themselves through LDS counters (an s_barrier would have to include the loader, which
-//           sits blocked at issue most of the time), and read W2 with ds_read_b128 as the slices complete.
-//   Arithmetic: per-wave k ranges, MFMA order (k-steps ascending), both cross-wave reductions and the epilogues are mlp_fused_kernel's,
-//   value for value: bit-identical slabs (tests/test_gpu_e2e.py::test_fused_mlp_launch_equals_the_two_launches_bit_for_bit runs both).
-//   Every wait is bounded by the wall clock (p.spin_ticks) and ends in the give-up code in *p.err: never a hang.
-// ------------------------------------------------------------------------------------------------
-#define MF2_LKS 15                                         // k-steps of a wave's W2 share that live in LDS (the 16th: a register load)
-struct Mf2Sync { int issued, red1, tile, red2, ready[8], pad[4]; };      // LDS; zeroed by the loader wave before the opening barrier
-// bounded wait on an LDS counter: false when the wall-clock budget is spent or another wave / an earlier launch of the step has already
-// given up (*err != 0: the step is void, nobody waits for anything any more)
-__device__ __forceinline__ bool mf2_wait(volatile int* ctr, int target, long long t0, long long budget, const int* err) {
-    for (int it = 0;; ++it) {
-        if (*ctr >= target) return true;
-        if ((it & 63) == 63 && (wall_clock64() - t0 > budget || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) return false;
-        __builtin_amdgcn_s_sleep(1);
-    }
-}
-__device__ __forceinline__ void mf2_arrive(int* ctr, int lane) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // this wave's LDS writes are performed before its arrival is counted
-    if (lane == 0) __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__global__ __launch_bounds__(576) void mlp_fused_ld_kernel(const bf16_t* W1_, const bf16_t* x1_, const bf16_t* W2_, int KS1_, int KS2_, int S_,
-                                                           MlpFusedArgs p_unused) {
-    constexpr int WAVES = 8, CH = 4, NB = 2, RPW = 2, KPW = 16, LKS = MF2_LKS;
-    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
-    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(sk_smem);          // [WAVES][16][64]
-    float2* fst_s = reinterpret_cast<float2*>(sk_smem + (size_t)WAVES * 16 * 64 * 4);      // [WAVES][32] partial row statistics
-    bf16_t* tile_s = reinterpret_cast<bf16_t*>(sk_smem + (size_t)WAVES * 16 * 64 * 4 + (size_t)WAVES * 32 * 8);   // 2 KiB: the c_fc tile
-    Mf2Sync* sy = reinterpret_cast<Mf2Sync*>(tile_s + 1024);
-    char* w2_s = reinterpret_cast<char*>(sy) + 64;                                // [WAVES][LKS][1 KiB]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int m = lane & 31, half = lane >> 5;
-    const int L = blockIdx.x, xcd = L & 7, ii = L >> 3;
-    const int T1 = gridDim.x, tpg = T1 >> 3;
-    const int split = xcd % S_, grp = xcd / S_;
-    const int nt2 = grp * tpg + ii;
-    const int nt1 = split * (T1 / S_) + nt2;
-    const long long t_start = wall_clock64();
-
-    if (wave == WAVES) {
-        // ---------------- the loader wave ----------------
-        if (lane < 16) reinterpret_cast<int*>(sy)[lane] = 0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");                                   // (1) the counters are armed
-        const MlpFusedArgs p = sv_late_args<MlpFusedArgs>(offsetof(MlpFusedKernarg, p));
-        // the c_fc stream goes first: nothing is requested here until every consumer wave has issued its last c_fc load
-        if (!mf2_wait(&sy->issued, WAVES, t_start, (long long)p.spin_ticks, p.err)) {
-            if (lane == 0) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        const char* src = reinterpret_cast<const char*>(W2_) + (((size_t)nt2 * KS2_ + (size_t)split * (WAVES * KPW)) * 64 + lane) * 16;
-        const unsigned ready_off = (unsigned)(size_t)(lptr_t)(&sy->ready[0]);    // LDS byte address of the flags
-        // DEPTH slots (15 KiB each) in flight: after issuing slot w wait until at most DEPTH - 1 slots are outstanding, i.e. slot
-        // w - (DEPTH - 1) has landed (loads return in order), and raise its flag.  The flags go out through asm stores: a C++ store
-        // to LDS makes hipcc drain the LDS-DMA queue first (it treats every pending global_load_lds as a possible alias:
-        // s_waitcnt vmcnt(0) -> one slot in flight -> half the fill rate).
-        auto flag = [&](int slot) {
-            if (lane == 0) asm volatile("ds_write_b32 %0, %1" :: "v"(ready_off + 4u * (unsigned)slot), "v"(1) : "memory");
-        };
-        auto stream = [&](auto depth_tag) {
-            constexpr int DEPTH = decltype(depth_tag)::value;
-#pragma unroll
-            for (int w = 0; w < WAVES; ++w) {
-#pragma unroll
-                for (int u = 0; u < LKS; ++u)
-                    __builtin_amdgcn_global_load_lds((gptr_t)(src + (size_t)(w * KPW + u) * 1024), (lptr_t)(w2_s + (w * LKS + u) * 1024), 16, 0, 2);   // nt
-                if (w >= DEPTH - 1) {
-                    if constexpr (DEPTH == 2) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-                    else if constexpr (DEPTH == 3) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(45)" ::: "memory");
-                    flag(w - (DEPTH - 1));
-                }
-            }
-            if constexpr (DEPTH >= 4) { asm volatile("s_waitcnt vmcnt(30)" ::: "memory"); flag(WAVES - 3); }
-            if constexpr (DEPTH >= 3) { asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); flag(WAVES - 2); }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            flag(WAVES - 1);
-        };
-        const int depth = (p.loader >> 8) & 7;
-        if (depth == 4) stream(std::integral_constant<int, 4>{});
-        else if (depth == 3) stream(std::integral_constant<int, 3>{});
-        else stream(std::integral_constant<int, 2>{});
-        return;
-    }
-
-    // ---------------- consumer waves: phase 1 = mlp_fused_kernel's, request for request ----------------
-    const int ks0 = wave * KPW;
-    const u32x4* wptr = reinterpret_cast<const u32x4*>(W1_) + ((size_t)nt1 * KS1_ + ks0) * 64 + lane;
-    const u32x4* xptr = reinterpret_cast<const u32x4*>(x1_) + (size_t)ks0 * 64 + lane;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    SkChunk<CH> ck[NB];
-    float fs1 = 0.f, fs2 = 0.f;
-    auto fold_acc = [&](const u32x4& xv) {
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            const float a = __uint_as_float(xv[w] << 16), b = __uint_as_float(xv[w] & 0xffff0000u);
-            fs1 += a + b;
-            fs2 = fmaf(a, a, fmaf(b, b, fs2));
-        }
-    };
-#pragma unroll
-    for (int b = 0; b < NB; ++b) sk_load_full<CH>(ck[b], wptr, xptr, b * CH);
-    asm volatile("s_barrier" ::: "memory");                                       // (1) raw: the loads above stay in flight
-    const MlpFusedArgs p = sv_late_args<MlpFusedArgs>(offsetof(MlpFusedKernarg, p));
-    const long long budget = (long long)p.spin_ticks;
-    const int trigger = (p.loader >> 4) & 3;                 // when the loader may start: 0 last c_fc request issued, 1 one chunk to come, 2 loop done
-    float c2v[RPW], c1v[RPW];
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        const int r = wave * RPW + i;
-        const int n = nt1 * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-        c1v[i] = n < p.N1 ? p.fold_c1[n] : 0.f;
-        c2v[i] = n < p.N1 ? p.fold_c2[n] : 0.f;
-    }
-    sk_settle<RPW>(c2v, c1v);
-#pragma unroll
-    for (int ks = 0; ks < KPW; ks += NB * CH) {
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-#pragma unroll
-            for (int u = 0; u < CH; ++u) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(ck[b].w[u]), as_frag4(ck[b].x[u]), acc, 0, 0, 0);
-                fold_acc(ck[b].x[u]);
-            }
-            if (ks + (b + NB) * CH < KPW) {
-                __builtin_amdgcn_sched_barrier(0);
-                sk_load_full<CH>(ck[b], wptr, xptr, ks + (b + NB) * CH);
-                __builtin_amdgcn_sched_barrier(0);
-                if (trigger == 0 && ks + (b + NB) * CH + CH >= KPW && lane == 0)   // that was this wave's last c_fc request
-                    __hip_atomic_fetch_add(&sy->issued, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            if (trigger == 1 && ks + b * CH + 2 * CH == KPW && lane == 0)          // one chunk (4 KiB per wave) of c_fc still to come
-                __hip_atomic_fetch_add(&sy->issued, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    }
-    if (trigger == 2 && lane == 0) __hip_atomic_fetch_add(&sy->issued, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // c_fc stream consumed
-    const long long t_loop1 = wall_clock64();
-    const int ks2 = split * (WAVES * KPW) + wave * KPW;
-    const u32x4* w2ptr = reinterpret_cast<const u32x4*>(W2_) + ((size_t)nt2 * KS2_ + ks2) * 64 + lane;
-    bool ok = true;
-
-    // K reduction across the waves (wave order) + LayerNorm fold epilogue: value for value mlp_fused_kernel's; the two block barriers
-    // are LDS counters over the 8 consumer waves
-    float v[RPW];
-    fs1 += __shfl_xor(fs1, 32, 64);
-    fs2 += __shfl_xor(fs2, 32, 64);
-    if (half == 0) fst_s[wave * 32 + m] = make_float2(fs1, fs2);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
-    mf2_arrive(&sy->red1, lane);
-    ok = mf2_wait(&sy->red1, WAVES, t_start, budget, p.err) && ok;
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        const int r = wave * RPW + i;
-        float t = red[0][r][lane];
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) t += red[w][r][lane];
-        v[i] = t;
-    }
-    {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int q = 0; q < WAVES; ++q) { const float2 t = fst_s[q * 32 + m]; s1 += t.x; s2 += t.y; }
-        const float invD = 1.0f / (float)p.fold_D;
-        const float mean = s1 * invD;
-        float var = s2 * invD - mean * mean;
-        var = var > 0.f ? var : 0.f;
-        const float rstd = rsqrtf(var + p.fold_eps);
-        const int r = wave * RPW;
-        const int nl = 8 * (r >> 2) + 4 * half + (r & 3);
-        float o[RPW];
-#pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            float x = 0.f;
-            if (nt1 * 32 + nl + i < p.N1) {
-                x = bfround(rstd * (v[i] - mean * c1v[i]) + c2v[i]);
-                if (p.act != ACT_NONE) x = sv_act(x, p.act);
-            }
-            o[i] = x;
-        }
-        *reinterpret_cast<uint32_t*>(tile_s + (((nl >> 4) * 64 + ((nl >> 3) & 1) * 32 + m) * 8 + (nl & 7))) = pack2bf(o[0], o[1]);
-    }
-    mf2_arrive(&sy->tile, lane);                            // (the arrival also says: this wave has finished READING red / fst_s)
-    ok = mf2_wait(&sy->tile, WAVES, t_start, budget, p.err) && ok;
-    const __amdgpu_buffer_rsrc_t rs_act = __builtin_amdgcn_make_buffer_rsrc(p.out_xp, 0, (unsigned)((size_t)p.out_KS * 1024), 0x00020000);
-    if (wave < 2) {
-        const u32x4 q = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(tile_s) + tid * 16);
-        __builtin_amdgcn_raw_buffer_store_b128(q, rs_act, nt1 * 2048 + tid * 16, 0, 16);          // sc1: write-through
-    }
-    const long long t_pub = wall_clock64();
-
-    // ---- phase 2: the polls go out at once (nothing else is in this wave's queue), then the one k-step of W2 that has no LDS slot ----
-    u32x4 x2[KPW];
-#pragma unroll
-    for (int u = 0; u < KPW; ++u) x2[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, (ks2 + u) * 1024 + lane * 16, 0, 16);   // sc1: L1 bypass
-    const u32x4 w2last = __builtin_nontemporal_load(w2ptr + (size_t)LKS * 64);
-    unsigned pending = 0xffffu;
-    int gave_up = 1;
-    for (int it = 0;; ++it) {
-        unsigned still = 0u;
-#pragma unroll
-        for (int u = 0; u < KPW; ++u) {
-            if (pending & (1u << u)) {
-                const bool bad = x2[u][0] == 0xffffffffu || x2[u][1] == 0xffffffffu || x2[u][2] == 0xffffffffu || x2[u][3] == 0xffffffffu;
-                if (__any(bad)) still |= 1u << u;
-            }
-        }
-        pending = still;
-        if (!pending) { gave_up = 0; break; }
-        if ((it & 7) == 7 && (wall_clock64() - t_pub > budget ||
-                              __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) break;
-        __builtin_amdgcn_s_sleep(8);
-#pragma unroll
-        for (int u = 0; u < KPW; ++u)
-            if (pending & (1u << u)) x2[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, (ks2 + u) * 1024 + lane * 16, 0, 16);
-    }
-    ok = mf2_wait(&sy->ready[wave], 1, t_start, budget, p.err) && ok;                    // this wave's 15 KiB of W2 are in LDS
-    if ((gave_up || !ok) && lane == 0) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the step's result is void
-    const long long t_go = wall_clock64();
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    const char* my_w2 = w2_s + (size_t)wave * LKS * 1024 + lane * 16;
-#pragma unroll
-    for (int u = 0; u < LKS; ++u) {
-        const u32x4 wf = *reinterpret_cast<const u32x4*>(my_w2 + u * 1024);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wf), as_frag4(x2[u]), acc, 0, 0, 0);
-    }
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(w2last), as_frag4(x2[LKS]), acc, 0, 0, 0);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
-    mf2_arrive(&sy->red2, lane);
-    (void)mf2_wait(&sy->red2, WAVES, t_start, budget, p.err);
-#pragma unroll
-    for (int i = 0; i < RPW; ++i) {
-        const int r = wave * RPW + i;
-        float t = red[0][r][lane];
-#pragma unroll
-        for (int w = 1; w < WAVES; ++w) t += red[w][r][lane];
-        v[i] = t;
-    }
-    {
-        const int r = wave * RPW;
-        const int n0 = nt2 * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-        *reinterpret_cast<float2*>(p.ws + ((size_t)split * p.rows_ws + m) * p.ldws + n0) = make_float2(v[0], v[1]);
-    }
-    if (p.trace && tid == 0) {
-        long long* q = p.trace + (size_t)L * 8;
-        q[0] = t_start; q[1] = t_loop1; q[2] = t_pub; q[3] = t_go; q[4] = wall_clock64(); { unsigned xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc)); q[5] = (long long)(xcc & 0xf); }
-    }
-}
-static size_t mlp_fused_ld_smem() { return (size_t)8 * 16 * 64 * 4 + (size_t)8 * 32 * 8 + 2048 + 64 + (size_t)8 * MF2_LKS * 1024; }
-
 static size_t mlp_fused_smem() { return (size_t)8 * 16 * 64 * 4 + (size_t)8 * 32 * 8 + 2048 + 64; }
 
 // 0 = launched; -1 = the shapes are outside the kernel's scope (the caller runs the two launches)
@@ -1823,8 +1558,7 @@ int launch_mlp_fused(const MlpFusedArgs& a, hipStream_t st) {
     if (a.splitk < 1 || 8 % a.splitk || T1 % 8 || KS1 != 8 * 16 || KS2 != a.splitk * 8 * 16) return -1;      // 16 k-steps per wave in both phases
     if (T2 * a.splitk != T1 || a.K2 != a.N1pad || a.N1 != a.N1pad || a.N2 != a.N2pad) return -1;
     if (!a.err || !a.fold_c1 || !a.fold_c2) return -1;
-    if (a.loader) mlp_fused_ld_kernel<<<T1, 576, mlp_fused_ld_smem(), st>>>(a.W1, a.x1, a.W2, KS1, KS2, a.splitk, a);
-    else mlp_fused_kernel<<<T1, 512, mlp_fused_smem(), st>>>(a.W1, a.x1, a.W2, KS1, KS2, a.splitk, a);
+    mlp_fused_kernel<<<T1, 512, mlp_fused_smem(), st>>>(a.W1, a.x1, a.W2, KS1, KS2, a.splitk, a);
     return 0;
 }
 
@@ -1836,7 +1570,6 @@ int init_gemm_kernels() {
     int r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (!r) r = init_mt2_attrs();
-    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_ld_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)mlp_fused_ld_smem());
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<bf16_t>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<float>),

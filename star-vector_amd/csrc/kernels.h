@@ -106,8 +106,6 @@ struct MlpFusedArgs {
     int spin_ticks;                          // wall-clock budget of a wave's wait in 100 MHz ticks (s_memrealtime): on expiry -- or when
                                              // *err is already set by another wave / launch -- the wave gives up (code 3)
     long long* trace;                        // optional [N1pad / 32][8] wall-clock stamps per block (tools/mlp_trace.py); nullptr in production
-    int loader;                              // != 0: mlp_fused_ld_kernel -- a ninth wave streams the down projection's weights into LDS (LDS-DMA), the
-                                             // consumer waves request none but their last k-step (round 5); 0: the round-4 form (SV_EXP bit 4096)
 };
 int launch_mlp_fused(const MlpFusedArgs& a, hipStream_t st);
 

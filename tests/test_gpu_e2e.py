@@ -845,7 +845,7 @@ def test_fused_mlp_launch_equals_the_two_launches_bit_for_bit():
     prompt = torch.tensor([[7, 11]] * B, dtype=torch.long, device=dev())
     emb = torch.cat([eng.adapter(eng.encode_image(img)), eng.embed_tokens(prompt)], 1)
     runs = {}
-    for mask in (0, 128, 128 + 4096):                                       # two launches | fused, loader wave (default) | fused, round-4 form
+    for mask in (0, 128):
         eng.set_exp(mask)
         lg = [eng.prefill(emb)]
         tok = lg[0].argmax(-1)
@@ -856,9 +856,8 @@ def test_fused_mlp_launch_equals_the_two_launches_bit_for_bit():
         assert eng.last_timing()["graph"]
         runs[mask] = (torch.stack(lg).cpu(), toks.cpu())
     eng.set_exp(0)
-    for mask in (128, 128 + 4096):
-        assert torch.equal(runs[0][0], runs[mask][0]), f"fused MLP launch (SV_EXP {mask}) changes the logits"
-        assert torch.equal(runs[0][1], runs[mask][1]), f"fused MLP launch (SV_EXP {mask}) changes the token stream"
+    assert torch.equal(runs[0][0], runs[128][0]), "fused MLP launch changes the logits"
+    assert torch.equal(runs[0][1], runs[128][1]), "fused MLP launch changes the token stream"
     assert runs[0][1].unique().numel() > 8                                  # not a degenerate stream
     eng.close()
     # an engine that owns its GPU (sv_config.exclusive_device) runs the fused launch by default: same tokens again

@@ -19,7 +19,7 @@ eng.load_random_weights(seed=1234)
 img = synthetic_images(torch, B, 224, seed=0).to(dev)
 prompt = torch.tensor([[7, 11]] * B, dtype=torch.long, device=dev)
 emb = torch.cat([eng.adapter(eng.encode_image(img)), eng.embed_tokens(prompt)], 1)
-mask = int(sys.argv[1]) if len(sys.argv) > 1 else 128       # SV_EXP mask: 128 = the fused launch; + 2048 = round 5's request order
+mask = int(sys.argv[1]) if len(sys.argv) > 1 else 128       # SV_EXP mask: 128 = the fused launch
 eng.set_exp(mask)
 print(f"=== SV_EXP {mask}")
 for rep in range(3):
