@@ -83,6 +83,46 @@ def test_linear_big_m_kernels_agree_bitwise(M, N, K, act, res):
     assert rel_err(y, ref) <= 2.2 * BF16_1ULP and mean_err(y, ref) <= 6e-4
 
 
+@pytest.mark.parametrize("M,N,K,act,res", [(8288, 2048, 2048, "none", True),             # prefill c_proj: 96 remainder rows, K = 8 chunks
+                                           (8288, 2048, 8192, "none", True),             # down projection: K = 32 chunks (the steady loop)
+                                           (8288, 8192, 2048, "gelu_tanh", False),       # c_fc: 256 column tiles
+                                           (8224, 1024, 1024, "none", True),             # ViT out_proj: 32 remainder rows, K = 4 chunks (no steady state)
+                                           (8224, 1024, 4096, "none", True),             # ViT MLP c_proj
+                                           (512 + 70, 1000, 1280, "quickgelu", False),   # ragged rows and columns, K = 5 chunks
+                                           (2048 + 33, 3072, 1536, "none", False),       # K = 6 chunks: one full pass of the 3-chunk loop
+                                           (2048 + 96, 1024, 640, "none", False)])       # K = 640: 40 k-steps, not a multiple of 16 -> one wave per tile
+def test_remainder_row_kernels_agree_with_the_tile_kernels_bitwise(M, N, K, act, res):
+    """Round 5: gemm_tail4_kernel (four waves per 32-row tile, activation fragments through LDS-DMA, weight ring and all waits by hand)
+    against gemm_tail_kernel (one wave per tile) and the 256^2 tile kernel computing the same rows as part of a 33rd tile row: the
+    same MFMA in the same ascending k order -> the same bits, whichever of the three runs the remainder rows (forms 2 / 3 / 1 of
+    sv_debug_set_gemm_form)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    b = (0.1 * torch.randn(N, generator=g)).bfloat16()
+    r = torch.randn(M, N, generator=g).bfloat16() if res else None
+    outs = {}
+    try:
+        for form in (1, 2, 3):
+            E.set_gemm_form(form)
+            outs[form] = E.op_linear(bf(x), bf(W), bf(b), bf(r) if res else None, act=act).cpu()
+    finally:
+        E.set_gemm_form(-1)
+    tail = M % 256
+    for form in (2, 3):
+        same = torch.equal(outs[form].view(torch.int16), outs[1].view(torch.int16))
+        if not same:
+            bad = (outs[form].view(torch.int16) != outs[1].view(torch.int16)).nonzero()
+            raise AssertionError(f"form {form} != the 256^2 kernel at {bad.shape[0]} elements, first (row, col) {bad[0].tolist()} (rows >= {M - tail} are remainder rows)")
+    ref = x.float() @ W.float().T + b.float()
+    if act != "none":
+        ref = {"gelu_tanh": lambda t: torch.nn.functional.gelu(t, approximate="tanh"),
+               "quickgelu": lambda t: t * torch.sigmoid(1.702 * t)}[act](ref.bfloat16().float())
+    if res:
+        ref = ref.bfloat16().float() + r.float()
+    assert rel_err(outs[2], ref) <= 2.2 * BF16_1ULP
+
+
 @pytest.mark.parametrize("M,N,K,act,res", [(8288, 2304, 2048, "none", False),          # prefill c_attn: 297 tiles of 256^2
                                            (8288, 8192, 2048, "gelu_tanh", True),       # c_fc shape + residual: 1056 tiles
                                            (8224, 3072, 1024, "quickgelu", False),      # ViT: K = 16 K-tiles
