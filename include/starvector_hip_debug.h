@@ -60,9 +60,8 @@ int  sv_debug_attn_plan(int32_t max_batch, int32_t n_kv_head, int32_t num_cus, i
  *                             decode loop is not affected (it carries its own plan per Linear). */
 int  sv_debug_set_col_tiles(int32_t col_tiles);
 /*   sv_debug_set_gemm_form    process-wide: every big-M GEMM launch takes ONE form -- 0 = 128x128 tiles, 1 = 256x256 tiles (rows not peeled),
-     2 = 256x256 tiles + the row remainder over a multiple of 256 through the tail kernel (four waves per 32-row tile where K allows, else one
-     wave per tile), 3 = the same with the one-wave-per-tile tail kernel always; -1 = the tuned choice (default).  The forms give the same
-     bits; the tests compare them through this switch. */
+     2 = 256x256 tiles + the row remainder over a multiple of 256 through the one-wave-per-tile tail kernel; -1 = the tuned choice (default).
+     The forms give the same bits; the tests compare them through this switch. */
 int  sv_debug_set_gemm_form(int32_t form);
 /* The decode attention (gpt_bigcode/modeling_gpt_bigcode.py:151-285, llm/starcoder2.py:22-27 sliding window) on
  * its own, over the engine's real paged KV pool, block table and context-split plan.  Test surface: the caller chooses q / K / V.

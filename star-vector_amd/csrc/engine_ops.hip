@@ -169,7 +169,7 @@ extern "C" int sv_debug_xcc_map(sv_engine* e, int32_t blocks, int32_t heavy, int
 }
 
 extern "C" int sv_debug_set_gemm_form(int32_t form) {
-    if (form < -1 || form > 3) return fail(SV_EINVAL, "sv_debug_set_gemm_form: -1 (tuned), 0 .. 3");
+    if (form < -1 || form > 2) return fail(SV_EINVAL, "sv_debug_set_gemm_form: -1 (tuned), 0 .. 2");
     set_gemm_form(form);
     return 0;
 }

@@ -809,156 +809,13 @@ __global__ __launch_bounds__(64) void gemm_tail_kernel(GemmArgs p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// gemm_tail4_kernel (round 5): the remainder rows with FOUR waves per block sharing one 32-row tile.
-//   gemm_tail_kernel's wave loads 2 KiB per k-step (its weight fragment AND its activation fragment) and a wave holds at most
-//   63 vector loads in flight: ~63 KiB per ~2 us of latency = one k-step per ~64 ns, against the 30 ns a dependent
-//   v_mfma_f32_32x32x16_bf16 takes -- the launch is bound by the loads one wave can keep outstanding (K = 8192: 34 us for 96 rows).
-//   Here the four waves of a block own four adjacent 32-column tiles of the SAME 32 rows: the activation fragments reach LDS once
-//   per block by LDS-DMA (global_load_lds: lane l fetches A[row0 + (l & 31)][16 ks + 8 (l >> 5) .. + 8] and the hardware drops it
-//   at lane * 16 -- the MFMA B-fragment image, conflict-free to read back), in chunks of 16 k-steps, three buffers, each wave
-//   issuing a quarter of a chunk two chunks ahead; a wave's own loads are its weight fragments only: 1 KiB per k-step, 48 k-steps
-//   in flight.  Same MFMA, operand roles and ascending k order per tile as every other big-M kernel: bit-identical
-//   (tests/test_gpu_ops.py::test_linear_big_m_kernels_agree_bitwise).
-//   ALL waits are by hand.  Left to hipcc, (a) a C++ LDS read behind a pending global_load_lds draws s_waitcnt vmcnt(0) (a possible
-//   alias in its view) and (b) the register ring pending across the loop's back edge draws a vmcnt(0) at the top of every iteration
-//   -- either way the whole ring drains every 16-48 k-steps and the kernel is no faster than one wave per tile.  So the weight loads
-//   and the LDS reads are asm statements (cdna guide section 5.7: register loads form (iii), LDS reads form (i)) and ONE counted wait
-//   per chunk covers both operands.  Issue order of a wave: A(0) A(1) W(0..47) | chunk c: WAIT(c), barrier, A(c + 2), then per k-step
-//   MFMA + W(k + 48).  At WAIT(c) the loads younger than everything chunk c needs number >= 32 while chunk c - 1 still refilled
-//   (c = 0: W(16..47); c >= 3: A(c) is followed by 16 + 4 + 16), so WAIT = vmcnt(32); once the refills have stopped, vmcnt(0).
-//   At most 56 loads are outstanding (the counter holds 63).
-// ------------------------------------------------------------------------------------------------
-#define GT4_CH 16          // k-steps per activation chunk (16 KiB of LDS)
-#define GT4_D 48           // weight k-steps in flight per wave = 3 chunks
-__global__ __launch_bounds__(256) void gemm_tail4_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) char a_s[3][GT4_CH * 1024];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int NT_total = (p.N + 31) >> 5;
-    const int nt_raw = blockIdx.x * 4 + wave, mt = blockIdx.y;
-    const int nt = nt_raw < NT_total ? nt_raw : NT_total - 1;          // a wave past the last tile streams it again, stores nothing
-    const int KS = p.K >> 4;
-    const int NCHK = KS / GT4_CH;                  // launcher: KS % 16 == 0, KS >= 64
-    int row = mt * 32 + (lane & 31);
-    const bool rok = row < p.M;
-    row = rok ? row : p.M - 1;
-    const bf16_t* xrow = p.A + (size_t)row * p.lda + 8 * (lane >> 5);
-    const char* wfr = reinterpret_cast<const char*>(p.Wp + ((size_t)nt * KS * 64 + lane) * 8);
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    bf16x8 w[GT4_D];
-    auto dma = [&](int c) {                        // this wave's quarter of chunk c: k-steps wave, wave + 4, wave + 8, wave + 12
-        char* buf = a_s[c % 3];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int j = wave + 4 * q;
-            lds_dma16(xrow + (size_t)(c * GT4_CH + j) * 16, buf + j * 1024);
-        }
-    };
-    // a weight fragment -> a ring register, invisible to hipcc's wait-count bookkeeping (it neither waits for it nor counts it)
-    auto wload = [&](bf16x8& dst, int ks) {
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(wfr + (size_t)ks * 1024) : "memory");
-    };
-    dma(0);
-    dma(1);
-#pragma unroll
-    for (int d = 0; d < GT4_D; ++d) wload(w[d], d);
-    // one chunk: CC = c % 3 at compile time (the ring and the activation buffers are statically indexed), REFILL = the ring is
-    // topped up behind every MFMA
-    auto chunk = [&](int c, auto cc_tag, auto refill_tag) {
-        constexpr int CC = decltype(cc_tag)::value;
-        constexpr bool REFILL = decltype(refill_tag)::value;
-        if (c == 0 || c - 1 < NCHK - 3) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_barrier" ::: "memory");     // every wave's quarter of chunk c has landed; every wave is done with chunk c - 1
-        __builtin_amdgcn_sched_barrier(0);          // no MFMA of this chunk above the wait (cdna guide rule 18)
-        if (c + 2 < NCHK) dma(c + 2);
-        const unsigned ab = (unsigned)(size_t)(lptr_t)(a_s[CC]) + (unsigned)lane * 16u;
-#pragma unroll
-        for (int g4 = 0; g4 < GT4_CH / 4; ++g4) {
-            bf16x8 x0, x1, x2, x3;
-            asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\tds_read_b128 %2, %4 offset:%7\n\t"
-                         "ds_read_b128 %3, %4 offset:%8\n\ts_waitcnt lgkmcnt(0)"
-                         : "=&v"(x0), "=&v"(x1), "=&v"(x2), "=&v"(x3)
-                         : "v"(ab), "i"((4 * g4 + 0) * 1024), "i"((4 * g4 + 1) * 1024), "i"((4 * g4 + 2) * 1024), "i"((4 * g4 + 3) * 1024)
-                         : "memory");
-            const bf16x8 xs[4] = {x0, x1, x2, x3};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int j = 4 * g4 + q;
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[CC * GT4_CH + j], xs[q], acc, 0, 0, 0);
-                if constexpr (REFILL) {
-                    __builtin_amdgcn_sched_barrier(0);      // the refill of a ring register stays BEHIND the MFMA that reads it
-                    wload(w[CC * GT4_CH + j], c * GT4_CH + j + GT4_D);
-                }
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    using T = std::true_type; using F = std::false_type;
-    using C0 = std::integral_constant<int, 0>; using C1 = std::integral_constant<int, 1>; using C2 = std::integral_constant<int, 2>;
-    int c = 0;
-    for (; c + 3 <= NCHK - 3; c += 3) { chunk(c, C0{}, T{}); chunk(c + 1, C1{}, T{}); chunk(c + 2, C2{}, T{}); }
-    // 3 .. 5 chunks left: up to two with refills, then the last three without (chunk-level, block-uniform conditions only)
-    if (c < NCHK) { if (c < NCHK - 3) chunk(c, C0{}, T{}); else chunk(c, C0{}, F{}); }
-    if (c + 1 < NCHK) { if (c + 1 < NCHK - 3) chunk(c + 1, C1{}, T{}); else chunk(c + 1, C1{}, F{}); }
-    if (c + 2 < NCHK) chunk(c + 2, C2{}, F{});
-    if (c + 3 < NCHK) chunk(c + 3, C0{}, F{});
-    if (c + 4 < NCHK) chunk(c + 4, C1{}, F{});
-    if (!rok || nt_raw >= NT_total) return;
-    const int half = lane >> 5;
-    const int m = row;
-    uint2 bq[4], rq[4];
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-        const int n = nt * 32 + rg * 8 + half * 4;
-        bq[rg] = (p.bias && n < p.N) ? *reinterpret_cast<const uint2*>(p.bias + n) : make_uint2(0u, 0u);
-        rq[rg] = (p.R && n < p.N) ? *reinterpret_cast<const uint2*>(p.R + (size_t)m * p.ldr + n) : make_uint2(0u, 0u);
-    }
-#pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-        const int n = nt * 32 + rg * 8 + half * 4;
-        if (n >= p.N) continue;       // N % 4 == 0
-        const float bj[4] = {__uint_as_float(bq[rg].x << 16), __uint_as_float(bq[rg].x & 0xffff0000u),
-                             __uint_as_float(bq[rg].y << 16), __uint_as_float(bq[rg].y & 0xffff0000u)};
-        const float4 c4 = p.cscale ? *reinterpret_cast<const float4*>(p.cscale + n) : make_float4(1.f, 1.f, 1.f, 1.f);
-        const float cs[4] = {c4.x, c4.y, c4.z, c4.w};
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float x = acc[rg * 4 + e] * cs[e] + bj[e];
-            if (p.act != ACT_NONE) x = sv_act(bfround(x), p.act);
-            v[e] = x;
-        }
-        if (p.R) {
-            v[0] = bfround(v[0]) + __uint_as_float(rq[rg].x << 16);
-            v[1] = bfround(v[1]) + __uint_as_float(rq[rg].x & 0xffff0000u);
-            v[2] = bfround(v[2]) + __uint_as_float(rq[rg].y << 16);
-            v[3] = bfround(v[3]) + __uint_as_float(rq[rg].y & 0xffff0000u);
-        }
-        if (p.out_f32) {
-            *reinterpret_cast<float4*>((float*)p.C + (size_t)m * p.ldc + n) = make_float4(v[0], v[1], v[2], v[3]);
-        } else {
-            uint2 o;
-            o.x = pack2bf(v[0], v[1]);
-            o.y = pack2bf(v[2], v[3]);
-            *reinterpret_cast<uint2*>((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
-        }
-    }
-}
-static std::atomic<int> g_tail_form{1};          // 1: gemm_tail4_kernel where its shape rule holds; 0: always one wave per tile (A/B, SV_TAIL_FORM=0)
+// (Round 5 built the four-waves-per-row-tile form of this kernel -- activation fragments once per block through LDS-DMA, a 48-deep weight ring per
+// wave, every wait by hand: bit-identical and slower on 7 of 8 prefill / ViT shapes, see profiles/gemm_tail4_r05_ab.log; removed.  The test that
+// put it next to this kernel and the 256^2 kernel stays: forms 2 / 1 of sv_debug_set_gemm_form.)
 // the remainder rows [tail x N] of a peeled GEMM (t = the GemmArgs of those rows)
 static void launch_gemm_tail(const GemmArgs& t, hipStream_t st) {
-    static const bool env_off = getenv("SV_TAIL_FORM") && atoi(getenv("SV_TAIL_FORM")) == 0;
-    const int KS = t.K >> 4;
-    if (!env_off && g_tail_form.load(std::memory_order_relaxed) && KS % GT4_CH == 0 && KS >= 64)
-        gemm_tail4_kernel<<<dim3(((t.N + 31) / 32 + 3) / 4, (t.M + 31) / 32), 256, 0, st>>>(t);
-    else
-        gemm_tail_kernel<<<dim3((t.N + 31) / 32, (t.M + 31) / 32), 64, 0, st>>>(t);
+    gemm_tail_kernel<<<dim3((t.N + 31) / 32, (t.M + 31) / 32), 64, 0, st>>>(t);
 }
-void set_gemm_tail_form(int form) { g_tail_form = form; }
 
 // Pick the tile kernel, and decide whether to peel a small row remainder, by a cost model fitted to measurements at
 // the prefill / ViT shapes (tools/bench_gemm.py).  A "round" is one wave of tiles over the chip (128^2: 2 blocks per
@@ -1113,15 +970,9 @@ void set_gemm_form(int form) { g_gemm_form = form; }
 void launch_gemm(const GemmArgs& a0, hipStream_t st) {
     const GemmArgs& a = a0;
     const int fixed = g_gemm_form.load();
-    // forms 0 / 1: one tile kernel, rows not peeled; 2 / 3: 256^2 tiles + the row remainder through the tail kernel, 3 = the one-wave-per-
-    // tile tail (gemm_tail_kernel) even where the four-wave form applies -- the test surface that puts every kernel next to the others
-    if (fixed >= 2) {
-        const int keep = g_tail_form.load();
-        if (fixed == 3) g_tail_form = 0;
-        launch_gemm_fixed(a, 1, 1, st);
-        g_tail_form = keep;
-        return;
-    }
+    // forms 0 / 1: one tile kernel, rows not peeled; 2: 256^2 tiles + the row remainder through the tail kernel -- the test surface that puts
+    // every kernel next to the others
+    if (fixed >= 2) { launch_gemm_fixed(a, 1, 1, st); return; }
     if (fixed >= 0) { launch_gemm_fixed(a, fixed, 0, st); return; }
     const GemmPlan pl = gemm_plan(a.M, a.N, a.K, a.act, 1);
     static const bool tune_on = !(getenv("SV_GEMM_AUTOTUNE") && atoi(getenv("SV_GEMM_AUTOTUNE")) == 0);

@@ -530,7 +530,7 @@ def op_linear(x, W, bias=None, residual=None, act="none", out_f32=False):
 
 def set_gemm_form(form: int) -> None:
     """-1: the tuned choice (default); 0 / 1: every big-M GEMM launch of the process takes 128^2 tiles / 256^2 tiles, rows not peeled;
-    2 / 3: 256^2 tiles + the row remainder through the tail kernel (3: always the one-wave-per-tile form) (sv_debug_set_gemm_form).
+    2: 256^2 tiles + the row remainder through the tail kernel (sv_debug_set_gemm_form).
     Same bits every way; test and A/B surface."""
     check(_lib.load().sv_debug_set_gemm_form(int(form)))
 

@@ -169,7 +169,7 @@ def test_argument_validation_precedes_any_device_work(lib):
         setattr(c, field, val)
         assert lib.sv_create(C.byref(c), C.byref(h)) == -22 and msg in err(), (field, err())
     # the measurement / A-B surfaces validate before they touch the device as well
-    assert lib.sv_debug_set_gemm_form(4) == -22 and lib.sv_debug_set_gemm_form(-2) == -22
+    assert lib.sv_debug_set_gemm_form(3) == -22 and lib.sv_debug_set_gemm_form(-2) == -22
     assert lib.sv_debug_set_gemm_form(1) == 0 and lib.sv_debug_set_gemm_form(-1) == 0
     buf = (C.c_int64 * 16)()
     assert lib.sv_debug_gemm_trace(100, 256, 256, 0, 1, buf, 1) == -22            # M < one tile

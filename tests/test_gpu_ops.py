@@ -90,12 +90,12 @@ def test_linear_big_m_kernels_agree_bitwise(M, N, K, act, res):
                                            (8224, 1024, 4096, "none", True),             # ViT MLP c_proj
                                            (512 + 70, 1000, 1280, "quickgelu", False),   # ragged rows and columns, K = 5 chunks
                                            (2048 + 33, 3072, 1536, "none", False),       # K = 6 chunks: one full pass of the 3-chunk loop
-                                           (2048 + 96, 1024, 640, "none", False)])       # K = 640: 40 k-steps, not a multiple of 16 -> one wave per tile
+                                           (2048 + 96, 1024, 640, "none", False)])       # K = 640: the patch embedding's padded K
 def test_remainder_row_kernels_agree_with_the_tile_kernels_bitwise(M, N, K, act, res):
-    """Round 5: gemm_tail4_kernel (four waves per 32-row tile, activation fragments through LDS-DMA, weight ring and all waits by hand)
-    against gemm_tail_kernel (one wave per tile) and the 256^2 tile kernel computing the same rows as part of a 33rd tile row: the
-    same MFMA in the same ascending k order -> the same bits, whichever of the three runs the remainder rows (forms 2 / 3 / 1 of
-    sv_debug_set_gemm_form)."""
+    """The remainder rows through gemm_tail_kernel (one wave per 32 x 32 tile, FORCED: form 2 of sv_debug_set_gemm_form -- the tuned
+    choice may or may not peel) against the 256^2 tile kernel computing the same rows as part of a 33rd tile row (form 1): the same
+    MFMA in the same ascending k order -> the same bits.  (Written in round 5 for a four-wave form of the tail kernel that was
+    bit-identical and slower -- profiles/gemm_tail4_r05_ab.log; the direct check of the peeled path stays.)"""
     g = torch.Generator().manual_seed(M + N + K)
     x = torch.randn(M, K, generator=g).bfloat16()
     W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
@@ -103,13 +103,13 @@ def test_remainder_row_kernels_agree_with_the_tile_kernels_bitwise(M, N, K, act,
     r = torch.randn(M, N, generator=g).bfloat16() if res else None
     outs = {}
     try:
-        for form in (1, 2, 3):
+        for form in (1, 2):
             E.set_gemm_form(form)
             outs[form] = E.op_linear(bf(x), bf(W), bf(b), bf(r) if res else None, act=act).cpu()
     finally:
         E.set_gemm_form(-1)
     tail = M % 256
-    for form in (2, 3):
+    for form in (2,):
         same = torch.equal(outs[form].view(torch.int16), outs[1].view(torch.int16))
         if not same:
             bad = (outs[form].view(torch.int16) != outs[1].view(torch.int16)).nonzero()
