@@ -12,7 +12,6 @@
 //    K/V byte is read once for all heads.  K and V^T live in the cache in MFMA fragment order: each
 //    wave-load is one contiguous 1 KiB.  The kernel also finishes the c_attn split-K reduction
 //    (+bias, bf16 round) for its sequence and appends the new token's K/V to the cache.
-#include <cstdlib>
 #include "kernels.h"
 
 namespace sv {
@@ -22,21 +21,18 @@ __device__ __forceinline__ int swap23(int x) { return (x & ~0xC) | ((x & 4) << 1
 // ------------------------------------------------------------------------------------------------
 // prefill
 // ------------------------------------------------------------------------------------------------
-// RT (HPB == 1, no causal mask, no window): 32-row query tiles per WAVE.  RT = 1: a block covers 128 query rows, grid.x = ceil(S / 128) --
-// for the ViT's S = 257 that is three blocks per (image, head) of which the third holds ONE row and still walks all five key tiles
-// (a third of the launch's blocks for 0.4 % of its rows; the kernel is bound by the per-tile latency chain global -> LDS -> barrier, not
-// by MFMA throughput, so an almost empty block costs a full slot).  RT = 3: ONE block per (image, head) covers up to 384 rows -- wave w
-// owns the tiles w, w + 4, w + 8 -- so every K / V tile is fetched and transposed once instead of three times, the two barriers of a
-// tile are followed by up to three tiles' worth of independent MFMA work, and 512 blocks are exactly one round of two blocks per CU.
-// Per-row arithmetic (key tile order, online-softmax updates, cast points) is unchanged: the same bits as RT = 1.
-template <int D, int HPB, int RT = 1>
+// (Round 5 measured a form with ONE block per (image, head) and three 32-row query tiles per wave for the ViT's S = 257 -- no third block for one
+// row, every K / V tile fetched and transposed once instead of three times, 512 blocks = one round: the same bits, and no faster (encoder attention
+// 1.04 vs 0.96 ms of TTFT on a box whose GEMMs ran 8 % slower).  The launch is bound by instruction issue per SIMD -- per 32 x 64 tile pair ~300 VALU
+// instructions of mask / exp / rescale / pack next to 16 MFMAs -- not by the global -> LDS -> barrier chain the restructure removed; 45 of those
+// tile pairs cover 257 x 257 scores where 32.3 would do (the 257th key and the 257th row each cost a whole tile).  profiles/SUMMARY_r05.md; removed.)
+template <int D, int HPB>
 __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs p) {      // two blocks per CU: <= 256 registers
 
     constexpr int KSTR = D + 8;          // K tile row stride (elements): +16 B pad -> conflict-free b128
     constexpr int VSTR = 64 + 8;         // V^T tile row stride
     constexpr int NKS = D / 16;          // k-steps of the QK^T product
     constexpr int NDV = D / 32;          // 32-wide dv tiles of the output
-    static_assert(RT == 1 || HPB == 1, "several row tiles per wave: the one-head-per-block form only");
     __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * KSTR];
     __shared__ __attribute__((aligned(16))) bf16_t Vt[D * VSTR];
 
@@ -45,47 +41,41 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs p)
     const int c = lane >> 5;
     const int b = blockIdx.z;
     const int S = p.S;
-    int head, q0[RT], qblock_end;
+    int head, q0, qblock_end;
     if (HPB == 1) {
         head = blockIdx.y;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) q0[rt] = blockIdx.x * (128 * RT) + (wave + 4 * rt) * 32;
-        qblock_end = blockIdx.x * (128 * RT) + 128 * RT;
+        q0 = blockIdx.x * 128 + wave * 32;
+        qblock_end = blockIdx.x * 128 + 128;
     } else {
         head = blockIdx.y * HPB + wave;
-        q0[0] = blockIdx.x * 32;
-        qblock_end = q0[0] + 32;
+        q0 = blockIdx.x * 32;
+        qblock_end = q0 + 32;
     }
     const int kvh = (HPB == 1 ? head : blockIdx.y * HPB) / p.kv_group;
-    int qabs[RT];
+    const int qabs = q0 + (lane & 31);
+    const int qrow = qabs < S ? qabs : S - 1;
+
     // Q fragments (B operand): lane (q = l&31, c = l>>5) holds Q[q][16 s + 8 c .. +8]
-    bf16x8 qf[RT][NKS];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        qabs[rt] = q0[rt] + (lane & 31);
-        const int qrow = qabs[rt] < S ? qabs[rt] : S - 1;
+    bf16x8 qf[NKS];
+    {
         const bf16_t* qp = p.q + ((size_t)b * S + qrow) * p.q_row_stride + (size_t)head * p.q_head_stride + c * 8;
 #pragma unroll
-        for (int s = 0; s < NKS; ++s) qf[rt][s] = as_frag(*reinterpret_cast<const uint4*>(qp + s * 16));
+        for (int s = 0; s < NKS; ++s) qf[s] = as_frag(*reinterpret_cast<const uint4*>(qp + s * 16));
     }
 
-    f32x16 accO[RT][NDV];
-    float m_run[RT], l_run[RT];
+    f32x16 accO[NDV];
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        m_run[rt] = -INFINITY; l_run[rt] = 0.f;
+    for (int t = 0; t < NDV; ++t)
 #pragma unroll
-        for (int t = 0; t < NDV; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accO[rt][t][r] = 0.f;
-    }
+        for (int r = 0; r < 16; ++r) accO[t][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
 
     int last = (qblock_end < S ? qblock_end : S) - 1;        // last query row of the block
     const int ntiles = p.causal ? (last / 64 + 1) : ((S + 63) / 64);
     // sliding window (StarCoder2, prompts longer than the window): key tiles entirely below the block's first query's window
     // are never loaded; inside the first tiles a query row may see nothing yet (statistics stay at -inf / 0, see m_use below)
     const int win = p.causal ? p.window : 0;
-    const int qfirst = HPB == 1 ? blockIdx.x * (128 * RT) : q0[0];
+    const int qfirst = HPB == 1 ? blockIdx.x * 128 : q0;
     const int kt0 = (win > 0 && qfirst - win + 1 > 0) ? (qfirst - win + 1) / 64 : 0;
     const bf16_t* kbase = p.k + (size_t)b * S * p.kv_row_stride + (size_t)kvh * p.kv_head_stride;
     const bf16_t* vbase = p.v + (size_t)b * S * p.kv_row_stride + (size_t)kvh * p.kv_head_stride;
@@ -136,9 +126,6 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs p)
         __syncthreads();
         if (kt + 1 < ntiles) gload(kt + 1);
 
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-        if (RT > 1 && q0[rt] >= S) continue;                 // (wave-uniform) this wave has no such row tile
         // S^T = K . Q^T : two 32-key sub-tiles
         f32x16 accS[2];
 #pragma unroll
@@ -148,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs p)
 #pragma unroll
             for (int s = 0; s < NKS; ++s) {
                 const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (32 * j + (lane & 31)) * KSTR + 16 * s + 8 * c);
-                accS[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[rt][s], accS[j], 0, 0, 0);
+                accS[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], accS[j], 0, 0, 0);
             }
         }
         // mask + online softmax; lane holds keys kt*64 + 32 j + (r&3) + 8 (r>>2) + 4 c of its query row
@@ -158,15 +145,15 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt * 64 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * c;
-                const bool ok = key < S && (!p.causal || key <= qabs[rt]) && (win <= 0 || key > qabs[rt] - win);
+                const bool ok = key < S && (!p.causal || key <= qabs) && (win <= 0 || key > qabs - win);
                 const float sc = ok ? accS[j][r] * p.scale : -INFINITY;
                 accS[j][r] = sc;
                 mt = fmaxf(mt, sc);
             }
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run[rt], mt);
+        const float m_new = fmaxf(m_run, mt);
         const float m_use = m_new == -INFINITY ? 0.f : m_new;    // a row that has seen no key yet (window): exp(-inf - 0) = 0, no NaN
-        const float alpha = __expf(m_run[rt] - m_use);
+        const float alpha = __expf(m_run - m_use);
         float ls = 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -176,8 +163,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs p)
                 accS[j][r] = pv;
                 ls += pv;
             }
-        l_run[rt] = l_run[rt] * alpha + ls;
-        m_run[rt] = m_new;
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
         // P fragments (B operand of O^T = V^T.P^T): element e of k-step (j, s2) = accS[j][8 s2 + e]
         bf16x8 pf[2][2];
 #pragma unroll
@@ -194,35 +181,31 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs p)
 #pragma unroll
         for (int t = 0; t < NDV; ++t) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) accO[rt][t][r] *= alpha;
+            for (int r = 0; r < 16; ++r) accO[t][r] *= alpha;
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
                     const bf16x8 vf = *reinterpret_cast<const bf16x8*>(
                         Vt + (32 * t + (lane & 31)) * VSTR + 32 * j + 16 * s2 + 8 * c);
-                    accO[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[j][s2], accO[rt][t], 0, 0, 0);
+                    accO[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[j][s2], accO[t], 0, 0, 0);
                 }
         }
-        }   // rt
     }
 
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qabs < S) {
+        bf16_t* op = p.o + ((size_t)b * S + qabs) * p.o_row_stride + (size_t)head * D;
 #pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const float l_tot = l_run[rt] + __shfl_xor(l_run[rt], 32, 64);
-        const float inv = 1.0f / l_tot;
-        if (qabs[rt] < S) {
-            bf16_t* op = p.o + ((size_t)b * S + qabs[rt]) * p.o_row_stride + (size_t)head * D;
+        for (int t = 0; t < NDV; ++t)
 #pragma unroll
-            for (int t = 0; t < NDV; ++t)
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    uint2 o;
-                    o.x = pack2bf(accO[rt][t][rg * 4 + 0] * inv, accO[rt][t][rg * 4 + 1] * inv);
-                    o.y = pack2bf(accO[rt][t][rg * 4 + 2] * inv, accO[rt][t][rg * 4 + 3] * inv);
-                    *reinterpret_cast<uint2*>(op + 32 * t + 8 * rg + 4 * c) = o;
-                }
-        }
+            for (int rg = 0; rg < 4; ++rg) {
+                uint2 o;
+                o.x = pack2bf(accO[t][rg * 4 + 0] * inv, accO[t][rg * 4 + 1] * inv);
+                o.y = pack2bf(accO[t][rg * 4 + 2] * inv, accO[t][rg * 4 + 3] * inv);
+                *reinterpret_cast<uint2*>(op + 32 * t + 8 * rg + 4 * c) = o;
+            }
     }
 }
 
@@ -233,13 +216,6 @@ void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st) {
         if (a.head_dim == 128) attn_prefill_kernel<128, 4><<<grid, 256, 0, st>>>(a);
         else attn_prefill_kernel<64, 4><<<grid, 256, 0, st>>>(a);
     } else {
-        // the ViT's MHSA (no mask, head_dim 64, S = 257 / 577): one block per (image, head) walking three row tiles per wave where the
-        // sequence fits 384 rows (see RT above); SV_ATTN_PREFILL_RT1=1 keeps the 128-row blocks (A/B)
-        static const bool rt1 = getenv("SV_ATTN_PREFILL_RT1") && atoi(getenv("SV_ATTN_PREFILL_RT1")) != 0;
-        if (!rt1 && !a.causal && a.window == 0 && a.head_dim == 64 && a.S > 128 && a.S <= 384) {
-            attn_prefill_kernel<64, 1, 3><<<dim3(1, a.H, a.B), 256, 0, st>>>(a);
-            return;
-        }
         dim3 grid((a.S + 127) / 128, a.H, a.B);
         if (a.head_dim == 128) attn_prefill_kernel<128, 1><<<grid, 256, 0, st>>>(a);
         else attn_prefill_kernel<64, 1><<<grid, 256, 0, st>>>(a);

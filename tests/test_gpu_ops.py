@@ -248,8 +248,7 @@ def test_linear_skinny_logits_epilogue(M, V, K):
     (2, 1, 2, 2, 64, 0), (2, 17, 2, 2, 64, 0), (2, 257, 16, 16, 64, 0),       # ViT MHSA shapes
     (3, 19, 2, 1, 128, 1), (2, 259, 16, 1, 128, 1),                           # decoder MQA prefill
     (1, 64, 4, 4, 128, 1), (1, 130, 4, 4, 128, 1), (1, 70, 8, 2, 64, 1), (1, 300, 16, 1, 128, 0),
-    # round 5: one block per (image, head), three 32-row tiles per wave for 128 < S <= 384 (no mask, head_dim 64): the edges of that
-    # rule, a sequence where some waves own two tiles and some three, and the SigLIP tower's 577 rows (back on 128-row blocks)
+    # more unmasked head_dim-64 shapes around the 128-row block edges, and the SigLIP tower's 577 rows
     (2, 129, 2, 2, 64, 0), (1, 160, 3, 3, 64, 0), (2, 384, 4, 4, 64, 0), (1, 385, 2, 2, 64, 0), (1, 577, 2, 2, 64, 0), (1, 128, 2, 2, 64, 0)])
 def test_attention_prefill(B, S, H, Hkv, hd, causal):
     g = torch.Generator().manual_seed(B + S + H + hd)
