@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs p)
     for (int t = 0; t < NDV; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) accO[t][r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;                     // m_run: running row maximum in the log2 domain (score * scale * log2 e)
+    const float c2 = p.scale * 1.4426950408889634f;
 
     int last = (qblock_end < S ? qblock_end : S) - 1;        // last query row of the block
     const int ntiles = p.causal ? (last / 64 + 1) : ((S + 63) / 64);
@@ -145,15 +146,13 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs p)
         // (round 5: ~300 VALU instructions next to 16 MFMAs per tile pair).  Same values either way.
         const int k_lo = kt * 64, k_hi = kt * 64 + 63;
         const bool interior = k_hi < S && (!p.causal || k_hi <= q0) && (win <= 0 || k_lo > q0 + 31 - win);
+        // the softmax runs in the log2 domain on the RAW products: p = 2^(s * c2 - m2) with c2 = scale * log2(e) -- one fma + one v_exp_f32 per
+        // score instead of mul (scale), sub, mul (log2 e), v_exp_f32; the row maximum is taken before the scaling (c2 > 0)
         if (interior) {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float sc = accS[j][r] * p.scale;
-                    accS[j][r] = sc;
-                    mt = fmaxf(mt, sc);
-                }
+                for (int r = 0; r < 16; ++r) mt = fmaxf(mt, accS[j][r]);
         } else {
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -161,21 +160,21 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs p)
                 for (int r = 0; r < 16; ++r) {
                     const int key = kt * 64 + 32 * j + (r & 3) + 8 * (r >> 2) + 4 * c;
                     const bool ok = key < S && (!p.causal || key <= qabs) && (win <= 0 || key > qabs - win);
-                    const float sc = ok ? accS[j][r] * p.scale : -INFINITY;
+                    const float sc = ok ? accS[j][r] : -INFINITY;
                     accS[j][r] = sc;
                     mt = fmaxf(mt, sc);
                 }
         }
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64)) * c2;             // (-inf stays -inf)
         const float m_new = fmaxf(m_run, mt);
-        const float m_use = m_new == -INFINITY ? 0.f : m_new;    // a row that has seen no key yet (window): exp(-inf - 0) = 0, no NaN
-        const float alpha = __expf(m_run - m_use);
+        const float m_use = m_new == -INFINITY ? 0.f : m_new;    // a row that has seen no key yet (window): 2^(-inf - 0) = 0, no NaN
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
         float ls = 0.f;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float pv = __expf(accS[j][r] - m_use);
+                const float pv = __builtin_amdgcn_exp2f(fmaf(accS[j][r], c2, -m_use));
                 accS[j][r] = pv;
                 ls += pv;
             }
