@@ -407,6 +407,12 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
             const unsigned off = ((blockIdx.y * gridDim.x + blockIdx.x) * (AD_WAVES * 64) + threadIdx.x) * 16u;
             if (off < q.poison_bytes)
                 *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(q.poison) + off) = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            else if (q.poison2 && off - q.poison_bytes < q.poison2_bytes)
+                *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(q.poison2) + (off - q.poison_bytes)) = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+        } else if (q.poison2) {
+            const unsigned off = ((blockIdx.y * gridDim.x + blockIdx.x) * (AD_WAVES * 64) + threadIdx.x) * 16u;
+            if (off < q.poison2_bytes)
+                *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(q.poison2) + off) = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
         }
     };
     if (split >= act) {

@@ -476,6 +476,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     A(dalloc(e, &e->h_xp, R * D));
     A(dalloc(e, &e->hl, R * D));
     A(dalloc(e, &e->xp_a, R * D));
+    A(dalloc(e, &e->xp_f, R * D));
     A(dalloc(e, &e->xp_attn, R * D));
     A(dalloc(e, &e->xp_mlp, R * F));
     A(dalloc(e, &e->ws, (size_t)8 * R * e->ldws));
@@ -565,6 +566,9 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
                           dn.splitk >= 1 && 8 % dn.splitk == 0 && dn.Kpad / 16 == dn.splitk * 128 && (dn.Npad / 32) * dn.splitk == T1 &&
                           dn.Kpad == fc.Npad;
         if (e->mlp_fused_ok && getenv("SV_MLP_TRACE")) rc = dalloc(e, &e->mlp_trace, (size_t)T1 * 8);
+        // the row update + c_attn launch (rowops.hip): the projection's whole weight share per wave is 4 k-steps, every block resident
+        const Linear& ca = e->dec[0].c_attn;
+        e->rc_fused_ok = !ca.fp8 && rowln_cattn_fits(D, ca.Npad, ca.Kpad, ca.splitk, dn.splitk, e->num_cus);
     }
     if (rc) { sv_destroy(e); return rc; }
     *out = e;

@@ -283,25 +283,49 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
         prof_mark(e, PK_SKINNY, st);
         launch_gemm_skinny(a, st);
     };
+    // Row update + c_attn as ONE launch (rowops.hip rowln_cattn_kernel): on when the engine owns its GPU (like the fused MLP launch: its
+    // blocks wait for blocks of the same launch); SV_EXP bit 8192 = off, 16384 = on without exclusive_device (A/B).  The GEMM blocks
+    // recognise unwritten activations by the 0xFFFF'FFFF pattern: xp_a gets it from a memset node at the head of the step (layer 0) and
+    // from the attention launch of layer i for layer i + 1; ln_f's output therefore lives in its own buffer.  Not inside the profiling
+    // legs (they time the row updates and the GEMMs apart).
+    const bool rc = fold6 && e->rc_fused_ok && MT == 1 && !(e->exp & 8192) && (c.exclusive_device || (e->exp & 16384)) &&
+                    !e->only_skinny && !e->skip_skinny && !e->prof_on;
+    const unsigned xpa_bytes = (unsigned)((size_t)(D / 16) * 1024);
+    if (rc) (void)hipMemsetAsync(e->xp_a, 0xFF, xpa_bytes, st);
     for (int i = 0; i < c.n_layer; ++i) {
         DecLayer& L = e->dec[i];
-        row_update();                                            // embedding or the previous layer's down-proj -> LN1(h)
-        skinny(e->xp_a, L.c_attn, SK_OUT_PARTIAL, wsA);
+        bool rc_done = false;
+        if (rc) {
+            SkinnyArgs a;
+            memset(&a, 0, sizeof(a));
+            a.xp = e->xp_a; a.Wp = L.c_attn.Wp; a.MT = MT; a.Npad = L.c_attn.Npad; a.K = L.c_attn.Kpad; a.N = L.c_attn.N;
+            a.out_mode = SK_OUT_PARTIAL; a.splitk = L.c_attn.splitk; a.ws = wsA; a.ldws = e->ldws;
+            prof_mark(e, PK_SKINNY, st);
+            rc_done = launch_rowln_cattn(ru, a, e->d_bad, 500000, st) == 0;          // 5 ms at 100 MHz; a refusal takes the two launches
+        }
+        if (!rc_done) {
+            row_update();                                        // embedding or the previous layer's down-proj -> LN1(h)
+            skinny(e->xp_a, L.c_attn, SK_OUT_PARTIAL, wsA);
+        }
         // c_fc + down projection in ONE launch (gemm.hip mlp_fused_kernel): on when the engine owns its GPU (sv_config.exclusive_device);
         // SV_EXP bit 128 forces it on, bit 512 off (in-process A/B, tools/ab_exp.py).  It recognises unwritten activations by a pattern
         // that an EARLIER launch of the layer leaves in the buffer: the attention launch (16 bytes per thread: free in a latency-bound
         // kernel), or -- grid too small, or the profiling leg without attention -- the projection kernel (+0.5 us there)
         const bool fused = fold6 && e->mlp_fused_ok && !(e->exp & 512) && (c.exclusive_device || (e->exp & 128));
         const size_t pat_bytes = (size_t)(F / 16) * 1024;
-        const bool attn_poisons = fused && !e->only_skinny && pat_bytes <= (size_t)B * e->nkv * attn_max_splits(e) * 512 * 16;
+        const size_t poison_cap = (size_t)B * e->nkv * attn_max_splits(e) * 512 * 16;      // 16 bytes per thread of the attention launch
+        const bool attn_poisons = fused && !e->only_skinny && pat_bytes + (rc ? xpa_bytes : 0u) <= poison_cap;
+        const bool attn_poisons_xpa = rc && i + 1 < c.n_layer && (fused ? attn_poisons : xpa_bytes <= poison_cap);
         if (!e->only_skinny) {
             AttnDecodeArgs ad;
             attn_decode_args(e, i, B, wsA, L.c_attn.splitk, L.c_attn.bias, e->xp_attn, ad);
             if (i == c.n_layer / 2) ad.trace = e->attn_trace;             // SV_ATTN_TRACE=1: one layer in the middle of the step
             if (attn_poisons) { ad.poison = e->xp_mlp; ad.poison_bytes = (unsigned)pat_bytes; }
+            if (attn_poisons_xpa) { ad.poison2 = e->xp_a; ad.poison2_bytes = xpa_bytes; }     // the next layer's rowln_cattn launch
             prof_mark(e, PK_ATTN, st);
             launch_attn_decode(ad, st);
         }
+        if (rc && i + 1 < c.n_layer && !attn_poisons_xpa) (void)hipMemsetAsync(e->xp_a, 0xFF, xpa_bytes, st);      // (tiny grids: no room in the attention launch)
         if (fold6) {
             // attention output projection over the whole K per block: h += bf(x W^T + b) in place (+ partial row statistics), then
             // c_fc on the raw h with ln_2 folded into its weights / epilogue: no slabs, no row-update launch (decode_cols.hip)
@@ -346,8 +370,10 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
         const LNp& nxt = (i + 1 < c.n_layer) ? e->dec[i + 1].ln1 : e->ln_f;
         ru.ws = wsB; ru.splitk = L.c_proj2.splitk; ru.bias = L.c_proj2.bias; ru.g = nxt.g; ru.b = nxt.b;
     }
+    bf16_t* xp_last = rc ? e->xp_f : e->xp_a;                    // (xp_a carries the pattern / the last layer's operand when the launches are fused)
+    ru.xp_out = xp_last;
     row_update();                                                // + bias + residual, ln_f
-    skinny(e->xp_a, e->lm_head, SK_OUT_F32, nullptr);
+    skinny(xp_last, e->lm_head, SK_OUT_F32, nullptr);
     prof_mark(e, PK_SAMPLE, st);      // closes the lm_head interval; whatever follows is sampling
 }
 
@@ -487,7 +513,7 @@ extern "C" int sv_decode_step(sv_engine* e, const int32_t* dev_tokens, int32_t B
     SVCHECK(copy_logits_out(e, B, dev_logits, st));
     HIPCHECK(hipGetLastError());
     // the fused MLP launch reports a give-up through d_bad (code 3): logits computed from its unwritten activations are void
-    if (e->mlp_fused_ok) SVCHECK(check_finite_logits(e, st, "sv_decode_step"));
+    if (e->mlp_fused_ok || e->rc_fused_ok) SVCHECK(check_finite_logits(e, st, "sv_decode_step"));
     return 0;
 }
 

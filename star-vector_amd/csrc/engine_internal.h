@@ -111,6 +111,8 @@ struct sv_engine {
     bf16_t* h_xp = nullptr;         // residual stream of the decode step in fragment order (6-launch layer)
     bool fold6 = false;             // 6 launches per layer: slab-free attention output projection + ln_2 folded into c_fc
     bool fold_ready = false;
+    bf16_t* xp_f = nullptr;         // ln_f output of the last row update (the lm_head's operand) when xp_a belongs to the fused row-update + c_attn launch
+    bool rc_fused_ok = false;       // row update + c_attn as one launch (rowops.hip rowln_cattn_kernel) fits this engine: shapes + all blocks resident
     bool mlp_fused_ok = false;      // the MLP half as one launch (gemm.hip mlp_fused_kernel) fits this engine: shapes + one block per CU
     long long* attn_trace = nullptr;// SV_ATTN_TRACE=1: wall-clock stamps of the decode attention of the middle layer, [rows * kv heads * splits][16]
     long long* mlp_trace = nullptr; // SV_MLP_TRACE=1: wall-clock stamps of the LAST fused MLP launch, [F / 32][8] (sv_debug_mlp_trace)
@@ -120,6 +122,7 @@ struct sv_engine {
                                     //   2 the 7-launch layer (no LayerNorm fold);
                                     //   (1: was the row update as one wave per row: 0.218 vs 0.131 ms per step, removed)
                                     //   8 (at sv_create only) the round 1-2 split-K rule of the decode GEMMs
+                                    //   8192 / 16384 (round 5) the row update and c_attn as ONE launch (rowln_cattn_kernel) forced off / on; default: on iff exclusive_device
                                     //   1024 (round 5) greedy selection as its own launch again (argmax_kernel), not folded into the lm_head epilogue
                                     //   128 / 512 (round 4) the MLP half of a layer as ONE launch (mlp_fused_kernel) forced on / off; default:
                                     //       on iff sv_config.exclusive_device

@@ -145,6 +145,19 @@ struct RowUpdateArgs {
     int M, D;
 };
 void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st);
+// the row update and the split-K projection that consumes its LayerNorm output (c_attn) as ONE launch (rowops.hip, rowln_cattn_kernel):
+// late arguments of the launch; the leading scalars (slabs, bias, residual stream, weights, shapes) travel as kernel parameters
+struct RowCattnArgs {
+    const bf16_t* g; const bf16_t* b; float eps; int D;
+    const bf16_t* wte; const bf16_t* wpe; const int32_t* tokens; const int32_t* positions;      // embedding mode (slabs == nullptr)
+    bf16_t* xp_out;                                          // LayerNorm output in fragment order = the projection's operand; pre-filled with
+                                                             // the 0xFFFF'FFFF pattern by an earlier launch of the step
+    float* ws_out; int ldws_out;                             // the projection's fp32 slabs [splitk][32][ldws]
+    int* err; int spin_ticks;                                // give-up code 3 after spin_ticks x 10 ns of waiting (never a hang)
+};
+// 0 = launched; -1 = outside the kernel's scope (the caller runs the two launches).  sk.xp must be ru.xp_out.
+int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, int spin_ticks, hipStream_t st);
+bool rowln_cattn_fits(int D, int Npad, int K, int splitk, int splitk_ru, int num_cus);
 
 // ---- embeddings ---------------------------------------------------------------------------------
 void launch_im2col(const bf16_t* img, bf16_t* out, int B, int img_size, int patch, int Kpad, hipStream_t st);
@@ -203,6 +216,8 @@ struct AttnDecodeArgs {
     int window;                                            // sliding window: keys pos - window < j <= pos (0 = all)
     int groups_per_block;                                  // 32-key groups a block takes before another context split joins (0 = 4)
     long long* trace;                                      // optional [B * n_kv * max_splits][16] wall-clock stamps (tools/attn_trace.py); nullptr in production
+    void* poison2; unsigned poison2_bytes;                 // a second buffer filled the same way, by the threads behind those of the first (the next layer's
+                                                           // LayerNorm output buffer: rowln_cattn_kernel)
     void* poison; unsigned poison_bytes;                   // optional: a buffer the launch fills with 0xFF bytes, 16 per thread, before anything else (the
                                                            // "not written yet" pattern of the fused MLP launch later in the layer): this kernel is bound by
                                                            // latencies, a store per thread costs it nothing -- in gemm_cols_resid_kernel it cost 0.5 us

@@ -1,5 +1,7 @@
 // Row-wise (HBM/L2-bound) kernels of the path: LayerNorm flavours, embeddings, im2col, adapter norms.
 // All loads/stores are 16-byte bf16x8 vectors; statistics in fp32 with wave64 shuffle reductions.
+#include <cstddef>
+#include <cstring>
 #include "kernels.h"
 
 namespace sv {
@@ -261,6 +263,225 @@ void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st) {
         row_update_ln_kernel<1024><<<a.M, 1024, a.D * sizeof(float), st>>>(a.ws, a.bias, a.h, a.g, a.b, a.splitk, a.ldws, a.rows_ws, a.ldh, a.D, a.M, a);
     else
         row_update_ln_kernel<256><<<a.M, 256, a.D * sizeof(float), st>>>(a.ws, a.bias, a.h, a.g, a.b, a.splitk, a.ldws, a.rows_ws, a.ldh, a.D, a.M, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// rowln_cattn_kernel (round 5): the row update AND the c_attn projection that consumes it, as ONE launch.
+//   Two launches today: row_update_ln_kernel (32 blocks: slabs + bias + residual -> h, LayerNorm -> xp; 4.95 us, a chain of latencies
+//   that touches ~1 MB) and gemm_skinny_kernel<8, false> (288 blocks: 9.4 MB of c_attn weights -> 4 fp32 slabs; 5.2 us of which ~1.3 us
+//   stream) with a kernel boundary between them: 10.2 us per layer, 24 % of the decode step, nearly all of it latency.
+//   What round 4 learned about hand-offs inside a launch (gemm.hip, mlp_fused_kernel): the price sits in the CONSUMER CU's own memory
+//   queue, and polls must not queue behind weight requests.  This pair is the favourable case: a c_attn block's WHOLE weight share is
+//   4 KiB per wave (K slice 512 = 4 k-steps per wave), so it is requested at t = 0, has landed long before the row update publishes,
+//   and from then on the consumer's queue holds nothing but its polls; the producers are 32 blocks that start first.
+//   Grid = 32 row blocks + (N / 32) x splitk GEMM blocks, 512 threads, all co-resident (two blocks per CU: <= 128 VGPRs, 34 KiB LDS).
+//   Row role   blocks 0 .. 31 (waves 4-7 leave at once): row_update_ln_kernel<256>, value for value; the LayerNorm output goes out with
+//              16-byte sc1 (write-through) stores.
+//   GEMM role  block 32 + L: the (tile, K slice) of gemm_skinny_kernel's XCD-aware assignment for block L; weights -> registers, then the
+//              wave polls the 4 KiB of activations of ITS k-steps with sc1 loads and recognises "not written yet" by the data: the buffer
+//              is pre-filled with the bf16 pair 0xFFFF'FFFF -- by the attention launch of the layer before (AttnDecodeArgs::poison2),
+//              for layer 0 by a memset node at the head of the step -- which no finite LayerNorm output produces.  Bounded by the wall
+//              clock (give-up code 3 in *err: never a hang).  Then gemm_skinny_kernel<8, false>'s 4 MFMAs, LDS reduction in wave order
+//              and slab store: bit-identical slabs.
+//   Needs every block resident at once: on for an engine that owns its GPU (sv_config.exclusive_device), like the fused MLP launch.
+// ------------------------------------------------------------------------------------------------
+struct RowCattnKernarg { const float* ws; const bf16_t* bias; bf16_t* h; const bf16_t* Wp; int splitk_ru, ldws, rows_ws, M, KS, ks_per_split, n_tiles, S;
+                         RowCattnArgs p; };
+__global__ __launch_bounds__(512, 4) void rowln_cattn_kernel(const float* ws_, const bf16_t* bias_, bf16_t* h_, const bf16_t* Wp_, int splitk_ru_,
+                                                             int ldws_, int rows_ws_, int M_, int KS_, int ks_per_split_, int n_tiles_, int S_,
+                                                             RowCattnArgs p_unused) {
+    extern __shared__ __attribute__((aligned(16))) char rc_smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int ROWB = 32;                                 // row-role blocks (a multiple of 8: the GEMM blocks keep their XCDs)
+    if (blockIdx.x < ROWB) {
+        // ------------------------------------------------ row role ------------------------------------------------
+        const int row = blockIdx.x;
+        if (row >= M_ || wave >= 4) return;
+        constexpr int THREADS = 256, NW = 4;
+        float* hrow = reinterpret_cast<float*>(rc_smem);                          // [D]
+        float* redbuf = hrow + 2048;                                              // [2 * NW]
+        const int KSD = KS_, D = KS_ << 4, NC = D >> 3;                           // launcher: K of the projection == D <= 2048 -> one 8-column chunk per thread
+        const int c = tid;
+        const bool on = c < NC;
+        bf16_t* hc = h_ + xp_index(row >> 5, KSD, row & 31, c * 8);               // the residual stream lives in fragment order
+        uint4 gq = make_uint4(0, 0, 0, 0), bq2 = gq, bq = gq, hq = gq;
+        float4 sa[4], sb[4];
+        // what the leading (preloaded) arguments reach goes out first: bias, residual and up to 4 slabs; then the late arguments
+        if (on && ws_ != nullptr) {
+            bq = *reinterpret_cast<const uint4*>(bias_ + c * 8);
+            hq = *reinterpret_cast<const uint4*>(hc);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sp = j < splitk_ru_ ? j : splitk_ru_ - 1;
+                const float* src = ws_ + ((size_t)sp * rows_ws_ + row) * ldws_ + c * 8;
+                sa[j] = *reinterpret_cast<const float4*>(src);
+                sb[j] = *reinterpret_cast<const float4*>(src + 4);
+            }
+        }
+        const RowCattnArgs p = sv_late_args<RowCattnArgs>(offsetof(RowCattnKernarg, p));
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = 0.f;
+        if (on) {
+            gq = *reinterpret_cast<const uint4*>(p.g + c * 8);
+            bq2 = *reinterpret_cast<const uint4*>(p.b + c * 8);
+            if (ws_ == nullptr) {                                                 // embedding mode: h = bf(wte[tok] + wpe[pos])
+                const int tok = p.tokens[row], pos = p.positions[row];
+                float a[8], w[8];
+                unpack8(*reinterpret_cast<const uint4*>(p.wte + (size_t)tok * D + c * 8), a);
+                if (p.wpe) {
+                    unpack8(*reinterpret_cast<const uint4*>(p.wpe + (size_t)pos * D + c * 8), w);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = bfround(a[e] + w[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) f[e] = a[e];
+                }
+            } else {                                                              // h = bf(h + bf(sum of the slabs in slab order + bias))
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                                     // slab order (launcher: at most 4 slabs)
+                    if (j < splitk_ru_) {
+                        v[0] += sa[j].x; v[1] += sa[j].y; v[2] += sa[j].z; v[3] += sa[j].w;
+                        v[4] += sb[j].x; v[5] += sb[j].y; v[6] += sb[j].z; v[7] += sb[j].w;
+                    }
+                }
+                float bb[8], hh[8];
+                unpack8(bq, bb);
+                unpack8(hq, hh);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = bfround(hh[e] + bfround(v[e] + bb[e]));
+            }
+            *reinterpret_cast<uint4*>(hc) = pack8(f);
+        }
+        float s = 0.f;
+        if (on) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { hrow[c * 8 + e] = f[e]; s += f[e]; }
+        }
+        s = wave_sum(s);
+        if (lane == 0) redbuf[wave] = s;
+        __syncthreads();
+        float ssum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) ssum += redbuf[w];
+        const float mean = ssum / (float)D;
+        float q = 0.f;
+        if (on) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = hrow[c * 8 + e] - mean; q += d * d; }
+        }
+        q = wave_sum(q);
+        if (lane == 0) redbuf[NW + wave] = q;
+        __syncthreads();
+        float qsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) qsum += redbuf[NW + w];
+        const float rstd = rsqrtf(qsum / (float)D + p.eps);
+        if (on) {
+            float gg[8], bb[8], o[8];
+            unpack8(gq, gg);
+            unpack8(bq2, bb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (hrow[c * 8 + e] - mean) * rstd * gg[e] + bb[e];
+            const uint4 ov = pack8(o);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.xp_out, 0, (unsigned)((size_t)KSD * 1024), 0x00020000);
+            u32x4 q4 = {ov.x, ov.y, ov.z, ov.w};
+            __builtin_amdgcn_raw_buffer_store_b128(q4, rs, (int)(xp_index(0, KSD, row & 31, c * 8) * 2), 0, 16);      // sc1: write-through
+        }
+        return;
+    }
+    // ------------------------------------------------ GEMM role ------------------------------------------------
+    constexpr int WAVES = 8, KPW = 4, RPW = 2;               // 4 k-steps per wave (launcher-checked): the whole share fits 16 registers
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(rc_smem);          // [WAVES][16][64]
+    const long long t_start = wall_clock64();
+    const int L = blockIdx.x - ROWB;
+    const int xcd = L & 7, ii = L >> 3;
+    const int tpg = (n_tiles_ * S_) >> 3;                    // tiles per XCD (gemm_skinny_kernel, flags & 1)
+    const int split = xcd % S_;
+    const int nt = (xcd / S_) * tpg + ii;
+    const int m = lane & 31, half = lane >> 5;
+    const int ks0 = split * ks_per_split_ + wave * KPW;
+    const u32x4* wptr = reinterpret_cast<const u32x4*>(Wp_) + ((size_t)nt * KS_ + ks0) * 64 + lane;
+    u32x4 w[KPW];
+#pragma unroll
+    for (int u = 0; u < KPW; ++u) w[u] = __builtin_nontemporal_load(wptr + (size_t)u * 64);          // streamed once, depends on nothing
+    const RowCattnArgs p = sv_late_args<RowCattnArgs>(offsetof(RowCattnKernarg, p));
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(p.xp_out, 0, (unsigned)((size_t)KS_ * 1024), 0x00020000);
+    u32x4 x[KPW];
+#pragma unroll
+    for (int u = 0; u < KPW; ++u) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (ks0 + u) * 1024 + lane * 16, 0, 16);      // sc1: L1 bypass
+    unsigned pending = (1u << KPW) - 1u;                     // k-steps whose activations are not (known to be) complete: wave-uniform
+    int gave_up = 1;
+    for (int it = 0;; ++it) {
+        unsigned still = 0u;
+#pragma unroll
+        for (int u = 0; u < KPW; ++u) {
+            if (pending & (1u << u)) {
+                // rows >= M of the tile are never written (the pattern stays): only the lanes of live rows are examined
+                const bool bad = m < M_ && (x[u][0] == 0xffffffffu || x[u][1] == 0xffffffffu || x[u][2] == 0xffffffffu || x[u][3] == 0xffffffffu);
+                if (__any(bad)) still |= 1u << u;
+            }
+        }
+        pending = still;
+        if (!pending) { gave_up = 0; break; }
+        if ((it & 7) == 7 && (wall_clock64() - t_start > (long long)p.spin_ticks ||
+                              __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) break;
+        __builtin_amdgcn_s_sleep(4);
+#pragma unroll
+        for (int u = 0; u < KPW; ++u)
+            if (pending & (1u << u)) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (ks0 + u) * 1024 + lane * 16, 0, 16);
+    }
+    if (gave_up && lane == 0) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the step's result is void
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < KPW; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(w[u]), as_frag4(x[u]), acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    float v[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = wave * RPW + i;
+        float t = red[0][r][lane];
+#pragma unroll
+        for (int q = 1; q < WAVES; ++q) t += red[q][r][lane];
+        v[i] = t;
+    }
+    {
+        const int r = wave * RPW;
+        const int n0 = nt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+        *reinterpret_cast<float2*>(p.ws_out + ((size_t)split * 32 + m) * p.ldws_out + n0) = make_float2(v[0], v[1]);
+    }
+}
+
+// shape rule of the launch (host arithmetic; sv_create): D = hidden = K of the projection, Npad x K weight, split-K `splitk` slabs, the row
+// update in front sums `splitk_ru` slabs; blocks = 32 + (Npad / 32) * splitk, all of which must be resident at once (two per CU)
+bool rowln_cattn_fits(int D, int Npad, int K, int splitk, int splitk_ru, int num_cus) {
+    const int KS = K / 16, NT = Npad / 32;
+    if (D > 2048 || (D & 15) || K != D || splitk < 1 || 8 % splitk || KS % (splitk * 8) || KS / splitk / 8 != 4) return false;
+    if ((NT * splitk) % 8 || NT % (8 / splitk) || splitk_ru < 1 || splitk_ru > 4) return false;
+    return 32 + NT * splitk <= 2 * num_cus;
+}
+int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, int spin_ticks, hipStream_t st) {
+    const int KS = sk.K / 16, NT = sk.Npad / 32;
+    if (ru.D > 2048 || (ru.D & 15) || ru.ldh != 0 || ru.M < 1 || ru.M > 32 || sk.MT != 1 || sk.Wq || sk.out_mode != SK_OUT_PARTIAL) return -1;
+    if (ru.ws && (ru.splitk < 1 || ru.splitk > 4)) return -1;              // the row role sums at most 4 slabs
+    if (sk.splitk < 1 || 8 % sk.splitk || KS % (sk.splitk * 8) || KS / sk.splitk / 8 != 4) return -1;      // 4 k-steps per wave
+    if ((NT * sk.splitk) % 8 || NT % (8 / sk.splitk) || sk.K != ru.D || sk.xp != ru.xp_out || !err) return -1;
+    RowCattnArgs a;
+    memset(&a, 0, sizeof(a));
+    a.g = ru.g; a.b = ru.b; a.eps = ru.eps; a.D = ru.D; a.wte = ru.wte; a.wpe = ru.wpe; a.tokens = ru.tokens; a.positions = ru.positions;
+    a.xp_out = ru.xp_out; a.ws_out = sk.ws; a.ldws_out = sk.ldws; a.err = err; a.spin_ticks = spin_ticks;
+    const size_t smem = (size_t)8 * 16 * 64 * 4 + 64;
+    rowln_cattn_kernel<<<32 + NT * sk.splitk, 512, smem, st>>>(ru.ws, ru.bias, ru.h, sk.Wp, ru.splitk, ru.ldws, ru.rows_ws, ru.M, KS, KS / sk.splitk,
+                                                                NT, sk.splitk, a);
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------------

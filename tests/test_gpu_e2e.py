@@ -963,3 +963,59 @@ def test_folded_greedy_selection_equals_the_argmax_launch_token_for_token():
     eng.generate(emb, do_sample=True, temperature=1.0, top_p=0.9, top_k=50, seed=3, **kw)
     assert torch.equal(eng.generate(emb, **kw).cpu(), ref)
     eng.close()
+
+
+def test_row_update_and_c_attn_as_one_launch_bit_for_bit():
+    """Round 5 (rowops.hip rowln_cattn_kernel, SV_EXP bit 16384 on a non-exclusive engine): the row update and the c_attn projection
+    behind it as ONE launch -- 32 row blocks publish the LayerNorm output with write-through stores, the 288 GEMM blocks hold their
+    whole weight share in registers from t = 0 and poll the activations in band (the buffer carries the 0xFFFF'FFFF pattern from a
+    memset node / the attention launch of the layer before).  Same per-wave k ranges, MFMA and reduction order as the two kernels:
+    logits and tokens must be IDENTICAL -- alone, together with the fused MLP launch, at 32 / 13 / 1 rows, under the graph and eager,
+    with EOS bookkeeping, with sampling, through sv_decode_step, and back to back (the pattern is re-armed every step)."""
+    import starvector_amd as sva
+    B = 32
+    eng = sva.HipEngine(sva.EngineConfig(max_batch=B, max_seq_len=259 + 200))
+    eng.load_random_weights(seed=13)
+    g = torch.Generator().manual_seed(9)
+    img = torch.randn(B, 3, 224, 224, generator=g).to(torch.bfloat16).to(dev())
+    prompt = torch.tensor([[7, 11]] * B, dtype=torch.long, device=dev())
+    emb = torch.cat([eng.adapter(eng.encode_image(img)), eng.embed_tokens(prompt)], 1)
+    S0 = emb.shape[1]
+    kw = dict(max_length=S0 + 170, eos_token_id=-1, pad_token_id=49152)
+    runs = {}
+    for mask in (0, 16384, 128, 128 + 16384):
+        eng.set_exp(mask)
+        lg = [eng.prefill(emb)]
+        tok = lg[0].argmax(-1)
+        for _ in range(5):
+            lg.append(eng.decode_step(tok))
+            tok = lg[-1].argmax(-1)
+        toks = eng.generate(emb, **kw)
+        assert eng.last_timing()["graph"]
+        small = eng.generate(emb[:13].contiguous(), **kw)
+        one = eng.generate(emb[5:6].contiguous(), **kw)
+        samp = eng.generate(emb, do_sample=True, temperature=1.0, top_p=0.9, top_k=50, seed=3, **kw)
+        again = eng.generate(emb, **kw)
+        runs[mask] = (torch.stack(lg).cpu(), toks.cpu(), small.cpu(), one.cpu(), samp.cpu(), again.cpu())
+    eng.set_exp(16384)
+    os.environ["SV_NO_GRAPH"] = "1"
+    try:
+        eager = eng.generate(emb, **kw).cpu()
+        assert not eng.last_timing()["graph"]
+    finally:
+        os.environ.pop("SV_NO_GRAPH", None)
+    eng.set_exp(0)
+    ref = runs[0]
+    assert ref[1].unique().numel() > 8
+    assert torch.equal(ref[1], ref[5]) and torch.equal(ref[2], ref[1][:13]) and torch.equal(ref[3][0], ref[1][5])
+    for mask in (16384, 128, 128 + 16384):
+        for k, what in enumerate(["teacher-forced logits", "tokens (32 rows)", "tokens (13 rows)", "tokens (1 row)", "sampled tokens", "second call"]):
+            assert torch.equal(runs[mask][k], ref[k]), f"SV_EXP {mask}: {what} differ from the unfused launches"
+    assert torch.equal(eager, ref[1])
+    eng.close()
+    # an engine that owns its GPU runs both fused launches by default: same tokens again
+    own = sva.HipEngine(sva.EngineConfig(max_batch=B, max_seq_len=259 + 200, exclusive_device=True))
+    own.load_random_weights(seed=13)
+    emb2 = torch.cat([own.adapter(own.encode_image(img)), own.embed_tokens(prompt)], 1)
+    assert torch.equal(own.generate(emb2, **kw).cpu(), ref[1])
+    own.close()
