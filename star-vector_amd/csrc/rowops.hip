@@ -411,29 +411,28 @@ __global__ __launch_bounds__(512, 4) void rowln_cattn_kernel(const float* ws_, c
     for (int u = 0; u < KPW; ++u) w[u] = __builtin_nontemporal_load(wptr + (size_t)u * 64);          // streamed once, depends on nothing
     const RowCattnArgs p = sv_late_args<RowCattnArgs>(offsetof(RowCattnKernarg, p));
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(p.xp_out, 0, (unsigned)((size_t)KS_ * 1024), 0x00020000);
+    // 2304 waves polling 4 KiB each would put ~9 MB per poll round on the L2s while the 32 row blocks are still loading (first form,
+    // measured: +1 us per layer over the two launches).  So: (1) nobody polls before the row update can possibly have published
+    // (~2 us of s_sleep: its loads alone take that long); (2) a wave watches ONE k-step (1 KiB) -- a row is published by one store
+    // instruction of its block, so its k-steps turn up together -- and only then fetches the other three, re-checking them.
+    __builtin_amdgcn_s_sleep(64);
     u32x4 x[KPW];
-#pragma unroll
-    for (int u = 0; u < KPW; ++u) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (ks0 + u) * 1024 + lane * 16, 0, 16);      // sc1: L1 bypass
-    unsigned pending = (1u << KPW) - 1u;                     // k-steps whose activations are not (known to be) complete: wave-uniform
     int gave_up = 1;
     for (int it = 0;; ++it) {
-        unsigned still = 0u;
+        x[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ks0 * 1024 + lane * 16, 0, 16);                 // sc1: L1 bypass
+        const bool bad0 = m < M_ && (x[0][0] == 0xffffffffu || x[0][1] == 0xffffffffu || x[0][2] == 0xffffffffu || x[0][3] == 0xffffffffu);
+        if (!__any(bad0)) {
 #pragma unroll
-        for (int u = 0; u < KPW; ++u) {
-            if (pending & (1u << u)) {
-                // rows >= M of the tile are never written (the pattern stays): only the lanes of live rows are examined
-                const bool bad = m < M_ && (x[u][0] == 0xffffffffu || x[u][1] == 0xffffffffu || x[u][2] == 0xffffffffu || x[u][3] == 0xffffffffu);
-                if (__any(bad)) still |= 1u << u;
-            }
+            for (int u = 1; u < KPW; ++u) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (ks0 + u) * 1024 + lane * 16, 0, 16);
+            bool bad = false;
+#pragma unroll
+            for (int u = 1; u < KPW; ++u)      // rows >= M of the tile are never written (the pattern stays): only live rows are examined
+                bad = bad || (m < M_ && (x[u][0] == 0xffffffffu || x[u][1] == 0xffffffffu || x[u][2] == 0xffffffffu || x[u][3] == 0xffffffffu));
+            if (!__any(bad)) { gave_up = 0; break; }
         }
-        pending = still;
-        if (!pending) { gave_up = 0; break; }
         if ((it & 7) == 7 && (wall_clock64() - t_start > (long long)p.spin_ticks ||
                               __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) break;
-        __builtin_amdgcn_s_sleep(4);
-#pragma unroll
-        for (int u = 0; u < KPW; ++u)
-            if (pending & (1u << u)) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (ks0 + u) * 1024 + lane * 16, 0, 16);
+        __builtin_amdgcn_s_sleep(8);
     }
     if (gave_up && lane == 0) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the step's result is void
     f32x16 acc;
