@@ -412,27 +412,49 @@ __global__ __launch_bounds__(512, 4) void rowln_cattn_kernel(const float* ws_, c
     const RowCattnArgs p = sv_late_args<RowCattnArgs>(offsetof(RowCattnKernarg, p));
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(p.xp_out, 0, (unsigned)((size_t)KS_ * 1024), 0x00020000);
     // 2304 waves polling 4 KiB each would put ~9 MB per poll round on the L2s while the 32 row blocks are still loading (first form,
-    // measured: +1 us per layer over the two launches).  So: (1) nobody polls before the row update can possibly have published
-    // (~2 us of s_sleep: its loads alone take that long); (2) a wave watches ONE k-step (1 KiB) -- a row is published by one store
-    // instruction of its block, so its k-steps turn up together -- and only then fetches the other three, re-checking them.
-    __builtin_amdgcn_s_sleep(64);
+    // measured: +1 us per layer over the two launches).  So nobody polls before the row update can possibly have published (its loads
+    // alone take ~2 us): p.delay x 64 clocks of s_sleep first.  p.mode 0: a wave watches ONE k-step (1 KiB) -- a row is published by one
+    // store instruction of its block, so its k-steps turn up together -- and only then fetches the other three, re-checking them;
+    // p.mode 1: all four k-steps per poll, only the incomplete ones re-requested.
+    if (p.delay >= 96) { __builtin_amdgcn_s_sleep(96); if (p.delay > 96) __builtin_amdgcn_s_sleep(31); }
+    else if (p.delay >= 64) __builtin_amdgcn_s_sleep(64);
+    else if (p.delay >= 32) __builtin_amdgcn_s_sleep(32);
     u32x4 x[KPW];
     int gave_up = 1;
-    for (int it = 0;; ++it) {
-        x[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ks0 * 1024 + lane * 16, 0, 16);                 // sc1: L1 bypass
-        const bool bad0 = m < M_ && (x[0][0] == 0xffffffffu || x[0][1] == 0xffffffffu || x[0][2] == 0xffffffffu || x[0][3] == 0xffffffffu);
-        if (!__any(bad0)) {
+    auto patt = [&](const u32x4& v) { return m < M_ && (v[0] == 0xffffffffu || v[1] == 0xffffffffu || v[2] == 0xffffffffu || v[3] == 0xffffffffu); };
+    if (p.mode == 0) {
+        for (int it = 0;; ++it) {
+            x[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ks0 * 1024 + lane * 16, 0, 16);                 // sc1: L1 bypass
+            if (!__any(patt(x[0]))) {
 #pragma unroll
-            for (int u = 1; u < KPW; ++u) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (ks0 + u) * 1024 + lane * 16, 0, 16);
-            bool bad = false;
+                for (int u = 1; u < KPW; ++u) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (ks0 + u) * 1024 + lane * 16, 0, 16);
+                bool bad = false;
 #pragma unroll
-            for (int u = 1; u < KPW; ++u)      // rows >= M of the tile are never written (the pattern stays): only live rows are examined
-                bad = bad || (m < M_ && (x[u][0] == 0xffffffffu || x[u][1] == 0xffffffffu || x[u][2] == 0xffffffffu || x[u][3] == 0xffffffffu));
-            if (!__any(bad)) { gave_up = 0; break; }
+                for (int u = 1; u < KPW; ++u) bad = bad || patt(x[u]);      // rows >= M of the tile are never written: only live rows are examined
+                if (!__any(bad)) { gave_up = 0; break; }
+            }
+            if ((it & 7) == 7 && (wall_clock64() - t_start > (long long)p.spin_ticks ||
+                                  __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) break;
+            __builtin_amdgcn_s_sleep(8);
         }
-        if ((it & 7) == 7 && (wall_clock64() - t_start > (long long)p.spin_ticks ||
-                              __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) break;
-        __builtin_amdgcn_s_sleep(8);
+    } else {
+#pragma unroll
+        for (int u = 0; u < KPW; ++u) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (ks0 + u) * 1024 + lane * 16, 0, 16);
+        unsigned pending = (1u << KPW) - 1u;
+        for (int it = 0;; ++it) {
+            unsigned still = 0u;
+#pragma unroll
+            for (int u = 0; u < KPW; ++u)
+                if ((pending & (1u << u)) && __any(patt(x[u]))) still |= 1u << u;
+            pending = still;
+            if (!pending) { gave_up = 0; break; }
+            if ((it & 7) == 7 && (wall_clock64() - t_start > (long long)p.spin_ticks ||
+                                  __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) break;
+            __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+            for (int u = 0; u < KPW; ++u)
+                if (pending & (1u << u)) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (ks0 + u) * 1024 + lane * 16, 0, 16);
+        }
     }
     if (gave_up && lane == 0) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the step's result is void
     f32x16 acc;
@@ -467,7 +489,7 @@ bool rowln_cattn_fits(int D, int Npad, int K, int splitk, int splitk_ru, int num
     if ((NT * splitk) % 8 || NT % (8 / splitk) || splitk_ru < 1 || splitk_ru > 4) return false;
     return 32 + NT * splitk <= 2 * num_cus;
 }
-int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, int spin_ticks, hipStream_t st) {
+int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, int spin_ticks, hipStream_t st, int delay, int mode) {
     const int KS = sk.K / 16, NT = sk.Npad / 32;
     if (ru.D > 2048 || (ru.D & 15) || ru.ldh != 0 || ru.M < 1 || ru.M > 32 || sk.MT != 1 || sk.Wq || sk.out_mode != SK_OUT_PARTIAL) return -1;
     if (ru.ws && (ru.splitk < 1 || ru.splitk > 4)) return -1;              // the row role sums at most 4 slabs
@@ -476,7 +498,7 @@ int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, 
     RowCattnArgs a;
     memset(&a, 0, sizeof(a));
     a.g = ru.g; a.b = ru.b; a.eps = ru.eps; a.D = ru.D; a.wte = ru.wte; a.wpe = ru.wpe; a.tokens = ru.tokens; a.positions = ru.positions;
-    a.xp_out = ru.xp_out; a.ws_out = sk.ws; a.ldws_out = sk.ldws; a.err = err; a.spin_ticks = spin_ticks;
+    a.xp_out = ru.xp_out; a.ws_out = sk.ws; a.ldws_out = sk.ldws; a.err = err; a.spin_ticks = spin_ticks; a.delay = delay; a.mode = mode;
     const size_t smem = (size_t)8 * 16 * 64 * 4 + 64;
     rowln_cattn_kernel<<<32 + NT * sk.splitk, 512, smem, st>>>(ru.ws, ru.bias, ru.h, sk.Wp, ru.splitk, ru.ldws, ru.rows_ws, ru.M, KS, KS / sk.splitk,
                                                                 NT, sk.splitk, a);
