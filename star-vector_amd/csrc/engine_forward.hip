@@ -301,9 +301,8 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
             a.xp = e->xp_a; a.Wp = L.c_attn.Wp; a.MT = MT; a.Npad = L.c_attn.Npad; a.K = L.c_attn.Kpad; a.N = L.c_attn.N;
             a.out_mode = SK_OUT_PARTIAL; a.splitk = L.c_attn.splitk; a.ws = wsA; a.ldws = e->ldws;
             prof_mark(e, PK_SKINNY, st);
-            // (sweep: SV_EXP bits 15-16 = delay before the first poll 64 / 96 / 127 / 32 s_sleep units, bit 17 = poll all four k-steps)
-            static const int delays[4] = {64, 96, 127, 32};
-            rc_done = launch_rowln_cattn(ru, a, e->d_bad, 500000, st, delays[(e->exp >> 15) & 3], (e->exp >> 17) & 1) == 0;   // 5 ms budget; a refusal takes the two launches
+            // (sweep: SV_EXP bits 15-17 = delay before the first poll = 128 + 32 x field s_sleep units, bit 18 = poll all four k-steps)
+            rc_done = launch_rowln_cattn(ru, a, e->d_bad, 500000, st, 128 + 32 * ((e->exp >> 15) & 7), (e->exp >> 18) & 1) == 0;   // 5 ms budget; a refusal takes the two launches
         }
         if (!rc_done) {
             row_update();                                        // embedding or the previous layer's down-proj -> LN1(h)
