@@ -416,7 +416,7 @@ __global__ __launch_bounds__(512, 4) void rowln_cattn_kernel(const float* ws_, c
     // alone take ~2 us): p.delay x 64 clocks of s_sleep first.  p.mode 0: a wave watches ONE k-step (1 KiB) -- a row is published by one
     // store instruction of its block, so its k-steps turn up together -- and only then fetches the other three, re-checking them;
     // p.mode 1: all four k-steps per poll, only the incomplete ones re-requested.
-    for (int d = p.delay; d > 0; d -= 32) __builtin_amdgcn_s_sleep(32);
+    for (int d = p.delay; d > 0; d -= 8) __builtin_amdgcn_s_sleep(8);
     u32x4 x[KPW];
     int gave_up = 1;
     auto patt = [&](const u32x4& v) { return m < M_ && (v[0] == 0xffffffffu || v[1] == 0xffffffffu || v[2] == 0xffffffffu || v[3] == 0xffffffffu); };
