@@ -413,10 +413,14 @@ __global__ __launch_bounds__(512, 4) void rowln_cattn_kernel(const float* ws_, c
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(p.xp_out, 0, (unsigned)((size_t)KS_ * 1024), 0x00020000);
     // 2304 waves polling 4 KiB each would put ~9 MB per poll round on the L2s while the 32 row blocks are still loading (first form,
     // measured: +1 us per layer over the two launches).  So nobody polls before the row update can possibly have published (its loads
-    // alone take ~2 us): p.delay x 64 clocks of s_sleep first.  p.mode 0: a wave watches ONE k-step (1 KiB) -- a row is published by one
+    // alone take ~2 us): the first poll goes out p.delay x 10 ns after the block started.  Measured (profiles/rowln_cattn_r05_ab.log): a
+    // poll that finds the pattern costs ~1.2 us whatever happens next (a full round trip before the retry), a poll that comes late
+    // costs its lateness: 1043 us per step with the first poll at <= 3.2 us, 1015 at 3.6 .. 3.9 us, +5 us per step for every 0.2 us
+    // after that -- so the poll is TIMED to land just behind the publish.  p.mode 0: a wave watches ONE k-step (1 KiB) -- a row is published by one
     // store instruction of its block, so its k-steps turn up together -- and only then fetches the other three, re-checking them;
     // p.mode 1: all four k-steps per poll, only the incomplete ones re-requested.
-    for (int d = p.delay; d > 0; d -= 8) __builtin_amdgcn_s_sleep(8);
+    // (wall clock, 100 MHz: the row update's latency is memory latency, not shader clocks -- an s_sleep count would drift with DVFS)
+    while (wall_clock64() - t_start < (long long)p.delay) __builtin_amdgcn_s_sleep(4);
     u32x4 x[KPW];
     int gave_up = 1;
     auto patt = [&](const u32x4& v) { return m < M_ && (v[0] == 0xffffffffu || v[1] == 0xffffffffu || v[2] == 0xffffffffu || v[3] == 0xffffffffu); };
