@@ -569,6 +569,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         // the row update + c_attn launch (rowops.hip): the projection's whole weight share per wave is 4 k-steps, every block resident
         const Linear& ca = e->dec[0].c_attn;
         e->rc_fused_ok = !ca.fp8 && rowln_cattn_fits(D, ca.Npad, ca.Kpad, ca.splitk, dn.splitk, e->num_cus);
+        if (const char* dl = getenv("SV_RC_DELAY")) { const int v = atoi(dl); if (v >= 0 && v <= 2000) e->rc_delay = v; }
     }
     if (rc) { sv_destroy(e); return rc; }
     *out = e;

@@ -154,10 +154,10 @@ struct RowCattnArgs {
                                                              // the 0xFFFF'FFFF pattern by an earlier launch of the step
     float* ws_out; int ldws_out;                             // the projection's fp32 slabs [splitk][32][ldws]
     int* err; int spin_ticks;                                // give-up code 3 after spin_ticks x 10 ns of waiting (never a hang)
-    int delay, mode;                                         // GEMM blocks: 10-ns ticks between block start and the first poll; 0 = watch one k-step, 1 = poll all four
+    int delay;                                               // GEMM blocks: 10-ns ticks between block start and the first poll
 };
 // 0 = launched; -1 = outside the kernel's scope (the caller runs the two launches).  sk.xp must be ru.xp_out.
-int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, int spin_ticks, hipStream_t st, int delay = 370, int mode = 0);
+int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, int spin_ticks, hipStream_t st, int delay = 390);
 bool rowln_cattn_fits(int D, int Npad, int K, int splitk, int splitk_ru, int num_cus);
 
 // ---- embeddings ---------------------------------------------------------------------------------

@@ -416,47 +416,27 @@ __global__ __launch_bounds__(512, 4) void rowln_cattn_kernel(const float* ws_, c
     // alone take ~2 us): the first poll goes out p.delay x 10 ns after the block started.  Measured (profiles/rowln_cattn_r05_ab.log): a
     // poll that finds the pattern costs ~1.2 us whatever happens next (a full round trip before the retry), a poll that comes late
     // costs its lateness: 1043 us per step with the first poll at <= 3.2 us, 1015 at 3.6 .. 3.9 us, +5 us per step for every 0.2 us
-    // after that -- so the poll is TIMED to land just behind the publish.  p.mode 0: a wave watches ONE k-step (1 KiB) -- a row is published by one
-    // store instruction of its block, so its k-steps turn up together -- and only then fetches the other three, re-checking them;
-    // p.mode 1: all four k-steps per poll, only the incomplete ones re-requested.
+    // after that -- so the poll is TIMED to land just behind the publish.  A wave watches ONE k-step (1 KiB) -- a row is published by one
+    // store instruction of its block, so its k-steps turn up together -- and only then fetches the other three, re-checking them
+    // (all four k-steps per poll: 1032 vs 1013 us per step at the same timing).
     // (wall clock, 100 MHz: the row update's latency is memory latency, not shader clocks -- an s_sleep count would drift with DVFS)
     while (wall_clock64() - t_start < (long long)p.delay) __builtin_amdgcn_s_sleep(4);
     u32x4 x[KPW];
     int gave_up = 1;
     auto patt = [&](const u32x4& v) { return m < M_ && (v[0] == 0xffffffffu || v[1] == 0xffffffffu || v[2] == 0xffffffffu || v[3] == 0xffffffffu); };
-    if (p.mode == 0) {
-        for (int it = 0;; ++it) {
-            x[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ks0 * 1024 + lane * 16, 0, 16);                 // sc1: L1 bypass
-            if (!__any(patt(x[0]))) {
+    for (int it = 0;; ++it) {
+        x[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ks0 * 1024 + lane * 16, 0, 16);                 // sc1: L1 bypass
+        if (!__any(patt(x[0]))) {
 #pragma unroll
-                for (int u = 1; u < KPW; ++u) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (ks0 + u) * 1024 + lane * 16, 0, 16);
-                bool bad = false;
+            for (int u = 1; u < KPW; ++u) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (ks0 + u) * 1024 + lane * 16, 0, 16);
+            bool bad = false;
 #pragma unroll
-                for (int u = 1; u < KPW; ++u) bad = bad || patt(x[u]);      // rows >= M of the tile are never written: only live rows are examined
-                if (!__any(bad)) { gave_up = 0; break; }
-            }
-            if ((it & 7) == 7 && (wall_clock64() - t_start > (long long)p.spin_ticks ||
-                                  __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) break;
-            __builtin_amdgcn_s_sleep(8);
+            for (int u = 1; u < KPW; ++u) bad = bad || patt(x[u]);      // rows >= M of the tile are never written: only live rows are examined
+            if (!__any(bad)) { gave_up = 0; break; }
         }
-    } else {
-#pragma unroll
-        for (int u = 0; u < KPW; ++u) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (ks0 + u) * 1024 + lane * 16, 0, 16);
-        unsigned pending = (1u << KPW) - 1u;
-        for (int it = 0;; ++it) {
-            unsigned still = 0u;
-#pragma unroll
-            for (int u = 0; u < KPW; ++u)
-                if ((pending & (1u << u)) && __any(patt(x[u]))) still |= 1u << u;
-            pending = still;
-            if (!pending) { gave_up = 0; break; }
-            if ((it & 7) == 7 && (wall_clock64() - t_start > (long long)p.spin_ticks ||
-                                  __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) break;
-            __builtin_amdgcn_s_sleep(8);
-#pragma unroll
-            for (int u = 0; u < KPW; ++u)
-                if (pending & (1u << u)) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (ks0 + u) * 1024 + lane * 16, 0, 16);
-        }
+        if ((it & 7) == 7 && (wall_clock64() - t_start > (long long)p.spin_ticks ||
+                              __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) break;
+        __builtin_amdgcn_s_sleep(8);
     }
     if (gave_up && lane == 0) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the step's result is void
     f32x16 acc;
@@ -491,7 +471,7 @@ bool rowln_cattn_fits(int D, int Npad, int K, int splitk, int splitk_ru, int num
     if ((NT * splitk) % 8 || NT % (8 / splitk) || splitk_ru < 1 || splitk_ru > 4) return false;
     return 32 + NT * splitk <= 2 * num_cus;
 }
-int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, int spin_ticks, hipStream_t st, int delay, int mode) {
+int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, int spin_ticks, hipStream_t st, int delay) {
     const int KS = sk.K / 16, NT = sk.Npad / 32;
     if (ru.D > 2048 || (ru.D & 15) || ru.ldh != 0 || ru.M < 1 || ru.M > 32 || sk.MT != 1 || sk.Wq || sk.out_mode != SK_OUT_PARTIAL) return -1;
     if (ru.ws && (ru.splitk < 1 || ru.splitk > 4)) return -1;              // the row role sums at most 4 slabs
@@ -500,7 +480,7 @@ int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, 
     RowCattnArgs a;
     memset(&a, 0, sizeof(a));
     a.g = ru.g; a.b = ru.b; a.eps = ru.eps; a.D = ru.D; a.wte = ru.wte; a.wpe = ru.wpe; a.tokens = ru.tokens; a.positions = ru.positions;
-    a.xp_out = ru.xp_out; a.ws_out = sk.ws; a.ldws_out = sk.ldws; a.err = err; a.spin_ticks = spin_ticks; a.delay = delay; a.mode = mode;
+    a.xp_out = ru.xp_out; a.ws_out = sk.ws; a.ldws_out = sk.ldws; a.err = err; a.spin_ticks = spin_ticks; a.delay = delay;
     const size_t smem = (size_t)8 * 16 * 64 * 4 + 64;
     rowln_cattn_kernel<<<32 + NT * sk.splitk, 512, smem, st>>>(ru.ws, ru.bias, ru.h, sk.Wp, ru.splitk, ru.ldws, ru.rows_ws, ru.M, KS, KS / sk.splitk,
                                                                 NT, sk.splitk, a);
