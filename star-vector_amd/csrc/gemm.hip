@@ -1508,6 +1508,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 
     // ---- phase 2: down projection (tile nt2, K slice `split`) -> fp32 slab, gemm_skinny_kernel<8, false>'s order ----
+    // (round 5 tried rowln_cattn_kernel's lesson here -- hold the first poll until a fixed time after the block's start: 1007.1 us per step at 10.0 us
+    //  against 1009.8 without, worse from 11 us on: the polls already sit where the data turns up; profiles/rowln_cattn_r05_ab.log)
     u32x4 x2[KPW];
 #pragma unroll
     for (int u = 0; u < KPW; ++u) x2[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, (ks2 + u) * 1024 + lane * 16, 0, 16);   // sc1: L1 bypass
