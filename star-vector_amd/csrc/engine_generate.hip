@@ -186,10 +186,10 @@ int sveng::check_finite_logits(sv_engine* e, hipStream_t st, const char* who) {
     const int what = e->h_flags[4];
     HIPCHECK(hipMemsetAsync(e->d_bad, 0, sizeof(int32_t), st));
     HIPCHECK(hipStreamSynchronize(st));
-    if (what == 3)
-        return fail(SV_EHIP, "%s: a block of a fused decode launch (MLP pair / row update + c_attn) gave up waiting for its producers (its blocks were not all resident at "
+    if (what == 3 || what == 4)
+        return fail(SV_EHIP, "%s: a block of a fused decode launch (code %d: 3 = MLP pair, 4 = row update + c_attn) gave up waiting for its producers (its blocks were not all resident at "
                              "once?  another process or engine on this GPU?); the tokens of this call are void -- create the engine with "
-                             "exclusive_device = 0 (SV_EXP bit 512) there", who);
+                             "exclusive_device = 0 (SV_EXP bit 512) there", who, what);
     return fail(SV_EHIP, "%s: a row of logits had no finite value (NaN / Inf in the weights or inputs?)", who);
 }
 

@@ -153,7 +153,7 @@ struct RowCattnArgs {
     bf16_t* xp_out;                                          // LayerNorm output in fragment order = the projection's operand; pre-filled with
                                                              // the 0xFFFF'FFFF pattern by an earlier launch of the step
     float* ws_out; int ldws_out;                             // the projection's fp32 slabs [splitk][32][ldws]
-    int* err; int spin_ticks;                                // give-up code 3 after spin_ticks x 10 ns of waiting (never a hang)
+    int* err; int spin_ticks;                                // give-up code 4 after spin_ticks x 10 ns of waiting (never a hang)
     int delay;                                               // GEMM blocks: 10-ns ticks between block start and the first poll
 };
 // 0 = launched; -1 = outside the kernel's scope (the caller runs the two launches).  sk.xp must be ru.xp_out.

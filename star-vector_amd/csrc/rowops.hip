@@ -281,7 +281,7 @@ void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st) {
 //              wave polls the 4 KiB of activations of ITS k-steps with sc1 loads and recognises "not written yet" by the data: the buffer
 //              is pre-filled with the bf16 pair 0xFFFF'FFFF -- by the attention launch of the layer before (AttnDecodeArgs::poison2),
 //              for layer 0 by a memset node at the head of the step -- which no finite LayerNorm output produces.  Bounded by the wall
-//              clock (give-up code 3 in *err: never a hang).  Then gemm_skinny_kernel<8, false>'s 4 MFMAs, LDS reduction in wave order
+//              clock (give-up code 4 in *err: never a hang).  Then gemm_skinny_kernel<8, false>'s 4 MFMAs, LDS reduction in wave order
 //              and slab store: bit-identical slabs.
 //   Needs every block resident at once: on for an engine that owns its GPU (sv_config.exclusive_device), like the fused MLP launch.
 // ------------------------------------------------------------------------------------------------
@@ -438,7 +438,7 @@ __global__ __launch_bounds__(512, 4) void rowln_cattn_kernel(const float* ws_, c
                               __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) break;
         __builtin_amdgcn_s_sleep(8);
     }
-    if (gave_up && lane == 0) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the step's result is void
+    if (gave_up && lane == 0) __hip_atomic_store(p.err, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the step's result is void
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
