@@ -291,7 +291,11 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
     const bool rc = fold6 && e->rc_fused_ok && MT == 1 && !(e->exp & 8192) && (c.exclusive_device || (e->exp & 16384)) &&
                     !e->only_skinny && !e->skip_skinny && !e->prof_on;
     const unsigned xpa_bytes = (unsigned)((size_t)(D / 16) * 1024);
-    if (rc) (void)hipMemsetAsync(e->xp_a, 0xFF, xpa_bytes, st);
+    static const bool poison_by_kernel = getenv("SV_RC_POISON_KERNEL") != nullptr;        // (diagnosis: a fill kernel instead of the memset node)
+    if (rc) {
+        if (poison_by_kernel) fill_i32(reinterpret_cast<int32_t*>(e->xp_a), -1, (int)(xpa_bytes / 4), st);
+        else (void)hipMemsetAsync(e->xp_a, 0xFF, xpa_bytes, st);
+    }
     for (int i = 0; i < c.n_layer; ++i) {
         DecLayer& L = e->dec[i];
         bool rc_done = false;

@@ -12,7 +12,7 @@ import starvector_amd as sva  # noqa: E402
 
 dev = torch.device("cuda", 0)
 B = 32
-for n_new, nograph in ((64, False), (64, True), (300, False)):
+for n_new, nograph in ((1024, False), (1024, True)):
     if nograph:
         os.environ["SV_NO_GRAPH"] = "1"
     else:
@@ -22,7 +22,7 @@ for n_new, nograph in ((64, False), (64, True), (300, False)):
     img = torch.randn(B, 3, 224, 224, generator=torch.Generator().manual_seed(1)).to(torch.bfloat16).to(dev)
     prompt = torch.tensor([[7, 11]] * B, dtype=torch.long, device=dev)
     outs = []
-    for call in range(3):
+    for call in range(4):
         emb = eng.prepare_inputs(eng.encode_image(img), prompt)
         try:
             outs.append(eng.generate(emb, max_length=emb.shape[1] + n_new, eos_token_id=-1, pad_token_id=49152).cpu())
