@@ -1,7 +1,9 @@
-# the default bench command, a few times (round 5: an intermittent give-up of a fused decode launch under the default steps / warmup)
-for i in 1 2 3; do
-  echo "=== run $i: default bench"
-  timeout 200 python bench.py --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | tail -2 | cut -c1-400
-done
-echo "=== SV_EXP=8192 (two row launches)"
-SV_EXP=8192 timeout 200 python bench.py --no-cpu-baseline 2>&1 | grep -v amdgpu.ids | tail -2 | cut -c1-400
+run() { echo "=== $*"; env "$@" 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-230; }
+B="timeout 200 python bench.py --no-cpu-baseline --ttft-requests 1"
+run X=1 $B --warmup 1 --steps 1
+run X=1 $B --warmup 0 --steps 2
+run SV_RC_POISON_KERNEL=1 $B --warmup 1 --steps 1
+run SV_NO_GRAPH=1 $B --warmup 1 --steps 1
+run SV_RC_DELAY=0 $B --warmup 1 --steps 1
+run SV_EXP=1024 $B --warmup 1 --steps 1
+run SV_EXP=512 $B --warmup 1 --steps 1
