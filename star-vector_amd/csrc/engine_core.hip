@@ -477,6 +477,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     A(dalloc(e, &e->hl, R * D));
     A(dalloc(e, &e->xp_a, R * D));
     A(dalloc(e, &e->xp_f, R * D));
+    A(dalloc(e, &e->rc_dbg, 8));
     A(dalloc(e, &e->xp_attn, R * D));
     A(dalloc(e, &e->xp_mlp, R * F));
     A(dalloc(e, &e->ws, (size_t)8 * R * e->ldws));

@@ -305,7 +305,7 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
             a.xp = e->xp_a; a.Wp = L.c_attn.Wp; a.MT = MT; a.Npad = L.c_attn.Npad; a.K = L.c_attn.Kpad; a.N = L.c_attn.N;
             a.out_mode = SK_OUT_PARTIAL; a.splitk = L.c_attn.splitk; a.ws = wsA; a.ldws = e->ldws;
             prof_mark(e, PK_SKINNY, st);
-            rc_done = launch_rowln_cattn(ru, a, e->d_bad, 500000, st, e->rc_delay) == 0;      // 5 ms budget; a refusal takes the two launches
+            rc_done = launch_rowln_cattn(ru, a, e->d_bad, 500000, st, e->rc_delay, e->rc_dbg, i) == 0;      // 5 ms budget; a refusal takes the two launches
         }
         if (!rc_done) {
             row_update();                                        // embedding or the previous layer's down-proj -> LN1(h)

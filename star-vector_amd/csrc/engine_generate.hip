@@ -186,6 +186,15 @@ int sveng::check_finite_logits(sv_engine* e, hipStream_t st, const char* who) {
     const int what = e->h_flags[4];
     HIPCHECK(hipMemsetAsync(e->d_bad, 0, sizeof(int32_t), st));
     HIPCHECK(hipStreamSynchronize(st));
+    if (what == 4 && e->rc_dbg) {
+        long long d[8] = {0};
+        int32_t stepv = -1;
+        (void)hipMemcpy(d, e->rc_dbg, sizeof(d), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(&stepv, e->d_step, sizeof(stepv), hipMemcpyDeviceToHost);
+        (void)hipMemset(e->rc_dbg, 0, sizeof(d));
+        fprintf(stderr, "[sv] rowln_cattn give-up: block %lld wave %lld ks0 %lld waited %lld ticks, x0 %016llx, layer %lld, rows %lld; device step %d\n",
+                d[0], d[1], d[2], d[3], (unsigned long long)d[4], d[5], d[6], stepv);
+    }
     if (what == 3 || what == 4)
         return fail(SV_EHIP, "%s: a block of a fused decode launch (code %d: 3 = MLP pair, 4 = row update + c_attn) gave up waiting for its producers (its blocks were not all resident at "
                              "once?  another process or engine on this GPU?); the tokens of this call are void -- create the engine with "

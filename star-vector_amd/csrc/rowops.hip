@@ -438,7 +438,14 @@ __global__ __launch_bounds__(512, 4) void rowln_cattn_kernel(const float* ws_, c
                               __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) break;
         __builtin_amdgcn_s_sleep(8);
     }
-    if (gave_up && lane == 0) __hip_atomic_store(p.err, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the step's result is void
+    if (gave_up && lane == 0) {
+        const int seen = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.err, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the step's result is void
+        if (p.dbg && seen == 0) {                // the first wave to give up leaves a note (read by the host when it reports the failure)
+            p.dbg[0] = blockIdx.x; p.dbg[1] = wave; p.dbg[2] = ks0; p.dbg[3] = wall_clock64() - t_start;
+            p.dbg[4] = ((long long)x[0][0] << 32) | x[0][1]; p.dbg[5] = p.layer; p.dbg[6] = M_; p.dbg[7] = 1;
+        }
+    }
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -471,7 +478,7 @@ bool rowln_cattn_fits(int D, int Npad, int K, int splitk, int splitk_ru, int num
     if ((NT * splitk) % 8 || NT % (8 / splitk) || splitk_ru < 1 || splitk_ru > 4) return false;
     return 32 + NT * splitk <= 2 * num_cus;
 }
-int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, int spin_ticks, hipStream_t st, int delay) {
+int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, int spin_ticks, hipStream_t st, int delay, long long* dbg, int layer) {
     const int KS = sk.K / 16, NT = sk.Npad / 32;
     if (ru.D > 2048 || (ru.D & 15) || ru.ldh != 0 || ru.M < 1 || ru.M > 32 || sk.MT != 1 || sk.Wq || sk.out_mode != SK_OUT_PARTIAL) return -1;
     if (ru.ws && (ru.splitk < 1 || ru.splitk > 4)) return -1;              // the row role sums at most 4 slabs
@@ -480,7 +487,7 @@ int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, 
     RowCattnArgs a;
     memset(&a, 0, sizeof(a));
     a.g = ru.g; a.b = ru.b; a.eps = ru.eps; a.D = ru.D; a.wte = ru.wte; a.wpe = ru.wpe; a.tokens = ru.tokens; a.positions = ru.positions;
-    a.xp_out = ru.xp_out; a.ws_out = sk.ws; a.ldws_out = sk.ldws; a.err = err; a.spin_ticks = spin_ticks; a.delay = delay;
+    a.xp_out = ru.xp_out; a.ws_out = sk.ws; a.ldws_out = sk.ldws; a.err = err; a.spin_ticks = spin_ticks; a.delay = delay; a.dbg = dbg; a.layer = layer;
     const size_t smem = (size_t)8 * 16 * 64 * 4 + 64;
     rowln_cattn_kernel<<<32 + NT * sk.splitk, 512, smem, st>>>(ru.ws, ru.bias, ru.h, sk.Wp, ru.splitk, ru.ldws, ru.rows_ws, ru.M, KS, KS / sk.splitk,
                                                                 NT, sk.splitk, a);
