@@ -199,7 +199,11 @@ int sveng::check_finite_logits(sv_engine* e, hipStream_t st, const char* who) {
         return fail(SV_EHIP, "%s: a block of a fused decode launch (code %d: 3 = MLP pair, 4 = row update + c_attn) gave up waiting for its producers (its blocks were not all resident at "
                              "once?  another process or engine on this GPU?); the tokens of this call are void -- create the engine with "
                              "exclusive_device = 0 (SV_EXP bit 512) there", who, what);
-    return fail(SV_EHIP, "%s: a row of logits had no finite value (NaN / Inf in the weights or inputs?)", who);
+    {
+        int32_t stepv = -1;
+        (void)hipMemcpy(&stepv, e->d_step, sizeof(stepv), hipMemcpyDeviceToHost);
+        return fail(SV_EHIP, "%s: a row of logits had no finite value (NaN / Inf in the weights or inputs?) [code %d, device step %d]", who, what, stepv);
+    }
 }
 
 extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int32_t S0, const sv_sampling* sp,

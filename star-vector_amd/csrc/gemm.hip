@@ -1536,7 +1536,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int u = 0; u < KPW; ++u)
             if (pending & (1u << u)) x2[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_act, (ks2 + u) * 1024 + lane * 16, 0, 16);
     }
-    if (gave_up && lane == 0) __hip_atomic_store(p.err, 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the step's result is void
+    if (gave_up && lane == 0) atomicCAS(p.err, 0, 3);      // the step's result is void; the first code raised survives
     const long long t_go = wall_clock64();
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;

@@ -439,8 +439,7 @@ __global__ __launch_bounds__(512, 4) void rowln_cattn_kernel(const float* ws_, c
         __builtin_amdgcn_s_sleep(8);
     }
     if (gave_up && lane == 0) {
-        const int seen = __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(p.err, 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // the step's result is void
+        const int seen = atomicCAS(p.err, 0, 4);       // the step's result is void; the FIRST code raised survives (0 -> 4 only)
         if (p.dbg && seen == 0) {                // the first wave to give up leaves a note (read by the host when it reports the failure)
             p.dbg[0] = blockIdx.x; p.dbg[1] = wave; p.dbg[2] = ks0; p.dbg[3] = wall_clock64() - t_start;
             p.dbg[4] = ((long long)x[0][0] << 32) | x[0][1]; p.dbg[5] = p.layer; p.dbg[6] = M_; p.dbg[7] = 1;
