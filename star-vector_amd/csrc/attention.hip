@@ -402,17 +402,21 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
     act = act < 1 ? 1 : act;
     // AttnDecodeArgs::poison: every block of the launch stores 16 bytes per thread of the pattern -- the inactive splits before they
     // leave, the active ones once their KV stream is in flight (the arguments are read late in both cases: off the critical path)
+    // (poison2 = the next layer's LayerNorm output buffer: only ever touched with write-through stores and L1-bypassing loads -- by this
+    //  launch, the lm_head launch and rowln_cattn_kernel -- so that no XCD's L2 can hold a line of it that memory does not)
+    auto poison2_store = [&](const AttnDecodeArgs& q, unsigned off) {
+        const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(q.poison2, 0, q.poison2_bytes, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, rsp, (int)off, 0, 16);      // sc1
+    };
     auto poison = [&](const AttnDecodeArgs& q) {
         if (q.poison) {
             const unsigned off = ((blockIdx.y * gridDim.x + blockIdx.x) * (AD_WAVES * 64) + threadIdx.x) * 16u;
             if (off < q.poison_bytes)
                 *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(q.poison) + off) = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
-            else if (q.poison2 && off - q.poison_bytes < q.poison2_bytes)
-                *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(q.poison2) + (off - q.poison_bytes)) = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            else if (q.poison2 && off - q.poison_bytes < q.poison2_bytes) poison2_store(q, off - q.poison_bytes);
         } else if (q.poison2) {
             const unsigned off = ((blockIdx.y * gridDim.x + blockIdx.x) * (AD_WAVES * 64) + threadIdx.x) * 16u;
-            if (off < q.poison2_bytes)
-                *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(q.poison2) + off) = u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu};
+            if (off < q.poison2_bytes) poison2_store(q, off);
         }
     };
     if (split >= act) {

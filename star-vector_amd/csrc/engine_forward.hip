@@ -141,9 +141,18 @@ int sveng::assign_pages(sv_engine* e, int B, int total_len, hipStream_t st) {
 }
 
 // lm_head -> e->logits; xp holds ln_f(h) in fragment order
+// The fused row-update + c_attn launch (rowops.hip) is on for this engine: then xp_a -- the LayerNorm output buffer its GEMM blocks poll --
+// is touched ONLY with write-through stores / L1-bypassing loads (row role, the attention launch's and the lm_head launch's pattern
+// stores, the GEMM role's polls), and ln_f's output lives in xp_f.  Invariant: behind every lm_head launch xp_a carries the pattern.
+// (First form: a memset node at the head of the step + the prompt pass's ln_f through xp_a with plain stores -- NaN logits in the third
+//  sv_generate call of bench.py: a stale line of the buffer in some XCD's L2.)
+static bool rc_enabled(const sv_engine* e) {
+    return e->fold6 && e->fold_ready && !(e->exp & 2) && e->rc_fused_ok && !(e->exp & 8192) && (e->cfg.exclusive_device || (e->exp & 16384));
+}
 static void lm_head_logits(sv_engine* e, int MT, const bf16_t* xp, hipStream_t st) {
     SkinnyArgs a;
     memset(&a, 0, sizeof(a));
+    if (rc_enabled(e) && MT == 1 && xp != e->xp_a) { a.poison = e->xp_a; a.poison_bytes = (unsigned)((size_t)(e->cfg.hidden / 16) * 1024); }
     a.xp = xp; a.Wp = e->lm_head.Wp; a.Wq = e->lm_head.Wq; a.wscale = e->lm_head.wscale; a.MT = MT; a.Npad = e->lm_head.Npad; a.K = e->lm_head.Kpad;
     a.splitk = 1; a.out_mode = SK_OUT_F32; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1;
     a.N = e->lm_head.N;
@@ -212,9 +221,9 @@ int sveng::prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hi
     // only the last prompt row feeds ln_f + lm_head (HF computes all rows; same result)
     prof_mark(e, PK_PF_ROWS, st);
     launch_gather_last_rows(e->ph, e->hl, B, S0, D, st);
-    launch_layernorm_rows_packed(e->hl, D, e->ln_f.g, e->ln_f.b, e->xp_a, B, D, c.ln_eps, st);
+    launch_layernorm_rows_packed(e->hl, D, e->ln_f.g, e->ln_f.b, e->xp_f, B, D, c.ln_eps, st);
     prof_mark(e, PK_PF_LMHEAD, st);
-    lm_head_logits(e, (B + 31) / 32, e->xp_a, st);
+    lm_head_logits(e, (B + 31) / 32, e->xp_f, st);
     return 0;
 }
 
@@ -251,8 +260,20 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
     RowUpdateArgs ru;
     memset(&ru, 0, sizeof(ru));
     const bool fold6 = e->fold6 && e->fold_ready && !(e->exp & 2);
+    // Row update + c_attn as ONE launch (rowops.hip rowln_cattn_kernel): on when the engine owns its GPU (like the fused MLP launch: its
+    // blocks wait for blocks of the same launch); SV_EXP bit 8192 = off, 16384 = on without exclusive_device (A/B).  The GEMM blocks
+    // recognise unwritten activations by the 0xFFFF'FFFF pattern: xp_a gets it from the lm_head launch of the step (or prompt pass) before
+    // (layer 0) and from the attention launch of layer i for layer i + 1 -- which must have room for it: 16 bytes per thread of its grid
+    // (B >= 10 at StarVector-1B's shapes).  Not inside the profiling legs (they time the row updates and the GEMMs apart).  A call that
+    // cannot fuse on an engine that does (see rc_enabled) keeps its LayerNorm outputs out of xp_a.
+    const size_t attn_threads_bytes = (size_t)B * e->nkv * attn_max_splits(e) * 512 * 16;
+    const bool rc = rc_enabled(e) && MT == 1 && !e->only_skinny && !e->skip_skinny && !e->prof_on &&
+                    (size_t)(D / 16) * 1024 + (size_t)(F / 16) * 1024 <= attn_threads_bytes;
+    const unsigned xpa_bytes = (unsigned)((size_t)(D / 16) * 1024);
+    bf16_t* const xp_ln = (rc_enabled(e) && !rc) ? e->xp_f : e->xp_a;      // LayerNorm(ln_1) output = the c_attn operand
+
     ru.h = fold6 ? e->h_xp : e->h_dec; ru.ldh = fold6 ? 0 : D;        // 6-launch layer: the residual stream lives in fragment order
-    ru.M = B; ru.D = D; ru.eps = c.ln_eps; ru.xp_out = e->xp_a;
+    ru.M = B; ru.D = D; ru.eps = c.ln_eps; ru.xp_out = xp_ln;
     ru.ldws = e->ldws; ru.rows_ws = MT * 32;
     ru.ws = nullptr; ru.wte = e->wte; ru.wpe = e->wpe; ru.tokens = e->cur_tok; ru.positions = e->positions;
     ru.g = e->dec[0].ln1.g; ru.b = e->dec[0].ln1.b;
@@ -278,24 +299,12 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
         else {
             a.splitk = 1; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1;
             if (e->greedy_fused) { a.amax = e->amax; a.amax_rows = B; }      // greedy selection inside the lm_head launch (sv_generate)
+            if (rc_enabled(e) && MT == 1 && xp != e->xp_a) { a.poison = e->xp_a; a.poison_bytes = xpa_bytes; }      // the next step's layer 0
         }
         if (e->skip_skinny) return;
         prof_mark(e, PK_SKINNY, st);
         launch_gemm_skinny(a, st);
     };
-    // Row update + c_attn as ONE launch (rowops.hip rowln_cattn_kernel): on when the engine owns its GPU (like the fused MLP launch: its
-    // blocks wait for blocks of the same launch); SV_EXP bit 8192 = off, 16384 = on without exclusive_device (A/B).  The GEMM blocks
-    // recognise unwritten activations by the 0xFFFF'FFFF pattern: xp_a gets it from a memset node at the head of the step (layer 0) and
-    // from the attention launch of layer i for layer i + 1; ln_f's output therefore lives in its own buffer.  Not inside the profiling
-    // legs (they time the row updates and the GEMMs apart).
-    const bool rc = fold6 && e->rc_fused_ok && MT == 1 && !(e->exp & 8192) && (c.exclusive_device || (e->exp & 16384)) &&
-                    !e->only_skinny && !e->skip_skinny && !e->prof_on;
-    const unsigned xpa_bytes = (unsigned)((size_t)(D / 16) * 1024);
-    static const bool poison_by_kernel = getenv("SV_RC_POISON_KERNEL") != nullptr;        // (diagnosis: a fill kernel instead of the memset node)
-    if (rc) {
-        if (poison_by_kernel) fill_i32(reinterpret_cast<int32_t*>(e->xp_a), -1, (int)(xpa_bytes / 4), st);
-        else (void)hipMemsetAsync(e->xp_a, 0xFF, xpa_bytes, st);
-    }
     for (int i = 0; i < c.n_layer; ++i) {
         DecLayer& L = e->dec[i];
         bool rc_done = false;
@@ -309,7 +318,7 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
         }
         if (!rc_done) {
             row_update();                                        // embedding or the previous layer's down-proj -> LN1(h)
-            skinny(e->xp_a, L.c_attn, SK_OUT_PARTIAL, wsA);
+            skinny(xp_ln, L.c_attn, SK_OUT_PARTIAL, wsA);
         }
         // c_fc + down projection in ONE launch (gemm.hip mlp_fused_kernel): on when the engine owns its GPU (sv_config.exclusive_device);
         // SV_EXP bit 128 forces it on, bit 512 off (in-process A/B, tools/ab_exp.py).  It recognises unwritten activations by a pattern
@@ -329,7 +338,6 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
             prof_mark(e, PK_ATTN, st);
             launch_attn_decode(ad, st);
         }
-        if (rc && i + 1 < c.n_layer && !attn_poisons_xpa) (void)hipMemsetAsync(e->xp_a, 0xFF, xpa_bytes, st);      // (tiny grids: no room in the attention launch)
         if (fold6) {
             // attention output projection over the whole K per block: h += bf(x W^T + b) in place (+ partial row statistics), then
             // c_fc on the raw h with ln_2 folded into its weights / epilogue: no slabs, no row-update launch (decode_cols.hip)
@@ -374,7 +382,7 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
         const LNp& nxt = (i + 1 < c.n_layer) ? e->dec[i + 1].ln1 : e->ln_f;
         ru.ws = wsB; ru.splitk = L.c_proj2.splitk; ru.bias = L.c_proj2.bias; ru.g = nxt.g; ru.b = nxt.b;
     }
-    bf16_t* xp_last = rc ? e->xp_f : e->xp_a;                    // (xp_a carries the pattern / the last layer's operand when the launches are fused)
+    bf16_t* xp_last = rc_enabled(e) ? e->xp_f : e->xp_a;         // (an engine with the fused launch keeps xp_a for it alone: see rc_enabled)
     ru.xp_out = xp_last;
     row_update();                                                // + bias + residual, ln_f
     skinny(xp_last, e->lm_head, SK_OUT_F32, nullptr);

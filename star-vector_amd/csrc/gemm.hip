@@ -1214,6 +1214,15 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
     auto late = [&]() {                                     // the stream is in flight: now the rest of the arguments + the bias
         p = sv_late_args<SkinnyArgs>(offsetof(SkinnyKernarg, p));
         sk_bias<RPW>(p, bias_d, wave * RPW, nt, half, FOLD ? fc1 : nullptr);
+        if constexpr (!FOLD && WAVES > 1) {
+            if (p.out_mode == SK_OUT_F32 && p.poison) {      // SkinnyArgs::poison: the first blocks of the lm_head launch, fire and forget
+                const unsigned off = ((blockIdx.x + gridDim.x * blockIdx.z) * (unsigned)(WAVES * 64) + (unsigned)tid) * 16u;
+                if (off < p.poison_bytes) {
+                    const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(p.poison, 0, p.poison_bytes, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, rsp, (int)off, 0, 16);      // sc1: write-through
+                }
+            }
+        }
         sk_settle<RPW>(bias_d, FOLD ? fc1 : nullptr);
     };
     auto guarded = [&](int ks) {                            // the ragged end of the range (and short ranges): guard per k-step

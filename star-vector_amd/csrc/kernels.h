@@ -70,6 +70,9 @@ struct SkinnyArgs {
     // (value, lowest index) of its 32 columns per row in amax[row * SV_AMAX_STRIDE] through an atomic max on a 64-bit key
     // (sv_amax_key); finish_step_kernel decodes and re-arms it.  nullptr: off.
     unsigned long long* amax; int amax_rows;               // rows < amax_rows take part
+    // F32 mode (lm_head), one-row-tile bf16 kernel only: a buffer the launch fills with the 0xFFFF'FFFF pattern through write-through
+    // stores, 16 bytes per thread (the LayerNorm output buffer of the fused row-update + c_attn launch of the NEXT decode step)
+    void* poison; unsigned poison_bytes;
 };
 #define SV_AMAX_STRIDE 16          // one 128-byte line per row: the rows' atomics do not share an L2 line
 // key = (order-preserving image of the float) << 32 | (0xFFFFFFFF - column): larger value wins, equal values -> LOWER column wins
