@@ -1013,9 +1013,18 @@ def test_row_update_and_c_attn_as_one_launch_bit_for_bit():
             assert torch.equal(runs[mask][k], ref[k]), f"SV_EXP {mask}: {what} differ from the unfused launches"
     assert torch.equal(eager, ref[1])
     eng.close()
-    # an engine that owns its GPU runs both fused launches by default: same tokens again
-    own = sva.HipEngine(sva.EngineConfig(max_batch=B, max_seq_len=259 + 200, exclusive_device=True))
+    # an engine that owns its GPU runs both fused launches by default: same tokens again -- and again through the KEPT hipGraph with a
+    # prompt pass in between (round 5: the first form fed the prompt pass's ln_f through the polled buffer with plain stores and armed it
+    # with a memset node; bench.py's third call then read a stale line of it out of an L2 -> NaN logits.  The buffer is now touched with
+    # write-through stores / L1-bypassing loads only, and this is the sequence that found it: several identical long calls)
+    own = sva.HipEngine(sva.EngineConfig(max_batch=B, max_seq_len=259 + 700, exclusive_device=True))
     own.load_random_weights(seed=13)
     emb2 = torch.cat([own.adapter(own.encode_image(img)), own.embed_tokens(prompt)], 1)
     assert torch.equal(own.generate(emb2, **kw).cpu(), ref[1])
+    kw_long = dict(max_length=S0 + 690, eos_token_id=-1, pad_token_id=49152)
+    first = own.generate(emb2, **kw_long).cpu()
+    assert torch.equal(first[:, :170], ref[1])
+    for _ in range(3):
+        emb3 = own.prepare_inputs(own.encode_image(img), prompt)
+        assert torch.equal(own.generate(emb3, **kw_long).cpu(), first) and own.last_timing()["graph"]
     own.close()
