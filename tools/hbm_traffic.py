@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """profiles/hbm_traffic.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; tools/pmc_summary.py output), for the
-decoder's weight-streaming GEMM family of the decode step (gemm_skinny_kernel<*, false|true> + gemm_cols_resid_kernel + mlp_fused_kernel):
+decoder's weight-streaming GEMM family of the decode step (gemm_skinny_kernel<*, false|true> + gemm_cols_resid_kernel + mlp_fused_kernel +
+rowln_cattn_kernel, the round-5 launch that carries the c_attn projection behind its row update):
     python tools/hbm_traffic.py <pmc_FETCH_SIZE.json> <pmc_WRITE_SIZE.json> <algorithmic bytes per launch> "<where measured>"
 Rule (MI355X_MICROARCH.md, HBM section): both counters are KiB; on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced
 streaming read (16 B per lane) -> doubled; WRITE_SIZE taken as is; separate passes, --kernel-trace only.  bench.py reads the result."""
 import json
 import sys
 
-FAMILY = ("gemm_skinny_kernel", "gemm_cols_resid_kernel", "mlp_fused_kernel")
+FAMILY = ("gemm_skinny_kernel", "gemm_cols_resid_kernel", "mlp_fused_kernel", "rowln_cattn_kernel")
 
 
 def family(path, counter):
