@@ -381,7 +381,10 @@ def main():
                 "bound": "hbm", "bytes_per_step": int(W_BYTES_PER_STEP + kvb), "us_per_step": round(us, 1),
                 "achieved": round((W_BYTES_PER_STEP + kvb) / (us * 1e-6) / 1e9, 1) if us > 0 else None, "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round((W_BYTES_PER_STEP + kvb) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us > 0 else None,
-                "launches_per_step": int(sum(v["launches_per_step"] for v in prof.values() if isinstance(v, dict))) + 2})(
+                # the profiling legs time the UNFUSED launches; the captured step of an engine that owns its GPU runs the layer's row update inside
+                # the c_attn launch (n_layer launches less) and a plain greedy step selects inside the lm_head launch (no argmax launch)
+                "launches_per_step": int(sum(v["launches_per_step"] for v in prof.values() if isinstance(v, dict))) + 2
+                                     - (cfg.n_layer if rc_on else 0) - (0 if (is8b or B_PER_GPU > 32 or args.weights != "bf16") else 1)})(
                     B_PER_GPU * (S0 + n_new / 2.0) * cfg.n_layer * 2 * cfg.n_kv_head * head_dim * 2,
                     decode_ms / max(decode_steps, 1) * 1e3),
             "decode_step_profile_ms": {k: round(v["ms_per_step"], 4) for k, v in prof.items() if isinstance(v, dict)},

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define SV_ABI_VERSION 7
+#define SV_ABI_VERSION 8
 #define SV_WEIGHT_BF16 0
 #define SV_WEIGHT_FP8_E4M3 1
 

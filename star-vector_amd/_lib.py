@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libstarvector_hip.so")
 HEADER_PATH = os.path.normpath(os.path.join(HERE, "..", "include", "starvector_hip.h"))
 DEBUG_HEADER_PATH = os.path.normpath(os.path.join(HERE, "..", "include", "starvector_hip_debug.h"))
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 SV_DTYPE_BF16, SV_DTYPE_F32 = 0, 1
 SV_NORM_LAYER, SV_NORM_BATCH = 0, 1
 SV_ARCH_V1, SV_ARCH_V2 = 0, 1
