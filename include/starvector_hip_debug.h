@@ -81,6 +81,11 @@ int  sv_debug_mlp_trace(sv_engine* e, int64_t* host_out, int32_t capacity_blocks
      the blocks the decode attention's LDS footprint and 10 us of residence (a grid above the CU count then runs in rounds, like a 64-row
      attention launch).  Evidence for the XCD-aware block -> tile mappings (block L runs on XCD (L + c) % 8): DESIGN.md sections 3c / 3f. */
 int  sv_debug_xcc_map(sv_engine* e, int32_t blocks, int32_t heavy, int32_t* host_out);
+/*   sv_debug_occupy_cus  a foreign tenant for the safety test of exclusive_device (tests/test_gpu_safety.py): `blocks` 4-wave blocks on a stream
+     of their own, each pinning `lds_bytes` of a CU's LDS for `ms` milliseconds; returns at once.  With 144 KiB per block no block of the
+     fused MLP / fused row-update launch fits beside one: those CUs are taken the way another process's kernels would take them, and a decode
+     call made meanwhile has to END WITH AN ERROR (give-up code 3 / 4), never hang and never return tokens. */
+int  sv_debug_occupy_cus(sv_engine* e, int32_t blocks, int32_t lds_bytes, int32_t ms);
 /*   sv_debug_gemm_trace  the 256x256 big-M GEMM kernel (prefill / ViT) on random operands of the given shape, one launch with wall-clock
      stamps (form = 1): host_out [blocks * 2][8] = {start, K-tile 0 staged, K loop done, epilogue stored, tile m, tile n, wave, 0}
      (tools/gemm_trace.py).  Needs no engine.  Returns the number of blocks. */

@@ -122,6 +122,7 @@ DEBUG_PROTOTYPES = {
     "sv_debug_attn_trace": (_I, [_P, C.POINTER(C.c_int64), _I]),
     "sv_debug_mlp_trace": (_I, [_P, C.POINTER(C.c_int64), _I]),
     "sv_debug_xcc_map": (_I, [_P, _I, _I, C.POINTER(_I)]),
+    "sv_debug_occupy_cus": (_I, [_P, _I, _I, _I]),
     "sv_debug_gemm_trace": (_I, [_I, _I, _I, _I, _I, C.POINTER(C.c_int64), _I]),
     "sv_debug_kv_load": (_I, [_P, _I, _P, _I, _I, _P, _P]),
     "sv_debug_attn_decode": (_I, [_P, _I, _P, _I, _P, _I, _P]),

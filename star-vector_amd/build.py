@@ -40,6 +40,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     hdrs = [os.path.normpath(os.path.join(CSRC, h)) for h in HEADERS]
+    # the flags are a dependency too: objects built with other SV_HIPCC_FLAGS / SV_NO_KERNARG_PRELOAD must not be reused
+    stamp = os.path.join(OBJ, "flags.txt")
+    flags_now = " ".join(FLAGS)
+    if not os.path.exists(stamp) or open(stamp).read() != flags_now:
+        force = True
     jobs = []
     for s in SOURCES:
         src = os.path.join(CSRC, s)
@@ -60,6 +65,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(f"[starvector_amd.build] compiling {len(jobs)} HIP source(s) for gfx950", file=sys.stderr)
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 4)) as ex:
             list(ex.map(compile_one, jobs))
+    with open(stamp, "w") as f:
+        f.write(flags_now)
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or not _newer(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs

@@ -545,6 +545,22 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
                 for (int w = 0; w < 4; ++w)
                     if (vlane && w == ws) f.v[t][w] = (f.v[t][w] & keep) | nv;
             }
+            // The keys of this group BEHIND the new token are stale rows of the page (whatever its last owner left there).  Their scores are
+            // masked below by a select -- NaN-safe -- but their V rows still go through the P.V MFMA with P = 0, and 0 x NaN = NaN: a page that
+            // ever held a non-finite row (a request with NaN inputs, a step voided by a give-up) would fail its NEXT owner, call after call,
+            // until every stale row had been overwritten (round 5, tests/test_gpu_safety.py).  So the stale V columns are cleared here -- in
+            // the one group per sequence and step that has any, a few dozen v_and per lane.  Element e of a lane's V fragment is key
+            // 16 (e >> 2) + 4 c + (e & 3) of the group.
+            uint32_t vm[4];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const int klo = 16 * (w >> 1) + 4 * c + 2 * (w & 1);             // e = 2 w (low half of the dword), e + 1 (high half)
+                vm[w] = (klo <= k32 ? 0x0000ffffu : 0u) | (klo + 1 <= k32 ? 0xffff0000u : 0u);
+            }
+#pragma unroll
+            for (int t = 0; t < NDV; ++t)
+#pragma unroll
+                for (int w = 0; w < 4; ++w) f.v[t][w] &= vm[w];
         }
         f32x4 accS[2];
         float sc[2][4];
@@ -768,6 +784,21 @@ __global__ __launch_bounds__(AD_WAVES * 64) void xcc_probe_kernel(int32_t* out, 
         while (wall_clock64() - t0 < spin_ticks) __builtin_amdgcn_s_sleep(8);
     }
     if (threadIdx.x == 0) out[blockIdx.x] = (int32_t)xcc_id();
+}
+// occupy_kernel: a foreign tenant for the safety test of the launches whose blocks wait for each other (tests/test_gpu_safety.py): `blocks`
+// 4-wave blocks that each pin `lds_bytes` of a CU's LDS for `ticks` x 10 ns and do nothing else -- with 144 KiB no block of the fused MLP /
+// fused row-update launch fits beside one, i.e. those CUs are taken the way another process's kernels would take them.
+__global__ __launch_bounds__(256) void occupy_kernel(int ticks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    smem[threadIdx.x] = 1;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+int launch_occupy(int blocks, int lds_bytes, int ticks, hipStream_t st) {
+    const hipError_t r = hipFuncSetAttribute(reinterpret_cast<const void*>(&occupy_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    if (r != hipSuccess) return (int)r;
+    occupy_kernel<<<blocks, 256, (size_t)lds_bytes, st>>>(ticks);
+    return (int)hipGetLastError();
 }
 int launch_xcc_probe(int32_t* out, int blocks, int heavy, hipStream_t st) {
     if (heavy) {

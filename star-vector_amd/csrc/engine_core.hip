@@ -319,6 +319,7 @@ extern "C" int sv_destroy(sv_engine* e) {
     for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
     if (e->gen_event) (void)hipEventDestroy(e->gen_event);
     if (e->gen_stream) (void)hipStreamDestroy(e->gen_stream);
+    if (e->tenant_stream) (void)hipStreamDestroy(e->tenant_stream);
     delete e;
     return 0;
 }

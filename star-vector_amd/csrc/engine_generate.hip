@@ -185,6 +185,8 @@ int sveng::check_finite_logits(sv_engine* e, hipStream_t st, const char* who) {
     if (!e->h_flags[4]) return 0;
     const int what = e->h_flags[4];
     HIPCHECK(hipMemsetAsync(e->d_bad, 0, sizeof(int32_t), st));
+    // (The failed steps may have appended non-finite K / V rows to their pages.  Nothing is scrubbed here: the decode attention clears the stale
+    //  V columns of a sequence's current key group itself -- attention.hip, process() -- so a page's next owner never multiplies them.)
     HIPCHECK(hipStreamSynchronize(st));
     if (what == 4 && e->rc_dbg) {
         long long d[8] = {0};

@@ -168,6 +168,19 @@ extern "C" int sv_debug_xcc_map(sv_engine* e, int32_t blocks, int32_t heavy, int
     return 0;
 }
 
+// A foreign tenant for the safety tests: `blocks` blocks that each pin `lds_bytes` of LDS on a CU for `ms` milliseconds, launched on a
+// stream of their own; returns at once.  The caller then decodes on the same GPU.
+extern "C" int sv_debug_occupy_cus(sv_engine* e, int32_t blocks, int32_t lds_bytes, int32_t ms) {
+    if (!e || blocks < 1 || blocks > 4096 || lds_bytes < 1024 || lds_bytes > 160 * 1024 || ms < 1 || ms > 5000)
+        return fail(SV_EINVAL, "sv_debug_occupy_cus: blocks 1..4096, lds_bytes 1 KiB..160 KiB, ms 1..5000");
+    std::lock_guard<std::mutex> lk(e->mu);
+    HIPCHECK(hipSetDevice(e->cfg.device));
+    if (!e->tenant_stream) HIPCHECK(hipStreamCreateWithFlags(&e->tenant_stream, hipStreamNonBlocking));      // kept: hipStreamDestroy would wait for the kernel
+    const int rc = launch_occupy(blocks, lds_bytes, ms * 100000, e->tenant_stream);
+    if (rc) return fail(SV_EHIP, "sv_debug_occupy_cus: launch failed (%d)", rc);
+    return 0;
+}
+
 extern "C" int sv_debug_set_gemm_form(int32_t form) {
     if (form < -1 || form > 2) return fail(SV_EINVAL, "sv_debug_set_gemm_form: -1 (tuned), 0 .. 2");
     set_gemm_form(form);

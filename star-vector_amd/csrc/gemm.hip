@@ -1157,7 +1157,10 @@ __device__ __forceinline__ void sk_store(const SkinnyArgs& p, float* v, const fl
 struct SkinnyKernarg { const void* W; const bf16_t* x; int KS; int ks_per_split; int flags; SkinnyArgs p; };      // the kernarg segment of the skinny kernels
 // FOLD: the LayerNorm-folded c_fc (decode_cols.hip) -- its own instantiation, so that the statistics registers do not cost the
 // other GEMMs their second block per CU (<= 128 VGPRs)
-template <int WAVES, bool FOLD = false>
+// HEAD: the lm_head launch of a step that folds the greedy selection into the epilogue and / or arms the polled buffer of the next
+// step's fused row-update launch (SkinnyArgs::amax / ::poison) -- its own instantiation as well: carried as run-time branches by every
+// skinny launch, the two cost StarVector-8B's 129 GEMM launches per step 0.2 us each (3982 vs 3950 us per step, same box: round 5)
+template <int WAVES, bool FOLD = false, bool HEAD = false>
 __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* Wp_, const bf16_t* xp_, int KS_, int ks_per_split_, int flags_, SkinnyArgs p_unused) {
     constexpr int CH = 4;                            // k-steps per register chunk (two chunks = 8 KiB of W in flight per wave)
     constexpr int NB = 2;
@@ -1214,7 +1217,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
     auto late = [&]() {                                     // the stream is in flight: now the rest of the arguments + the bias
         p = sv_late_args<SkinnyArgs>(offsetof(SkinnyKernarg, p));
         sk_bias<RPW>(p, bias_d, wave * RPW, nt, half, FOLD ? fc1 : nullptr);
-        if constexpr (!FOLD && WAVES > 1) {
+        if constexpr (HEAD) {
             if (p.out_mode == SK_OUT_F32 && p.poison) {      // SkinnyArgs::poison: the first blocks of the lm_head launch, fire and forget
                 const unsigned off = ((blockIdx.x + gridDim.x * blockIdx.z) * (unsigned)(WAVES * 64) + (unsigned)tid) * 16u;
                 if (off < p.poison_bytes) {
@@ -1305,7 +1308,7 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
         fold = SkFold{true, mean, rsqrtf(var + p.fold_eps)};
     }
     sk_store<RPW>(p, v, bias_d, wave * RPW, nt, mt, split, m, half, fold, fc1);
-    if constexpr (!FOLD && WAVES > 1) {
+    if constexpr (HEAD) {
         // Greedy selection folded into the lm_head launch: the logits this block has just rounded and stored are
         // still in registers -- lane (m, half) of wave w holds RPW columns of row m.  Best (value, lowest column) of the lane, of the
         // two halves (one shuffle), of the 8 waves (the statistics slots of the FOLD instantiation: unused here), then ONE atomic max
@@ -1591,6 +1594,7 @@ int init_gemm_kernels() {
     // 16-wave blocks reduce through 64 KiB of LDS: above the default dynamic-LDS limit
     int r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<16, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<16, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (!r) r = init_mt2_attrs();
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<bf16_t>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
@@ -1602,6 +1606,8 @@ int init_gemm_kernels() {
 template <int W>
 static void launch_sk(const SkinnyArgs& a, dim3 grid, hipStream_t st) {
     if (a.fold_c1) gemm_skinny_kernel<W, true><<<grid, W * 64, skinny_smem(W), st>>>(a.Wp, a.xp, a.K / 16, (a.K / 16) / a.splitk, a.xcd_remap, a);
+    else if (W > 1 && a.out_mode == SK_OUT_F32 && (a.amax || a.poison))
+        gemm_skinny_kernel<W, false, (W > 1)><<<grid, W * 64, skinny_smem(W), st>>>(a.Wp, a.xp, a.K / 16, (a.K / 16) / a.splitk, a.xcd_remap, a);
     else gemm_skinny_kernel<W, false><<<grid, W * 64, skinny_smem(W), st>>>(a.Wp, a.xp, a.K / 16, (a.K / 16) / a.splitk, a.xcd_remap, a);
 }
 

@@ -233,6 +233,7 @@ void launch_rope_prefill(bf16_t* qkv, int row_stride, int rows, int S0, int n_he
 void launch_attn_decode(const AttnDecodeArgs& a, hipStream_t st);
 // XCC_ID of every block of a 1-D launch of `blocks` 8-wave blocks (heavy = 1: with the decode attention's LDS footprint and 10 us of residence)
 int launch_xcc_probe(int32_t* out, int blocks, int heavy, hipStream_t st);
+int launch_occupy(int blocks, int lds_bytes, int ticks, hipStream_t st);     // test tenant: pins LDS of `blocks` CUs for ticks x 10 ns
 size_t attn_decode_part_floats(int head_dim);            // floats of `part` per sequence
 int init_attention_kernels();   // returns a hipError_t value (0 = ok)
 

@@ -351,6 +351,11 @@ class HipEngine:
             check(n, "sv_debug_attn_trace")
         return torch.tensor(list(buf[: n * 16]), dtype=torch.int64).view(n, 16)
 
+    def debug_occupy_cus(self, blocks: int, lds_bytes: int = 144 * 1024, ms: int = 300):
+        """Test tenant (include/starvector_hip_debug.h, sv_debug_occupy_cus): pin `lds_bytes` of LDS on `blocks` CUs for `ms` milliseconds
+        from a stream of its own; returns at once."""
+        check(self.lib.sv_debug_occupy_cus(self._h, blocks, lds_bytes, ms), "sv_debug_occupy_cus")
+
     def debug_xcc_map(self, blocks: int, heavy: bool = False):
         """[blocks] list of XCC_IDs: where the blocks of a 1-D launch of 8-wave blocks ran (heavy: with the decode attention's LDS footprint and
         10 us of residence, so that a grid above the CU count runs in rounds; include/starvector_hip.h, sv_debug_xcc_map)."""

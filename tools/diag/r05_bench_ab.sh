@@ -1,0 +1,11 @@
+# same-box A/B: the round-4 tree (_ab_r04, exported from the r04 commit and built in place) against this tree, configs 2 / 4 / 5
+OUT=gpurun_out/r05ab2; mkdir -p $OUT; n=0
+for tree in _ab_r04 . _ab_r04 .; do
+  n=$((n+1)); tag=$( [ "$tree" = "." ] && echo r05 || echo r04 )_$n
+  ( cd $tree && timeout 300 python bench.py --no-cpu-baseline ) > $OUT/cfg2_${tag}.json 2> $OUT/cfg2_${tag}.err
+  ( cd $tree && timeout 300 python bench.py --model 8b --new-tokens 256 --steps 2 --no-cpu-baseline ) > $OUT/cfg4_${tag}.json 2> $OUT/cfg4_${tag}.err
+  ( cd $tree && timeout 300 python bench.py --model 8b --weights fp8 --task text2svg --new-tokens 256 --steps 2 --no-cpu-baseline ) > $OUT/cfg5_${tag}.json 2> $OUT/cfg5_${tag}.err
+done
+for f in $OUT/cfg*.json; do echo "== $f"; grep "^{" $f | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print(d['value'], d.get('ttft_p50_ms'), d.get('decode_us_per_step'), d['roofline']['frac'])" || tail -3 ${f%.json}.err; done
