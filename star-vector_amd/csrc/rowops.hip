@@ -279,11 +279,16 @@ void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st) {
 //              16-byte sc1 (write-through) stores.
 //   GEMM role  block 32 + L: the (tile, K slice) of gemm_skinny_kernel's XCD-aware assignment for block L; weights -> registers, then the
 //              wave polls the 4 KiB of activations of ITS k-steps with sc1 loads and recognises "not written yet" by the data: the buffer
-//              is pre-filled with the bf16 pair 0xFFFF'FFFF -- by the attention launch of the layer before (AttnDecodeArgs::poison2),
-//              for layer 0 by a memset node at the head of the step -- which no finite LayerNorm output produces.  Bounded by the wall
+//              is pre-filled with the bf16 pair 0xFFFF'FFFF, which no finite LayerNorm output produces -- by the attention launch of the
+//              layer before (AttnDecodeArgs::poison2), for layer 0 by the lm_head launch of the step / prompt pass before
+//              (SkinnyArgs::poison).  ONLY write-through stores and L1-bypassing loads ever touch this buffer: the first wiring armed it
+//              with a memset node and shared it with the prompt pass's plain stores, and a stale line in one XCD's L2 turned up as NaN
+//              logits in bench.py's third call.  Bounded by the wall
 //              clock (give-up code 4 in *err: never a hang).  Then gemm_skinny_kernel<8, false>'s 4 MFMAs, LDS reduction in wave order
 //              and slab store: bit-identical slabs.
 //   Needs every block resident at once: on for an engine that owns its GPU (sv_config.exclusive_device), like the fused MLP launch.
+//   (The row blocks are the FIRST blocks of the grid and wait for nothing, so a GEMM block never waits for a block dispatched behind it;
+//    the all-resident rule is kept anyway -- dispatch order is observed behaviour, not a documented guarantee.)
 // ------------------------------------------------------------------------------------------------
 struct RowCattnKernarg { const float* ws; const bf16_t* bias; bf16_t* h; const bf16_t* Wp; int splitk_ru, ldws, rows_ws, M, KS, ks_per_split, n_tiles, S;
                          RowCattnArgs p; };
