@@ -317,8 +317,11 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
             rc_done = launch_rowln_cattn(ru, a, e->d_bad, 500000, st, e->rc_delay, e->rc_dbg, i) == 0;      // 5 ms budget; a refusal takes the two launches
         }
         if (!rc_done) {
+            bf16_t* const xo = rc ? e->xp_f : xp_ln;             // a refused fused launch must not reach the polled buffer with plain stores / loads
+            ru.xp_out = xo;
             row_update();                                        // embedding or the previous layer's down-proj -> LN1(h)
-            skinny(xp_ln, L.c_attn, SK_OUT_PARTIAL, wsA);
+            skinny(xo, L.c_attn, SK_OUT_PARTIAL, wsA);
+            ru.xp_out = xp_ln;
         }
         // c_fc + down projection in ONE launch (gemm.hip mlp_fused_kernel): on when the engine owns its GPU (sv_config.exclusive_device);
         // SV_EXP bit 128 forces it on, bit 512 off (in-process A/B, tools/ab_exp.py).  It recognises unwritten activations by a pattern

@@ -388,6 +388,44 @@ def test_config2_batch32_long_contexts(config2, S0, n_new, chunk):
     gc.collect(); torch.cuda.empty_cache()
 
 
+def test_config2_long_context_with_peaked_attention():
+    """with random weights the attention over thousands of keys is a small part of the residual, and the case above at
+    7780 -> 7800 moves by only ~1 x its tolerance when a far KV page is swapped -- it could not see the bug it is named for.  Same model, same
+    context, but the QUERY rows of every c_attn (weight and bias) are multiplied by Q_GAIN in the engine and in the oracle alike: a peaked
+    softmax, where a wrong page moves the oracle's own logits by several tolerances (asserted) while the engine still has to stay inside ONE
+    (LOGIT_TOL, teacher-forced, every step, every row).  How peaked: tools/diag/peaked_sweep.py -- gain 1 / 1.5 / 2 / 3 / 4 gives a page-swap
+    sensitivity of 1.0 / 1.3 / 1.7-2.8 / 3.9-9.0 / 21-30 x the tolerance, an engine error of 1.3 / 1.3 / 1.2 / 1.6 / 3.9e-2 of the scale and
+    a distance of the ORACLE'S OWN bf16 and fp32 modes of 1.0 / 1.1 / 1.1 / 1.1 / 3.4e-2: beyond gain 3 the function itself amplifies
+    roundings (any two correct bf16 implementations differ by more than the tolerance), so 2.5 is as discriminating as this test can be."""
+    Q_GAIN, B, S0, n_new = 2.5, 8, 7780, 12
+    cfg = dataclasses.replace(O.OracleConfig(), eos_token_id=-1)
+    w = O.make_weights(cfg, seed=1234)
+    D = cfg.hidden
+    for i in range(cfg.n_layer):
+        p = f"{O.P_DEC}h.{i}.attn.c_attn."
+        w[p + "weight"][:D] = (w[p + "weight"][:D].float() * Q_GAIN).to(torch.bfloat16).to(w[p + "weight"].dtype)
+        w[p + "bias"][:D] = (w[p + "bias"][:D].float() * Q_GAIN).to(torch.bfloat16).to(w[p + "bias"].dtype)
+    eng = build_engine(cfg, w, max_batch=B, max_seq_len=7808)
+    w_dev = {k: v.to(dev()) for k, v in w.items() if "image_encoder" not in k and "image_projection" not in k}
+    del w
+    gc.collect()
+    emb = _synthetic_prompt(B, S0, cfg.hidden, 8780)
+    o_toks, o_lg, cache = _oracle_long(w_dev, cfg, emb, n_new, 2)
+    tag = f"config2 dims, B={B}, q x {Q_GAIN:g}, context {S0}->{S0 + n_new}"
+    _teacher_forced_long(eng, emb, o_toks, o_lg, tag, 0.1, max_near=0.2)
+    with torch.no_grad():
+        ref_next, _ = O.decoder_decode_step(w_dev, cfg, o_toks[:, -1], cache, "bf16")
+    tol_abs = LOGIT_TOL * float(o_lg.abs().max())
+    last_page = (S0 + n_new - 2) // 64
+    sens = [_page_swap_sensitivity(w_dev, cfg, cache, o_toks[:, -1], ref_next.float(), pg, 0, tol_abs) for pg in (last_page - 1, 61, 7)]
+    print(f"[{tag}] sensitivity: swapping KV page {last_page - 1} / 61 / 7 for page 0 in every layer moves the oracle's logits by "
+          f"{sens[0]:.1f} / {sens[1]:.1f} / {sens[2]:.1f} x the tolerance")
+    assert min(sens) >= 1.5 and max(sens) >= 5.0, sens          # measured 16.5 / 2.1 / 5.2 (the unscaled case: ~1.0 each)
+    eng.close()
+    del w_dev, cache
+    gc.collect(); torch.cuda.empty_cache()
+
+
 def test_starvector_8b_dims_window_4096_at_long_context():
     """StarVector-8B dimensions (hidden 4608, 36 / 4 heads, RoPE, sliding_window = 4096 -- the real value), two StarCoder2 layers deep, B = 4:
     prompt of 4090 rows (the windowed prompt pass) then 30 decode steps to context 4120, where the window masks real keys."""
