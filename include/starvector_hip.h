@@ -98,10 +98,12 @@ typedef struct sv_config {
     int32_t exclusive_device;  /* != 0: this engine is the only thing launching kernels on its GPU while it decodes (the deployment the
                                   path is built for: one process per GPU).  Enables the decode launches that need ALL their
                                   workgroups resident at once (mlp_fused_kernel: the MLP half of a layer as one launch, 256 blocks, one
-                                  per CU, in-launch hand-off).  Results are bit-identical either way.  With ANOTHER process or engine
-                                  decoding on the same GPU such a launch can find its blocks only partly resident: the waiting
-                                  blocks then give up after a bounded spin and the call fails (never a hang, never wrong tokens) --
-                                  leave it 0 there.  Default 0. */
+                                  per CU, in-launch hand-off; rowln_cattn_kernel: the row update and the c_attn projection as one
+                                  launch).  Results are bit-identical either way.  With ANOTHER process or engine decoding on the same
+                                  GPU such a launch can find its blocks only partly resident: the waiting blocks then give up after
+                                  a wall-clock bound (5 ms) and the call -- sv_generate, beam search, sv_decode_step, sv_cb_step --
+                                  fails with SV_EHIP and a message naming the launch (never a hang, never tokens; executed by
+                                  tests/test_gpu_safety.py); the next call starts clean.  Leave it 0 there.  Default 0. */
 } sv_config;
 
 /* Streaming: called on the host with the tokens that became final since the last call -- tokens [batch][n_cols] int32
