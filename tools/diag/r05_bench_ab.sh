@@ -1,4 +1,6 @@
-# same-box A/B: the round-4 tree (_ab_r04, exported from the r04 commit and built in place) against this tree, configs 2 / 4 / 5
+# same-box A/B: the round-4 tree against this tree, configs 2 / 4 / 5, alternating inside ONE gpurun call.
+# Recipe for the other tree (not kept in the repository; _ab_r04/ is git-ignored but travels with the snapshot):
+#   mkdir _ab_r04 && git archive <round-4 commit> | tar -x -C _ab_r04 && (cd _ab_r04 && python -c 'import __graft_entry__ as g; g.build()')
 OUT=gpurun_out/r05ab2; mkdir -p $OUT; n=0
 for tree in _ab_r04 . _ab_r04 .; do
   n=$((n+1)); tag=$( [ "$tree" = "." ] && echo r05 || echo r04 )_$n
