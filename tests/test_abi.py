@@ -176,6 +176,7 @@ def test_argument_validation_precedes_any_device_work(lib):
     assert lib.sv_debug_gemm_trace(256, 256, 256, 0, 2, buf, 1) == -22 and "form" in err()
     assert lib.sv_debug_gemm_trace(512, 512, 256, 0, 1, buf, 1) == -22 and "capacity" in err()
     assert lib.sv_debug_xcc_map(None, 8, 0, None) == -22
+    assert lib.sv_debug_occupy_cus(None, 1, 1024, 1) == -22                       # the safety tests' tenant: no engine, no launch
     if not torch.cuda.is_available():
         c = SvConfig()
         lib.sv_config_default_1b(C.byref(c))
