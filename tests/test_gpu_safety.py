@@ -153,3 +153,46 @@ def test_a_poisoned_request_fails_its_batch_once_and_nothing_after_it():
         eng.generate(poisoned, max_length=emb.shape[1] + 24, eos_token_id=-1)
     assert torch.equal(eng.generate(emb, **kw).cpu(), gold)
     eng.close()
+
+
+def test_continuous_batching_on_an_engine_that_owns_its_gpu_equals_solo_runs():
+    """The serving deployment with SV_EXCLUSIVE_DEVICE=1: the slots of a continuous batch run through the same decode_forward as sv_generate, so
+    on an exclusive engine their steps take BOTH fused launches (rows >= 10: the attention launch has room for the patterns).  StarVector-1B
+    widths, 6 decoder layers: twelve requests admitted in two groups (bucket 16), greedy and sampled -- every slot's stream equals its solo
+    sv_generate run, and equals what an engine WITHOUT the fused launches (SV_EXP 512 + 8192) gives."""
+    B = 12
+    eng = sva.HipEngine(sva.EngineConfig(max_batch=16, max_seq_len=259 + 80, n_layer=6, vit_layers=2, exclusive_device=True))
+    eng.load_random_weights(seed=21)
+    g = torch.Generator().manual_seed(5)
+    img = torch.randn(B, 3, 224, 224, generator=g).to(torch.bfloat16).to(dev())
+    prompt = torch.tensor([[7, 11]] * B, dtype=torch.long, device=dev())
+    emb = torch.cat([eng.adapter(eng.encode_image(img)), eng.embed_tokens(prompt)], 1).contiguous()
+    S0 = emb.shape[1]
+    reqs = [dict(max_new_tokens=40 + 3 * i, eos_token_id=-1) if i % 3 else
+            dict(max_new_tokens=40 + 3 * i, eos_token_id=-1, do_sample=True, temperature=0.9, top_p=0.9, top_k=50, seed=100 + i) for i in range(B)]
+
+    def solo(i):
+        r = reqs[i]
+        return eng.generate(emb[i:i + 1].contiguous(), max_length=S0 + r["max_new_tokens"], eos_token_id=-1, do_sample=r.get("do_sample", False),
+                            temperature=r.get("temperature", 1.0), top_p=r.get("top_p", 1.0), top_k=r.get("top_k", 0), seed=r.get("seed", 0)).cpu()[0]
+
+    def batched():
+        slots = eng.cb_admit(emb[:7].contiguous(), reqs[:7])
+        eng.cb_step(5)
+        slots += eng.cb_admit(emb[7:].contiguous(), reqs[7:])
+        while eng.cb_step(8) > 0:
+            pass
+        out = [eng.cb_read(s, 0, reqs[i]["max_new_tokens"]) for i, s in enumerate(slots)]
+        eng.cb_reset()
+        return out
+
+    alone = [solo(i) for i in range(B)]
+    assert len({tuple(a.tolist()[:8]) for a in alone}) >= 4                     # distinct streams (a 6-layer random model repeats itself under greedy)
+    fused = batched()
+    eng.set_exp(512 + 8192)                                                     # neither fused launch
+    plain = batched()
+    eng.set_exp(0)
+    for i in range(B):
+        assert torch.equal(fused[i], alone[i]), f"slot {i}: continuous batch (fused launches) differs from the solo run"
+        assert torch.equal(plain[i], alone[i]), f"slot {i}: continuous batch (plain launches) differs from the solo run"
+    eng.close()
