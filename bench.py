@@ -285,11 +285,12 @@ def main():
     others_ms = prof.get("others_chain_ms_per_step", 0.0)
     # An engine that owns its GPU runs the row update of every layer INSIDE the c_attn launch (rowln_cattn_kernel); the profiling legs time the
     # unfused launches, so the 24 row updates that now belong to the family are taken out of the "others" chain (their event-delta share)
-    rc_on = bool(ec.exclusive_device) and not is8b and args.weights == "bf16" and os.environ.get("SV_EXP", "0") in ("", "0")
+    # (StarVector-8B, bf16, <= 32 rows: the same for the ln_1 row update of its 7-launch layer -- rowln_cattn_kernel<9, true>; ln_2's stays a launch)
+    rc_on = bool(ec.exclusive_device) and args.weights == "bf16" and B_PER_GPU <= 32 and os.environ.get("SV_EXP", "0") in ("", "0")
     if rc_on and others_ms > 0:
         ru = prof.get("row_update_ln", {})
         n_ru = max(ru.get("launches_per_step", 0.0), 1.0)
-        others_ms = max(others_ms - ru.get("ms_per_step", 0.0) * (n_ru - 1.0) / n_ru, 0.0)
+        others_ms = max(others_ms - ru.get("ms_per_step", 0.0) * min(float(cfg.n_layer), n_ru - 1.0) / n_ru, 0.0)
     sk_ms = max(sk_chain_ms, step_ms - others_ms) if others_ms > 0 and step_ms > others_ms else sk_chain_ms
     achieved = W_BYTES_PER_STEP / (sk_ms * 1e-3) / 1e9 if sk_ms > 0 else None
     # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process, so the figure is
@@ -356,6 +357,7 @@ def main():
             "decode_us_per_step": round(decode_ms / max(decode_steps, 1) * 1e3, 1),
             "roofline": {"bound": "hbm", "kernel": "decoder weight-streaming GEMMs: " + (
                              "gemm_skinny_mt2_kernel (two row tiles, up to three column tiles per block)" if B_PER_GPU > 32 else
+                             "rowln_cattn_kernel<9, true> (ln_1 row update + c_attn in one launch) + gemm_skinny_kernel" if (is8b and rc_on) else
                              "gemm_skinny_kernel" if (is8b or args.weights != "bf16") else
                              "rowln_cattn_kernel (row update + c_attn in one launch) + gemm_cols_resid_kernel (attention output projection) + mlp_fused_kernel "
                              "(c_fc and down projection in one launch) + gemm_skinny_kernel (lm_head)"
@@ -367,7 +369,7 @@ def main():
                          "algorithmic_bytes_per_launch": round(W_BYTES_PER_STEP / launches),
                          "avg_launch_us": round(sk_ms * 1e3 / launches, 2),
                          "avg_launch_us_source": ("in situ: (decode step - back-to-back chain of the step's other kernels) / launches" +
-                                                  ("; the 24 row updates that run inside the c_attn launch count with the family" if rc_on else "")),
+                                                  (f"; the {cfg.n_layer} row updates that run inside the c_attn launch count with the family" if rc_on else "")),
                          "avg_launch_us_gemm_chain": round(sk_chain_ms * 1e3 / launches, 2),
                          "frac_gemm_chain": round(W_BYTES_PER_STEP / (sk_chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sk_chain_ms > 0 else None,
                          "avg_exec_us_event_deltas": round(sk_exec_ms * 1e3 / launches, 2)},

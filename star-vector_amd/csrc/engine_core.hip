@@ -568,9 +568,16 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
                           dn.splitk >= 1 && 8 % dn.splitk == 0 && dn.Kpad / 16 == dn.splitk * 128 && (dn.Npad / 32) * dn.splitk == T1 &&
                           dn.Kpad == fc.Npad;
         if (e->mlp_fused_ok && getenv("SV_MLP_TRACE")) rc = dalloc(e, &e->mlp_trace, (size_t)T1 * 8);
-        // the row update + c_attn launch (rowops.hip): the projection's whole weight share per wave is 4 k-steps, every block resident
-        const Linear& ca = e->dec[0].c_attn;
-        e->rc_fused_ok = !ca.fp8 && rowln_cattn_fits(D, ca.Npad, ca.Kpad, ca.splitk, dn.splitk, e->num_cus);
+    }
+    if (!rc) {
+        // the row update + c_attn launch (rowops.hip): the projection's whole weight share per wave in registers (4 k-steps at
+        // StarVector-1B, 9 at StarVector-8B: round 5 carried the launch to the 7-launch layer of the wide model), bf16 weights, one row tile
+        const Linear& ca = e->dec[0].c_attn; const Linear& dn = e->dec[0].c_proj2;
+        e->rc_fused_ok = c.weight_dtype == SV_WEIGHT_BF16 && e->MT == 1 && !ca.fp8 &&
+                         rowln_cattn_fits(D, ca.Npad, ca.Kpad, ca.splitk, dn.splitk, e->num_cus);
+        // narrow rows (StarVector-1B): the first poll 3.9 us after block start; wide rows (StarVector-8B): the weight stream is the timer and the
+        // GEMM blocks' hold-back in front of it measured best at 0 (profiles/rowln_cattn_r05_ab.log, section 8)
+        e->rc_delay = D > 2048 ? 0 : 390;
         if (const char* dl = getenv("SV_RC_DELAY")) { const int v = atoi(dl); if (v >= 0 && v <= 2000) e->rc_delay = v; }
     }
     if (rc) { sv_destroy(e); return rc; }

@@ -147,7 +147,9 @@ int sveng::assign_pages(sv_engine* e, int B, int total_len, hipStream_t st) {
 // (First form: a memset node at the head of the step + the prompt pass's ln_f through xp_a with plain stores -- NaN logits in the third
 //  sv_generate call of bench.py: a stale line of the buffer in some XCD's L2.)
 static bool rc_enabled(const sv_engine* e) {
-    return e->fold6 && e->fold_ready && !(e->exp & 2) && e->rc_fused_ok && !(e->exp & 8192) && (e->cfg.exclusive_device || (e->exp & 16384));
+    // the 6-launch layer (fold6: residual stream in fragment order) or the 7-launch layer of the wide model (row-major residual stream)
+    const bool layer_ok = e->fold6 ? (e->fold_ready && !(e->exp & 2)) : e->cfg.hidden > 2048;
+    return layer_ok && e->rc_fused_ok && !(e->exp & 8192) && (e->cfg.exclusive_device || (e->exp & 16384));
 }
 static void lm_head_logits(sv_engine* e, int MT, const bf16_t* xp, hipStream_t st) {
     SkinnyArgs a;
@@ -267,8 +269,9 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
     // (B >= 10 at StarVector-1B's shapes).  Not inside the profiling legs (they time the row updates and the GEMMs apart).  A call that
     // cannot fuse on an engine that does (see rc_enabled) keeps its LayerNorm outputs out of xp_a.
     const size_t attn_threads_bytes = (size_t)B * e->nkv * attn_max_splits(e) * 512 * 16;
+    const bool mlp_pattern = fold6 && e->mlp_fused_ok;          // the attention launch may also have to arm the fused MLP launch's buffer
     const bool rc = rc_enabled(e) && MT == 1 && !e->only_skinny && !e->skip_skinny && !e->prof_on &&
-                    (size_t)(D / 16) * 1024 + (size_t)(F / 16) * 1024 <= attn_threads_bytes;
+                    (size_t)(D / 16) * 1024 + (mlp_pattern ? (size_t)(F / 16) * 1024 : 0u) <= attn_threads_bytes;
     const unsigned xpa_bytes = (unsigned)((size_t)(D / 16) * 1024);
     bf16_t* const xp_ln = (rc_enabled(e) && !rc) ? e->xp_f : e->xp_a;      // LayerNorm(ln_1) output = the c_attn operand
 
@@ -314,7 +317,7 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
             a.xp = e->xp_a; a.Wp = L.c_attn.Wp; a.MT = MT; a.Npad = L.c_attn.Npad; a.K = L.c_attn.Kpad; a.N = L.c_attn.N;
             a.out_mode = SK_OUT_PARTIAL; a.splitk = L.c_attn.splitk; a.ws = wsA; a.ldws = e->ldws;
             prof_mark(e, PK_SKINNY, st);
-            rc_done = launch_rowln_cattn(ru, a, e->d_bad, 500000, st, e->rc_delay, e->rc_dbg, i) == 0;      // 5 ms budget; a refusal takes the two launches
+            rc_done = launch_rowln_cattn(ru, a, e->d_bad, 500000, st, e->rc_delay, e->rc_dbg, i, e->num_cus) == 0;      // 5 ms budget; a refusal takes the two launches
         }
         if (!rc_done) {
             bf16_t* const xo = rc ? e->xp_f : xp_ln;             // a refused fused launch must not reach the polled buffer with plain stores / loads
@@ -378,8 +381,11 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
         } else {
             skinny(e->xp_attn, L.c_proj, SK_OUT_PARTIAL, wsB);
             ru.ws = wsB; ru.splitk = L.c_proj.splitk; ru.bias = L.c_proj.bias; ru.g = L.ln2.g; ru.b = L.ln2.b;
+            bf16_t* const x2 = rc_enabled(e) ? e->xp_f : e->xp_a;      // an engine with the fused launch keeps xp_a for it alone (write-through / L1-bypass only)
+            ru.xp_out = x2;
             row_update();                                        // + bias + residual, LN2
-            skinny(e->xp_a, L.c_fc, SK_OUT_PACKED_ACT, nullptr);
+            skinny(x2, L.c_fc, SK_OUT_PACKED_ACT, nullptr);
+            ru.xp_out = xp_ln;
         }
         skinny(e->xp_mlp, L.c_proj2, SK_OUT_PARTIAL, wsB);
         const LNp& nxt = (i + 1 < c.n_layer) ? e->dec[i + 1].ln1 : e->ln_f;

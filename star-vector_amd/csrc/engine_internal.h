@@ -114,7 +114,8 @@ struct sv_engine {
     bf16_t* xp_f = nullptr;         // ln_f output of the last row update (the lm_head's operand) when xp_a belongs to the fused row-update + c_attn launch
     long long* rc_dbg = nullptr;    //   [8] what the first GEMM wave to give up saw
     hipStream_t tenant_stream = nullptr;       // sv_debug_occupy_cus (safety tests): the stream the foreign tenant's kernel runs on
-    int rc_delay = 390;             //   its GEMM blocks' first poll, 10-ns ticks after block start (3.9 us: measured optimum; SV_RC_DELAY at sv_create)
+    int rc_delay = 390;             //   narrow rows: its GEMM blocks' first poll, 10-ns ticks after block start (3.9 us: measured optimum); wide rows: their
+                                    //   hold-back in front of the weight requests (0); SV_RC_DELAY at sv_create
     bool rc_fused_ok = false;       // row update + c_attn as one launch (rowops.hip rowln_cattn_kernel) fits this engine: shapes + all blocks resident
     bool mlp_fused_ok = false;      // the MLP half as one launch (gemm.hip mlp_fused_kernel) fits this engine: shapes + one block per CU
     long long* attn_trace = nullptr;// SV_ATTN_TRACE=1: wall-clock stamps of the decode attention of the middle layer, [rows * kv heads * splits][16]

@@ -158,10 +158,13 @@ struct RowCattnArgs {
     float* ws_out; int ldws_out;                             // the projection's fp32 slabs [splitk][32][ldws]
     int* err; int spin_ticks;                                // give-up code 4 after spin_ticks x 10 ns of waiting (never a hang)
     int delay;                                               // GEMM blocks: 10-ns ticks between block start and the first poll
+    int first_round;                                         //   ... for the blocks below this index (the ones resident when the launch starts)
+    int ldh;                                                 // WIDE row role: residual row stride (0 = fragment order)
     long long* dbg; int layer;                               // optional [8]: what the first wave to give up saw (reported with the failure)
 };
 // 0 = launched; -1 = outside the kernel's scope (the caller runs the two launches).  sk.xp must be ru.xp_out.
-int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, int spin_ticks, hipStream_t st, int delay = 390, long long* dbg = nullptr, int layer = 0);
+int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, int spin_ticks, hipStream_t st, int delay = 390, long long* dbg = nullptr, int layer = 0,
+                       int num_cus = 256);
 bool rowln_cattn_fits(int D, int Npad, int K, int splitk, int splitk_ru, int num_cus);
 
 // ---- embeddings ---------------------------------------------------------------------------------

@@ -290,9 +290,128 @@ void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st) {
 //   (The row blocks are the FIRST blocks of the grid and wait for nothing, so a GEMM block never waits for a block dispatched behind it;
 //    the all-resident rule is kept anyway -- dispatch order is observed behaviour, not a documented guarantee.)
 // ------------------------------------------------------------------------------------------------
+// The row role for wide rows (2048 < D <= 8192): row_update_ln_kernel<1024>, value for value, on the 512 threads of a rowln_cattn block.
+// That kernel gives thread v < 1024 the chunk v (8 columns) and reduces (sum, then sum of squared deviations) by a 64-lane shuffle
+// per wave and a sum over the 16 waves in wave order.  Here thread t takes the chunks t (virtual wave t >> 6) and 512 + t (virtual
+// wave 8 + (t >> 6)), each virtual wave is reduced by the same shuffle, and the 16 partials are added in the same order.
+__device__ __forceinline__ void rowln_wide_role(const float* ws_, const bf16_t* bias_, bf16_t* h_, int splitk_ru_, int ldws_, int rows_ws_, int KS_,
+                                                int row, char* smem, const RowCattnArgs p) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* hrow = reinterpret_cast<float*>(smem);                                 // [D] (D <= 8192 - 64 floats: launcher)
+    float* redbuf = hrow + ((KS_ << 4) + 63) / 64 * 64;                           // [32]
+    const int D = KS_ << 4, NC = D >> 3;
+    float part[2] = {0.f, 0.f};
+    uint4 gq[2], bq2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + i * 512;
+        if (c < NC) {
+            gq[i] = *reinterpret_cast<const uint4*>(p.g + c * 8);
+            bq2[i] = *reinterpret_cast<const uint4*>(p.b + c * 8);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + i * 512;
+        if (c >= NC) continue;
+        bf16_t* hc = p.ldh ? h_ + (size_t)row * p.ldh + c * 8 : h_ + xp_index(row >> 5, KS_, row & 31, c * 8);
+        float f[8];
+        if (ws_ == nullptr) {                                                     // embedding mode: h = bf(wte[tok] + wpe[pos])
+            const int tok = p.tokens[row], pos = p.positions[row];
+            float a[8], w[8];
+            unpack8(*reinterpret_cast<const uint4*>(p.wte + (size_t)tok * D + c * 8), a);
+            if (p.wpe) {
+                unpack8(*reinterpret_cast<const uint4*>(p.wpe + (size_t)pos * D + c * 8), w);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = bfround(a[e] + w[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = a[e];
+            }
+        } else {                                                                  // h = bf(h + bf(sum of the slabs in slab order + bias))
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = 0.f;
+            const uint4 bq = *reinterpret_cast<const uint4*>(bias_ + c * 8);
+            const uint4 hq = *reinterpret_cast<const uint4*>(hc);
+            float4 sa[4], sb[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int sp = j < splitk_ru_ ? j : splitk_ru_ - 1;
+                const float* src = ws_ + ((size_t)sp * rows_ws_ + row) * ldws_ + c * 8;
+                sa[j] = *reinterpret_cast<const float4*>(src);
+                sb[j] = *reinterpret_cast<const float4*>(src + 4);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                                         // slab order (launcher: at most 4 slabs)
+                if (j < splitk_ru_) {
+                    v[0] += sa[j].x; v[1] += sa[j].y; v[2] += sa[j].z; v[3] += sa[j].w;
+                    v[4] += sb[j].x; v[5] += sb[j].y; v[6] += sb[j].z; v[7] += sb[j].w;
+                }
+            }
+            float bb[8], hh[8];
+            unpack8(bq, bb);
+            unpack8(hq, hh);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) f[e] = bfround(hh[e] + bfround(v[e] + bb[e]));
+        }
+        *reinterpret_cast<uint4*>(hc) = pack8(f);
+        float s = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { hrow[c * 8 + e] = f[e]; s += f[e]; }
+        part[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                                                 // virtual waves wave and 8 + wave
+        const float t = wave_sum(part[i]);
+        if (lane == 0) redbuf[8 * i + wave] = t;
+    }
+    __syncthreads();
+    float ssum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) ssum += redbuf[w];
+    const float mean = ssum / (float)D;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + i * 512;
+        float q = 0.f;
+        if (c < NC) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = hrow[c * 8 + e] - mean; q += d * d; }
+        }
+        q = wave_sum(q);
+        if (lane == 0) redbuf[16 + 8 * i + wave] = q;
+    }
+    __syncthreads();
+    float qsum = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) qsum += redbuf[16 + w];
+    const float rstd = rsqrtf(qsum / (float)D + p.eps);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.xp_out, 0, (unsigned)((size_t)KS_ * 1024), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = tid + i * 512;
+        if (c < NC) {
+            float gg[8], bb[8], o[8];
+            unpack8(gq[i], gg);
+            unpack8(bq2[i], bb);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (hrow[c * 8 + e] - mean) * rstd * gg[e] + bb[e];
+            const uint4 ov = pack8(o);
+            u32x4 q4 = {ov.x, ov.y, ov.z, ov.w};
+            __builtin_amdgcn_raw_buffer_store_b128(q4, rs, (int)(xp_index(0, KS_, row & 31, c * 8) * 2), 0, 16);      // sc1: write-through
+        }
+    }
+}
+
 struct RowCattnKernarg { const float* ws; const bf16_t* bias; bf16_t* h; const bf16_t* Wp; int splitk_ru, ldws, rows_ws, M, KS, ks_per_split, n_tiles, S;
                          RowCattnArgs p; };
-__global__ __launch_bounds__(512, 4) void rowln_cattn_kernel(const float* ws_, const bf16_t* bias_, bf16_t* h_, const bf16_t* Wp_, int splitk_ru_,
+// KPW: k-steps per GEMM wave (= K / 16 / splitk / 8: 4 at StarVector-1B, 9 at StarVector-8B -- the wave's whole weight share in 16 / 36
+// registers).  WIDE: the row role of row_update_ln_kernel<1024> (D > 2048: one 8-column chunk per thread of 1024) run by the 512 threads of
+// a block -- thread t takes the chunks t and 512 + t and the block reduces over the SAME 16 groups of 64 chunks in the same order, so the
+// statistics are the 1024-thread kernel's bit for bit (rowln_wide_role below); otherwise row_update_ln_kernel<256> on waves 0-3.
+template <int KPW, bool WIDE>
+__global__ __launch_bounds__(512, WIDE ? 6 : 4) void rowln_cattn_kernel(const float* ws_, const bf16_t* bias_, bf16_t* h_, const bf16_t* Wp_, int splitk_ru_,
                                                              int ldws_, int rows_ws_, int M_, int KS_, int ks_per_split_, int n_tiles_, int S_,
                                                              RowCattnArgs p_unused) {
     extern __shared__ __attribute__((aligned(16))) char rc_smem[];
@@ -302,7 +421,13 @@ __global__ __launch_bounds__(512, 4) void rowln_cattn_kernel(const float* ws_, c
     if (blockIdx.x < ROWB) {
         // ------------------------------------------------ row role ------------------------------------------------
         const int row = blockIdx.x;
-        if (row >= M_ || wave >= 4) return;
+        if (row >= M_) return;
+        if constexpr (WIDE) {
+            rowln_wide_role(ws_, bias_, h_, splitk_ru_, ldws_, rows_ws_, KS_, row, rc_smem,
+                            sv_late_args<RowCattnArgs>(offsetof(RowCattnKernarg, p)));
+            return;
+        }
+        if (wave >= 4) return;
         constexpr int THREADS = 256, NW = 4;
         float* hrow = reinterpret_cast<float*>(rc_smem);                          // [D]
         float* redbuf = hrow + 2048;                                              // [2 * NW]
@@ -400,7 +525,7 @@ __global__ __launch_bounds__(512, 4) void rowln_cattn_kernel(const float* ws_, c
         return;
     }
     // ------------------------------------------------ GEMM role ------------------------------------------------
-    constexpr int WAVES = 8, KPW = 4, RPW = 2;               // 4 k-steps per wave (launcher-checked): the whole share fits 16 registers
+    constexpr int WAVES = 8, RPW = 2;                        // KPW k-steps per wave (launcher-checked): the whole share fits 4 * KPW registers
     float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(rc_smem);          // [WAVES][16][64]
     const long long t_start = wall_clock64();
     const int L = blockIdx.x - ROWB;
@@ -412,6 +537,17 @@ __global__ __launch_bounds__(512, 4) void rowln_cattn_kernel(const float* ws_, c
     const int ks0 = split * ks_per_split_ + wave * KPW;
     const u32x4* wptr = reinterpret_cast<const u32x4*>(Wp_) + ((size_t)nt * KS_ + ks0) * 64 + lane;
     u32x4 w[KPW];
+    if constexpr (WIDE) {
+        // StarVector-8B: the projection's weights are 52 MB -- 8 us of HBM stream that the launch cannot go below, and a memory system
+        // saturated from t = 0 stretches every dependent access of the 16 row blocks by the drain time of the CUs' miss queues (measured:
+        // the row role published after > 6.5 us instead of 3.6, and polls that fail add their traffic on top: 4037 vs 3969 us per step).
+        // So the row blocks' loads go FIRST -- the GEMM blocks of the first resident round hold their weight requests back for p.delay
+        // ticks -- and nobody polls before its weights have landed (by then the LayerNorm output has long been published): the weight
+        // stream itself is the timer.
+        const RowCattnArgs pw = sv_late_args<RowCattnArgs>(offsetof(RowCattnKernarg, p));
+        if ((int)blockIdx.x < pw.first_round)
+            while (wall_clock64() - t_start < (long long)pw.delay) __builtin_amdgcn_s_sleep(4);
+    }
 #pragma unroll
     for (int u = 0; u < KPW; ++u) w[u] = __builtin_nontemporal_load(wptr + (size_t)u * 64);          // streamed once, depends on nothing
     const RowCattnArgs p = sv_late_args<RowCattnArgs>(offsetof(RowCattnKernarg, p));
@@ -425,23 +561,65 @@ __global__ __launch_bounds__(512, 4) void rowln_cattn_kernel(const float* ws_, c
     // store instruction of its block, so its k-steps turn up together -- and only then fetches the other three, re-checking them
     // (all four k-steps per poll: 1032 vs 1013 us per step at the same timing).
     // (wall clock, 100 MHz: the row update's latency is memory latency, not shader clocks -- an s_sleep count would drift with DVFS)
-    while (wall_clock64() - t_start < (long long)p.delay) __builtin_amdgcn_s_sleep(4);
-    u32x4 x[KPW];
+    // (blocks beyond the first resident round -- StarVector-8B: 704 GEMM blocks on 512 slots -- start when the data has long been there: no wait)
+    if constexpr (WIDE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // the weights are here: now look for the activations
+        // (requesting the first batch of activations BEHIND the weights at t = 0 -- a wave's loads return in order -- was tried: the batch is
+        //  read out of L2 long before the row blocks publish, every wave then pays the retry anyway, and the 20 registers held across the
+        //  stream spill: 4298 vs 3909 us per step)
+    } else {
+        if ((int)blockIdx.x < p.first_round)
+            while (wall_clock64() - t_start < (long long)p.delay) __builtin_amdgcn_s_sleep(4);
+    }
+    // XB: activation k-steps requested per batch.  The narrow form keeps all 4 in flight; the wide form takes its 9 as 5 + 4 (20
+    // registers instead of 36: with the 36 weight registers the kernel stays at <= 80 VGPRs, i.e. THREE blocks per CU -- all 736 blocks
+    // resident at once; at two per CU the last 224 blocks only start when the first ones leave and the launch streams its weights in two
+    // rounds: 17.7 us against ... measured below) -- the weights have landed by then, so a batch costs one L2 round trip.
+    constexpr int XB = WIDE ? 5 : KPW;
+    u32x4 x[XB];
     int gave_up = 1;
     auto patt = [&](const u32x4& v) { return m < M_ && (v[0] == 0xffffffffu || v[1] == 0xffffffffu || v[2] == 0xffffffffu || v[3] == 0xffffffffu); };
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     for (int it = 0;; ++it) {
         x[0] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, ks0 * 1024 + lane * 16, 0, 16);                 // sc1: L1 bypass
         if (!__any(patt(x[0]))) {
 #pragma unroll
-            for (int u = 1; u < KPW; ++u) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (ks0 + u) * 1024 + lane * 16, 0, 16);
+            for (int u = 1; u < XB; ++u) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (ks0 + u) * 1024 + lane * 16, 0, 16);
             bool bad = false;
 #pragma unroll
-            for (int u = 1; u < KPW; ++u) bad = bad || patt(x[u]);      // rows >= M of the tile are never written: only live rows are examined
+            for (int u = 1; u < XB; ++u) bad = bad || patt(x[u]);      // rows >= M of the tile are never written: only live rows are examined
             if (!__any(bad)) { gave_up = 0; break; }
         }
         if ((it & 7) == 7 && (wall_clock64() - t_start > (long long)p.spin_ticks ||
                               __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) break;
         __builtin_amdgcn_s_sleep(8);
+    }
+#pragma unroll
+    for (int u = 0; u < XB; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(w[u]), as_frag4(x[u]), acc, 0, 0, 0);
+    if constexpr (XB < KPW) {
+        // the remaining batches, in k order (the accumulation order of gemm_skinny_kernel: one chain over the wave's k-steps); every value
+        // that reaches an MFMA has been examined for the pattern
+#pragma unroll
+        for (int b0 = XB; b0 < KPW; b0 += XB) {
+            for (int it = 0; !gave_up; ++it) {
+#pragma unroll
+                for (int u = 0; u < XB; ++u)
+                    if (b0 + u < KPW) x[u] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (ks0 + b0 + u) * 1024 + lane * 16, 0, 16);
+                bool bad = false;
+#pragma unroll
+                for (int u = 0; u < XB; ++u)
+                    if (b0 + u < KPW) bad = bad || patt(x[u]);
+                if (!__any(bad)) break;
+                if ((it & 7) == 7 && (wall_clock64() - t_start > (long long)p.spin_ticks ||
+                                      __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) { gave_up = 1; break; }
+                __builtin_amdgcn_s_sleep(8);
+            }
+#pragma unroll
+            for (int u = 0; u < XB; ++u)
+                if (b0 + u < KPW) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(w[b0 + u]), as_frag4(x[u]), acc, 0, 0, 0);
+        }
     }
     if (gave_up && lane == 0) {
         const int seen = atomicCAS(p.err, 0, 4);       // the step's result is void; the FIRST code raised survives (0 -> 4 only)
@@ -450,11 +628,6 @@ __global__ __launch_bounds__(512, 4) void rowln_cattn_kernel(const float* ws_, c
             p.dbg[4] = ((long long)x[0][0] << 32) | x[0][1]; p.dbg[5] = p.layer; p.dbg[6] = M_; p.dbg[7] = 1;
         }
     }
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-    for (int u = 0; u < KPW; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(w[u]), as_frag4(x[u]), acc, 0, 0, 0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
     __syncthreads();
@@ -475,26 +648,41 @@ __global__ __launch_bounds__(512, 4) void rowln_cattn_kernel(const float* ws_, c
 }
 
 // shape rule of the launch (host arithmetic; sv_create): D = hidden = K of the projection, Npad x K weight, split-K `splitk` slabs, the row
-// update in front sums `splitk_ru` slabs; blocks = 32 + (Npad / 32) * splitk, all of which must be resident at once (two per CU)
-bool rowln_cattn_fits(int D, int Npad, int K, int splitk, int splitk_ru, int num_cus) {
-    const int KS = K / 16, NT = Npad / 32;
-    if (D > 2048 || (D & 15) || K != D || splitk < 1 || 8 % splitk || KS % (splitk * 8) || KS / splitk / 8 != 4) return false;
-    if ((NT * splitk) % 8 || NT % (8 / splitk) || splitk_ru < 1 || splitk_ru > 4) return false;
-    return 32 + NT * splitk <= 2 * num_cus;
+// update in front sums `splitk_ru` slabs; blocks = 32 + (Npad / 32) * splitk.  k-steps per wave 4 (StarVector-1B) or 9 (StarVector-8B).
+// D <= 2048: all blocks resident at once (two per CU).  Wider rows (StarVector-8B: 32 + 704 blocks on 512 slots) rely on what the narrow
+// form only has as a second line of defence: the row blocks are the FIRST blocks of the grid and wait for nothing, blocks are dispatched in
+// index order, so a GEMM block never waits for a block dispatched behind it (and every wait is bounded by the wall clock anyway).
+static int rowln_kpw(int K, int splitk) {
+    const int KS = K / 16;
+    if (splitk < 1 || 8 % splitk || KS % (splitk * 8)) return 0;
+    const int kpw = KS / splitk / 8;
+    return (kpw == 4 || kpw == 9) ? kpw : 0;
 }
-int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, int spin_ticks, hipStream_t st, int delay, long long* dbg, int layer) {
+bool rowln_cattn_fits(int D, int Npad, int K, int splitk, int splitk_ru, int num_cus) {
+    const int NT = Npad / 32;
+    if (D > 8128 || (D & 15) || K != D || !rowln_kpw(K, splitk)) return false;
+    if ((NT * splitk) % 8 || NT % (8 / splitk) || splitk_ru < 1 || splitk_ru > 4) return false;
+    return D > 2048 || 32 + NT * splitk <= 2 * num_cus;
+}
+int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, int spin_ticks, hipStream_t st, int delay, long long* dbg, int layer, int num_cus) {
     const int KS = sk.K / 16, NT = sk.Npad / 32;
-    if (ru.D > 2048 || (ru.D & 15) || ru.ldh != 0 || ru.M < 1 || ru.M > 32 || sk.MT != 1 || sk.Wq || sk.out_mode != SK_OUT_PARTIAL) return -1;
+    const bool wide = ru.D > 2048;
+    if (ru.D > 8128 || (ru.D & 15) || (!wide && ru.ldh != 0) || ru.M < 1 || ru.M > 32 || sk.MT != 1 || sk.Wq || sk.out_mode != SK_OUT_PARTIAL) return -1;
     if (ru.ws && (ru.splitk < 1 || ru.splitk > 4)) return -1;              // the row role sums at most 4 slabs
-    if (sk.splitk < 1 || 8 % sk.splitk || KS % (sk.splitk * 8) || KS / sk.splitk / 8 != 4) return -1;      // 4 k-steps per wave
+    const int kpw = rowln_kpw(sk.K, sk.splitk);
+    if (!kpw || (wide && kpw != 9) || (!wide && kpw != 4)) return -1;      // the two instantiations
     if ((NT * sk.splitk) % 8 || NT % (8 / sk.splitk) || sk.K != ru.D || sk.xp != ru.xp_out || !err) return -1;
     RowCattnArgs a;
     memset(&a, 0, sizeof(a));
     a.g = ru.g; a.b = ru.b; a.eps = ru.eps; a.D = ru.D; a.wte = ru.wte; a.wpe = ru.wpe; a.tokens = ru.tokens; a.positions = ru.positions;
     a.xp_out = ru.xp_out; a.ws_out = sk.ws; a.ldws_out = sk.ldws; a.err = err; a.spin_ticks = spin_ticks; a.delay = delay; a.dbg = dbg; a.layer = layer;
+    a.first_round = (wide ? 3 : 2) * (num_cus > 0 ? num_cus : 256); a.ldh = ru.ldh;
     const size_t smem = (size_t)8 * 16 * 64 * 4 + 64;
-    rowln_cattn_kernel<<<32 + NT * sk.splitk, 512, smem, st>>>(ru.ws, ru.bias, ru.h, sk.Wp, ru.splitk, ru.ldws, ru.rows_ws, ru.M, KS, KS / sk.splitk,
-                                                                NT, sk.splitk, a);
+    const int grid = 32 + NT * sk.splitk;
+    if (wide)
+        rowln_cattn_kernel<9, true><<<grid, 512, smem, st>>>(ru.ws, ru.bias, ru.h, sk.Wp, ru.splitk, ru.ldws, ru.rows_ws, ru.M, KS, KS / sk.splitk, NT, sk.splitk, a);
+    else
+        rowln_cattn_kernel<4, false><<<grid, 512, smem, st>>>(ru.ws, ru.bias, ru.h, sk.Wp, ru.splitk, ru.ldws, ru.rows_ws, ru.M, KS, KS / sk.splitk, NT, sk.splitk, a);
     return 0;
 }
 

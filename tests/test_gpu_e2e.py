@@ -721,6 +721,54 @@ def test_starvector_8b_full_size_properties():
     eng.close()
 
 
+def test_row_update_and_c_attn_as_one_launch_at_starvector_8b_widths():
+    """Round 5, VERDICT r04 item 3 (one of the 1B launches carried to the wide model): StarVector-8B's decode layer is the 7-launch layer
+    (row-major residual stream, hidden 4608: a 1024-thread row update, a c_attn of 176 tiles x 4 K slices with NINE k-steps per wave); the
+    fused launch there is rowln_cattn_kernel<9, true> -- the wide row role on a block's 512 threads with the 1024-thread kernel's reduction
+    tree, 704 GEMM blocks behind 32 row blocks.  8B widths, 4 decoder layers, SV_EXP 16384 on a non-exclusive engine: teacher-forced logits,
+    greedy and sampled tokens at 16 / 11 rows and a single row (too few attention threads for the pattern stores: falls back by itself) are
+    IDENTICAL to the two launches."""
+    import starvector_amd as sva
+    ec = sva.EngineConfig.starvector_8b(max_batch=16, max_seq_len=578 + 80)
+    ec.n_layer, ec.vit_layers = 4, 1
+    eng = sva.HipEngine(ec)
+    eng.load_random_weights(seed=17)
+    B = 16
+    g = torch.Generator().manual_seed(3)
+    img = torch.randn(B, 3, 384, 384, generator=g).to(torch.bfloat16).to(dev())
+    prompt = torch.tensor([[7, 11]] * B, dtype=torch.long, device=dev())
+    emb = torch.cat([eng.adapter(eng.encode_image(img)), eng.embed_tokens(prompt)], 1).contiguous()
+    S0 = emb.shape[1]
+    kw = dict(max_length=S0 + 60, eos_token_id=-1, pad_token_id=0)
+    runs = {}
+    for mask in (0, 16384):
+        eng.set_exp(mask)
+        lg = [eng.prefill(emb)]
+        tok = lg[0].argmax(-1)
+        for _ in range(6):
+            lg.append(eng.decode_step(tok))
+            tok = lg[-1].argmax(-1)
+        toks = eng.generate(emb, **kw).cpu()
+        assert eng.last_timing()["graph"]
+        small = eng.generate(emb[:11].contiguous(), **kw).cpu()
+        one = eng.generate(emb[5:6].contiguous(), **kw).cpu()
+        samp = eng.generate(emb, do_sample=True, temperature=1.0, top_p=0.95, top_k=50, seed=3, **kw).cpu()
+        again = eng.generate(emb, **kw).cpu()
+        runs[mask] = (torch.stack(lg).cpu(), toks, small, one, samp, again)
+    eng.set_exp(0)
+    ref = runs[0]
+    assert torch.isfinite(ref[0].float()).all() and ref[4].unique().numel() > 16
+    for k, what in enumerate(["teacher-forced logits", "tokens (16 rows)", "tokens (11 rows)", "tokens (1 row)", "sampled tokens", "second call"]):
+        assert torch.equal(runs[16384][k], ref[k]), f"8B widths, SV_EXP 16384: {what} differ from the two launches"
+    eng.close()
+    own = sva.HipEngine(dataclasses.replace(ec, exclusive_device=True))           # the deployment: on by itself, same tokens
+    own.load_random_weights(seed=17)
+    emb2 = torch.cat([own.adapter(own.encode_image(img)), own.embed_tokens(prompt)], 1).contiguous()
+    assert torch.equal(own.generate(emb2, **kw).cpu(), ref[1])
+    assert torch.equal(own.generate(emb2, do_sample=True, temperature=1.0, top_p=0.95, top_k=50, seed=3, **kw).cpu(), ref[4])
+    own.close()
+
+
 def test_repetition_penalty_on_device():
     """starvector_base.py:237 -> HF RepetitionPenaltyLogitsProcessor, restated on device (bitmap of generated ids).
     Property: an overwhelming penalty never lets a token with a positive logit repeat; parity: the engine's stream equals
