@@ -1,3 +1,4 @@
+# the frozen tree of the round: the whole GPU suite, smoke, the bench lines, then the same-box A/B against the round-4 tree (recipe for _ab_r04/: tools/diag/r05_bench_ab.sh)
 bash tools/gpu_round_start.sh r05f4 pytestall smoke bench bench8b 2>&1 | tail -12
 OUT=gpurun_out/r05f4; n=0
 for tree in _ab_r04 . _ab_r04 .; do
