@@ -54,6 +54,13 @@ int  sv_debug_decode_plan(int32_t rows, int32_t N, int32_t K, int32_t fp8, int32
  *                             before another split joins (8 where rows x KV heads alone cover the CUs, else 4)} -- functions of the
  *                             engine's max_batch / KV heads only, never of the call's batch (a row's bits do not depend on its batch) */
 int  sv_debug_attn_plan(int32_t max_batch, int32_t n_kv_head, int32_t num_cus, int32_t* out2);
+/*   sv_debug_rowln_plan       whether (and how) an engine that owns its GPU runs a decode layer's row update and c_attn projection as ONE
+ *                             launch (rowops.hip rowln_cattn_kernel): hidden size D, the projection W [N][D] with
+ *                             split-K `splitk`, `splitk_ru` slabs summed by the row update in front, a GPU with `num_cus` CUs;
+ *                             out3 = {1 if the shapes fit, k-steps a GEMM wave holds in registers (4: StarVector-1B, 9: StarVector-8B), blocks of
+ *                             the launch = 32 row blocks + (N / 32) * splitk} -- narrow rows (D <= 2048) need every block resident at once
+ *                             (two per CU), wide rows rely on the row blocks being dispatched first.  Host arithmetic, pinned by the CPU tests */
+int  sv_debug_rowln_plan(int32_t D, int32_t N, int32_t splitk, int32_t splitk_ru, int32_t num_cus, int32_t* out3);
 /*   sv_debug_set_col_tiles    column tiles per block (1..3; 0 = the launcher's own choice) the OP-LEVEL decode GEMM entry points
  *                             (sv_op_linear_skinny*, 33..64 rows) launch with from now on, process-wide: lets the parity tests put
  *                             every variant of the two-row-tile kernel next to the one-tile kernels (all bit-identical).  An engine's

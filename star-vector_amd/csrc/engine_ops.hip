@@ -29,6 +29,16 @@ extern "C" int sv_debug_set_exp(sv_engine* e, int32_t mask) {
     return 0;
 }
 
+extern "C" int sv_debug_rowln_plan(int32_t D, int32_t N, int32_t splitk, int32_t splitk_ru, int32_t num_cus, int32_t* out3) {
+    if (!out3 || D < 16 || N < 1 || splitk < 1 || splitk_ru < 1 || num_cus < 1) return fail(SV_EINVAL, "sv_debug_rowln_plan: bad argument");
+    const int Npad = round_up(N, 32);
+    const bool fits = rowln_cattn_fits(D, Npad, D, splitk, splitk_ru, num_cus);
+    out3[0] = fits ? 1 : 0;
+    out3[1] = fits ? D / 16 / splitk / 8 : 0;
+    out3[2] = 32 + (Npad / 32) * splitk;
+    return 0;
+}
+
 extern "C" int sv_debug_skinny_plan(int32_t rows, int32_t N, int32_t K, int32_t splitk, int32_t fp8, int32_t* out2) {
     if (!out2 || rows < 1 || N < 1 || K < 16 || K % 16 || splitk < 1 || (K / 16) % splitk)
         return fail(SV_EINVAL, "sv_debug_skinny_plan: bad argument");

@@ -150,3 +150,23 @@ def test_decode_attention_split_constants(lib):
     assert plan(32, 4) == (2, 4)
     out = (C.c_int32 * 2)()
     assert lib.sv_debug_attn_plan(0, 1, 256, out) == -22
+
+
+def test_fused_row_update_c_attn_launch_shapes(lib):
+    """Where an engine that owns its GPU runs the row update and the c_attn projection as one launch (host arithmetic of
+    rowops.hip rowln_cattn_fits): a GEMM wave must hold its whole weight share in registers -- 4 k-steps (StarVector-1B: 2048 / 16 / 4 slices / 8
+    waves) or 9 (StarVector-8B: 4608 / 16 / 4 / 8) -- narrow rows need all blocks resident at once (two per CU), the XCD-aware (tile, slice)
+    assignment needs its divisibilities, the row update in front sums at most four slabs."""
+    def plan(D, N, splitk, splitk_ru=4, cus=256):
+        out = (C.c_int32 * 3)()
+        assert lib.sv_debug_rowln_plan(D, N, splitk, splitk_ru, cus, out) == 0
+        return out[0], out[1], out[2]
+    assert plan(2048, 2304, 4) == (1, 4, 32 + 72 * 4)           # StarVector-1B: 320 blocks of 512 threads on 512 slots
+    assert plan(4608, 5632, 4, splitk_ru=3) == (1, 9, 32 + 176 * 4)   # StarVector-8B: 736 blocks, three per CU
+    assert plan(2048, 2304, 4, cus=128)[0] == 0                # 320 blocks do not fit 256 slots: the two launches
+    assert plan(2048, 2304, 2)[0] == 0 and plan(2048, 2304, 8)[0] == 0      # 8 / 2 k-steps per wave: not an instantiation
+    assert plan(4608, 5632, 3)[0] == 0                         # 8 % 3: no XCD-aware assignment
+    assert plan(2048, 2304, 4, splitk_ru=5)[0] == 0            # the row role sums at most four slabs
+    assert plan(1024, 1152, 2)[0] == 1 and plan(1024, 1152, 2)[1] == 4      # another narrow width with 4 k-steps per wave
+    out = (C.c_int32 * 3)()
+    assert lib.sv_debug_rowln_plan(0, 2304, 4, 4, 256, out) == -22
