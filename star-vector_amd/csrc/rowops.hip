@@ -286,6 +286,11 @@ void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st) {
 //              logits in bench.py's third call.  Bounded by the wall
 //              clock (give-up code 4 in *err: never a hang).  Then gemm_skinny_kernel<8, false>'s 4 MFMAs, LDS reduction in wave order
 //              and slab store: bit-identical slabs.
+//   Wide rows (StarVector-8B's 7-launch layer, hidden 4608: rowln_cattn_kernel<9, true>): the 1024-thread row update on a block's 512 threads
+//              (rowln_wide_role), nine k-steps of weights per GEMM wave, 736 blocks at three per CU.  The 1B timing does NOT carry over: 52 MB
+//              of weight requests from t = 0 are 8+ us of HBM stream and stretch the row role past 6.5 us -- there nobody polls before its own
+//              weights have landed (the stream is the timer) and the activations are fetched in two batches behind them.  17.3 us per launch
+//              against 18.5 for the pair (-1 ... -1.5 % per step on config 4); profiles/rowln_cattn_r05_ab.log, section 8.
 //   Needs every block resident at once: on for an engine that owns its GPU (sv_config.exclusive_device), like the fused MLP launch.
 //   (The row blocks are the FIRST blocks of the grid and wait for nothing, so a GEMM block never waits for a block dispatched behind it;
 //    the all-resident rule is kept anyway -- dispatch order is observed behaviour, not a documented guarantee.)
