@@ -580,7 +580,10 @@ __global__ __launch_bounds__(512, WIDE ? 6 : 4) void rowln_cattn_kernel(const fl
     // registers instead of 36: with the 36 weight registers the kernel stays at <= 80 VGPRs, i.e. THREE blocks per CU -- all 736 blocks
     // resident at once; at two per CU the last 224 blocks only start when the first ones leave and the launch streams its weights in two
     // rounds: 17.7 us against ... measured below) -- the weights have landed by then, so a batch costs one L2 round trip.
-    constexpr int XB = WIDE ? 5 : KPW;
+#ifndef SV_RC_XB
+#define SV_RC_XB 5           // (build-time A/B: -DSV_RC_XB=3 = three batches of three)
+#endif
+    constexpr int XB = WIDE ? SV_RC_XB : KPW;
     u32x4 x[XB];
     int gave_up = 1;
     auto patt = [&](const u32x4& v) { return m < M_ && (v[0] == 0xffffffffu || v[1] == 0xffffffffu || v[2] == 0xffffffffu || v[3] == 0xffffffffu); };
