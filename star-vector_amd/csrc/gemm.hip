@@ -426,25 +426,37 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 // big-M GEMM, 256x256x64 tile, 8 waves in two ping-pong groups (prefill / ViT when the tile count fills the chip)
 //
 //   The 128^2 kernel above parks every wave at `vmcnt(0)` + barrier once per K-tile and issues its LDS reads right
-//   in front of the MFMAs that need them.  Here a K-tile is cut into 4 PHASES (one 64x32 quadrant of the wave's
-//   128x64 output each: 8 MFMAs 32x32x16), and every phase is
-//        [ds_read this phase's fragments | LDS-DMA one half-tile of the NEXT K-tile]  barrier
-//        [8 MFMAs at raised priority]  vmcnt(2)  barrier
+//   in front of the MFMAs that need them.  Here a K-tile is cut into 2 PHASES (two 64x32 quadrants of the wave's
+//   128x64 output each: 16 MFMAs 32x32x16), and every phase is
+//        [ds_read this phase's fragments | LDS-DMA two half-tiles | vmcnt(8) lgkmcnt(0)]  barrier
+//        [16 MFMAs at raised priority]  barrier
 //   Waves 0-3 and 4-7 (one of each per SIMD) run one barrier apart, so while one group feeds the MFMA pipe the other
-//   issues its LDS / LDS-DMA traffic.  The LDS-DMA queue is never drained in steady state: `vmcnt(2)` leaves the
-//   half-tile staged in this phase in flight across both barriers.
+//   issues its LDS / LDS-DMA traffic.  The LDS-DMA queue is never drained in steady state: `vmcnt(8)` leaves the
+//   four half-tiles staged in this phase and the one before in flight across the barriers.
 //
 //   LDS (2 K-tile buffers x 64 KiB): [X0 | X1 | W0 | W1], 16 KiB each.  X-half i = rows {128*wr + 64*i + 0..63} of
 //   both wave rows (128 rows x 64 k, XOR-swizzled 16-B chunks like the 128^2 kernel); W-half j = fragment
-//   (2*wc + j) of the four wave columns (packed fragments, lane-linear).  Quadrant order (i,j) = (0,0) (0,1) (1,1)
-//   (1,0): the half-tiles are first needed in phases 0,0,1,2 and are staged in the order X0 W0 W1 X1 one K-tile ahead.
+//   (2*wc + j) of the four wave columns (packed fragments, lane-linear).  Phase 1 = quadrants (0,0) (0,1), reads W0 W1;
+//   phase 2 = (1,1) (1,0), reads X1 and X0 of the NEXT K-tile.
 //
-//   Hazards (s = staging phase, counted in global phases; B = the group that runs one barrier late):
-//     RAW  a half-tile read in phase Q must be retired (`vmcnt`) by every staging wave before a barrier that precedes
-//          the read; for group B that is the wait at the END of phase Q-2 -> with one half-tile (2 LDS-DMAs) issued per
-//          phase the count is vmcnt(2); the last K-tile stages nothing and waits vmcnt(0).  (X0 of the next K-tile is
-//          read one phase early, in phase 3: staged in phase 0, it is the only half-tile old enough for that.)
-//     WAR  a slot is restaged >= 4 phases after its last ds_read, and those reads were consumed by MFMAs long before.
+//   Staging (round 6; tools/diag/gemm_lab.hip is the A/B lab, profiles/gemm_lab_r06.log the numbers): there are only two K-tile
+//   buffers, but a half-tile's slot is free as soon as its fragments sit in registers, so K-tile t+2 is staged INTO THE
+//   BUFFER K-TILE t IS BEING COMPUTED FROM, slot by slot, one phase after the slot's last ds_read:
+//        phase 1 of t:  X1(t+1)  X0(t+2)          phase 2 of t:  W0(t+2)  W1(t+2)
+//   Every half-tile is issued three phases (1.5 K-tiles) before its first read and has two phases to land before the
+//   wait that retires it.  Round 2-5's loop (4 phases of 8 MFMAs, one half-tile per phase ONE K-tile ahead, vmcnt(2) after
+//   every phase, wave-uniform `more ?` branches at every phase) measured 1195-1258 TF at 8192^3 on uniform random operands
+//   where this one does 1315 (zero-filled: 1453 -> 1768); the same loop without LDS-DMA runs at 2190 TF and the LDS-DMA
+//   stream alone at the equivalent of 2050 TF (1.05 us per K-tile): the loop is now within 16 % of max(MFMA, LDS-DMA).
+//
+//   Hazards (A = waves 0-3, B = waves 4-7, one barrier late; a phase's first barrier = B1, second = B2):
+//     WAR  the ds_reads of a phase are waited for (`lgkmcnt(0)`) BEFORE its B1; the slot is restaged in the NEXT phase,
+//          i.e. after B2 of the reading phase for group A and after the following B1 for group B: both groups' reads are
+//          complete (B's reads of phase p complete before the barrier A meets as B2 of p).
+//     RAW  LDS-DMA data is ordered for a ds_read only by the issuing wave's vmcnt followed by a barrier the reader has
+//          passed.  The wait sits before B1 of phase p (every wave, both groups) and the data is read in phase p+1: group A's
+//          reads of p+1 come after its B2 of p, which B meets as its B1 of p -- B has waited.  vmcnt(8) after the phase's own
+//          two half-tiles retires everything issued two or more phases ago = exactly what phase p+1 reads.
 // ------------------------------------------------------------------------------------------------
 #define G2_T 256
 #define G2_HALF 16384
@@ -541,46 +553,61 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p, int tiles_m, i
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) w[ks] = *reinterpret_cast<const bf16x8*>(half + woff + ks * 1024);
     };
-    auto quad = [&](bf16x8 (&w)[4], bf16x8 (&x)[2][4], int j, int i) {
+    // two quadrants = 16 MFMAs between a barrier pair
+    auto quads = [&](bf16x8 (&wa)[4], bf16x8 (&wb)[4], bf16x8 (&x)[2][4], int ja, int jb, int i) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int mt2 = 0; mt2 < 2; ++mt2)
-                acc[j][2 * i + mt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[ks], x[mt2][ks], acc[j][2 * i + mt2], 0, 0, 0);
+                acc[ja][2 * i + mt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[ks], x[mt2][ks], acc[ja][2 * i + mt2], 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mt2 = 0; mt2 < 2; ++mt2)
+                acc[jb][2 * i + mt2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[ks], x[mt2][ks], acc[jb][2 * i + mt2], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
     };
 
-    // prologue: K-tile 0 entirely
+    // prologue: K-tile 0 entirely and X0 W0 W1 of K-tile 1, in the loop's issue order (X1(t), X0(t+1) | W0(t+1), W1(t+1) | ...)
     stage(0, 0, smem); stage(1, 0, smem); stage(2, 0, smem); stage(3, 0, smem);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stage(0, 1, smem + G2_BUF); stage(1, 1, smem + G2_BUF); stage(2, 1, smem + G2_BUF);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");      // X0 W0 W1 of K-tile 0 have landed; X1(0) X0(1) W0(1) W1(1) stay in flight
     G2_BARRIER();
+    read_x(x0, smem);                                     // X0 of K-tile 0 (later tiles: read in phase 2 of the tile before)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    G2_BARRIER();                                         // every wave holds its X0(0): phase 1 of K-tile 0 restages that slot
     if (wr == 1) G2_BARRIER();                            // group B runs one barrier behind group A
-    read_x(x0, smem);                                     // X0 of K-tile 0 (later tiles: read in phase 3 of the tile before)
     const long long t_pro = p.trace ? wall_clock64() : 0;
 
-#define G2_WAIT(n) do { if (more) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } while (0)
-    for (int t = 0; t < KT; ++t) {
+    // one K-tile = two phases; MODE 0: steady state, 1: second-to-last K-tile (only X1 of the last one is still to be staged), 2: last
+    auto ktile = [&](int t, auto mode_tag) {
+        constexpr int MODE = decltype(mode_tag)::value;
         char* buf = smem + (t & 1) * G2_BUF;
         char* nbuf = smem + ((t + 1) & 1) * G2_BUF;
-        const bool more = t + 1 < KT;
-        // one half-tile per phase, X0 W0 W1 X1: every half-tile has ~2 phases to land.  (Staging the whole next K-tile in
-        // phases 0-1 instead, 3-4 phases of slack, measured the same: the loop is not waiting on LDS-DMA latency.)
-        read_w(w0, buf + 2 * G2_HALF);
-        if (more) stage(0, t + 1, nbuf);
-        G2_BARRIER(); quad(w0, x0, 0, 0); G2_WAIT(2); G2_BARRIER();
-        read_w(w1, buf + 3 * G2_HALF);
-        if (more) stage(1, t + 1, nbuf);
-        G2_BARRIER(); quad(w1, x0, 1, 0); G2_WAIT(2); G2_BARRIER();
+        // phase 1: quadrants (0,0) (0,1)
+        read_w(w0, buf + 2 * G2_HALF); read_w(w1, buf + 3 * G2_HALF);
+        if constexpr (MODE <= 1) stage(3, t + 1, nbuf);                  // X1(t+1): slot last read in phase 2 of t-1
+        if constexpr (MODE == 0) stage(0, t + 2, buf);                   // X0(t+2): slot last read in phase 2 of t-1
+        if constexpr (MODE == 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        G2_BARRIER(); quads(w0, w1, x0, 0, 1, 0); G2_BARRIER();
+        // phase 2: quadrants (1,1) (1,0)
         read_x(x1, buf + G2_HALF);
-        if (more) stage(2, t + 1, nbuf);
-        G2_BARRIER(); quad(w1, x1, 1, 1); G2_WAIT(2); G2_BARRIER();
-        // x0 is free again: fetch X0 of the next K-tile (staged in phase 0, retired by every wave's wait at the
-        // end of phase 1) so that no phase issues more than 8 LDS reads
-        if (more) { read_x(x0, nbuf); stage(3, t + 1, nbuf); }
-        G2_BARRIER(); quad(w0, x1, 0, 1); G2_WAIT(2); G2_BARRIER();
+        if constexpr (MODE <= 1) read_x(x0, nbuf);                        // X0 of the next K-tile
+        if constexpr (MODE == 0) { stage(1, t + 2, buf); stage(2, t + 2, buf); }      // W0 W1 of t+2: slots last read in phase 1 of t
+        if constexpr (MODE == 0) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        G2_BARRIER(); quads(w1, w0, x1, 1, 0, 1); G2_BARRIER();
+    };
+    {
+        int t = 0;
+        for (; t < KT - 2; ++t) ktile(t, std::integral_constant<int, 0>{});
+        ktile(t, std::integral_constant<int, 1>{}); ++t;
+        ktile(t, std::integral_constant<int, 2>{});
     }
-#undef G2_WAIT
     if (wr == 0) G2_BARRIER();                            // both groups execute the same number of barriers
     const long long t_loop = p.trace ? wall_clock64() : 0;
     auto stamp = [&]() {          // tools/gemm_trace.py: {start, K-tile 0 staged, K loop done, epilogue stored (drained), tile m, tile n, wave}
@@ -704,6 +731,12 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p, int tiles_m, i
 }
 
 static void launch_gemm256(const GemmArgs& a, hipStream_t st) {
+    if (a.K < 128) {                     // the loop's prologue stages into K-tile 1: a single K-tile goes through the 128^2 kernel (same bits)
+        dim3 grid((a.N + GB_N - 1) / GB_N, (a.M + GB_M - 1) / GB_M);
+        if (a.out_f32) gemm_bf16_kernel<float><<<grid, 256, 2 * GB_BUF, st>>>(a);
+        else gemm_bf16_kernel<bf16_t><<<grid, 256, 2 * GB_BUF, st>>>(a);
+        return;
+    }
     const int tiles_m = (a.M + G2_T - 1) / G2_T, tiles_n = (a.N + G2_T - 1) / G2_T;
     if (a.out_f32) gemm256_kernel<float><<<tiles_m * tiles_n, 512, 2 * G2_BUF, st>>>(a, tiles_m, tiles_n);
     else gemm256_kernel<bf16_t><<<tiles_m * tiles_n, 512, 2 * G2_BUF, st>>>(a, tiles_m, tiles_n);
