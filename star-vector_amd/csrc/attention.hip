@@ -42,13 +42,14 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs p)
     const int b = blockIdx.z;
     const int S = p.S;
     int head, q0, qblock_end;
+    const int qtile = blockIdx.x + p.q_tile0;               // (q_tile0 > 0: only the trailing query tiles, e.g. the last prompt row's)
     if (HPB == 1) {
         head = blockIdx.y;
-        q0 = blockIdx.x * 128 + wave * 32;
-        qblock_end = blockIdx.x * 128 + 128;
+        q0 = qtile * 128 + wave * 32;
+        qblock_end = qtile * 128 + 128;
     } else {
         head = blockIdx.y * HPB + wave;
-        q0 = blockIdx.x * 32;
+        q0 = qtile * 32;
         qblock_end = q0 + 32;
     }
     const int kvh = (HPB == 1 ? head : blockIdx.y * HPB) / p.kv_group;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs p)
     // sliding window (StarCoder2, prompts longer than the window): key tiles entirely below the block's first query's window
     // are never loaded; inside the first tiles a query row may see nothing yet (statistics stay at -inf / 0, see m_use below)
     const int win = p.causal ? p.window : 0;
-    const int qfirst = HPB == 1 ? blockIdx.x * 128 : q0;
+    const int qfirst = HPB == 1 ? qtile * 128 : q0;
     const int kt0 = (win > 0 && qfirst - win + 1 > 0) ? (qfirst - win + 1) / 64 : 0;
     const bf16_t* kbase = p.k + (size_t)b * S * p.kv_row_stride + (size_t)kvh * p.kv_head_stride;
     const bf16_t* vbase = p.v + (size_t)b * S * p.kv_row_stride + (size_t)kvh * p.kv_head_stride;
@@ -229,14 +230,22 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs p)
     }
 }
 
-void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st) {
-    const bool mqa4 = (a.kv_group % 4 == 0) && (a.H % 4 == 0);
+static bool mqa4_tile(const AttnPrefillArgs& a) { return (a.kv_group % 4 == 0) && (a.H % 4 == 0); }
+void launch_attn_prefill(const AttnPrefillArgs& a_in, hipStream_t st) {
+    const bool mqa4 = mqa4_tile(a_in);
+    // last_rows > 0: only the query tiles that hold the last `last_rows` rows of every sequence (same bits for those rows: a row's
+    // online softmax walks the key tiles in the same order whatever other query tiles are launched)
+    AttnPrefillArgs a = a_in;
+    const int qt = mqa4_tile(a) ? 32 : 128;
+    const int tiles_all = (a.S + qt - 1) / qt;
+    a.q_tile0 = a.last_rows > 0 ? (a.S - (a.last_rows < a.S ? a.last_rows : a.S)) / qt : 0;
+    const int tiles = tiles_all - a.q_tile0;
     if (mqa4) {
-        dim3 grid((a.S + 31) / 32, a.H / 4, a.B);
+        dim3 grid(tiles, a.H / 4, a.B);
         if (a.head_dim == 128) attn_prefill_kernel<128, 4><<<grid, 256, 0, st>>>(a);
         else attn_prefill_kernel<64, 4><<<grid, 256, 0, st>>>(a);
     } else {
-        dim3 grid((a.S + 127) / 128, a.H, a.B);
+        dim3 grid(tiles, a.H, a.B);
         if (a.head_dim == 128) attn_prefill_kernel<128, 1><<<grid, 256, 0, st>>>(a);
         else attn_prefill_kernel<64, 1><<<grid, 256, 0, st>>>(a);
     }

@@ -180,6 +180,12 @@ int sveng::prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hi
     at.o = e->pattn; at.o_row_stride = QD; at.B = B; at.S = S0; at.H = c.n_head; at.head_dim = dh;
     at.kv_group = c.n_head / nkv; at.causal = 1; at.scale = 1.0f / sqrtf((float)dh);
     at.window = c.sliding_window > 0 ? c.sliding_window : 0;      // StarCoder2: also inside the prompt pass (prompts longer than the window)
+    // The LAST layer of a generation prompt pass (n_keep == 0) is only needed for (a) its K / V rows and (b) the residual stream of
+    // the last prompt row, which alone feeds ln_f + lm_head.  So after its attention only the last row of every sequence goes on:
+    // attention over the last query tile, then c_proj / ln_2 / c_fc / down-proj on B rows instead of B * S0 (HF computes all rows and
+    // reads logits[:, -1]; a row's GEMM / attention result does not depend on the rows around it: bit-identical, test_gpu_e2e.py).
+    // SV_EXP bit 32768 = off (A/B).
+    const bool prune_last = n_keep == 0 && S0 >= 2 && !(e->exp & 32768);
     for (int i = 0; i < c.n_layer; ++i) {
         DecLayer& L = e->dec[i];
         prof_mark(e, PK_PF_ROWS, st);
@@ -191,6 +197,27 @@ int sveng::prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hi
             launch_kv_write_prefill(e->pqkv, QKV, QD + kh * dh, QD + nkv * dh + kh * dh,
                                     e->kv_pool + (size_t)i * e->layer_stride + (size_t)kh * e->kv_head_stride,
                                     table, e->pages_per_seq, B, S0, dh, st);
+        if (prune_last && i + 1 == c.n_layer) {
+            at.last_rows = 1;
+            launch_attn_prefill(at, st);
+            at.last_rows = 0;
+            // compact buffers inside the (now free) LayerNorm workspace: [B][QD] attention rows | [B][D] ln_2 rows; the MLP rows in pmlp
+            bf16_t* pa_l = e->pln;
+            bf16_t* ln_l = e->pln + (size_t)B * QD;
+            prof_mark(e, PK_PF_ROWS, st);
+            launch_gather_last_rows(e->pattn, pa_l, B, S0, QD, st);
+            launch_gather_last_rows(e->ph, e->hl, B, S0, D, st);
+            gemm(e, PK_PF_GEMM, pa_l, QD, L.c_proj, e->hl, D, e->hl, D, B, ACT_NONE, 0, st);
+            prof_mark(e, PK_PF_ROWS, st);
+            launch_layernorm_rows(e->hl, D, L.ln2.g, L.ln2.b, ln_l, D, B, D, c.ln_eps, st);
+            gemm(e, PK_PF_GEMM, ln_l, D, L.c_fc, nullptr, 0, e->pmlp, F, B, ACT_GELU_TANH, 0, st);
+            gemm(e, PK_PF_GEMM, e->pmlp, F, L.c_proj2, e->hl, D, e->hl, D, B, ACT_NONE, 0, st);
+            prof_mark(e, PK_PF_ROWS, st);
+            launch_layernorm_rows_packed(e->hl, D, e->ln_f.g, e->ln_f.b, e->xp_f, B, D, c.ln_eps, st);
+            prof_mark(e, PK_PF_LMHEAD, st);
+            lm_head_logits(e, (B + 31) / 32, e->xp_f, st);
+            return 0;
+        }
         launch_attn_prefill(at, st);
         gemm(e, PK_PF_GEMM, e->pattn, QD, L.c_proj, e->ph, D, e->ph, D, M, ACT_NONE, 0, st);
         prof_mark(e, PK_PF_ROWS, st);

@@ -1007,6 +1007,9 @@ void launch_gemm(const GemmArgs& a0, hipStream_t st) {
     // every kernel next to the others
     if (fixed >= 2) { launch_gemm_fixed(a, 1, 1, st); return; }
     if (fixed >= 0) { launch_gemm_fixed(a, fixed, 0, st); return; }
+    // a handful of rows (the pruned last layer of a prompt pass: one row per sequence): one wave per 32 x 32 tile with 56 loads in flight
+    // beats a single row of 128^2 tiles that walk the whole K alone -- same bits either way
+    if (a.M <= 96 && tail_us(a.M, a.N, a.K) < 10.0 + 0.03 * (double)a.K) { launch_gemm_tail(a, st); return; }
     const GemmPlan pl = gemm_plan(a.M, a.N, a.K, a.act, 1);
     static const bool tune_on = !(getenv("SV_GEMM_AUTOTUNE") && atoi(getenv("SV_GEMM_AUTOTUNE")) == 0);
     if (tune_on && a.M >= 1024 && (long)a.M * a.N >= (1L << 22)) {

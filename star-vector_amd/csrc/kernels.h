@@ -194,6 +194,8 @@ struct AttnPrefillArgs {
     int B, S, H, head_dim, kv_group;                      // kv head = head / kv_group
     int causal; float scale;
     int window = 0;                                       // causal only: query q sees keys q - window < k <= q (StarCoder2); 0 = all
+    int last_rows = 0;                                    // > 0: only the query tiles holding the last `last_rows` rows of every sequence are launched
+    int q_tile0 = 0;                                      //   (set by the launcher: first query tile of the grid)
 };
 void launch_attn_prefill(const AttnPrefillArgs& a, hipStream_t st);
 
