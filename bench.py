@@ -271,6 +271,9 @@ def main():
         ttft_stages = {"error": f"{type(ex).__name__}: {ex}"}
 
     # dominant kernel = skinny weight-streaming GEMM (97 launches / decode step): HIP-event time per step
+    # the decode step's real shape, asked of the engine BEFORE the profiling legs run their own (unfused) steps: kernel nodes of the captured
+    # step graph and which fused launches were on (sv_debug_step_plan; ADVICE r05: not re-derived from the configuration)
+    plan = eng.step_plan()
     prof = eng.profile_decode_step(B_PER_GPU, iters=5)
     sk = prof["skinny_gemm"]
     launches = max(sk["launches_per_step"], 1.0)
@@ -286,7 +289,7 @@ def main():
     # An engine that owns its GPU runs the row update of every layer INSIDE the c_attn launch (rowln_cattn_kernel); the profiling legs time the
     # unfused launches, so the 24 row updates that now belong to the family are taken out of the "others" chain (their event-delta share)
     # (StarVector-8B, bf16, <= 32 rows: the same for the ln_1 row update of its 7-launch layer -- rowln_cattn_kernel<9, true>; ln_2's stays a launch)
-    rc_on = bool(ec.exclusive_device) and args.weights == "bf16" and B_PER_GPU <= 32 and os.environ.get("SV_EXP", "0") in ("", "0")
+    rc_on = plan["rowln_cattn_fused"]
     if rc_on and others_ms > 0:
         ru = prof.get("row_update_ln", {})
         n_ru = max(ru.get("launches_per_step", 0.0), 1.0)
@@ -385,8 +388,12 @@ def main():
                 "unit": "GB/s", "frac": round((W_BYTES_PER_STEP + kvb) / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us > 0 else None,
                 # the profiling legs time the UNFUSED launches; the captured step of an engine that owns its GPU runs the layer's row update inside
                 # the c_attn launch (n_layer launches less) and a plain greedy step selects inside the lm_head launch (no argmax launch)
-                "launches_per_step": int(sum(v["launches_per_step"] for v in prof.values() if isinstance(v, dict))) + 2
-                                     - (cfg.n_layer if rc_on else 0) - (0 if (is8b or B_PER_GPU > 32 or args.weights != "bf16") else 1)})(
+                "launches_per_step": plan["graph_kernel_nodes"] or (
+                    int(sum(v["launches_per_step"] for v in prof.values() if isinstance(v, dict))) + 2
+                    - (cfg.n_layer if rc_on else 0) - (1 if plan["greedy_in_lm_head"] else 0)),
+                "launches_per_step_source": "kernel nodes of the captured decode-step graph (sv_debug_step_plan)" if plan["graph_kernel_nodes"]
+                                            else "profiling legs' launch counts, corrected by the engine's fused-launch decisions",
+                "fused_launches": {k: plan[k] for k in ("rowln_cattn_fused", "greedy_in_lm_head", "mlp_fused")}})(
                     B_PER_GPU * (S0 + n_new / 2.0) * cfg.n_layer * 2 * cfg.n_kv_head * head_dim * 2,
                     decode_ms / max(decode_steps, 1) * 1e3),
             "decode_step_profile_ms": {k: round(v["ms_per_step"], 4) for k, v in prof.items() if isinstance(v, dict)},

@@ -61,6 +61,11 @@ int  sv_debug_attn_plan(int32_t max_batch, int32_t n_kv_head, int32_t num_cus, i
  *                             the launch = 32 row blocks + (N / 32) * splitk} -- narrow rows (D <= 2048) need every block resident at once
  *                             (two per CU), wide rows rely on the row blocks being dispatched first.  Host arithmetic, pinned by the CPU tests */
 int  sv_debug_rowln_plan(int32_t D, int32_t N, int32_t splitk, int32_t splitk_ru, int32_t num_cus, int32_t* out3);
+/*   sv_debug_step_plan        what the LAST sv_generate call's decode step actually was, from the engine itself (bench.py's `launches_per_step`
+ *                             and roofline captions; ADVICE r05: not re-derived from the configuration): out4 = {kernel nodes of the captured
+ *                             decode-step graph (0: no graph, plain launches), 1 if the layers' row update + c_attn ran as one launch,
+ *                             1 if the greedy selection rode in the lm_head launch, 1 if c_fc + down-projection ran as one launch} */
+int  sv_debug_step_plan(sv_engine* e, int32_t* out4);
 /*   sv_debug_set_col_tiles    column tiles per block (1..3; 0 = the launcher's own choice) the OP-LEVEL decode GEMM entry points
  *                             (sv_op_linear_skinny*, 33..64 rows) launch with from now on, process-wide: lets the parity tests put
  *                             every variant of the two-row-tile kernel next to the one-tile kernels (all bit-identical).  An engine's

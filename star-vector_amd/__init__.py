@@ -7,9 +7,15 @@ import os as _os
 
 # Multi-process GPU work (generate_im2svg_dp: one process per GPU, RCCL all-gather) needs dmabuf IPC on hosts whose driver has no
 # legacy IPC -- without this RCCL's hipIpcGetMemHandle fails with "invalid argument".  The HSA runtime reads the variable ONCE, when
-# torch first initialises HIP, so it is set at import time (a setdefault: an explicit value from the launcher wins); if HIP is already
-# up in this process the variable must come from the launcher's environment instead.
-_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# torch first initialises HIP, so it has to be in the environment before that.  The package sets it ONLY in a process that a
+# distributed launcher started (torchrun / torch.distributed.run export WORLD_SIZE): a plain single-GPU import changes nothing in the
+# caller's environment; an explicit value from the launcher wins (setdefault); SV_LOG_ENV=1 says when it was applied.  If HIP
+# is already up in this process the variable must come from the launcher's environment instead.
+if int(_os.environ.get("WORLD_SIZE", "1") or "1") > 1 and "HSA_ENABLE_IPC_MODE_LEGACY" not in _os.environ:
+    _os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if _os.environ.get("SV_LOG_ENV"):
+        import sys as _sys
+        print("[starvector_amd] WORLD_SIZE > 1: set HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC for RCCL)", file=_sys.stderr)
 
 from ._lib import StarVectorHipError, LIB_PATH, HEADER_PATH  # noqa: F401
 from .engine import EngineConfig, HipEngine  # noqa: F401

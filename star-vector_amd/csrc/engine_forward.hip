@@ -151,10 +151,16 @@ static bool rc_enabled(const sv_engine* e) {
     const bool layer_ok = e->fold6 ? (e->fold_ready && !(e->exp & 2)) : e->cfg.hidden > 2048;
     return layer_ok && e->rc_fused_ok && !(e->exp & 8192) && (e->cfg.exclusive_device || (e->exp & 16384));
 }
+// the lm_head launch stores the pattern 16 bytes per thread from its first blocks: its grid must cover the buffer (a tiny-vocabulary
+// configuration would arm only part of it: then layer 0 of the next step takes the two launches)
+static bool lm_head_covers(const sv_engine* e, unsigned bytes) {
+    return (size_t)(e->lm_head.Npad / 32 / 3) * 128 * 16 >= bytes;      // at least: three column tiles per block, two waves
+}
 static void lm_head_logits(sv_engine* e, int MT, const bf16_t* xp, hipStream_t st) {
     SkinnyArgs a;
     memset(&a, 0, sizeof(a));
     if (rc_enabled(e) && MT == 1 && xp != e->xp_a) { a.poison = e->xp_a; a.poison_bytes = (unsigned)((size_t)(e->cfg.hidden / 16) * 1024); }
+    e->xpa_armed = a.poison != nullptr && lm_head_covers(e, a.poison_bytes);
     a.xp = xp; a.Wp = e->lm_head.Wp; a.Wq = e->lm_head.Wq; a.wscale = e->lm_head.wscale; a.MT = MT; a.Npad = e->lm_head.Npad; a.K = e->lm_head.Kpad;
     a.splitk = 1; a.out_mode = SK_OUT_F32; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1;
     a.N = e->lm_head.N;
@@ -297,9 +303,12 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
     // cannot fuse on an engine that does (see rc_enabled) keeps its LayerNorm outputs out of xp_a.
     const size_t attn_threads_bytes = (size_t)B * e->nkv * attn_max_splits(e) * 512 * 16;
     const bool mlp_pattern = fold6 && e->mlp_fused_ok;          // the attention launch may also have to arm the fused MLP launch's buffer
-    const bool rc = rc_enabled(e) && MT == 1 && !e->only_skinny && !e->skip_skinny && !e->prof_on &&
+    // (xpa_armed: the launch that arms layer 0's buffer really ran in front of this step -- not after sv_create, sv_debug_set_exp or
+    //  sv_debug_kv_load, whose first step takes the two launches and arms the next one)
+    const bool rc = rc_enabled(e) && e->xpa_armed && MT == 1 && !e->only_skinny && !e->skip_skinny && !e->prof_on &&
                     (size_t)(D / 16) * 1024 + (mlp_pattern ? (size_t)(F / 16) * 1024 : 0u) <= attn_threads_bytes;
     const unsigned xpa_bytes = (unsigned)((size_t)(D / 16) * 1024);
+    e->step_rc = false; e->step_mlp = false; e->step_sel = e->greedy_fused;
     bf16_t* const xp_ln = (rc_enabled(e) && !rc) ? e->xp_f : e->xp_a;      // LayerNorm(ln_1) output = the c_attn operand
 
     ru.h = fold6 ? e->h_xp : e->h_dec; ru.ldh = fold6 ? 0 : D;        // 6-launch layer: the residual stream lives in fragment order
@@ -330,6 +339,7 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
             a.splitk = 1; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1;
             if (e->greedy_fused) { a.amax = e->amax; a.amax_rows = B; }      // greedy selection inside the lm_head launch (sv_generate)
             if (rc_enabled(e) && MT == 1 && xp != e->xp_a) { a.poison = e->xp_a; a.poison_bytes = xpa_bytes; }      // the next step's layer 0
+            if (!e->skip_skinny) e->xpa_armed = a.poison != nullptr && lm_head_covers(e, xpa_bytes);
         }
         if (e->skip_skinny) return;
         prof_mark(e, PK_SKINNY, st);
@@ -345,6 +355,7 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
             a.out_mode = SK_OUT_PARTIAL; a.splitk = L.c_attn.splitk; a.ws = wsA; a.ldws = e->ldws;
             prof_mark(e, PK_SKINNY, st);
             rc_done = launch_rowln_cattn(ru, a, e->d_bad, 500000, st, e->rc_delay, e->rc_dbg, i, e->num_cus) == 0;      // 5 ms budget; a refusal takes the two launches
+            e->step_rc = e->step_rc || rc_done;
         }
         if (!rc_done) {
             bf16_t* const xo = rc ? e->xp_f : xp_ln;             // a refused fused launch must not reach the polled buffer with plain stores / loads
@@ -394,6 +405,7 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
                 bool done = e->skip_skinny;
                 if (!done) { prof_mark(e, PK_SKINNY, st); done = launch_mlp_fused(ma, st) == 0; }
                 if (done) {
+                    e->step_mlp = e->step_mlp || !e->skip_skinny;
                     const LNp& nx = (i + 1 < c.n_layer) ? e->dec[i + 1].ln1 : e->ln_f;
                     ru.ws = wsB; ru.splitk = L.c_proj2.splitk; ru.bias = L.c_proj2.bias; ru.g = nx.g; ru.b = nx.b;
                     continue;

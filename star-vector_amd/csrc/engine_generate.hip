@@ -316,6 +316,16 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
             } else {
                 e->gen_graph_key = key;
                 gexec = e->gen_gexec;
+                size_t nn = 0;                     // sv_debug_step_plan: the step's launches, counted on the captured graph itself
+                e->step_nodes = 0;
+                if (hipGraphGetNodes(e->gen_graph, nullptr, &nn) == hipSuccess && nn > 0) {
+                    std::vector<hipGraphNode_t> nodes(nn);
+                    if (hipGraphGetNodes(e->gen_graph, nodes.data(), &nn) == hipSuccess)
+                        for (size_t i = 0; i < nn; ++i) {
+                            hipGraphNodeType ty;
+                            if (hipGraphNodeGetType(nodes[i], &ty) == hipSuccess && ty == hipGraphNodeTypeKernel) ++e->step_nodes;
+                        }
+                }
             }
         }
     }

@@ -116,6 +116,8 @@ struct sv_engine {
     hipStream_t tenant_stream = nullptr;       // sv_debug_occupy_cus (safety tests): the stream the foreign tenant's kernel runs on
     int rc_delay = 390;             //   narrow rows: its GEMM blocks' first poll, 10-ns ticks after block start (3.9 us: measured optimum); wide rows: their
                                     //   hold-back in front of the weight requests (0); SV_RC_DELAY at sv_create
+    int step_nodes = 0; bool step_rc = false, step_sel = false, step_mlp = false;      // sv_debug_step_plan: the last captured / launched decode step
+    bool xpa_armed = false;         // xp_a carries the "not written yet" pattern, put there by a write-through fill of the lm_head launch in front (layer 0 of the next fused step polls it)
     bool rc_fused_ok = false;       // row update + c_attn as one launch (rowops.hip rowln_cattn_kernel) fits this engine: shapes + all blocks resident
     bool mlp_fused_ok = false;      // the MLP half as one launch (gemm.hip mlp_fused_kernel) fits this engine: shapes + one block per CU
     long long* attn_trace = nullptr;// SV_ATTN_TRACE=1: wall-clock stamps of the decode attention of the middle layer, [rows * kv heads * splits][16]

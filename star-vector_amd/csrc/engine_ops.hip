@@ -21,11 +21,20 @@ extern "C" int sv_debug_set_exp(sv_engine* e, int32_t mask) {
     if (!e) return fail(SV_EINVAL, "null engine");
     std::lock_guard<std::mutex> lk(e->mu);
     e->exp = mask;
+    e->xpa_armed = false;                    // another mask may have run plain stores through xp_a: the next step re-arms it
     for (auto& kv : e->cb_graphs) {          // the continuous-batching step graphs were captured with the old mask
         if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
         if (kv.second.first) (void)hipGraphDestroy(kv.second.first);
     }
     e->cb_graphs.clear();
+    return 0;
+}
+
+extern "C" int sv_debug_step_plan(sv_engine* e, int32_t* out4) {
+    if (!e || !out4) return fail(SV_EINVAL, "sv_debug_step_plan: null argument");
+    std::lock_guard<std::mutex> lk(e->mu);
+    out4[0] = e->gen_gexec ? e->step_nodes : 0;
+    out4[1] = e->step_rc ? 1 : 0; out4[2] = e->step_sel ? 1 : 0; out4[3] = e->step_mlp ? 1 : 0;
     return 0;
 }
 
@@ -95,6 +104,7 @@ extern "C" int sv_debug_kv_load(sv_engine* e, int32_t layer, const void* dev_kv,
     if (dev_lens) HIPCHECK(hipMemcpyAsync(e->positions, dev_lens, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     else fill_i32(e->positions, S, B, st);
     e->cached_B = B;
+    e->xpa_armed = false;                       // no lm_head launch in front of the step that follows
     e->dbg_pos_hi = S;                          // dev_lens[b] <= S by contract
     HIPCHECK(hipGetLastError());
     return 0;

@@ -295,6 +295,12 @@ void launch_row_update_ln(const RowUpdateArgs& a, hipStream_t st) {
 //   (The row blocks are the FIRST blocks of the grid and wait for nothing, so a GEMM block never waits for a block dispatched behind it;
 //    the all-resident rule is kept anyway -- dispatch order is observed behaviour, not a documented guarantee.)
 // ------------------------------------------------------------------------------------------------
+// A LayerNorm output that is NaN may carry ANY payload -- AMD hardware propagates the input's -- including the bf16 pair 0xFFFF'FFFF, which the
+// GEMM role of the fused launch reads as "not written yet": every c_attn wave of the layer would then spin to its 5 ms budget and the call
+// would fail with code 4 (blocks not resident) instead of code 1 (non-finite logits).  The row role therefore publishes that one pattern as
+// the canonical quiet NaN pair: still NaN (the logits check reports it), never mistaken for the pattern.
+__device__ __forceinline__ uint32_t sv_not_pattern(uint32_t w) { return w == 0xffffffffu ? 0x7fc07fc0u : w; }
+
 // The row role for wide rows (2048 < D <= 8192): row_update_ln_kernel<1024>, value for value, on the 512 threads of a rowln_cattn block.
 // That kernel gives thread v < 1024 the chunk v (8 columns) and reduces (sum, then sum of squared deviations) by a 64-lane shuffle
 // per wave and a sum over the 16 waves in wave order.  Here thread t takes the chunks t (virtual wave t >> 6) and 512 + t (virtual
@@ -403,7 +409,7 @@ __device__ __forceinline__ void rowln_wide_role(const float* ws_, const bf16_t* 
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (hrow[c * 8 + e] - mean) * rstd * gg[e] + bb[e];
             const uint4 ov = pack8(o);
-            u32x4 q4 = {ov.x, ov.y, ov.z, ov.w};
+            u32x4 q4 = {sv_not_pattern(ov.x), sv_not_pattern(ov.y), sv_not_pattern(ov.z), sv_not_pattern(ov.w)};
             __builtin_amdgcn_raw_buffer_store_b128(q4, rs, (int)(xp_index(0, KS_, row & 31, c * 8) * 2), 0, 16);      // sc1: write-through
         }
     }
@@ -524,7 +530,7 @@ __global__ __launch_bounds__(512, WIDE ? 6 : 4) void rowln_cattn_kernel(const fl
             for (int e = 0; e < 8; ++e) o[e] = (hrow[c * 8 + e] - mean) * rstd * gg[e] + bb[e];
             const uint4 ov = pack8(o);
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.xp_out, 0, (unsigned)((size_t)KSD * 1024), 0x00020000);
-            u32x4 q4 = {ov.x, ov.y, ov.z, ov.w};
+            u32x4 q4 = {sv_not_pattern(ov.x), sv_not_pattern(ov.y), sv_not_pattern(ov.z), sv_not_pattern(ov.w)};
             __builtin_amdgcn_raw_buffer_store_b128(q4, rs, (int)(xp_index(0, KSD, row & 31, c * 8) * 2), 0, 16);      // sc1: write-through
         }
         return;

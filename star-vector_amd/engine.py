@@ -337,6 +337,13 @@ class HipEngine:
         check(self.lib.sv_last_timing(self._h, buf), "sv_last_timing")
         return {"ttft_ms": buf[0], "decode_ms": buf[1], "decode_steps": buf[2], "graph": bool(buf[3])}
 
+    def step_plan(self) -> Dict[str, int]:
+        """What the last generate() call's decode step actually was (sv_debug_step_plan): kernel nodes of its captured graph and which
+        of the fused launches ran -- the engine's own decisions, not a re-derivation from the configuration."""
+        buf = (C.c_int32 * 4)()
+        check(self.lib.sv_debug_step_plan(self._h, buf), "sv_debug_step_plan")
+        return {"graph_kernel_nodes": int(buf[0]), "rowln_cattn_fused": bool(buf[1]), "greedy_in_lm_head": bool(buf[2]), "mlp_fused": bool(buf[3])}
+
     def set_exp(self, mask: int) -> None:
         """Experiment bit mask (SV_EXP) of the live engine: in-process A/B runs (tools/ab_exp.py)."""
         check(self.lib.sv_debug_set_exp(self._h, int(mask)), "sv_debug_set_exp")

