@@ -59,6 +59,10 @@ def parse():
     ap.add_argument("--task", choices=["im2svg", "text2svg"], default="im2svg",
                     help="text2svg: BASELINE config 5's workload (no image encoder; the prompt is 32 caption ids + <svg-start>, "
                          "batch 64 per GPU with --model 8b) -- a secondary line, never the headline")
+    ap.add_argument("--beams", type=int, default=1,
+                    help="num_beams of the decode (1: BASELINE's greedy line).  2 with --sample = the reference's DEFAULT generate_im2svg call "
+                         "(starvector_base.py:231-239: beam-sample, num_beams 2, top-p 0.9): batch x beams rows per decode step -- a secondary line")
+    ap.add_argument("--sample", action="store_true", help="with --beams > 1: HF beam-sample (do_sample, top-p 0.9, temperature 1.0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ttft-requests", type=int, default=20)
     return ap.parse_args()
@@ -176,7 +180,9 @@ def main():
     n_new = args.new_tokens
     CAPTION_TOKENS = 32
     PAD_ID = 0 if is8b else 49152            # llm/starcoder2.py:47 / llm/starcoder.py:40-53 ([PAD] appended to the 49152-entry vocabulary)
-    ec = sva.EngineConfig.starvector_8b(max_batch=B_PER_GPU, max_seq_len=16) if is8b else sva.EngineConfig(max_batch=B_PER_GPU)
+    NB = max(int(args.beams), 1)
+    ROWS = B_PER_GPU * NB                     # rows of a decode step: every beam is a row of the engine's batch
+    ec = sva.EngineConfig.starvector_8b(max_batch=ROWS, max_seq_len=16) if is8b else sva.EngineConfig(max_batch=ROWS)
     S0 = CAPTION_TOKENS + 1 if t2s else ec.query_length + len(PROMPT_IDS)
     ec.max_seq_len = S0 + n_new
     cfg = ec                                  # the shapes of the path come from the product's own config (StarVectorConfig's defaults)
@@ -188,7 +194,7 @@ def main():
     # ranks SHARING a GPU (the functional gloo run on a 1-GPU box) must not claim that
     ec.exclusive_device = not shared and os.environ.get("SV_SHARED_GPU", "") != "1"
     eng = sva.HipEngine(ec, device=dev_index)
-    keep_cpu = (world == 1 and rank == 0 and not args.no_cpu_baseline and not is8b and not t2s)   # 8B fp32 on CPU: 29 GB, skipped
+    keep_cpu = (world == 1 and rank == 0 and not args.no_cpu_baseline and not is8b and not t2s and NB == 1)   # 8B fp32 on CPU: 29 GB, skipped
     eng.load_random_weights(seed=1234, std=0.02)   # drawn on the GPU, one tensor at a time, same values on every rank
     # this rank's shard of the global batch (seeded per global row -> identical under any sharding)
     images = synthetic_images(torch, B_PER_GPU * world, cfg.image_size, seed=0)[rank * B_PER_GPU:(rank + 1) * B_PER_GPU].to(dev)
@@ -206,10 +212,14 @@ def main():
         else:
             enc = eng.encode_image(images)                     # a2-a5
             emb = eng.prepare_inputs(enc, prompt)              # a6 + a1 / a7: adapter rows and prompt rows written into one buffer
-        new = eng.generate(emb, max_length=S0 + max_new, eos_token_id=-1,      # EOS disabled:
-                           pad_token_id=PAD_ID,                                # fixed-length workload
-                           do_sample=is8b, temperature=1.0, top_p=0.95, top_k=50 if is8b else 0,
-                           seed=1)       # config 4 samples: top-p 0.95 after HF 4.49's implicit top-k 50
+        if NB > 1:     # the reference's default decode (starvector_base.py:231-239): beam search / beam-sample over B x num_beams rows
+            new = eng.generate(emb, max_length=S0 + max_new, eos_token_id=-1, pad_token_id=PAD_ID, num_beams=NB,
+                               do_sample=bool(args.sample), temperature=1.0, top_p=0.9 if args.sample else 1.0, seed=1)
+        else:
+            new = eng.generate(emb, max_length=S0 + max_new, eos_token_id=-1,      # EOS disabled:
+                               pad_token_id=PAD_ID,                                # fixed-length workload
+                               do_sample=is8b, temperature=1.0, top_p=0.95, top_k=50 if is8b else 0,
+                               seed=1)       # config 4 samples: top-p 0.95 after HF 4.49's implicit top-k 50
         out = new if t2s else torch.cat([prompt, new], 1)      # starvector_base.py:256 (text2svg returns the new ids, :329-330)
         if world > 1:
             # ONE collective: int32 [B, 1 + width] per rank (column 0 = the row's length); the width is known up front
@@ -273,8 +283,10 @@ def main():
     # dominant kernel = skinny weight-streaming GEMM (97 launches / decode step): HIP-event time per step
     # the decode step's real shape, asked of the engine BEFORE the profiling legs run their own (unfused) steps: kernel nodes of the captured
     # step graph and which fused launches were on (sv_debug_step_plan; ADVICE r05: not re-derived from the configuration)
+    if NB > 1:
+        step(max_new=8)      # the one-token TTFT requests left B rows in the cache: the profiling legs below need all B x num_beams rows live
     plan = eng.step_plan()
-    prof = eng.profile_decode_step(B_PER_GPU, iters=5)
+    prof = eng.profile_decode_step(ROWS, iters=5)
     sk = prof["skinny_gemm"]
     launches = max(sk["launches_per_step"], 1.0)
     # average launch duration of the dominant kernel: its 97 launches of one step enqueued back to back between
@@ -345,8 +357,10 @@ def main():
                                     f"{n_new} new tokens/seq, EOS disabled") if t2s else
                                    (f"StarVector-8B im2svg, batch {B_PER_GPU}/GPU, bf16, top-k 50 + top-p 0.95, 384x384, prompt rows "
                                     f"{S0} (576 visual + {len(PROMPT_IDS)}), {n_new} new tokens/seq, EOS disabled") if is8b else
-                                   (f"StarVector-1B im2svg, batch {B_PER_GPU}/GPU, bf16, greedy, 224x224, prompt rows "
-                                    f"{S0} (257 visual + {len(PROMPT_IDS)}), {n_new} new tokens/seq, EOS disabled"),
+                                   (f"StarVector-1B im2svg, batch {B_PER_GPU}/GPU, bf16, " +
+                                    (f"{'beam-sample (top-p 0.9)' if args.sample else 'beam search'} num_beams {NB} = {ROWS} rows per decode step "
+                                     "(the reference's default generate_im2svg call), " if NB > 1 else "greedy, ") +
+                                    f"224x224, prompt rows {S0} (257 visual + {len(PROMPT_IDS)}), {n_new} new tokens/seq, EOS disabled"),
                        "global_batch": B_PER_GPU * world, "new_tokens": n_new,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        **({"dist_backend": ("gloo, ranks SHARE GPUs (functional run of the sharded path on a box with fewer GPUs than "
@@ -359,7 +373,7 @@ def main():
             "ttft_breakdown_ms": ttft_stages,
             "decode_us_per_step": round(decode_ms / max(decode_steps, 1) * 1e3, 1),
             "roofline": {"bound": "hbm", "kernel": "decoder weight-streaming GEMMs: " + (
-                             "gemm_skinny_mt2_kernel (two row tiles, up to three column tiles per block)" if B_PER_GPU > 32 else
+                             "gemm_skinny_mt2_kernel (two row tiles, up to three column tiles per block)" if ROWS > 32 else
                              "rowln_cattn_kernel<9, true> (ln_1 row update + c_attn in one launch) + gemm_skinny_kernel" if (is8b and rc_on) else
                              "gemm_skinny_kernel" if (is8b or args.weights != "bf16") else
                              "rowln_cattn_kernel (row update + c_attn in one launch) + gemm_cols_resid_kernel (attention output projection) + mlp_fused_kernel "
@@ -394,7 +408,7 @@ def main():
                 "launches_per_step_source": "kernel nodes of the captured decode-step graph (sv_debug_step_plan)" if plan["graph_kernel_nodes"]
                                             else "profiling legs' launch counts, corrected by the engine's fused-launch decisions",
                 "fused_launches": {k: plan[k] for k in ("rowln_cattn_fused", "greedy_in_lm_head", "mlp_fused")}})(
-                    B_PER_GPU * (S0 + n_new / 2.0) * cfg.n_layer * 2 * cfg.n_kv_head * head_dim * 2,
+                    ROWS * (S0 + n_new / 2.0) * cfg.n_layer * 2 * cfg.n_kv_head * head_dim * 2,
                     decode_ms / max(decode_steps, 1) * 1e3),
             "decode_step_profile_ms": {k: round(v["ms_per_step"], 4) for k, v in prof.items() if isinstance(v, dict)},
             "setup_s": round(t_setup, 1),

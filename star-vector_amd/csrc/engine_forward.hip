@@ -338,7 +338,7 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
         else {
             a.splitk = 1; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1;
             if (e->greedy_fused) { a.amax = e->amax; a.amax_rows = B; }      // greedy selection inside the lm_head launch (sv_generate)
-            if (rc_enabled(e) && MT == 1 && xp != e->xp_a) { a.poison = e->xp_a; a.poison_bytes = xpa_bytes; }      // the next step's layer 0
+                    if (rc_enabled(e) && MT == 1 && xp != e->xp_a) { a.poison = e->xp_a; a.poison_bytes = xpa_bytes; }      // the next step's layer 0
             if (!e->skip_skinny) e->xpa_armed = a.poison != nullptr && lm_head_covers(e, xpa_bytes);
         }
         if (e->skip_skinny) return;
