@@ -71,6 +71,12 @@ int  sv_debug_step_plan(sv_engine* e, int32_t* out4);
  *                             every variant of the two-row-tile kernel next to the one-tile kernels (all bit-identical).  An engine's
  *                             decode loop is not affected (it carries its own plan per Linear). */
 int  sv_debug_set_col_tiles(int32_t col_tiles);
+/*   sv_debug_set_skinny_form  which kernel the 33..64-row decode GEMMs take from now on, process-wide (all forms are bit-identical; the choice is speed):
+ *                             0 = gemm_skinny_mt2_kernel (both operands of the stream in registers, rounds 2-5), 1 = gemm_skinny_mt2x_kernel
+ *                             (activations through a wave-private LDS ring, weights by hand-counted register loads; chunk depth by block
+ *                             count: the default), 2 / 3 = that kernel's two-blocks-per-CU / one-block-per-CU form wherever the shape allows.
+ *                             SV_EXP bits 131072 / 262144 / 524288 select 0 / 2 / 3 at sv_create and in sv_debug_set_exp */
+int  sv_debug_set_skinny_form(int32_t form);
 /*   sv_debug_set_gemm_form    process-wide: every big-M GEMM launch takes ONE form -- 0 = 128x128 tiles, 1 = 256x256 tiles (rows not peeled),
      2 = 256x256 tiles + the row remainder over a multiple of 256 through the one-wave-per-tile tail kernel; -1 = the tuned choice (default).
      The forms give the same bits; the tests compare them through this switch. */

@@ -117,6 +117,7 @@ DEBUG_PROTOTYPES = {
     "sv_debug_skinny_plan": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),
     "sv_debug_set_exp": (_I, [_P, _I]),
     "sv_debug_set_col_tiles": (_I, [_I]),
+    "sv_debug_set_skinny_form": (_I, [_I]),
     "sv_debug_set_gemm_form": (_I, [_I]),
     "sv_debug_attn_plan": (_I, [_I, _I, _I, C.POINTER(_I)]),
     "sv_debug_rowln_plan": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),

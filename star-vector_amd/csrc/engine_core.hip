@@ -550,6 +550,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
             rc = fail(SV_EHIP, "rope table upload failed");
     }
     if (getenv("SV_EXP")) e->exp = atoi(getenv("SV_EXP"));
+    set_mt2x((e->exp & 131072) ? 0 : (e->exp & 262144) ? 2 : (e->exp & 524288) ? 3 : 1);      // 33..64-row decode GEMM form (process-wide: gemm.hip g_mt2x)
     if (!rc && getenv("SV_ATTN_TRACE")) rc = dalloc(e, &e->attn_trace, R * (size_t)nkv * 16 * 16);
     // 6 launches per layer (decode_cols.hip): bf16 weights, at most one 32-row tile per launch; SV_EXP bit 2 = A/B, the 7-launch layer.
     // Hidden sizes above 2048 keep the 7-launch layer: every block of the whole-K projection re-reads 32 x K activations from L2,

@@ -21,6 +21,7 @@ extern "C" int sv_debug_set_exp(sv_engine* e, int32_t mask) {
     if (!e) return fail(SV_EINVAL, "null engine");
     std::lock_guard<std::mutex> lk(e->mu);
     e->exp = mask;
+    set_mt2x((mask & 131072) ? 0 : (mask & 262144) ? 2 : (mask & 524288) ? 3 : 1);      // process-wide (the launcher has no engine): the A/B tools run one engine
     e->xpa_armed = false;                    // another mask may have run plain stores through xp_a: the next step re-arms it
     for (auto& kv : e->cb_graphs) {          // the continuous-batching step graphs were captured with the old mask
         if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
@@ -210,6 +211,12 @@ extern "C" int sv_debug_set_gemm_form(int32_t form) {
 extern "C" int sv_debug_set_col_tiles(int32_t col_tiles) {
     if (col_tiles < 0 || col_tiles > 3) return fail(SV_EINVAL, "sv_debug_set_col_tiles: 0..3");
     g_op_col_tiles = col_tiles;
+    return 0;
+}
+
+extern "C" int sv_debug_set_skinny_form(int32_t form) {
+    if (form < 0 || form > 3) return fail(SV_EINVAL, "sv_debug_set_skinny_form: 0..3");
+    set_mt2x(form);
     return 0;
 }
 

@@ -1978,6 +1978,186 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_mt2_kernel(const void*
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// gemm_skinny_mt2x_kernel (round 6): the two-row-tile kernel with the ACTIVATIONS landing in LDS and twice the waves per CU.
+//   gemm_skinny_mt2_kernel holds both operands of its two register chunks in VGPRs (NT = 3: ~250 registers -> one 8-wave block
+//   per CU, 8 x 14 KiB = 112 KiB in flight per CU) and runs at 34 GB/s per CU where the traffic-only probe (tools/diag/mem_mix.hip)
+//   does 70: the launch is bound by the bytes a CU has in flight, not by HBM or by the L2 -> CU side.  Here
+//     * the activation fragments (2 KiB per k-step: two row tiles) go global -> LDS by LDS-DMA into a WAVE-PRIVATE ring of two chunks
+//       (8 KiB per wave; the ring IS the cross-wave reduction buffer, used after the loop): in flight they cost no register;
+//     * the weights go straight to registers as before, but through inline-asm loads: beside an LDS-DMA hipcc waits vmcnt(0) for
+//       every ordinary register load (cdna guide, section 5 "three .s-level traps" (b)), which would drain the ring at every chunk;
+//       the wave counts its own queue: per chunk NX LDS-DMA pieces, then NW weight loads, `s_waitcnt vmcnt(NX + NW)` before a chunk's
+//       first use = "everything but the refill issued last"; the weight registers are re-defined by an empty asm behind the wait, so
+//       no use can be scheduled above it (guide section 5.7, form (ii));
+//     * <= 128 VGPRs (two column tiles per block): two blocks = 16 waves per CU, ~12 KiB in flight each.
+//   Same per-wave k ranges, same MFMA order, same LDS reduction in wave order, same epilogues as gemm_skinny_mt2_kernel and the
+//   one-tile kernels: bit-identical results (tests/test_gpu_ops.py), so a row's tokens still do not depend on the batch around it.
+// ------------------------------------------------------------------------------------------------
+//   CH = k-steps per chunk: 2 -> 8 KiB of ring per wave, 64 KiB per block, <= 128 VGPRs: two blocks per CU (launches of >= 512 blocks);
+//        4 -> 16 KiB per wave, 128 KiB per block, one block per CU, up to three column tiles per block (the shapes whose tile count
+//        cannot fill 512 block slots: the depth per wave has to make up for the second block)
+template <bool FP8, int NT, int CH>
+__global__ __launch_bounds__(512, CH == 2 ? 4 : 2) void gemm_skinny_mt2x_kernel(const void* W_, const bf16_t* xp_, int KS_, int ks_per_split_, int n_tiles_, SkinnyArgs p_unused) {
+    constexpr int WAVES = 8, RPW = 2;
+    constexpr int RING = 2 * CH * 2048;                    // bytes of ring per wave
+    constexpr int WCH = FP8 ? CH / 2 : CH;                 // 16-byte weight loads per chunk, lane and column tile
+    constexpr int NW = NT * WCH, NX = 2 * CH;              // weight loads / LDS-DMA pieces a wave issues per chunk
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    float (*red)[WAVES][16][64] = reinterpret_cast<float (*)[WAVES][16][64]>(sk_smem);          // [2][WAVES][16][64], after the loop
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    char* const xring = sk_smem + wave * RING;             // [2 slots][CH k-steps][2 row tiles][1 KiB]
+    const int nt0 = blockIdx.x * NT, split = blockIdx.y, mt0 = blockIdx.z * 2;
+    const int KS = KS_;
+    const int ks_per_split = ks_per_split_;
+    const int ks_per_wave = ks_per_split / WAVES;          // a multiple of CH, >= 2 * CH (launcher)
+    const int ks0 = split * ks_per_split + wave * ks_per_wave;
+    const int m = lane & 31, half = lane >> 5;
+
+    const u32x4* wptr[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        int nt = nt0 + j;
+        nt = nt < n_tiles_ ? nt : n_tiles_ - 1;
+        wptr[j] = FP8 ? reinterpret_cast<const u32x4*>(W_) + ((size_t)nt * (KS >> 1) + (ks0 >> 1)) * 64 + lane
+                      : reinterpret_cast<const u32x4*>(W_) + ((size_t)nt * KS + ks0) * 64 + lane;
+    }
+    const u32x4* xg0 = reinterpret_cast<const u32x4*>(xp_) + ((size_t)mt0 * KS + ks0) * 64 + lane;
+    const u32x4* xg1 = xg0 + (size_t)KS * 64;
+
+    f32x16 acc[NT][2];
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[j][0][r] = 0.f; acc[j][1][r] = 0.f; }
+
+    u32x4 wa[NT][WCH], wb[NT][WCH];                        // the two register slots of the weight stream (statically named: no rotation copies)
+    auto issue = [&](int slot, int ks, u32x4 (&w)[NT][WCH]) {        // chunk = k-steps [ks, ks + CH) of this wave's range
+        char* dst = xring + slot * (CH * 2048);
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            lds_dma16(xg0 + (size_t)(ks + u) * 64, dst + u * 2048);
+            lds_dma16(xg1 + (size_t)(ks + u) * 64, dst + u * 2048 + 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int u = 0; u < WCH; ++u) {
+                const u32x4* g = wptr[j] + (size_t)(FP8 ? (ks >> 1) + u : ks + u) * 64;
+                asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(w[j][u]) : "v"(g) : "memory");
+            }
+    };
+    // everything but the LAST `keep` loads of this wave's queue has landed; the slot's weight registers are (re)defined here
+    auto landed = [&](auto keep_tag, u32x4 (&w)[NT][WCH]) {
+        constexpr int KEEP = decltype(keep_tag)::value;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KEEP) : "memory");
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int u = 0; u < WCH; ++u) asm volatile("" : "+v"(w[j][u]));
+    };
+    auto compute = [&](int slot, u32x4 (&w)[NT][WCH]) {
+        const char* xs = xring + slot * (CH * 2048) + lane * 16;
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const u32x4 x0 = *reinterpret_cast<const u32x4*>(xs + u * 2048);
+            const u32x4 x1 = *reinterpret_cast<const u32x4*>(xs + u * 2048 + 1024);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                u32x4 wf;
+                if constexpr (FP8) wf = fp8x8_to_bf16x8(w[j][u >> 1][(u & 1) * 2], w[j][u >> 1][(u & 1) * 2 + 1]);
+                else wf = w[j][u];
+                acc[j][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wf), as_frag4(x0), acc[j][0], 0, 0, 0);
+                acc[j][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(wf), as_frag4(x1), acc[j][1], 0, 0, 0);
+            }
+        }
+        // the slot's LDS reads are complete before its refill is issued (program order + the MFMAs above consumed them); make it explicit
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    };
+    // epilogue constants of the block's NT x 32 columns (fp8 scale, bias) live in LDS behind the ring, not in registers across the loop
+    float* cs = reinterpret_cast<float*>(sk_smem + WAVES * RING);  // [NT][32] per-column scale
+    float* cb = cs + NT * 32;                               // [NT][32] bias (PACKED_ACT), else 0
+    SkinnyArgs p;
+    auto late = [&]() {                                     // the stream is in flight: now the rest of the arguments
+        p = sv_late_args<SkinnyArgs>(offsetof(SkinnyKernarg, p));
+        if (tid < NT * 32) {
+            const int j = tid >> 5;
+            const int nt = nt0 + j < n_tiles_ ? nt0 + j : n_tiles_ - 1;
+            const int n = nt * 32 + (tid & 31);
+            float sc = 1.f, bi = 0.f;
+            if constexpr (FP8) sc = p.wscale[n];
+            if (p.out_mode == SK_OUT_PACKED_ACT && n < p.N && p.bias) bi = bf2f(p.bias[n]);
+            cs[tid] = sc;
+            cb[tid] = bi;
+        }
+    };
+    const int nch = ks_per_wave / CH;                       // >= 2
+    issue(0, 0, wa);
+    issue(1, CH, wb);
+    late();
+    using Keep1 = std::integral_constant<int, NX + NW>;     // the refill issued last stays in flight
+    using Keep0 = std::integral_constant<int, 0>;
+    int c = 0;
+    for (; c + 3 < nch; c += 2) {
+        landed(Keep1{}, wa); compute(0, wa); issue(0, (c + 2) * CH, wa);
+        landed(Keep1{}, wb); compute(1, wb); issue(1, (c + 3) * CH, wb);
+    }
+    {   // two or three chunks left: c, c + 1 (in flight), c + 2 (not yet issued)
+        const bool three = c + 2 < nch;                     // wave-uniform
+        landed(Keep1{}, wa); compute(0, wa);
+        if (three) issue(0, (c + 2) * CH, wa);
+        if (three) landed(Keep1{}, wb); else landed(Keep0{}, wb);
+        compute(1, wb);
+        if (three) { landed(Keep0{}, wa); compute(0, wa); }
+    }
+    __syncthreads();                                        // every wave is done with its ring: the buffer becomes the reduction buffer
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        if constexpr (FP8) {
+            // per-column scale before the reduction, as the one-tile kernel (accumulator row r <-> column 8 (r >> 2) + 4 half + (r & 3))
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const float4 sc = *reinterpret_cast<const float4*>(cs + j * 32 + rg * 8 + half * 4);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    acc[j][mi][rg * 4 + 0] *= sc.x; acc[j][mi][rg * 4 + 1] *= sc.y; acc[j][mi][rg * 4 + 2] *= sc.z; acc[j][mi][rg * 4 + 3] *= sc.w;
+                }
+            }
+        }
+        float bias_d[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int r = wave * RPW + i;
+            bias_d[i] = cb[j * 32 + 8 * (r >> 2) + 4 * half + (r & 3)];
+        }
+        if (j > 0) __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { red[0][wave][r][lane] = acc[j][0][r]; red[1][wave][r][lane] = acc[j][1][r]; }
+        __syncthreads();
+        if (nt0 + j < n_tiles_) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                float v[RPW];
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) {
+                    const int r = wave * RPW + i;
+                    float t = red[mi][0][r][lane];
+#pragma unroll
+                    for (int w = 1; w < WAVES; ++w) t += red[mi][w][r][lane];
+                    v[i] = t;
+                }
+                sk_store<RPW>(p, v, bias_d, wave * RPW, nt0 + j, mt0 + mi, split, m, half);
+            }
+        }
+    }
+}
+
+#define MT2X_SMEM(ch) (8 * 2 * (ch) * 2048 + 2 * 3 * 32 * 4)      // the ring / reduction buffer + [NT <= 3][32] scales + biases
+std::atomic<int> g_mt2x{1};             // 33..64 rows: 0 = gemm_skinny_mt2_kernel, 1 = the LDS-ring form (chunk depth by block count), 2 / 3 = its CH = 2 / 4 form always
+void set_mt2x(int on) { g_mt2x = on; }
+
 std::atomic<int> g_op_col_tiles{0};     // op-level entry points only (SkinnyArgs.col_tiles == 0); engines always pass their plan
 static int init_mt2_attrs() {
     int r = 0;
@@ -1988,6 +2168,16 @@ static int init_mt2_attrs() {
     set(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, false, 2>), 2 * 8 * 16 * 64 * 4);
     set(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, true, 3>), 2 * 8 * 16 * 64 * 4);
     set(reinterpret_cast<const void*>(&gemm_skinny_mt2_kernel<8, false, 3>), 2 * 8 * 16 * 64 * 4);
+    set(reinterpret_cast<const void*>(&gemm_skinny_mt2x_kernel<true, 1, 2>), MT2X_SMEM(2));
+    set(reinterpret_cast<const void*>(&gemm_skinny_mt2x_kernel<false, 1, 2>), MT2X_SMEM(2));
+    set(reinterpret_cast<const void*>(&gemm_skinny_mt2x_kernel<true, 2, 2>), MT2X_SMEM(2));
+    set(reinterpret_cast<const void*>(&gemm_skinny_mt2x_kernel<false, 2, 2>), MT2X_SMEM(2));
+    set(reinterpret_cast<const void*>(&gemm_skinny_mt2x_kernel<true, 1, 4>), MT2X_SMEM(4));
+    set(reinterpret_cast<const void*>(&gemm_skinny_mt2x_kernel<false, 1, 4>), MT2X_SMEM(4));
+    set(reinterpret_cast<const void*>(&gemm_skinny_mt2x_kernel<true, 2, 4>), MT2X_SMEM(4));
+    set(reinterpret_cast<const void*>(&gemm_skinny_mt2x_kernel<false, 2, 4>), MT2X_SMEM(4));
+    set(reinterpret_cast<const void*>(&gemm_skinny_mt2x_kernel<true, 3, 4>), MT2X_SMEM(4));
+    set(reinterpret_cast<const void*>(&gemm_skinny_mt2x_kernel<false, 3, 4>), MT2X_SMEM(4));
     return r;
 }
 // two-row-tile launch: false when the shape / mode is outside the kernel's scope (the caller falls back to one tile per block)
@@ -2001,6 +2191,34 @@ static bool launch_gemm_skinny_mt2(const SkinnyArgs& a, hipStream_t st) {
     // the SAME number of waves (= the same per-wave k ranges and reduction order) as the one-tile kernel of this GEMM
     const int waves = a.Wq ? skinny_waves_fp8(KS, a.splitk) : skinny_waves(a.Npad, KS, a.splitk);
     const void* W = a.Wq ? (const void*)a.Wq : (const void*)a.Wp;
+    const int mode = g_mt2x.load(std::memory_order_relaxed);
+    if (waves == 8 && mode && per % 8 == 0 && (per / 8) % 2 == 0 && per / 8 >= 4) {
+        // the LDS-ring form (gemm_skinny_mt2x_kernel).  Column tiles per block = the plan's (the engine's pick_decode_plan; 0: this launcher's
+        // default).  Chunk depth: launches that fill 512 block slots take the two-blocks-per-CU form (CH = 2, <= 2 column tiles); the others
+        // one block per CU with 16 KiB of ring per wave (CH = 4) when the wave's k range is a multiple of 4 k-steps and >= 8.
+        int ct = a.col_tiles ? a.col_tiles : g_op_col_tiles.load(std::memory_order_relaxed);
+        if (ct == 0) ct = n_tiles * a.splitk >= 512 ? 2 : 1;
+        const int pw = per / 8;
+        const long blocks2 = (long)((n_tiles + 1) / 2) * a.splitk * (a.MT / 2), blocks1 = (long)n_tiles * a.splitk * (a.MT / 2);
+        const bool deep_ok = pw % 4 == 0 && pw >= 8;
+        int ch = 2;
+        if (mode == 2) ch = 2; else if (mode == 3) ch = deep_ok ? 4 : 2;
+        else ch = (deep_ok && (ct >= 3 || (ct == 2 ? blocks2 : blocks1) < 512)) ? 4 : 2;
+        if (ch == 2 && ct > 2) ct = 2;
+        const dim3 grid((n_tiles + ct - 1) / ct, a.splitk, a.MT / 2);
+#define SV_MT2X(F, N_, C_) gemm_skinny_mt2x_kernel<F, N_, C_><<<grid, 512, MT2X_SMEM(C_), st>>>(W, a.xp, KS, per, n_tiles, a)
+        const bool f8 = a.Wq != nullptr;
+        if (ch == 2) {
+            if (ct == 2) { if (f8) SV_MT2X(true, 2, 2); else SV_MT2X(false, 2, 2); }
+            else { if (f8) SV_MT2X(true, 1, 2); else SV_MT2X(false, 1, 2); }
+        } else {
+            if (ct == 3) { if (f8) SV_MT2X(true, 3, 4); else SV_MT2X(false, 3, 4); }
+            else if (ct == 2) { if (f8) SV_MT2X(true, 2, 4); else SV_MT2X(false, 2, 4); }
+            else { if (f8) SV_MT2X(true, 1, 4); else SV_MT2X(false, 1, 4); }
+        }
+#undef SV_MT2X
+        return true;
+    }
     if (waves == 8) {
         // the engine picks (column tiles, split-K) together (engine_core.hip, pick_decode_plan); on its own (col_tiles = 0: the op-level
         // entry points) the launcher takes two column tiles when half the blocks still cover the chip

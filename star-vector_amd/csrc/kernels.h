@@ -38,6 +38,7 @@ struct GemmArgs {
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 // one fixed configuration (kernel256: 0 = 128^2 tiles, 1 = 256^2; peel: the row remainder over a multiple of 256 in its own launch), no tuning
 void launch_gemm_fixed(const GemmArgs& a, int kernel256, int peel, hipStream_t st);
+void set_mt2x(int on);                // 33..64-row decode GEMMs: 1 = activations through a wave-private LDS ring (gemm_skinny_mt2x_kernel, default), 0 = both operands in registers
 void set_gemm_form(int form);         // -1: tuned (default); 0 / 1: every big-M launch takes that form, rows not peeled
 // what launch_gemm decides for a shape (host arithmetic only; tail_on: 0 never peel, 1 cost model, 2 always)
 struct GemmPlan { int peel, tail_rows, tail_by_tiles, main_256; double est_us; };

@@ -547,6 +547,11 @@ def set_gemm_form(form: int) -> None:
     check(_lib.load().sv_debug_set_gemm_form(int(form)))
 
 
+def set_skinny_form(form: int) -> None:
+    """Kernel of the 33..64-row decode GEMMs (sv_debug_set_skinny_form): 0 registers only, 1 LDS ring (default), 2 / 3 its fixed depths."""
+    check(_lib.load().sv_debug_set_skinny_form(int(form)))
+
+
 def set_op_col_tiles(col_tiles: int) -> None:
     """Column tiles per block (1..3, 0 = default) of the op-level decode GEMMs at 33..64 rows (sv_debug_set_col_tiles)."""
     check(_lib.load().sv_debug_set_col_tiles(int(col_tiles)))

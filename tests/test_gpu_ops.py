@@ -202,13 +202,18 @@ def test_linear_skinny_two_row_tiles_per_block_is_bitwise_the_one_tile_kernel(M,
     assert rel_err(two, x @ W.T + b) <= 1e-5
     # one, two or three column tiles per block (the engine picks per Linear; ragged last block when N / 32 is not a multiple):
     # the same bits every time
+    # ... and whichever kernel streams them: both operands in registers (form 0, rounds 2-5) or the activations through a wave-private
+    # LDS ring with hand-counted weight loads (round 6: forms 2 / 3 = two chunks of 2 / 4 k-steps per wave, form 1 = the launcher's pick)
     try:
-        for ct in (1, 2, 3):
-            E.set_op_col_tiles(ct)
-            assert torch.equal(E.op_linear_skinny(bf(x), bf(W), bf(b), splitk=sk), two), ct
-            assert torch.equal(E.op_linear_skinny_fp8(bf(x), bf(W), bf(b), splitk=sk)[0], two8), ct
+        for form in (0, 2, 3, 1):
+            E.set_skinny_form(form)
+            for ct in (1, 2, 3):
+                E.set_op_col_tiles(ct)
+                assert torch.equal(E.op_linear_skinny(bf(x), bf(W), bf(b), splitk=sk), two), (form, ct)
+                assert torch.equal(E.op_linear_skinny_fp8(bf(x), bf(W), bf(b), splitk=sk)[0], two8), (form, ct)
     finally:
         E.set_op_col_tiles(0)
+        E.set_skinny_form(1)
     # each row tile alone (<= 32 rows: the one-tile-per-block kernel) gives the same bits as inside the two-tile launch: batch
     # composition cannot change a row
     for lo, hi in ((0, 32), (32, M)):
