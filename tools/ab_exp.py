@@ -20,10 +20,13 @@ ap.add_argument("masks", nargs="*", type=int, default=[0, 1, 2, 3])
 ap.add_argument("--new-tokens", type=int, default=512)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--batch", type=int, default=32)
+ap.add_argument("--shared", action="store_true", help="engine WITHOUT exclusive_device (none of the all-blocks-resident fused launches)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 B = a.batch
-eng = sva.HipEngine(sva.EngineConfig(max_batch=B, max_seq_len=259 + a.new_tokens + 8))
+ec = sva.EngineConfig(max_batch=B, max_seq_len=259 + a.new_tokens + 8)
+ec.exclusive_device = not a.shared          # bench.py's engine: one process per GPU
+eng = sva.HipEngine(ec)
 eng.load_random_weights(seed=1234)
 img = synthetic_images(torch, B, 224, seed=0).to(dev)
 prompt = torch.tensor([[7, 11]] * B, dtype=torch.long, device=dev)
