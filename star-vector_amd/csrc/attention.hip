@@ -623,57 +623,93 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
     }
 
     const long long t_loop = wall_clock64();           // this wave's key groups processed
-    // merge the waves of this block (LDS), in wave order
+    // merge the waves of this block (LDS), in wave order.  Only the waves that had a key group take part (round 6): at the run's mean context a
+    // block owns 4 groups, waves 4-7 carry (m, l, O) = (-inf, 0, 0) -- terms that add exactly zero, so the result is bit-identical -- and used to
+    // cost half of the merge's LDS traffic (64 KiB written, every output thread reading 8 x 20 bytes instead of 4 x).  Two fully unrolled
+    // instantiations (4 / 8 waves) picked by a block-uniform branch: a run-time loop bound measured SLOWER than the old form (LDS reads behind
+    // branches: +1.2 us at context 1283).  p.merge_all (SV_EXP bit 2097152) = always 8.
+    int nwa = (ngroups - g0 - split + act - 1) / act;
+    nwa = p.merge_all ? AD_WAVES : (nwa < 1 ? 1 : (nwa > AD_WAVES ? AD_WAVES : nwa));
     float l_tot = l_run + __shfl_xor(l_run, 16, 64);
     l_tot += __shfl_xor(l_tot, 32, 64);
-    if (c == 0) {
-        m_s[wave * 16 + hd] = m_run;
-        l_s[wave * 16 + hd] = l_tot;
-    }
-#pragma unroll
-    for (int t = 0; t < NDV; ++t)
-        *reinterpret_cast<float4*>(O_s + ((size_t)(wave * 16 + hd)) * D + 16 * t + 4 * c) =
-            make_float4(accO[t][0], accO[t][1], accO[t][2], accO[t][3]);
-    __syncthreads();
     // each thread owns 4 consecutive outputs (same head): 16-byte stores for the partial / 8-byte for the result
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         p.part, 0, (unsigned)((size_t)p.B * p.n_kv * AD_SPLIT * PART * sizeof(float)), 0x00020000);
     const int my_off = (int)(((size_t)bx * AD_SPLIT + split) * PART * 4);            // bytes
     const int col0 = kvh * G * D;            // this block's first output column ((kvh*G + h)*D + dv = col0 + idx)
-    for (int idx = tid * 4; idx < 16 * D; idx += AD_WAVES * 64 * 4) {
-        const int h = idx / D, dv = idx % D;
-        float M = -INFINITY;
+    auto block_merge = [&](auto nw_tag) {
+        constexpr int NWV = decltype(nw_tag)::value;
+        if (wave < NWV) {
+            if (c == 0) {
+                m_s[wave * 16 + hd] = m_run;
+                l_s[wave * 16 + hd] = l_tot;
+            }
 #pragma unroll
-        for (int w = 0; w < AD_WAVES; ++w) M = fmaxf(M, m_s[w * 16 + h]);
-        float num[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int w = 0; w < AD_WAVES; ++w) {
-            const float mw = m_s[w * 16 + h];
-            const float f = (mw == -INFINITY) ? 0.f : __expf(mw - M);
-            const float4 o = *reinterpret_cast<const float4*>(O_s + ((size_t)(w * 16 + h)) * D + dv);
-            num[0] += f * o.x; num[1] += f * o.y; num[2] += f * o.z; num[3] += f * o.w;
+            for (int t = 0; t < NDV; ++t)
+                *reinterpret_cast<float4*>(O_s + ((size_t)(wave * 16 + hd)) * D + 16 * t + 4 * c) =
+                    make_float4(accO[t][0], accO[t][1], accO[t][2], accO[t][3]);
         }
-        if (act == 1) {
-            if (idx < HD) {
+        __syncthreads();
+        for (int idx = tid * 4; idx < 16 * D; idx += AD_WAVES * 64 * 4) {
+            const int h = idx / D, dv = idx % D;
+            float M = -INFINITY;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) M = fmaxf(M, m_s[w * 16 + h]);
+            float num[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) {
+                const float mw = m_s[w * 16 + h];
+                const float f = (mw == -INFINITY) ? 0.f : __expf(mw - M);
+                const float4 o = *reinterpret_cast<const float4*>(O_s + ((size_t)(w * 16 + h)) * D + dv);
+                // (explicit fused multiply-adds: what the compiler's contraction made of `num += f * o` in the one-instantiation form of rounds 1-5 --
+                //  left to its mood, the two-instantiation form came out with other roundings and four more near-tie flips in the free-running test)
+                num[0] = fmaf(f, o.x, num[0]); num[1] = fmaf(f, o.y, num[1]); num[2] = fmaf(f, o.z, num[2]); num[3] = fmaf(f, o.w, num[3]);
+            }
+            if (act == 1) {
+                if (idx < HD) {
+                    float den = 0.f;
+#pragma unroll
+                    for (int w = 0; w < NWV; ++w) {
+                        const float mw = m_s[w * 16 + h];
+                        den = fmaf((mw == -INFINITY) ? 0.f : __expf(mw - M), l_s[w * 16 + h], den);
+                    }
+                    const float inv = 1.0f / den;
+                    uint2 o;
+                    o.x = pack2bf(num[0] * inv, num[1] * inv);
+                    o.y = pack2bf(num[2] * inv, num[3] * inv);
+                    *reinterpret_cast<uint2*>(p.out_xp + xp_index(b >> 5, p.out_KS, b & 31, col0 + idx)) = o;
+                }
+            } else {
+                u32x4 v;
+                v[0] = __float_as_uint(num[0]); v[1] = __float_as_uint(num[1]);
+                v[2] = __float_as_uint(num[2]); v[3] = __float_as_uint(num[3]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rs, my_off + (32 + idx) * 4, 0, 16);   // write-through
+            }
+        }
+        if (act > 1 && tid < 8) {
+            // m[16] | l[16] of this block's partial: 8 x 16 bytes
+            const bool is_l = tid >= 4;
+            u32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int h = (tid & 3) * 4 + j;
+                float M = -INFINITY;
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) M = fmaxf(M, m_s[w * 16 + h]);
                 float den = 0.f;
 #pragma unroll
-                for (int w = 0; w < AD_WAVES; ++w) {
+                for (int w = 0; w < NWV; ++w) {
                     const float mw = m_s[w * 16 + h];
-                    den += ((mw == -INFINITY) ? 0.f : __expf(mw - M)) * l_s[w * 16 + h];
+                    den = fmaf((mw == -INFINITY) ? 0.f : __expf(mw - M), l_s[w * 16 + h], den);
                 }
-                const float inv = 1.0f / den;
-                uint2 o;
-                o.x = pack2bf(num[0] * inv, num[1] * inv);
-                o.y = pack2bf(num[2] * inv, num[3] * inv);
-                *reinterpret_cast<uint2*>(p.out_xp + xp_index(b >> 5, p.out_KS, b & 31, col0 + idx)) = o;
+                v[j] = __float_as_uint(is_l ? den : M);
             }
-        } else {
-            u32x4 v;
-            v[0] = __float_as_uint(num[0]); v[1] = __float_as_uint(num[1]);
-            v[2] = __float_as_uint(num[2]); v[3] = __float_as_uint(num[3]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rs, my_off + (32 + idx) * 4, 0, 16);   // write-through
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs, my_off + tid * 16, 0, 16);
         }
-    }
+    };
+    if (nwa <= 4) block_merge(std::integral_constant<int, 4>{});                 // contexts <= 1024 at 4 groups per block
+    else if (nwa <= 6) block_merge(std::integral_constant<int, 6>{});            // <= 1536
+    else block_merge(std::integral_constant<int, AD_WAVES>{});
     auto stamp = [&](long long t_part, long long t_tick, long long t_end) {
         if (p.trace && tid == 0) {
             long long* q = p.trace + ((size_t)bx * gridDim.y + split) * 16;
@@ -681,26 +717,6 @@ __global__ __launch_bounds__(AD_WAVES * 64) void attn_decode_kernel(const int32_
         }
     };
     if (act == 1) { stamp(0, 0, wall_clock64()); return; }
-    if (tid < 8) {
-        // m[16] | l[16] of this block's partial: 8 x 16 bytes
-        const bool is_l = tid >= 4;
-        u32x4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int h = (tid & 3) * 4 + j;
-            float M = -INFINITY;
-#pragma unroll
-            for (int w = 0; w < AD_WAVES; ++w) M = fmaxf(M, m_s[w * 16 + h]);
-            float den = 0.f;
-#pragma unroll
-            for (int w = 0; w < AD_WAVES; ++w) {
-                const float mw = m_s[w * 16 + h];
-                den += ((mw == -INFINITY) ? 0.f : __expf(mw - M)) * l_s[w * 16 + h];
-            }
-            v[j] = __float_as_uint(is_l ? den : M);
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(v, rs, my_off + tid * 16, 0, 16);
-    }
 
     // hand-off without fences: write-through (sc1) partial, every storing wave drains, one relaxed
     // agent-scope ticket; the last arriver reads the partials with sc1 loads (L1 bypass)

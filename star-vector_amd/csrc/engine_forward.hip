@@ -278,6 +278,7 @@ void sveng::attn_decode_args(sv_engine* e, int layer, int B, const float* ws, in
     ad.max_splits = attn_max_splits(e);
     ad.groups_per_block = attn_groups_per_block(e);
     ad.n_kv = e->nkv; ad.kv_head_stride = e->kv_head_stride; ad.rope_cos = e->rope_cos; ad.rope_sin = e->rope_sin;
+    ad.merge_all = (e->exp & 2097152) ? 1 : 0;
 }
 
 // One autoregressive step: consumes cur_tok / positions, leaves logits in e->logits.  6 launches per layer + 2 (bf16 weights,

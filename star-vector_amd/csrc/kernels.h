@@ -227,6 +227,7 @@ struct AttnDecodeArgs {
     int window;                                            // sliding window: keys pos - window < j <= pos (0 = all)
     int groups_per_block;                                  // 32-key groups a block takes before another context split joins (0 = 4)
     long long* trace;                                      // optional [B * n_kv * max_splits][16] wall-clock stamps (tools/attn_trace.py); nullptr in production
+    int merge_all;                                         // 1: every wave takes part in the block's LDS merge (rounds 1-5); 0: only the waves that had a key group
     void* poison2; unsigned poison2_bytes;                 // a second buffer filled the same way, by the threads behind those of the first (the next layer's
                                                            // LayerNorm output buffer: rowln_cattn_kernel)
     void* poison; unsigned poison_bytes;                   // optional: a buffer the launch fills with 0xFF bytes, 16 per thread, before anything else (the
