@@ -83,7 +83,18 @@ __global__ __launch_bounds__(WP_THREADS) void beam_row_warp_kernel(BeamDev p) {
     const uint32_t* seen = p.seen ? p.seen + (size_t)row * p.seen_words : nullptr;
     float M, logS;
     bm_row_lse(p, row, M, logS);
-    auto sc = [&](int i) { return bm_logprob(p, x, seen, M, logS, i) * p.inv_temp; };
+    // bm_logprob with everything that does not depend on the column hoisted (the step counter, the penalty, the temperature): the functor is
+    // inlined into a 52-values-per-thread register sweep under a 128-VGPR cap (1024 threads)
+    const bool hold_eos = *p.step < p.min_new;
+    const int eos = p.eos;
+    const float pen = p.penalty, inv_pen = 1.0f / p.penalty, inv_temp = p.inv_temp;
+    auto sc = [&](int i) {
+        float lp = (x[i] - M) - logS;
+        if (seen && ((seen[i >> 5] >> (i & 31)) & 1u)) lp = lp < 0.f ? lp * pen : lp / pen;
+        if (i == eos && hold_eos) lp = -INFINITY;
+        return lp * inv_temp;
+    };
+    (void)inv_pen;
     const WarpStats w = row_warp_stats<false>(sc, p.V, p.top_k, p.top_p, 2, red);   // min_tokens_to_keep = 2 under beams
     if (threadIdx.x == 0) {
         float* o = p.warp + (size_t)row * 8;

@@ -63,19 +63,37 @@ __device__ __forceinline__ float wp_prob(const WarpStats& w, float s) { return _
 // The thresholds need ~70 passes over the row (two bisections).  The row is read ONCE into registers (NPT values per
 // thread, strided: value j of thread t is score t + 1024 j) and every pass runs on registers; `sc` is only evaluated in
 // that first sweep.  NPT * 1024 must cover V (StarVector: 49156 / 49157 -> NPT 52).
-template <int NPT, class F>
+// ONCE (round 6, beam-sample): `sc` is evaluated exactly once per element -- the statistics min_tokens_to_keep = 2 needs (does the maximum occur
+// twice?  else the largest score below it) are taken in the first sweep too, from each thread's own top two, so a heavy score functor (log-prob +
+// repetition penalty + min-length hold) is inlined once and the 52 values stay in registers.  Same sums in the same order as the other forms:
+// identical thresholds (tests/test_gpu_beam.py).
+template <int NPT, bool ONCE = false, class F>
 __device__ WarpStats row_warp_stats_regs(F sc, int V, int top_k, float top_p, int min_keep, float* red) {
     const int tid = threadIdx.x;
     WarpStats w;
     float v[NPT];
     float mx = -INFINITY;
+    float t1 = -INFINITY, t2 = -INFINITY;               // ONCE: this thread's largest and second largest score (t2 == t1 when it occurs twice)
 #pragma unroll
     for (int j = 0; j < NPT; ++j) {
         const int i = tid + j * WP_THREADS;
         v[j] = i < V ? sc(i) : -INFINITY;
         mx = fmaxf(mx, v[j]);
+        if (ONCE && i < V) {
+            if (v[j] > t1) { t2 = t1; t1 = v[j]; } else if (v[j] > t2) t2 = v[j];
+        }
+        // ONCE: at most 8 elements' loads in flight at a time (all NPT hoisted to the top cost NPT more registers: scratch under the 128-VGPR cap)
+        if (ONCE && (j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
     }
     w.mx = mx = wp_block_max(mx, red);
+    float once_cnt = 0.f, once_below = -INFINITY;
+    if (ONCE && min_keep >= 2) {
+        // how often the block maximum occurs (0, 1 or "2 or more" per thread is all that matters) and the largest score below it
+        once_cnt = t1 == mx ? (t2 == mx ? 2.f : 1.f) : 0.f;
+        once_below = t1 == mx ? (t2 == mx ? -INFINITY : t2) : t1;
+        once_cnt = wp_block_sum(once_cnt, red);
+        once_below = wp_block_max(once_below, red);
+    }
 
     // TopK: kth = the k-th largest score, k = max(top_k, min_keep); off when top_k <= 0 or k >= V.  Padding entries are
     // -inf = the smallest key, so they only ever count towards thresholds at the very bottom (k < V keeps them out).
@@ -127,18 +145,22 @@ __device__ WarpStats row_warp_stats_regs(F sc, int V, int top_k, float top_p, in
     // only approximately -- recover it from the scores instead (one more sweep of `sc`, beam-sample only).
     w.smin = mx;
     if (min_keep >= 2) {
-        float cnt = 0.f, below = -INFINITY;
+        if constexpr (ONCE) {
+            if (once_cnt < 2.f) w.smin = once_below;
+        } else {
+            float cnt = 0.f, below = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < NPT; ++j) {
-            const int i = tid + j * WP_THREADS;
-            if (i < V) {
-                const float s = sc(i);
-                if (s == mx) cnt += 1.f; else below = fmaxf(below, s);
+            for (int j = 0; j < NPT; ++j) {
+                const int i = tid + j * WP_THREADS;
+                if (i < V) {
+                    const float s = sc(i);
+                    if (s == mx) cnt += 1.f; else below = fmaxf(below, s);
+                }
             }
+            cnt = wp_block_sum(cnt, red);
+            below = wp_block_max(below, red);
+            if (cnt < 2.f) w.smin = below;
         }
-        cnt = wp_block_sum(cnt, red);
-        below = wp_block_max(below, red);
-        if (cnt < 2.f) w.smin = below;
     }
     return w;
 }
@@ -207,7 +229,12 @@ __device__ WarpStats row_warp_stats_global(F sc, int V, int top_k, float top_p, 
 // REGS = false keeps every pass on `sc` (beam-sample: its score functor is heavier and the register copy spills)
 template <bool REGS = true, class F>
 __device__ WarpStats row_warp_stats(F sc, int V, int top_k, float top_p, int min_keep, float* red) {
-    if (!REGS) return row_warp_stats_global(sc, V, top_k, top_p, min_keep, red);
+    if (!REGS) {
+        // beam-sample: one evaluation of the (heavy) score functor per element, everything else on registers -- the all-passes-on-`sc` form took
+        // 317 us per decode step at 64 rows x 49157 columns (rocprof, BASELINE config 2 with num_beams 2: 17 % of the step)
+        if (V <= 49 * WP_THREADS) return row_warp_stats_regs<49, true>(sc, V, top_k, top_p, min_keep, red);       // StarVector: 49156 / 49157 columns
+        return row_warp_stats_global(sc, V, top_k, top_p, min_keep, red);
+    }
     if (V <= 16 * WP_THREADS) return row_warp_stats_regs<16>(sc, V, top_k, top_p, min_keep, red);
     if (V <= 52 * WP_THREADS) return row_warp_stats_regs<52>(sc, V, top_k, top_p, min_keep, red);
     return row_warp_stats_global(sc, V, top_k, top_p, min_keep, red);
