@@ -326,6 +326,18 @@ def main():
         except Exception:
             traffic = None
 
+    # the profiler's own figure for the same family (rocprofv3 --kernel-trace of this command, tools/rocprof_family.py -> profiles/rocprof_family.json):
+    # quoted beside the in-situ one, which is a subtraction of chains
+    rocprof_us, rocprof_src = None, None
+    rfile = os.path.join(ROOT, "profiles", "rocprof_family.json")
+    if os.path.exists(rfile) and not is8b and args.weights == "bf16" and not t2s and NB == 1:
+        try:
+            rj = json.load(open(rfile))
+            rocprof_us = rj.get("avg_launch_us")
+            rocprof_src = f"static: profiles/rocprof_family.json ({rj.get('measured', '')}; {rj.get('launches')} launches of the family, {rj.get('source')})"
+        except Exception:
+            rocprof_us = None
+
     # secondary, MFMA-bound kernels (TTFT path): the four decoder GEMMs of one prefill layer at M = B * S0 rows, live,
     # through the same dispatch the engine uses (128^2 / 256^2 tile kernel + tail kernel)
     from starvector_amd.engine import bench_linear
@@ -387,6 +399,8 @@ def main():
                          "avg_launch_us": round(sk_ms * 1e3 / launches, 2),
                          "avg_launch_us_source": ("in situ: (decode step - back-to-back chain of the step's other kernels) / launches" +
                                                   (f"; the {cfg.n_layer} row updates that run inside the c_attn launch count with the family" if rc_on else "")),
+                         "avg_launch_us_rocprof": rocprof_us, "avg_launch_us_rocprof_source": rocprof_src,
+                         "frac_rocprof": round(W_BYTES_PER_STEP / launches / (rocprof_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if rocprof_us else None,
                          "avg_launch_us_gemm_chain": round(sk_chain_ms * 1e3 / launches, 2),
                          "frac_gemm_chain": round(W_BYTES_PER_STEP / (sk_chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sk_chain_ms > 0 else None,
                          "avg_exec_us_event_deltas": round(sk_exec_ms * 1e3 / launches, 2)},
