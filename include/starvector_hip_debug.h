@@ -11,7 +11,7 @@
  *   sv_debug_kv_load / sv_debug_attn_decode   the decode attention alone over an engine's real paged pool (tests/test_gpu_long_context.py)
  *   sv_debug_*_trace, sv_debug_xcc_map        in-kernel wall-clock traces and block placement (tools/*_trace.py)
  *   sv_bench_*, sv_profile_decode_step        micro-benchmarks and the HIP-event profile bench.py's roofline leg reads
- *   sv_debug_set_exp / sv_debug_set_col_tiles / sv_debug_set_gemm_form
+ *   sv_debug_set_exp / sv_debug_set_col_tiles / sv_debug_set_gemm_form / sv_debug_set_linear_seq_rows
  *                           A/B switches: they CHANGE which kernels a live engine (set_exp) or the process (the other two) launches
  *                           from then on -- every form computes the same bits (tests), but a product deployment has no reason to
  *                           call them.  The environment variable SV_EXP sets the same mask at sv_create.
@@ -81,6 +81,16 @@ int  sv_debug_set_skinny_form(int32_t form);
      2 = 256x256 tiles + the row remainder over a multiple of 256 through the one-wave-per-tile tail kernel; -1 = the tuned choice (default).
      The forms give the same bits; the tests compare them through this switch. */
 int  sv_debug_set_gemm_form(int32_t form);
+/*   sv_debug_set_linear_seq_rows  process-wide: the sequence structure sv_op_linear / sv_bench_linear hand to the big-M dispatch from now on --
+     S > 0: the M rows are M / S sequences of S rows.  Where S leaves 1..3 rows over its 256-row tiles (a 259-row prompt, a 257-token image:
+     starvector_base.py:131-170, clip_model.py:140-155 produce exactly those row counts) AND the dispatch's cost model peels the remainder of a
+     32-sequence batch for this projection, the tile kernels cover the full tiles of EVERY sequence and gemm_tailk_kernel (8 waves per 32 x 32
+     tile, K split over the waves) the rows left over -- what the engine's prompt pass and vision tower launch; S < 0: the M rows are the LAST
+     rows of sequences of |S| rows (the pruned last prompt layer) and take the kernel they take inside the full problem; 0 = none (default). */
+int  sv_debug_set_linear_seq_rows(int32_t seq_rows);
+/*   sv_debug_gemm_seq_form    1 / 0: does the projection (N, K, act) take that per-sequence form for sequences of S rows?  Host arithmetic only
+     (callable without a GPU); a function of S and the projection alone, never of the batch: a sequence's tokens do not depend on its neighbours. */
+int  sv_debug_gemm_seq_form(int32_t S, int32_t N, int32_t K, int32_t act);
 /* The decode attention (gpt_bigcode/modeling_gpt_bigcode.py:151-285, llm/starcoder2.py:22-27 sliding window) on
  * its own, over the engine's real paged KV pool, block table and context-split plan.  Test surface: the caller chooses q / K / V.
  *   sv_debug_kv_load     dev_kv bf16 [B][S][2*n_kv*head_dim] (k heads | v heads, K as cached = after RoPE) -> pages of `layer`;

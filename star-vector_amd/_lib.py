@@ -119,6 +119,8 @@ DEBUG_PROTOTYPES = {
     "sv_debug_set_col_tiles": (_I, [_I]),
     "sv_debug_set_skinny_form": (_I, [_I]),
     "sv_debug_set_gemm_form": (_I, [_I]),
+    "sv_debug_set_linear_seq_rows": (_I, [_I]),
+    "sv_debug_gemm_seq_form": (_I, [_I, _I, _I, _I]),
     "sv_debug_attn_plan": (_I, [_I, _I, _I, C.POINTER(_I)]),
     "sv_debug_rowln_plan": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),
     "sv_debug_step_plan": (_I, [_P, C.POINTER(_I)]),

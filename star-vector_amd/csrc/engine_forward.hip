@@ -24,8 +24,11 @@ void prof_mark(sv_engine* e, int kind, hipStream_t st) {
 // remainder-row launch of a peeled GEMM is marked PK_GEMM_TAIL through the launcher's hook
 struct TailMarkCtx { sv_engine* e; };
 static void tail_mark_cb(void* c, hipStream_t st) { prof_mark(static_cast<TailMarkCtx*>(c)->e, PK_GEMM_TAIL, st); }
+// seq_rows: the M rows are whole sequences of that many rows (vision tokens of an image, prompt rows of a request): where gemm_seq_form holds
+// the rows a sequence leaves over its 256-row tiles go through the split-K remainder kernel (gemm.hip); last_rows: the M rows are the LAST
+// rows of such sequences (compact) and take the kernel they take inside the full problem
 static void gemm(sv_engine* e, int kind, const bf16_t* A, int lda, const Linear& l, const bf16_t* R, int ldr, void* C, int ldc, int M,
-                 int act, int out_f32, hipStream_t st) {
+                 int act, int out_f32, hipStream_t st, int seq_rows = 0, int last_rows = 0) {
     TailMarkCtx tc{e};
     prof_mark(e, kind, st);
     GemmArgs g;
@@ -33,6 +36,8 @@ static void gemm(sv_engine* e, int kind, const bf16_t* A, int lda, const Linear&
     g.A = A; g.lda = lda; g.Wp = l.Wp; g.bias = l.bias; g.R = R; g.ldr = ldr; g.C = C; g.ldc = ldc;
     g.M = M; g.N = l.N; g.K = l.Kpad; g.act = act; g.out_f32 = out_f32;
     g.cscale = l.fp8 ? l.wscale : nullptr;
+    g.seq_rows = (e->exp & 4194304) ? 0 : seq_rows;          // SV_EXP bit 4194304: A/B, the batch-level remainder of rounds 2-5
+    g.splitk_rows = (e->exp & 4194304) ? 0 : last_rows;
     launch_gemm(g, st);
 }
 
@@ -80,14 +85,14 @@ static int vision_forward(sv_engine* e, const bf16_t* img, int B, bf16_t* out, h
         VitLayer& L = e->vit[i];
         prof_mark(e, PK_VIT_ROWS, st);
         launch_layernorm_rows(e->vx, Dv, L.ln1.g, L.ln1.b, e->vln, Dv, M, Dv, eps, st);
-        gemm(e, PK_VIT_GEMM, e->vln, Dv, L.in_proj, nullptr, 0, e->vqkv, 3 * Dv, M, ACT_NONE, 0, st);
+        gemm(e, PK_VIT_GEMM, e->vln, Dv, L.in_proj, nullptr, 0, e->vqkv, 3 * Dv, M, ACT_NONE, 0, st, T);
         prof_mark(e, PK_VIT_ATTN, st);
         launch_attn_prefill(at, st);
-        gemm(e, PK_VIT_GEMM, e->vattn, Dv, L.out_proj, e->vx, Dv, e->vx, Dv, M, ACT_NONE, 0, st);
+        gemm(e, PK_VIT_GEMM, e->vattn, Dv, L.out_proj, e->vx, Dv, e->vx, Dv, M, ACT_NONE, 0, st, T);
         prof_mark(e, PK_VIT_ROWS, st);
         launch_layernorm_rows(e->vx, Dv, L.ln2.g, L.ln2.b, e->vln, Dv, M, Dv, eps, st);
-        gemm(e, PK_VIT_GEMM, e->vln, Dv, L.c_fc, nullptr, 0, e->vmlp, Fv, M, act, 0, st);
-        gemm(e, PK_VIT_GEMM, e->vmlp, Fv, L.c_proj, e->vx, Dv, e->vx, Dv, M, ACT_NONE, 0, st);
+        gemm(e, PK_VIT_GEMM, e->vln, Dv, L.c_fc, nullptr, 0, e->vmlp, Fv, M, act, 0, st, T);
+        gemm(e, PK_VIT_GEMM, e->vmlp, Fv, L.c_proj, e->vx, Dv, e->vx, Dv, M, ACT_NONE, 0, st, T);
     }
     prof_mark(e, PK_VIT_ROWS, st);
     launch_layernorm_rows(e->vx, Dv, e->ln_vision.g, e->ln_vision.b, out, Dv, M, Dv, eps, st);
@@ -98,8 +103,8 @@ static int vision_forward(sv_engine* e, const bf16_t* img, int B, bf16_t* out, h
 static int adapter_forward(sv_engine* e, const bf16_t* in, int B, bf16_t* out, hipStream_t st, size_t out_batch_stride = 0) {
     const sv_config& c = e->cfg;
     const int Dv = c.vit_width, D = c.hidden, T = e->T, M = B * T;
-    gemm(e, PK_AD_GEMM, in, Dv, e->ad_fc, nullptr, 0, e->a1, 2 * Dv, M, ACT_SWISH, 0, st);
-    gemm(e, PK_AD_GEMM, e->a1, 2 * Dv, e->ad_proj, nullptr, 0, e->a2, D, M, ACT_NONE, 0, st);
+    gemm(e, PK_AD_GEMM, in, Dv, e->ad_fc, nullptr, 0, e->a1, 2 * Dv, M, ACT_SWISH, 0, st, T);
+    gemm(e, PK_AD_GEMM, e->a1, 2 * Dv, e->ad_proj, nullptr, 0, e->a2, D, M, ACT_NONE, 0, st, T);
     prof_mark(e, PK_AD_NORM, st);
     if (c.adapter_norm == SV_NORM_LAYER)
         launch_plane_layernorm(e->a2, e->ad_w, e->ad_b, out, B, T * D, c.ln_eps, st, out_batch_stride);
@@ -192,11 +197,12 @@ int sveng::prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hi
     // reads logits[:, -1]; a row's GEMM / attention result does not depend on the rows around it: bit-identical, test_gpu_e2e.py).
     // SV_EXP bit 32768 = off (A/B).
     const bool prune_last = n_keep == 0 && S0 >= 2 && !(e->exp & 32768);
+    // the last prompt row may be one of the rows its sequence leaves over its 256-row tiles: the launcher gives it the kernel it takes in the full layers
     for (int i = 0; i < c.n_layer; ++i) {
         DecLayer& L = e->dec[i];
         prof_mark(e, PK_PF_ROWS, st);
         launch_layernorm_rows(e->ph, D, L.ln1.g, L.ln1.b, e->pln, D, M, D, c.ln_eps, st);
-        gemm(e, PK_PF_GEMM, e->pln, D, L.c_attn, nullptr, 0, e->pqkv, QKV, M, ACT_NONE, 0, st);
+        gemm(e, PK_PF_GEMM, e->pln, D, L.c_attn, nullptr, 0, e->pqkv, QKV, M, ACT_NONE, 0, st, S0);
         prof_mark(e, PK_PF_ATTN, st);                      // RoPE + KV scatter + flash attention
         if (e->v2) launch_rope_prefill(e->pqkv, QKV, M, S0, c.n_head + nkv, dh, e->rope_cos, e->rope_sin, st);
         for (int kh = 0; kh < nkv; ++kh)
@@ -213,11 +219,11 @@ int sveng::prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hi
             prof_mark(e, PK_PF_ROWS, st);
             launch_gather_last_rows(e->pattn, pa_l, B, S0, QD, st);
             launch_gather_last_rows(e->ph, e->hl, B, S0, D, st);
-            gemm(e, PK_PF_GEMM, pa_l, QD, L.c_proj, e->hl, D, e->hl, D, B, ACT_NONE, 0, st);
+            gemm(e, PK_PF_GEMM, pa_l, QD, L.c_proj, e->hl, D, e->hl, D, B, ACT_NONE, 0, st, S0, 1);
             prof_mark(e, PK_PF_ROWS, st);
             launch_layernorm_rows(e->hl, D, L.ln2.g, L.ln2.b, ln_l, D, B, D, c.ln_eps, st);
-            gemm(e, PK_PF_GEMM, ln_l, D, L.c_fc, nullptr, 0, e->pmlp, F, B, ACT_GELU_TANH, 0, st);
-            gemm(e, PK_PF_GEMM, e->pmlp, F, L.c_proj2, e->hl, D, e->hl, D, B, ACT_NONE, 0, st);
+            gemm(e, PK_PF_GEMM, ln_l, D, L.c_fc, nullptr, 0, e->pmlp, F, B, ACT_GELU_TANH, 0, st, S0, 1);
+            gemm(e, PK_PF_GEMM, e->pmlp, F, L.c_proj2, e->hl, D, e->hl, D, B, ACT_NONE, 0, st, S0, 1);
             prof_mark(e, PK_PF_ROWS, st);
             launch_layernorm_rows_packed(e->hl, D, e->ln_f.g, e->ln_f.b, e->xp_f, B, D, c.ln_eps, st);
             prof_mark(e, PK_PF_LMHEAD, st);
@@ -225,11 +231,11 @@ int sveng::prefill_forward(sv_engine* e, const bf16_t* embeds, int B, int S0, hi
             return 0;
         }
         launch_attn_prefill(at, st);
-        gemm(e, PK_PF_GEMM, e->pattn, QD, L.c_proj, e->ph, D, e->ph, D, M, ACT_NONE, 0, st);
+        gemm(e, PK_PF_GEMM, e->pattn, QD, L.c_proj, e->ph, D, e->ph, D, M, ACT_NONE, 0, st, S0);
         prof_mark(e, PK_PF_ROWS, st);
         launch_layernorm_rows(e->ph, D, L.ln2.g, L.ln2.b, e->pln, D, M, D, c.ln_eps, st);
-        gemm(e, PK_PF_GEMM, e->pln, D, L.c_fc, nullptr, 0, e->pmlp, F, M, ACT_GELU_TANH, 0, st);
-        gemm(e, PK_PF_GEMM, e->pmlp, F, L.c_proj2, e->ph, D, e->ph, D, M, ACT_NONE, 0, st);
+        gemm(e, PK_PF_GEMM, e->pln, D, L.c_fc, nullptr, 0, e->pmlp, F, M, ACT_GELU_TANH, 0, st, S0);
+        gemm(e, PK_PF_GEMM, e->pmlp, F, L.c_proj2, e->ph, D, e->ph, D, M, ACT_NONE, 0, st, S0);
     }
     if (n_keep > 0) {
         // scoring forward (starvector_arch.py:161-184): ln_f + lm_head over the last n_keep rows of every sequence, as one

@@ -208,6 +208,15 @@ extern "C" int sv_debug_set_gemm_form(int32_t form) {
     return 0;
 }
 
+// sequence structure sv_op_linear / sv_bench_linear hand to the big-M dispatch (GemmArgs::seq_rows; 0 = none): the test surface of
+// the per-sequence remainder (gemm_tailk_kernel)
+static std::atomic<int> g_op_seq_rows{0};
+extern "C" int sv_debug_set_linear_seq_rows(int32_t seq_rows) {
+    if (seq_rows < -65536 || seq_rows > 65536) return fail(SV_EINVAL, "sv_debug_set_linear_seq_rows: |S| <= 65536");
+    g_op_seq_rows = seq_rows;
+    return 0;
+}
+
 extern "C" int sv_debug_set_col_tiles(int32_t col_tiles) {
     if (col_tiles < 0 || col_tiles > 3) return fail(SV_EINVAL, "sv_debug_set_col_tiles: 0..3");
     g_op_col_tiles = col_tiles;
@@ -218,6 +227,12 @@ extern "C" int sv_debug_set_skinny_form(int32_t form) {
     if (form < 0 || form > 3) return fail(SV_EINVAL, "sv_debug_set_skinny_form: 0..3");
     set_mt2x(form);
     return 0;
+}
+
+// 1 / 0: does the projection (N, K, act) take the per-sequence remainder form for sequences of S rows (host arithmetic only; < 0: bad argument)
+extern "C" int sv_debug_gemm_seq_form(int32_t S, int32_t N, int32_t K, int32_t act) {
+    if (S < 1 || N < 1 || K < 1) return fail(SV_EINVAL, "sv_debug_gemm_seq_form: bad argument");
+    return gemm_seq_form(S, N, K, act) ? 1 : 0;
 }
 
 extern "C" int sv_debug_gemm_plan(int32_t M, int32_t N, int32_t K, int32_t act, int32_t* out5) {
@@ -390,6 +405,8 @@ extern "C" int sv_op_linear(const void* x, const void* W, const void* bias, cons
     GemmArgs g;
     g.A = A; g.lda = lda; g.Wp = Wp; g.bias = (const bf16_t*)bias; g.R = (const bf16_t*)residual; g.ldr = N;
     g.C = y; g.ldc = N; g.M = M; g.N = N; g.K = Kpad; g.act = act; g.out_f32 = out_f32;
+    g.seq_rows = g_op_seq_rows.load();
+    if (g.seq_rows < 0) { g.seq_rows = -g.seq_rows; g.splitk_rows = 1; }      // the rows are the last rows of sequences of |S| rows
     launch_gemm(g, st);
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(st));
@@ -428,6 +445,7 @@ extern "C" int sv_bench_linear(int32_t M, int32_t N, int32_t K, int32_t act, int
     GemmArgs g;
     g.A = A; g.lda = K; g.Wp = Wp; g.bias = bias; g.R = residual ? C : nullptr; g.ldr = N; g.C = C; g.ldc = N;
     g.M = M; g.N = N; g.K = K; g.act = act; g.out_f32 = 0;
+    g.seq_rows = g_op_seq_rows.load() > 0 ? g_op_seq_rows.load() : 0;
     // SV_BENCH_GEMM_FORM = 0 / 1: one fixed form (128^2 tiles, 256^2 tiles; rows not peeled) instead of the tuned choice
     const char* form_s = getenv("SV_BENCH_GEMM_FORM");
     const int form = form_s ? atoi(form_s) : -1;

@@ -224,6 +224,15 @@ __device__ __forceinline__ void epi_flush_strip(const char* strip, const GemmArg
     }
 }
 
+// first row of row tile tm (tile height T = 128 / 256).  With a sequence structure (GemmArgs::seq_rows) the tiles cover the first
+// 256 * (seq_rows / 256) rows of every sequence and never straddle two sequences; the rows left over go through gemm_tailk_kernel.
+__device__ __forceinline__ int tile_first_row(const GemmArgs& p, int tm, int T) {
+    if (p.seq_rows == 0) return tm * T;
+    const int per = (p.seq_rows >> 8) * (256 / T);
+    const int s = tm / per;
+    return s * p.seq_rows + (tm - s * per) * T;
+}
+
 template <typename OutT>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
         tm = band * 8 + r_in % band_rows;
         tn = r_in / band_rows;
     }
-    const int m0 = tm * GB_M;
+    const int m0 = tile_first_row(p, tm, GB_M);
     const int n0 = tn * GB_N;
     const int KS = p.K >> 4;
     const int KT = p.K / GB_K;
@@ -482,7 +491,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p, int tiles_m, i
     const int band = wg / (4 * tiles_n), r_in = wg - band * 4 * tiles_n;
     const int band_rows = min(4, tiles_m - band * 4);
     const int tm = band * 4 + r_in % band_rows, tn = r_in / band_rows;
-    const int m0 = tm * G2_T, n0 = tn * G2_T;
+    const int m0 = tile_first_row(p, tm, G2_T), n0 = tn * G2_T;
     const int KS = p.K >> 4;
     const int KT = p.K >> 6;
     const int NT_total = (p.N + 31) >> 5;
@@ -730,14 +739,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(GemmArgs p, int tiles_m, i
     stamp();
 }
 
+// row tiles of the 128^2 kernel's grid (sequence structure: two per 256 rows of every sequence)
+static int tiles128_m(const GemmArgs& a) { return a.seq_rows ? (a.M / a.seq_rows) * (a.seq_rows / 256) * 2 : (a.M + GB_M - 1) / GB_M; }
 static void launch_gemm256(const GemmArgs& a, hipStream_t st) {
     if (a.K < 128) {                     // the loop's prologue stages into K-tile 1: a single K-tile goes through the 128^2 kernel (same bits)
-        dim3 grid((a.N + GB_N - 1) / GB_N, (a.M + GB_M - 1) / GB_M);
+        dim3 grid((a.N + GB_N - 1) / GB_N, tiles128_m(a));
         if (a.out_f32) gemm_bf16_kernel<float><<<grid, 256, 2 * GB_BUF, st>>>(a);
         else gemm_bf16_kernel<bf16_t><<<grid, 256, 2 * GB_BUF, st>>>(a);
         return;
     }
-    const int tiles_m = (a.M + G2_T - 1) / G2_T, tiles_n = (a.N + G2_T - 1) / G2_T;
+    const int tiles_m = a.seq_rows ? (a.M / a.seq_rows) * (a.seq_rows / G2_T) : (a.M + G2_T - 1) / G2_T, tiles_n = (a.N + G2_T - 1) / G2_T;
     if (a.out_f32) gemm256_kernel<float><<<tiles_m * tiles_n, 512, 2 * G2_BUF, st>>>(a, tiles_m, tiles_n);
     else gemm256_kernel<bf16_t><<<tiles_m * tiles_n, 512, 2 * G2_BUF, st>>>(a, tiles_m, tiles_n);
 }
@@ -850,6 +861,111 @@ static void launch_gemm_tail(const GemmArgs& t, hipStream_t st) {
     gemm_tail_kernel<<<dim3((t.N + 31) / 32, (t.M + 31) / 32), 64, 0, st>>>(t);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The rows a SEQUENCE leaves over its 256-row tiles (round 6).  A prompt of 259 rows (257 visual + 2) is one tile + 3 rows, a ViT
+// image of 257 tokens one tile + 1 row: at batch 32 that is 96 / 32 remainder rows per GEMM, and through gemm_tail_kernel -- one
+// wave per 32 x 32 tile walking the WHOLE K, because its bits had to equal the tile kernels' -- they cost 10 / 18 / 33 us (c_proj /
+// c_fc / down projection: a 512-MFMA dependent chain fed by one wave's 56 loads in flight) and 1.9 ms of a 26 ms time to first token.
+// Here the remainder is defined per SEQUENCE instead of per batch (GemmArgs::seq_rows: the last S % 256 rows of every sequence,
+// whatever the batch), which frees the summation order: a block of 8 waves per 32 x 32 tile, wave w walks chunks
+// [w * NCH / 8, (w + 1) * NCH / 8) of 64 k (a function of K alone), the eight partial tiles meet in LDS and are summed in wave
+// order.  Which kernel computes a row -- and in what order its k are summed -- depends on the row's position in its sequence only:
+// a sequence's tokens stay independent of the batch it shares (the property the tail kernel's bit-identity bought, kept by
+// construction instead).  The pruned last prompt layer (one row per sequence, GemmArgs::splitk_rows) takes the same kernel when its
+// rows are such remainder rows.
+// ------------------------------------------------------------------------------------------------
+#define GTK_WAVES 8
+template <int D>
+__global__ __launch_bounds__(GTK_WAVES * 64) void gemm_tailk_kernel(GemmArgs p) {
+    __shared__ float red[GTK_WAVES][16][64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nt = blockIdx.x, mt = blockIdx.y;
+    const int KS = p.K >> 4;
+    const int NCH = KS >> 2;                       // K % 64 == 0
+    const int c0 = wave * NCH / GTK_WAVES, n = (wave + 1) * NCH / GTK_WAVES - c0;
+    int i = mt * 32 + (lane & 31);
+    const bool rok = i < p.M;
+    i = rok ? i : p.M - 1;
+    const int row = p.seq_tail ? (i / p.seq_tail) * p.seq_rows + (p.seq_rows - p.seq_tail) + i % p.seq_tail : i;
+    const bf16_t* xrow = p.A + (size_t)row * p.lda + 8 * (lane >> 5) + c0 * 64;
+    const bf16_t* wfr = p.Wp + (((size_t)nt * KS + c0 * 4) * 64 + lane) * 8;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    // a ring of D chunks of 4 k-steps, statically indexed (see gemm_tail_kernel)
+    bf16x8 w[D][4], x[D][4];
+    auto load = [&](int d, int c) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            w[d][s] = *reinterpret_cast<const bf16x8*>(wfr + (size_t)(4 * c + s) * 512);
+            x[d][s] = *reinterpret_cast<const bf16x8*>(xrow + (4 * c + s) * 16);
+        }
+    };
+    auto mma = [&](int d) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[d][s], x[d][s], acc, 0, 0, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (d < n) load(d, d);
+    int c = 0;
+    for (; c + 2 * D <= n; c += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) { mma(d); load(d, c + D + d); }
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        if (c + d < n) mma(d);
+        if (c + D + d < n) load(d, c + D + d);
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+        if (c + D + d < n) mma(d);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    if (wave >= 4 || !rok) return;
+    // waves 0..3 finish register group rg = wave of every lane: 4 consecutive columns of the lane's row, partial tiles summed in wave order
+    const int rg = wave, half = lane >> 5, m = row;
+    const int ncol = nt * 32 + rg * 8 + half * 4;
+    if (ncol >= p.N) return;              // N % 4 == 0
+    const uint2 bq = p.bias ? *reinterpret_cast<const uint2*>(p.bias + ncol) : make_uint2(0u, 0u);
+    const uint2 rq = p.R ? *reinterpret_cast<const uint2*>(p.R + (size_t)m * p.ldr + ncol) : make_uint2(0u, 0u);
+    const float4 c4 = p.cscale ? *reinterpret_cast<const float4*>(p.cscale + ncol) : make_float4(1.f, 1.f, 1.f, 1.f);
+    const float cs[4] = {c4.x, c4.y, c4.z, c4.w};
+    const float bj[4] = {__uint_as_float(bq.x << 16), __uint_as_float(bq.x & 0xffff0000u), __uint_as_float(bq.y << 16), __uint_as_float(bq.y & 0xffff0000u)};
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float t = red[0][rg * 4 + e][lane];
+#pragma unroll
+        for (int ww = 1; ww < GTK_WAVES; ++ww) t += red[ww][rg * 4 + e][lane];
+        float xv = t * cs[e] + bj[e];
+        if (p.act != ACT_NONE) xv = sv_act(bfround(xv), p.act);
+        v[e] = xv;
+    }
+    if (p.R) {
+        v[0] = bfround(v[0]) + __uint_as_float(rq.x << 16);
+        v[1] = bfround(v[1]) + __uint_as_float(rq.x & 0xffff0000u);
+        v[2] = bfround(v[2]) + __uint_as_float(rq.y << 16);
+        v[3] = bfround(v[3]) + __uint_as_float(rq.y & 0xffff0000u);
+    }
+    if (p.out_f32) {
+        *reinterpret_cast<float4*>((float*)p.C + (size_t)m * p.ldc + ncol) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        uint2 o;
+        o.x = pack2bf(v[0], v[1]);
+        o.y = pack2bf(v[2], v[3]);
+        *reinterpret_cast<uint2*>((bf16_t*)p.C + (size_t)m * p.ldc + ncol) = o;
+    }
+}
+// t: the GemmArgs of the remainder rows (M = their number; seq_tail / seq_rows = the row map, or compact rows)
+static void launch_gemm_tailk(const GemmArgs& t, hipStream_t st) {
+    // ring depth 3 / 4 / 6 chunks measured equal at every prefill shape (profiles/gemm_seq_remainder_r06.log): the launch is bound by its L2 traffic
+    gemm_tailk_kernel<4><<<dim3((t.N + 31) / 32, (t.M + 31) / 32), GTK_WAVES * 64, 0, st>>>(t);
+}
+
 // Pick the tile kernel, and decide whether to peel a small row remainder, by a cost model fitted to measurements at
 // the prefill / ViT shapes (tools/bench_gemm.py).  A "round" is one wave of tiles over the chip (128^2: 2 blocks per
 // CU, 256^2: 1 block per CU); the last round costs as much as a full one, which is the whole reason for peeling.
@@ -874,9 +990,9 @@ static double tail_us(int tail, int N, int K) {
 }
 
 static void launch_gemm_tiles(const GemmArgs& a, hipStream_t st, bool force128 = false) {
-    dim3 grid((a.N + GB_N - 1) / GB_N, (a.M + GB_M - 1) / GB_M);
+    dim3 grid((a.N + GB_N - 1) / GB_N, tiles128_m(a));
     bool use256 = false;
-    (void)tiles_us(a.M, a.N, a.K, a.act, &use256);
+    (void)tiles_us(a.seq_rows ? (int)grid.y * GB_M : a.M, a.N, a.K, a.act, &use256);
     if (!force128 && use256) { launch_gemm256(a, st); return; }
     if (a.out_f32) gemm_bf16_kernel<float><<<grid, 256, 2 * GB_BUF, st>>>(a);
     else gemm_bf16_kernel<bf16_t><<<grid, 256, 2 * GB_BUF, st>>>(a);
@@ -908,11 +1024,20 @@ GemmPlan gemm_plan(int M, int N, int K, int act, int tail_on) {
 // and ascending-k order: tests/test_gpu_ops.py::test_linear_big_m_kernels_agree_bitwise), so the choice is speed only.
 static void launch_gemm_config(const GemmArgs& a, hipStream_t st, int kernel256, bool peel, bool tail_by_tiles) {
     auto tiles = [&](const GemmArgs& g, bool force128) {
-        dim3 grid((g.N + GB_N - 1) / GB_N, (g.M + GB_M - 1) / GB_M);
+        dim3 grid((g.N + GB_N - 1) / GB_N, tiles128_m(g));
         if (kernel256 && !force128) { launch_gemm256(g, st); return; }
         if (g.out_f32) gemm_bf16_kernel<float><<<grid, 256, 2 * GB_BUF, st>>>(g);
         else gemm_bf16_kernel<bf16_t><<<grid, 256, 2 * GB_BUF, st>>>(g);
     };
+    if (a.seq_rows) {                    // (sanitised by the caller: the rule holds) tiles over the full 256-row tiles of every sequence + the split-K remainder
+        tiles(a, false);
+        GemmArgs t = a;
+        t.seq_tail = seq_peel_rows(a.seq_rows);
+        t.M = (a.M / a.seq_rows) * t.seq_tail;
+        if (a.tail_mark) a.tail_mark(a.tail_ctx, st);
+        launch_gemm_tailk(t, st);
+        return;
+    }
     const int tail = a.M % 256, main_rows = a.M - tail;
     if (peel && tail > 0 && main_rows > 0) {
         GemmArgs m = a;
@@ -970,8 +1095,8 @@ static int autotune_gemm(const GemmArgs& a, hipStream_t st, const GemmPlan& mode
     t.C = scratch;
     t.tail_mark = nullptr;                       // the timing runs are not part of anybody's profile
     const int tail = a.M % 256, main_rows = a.M - tail;
-    const bool can_peel = tail > 0 && tail <= 96 && main_rows >= 2048;
-    const long t256 = (long)((a.M + 255) / 256) * ((a.N + 255) / 256);
+    const bool can_peel = !a.seq_rows && tail > 0 && tail <= 96 && main_rows >= 2048;
+    const long t256 = (long)(a.seq_rows ? (a.M / a.seq_rows) * (a.seq_rows / 256) : (a.M + 255) / 256) * ((a.N + 255) / 256);
     int best = fallback;
     float best_ms = 1e30f;
     for (int k256 = 0; k256 < 2; ++k256) {
@@ -989,19 +1114,40 @@ static int autotune_gemm(const GemmArgs& a, hipStream_t st, const GemmPlan& mode
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     if (getenv("SV_GEMM_AUTOTUNE_LOG"))
-        fprintf(stderr, "[sv gemm autotune] M %d N %d K %d act %d res %d -> %s%s (%.1f us; model said %s%s)\n", a.M, a.N, a.K, a.act,
-                a.R ? 1 : 0, (best & 1) ? "256^2" : "128^2", (best & 2) ? " + peeled tail" : "", best_ms * 1000.f / 3.f,
+        fprintf(stderr, "[sv gemm autotune] M %d N %d K %d act %d res %d%s -> %s%s (%.1f us; model said %s%s)\n", a.M, a.N, a.K, a.act,
+                a.R ? 1 : 0, a.seq_rows ? " seq" : "", (best & 1) ? "256^2" : "128^2", (best & 2) ? " + peeled tail" : "", best_ms * 1000.f / 3.f,
                 (fallback & 1) ? "256^2" : "128^2", (fallback & 2) ? " + peeled tail" : "");
     return best;
 }
 
-void launch_gemm_fixed(const GemmArgs& a, int kernel256, int peel, hipStream_t st) { launch_gemm_config(a, st, kernel256 != 0, peel != 0, false); }
+// the per-sequence form: where the cost model peels the remainder of a reference batch of 32 sequences (measured, tools/tail_ab.py /
+// profiles/gemm_seq_remainder_r06.log: the split-K remainder launch beats the one-wave-per-tile one where there WAS a remainder launch -- c_proj,
+// down projection, the ViT's out / MLP projections, the adapter -- and costs a launch where the rows were not peeled -- c_attn, the ViT's in_proj)
+bool gemm_seq_form(int S, int N, int K, int act) {
+    if (S <= 0 || !seq_peel_rows(S)) return false;
+    return gemm_plan(32 * S, N, K, act, 1).peel != 0;
+}
+// the sequence structure is used only where its rule holds and the rows are whole sequences
+static GemmArgs seq_sanitised(const GemmArgs& a0) {
+    GemmArgs a = a0;
+    const bool form = a.seq_rows > 0 && gemm_seq_form(a.seq_rows, a.N, a.K, a.act);
+    if (a.splitk_rows) { a.splitk_rows = form ? 1 : 0; a.seq_rows = 0; }       // compact last rows: the remainder kernel iff the full problem would use it for them
+    else if (!form || a.M % a.seq_rows) a.seq_rows = 0;
+    a.seq_tail = 0;
+    return a;
+}
+void launch_gemm_fixed(const GemmArgs& a0, int kernel256, int peel, hipStream_t st) {
+    const GemmArgs a = seq_sanitised(a0);
+    if (a.splitk_rows) { launch_gemm_tailk(a, st); return; }
+    launch_gemm_config(a, st, kernel256 != 0, peel != 0, false);
+}
 
 static std::atomic<int> g_gemm_form{-1};        // test surface (sv_debug_set_gemm_form): -1 = tuned, 0 / 1 = one fixed form
 void set_gemm_form(int form) { g_gemm_form = form; }
 
 void launch_gemm(const GemmArgs& a0, hipStream_t st) {
-    const GemmArgs& a = a0;
+    const GemmArgs a = seq_sanitised(a0);
+    if (a.splitk_rows) { launch_gemm_tailk(a, st); return; }       // compact remainder rows (the pruned last prompt layer)
     const int fixed = g_gemm_form.load();
     // forms 0 / 1: one tile kernel, rows not peeled; 2: 256^2 tiles + the row remainder through the tail kernel -- the test surface that puts
     // every kernel next to the others
@@ -1010,11 +1156,12 @@ void launch_gemm(const GemmArgs& a0, hipStream_t st) {
     // a handful of rows (the pruned last layer of a prompt pass: one row per sequence): one wave per 32 x 32 tile with 56 loads in flight
     // beats a single row of 128^2 tiles that walk the whole K alone -- same bits either way
     if (a.M <= 96 && tail_us(a.M, a.N, a.K) < 10.0 + 0.03 * (double)a.K) { launch_gemm_tail(a, st); return; }
-    const GemmPlan pl = gemm_plan(a.M, a.N, a.K, a.act, 1);
+    const int Mt = a.seq_rows ? (a.M / a.seq_rows) * (a.seq_rows / 256) * 256 : a.M;       // rows the tile kernels cover
+    const GemmPlan pl = gemm_plan(Mt, a.N, a.K, a.act, 1);
     static const bool tune_on = !(getenv("SV_GEMM_AUTOTUNE") && atoi(getenv("SV_GEMM_AUTOTUNE")) == 0);
     if (tune_on && a.M >= 1024 && (long)a.M * a.N >= (1L << 22)) {
         const int tail = a.M % 256;
-        const TuneKey key{(a.M + 1023) / 1024, (tail > 0 && tail <= 96 && a.M - tail >= 2048) ? 1 : 0, a.N, a.K, a.act, a.R ? 1 : 0,
+        const TuneKey key{(a.M + 1023) / 1024, a.seq_rows ? 2 : (tail > 0 && tail <= 96 && a.M - tail >= 2048) ? 1 : 0, a.N, a.K, a.act, a.R ? 1 : 0,
                           a.out_f32, a.cscale ? 1 : 0};
         int cfg;
         {
@@ -1026,6 +1173,7 @@ void launch_gemm(const GemmArgs& a0, hipStream_t st) {
         launch_gemm_config(a, st, cfg & 1, (cfg & 2) != 0, (cfg & 4) != 0);
         return;
     }
+    if (a.seq_rows) { launch_gemm_config(a, st, pl.main_256, false, false); return; }
     const int tail = a.M % 256, main_rows = a.M - tail;
     const bool peel = pl.peel != 0, tail_by_tiles = pl.tail_by_tiles != 0;
     if (peel) {

@@ -34,7 +34,21 @@ struct GemmArgs {
     long long* trace = nullptr;      // optional [blocks][8] wall-clock stamps of the 256^2 kernel (tools/gemm_trace.py); nullptr in production
     void (*tail_mark)(void* ctx, hipStream_t st) = nullptr;   // profiling hook: called right before the remainder-row launch of a peeled GEMM
     void* tail_ctx = nullptr;        //   (sv_profile_ttft prices the tails apart from the tile launches); nullptr in production
+    // Sequence structure of the rows (round 6, gemm.hip "rows a sequence leaves over"): the M rows are M / seq_rows sequences of seq_rows
+    // rows each.  Where gemm_seq_form(seq_rows, N, K, act) holds, the first seq_rows - r rows of EVERY sequence go through the tile
+    // kernels (a tile never straddles two sequences) and the last r = seq_rows % 256 rows of every sequence through the split-K
+    // remainder kernel -- which kernel computes a row depends on the row's position in its sequence and on the projection, never on
+    // the batch around it.  0 = plain row-major problem.
+    int seq_rows = 0;
+    int seq_tail = 0;                // set by the launcher for the remainder launch: row i -> (i / seq_tail) * seq_rows + seq_rows - seq_tail + i % seq_tail
+    int splitk_rows = 0;             // 1: the M rows (compact, contiguous) are LAST rows of sequences of seq_rows rows (the pruned last prompt layer): they take
+                                     //    the kernel the same rows take inside the full problem (split-K remainder kernel where gemm_seq_form holds)
 };
+// r = rows a sequence of S rows leaves over its 256-row tiles when that is a handful (32 sequences leave at most 96 rows) and a full tile exists; else 0
+inline int seq_peel_rows(int S) { const int r = S % 256; return (S > 256 && r >= 1 && r <= 3) ? r : 0; }
+// Does the projection (N, K, act) take the per-sequence form for sequences of S rows?  A function of the sequence length and the projection ONLY
+// (never of the batch): where the dispatch's cost model peels the row remainder of a 32-sequence batch (gemm.hip gemm_plan).
+bool gemm_seq_form(int S, int N, int K, int act);
 void launch_gemm(const GemmArgs& a, hipStream_t st);
 // one fixed configuration (kernel256: 0 = 128^2 tiles, 1 = 256^2; peel: the row remainder over a multiple of 256 in its own launch), no tuning
 void launch_gemm_fixed(const GemmArgs& a, int kernel256, int peel, hipStream_t st);

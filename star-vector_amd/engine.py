@@ -547,6 +547,21 @@ def set_gemm_form(form: int) -> None:
     check(_lib.load().sv_debug_set_gemm_form(int(form)))
 
 
+def set_linear_seq_rows(seq_rows: int) -> None:
+    """Sequence structure `linear` / `bench_linear` hand to the big-M dispatch (sv_debug_set_linear_seq_rows): S > 0 = the rows are
+    sequences of S rows (where the per-sequence form holds for the projection, the rows a sequence leaves over its 256-row tiles take
+    the split-K remainder kernel), S < 0 = the rows are the last rows of sequences of |S| rows, 0 = none (default)."""
+    check(_lib.load().sv_debug_set_linear_seq_rows(int(seq_rows)))
+
+
+def gemm_seq_form(S: int, N: int, K: int, act: str = "none") -> bool:
+    """Does the projection (N, K, act) take the per-sequence remainder form for sequences of S rows (sv_debug_gemm_seq_form; host arithmetic)?"""
+    rc = _lib.load().sv_debug_gemm_seq_form(int(S), int(N), int(K), _lib.ACT[act])
+    if rc < 0:
+        check(rc, "sv_debug_gemm_seq_form")
+    return rc == 1
+
+
 def set_skinny_form(form: int) -> None:
     """Kernel of the 33..64-row decode GEMMs (sv_debug_set_skinny_form): 0 registers only, 1 LDS ring (default), 2 / 3 its fixed depths."""
     check(_lib.load().sv_debug_set_skinny_form(int(form)))

@@ -171,6 +171,7 @@ def test_argument_validation_precedes_any_device_work(lib):
     # the measurement / A-B surfaces validate before they touch the device as well
     assert lib.sv_debug_set_gemm_form(3) == -22 and lib.sv_debug_set_gemm_form(-2) == -22
     assert lib.sv_debug_set_gemm_form(1) == 0 and lib.sv_debug_set_gemm_form(-1) == 0
+    assert lib.sv_debug_set_linear_seq_rows(-70000) == -22 and lib.sv_debug_set_linear_seq_rows(259) == 0 and lib.sv_debug_set_linear_seq_rows(0) == 0
     buf = (C.c_int64 * 16)()
     assert lib.sv_debug_gemm_trace(100, 256, 256, 0, 1, buf, 1) == -22            # M < one tile
     assert lib.sv_debug_gemm_trace(256, 256, 256, 0, 2, buf, 1) == -22 and "form" in err()

@@ -153,6 +153,66 @@ def test_linear_tile_kernels_and_the_tuned_choice_agree_at_the_prefill_shapes(M,
     assert rel_err(outs[1], ref) <= 2.2 * BF16_1ULP
 
 
+@pytest.mark.parametrize("B,S,N,K,act,res", [(32, 259, 2048, 2048, "none", True),          # prefill c_proj: 32 tiles + 96 remainder rows
+                                             (32, 259, 2048, 8192, "none", True),          # down projection: 16 chunks per wave
+                                             (32, 259, 8192, 2048, "gelu_tanh", False),    # c_fc: NOT the per-sequence form (the cost model does not peel it)
+                                             (32, 259, 2304, 2048, "none", False),         # c_attn: not either
+                                             (32, 257, 1024, 4096, "none", True),          # ViT MLP c_proj: 1 row per image
+                                             (32, 257, 1024, 1024, "none", True),          # ViT out_proj: 2 chunks per wave
+                                             (5, 515, 1024, 640, "none", True),            # 2 tiles + 3 rows per sequence, 10 chunks over 8 waves
+                                             (3, 258, 1000, 320, "quickgelu", False)])     # ragged N, 5 chunks: three waves have nothing to do
+def test_linear_rows_a_sequence_leaves_over_its_tiles(B, S, N, K, act, res):
+    """GemmArgs::seq_rows: where gemm_seq_form holds for the projection, the tile kernels cover the full 256-row tiles of EVERY sequence
+    and gemm_tailk_kernel (K split over 8 waves) the S % 256 rows each sequence leaves over.  (a) against the fp32 reference; (b) rows
+    inside full tiles carry the tile kernels' bits (the same call without the sequence structure); (c) a sequence's rows do not depend
+    on the batch: the same sequence alone (B = 1) and at another place of the batch gives the same bits; (d) the compact form (the last
+    rows of the sequences on their own: the pruned last prompt layer) gives those rows' bits; (e) where the form does not hold, the
+    sequence structure changes nothing."""
+    g = torch.Generator().manual_seed(B + S + N + K)
+    M = B * S
+    x = torch.randn(M, K, generator=g).bfloat16()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16()
+    b = (0.1 * torch.randn(N, generator=g)).bfloat16()
+    r = torch.randn(M, N, generator=g).bfloat16() if res else None
+    rem = S % 256
+    form = E.gemm_seq_form(S, N, K, act)
+    try:
+        E.set_linear_seq_rows(0)
+        y_plain = E.op_linear(bf(x), bf(W), bf(b), bf(r) if res else None, act=act).cpu()
+        E.set_linear_seq_rows(S)
+        y = E.op_linear(bf(x), bf(W), bf(b), bf(r) if res else None, act=act).cpu()
+        # (c) the last sequence alone, and the batch reversed sequence-wise
+        xs, rs = x.view(B, S, K), (r.view(B, S, N) if res else None)
+        y1 = E.op_linear(bf(xs[-1].contiguous()), bf(W), bf(b), bf(rs[-1].contiguous()) if res else None, act=act).cpu()
+        yr = E.op_linear(bf(xs.flip(0).contiguous().view(M, K)), bf(W), bf(b), bf(rs.flip(0).contiguous().view(M, N)) if res else None, act=act).cpu()
+        # (d) the last row of every sequence as a compact problem
+        E.set_linear_seq_rows(-S)
+        xc = xs[:, -1].contiguous()
+        rc = rs[:, -1].contiguous() if res else None
+        yc = E.op_linear(bf(xc), bf(W), bf(b), bf(rc) if res else None, act=act).cpu()
+    finally:
+        E.set_linear_seq_rows(0)
+    ref = x.float() @ W.float().T + b.float()
+    if act != "none":
+        ref = {"gelu_tanh": lambda t: torch.nn.functional.gelu(t, approximate="tanh"),
+               "quickgelu": lambda t: t * torch.sigmoid(1.702 * t)}[act](ref.bfloat16().float())
+    if res:
+        ref = ref.bfloat16().float() + r.float()
+    assert rel_err(y, ref) <= 2.2 * BF16_1ULP and mean_err(y, ref) <= 6e-4
+    yb, pb = y.view(B, S, N).view(torch.int16), y_plain.view(B, S, N).view(torch.int16)
+    assert torch.equal(yb[:, :S - rem], pb[:, :S - rem])                 # every tile form sums the whole K in ascending order
+    assert torch.equal(y1.view(torch.int16), yb[-1])
+    assert torch.equal(yr.view(B, S, N).view(torch.int16), yb.flip(0))
+    assert torch.equal(yc.view(torch.int16), yb[:, -1])
+    if form:
+        # the remainder rows are close to, not bit-equal with, the whole-K order (a different summation order, by design)
+        assert not torch.equal(yb[:, S - rem:], pb[:, S - rem:])
+        assert rel_err(y.view(B, S, N)[:, S - rem:], y_plain.view(B, S, N)[:, S - rem:].float()) <= 2.2 * BF16_1ULP
+    else:
+        assert torch.equal(yb, pb)
+    print(f"[seq remainder] B={B} S={S} N={N} K={K}: per-sequence form {'ON' if form else 'off'}, {B * rem} remainder rows")
+
+
 def test_linear_transpose_detecting():
     """A = identity with an ASYMMETRIC weight: catches swapped row/column in the MFMA C layout."""
     K = N = 128

@@ -68,6 +68,23 @@ def test_gemm_dispatch_at_the_measured_shapes(lib):
     assert lib.sv_debug_gemm_plan(0, 8, 8, 0, out) == -22
 
 
+def test_per_sequence_remainder_form_is_a_function_of_sequence_length_and_projection(lib):
+    """gemm.hip gemm_seq_form: the rows a sequence leaves over its 256-row tiles take the split-K remainder kernel where the cost model
+    peels the remainder of a 32-sequence batch -- decided from (S, N, K, act) alone, so the kernel (and the summation order) a row gets
+    never depends on the batch around it."""
+    f = lib.sv_debug_gemm_seq_form
+    # StarVector-1B prompt rows (259 = 256 + 3): attention output projection and down projection yes; c_attn / c_fc no (not peeled)
+    assert f(259, 2048, 2048, 0) == 1 and f(259, 2048, 8192, 0) == 1
+    assert f(259, 2304, 2048, 0) == 0 and f(259, 8192, 2048, 3) == 0
+    # ViT tokens (257 = 256 + 1): out_proj and the MLP's second projection yes, in_proj no
+    assert f(257, 1024, 1024, 0) == 1 and f(257, 1024, 4096, 0) == 1 and f(257, 3072, 1024, 0) == 0
+    # no full tile, nothing left over, or too many rows left over: never
+    for S in (3, 33, 250, 256, 512, 260, 578, 729):
+        assert f(S, 2048, 2048, 0) == 0, S
+    assert f(515, 2048, 2048, 0) == 1                                        # two tiles + 3 rows
+    assert f(0, 8, 8, 0) == -22
+
+
 def _skinny(lib, rows, N, K, sk, fp8=0):
     out = (C.c_int32 * 2)()
     assert lib.sv_debug_skinny_plan(rows, N, K, sk, fp8, out) == 0
