@@ -340,8 +340,9 @@ def main():
 
     # secondary, MFMA-bound kernels (TTFT path): the four decoder GEMMs of one prefill layer at M = B * S0 rows, live,
     # through the same dispatch the engine uses (128^2 / 256^2 tile kernel + tail kernel)
-    from starvector_amd.engine import bench_linear
+    from starvector_amd.engine import bench_linear, set_linear_seq_rows, gemm_seq_form
     Mp = B_PER_GPU * S0
+    set_linear_seq_rows(S0)          # the prompt pass's own form: rows of S0-row sequences (per-sequence remainder where gemm_seq_form holds)
     D, F = cfg.hidden, cfg.n_inner
     qkv = D + 2 * (D // cfg.n_head) * cfg.n_kv_head
     head_dim = D // cfg.n_head
@@ -353,7 +354,9 @@ def main():
         fl_ = 2.0 * Mp * n_ * k_
         pf_us += us_
         pf_flop += fl_
-        per_gemm[gname] = {"shape": [Mp, n_, k_], "us": round(us_, 1), "tflops": round(fl_ / us_ / 1e6, 1)}
+        per_gemm[gname] = {"shape": [Mp, n_, k_], "us": round(us_, 1), "tflops": round(fl_ / us_ / 1e6, 1),
+                           "per_sequence_remainder": bool(gemm_seq_form(S0, n_, k_, act_))}
+    set_linear_seq_rows(0)
     tf_fc = pf_flop / pf_us / 1e6
 
     if rank == 0:
@@ -405,7 +408,7 @@ def main():
                          "frac_gemm_chain": round(W_BYTES_PER_STEP / (sk_chain_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if sk_chain_ms > 0 else None,
                          "avg_exec_us_event_deltas": round(sk_exec_ms * 1e3 / launches, 2)},
             "roofline_prefill_gemm": {"bound": "mfma",
-                                      "kernel": "gemm_bf16_kernel / gemm256_kernel / gemm_tail_kernel (the 4 decoder GEMMs of a prefill layer)",
+                                      "kernel": "gemm_bf16_kernel / gemm256_kernel + gemm_tail_kernel / gemm_tailk_kernel for the remainder rows (the 4 decoder GEMMs of a prefill layer, dispatched as the prompt pass dispatches them)",
                                       "achieved": round(tf_fc, 1), "peak": 2500.0, "unit": "TFLOP/s",
                                       "frac": round(tf_fc / 2500.0, 4), "us_per_layer": round(pf_us, 1), "gemms": per_gemm},
             # the whole decode step against the same roof: every byte a step must move (decoder weights once + the KV cache of
