@@ -42,7 +42,9 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs p)
     const int b = blockIdx.z;
     const int S = p.S;
     int head, q0, qblock_end;
-    const int qtile = blockIdx.x + p.q_tile0;               // (q_tile0 > 0: only the trailing query tiles, e.g. the last prompt row's)
+    // (q_tile0 > 0: only the trailing query tiles, e.g. the last prompt row's.  Round 6 numbered the causal tiles longest-first -- the last query tile walks 5 key tiles,
+    // the first 1 -- so that the short ones fill the end of the launch: 41.4 vs 40.8 us per layer, nothing; profiles/prefill_small_r06.log.)
+    const int qtile = blockIdx.x + p.q_tile0;
     if (HPB == 1) {
         head = blockIdx.y;
         q0 = qtile * 128 + wave * 32;
@@ -127,6 +129,8 @@ __global__ __launch_bounds__(256, 2) void attn_prefill_kernel(AttnPrefillArgs p)
         lstore();
         __syncthreads();
         if (kt + 1 < ntiles) gload(kt + 1);
+        // a wave whose 32 query rows all lie behind the sequence (S = 257: three of the four waves of every third block) only helps with the K / V tiles
+        if (q0 >= S) continue;
 
         // S^T = K . Q^T : two 32-key sub-tiles
         f32x16 accS[2];
@@ -268,32 +272,42 @@ __device__ __forceinline__ size_t kv_v_offset(int D, int t64, int dv) {
     return (size_t)64 * D * 2 + ((size_t)((g * (D >> 4) + t) * 64 + c * 16 + dl)) * 16 + e * 2;
 }
 
-__global__ void kv_write_prefill_kernel(const bf16_t* __restrict__ qkv, int row_stride, int k_off, int v_off,
-                                        char* __restrict__ pool, const int32_t* __restrict__ table,
-                                        int max_pages, int B, int S0, int D) {
-    const int NC = D >> 3;
-    const size_t total = (size_t)B * S0 * NC * 2;
+// Prompt rows -> pages.  One block per (32-token group, sequence): the K rows are 16-byte pieces of the fragment image as they are; the V rows go
+// through LDS and leave as whole 16-byte fragment pieces (8 tokens of one dv column each) -- the first form stored V element by element, eight 2-byte
+// stores per thread: 8.7 us per layer for 8.5 MB of traffic.  Tokens of the group behind the prompt get V = 0 (a V column is only ever read for keys the
+// attention admits; zero is what the decode attention leaves behind a sequence's position as well).
+__global__ __launch_bounds__(256) void kv_write_prefill_kernel(const bf16_t* __restrict__ qkv, int row_stride, int k_off, int v_off,
+                                                               char* __restrict__ pool, const int32_t* __restrict__ table,
+                                                               int max_pages, int B, int S0, int D) {
+    extern __shared__ __attribute__((aligned(16))) char kvw_smem[];
+    bf16_t* Vs = reinterpret_cast<bf16_t*>(kvw_smem);                 // [32][D + 8]
+    const int VST = D + 8;
+    const int b = blockIdx.y, tok0 = blockIdx.x * 32, NC = D >> 3;
     const int page_bytes = kv_page_bytes(D);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % NC);
-        size_t r = i / NC;
-        const int isv = (int)(r & 1);
-        r >>= 1;
-        const int tok = (int)(r % S0), b = (int)(r / S0);
-        const bf16_t* src = qkv + ((size_t)b * S0 + tok) * row_stride + (isv ? v_off : k_off) + ch * 8;
-        const uint4 v = *reinterpret_cast<const uint4*>(src);
-        char* page = pool + (size_t)table[b * max_pages + (tok >> 6)] * page_bytes;
-        const int t64 = tok & 63;
-        if (!isv) {
-            *reinterpret_cast<uint4*>(page + kv_k_offset(D, t64, ch * 8)) = v;
-        } else {
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                *reinterpret_cast<bf16_t*>(page + kv_v_offset(D, t64, ch * 8 + e)) =
-                    (bf16_t)(w[e >> 1] >> ((e & 1) * 16));
+    char* page = pool + (size_t)table[b * max_pages + (tok0 >> 6)] * page_bytes;
+    for (int i = threadIdx.x; i < 32 * NC; i += 256) {
+        const int r = i / NC, ch = i - r * NC, tok = tok0 + r;
+        uint4 kq = make_uint4(0u, 0u, 0u, 0u), vq = kq;
+        if (tok < S0) {
+            const bf16_t* src = qkv + ((size_t)b * S0 + tok) * row_stride;
+            kq = *reinterpret_cast<const uint4*>(src + k_off + ch * 8);
+            vq = *reinterpret_cast<const uint4*>(src + v_off + ch * 8);
+            *reinterpret_cast<uint4*>(page + kv_k_offset(D, tok & 63, ch * 8)) = kq;
         }
+        *reinterpret_cast<uint4*>(Vs + r * VST + ch * 8) = vq;
+    }
+    __syncthreads();
+    const int g = (tok0 >> 5) & 1;                                    // the page's 32-key group
+    for (int i = threadIdx.x; i < (D >> 4) * 64; i += 256) {
+        const int t = i >> 6, l = i & 63, dl = l & 15, c = l >> 4;
+        uint32_t w[4];
+#pragma unroll
+        for (int e2 = 0; e2 < 4; ++e2) {
+            const int e = 2 * e2;
+            const int ka = 16 * (e >> 2) + 4 * c + (e & 3);           // e and e + 1: consecutive tokens
+            w[e2] = (uint32_t)Vs[ka * VST + 16 * t + dl] | ((uint32_t)Vs[(ka + 1) * VST + 16 * t + dl] << 16);
+        }
+        *reinterpret_cast<uint4*>(page + (size_t)64 * D * 2 + ((size_t)((g * (D >> 4) + t) * 64 + l)) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 }
 // rotary embedding over the prompt rows (Starcoder2: apply_rotary_pos_emb on q and k before the cache / attention)
@@ -325,11 +339,9 @@ void launch_rope_prefill(bf16_t* qkv, int row_stride, int rows, int S0, int n_he
 void launch_kv_write_prefill(const bf16_t* qkv, int row_stride, int k_off, int v_off, char* pool_layer,
                              const int32_t* block_table, int max_pages, int B, int S0, int head_dim,
                              hipStream_t st) {
-    size_t total = (size_t)B * S0 * (head_dim / 8) * 2;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 8192) blocks = 8192;
-    kv_write_prefill_kernel<<<blocks, 256, 0, st>>>(qkv, row_stride, k_off, v_off, pool_layer, block_table,
-                                                     max_pages, B, S0, head_dim);
+    dim3 grid((S0 + 31) / 32, B);
+    kv_write_prefill_kernel<<<grid, 256, (size_t)32 * (head_dim + 8) * 2, st>>>(qkv, row_stride, k_off, v_off, pool_layer, block_table,
+                                                                               max_pages, B, S0, head_dim);
 }
 
 // ------------------------------------------------------------------------------------------------
