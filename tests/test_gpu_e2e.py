@@ -23,6 +23,7 @@ from safetensors.torch import load_file
 
 from oracle import starvector_oracle as O
 from oracle.hostinfo import host_cores
+from starvector_amd import engine as E
 from tests.gpu_util import bf, build_engine, dev, rel_err
 
 pytestmark = pytest.mark.gpu
@@ -145,6 +146,53 @@ def test_generate_is_deterministic_graph_equals_eager_and_batch_invariant():
     assert torch.equal(solo[0], a[2])
     # sync_every only changes when the host looks at the done flag, never the tokens
     assert torch.equal(a, eng.generate(emb, sync_every=3, **kw).cpu())
+    eng.close()
+
+
+def test_prompts_of_259_rows_are_batch_independent_with_the_per_sequence_remainder():
+    """StarVector-1B's dimensions at reduced depth, 224 x 224 images -> 257 vision tokens + 2 prompt ids = 259 prompt rows: the GEMM remainder of every
+    sequence (3 of 259 rows, 1 of 257 tokens) runs through the split-K remainder kernel where gemm_seq_form holds (round 6, gemm.hip).  Which kernel computes
+    a row depends on its position in its SEQUENCE only: a request alone, at another place of the batch and in a batch of another size gives the same vision
+    tokens, the same first-token logits and the same tokens, bit for bit; the pruned last prompt layer equals the full one (SV_EXP bit 32768);
+    and against the batch-level remainder of rounds 2-5 (bit 4194304: another summation order for those rows -- some bf16 roundings downstream flip) the
+    logits stay inside the suite's tolerance."""
+    cfg = dataclasses.replace(O.OracleConfig(), n_layer=3, vit_layers=3, eos_token_id=-1)      # the defaults are StarVector-1B
+    w = O.make_weights(cfg, seed=77)
+    B = 5
+    eng = build_engine(cfg, w, B, 259 + 24)
+    img = bf(O.synthetic_images(B, cfg.image_size, seed=78))
+    prompt = torch.tensor([[7, 11]] * B, device=dev())
+    assert E.gemm_seq_form(259, cfg.hidden, cfg.hidden) and E.gemm_seq_form(257, cfg.vit_width, cfg.vit_width)
+
+    def run(im, pr):
+        enc = eng.encode_image(im)
+        emb = torch.cat([eng.adapter(enc), eng.embed_tokens(pr)], 1)
+        assert emb.shape[1] == 259
+        lg = eng.prefill(emb).float().cpu()
+        toks = eng.generate(emb, max_length=259 + 12, eos_token_id=-1, pad_token_id=cfg.pad_token_id).cpu()
+        return enc.cpu(), lg, toks
+
+    enc_a, lg_a, tok_a = run(img, prompt)
+    enc_s, lg_s, tok_s = run(img[3:4].contiguous(), prompt[3:4].contiguous())                       # alone
+    assert torch.equal(enc_s[0].view(torch.int16), enc_a[3].view(torch.int16))
+    assert torch.equal(lg_s[0], lg_a[3]) and torch.equal(tok_s[0], tok_a[3])
+    perm = torch.tensor([4, 2, 0], device=dev())                                                   # another batch size, another order
+    enc_p, lg_p, tok_p = run(img[perm].contiguous(), prompt[perm].contiguous())
+    for i, j in enumerate(perm.tolist()):
+        assert torch.equal(enc_p[i].view(torch.int16), enc_a[j].view(torch.int16))
+        assert torch.equal(lg_p[i], lg_a[j]) and torch.equal(tok_p[i], tok_a[j])
+    try:
+        eng.set_exp(32768)                                                                          # the last prompt layer on all rows
+        _, lg_full, tok_full = run(img, prompt)
+        assert torch.equal(lg_full, lg_a) and torch.equal(tok_full, tok_a)
+        eng.set_exp(4194304)                                                                        # the batch-level remainder (whole-K order for every row)
+        _, lg_old, _ = run(img, prompt)
+    finally:
+        eng.set_exp(0)
+    d = float((lg_old - lg_a).abs().max() / lg_a.abs().max())
+    print(f"[seq remainder e2e] 1B dims, 3 + 3 layers, B = {B}: solo / permuted / pruned-vs-full bit-identical; per-sequence vs batch-level remainder: "
+          f"first-token logits differ by {d:.2e} of max|logit|")
+    assert d < LOGIT_TOL
     eng.close()
 
 

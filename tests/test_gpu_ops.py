@@ -155,7 +155,7 @@ def test_linear_tile_kernels_and_the_tuned_choice_agree_at_the_prefill_shapes(M,
 
 @pytest.mark.parametrize("B,S,N,K,act,res", [(32, 259, 2048, 2048, "none", True),          # prefill c_proj: 32 tiles + 96 remainder rows
                                              (32, 259, 2048, 8192, "none", True),          # down projection: 16 chunks per wave
-                                             (32, 259, 8192, 2048, "gelu_tanh", False),    # c_fc: NOT the per-sequence form (the cost model does not peel it)
+                                             (32, 259, 8192, 2048, "gelu_tanh", False),    # c_fc: NOT the per-sequence form (the cost model does not peel it): the structure changes nothing
                                              (32, 259, 2304, 2048, "none", False),         # c_attn: not either
                                              (32, 257, 1024, 4096, "none", True),          # ViT MLP c_proj: 1 row per image
                                              (32, 257, 1024, 1024, "none", True),          # ViT out_proj: 2 chunks per wave
