@@ -238,12 +238,13 @@ def main():
     sync_all()
     t0 = time.perf_counter()
     n_tok = 0
-    decode_ms, decode_steps, graph = 0.0, 0.0, True
+    decode_ms, decode_steps, graph, graph_steps = 0.0, 0.0, True, 0
     for _ in range(args.steps):
         _, n = step()
         n_tok += n
         tm = eng.last_timing()
         decode_ms += tm["decode_ms"]; decode_steps += tm["decode_steps"]; graph = graph and tm["graph"]
+        graph_steps = tm.get("graph_steps", 0)
     sync_all()
     dt = time.perf_counter() - t0
     per_rank_tps = None
@@ -382,7 +383,7 @@ def main():
                                             "ranks; not a scaling number)") if shared else f"nccl (RCCL {rccl_version})",
                            "collectives_per_step": 1, "rccl_version": rccl_version,
                            "tokens_per_s_by_rank": per_rank_tps} if world > 1 else {}),
-                       "hipgraph_decode": bool(graph), "exclusive_device": bool(ec.exclusive_device)},
+                       "hipgraph_decode": bool(graph), "decode_steps_per_graph_launch": graph_steps, "exclusive_device": bool(ec.exclusive_device)},
             "tokens_per_s_per_gpu": round(value / world, 1),
             "ttft_p50_ms": round(ttft_p50, 2) if ttft_p50 is not None else None,
             "ttft_breakdown_ms": ttft_stages,

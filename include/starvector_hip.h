@@ -283,7 +283,8 @@ int  sv_beam_history(sv_engine* e, int32_t* host_parent, int32_t* host_tok, int3
                      int32_t* rows);
 
 /* host wall-clock of the last sv_generate, 4 doubles: [0] ms prefill + first token (TTFT),
- * [1] ms decode loop, [2] decode steps enqueued, [3] 1 if the step ran as a hipGraph replay */
+ * [1] ms decode loop, [2] decode steps enqueued, [3] decode steps per hipGraph launch (0: plain launches, 1: one step per replay,
+ * > 1: the step captured that many times into one graph for calls long enough to pay for it -- SV_GRAPH_STEPS, default 32, 1 = off) */
 int  sv_last_timing(sv_engine* e, double* out4);
 
 #ifdef __cplusplus

@@ -313,6 +313,8 @@ extern "C" int sv_destroy(sv_engine* e) {
     for (auto& kv : e->cb_graphs) { if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second); if (kv.second.first) (void)hipGraphDestroy(kv.second.first); }
     if (e->gen_gexec) (void)hipGraphExecDestroy(e->gen_gexec);
     if (e->gen_graph) (void)hipGraphDestroy(e->gen_graph);
+    if (e->gen_gexec_multi) (void)hipGraphExecDestroy(e->gen_gexec_multi);
+    if (e->gen_graph_multi) (void)hipGraphDestroy(e->gen_graph_multi);
     if (e->beam_staging) (void)hipFree(e->beam_staging);
     if (e->score_ws) (void)hipFree(e->score_ws);
     if (e->h_flags) (void)hipHostFree(e->h_flags);

@@ -285,6 +285,11 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
     };
     const bool use_graph = getenv("SV_NO_GRAPH") == nullptr;
     hipGraphExec_t gexec = nullptr;
+    auto drop_multi = [&]() {
+        if (e->gen_gexec_multi) { (void)hipGraphExecDestroy(e->gen_gexec_multi); e->gen_gexec_multi = nullptr; }
+        if (e->gen_graph_multi) { (void)hipGraphDestroy(e->gen_graph_multi); e->gen_graph_multi = nullptr; }
+        e->gen_multi_steps = 0;
+    };
     if (!e->h_flags[0] && use_graph) {
         // One decode step is captured as a hipGraph (all kernel arguments are stable device pointers; the step index,
         // positions and stop state live in device memory) and replayed every step.  The instantiated graph is KEPT on the
@@ -300,6 +305,7 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
         } else {
             if (e->gen_gexec) { (void)hipGraphExecDestroy(e->gen_gexec); e->gen_gexec = nullptr; }
             if (e->gen_graph) { (void)hipGraphDestroy(e->gen_graph); e->gen_graph = nullptr; }
+            drop_multi();
             e->gen_graph_key.clear();
             hipError_t ce = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
             if (ce == hipSuccess) {
@@ -329,24 +335,66 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
             }
         }
     }
+    // Several steps per graph launch.  Inside a replayed graph a kernel follows its predecessor with no measurable gap; from one hipGraphLaunch to
+    // the next the GPU idles 8.6 us (rocprofv3 kernel trace of the bench: finish_step_kernel of step i -> the first kernel of step i + 1,
+    // profiles/step_gaps_r06.log) -- 0.9 % of StarVector-1B's step.  So the SAME step is captured U times into a second graph (every kernel argument
+    // is a stable device pointer and the step index lives on the device: U copies of the node list ARE U consecutive steps) and a chunk of the loop
+    // below launches it while at least U steps of the chunk are left, the one-step graph for the rest.  U = the polling chunk (sync_every, at most
+    // SV_GRAPH_STEPS = 32 by default; 1 = off): nothing runs that did not run before -- the loop already issues a whole chunk before it looks at the
+    // done flag.  Built only for calls with at least 4 U steps in front of them (instantiating 32 x 99 nodes costs milliseconds), kept on the
+    // engine with the one-step graph (same key).
+    hipGraphExec_t gexec_multi = nullptr;
+    int U = 0;
+    if (gexec) {
+        static const int cap = getenv("SV_GRAPH_STEPS") ? atoi(getenv("SV_GRAPH_STEPS")) : 32;
+        U = chunk < cap ? chunk : cap;
+        if (U >= 2 && max_new - 1 >= 4 * U) {
+            if (e->gen_gexec_multi && e->gen_multi_steps == U) {
+                gexec_multi = e->gen_gexec_multi;
+            } else {
+                drop_multi();
+                hipError_t ce = hipStreamBeginCapture(st, hipStreamCaptureModeRelaxed);
+                if (ce == hipSuccess) {
+                    for (int u = 0; u < U; ++u) {
+                        decode_forward(e, B, st);
+                        sample_and_finish(e, B, *sp, max_new, st, fused_sel);
+                    }
+                    ce = hipStreamEndCapture(st, &e->gen_graph_multi);
+                    if (ce == hipSuccess && e->gen_graph_multi) ce = hipGraphInstantiate(&e->gen_gexec_multi, e->gen_graph_multi, nullptr, nullptr, 0);
+                }
+                if (ce != hipSuccess || !e->gen_gexec_multi) { (void)hipGetLastError(); drop_multi(); }      // the one-step graph carries the call
+                else { e->gen_multi_steps = U; gexec_multi = e->gen_gexec_multi; }
+            }
+        }
+    }
+    // The host looks at the device's done flag after every chunk -- a round trip that leaves the GPU idle for ~0.1 ms -- only when something can
+    // END the call before its budget (an EOS id inside the vocabulary, a stop sequence) or wants the columns as they become final (streaming).
+    // A fixed-length call (the benchmark's EOS-disabled workload, fixed-length rollouts) has nothing to poll for.
+    const bool poll = (sp->eos_token_id >= 0 && sp->eos_token_id < e->cfg.vocab) || sp->n_stop > 0 || sp->on_tokens != nullptr;
     while (!e->h_flags[0]) {
         int n = max_new - 1 - steps;
         if (n <= 0) break;                       // budget exhausted: the device flag is already set
         if (n > chunk) n = chunk;
-        for (int i = 0; i < n; ++i) {
-            if (gexec) {
+        for (int i = 0; i < n;) {
+            if (gexec_multi && n - i >= U) {
+                HIPCHECK(hipGraphLaunch(gexec_multi, st));
+                i += U;
+            } else if (gexec) {
                 HIPCHECK(hipGraphLaunch(gexec, st));
+                ++i;
             } else {
                 decode_forward(e, B, st);
                 sample_and_finish(e, B, *sp, max_new, st, fused_sel);
+                ++i;
             }
         }
         steps += n;
+        if (!poll) continue;                     // nothing can end this call before its budget: the next chunk follows without a host round trip
         HIPCHECK(hipMemcpyAsync(&e->h_flags[0], e->d_done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIPCHECK(hipStreamSynchronize(st));
         if (!e->h_flags[0]) SVCHECK(stream_upto(steps + 1));      // still running: every column so far is final
     }
-    const double gexec_used = gexec ? 1.0 : 0.0;
+    const double gexec_used = gexec_multi ? (double)U : gexec ? 1.0 : 0.0;       // steps per graph launch
     HIPCHECK(hipMemcpyAsync(&e->h_flags[1], e->d_nemit, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
     if (e->h_flags[1] >= 1 && e->h_flags[1] <= max_new) SVCHECK(stream_upto(e->h_flags[1]));

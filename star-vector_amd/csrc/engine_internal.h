@@ -178,6 +178,11 @@ struct sv_engine {
     std::string gen_graph_key;
     hipGraph_t gen_graph = nullptr;
     hipGraphExec_t gen_gexec = nullptr;
+    // the same step SV_GRAPH_STEPS times in ONE graph (engine_generate.hip: a hipGraphLaunch-to-hipGraphLaunch boundary costs 8.6 us of idle GPU per step,
+    // a kernel-to-kernel boundary inside a graph nothing measurable -- profiles/step_gaps_r06.log); built for calls long enough to pay for its instantiation
+    hipGraph_t gen_graph_multi = nullptr;
+    hipGraphExec_t gen_gexec_multi = nullptr;
+    int gen_multi_steps = 0;
     // optional per-kernel HIP-event profiling of the decode step (bench.py roofline leg)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;

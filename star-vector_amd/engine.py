@@ -335,7 +335,7 @@ class HipEngine:
     def last_timing(self) -> Dict[str, float]:
         buf = (C.c_double * 4)()
         check(self.lib.sv_last_timing(self._h, buf), "sv_last_timing")
-        return {"ttft_ms": buf[0], "decode_ms": buf[1], "decode_steps": buf[2], "graph": bool(buf[3])}
+        return {"ttft_ms": buf[0], "decode_ms": buf[1], "decode_steps": buf[2], "graph": bool(buf[3]), "graph_steps": int(buf[3])}
 
     def step_plan(self) -> Dict[str, int]:
         """What the last generate() call's decode step actually was (sv_debug_step_plan): kernel nodes of its captured graph and which

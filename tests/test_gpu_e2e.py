@@ -134,6 +134,7 @@ def test_generate_is_deterministic_graph_equals_eager_and_batch_invariant():
     os.environ.pop("SV_NO_GRAPH", None)
     a = eng.generate(emb, **kw).cpu()
     assert eng.last_timing()["graph"], "decode step did not run as a hipGraph replay"
+    assert eng.last_timing()["graph_steps"] == 1                   # 39 steps < 4 polling chunks of 32: one step per launch
     b = eng.generate(emb, **kw).cpu()
     os.environ["SV_NO_GRAPH"] = "1"
     try:
@@ -146,6 +147,22 @@ def test_generate_is_deterministic_graph_equals_eager_and_batch_invariant():
     assert torch.equal(solo[0], a[2])
     # sync_every only changes when the host looks at the done flag, never the tokens
     assert torch.equal(a, eng.generate(emb, sync_every=3, **kw).cpu())
+    # several steps per graph launch (round 6: a call with >= 4 polling chunks in front of it replays the step `sync_every` times per
+    # hipGraphLaunch): 39 steps at sync_every 8 = 4 launches of the 8-step graph + 7 of the one-step graph -- the same tokens; greedy,
+    # sampled, and with an EOS that ends rows in the middle of a chunk
+    assert eng.last_timing()["graph_steps"] == 3                   # (the sync_every = 3 call above already ran 13 launches of a 3-step graph)
+    m8 = eng.generate(emb, sync_every=8, **kw).cpu()
+    assert eng.last_timing()["graph_steps"] == 8 and torch.equal(a, m8)
+    assert torch.equal(a, eng.generate(emb, sync_every=8, **kw).cpu())          # the kept 8-step graph, replayed by the next call
+    skw = dict(do_sample=True, temperature=1.0, top_p=0.9, top_k=20, seed=5)
+    s1 = eng.generate(emb, sync_every=1, **skw, **kw).cpu()
+    assert eng.last_timing()["graph_steps"] == 1
+    s8 = eng.generate(emb, sync_every=8, **skw, **kw).cpu()
+    assert eng.last_timing()["graph_steps"] == 8 and torch.equal(s1, s8)
+    eos = int(a[1, 13])
+    e1 = eng.generate(emb, sync_every=1, max_length=S0 + 40, eos_token_id=eos, pad_token_id=cfg.pad_token_id).cpu()
+    e8 = eng.generate(emb, sync_every=8, max_length=S0 + 40, eos_token_id=eos, pad_token_id=cfg.pad_token_id).cpu()
+    assert torch.equal(e1, e8)
     eng.close()
 
 
