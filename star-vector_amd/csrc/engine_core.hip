@@ -88,7 +88,19 @@ __global__ void reduce_partials_kernel(const float* ws, int splitk, int rows_ws,
         y[(size_t)m * N + n] = v;
     }
 }
+// the generation state of a call in ONE launch (it was two fills and four memsets, 5 us each on the way to the first token): positions = pos0,
+// unfinished = 1, {step, done, n_emitted} = 0, the folded arg-max key slots = 0 (n_amax = 0: not this call's selection)
+__global__ void gen_state_init_kernel(int32_t* positions, int32_t pos0, int32_t* unfinished, int B, int32_t* state3, unsigned long long* amax, int n_amax) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) { positions[i] = pos0; unfinished[i] = 1; }
+    if (i < 3) state3[i] = 0;
+    if (i < n_amax) amax[i] = 0ull;
+}
 namespace sveng {
+void gen_state_init(int32_t* positions, int32_t pos0, int32_t* unfinished, int B, int32_t* state3, unsigned long long* amax, int n_amax, hipStream_t st) {
+    const int n = B > n_amax ? (B > 3 ? B : 3) : (n_amax > 3 ? n_amax : 3);
+    gen_state_init_kernel<<<(n + 255) / 256, 256, 0, st>>>(positions, pos0, unfinished, B, state3, amax, n_amax);
+}
 void fill_i32(int32_t* p, int32_t v, int n, hipStream_t st) { fill_i32_kernel<<<(n + 63) / 64, 64, 0, st>>>(p, v, n); }
 void add_i32(int32_t* p, int32_t v, int n, hipStream_t st) { add_i32_kernel<<<(n + 63) / 64, 64, 0, st>>>(p, v, n); }
 void suppress_token(float* logits, int ld, int token, const int32_t* step, int min_new, int B, hipStream_t st) {
@@ -318,6 +330,8 @@ extern "C" int sv_destroy(sv_engine* e) {
     if (e->beam_staging) (void)hipFree(e->beam_staging);
     if (e->score_ws) (void)hipFree(e->score_ws);
     if (e->h_flags) (void)hipHostFree(e->h_flags);
+    if (e->h_table) (void)hipHostFree(e->h_table);
+    if (e->table_ev) (void)hipEventDestroy(e->table_ev);
     for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
     if (e->gen_event) (void)hipEventDestroy(e->gen_event);
     if (e->gen_stream) (void)hipStreamDestroy(e->gen_stream);
@@ -500,10 +514,11 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     A(dalloc(e, &e->positions, R));
     e->out_ld = c.max_seq_len;
     A(dalloc(e, &e->out_tok, (size_t)c.max_batch * e->out_ld));
+    // one 16-byte block {step, done, n_emitted, bad}: the host reads the four in ONE copy (engine_generate.hip)
     A(dalloc(e, &e->d_step, 4));
-    A(dalloc(e, &e->d_done, 4));
-    A(dalloc(e, &e->d_nemit, 4));
-    A(dalloc(e, &e->d_bad, 4));       // raised by the selection kernels when a row has no finite logit
+    e->d_done = e->d_step + 1;
+    e->d_nemit = e->d_step + 2;
+    e->d_bad = e->d_step + 3;         // raised by the selection kernels when a row has no finite logit
     A(dalloc(e, &e->d_stop, 64));
 
     e->page_bytes = kv_page_bytes(dh);
@@ -525,6 +540,12 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     if (!rc) {
         hipError_t hr = hipHostMalloc(reinterpret_cast<void**>(&e->h_flags), 64, hipHostMallocDefault);
         if (hr != hipSuccess) rc = fail(SV_ENOMEM, "hipHostMalloc: %s", hipGetErrorString(hr));
+    }
+    if (!rc) {
+        // the block table's host image, pinned: assign_pages uploads it without a stream synchronise (an event guards its reuse)
+        hipError_t hr = hipHostMalloc(reinterpret_cast<void**>(&e->h_table), (size_t)c.max_batch * e->pages_per_seq * sizeof(int32_t), hipHostMallocDefault);
+        if (hr == hipSuccess) hr = hipEventCreateWithFlags(&e->table_ev, hipEventDisableTiming);
+        if (hr != hipSuccess) rc = fail(SV_ENOMEM, "hipHostMalloc / hipEventCreate (block table image): %s", hipGetErrorString(hr));
     }
     if (!rc) {
         hipError_t hr = hipStreamCreateWithFlags(&e->gen_stream, hipStreamNonBlocking);

@@ -134,14 +134,21 @@ int sveng::assign_pages(sv_engine* e, int B, int total_len, hipStream_t st) {
     if (need > e->pages_per_seq) return fail(SV_EINVAL, "sequence length %d exceeds max_seq_len %d", total_len, e->cfg.max_seq_len);
     e->free_pages.clear();
     for (int p = e->num_pages - 1; p >= 0; --p) e->free_pages.push_back(p);
-    std::vector<int32_t> table((size_t)e->cfg.max_batch * e->pages_per_seq, 0);
+    // The table goes up from a PINNED host image without a stream synchronise (the pageable copy + hipStreamSynchronize of rounds 1-5 drained the
+    // stream in front of every prompt pass: ~25 us of idle GPU on the way to the first token); the image is rewritten only after the upload
+    // before it has completed (an event, normally long past).
+    if (e->table_pending) { HIPCHECK(hipEventSynchronize(e->table_ev)); e->table_pending = false; }
+    const size_t n = (size_t)e->cfg.max_batch * e->pages_per_seq;
+    int32_t* table = e->h_table;
+    memset(table, 0, n * sizeof(int32_t));
     for (int b = 0; b < B; ++b)
         for (int i = 0; i < need; ++i) {
             table[(size_t)b * e->pages_per_seq + i] = e->free_pages.back();
             e->free_pages.pop_back();
         }
-    HIPCHECK(hipMemcpyAsync(e->block_table, table.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIPCHECK(hipStreamSynchronize(st));
+    HIPCHECK(hipMemcpyAsync(e->block_table, table, n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHECK(hipEventRecord(e->table_ev, st));
+    e->table_pending = true;
     return 0;
 }
 
@@ -522,13 +529,13 @@ int sveng::cb_guard(sv_engine* e, const char* who) {
     return 0;
 }
 
-int sveng::prefill_locked(sv_engine* e, const void* dev_embeds, int B, int S0, int total_len, hipStream_t st) {
+int sveng::prefill_locked(sv_engine* e, const void* dev_embeds, int B, int S0, int total_len, hipStream_t st, bool set_positions) {
     SVCHECK(cb_guard(e, "prefill"));
     if (!dev_embeds || B < 1 || B > e->cfg.max_batch) return fail(SV_EINVAL, "prefill: bad B=%d (max_batch %d)", B, e->cfg.max_batch);
     if (S0 < 1 || S0 > e->cfg.max_seq_len) return fail(SV_EINVAL, "prefill: S0=%d out of range (max_seq_len %d)", S0, e->cfg.max_seq_len);
     SVCHECK(assign_pages(e, B, total_len, st));
     SVCHECK(prefill_forward(e, (const bf16_t*)dev_embeds, B, S0, st));
-    fill_i32(e->positions, S0, B, st);
+    if (set_positions) fill_i32(e->positions, S0, B, st);          // (sv_generate sets its own generation state in one launch)
     e->cached_B = B;
     HIPCHECK(hipGetLastError());
     return 0;

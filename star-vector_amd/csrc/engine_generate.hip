@@ -182,8 +182,10 @@ static int generate_beam(sv_engine* e, const void* dev_embeds, int B, int S0, co
 int sveng::check_finite_logits(sv_engine* e, hipStream_t st, const char* who) {
     HIPCHECK(hipMemcpyAsync(&e->h_flags[4], e->d_bad, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
-    if (!e->h_flags[4]) return 0;
-    const int what = e->h_flags[4];
+    return report_bad_logits(e, st, who, e->h_flags[4]);
+}
+int sveng::report_bad_logits(sv_engine* e, hipStream_t st, const char* who, int what) {
+    if (!what) return 0;
     HIPCHECK(hipMemsetAsync(e->d_bad, 0, sizeof(int32_t), st));
     // (The failed steps may have appended non-finite K / V rows to their pages.  Nothing is scrubbed here: the decode attention clears the stale
     //  V columns of a sequence's current key group itself -- attention.hip, process() -- so a page's next owner never multiplies them.)
@@ -234,20 +236,7 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
 
     auto t0 = std::chrono::steady_clock::now();
     HIPCHECK(hipMemsetAsync(e->d_bad, 0, sizeof(int32_t), st));         // a flag left by an earlier, failed call is not this call's
-    SVCHECK(prefill_locked(e, dev_embeds, B, S0, S0 + max_new, st));
-    // generation state
-    fill_i32(e->positions, S0 - 1, B, st);     // finish_step adds 1
-    fill_i32(e->unfinished, 1, B, st);
-    HIPCHECK(hipMemsetAsync(e->d_step, 0, sizeof(int32_t), st));
-    HIPCHECK(hipMemsetAsync(e->d_done, 0, sizeof(int32_t), st));
-    HIPCHECK(hipMemsetAsync(e->d_nemit, 0, sizeof(int32_t), st));
-    if (sp->repetition_penalty > 0.f && sp->repetition_penalty != 1.0f)
-        HIPCHECK(hipMemsetAsync(e->seen, 0, (size_t)((B + 31) / 32) * 32 * e->seen_words * sizeof(uint32_t), st));
-    if (sp->n_stop > 0) {
-        if (!sp->stop_ids) return fail(SV_EINVAL, "n_stop > 0 but stop_ids is null");
-        HIPCHECK(hipMemcpyAsync(e->d_stop, sp->stop_ids, sp->n_stop * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    }
-    sample_and_finish(e, B, *sp, max_new, st);       // first token from the prefill logits
+    SVCHECK(prefill_locked(e, dev_embeds, B, S0, S0 + max_new, st, false));
     // Plain greedy decode (no repetition penalty, no min_length hold, one row tile, bf16 lm_head with the K split over the waves of a
     // block): the selection rides in the lm_head epilogue of every decode step -- one launch less per step, same tokens bit for bit.
     // SV_EXP bit 1024 = the separate argmax launch (A/B).
@@ -258,13 +247,22 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
         const bool pen = sp->repetition_penalty > 0.f && sp->repetition_penalty != 1.0f;
         fused_sel = !sp->do_sample && !pen && sp->min_new_tokens <= 0 && B <= 32 && !e->lm_head.fp8 && waves > 1 && !two && !(e->exp & 1024);
     }
-    struct FusedSel { sv_engine* e; ~FusedSel() { e->greedy_fused = false; } } fused_guard{e};
-    if (fused_sel) {
-        HIPCHECK(hipMemsetAsync(e->amax, 0, (size_t)64 * SV_AMAX_STRIDE * sizeof(unsigned long long), st));
-        e->greedy_fused = true;                      // read by decode_forward (capture and eager launches below); cleared on every exit
+    // generation state, one launch: positions = S0 - 1 (finish_step adds 1), unfinished = 1, {step, done, n_emitted} = 0, the folded selection's key slots = 0
+    gen_state_init(e->positions, S0 - 1, e->unfinished, B, e->d_step, e->amax, fused_sel ? 64 * SV_AMAX_STRIDE : 0, st);
+    if (sp->repetition_penalty > 0.f && sp->repetition_penalty != 1.0f)
+        HIPCHECK(hipMemsetAsync(e->seen, 0, (size_t)((B + 31) / 32) * 32 * e->seen_words * sizeof(uint32_t), st));
+    if (sp->n_stop > 0) {
+        if (!sp->stop_ids) return fail(SV_EINVAL, "n_stop > 0 but stop_ids is null");
+        HIPCHECK(hipMemcpyAsync(e->d_stop, sp->stop_ids, sp->n_stop * sizeof(int32_t), hipMemcpyHostToDevice, st));
     }
-    HIPCHECK(hipMemcpyAsync(&e->h_flags[0], e->d_done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    sample_and_finish(e, B, *sp, max_new, st);       // first token from the prefill logits
+    struct FusedSel { sv_engine* e; ~FusedSel() { e->greedy_fused = false; } } fused_guard{e};
+    if (fused_sel) e->greedy_fused = true;           // read by decode_forward (capture and eager launches below); cleared on every exit
+    // ONE copy of the device's {step, done, n_emitted, bad} block: a call that is over after its first token (budget 1, EOS) has everything
+    // it needs from this round trip and takes no other before the tokens go out
+    HIPCHECK(hipMemcpyAsync(&e->h_flags[8], e->d_step, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHECK(hipStreamSynchronize(st));
+    e->h_flags[0] = e->h_flags[9];
     auto t1 = std::chrono::steady_clock::now();
 
     int steps = 0;
@@ -395,10 +393,13 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
         if (!e->h_flags[0]) SVCHECK(stream_upto(steps + 1));      // still running: every column so far is final
     }
     const double gexec_used = gexec_multi ? (double)U : gexec ? 1.0 : 0.0;       // steps per graph launch
-    HIPCHECK(hipMemcpyAsync(&e->h_flags[1], e->d_nemit, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    HIPCHECK(hipStreamSynchronize(st));
+    if (steps > 0) {                             // (a call that ended at its first token has the block already)
+        HIPCHECK(hipMemcpyAsync(&e->h_flags[8], e->d_step, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipStreamSynchronize(st));
+    }
+    e->h_flags[1] = e->h_flags[10];
     if (e->h_flags[1] >= 1 && e->h_flags[1] <= max_new) SVCHECK(stream_upto(e->h_flags[1]));
-    SVCHECK(check_finite_logits(e, st, "sv_generate"));
+    SVCHECK(report_bad_logits(e, st, "sv_generate", e->h_flags[11]));
     const int n_emit = e->h_flags[1];
     if (n_emit < 1 || n_emit > max_new) return fail(SV_EHIP, "generation bookkeeping failed (n_emitted=%d)", n_emit);
     tokens_to_i64(e->out_tok, e->out_ld, dev_out_tokens, B, n_emit, max_new, st);

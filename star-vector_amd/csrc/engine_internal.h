@@ -144,7 +144,10 @@ struct sv_engine {
     int32_t *cur_tok = nullptr, *next_tok = nullptr, *unfinished = nullptr, *positions = nullptr,
             *out_tok = nullptr, *d_step = nullptr, *d_done = nullptr, *d_nemit = nullptr, *d_stop = nullptr, *d_bad = nullptr;
     int out_ld = 0;
-    int32_t* h_flags = nullptr;   // pinned: [0]=done [1]=n_emitted
+    int32_t* h_flags = nullptr;   // pinned: [0]=done [1]=n_emitted [4]=bad; [8..11] = a snapshot of the device block {step, done, n_emitted, bad}
+    int32_t* h_table = nullptr;   // pinned host image of block_table (assign_pages); table_ev = its last upload
+    hipEvent_t table_ev = nullptr;
+    bool table_pending = false;
     // KV pool
     char* kv_pool = nullptr;
     size_t layer_stride = 0;
@@ -198,6 +201,7 @@ enum { PK_SKINNY = 0, PK_ATTN = 1, PK_ROWLN = 2, PK_SAMPLE = 3, PK_COUNT = 4,
 namespace sveng {
 // engine_core.hip: small utility kernels behind host wrappers, allocation, decode planning
 void fill_i32(int32_t* p, int32_t v, int n, hipStream_t st);
+void gen_state_init(int32_t* positions, int32_t pos0, int32_t* unfinished, int B, int32_t* state3, unsigned long long* amax, int n_amax, hipStream_t st);
 void add_i32(int32_t* p, int32_t v, int n, hipStream_t st);
 void suppress_token(float* logits, int ld, int token, const int32_t* step, int min_new, int B, hipStream_t st);
 void tokens_to_i64(const int32_t* src, int ld, int64_t* dst, int B, int ncols, int dst_ld, hipStream_t st);
@@ -222,8 +226,9 @@ void decode_forward(sv_engine* e, int B, hipStream_t st);
 void attn_decode_args(sv_engine* e, int layer, int B, const float* ws, int splitk, const bf16_t* bias, bf16_t* out_xp, AttnDecodeArgs& ad);
 int check_ready(sv_engine* e);
 int cb_guard(sv_engine* e, const char* who);
-int prefill_locked(sv_engine* e, const void* dev_embeds, int B, int S0, int total_len, hipStream_t st);
+int prefill_locked(sv_engine* e, const void* dev_embeds, int B, int S0, int total_len, hipStream_t st, bool set_positions = true);
 // engine_generate.hip
 int check_finite_logits(sv_engine* e, hipStream_t st, const char* who);
+int report_bad_logits(sv_engine* e, hipStream_t st, const char* who, int what);      // what = the d_bad code already read (0: fine)
 }  // namespace sveng
 using namespace sveng;
