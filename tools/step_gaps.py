@@ -28,3 +28,6 @@ if not across:
 print(f"{len(across)} decode steps: step wall (finish -> finish) median {statistics.median(step_wall):.1f} us, kernel durations {statistics.median(step_busy):.1f} us")
 print(f"gap across the step boundary: median {statistics.median(across):.2f} us, mean {statistics.mean(across):.2f}, p90 {sorted(across)[int(0.9 * len(across))]:.2f}")
 print(f"sum of the gaps inside a step: median {statistics.median(inside):.2f} us")
+import collections
+hist = collections.Counter(round(x) for x in across)
+print("gap across the boundary, rounded to us -> steps:", sorted(hist.items()))
