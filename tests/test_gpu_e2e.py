@@ -163,6 +163,11 @@ def test_generate_is_deterministic_graph_equals_eager_and_batch_invariant():
     e1 = eng.generate(emb, sync_every=1, max_length=S0 + 40, eos_token_id=eos, pad_token_id=cfg.pad_token_id).cpu()
     e8 = eng.generate(emb, sync_every=8, max_length=S0 + 40, eos_token_id=eos, pad_token_id=cfg.pad_token_id).cpu()
     assert torch.equal(e1, e8)
+    # the reference's row-0 stop sequence (starvector_base.py:9-20) firing inside a chunk of the 8-step graph: the call ends at the same column
+    stop = [int(a[0, 17]), int(a[0, 18])]
+    t1 = eng.generate(emb, sync_every=1, stop_ids=stop, **kw).cpu()
+    t8 = eng.generate(emb, sync_every=8, stop_ids=stop, **kw).cpu()
+    assert torch.equal(t1, t8) and t1.shape[1] <= 19
     eng.close()
 
 
