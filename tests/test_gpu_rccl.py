@@ -42,6 +42,23 @@ def test_bench_two_ranks_over_rccl():
     assert (max(by_rank) - min(by_rank)) / max(by_rank) < 0.05, f"per-rank throughput spread above 5 %: {by_rank}"
 
 
+def test_rccl_itself_runs_on_this_box_world_of_one():
+    """What a 1-GPU box CAN execute of the multi-GPU path: backend "nccl" (RCCL) initialised as bench.py initialises it, the probe all_reduce and the
+    sharded path's one collective (all_gather_into_tensor of the token block) on device tensors -- with a world of one (tests/_rccl_world1.py).  No peer,
+    so nothing crosses xGMI; but the library, the communicator, the IPC environment and stream-ordered device collectives have then run on real hardware
+    before the driver's 8-GPU bench does."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "_rccl_world1.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, f"RCCL world-of-one run failed (rc {r.returncode}):\n{r.stderr[-3000:]}"
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    print(f"[rccl world 1] {res}")
+    assert res["world"] == 1 and res["backend"] == "nccl" and res["all_reduce"] == 1.0 and res["all_gather_equal"]
+
+
 def test_bench_bare_invocation_launches_itself_two_ranks_share_the_gpu():
     """`python bench.py --gpus 2` with NO launcher in the environment (what a driver without torchrun would type) must become the
     torch.distributed.run job itself.  On this 1-GPU box the two ranks share the device and rendezvous over gloo: the sharded path, the
