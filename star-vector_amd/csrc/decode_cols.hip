@@ -144,6 +144,16 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_cols_resid_kernel(const bf16_
             for (unsigned off = lo + tid * 16; off < hi; off += WAVES * 64 * 16)
                 *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(pl.poison) + off) = ff;
         }
+        // ColsArgs::poison2: the polled LayerNorm-output buffer of the NEXT layer's fused row-update + c_attn launch -- touched with write-through (sc1)
+        // stores only, like the attention launch's and the lm_head launch's pattern stores (rowops.hip, rowln_cattn_kernel): no XCD's L2 may keep a line
+        // of it that memory does not have
+        if (pl.poison2) {
+            const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(pl.poison2, 0, pl.poison2_bytes, 0x00020000);
+            const unsigned share = ((pl.poison2_bytes / 16 + gridDim.x - 1) / gridDim.x) * 16;
+            const unsigned lo = j * share, hi = min(lo + share, pl.poison2_bytes);
+            for (unsigned off = lo + tid * 16; off < hi; off += WAVES * 64 * 16)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, rsp, (int)off, 0, 16);      // sc1
+        }
     }
     // ---- K reduction across the waves (wave order), then one thread per output element / 8-column piece ----
     {

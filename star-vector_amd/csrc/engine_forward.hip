@@ -319,8 +319,11 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
     const bool mlp_pattern = fold6 && e->mlp_fused_ok;          // the attention launch may also have to arm the fused MLP launch's buffer
     // (xpa_armed: the launch that arms layer 0's buffer really ran in front of this step -- not after sv_create, sv_debug_set_exp or
     //  sv_debug_kv_load, whose first step takes the two launches and arms the next one)
-    const bool rc = rc_enabled(e) && e->xpa_armed && MT == 1 && !e->only_skinny && !e->skip_skinny && !e->prof_on &&
-                    (size_t)(D / 16) * 1024 + (mlp_pattern ? (size_t)(F / 16) * 1024 : 0u) <= attn_threads_bytes;
+    // (round 6, third session: a batch below 10 rows has an attention grid too small for the patterns -- B * 8 splits * 512 threads * 16 bytes -- and ran
+    //  the two launches, 123 launches per step instead of 99: slower at batch 1 than at batch 16.  On the 6-launch layer the attention output projection,
+    //  256 blocks of 1024 threads whatever the batch, arms the buffers instead: ColsArgs::poison / ::poison2)
+    const bool attn_room = (size_t)(D / 16) * 1024 + (mlp_pattern ? (size_t)(F / 16) * 1024 : 0u) <= attn_threads_bytes;
+    const bool rc = rc_enabled(e) && e->xpa_armed && MT == 1 && !e->only_skinny && !e->skip_skinny && !e->prof_on && (attn_room || fold6);
     const unsigned xpa_bytes = (unsigned)((size_t)(D / 16) * 1024);
     e->step_rc = false; e->step_mlp = false; e->step_sel = e->greedy_fused;
     bf16_t* const xp_ln = (rc_enabled(e) && !rc) ? e->xp_f : e->xp_a;      // LayerNorm(ln_1) output = the c_attn operand
@@ -387,6 +390,7 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
         const size_t poison_cap = (size_t)B * e->nkv * attn_max_splits(e) * 512 * 16;      // 16 bytes per thread of the attention launch
         const bool attn_poisons = fused && !e->only_skinny && pat_bytes + (rc ? xpa_bytes : 0u) <= poison_cap;
         const bool attn_poisons_xpa = rc && i + 1 < c.n_layer && (fused ? attn_poisons : xpa_bytes <= poison_cap);
+        const bool cols_poisons_xpa = rc && fold6 && i + 1 < c.n_layer && !attn_poisons_xpa;      // (rc without room in the attention grid implies fold6: see above)
         if (!e->only_skinny) {
             AttnDecodeArgs ad;
             attn_decode_args(e, i, B, wsA, L.c_attn.splitk, L.c_attn.bias, e->xp_attn, ad);
@@ -404,6 +408,7 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
             ca.xp = e->xp_attn; ca.Wp = L.c_proj.Wp; ca.bias = L.c_proj.bias; ca.MT = MT; ca.N = L.c_proj.N; ca.K = L.c_proj.Kpad;
             ca.cpb = L.c_proj.cpb; ca.h_xp = e->h_xp; ca.out_KS = D / 16;
             if (fused && !attn_poisons) { ca.poison = e->xp_mlp; ca.poison_bytes = (unsigned)pat_bytes; }
+            if (cols_poisons_xpa) { ca.poison2 = e->xp_a; ca.poison2_bytes = xpa_bytes; }
             if (!e->skip_skinny) { prof_mark(e, PK_SKINNY, st); launch_gemm_cols(ca, st); }
             if (fused) {
                 MlpFusedArgs ma;

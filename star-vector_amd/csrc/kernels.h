@@ -137,6 +137,8 @@ struct ColsArgs {
     bf16_t* h_xp; int out_KS;        // residual stream in fragment order, N = 16 * out_KS columns: h = bf(h + bf(x W^T + b)), in place
     void* poison; unsigned poison_bytes; // optional: a buffer the blocks fill with 0xFF bytes (the fused MLP launch behind this one
                                      // recognises unwritten activations by that pattern); a multiple of 16 bytes
+    void* poison2; unsigned poison2_bytes;   // optional: the NEXT layer's LayerNorm output buffer (the polled buffer of rowln_cattn_kernel), armed here with
+                                     // write-through stores when the attention launch's grid is too small to carry the pattern (batches below 10 rows)
 };
 int cols_pick_cpb(int N, int K);
 int launch_gemm_cols(const ColsArgs& a, hipStream_t st);        // 0 = ok, -1 = unsupported shape

@@ -1113,6 +1113,8 @@ def test_row_update_and_c_attn_as_one_launch_bit_for_bit():
         assert eng.last_timing()["graph"]
         small = eng.generate(emb[:13].contiguous(), **kw)
         one = eng.generate(emb[5:6].contiguous(), **kw)
+        if mask & 16384:       # (round 6: below 10 rows the attention grid has no room for the pattern; the output projection's launch arms the buffer instead)
+            assert eng.step_plan()["rowln_cattn_fused"], "a 1-row call fell back to the two launches"
         samp = eng.generate(emb, do_sample=True, temperature=1.0, top_p=0.9, top_k=50, seed=3, **kw)
         again = eng.generate(emb, **kw)
         runs[mask] = (torch.stack(lg).cpu(), toks.cpu(), small.cpu(), one.cpu(), samp.cpu(), again.cpu())

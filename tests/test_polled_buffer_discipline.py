@@ -40,6 +40,7 @@ def test_host_hands_the_polled_buffer_only_to_sanctioned_arguments():
     sanctioned = [
         r"a\.poison = e->xp_a",                       # lm_head launch: arms the buffer for the next step's layer 0 (write-through stores)
         r"ad\.poison2 = e->xp_a",                     # attention launch of layer i: arms it for layer i + 1 (write-through stores)
+        r"ca\.poison2 = e->xp_a",                     # ... or, where the attention grid is too small (batches below 10 rows), the output projection's launch
         r"a\.xp = e->xp_a",                           # the fused launch's GEMM role polls it (sc1 loads); its row role writes ru.xp_out = the same buffer
         r"\? e->xp_f : e->xp_a",                      # every other producer / consumer takes xp_f on an engine with the fused launch
         r"xp != e->xp_a",
@@ -86,6 +87,13 @@ def test_attention_launch_arms_the_buffer_with_write_through_stores():
     _only_through_resource(body, "poison2", "attn_decode_kernel")
     store = _body(body, r"auto poison2_store = ")
     _aux16_everywhere(store, "attn_decode_kernel poison2_store", 1)
+
+
+def test_output_projection_launch_arms_the_buffer_with_write_through_stores():
+    body = _body(_code("decode_cols.hip"), r"void gemm_cols_resid_kernel\(")
+    _only_through_resource(body, "poison2", "gemm_cols_resid_kernel")
+    i = body.index("pl.poison2)")
+    _aux16_everywhere(body[i:i + 900], "gemm_cols_resid_kernel poison2 store", 1)
 
 
 def test_lm_head_launch_arms_the_buffer_with_write_through_stores():

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Decode step time, tokens/s and time to first token of StarVector-1B im2svg over the batch size (one engine per batch size, `exclusive_device` as in bench.py;
+greedy, 256 new tokens, EOS disabled, synthetic images): what a caller with fewer than BASELINE config 2's 32 requests per GPU gets.
+    python tools/batch_sweep.py [--batches 1 2 4 8 16 32 64] [--new-tokens 256]"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import starvector_amd as sva  # noqa: E402
+from bench import synthetic_images  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batches", type=int, nargs="*", default=[1, 2, 4, 8, 16, 32, 64])
+ap.add_argument("--new-tokens", type=int, default=256)
+a = ap.parse_args()
+dev = torch.device("cuda", 0)
+for B in a.batches:
+    ec = sva.EngineConfig(max_batch=B, max_seq_len=259 + a.new_tokens)
+    ec.exclusive_device = True
+    eng = sva.HipEngine(ec)
+    eng.load_random_weights(seed=1234)
+    img = synthetic_images(torch, B, 224, seed=0).to(dev)
+    prompt = torch.tensor([[7, 11]] * B, dtype=torch.long, device=dev)
+
+    def request(n):
+        emb = eng.prepare_inputs(eng.encode_image(img), prompt)
+        return eng.generate(emb, max_length=emb.shape[1] + n, eos_token_id=-1, pad_token_id=49152)
+
+    request(a.new_tokens)                                   # warm-up: GEMM tuning, graph capture
+    ttft = []
+    for _ in range(5):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); request(1); torch.cuda.synchronize()
+        ttft.append((time.perf_counter() - t0) * 1e3)
+    dec = []
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); request(a.new_tokens); torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) * 1e3
+        tm = eng.last_timing()
+        dec.append((tm["decode_ms"] * 1e3 / max(tm["decode_steps"], 1), B * a.new_tokens / wall * 1e3))
+    plan = eng.step_plan()
+    print(json.dumps({"batch": B, "decode_us_per_step": round(statistics.median(d[0] for d in dec), 1), "tokens_per_s": round(statistics.median(d[1] for d in dec), 1),
+                      "tokens_per_s_per_sequence": round(statistics.median(d[1] for d in dec) / B, 1), "ttft_ms_p50": round(statistics.median(ttft), 2),
+                      "launches_per_step": plan["graph_kernel_nodes"], "new_tokens": a.new_tokens}), flush=True)
+    eng.close()
+    del eng
+    torch.cuda.empty_cache()
