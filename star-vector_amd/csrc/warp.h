@@ -101,15 +101,22 @@ __device__ WarpStats row_warp_stats_regs(F sc, int V, int top_k, float top_p, in
     const int k = top_k > 0 ? (top_k > min_keep ? top_k : min_keep) : 0;
     if (k > 0 && k < V) {
         uint32_t lo = 0u, hi = wp_key(mx) + 1u;          // count(key >= lo) >= k > count(key >= hi)
+        // (round 6: the keys REPLACE the scores in their registers for the duration of the search -- wp_unkey(wp_key(x)) is x bit for bit.  Written as
+        //  wp_key(v[j]) inside the loop, the compiler hoists the NPT loop-invariant keys and keeps 2 NPT values alive under the 128-VGPR cap of a
+        //  1024-thread block: 31 spilled registers, reloaded in every sweep)
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) v[j] = __uint_as_float(wp_key(v[j]));
         while (hi - lo > 1u) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
             float c = 0.f;
 #pragma unroll
-            for (int j = 0; j < NPT; ++j) c += wp_key(v[j]) >= mid ? 1.f : 0.f;
+            for (int j = 0; j < NPT; ++j) c += __float_as_uint(v[j]) >= mid ? 1.f : 0.f;
             c = wp_block_sum(c, red);                     // exact: counts < 2^24
             if (c >= (float)k) lo = mid; else hi = mid;
         }
         w.kth = wp_unkey(lo);
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) v[j] = wp_unkey(__float_as_uint(v[j]));
     }
     // probabilities over the top-k survivors (unnormalised e = exp(s - mx), 0 for the filtered and the padding)
     float z = 0.f;
@@ -126,15 +133,18 @@ __device__ WarpStats row_warp_stats_regs(F sc, int V, int top_k, float top_p, in
     if (top_p < 1.0f) {
         uint32_t lo = 0u, hi = 0x3f800000u;               // (lo, hi]
         const float cut = 1.0f - top_p;
+        // (the probabilities replace the unnormalised values in their registers, for the same reason: v[j] * invZ is loop-invariant; the same products,
+        //  formed once.  Beam-sample's warper: 1561 -> 1549 us per decode step at 64 rows, thresholds bit-identical.  An 8-way form of this search -- seven
+        //  thresholds per sweep, one pair of barriers for their seven sums, same boundary because the sums are monotone in the threshold -- was built and
+        //  is SLOWER: the accumulators push the sweep back into spills, profiles/beam_warp_r06.log)
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) v[j] = v[j] * w.invZ;
         while (hi - lo > 1u) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
             const float thr = __uint_as_float(mid);
             float f = 0.f;
 #pragma unroll
-            for (int j = 0; j < NPT; ++j) {
-                const float pr = v[j] * w.invZ;
-                f += pr <= thr ? pr : 0.f;
-            }
+            for (int j = 0; j < NPT; ++j) f += v[j] <= thr ? v[j] : 0.f;
             f = wp_block_sum(f, red);
             if (f > cut) hi = mid; else lo = mid;
         }

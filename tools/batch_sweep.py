@@ -19,10 +19,12 @@ from bench import synthetic_images  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--batches", type=int, nargs="*", default=[1, 2, 4, 8, 16, 32, 64])
 ap.add_argument("--new-tokens", type=int, default=256)
+ap.add_argument("--beams", type=int, default=1, help="num_beams (the reference's default decode: 2 with --sample)")
+ap.add_argument("--sample", action="store_true")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 for B in a.batches:
-    ec = sva.EngineConfig(max_batch=B, max_seq_len=259 + a.new_tokens)
+    ec = sva.EngineConfig(max_batch=B * a.beams, max_seq_len=259 + a.new_tokens)
     ec.exclusive_device = True
     eng = sva.HipEngine(ec)
     eng.load_random_weights(seed=1234)
@@ -31,6 +33,9 @@ for B in a.batches:
 
     def request(n):
         emb = eng.prepare_inputs(eng.encode_image(img), prompt)
+        if a.beams > 1:
+            return eng.generate(emb, max_length=emb.shape[1] + n, eos_token_id=-1, pad_token_id=49152, num_beams=a.beams, do_sample=a.sample,
+                                top_p=0.9 if a.sample else 1.0, seed=1)
         return eng.generate(emb, max_length=emb.shape[1] + n, eos_token_id=-1, pad_token_id=49152)
 
     request(a.new_tokens)                                   # warm-up: GEMM tuning, graph capture
@@ -45,7 +50,7 @@ for B in a.batches:
         tm = eng.last_timing()
         dec.append((tm["decode_ms"] * 1e3 / max(tm["decode_steps"], 1), B * a.new_tokens / wall * 1e3))
     plan = eng.step_plan()
-    print(json.dumps({"batch": B, "decode_us_per_step": round(statistics.median(d[0] for d in dec), 1), "tokens_per_s": round(statistics.median(d[1] for d in dec), 1),
+    print(json.dumps({"batch": B, "beams": a.beams, "sample": bool(a.sample), "decode_us_per_step": round(statistics.median(d[0] for d in dec), 1), "tokens_per_s": round(statistics.median(d[1] for d in dec), 1),
                       "tokens_per_s_per_sequence": round(statistics.median(d[1] for d in dec) / B, 1), "ttft_ms_p50": round(statistics.median(ttft), 2),
                       "launches_per_step": plan["graph_kernel_nodes"], "new_tokens": a.new_tokens}), flush=True)
     eng.close()
