@@ -63,6 +63,7 @@ def parse():
                     help="num_beams of the decode (1: BASELINE's greedy line).  2 with --sample = the reference's DEFAULT generate_im2svg call "
                          "(starvector_base.py:231-239: beam-sample, num_beams 2, top-p 0.9): batch x beams rows per decode step -- a secondary line")
     ap.add_argument("--sample", action="store_true", help="with --beams > 1: HF beam-sample (do_sample, top-p 0.9, temperature 1.0)")
+    ap.add_argument("--batch", type=int, default=0, help="requests per GPU (default: the BASELINE configuration's: 32 / 16 / 64); other values are sweep points, not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ttft-requests", type=int, default=20)
     return ap.parse_args()
@@ -177,6 +178,8 @@ def main():
     is8b = args.model == "8b"
     t2s = args.task == "text2svg"
     B_PER_GPU = (64 if t2s else 16) if is8b else 32
+    if args.batch > 0:
+        B_PER_GPU = args.batch
     n_new = args.new_tokens
     CAPTION_TOKENS = 32
     PAD_ID = 0 if is8b else 49152            # llm/starcoder2.py:47 / llm/starcoder.py:40-53 ([PAD] appended to the 49152-entry vocabulary)
