@@ -1136,6 +1136,68 @@ static GemmArgs seq_sanitised(const GemmArgs& a0) {
     a.seq_tail = 0;
     return a;
 }
+static void launch_gemm_model(const GemmArgs& a, const GemmPlan& pl, hipStream_t st);
+// every row through the one-wave-per-tile kernel (bit-identical to the tile kernels); with the sequence structure: the full 256-row tiles' rows of
+// every sequence that way, the rows a sequence leaves over through the per-sequence split-K remainder kernel as in every other form
+static void launch_gemm_rows_by_tail(const GemmArgs& a, hipStream_t st) {
+    if (!a.seq_rows) { launch_gemm_tail(a, st); return; }
+    const int nseq = a.M / a.seq_rows, main = 256 * (a.seq_rows / 256);
+    for (int sq = 0; sq < nseq; ++sq) {
+        GemmArgs m = a;
+        const size_t r0 = (size_t)sq * a.seq_rows;
+        m.seq_rows = 0;
+        m.A = a.A + r0 * a.lda;
+        m.R = a.R ? a.R + r0 * a.ldr : nullptr;
+        m.C = a.out_f32 ? (void*)((float*)a.C + r0 * a.ldc) : (void*)((bf16_t*)a.C + r0 * a.ldc);
+        m.M = main;
+        m.tail_mark = nullptr;
+        if (main > 0) launch_gemm_tail(m, st);
+    }
+    GemmArgs t = a;
+    t.seq_tail = seq_peel_rows(a.seq_rows);
+    t.M = nseq * t.seq_tail;
+    if (a.tail_mark) a.tail_mark(a.tail_ctx, st);
+    launch_gemm_tailk(t, st);
+}
+// the small-M decision, measured: bit 4 (16) = rows by the one-wave-per-tile kernel, 0 = the cost model's tiles
+static int autotune_small(const GemmArgs& a, hipStream_t st, const GemmPlan& model) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return 0; }
+    const size_t esz = a.out_f32 ? 4 : 2;
+    const size_t need = (size_t)a.M * a.ldc * esz;
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    TuneScratch& ts = g_tune_scratch[dev_id];           // (the caller holds g_tune_mu)
+    if (need > ts.bytes) {
+        void* bigger = nullptr;
+        if (hipMalloc(&bigger, need + need / 2) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        if (ts.p) (void)hipFree(ts.p);
+        ts.p = bigger; ts.bytes = need + need / 2;
+    }
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return 0;
+    GemmArgs t = a;
+    t.C = ts.p;
+    t.tail_mark = nullptr;
+    float ms[2] = {1e30f, 1e30f};
+    for (int form = 0; form < 2; ++form) {
+        auto run = [&]() { if (form) launch_gemm_rows_by_tail(t, st); else launch_gemm_model(t, model, st); };
+        run();                                               // warm-up
+        (void)hipEventRecord(e0, st);
+        for (int r = 0; r < 3; ++r) run();
+        (void)hipEventRecord(e1, st);
+        if (hipEventSynchronize(e1) != hipSuccess) { (void)hipGetLastError(); continue; }
+        float v = 0.f;
+        if (hipEventElapsedTime(&v, e0, e1) == hipSuccess) ms[form] = v;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    const int best = ms[1] < ms[0] ? 16 : 0;
+    if (getenv("SV_GEMM_AUTOTUNE_LOG"))
+        fprintf(stderr, "[sv gemm autotune] M %d N %d K %d act %d res %d%s -> %s (tiles %.1f us, one wave per tile %.1f us)\n", a.M, a.N, a.K, a.act, a.R ? 1 : 0,
+                a.seq_rows ? " seq" : "", best ? "one wave per 32 x 32 tile" : "tiles", ms[0] * 1000.f / 3.f, ms[1] * 1000.f / 3.f);
+    return best;
+}
+
 void launch_gemm_fixed(const GemmArgs& a0, int kernel256, int peel, hipStream_t st) {
     const GemmArgs a = seq_sanitised(a0);
     if (a.splitk_rows) { launch_gemm_tailk(a, st); return; }
@@ -1173,6 +1235,27 @@ void launch_gemm(const GemmArgs& a0, hipStream_t st) {
         launch_gemm_config(a, st, cfg & 1, (cfg & 2) != 0, (cfg & 4) != 0);
         return;
     }
+    // A FEW HUNDRED rows (round 6, third session: the prompt pass of one to three requests -- what the reference's own callers run): 2 - 9 row tiles
+    // of 128^2 are 16 - 54 blocks on 256 CUs, each walking the whole K alone (down projection at 259 rows: 108 us).  The one-wave-per-tile kernel --
+    // same MFMA, operand roles and ascending k as the tile kernels, hence the same bits, which is why it may be chosen by speed alone and a row's
+    // result still does not depend on the batch it arrives in -- spreads the same rows over M / 32 x N / 32 waves.  Measured once per shape like
+    // the big-M forms (the weights' re-reads per row tile decide; no model is trusted here).
+    if (tune_on && a.M > 96 && a.M < 1024 && (!a.seq_rows || a.M / a.seq_rows <= 4)) {
+        const TuneKey key{-((a.M + 63) / 64), a.seq_rows ? 2 : 0, a.N, a.K, a.act, a.R ? 1 : 0, a.out_f32, a.cscale ? 1 : 0};
+        int cfg;
+        {
+            std::lock_guard<std::mutex> lk(g_tune_mu);
+            auto it = g_tune.find(key);
+            if (it != g_tune.end()) cfg = it->second;
+            else { cfg = autotune_small(a, st, pl); g_tune[key] = cfg; }
+        }
+        if (cfg & 16) { launch_gemm_rows_by_tail(a, st); return; }
+    }
+    launch_gemm_model(a, pl, st);
+}
+
+// the untuned choice: the cost model's tile kernel, its peel decision, the per-sequence remainder
+static void launch_gemm_model(const GemmArgs& a, const GemmPlan& pl, hipStream_t st) {
     if (a.seq_rows) { launch_gemm_config(a, st, pl.main_256, false, false); return; }
     const int tail = a.M % 256, main_rows = a.M - tail;
     const bool peel = pl.peel != 0, tail_by_tiles = pl.tail_by_tiles != 0;
