@@ -103,7 +103,12 @@ typedef struct sv_config {
                                   GPU such a launch can find its blocks only partly resident: the waiting blocks then give up after
                                   a wall-clock bound (5 ms) and the call -- sv_generate, beam search, sv_decode_step, sv_cb_step --
                                   fails with SV_EHIP and a message naming the launch (never a hang, never tokens; executed by
-                                  tests/test_gpu_safety.py); the next call starts clean.  Leave it 0 there.  Default 0. */
+                                  tests/test_gpu_safety.py); the next call starts clean.  Leave it 0 there.  Default 0.
+                                  2 = OPTIMISTIC: as 1 until a fused launch gives up for the first time; the engine then switches those launches
+                                  off for the rest of its life (one line on stderr) and sv_generate runs the failed call again without them -- the
+                                  kernels are bit-identical either way, so the caller sees the same tokens, late by the failed attempt (<= 80 ms
+                                  in the safety test), and a streaming callback gets every column exactly once; sv_decode_step / sv_cb_step report
+                                  that one failure and are clean from the next call on.  What the Python wrapper passes by default. */
 } sv_config;
 
 /* Streaming: called on the host with the tokens that became final since the last call -- tokens [batch][n_cols] int32

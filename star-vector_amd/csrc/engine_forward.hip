@@ -161,7 +161,7 @@ int sveng::assign_pages(sv_engine* e, int B, int total_len, hipStream_t st) {
 static bool rc_enabled(const sv_engine* e) {
     // the 6-launch layer (fold6: residual stream in fragment order) or the 7-launch layer of the wide model (row-major residual stream)
     const bool layer_ok = e->fold6 ? (e->fold_ready && !(e->exp & 2)) : e->cfg.hidden > 2048;
-    return layer_ok && e->rc_fused_ok && !(e->exp & 8192) && (e->cfg.exclusive_device || (e->exp & 16384));
+    return layer_ok && e->rc_fused_ok && !(e->exp & 8192) && (e->cfg.exclusive_device || (e->exp & 16384)) && !e->fused_off;
 }
 // the lm_head launch stores the pattern 16 bytes per thread from its first blocks: its grid must cover the buffer (a tiny-vocabulary
 // configuration would arm only part of it: then layer 0 of the next step takes the two launches)
@@ -385,7 +385,7 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
         // SV_EXP bit 128 forces it on, bit 512 off (in-process A/B, tools/ab_exp.py).  It recognises unwritten activations by a pattern
         // that an EARLIER launch of the layer leaves in the buffer: the attention launch (16 bytes per thread: free in a latency-bound
         // kernel), or -- grid too small, or the profiling leg without attention -- the projection kernel (+0.5 us there)
-        const bool fused = fold6 && e->mlp_fused_ok && !(e->exp & 512) && (c.exclusive_device || (e->exp & 128));
+        const bool fused = fold6 && e->mlp_fused_ok && !(e->exp & 512) && (c.exclusive_device || (e->exp & 128)) && !e->fused_off;
         const size_t pat_bytes = (size_t)(F / 16) * 1024;
         const size_t poison_cap = (size_t)B * e->nkv * attn_max_splits(e) * 512 * 16;      // 16 bytes per thread of the attention launch
         const bool attn_poisons = fused && !e->only_skinny && pat_bytes + (rc ? xpa_bytes : 0u) <= poison_cap;

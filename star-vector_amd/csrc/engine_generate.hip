@@ -199,6 +199,17 @@ int sveng::report_bad_logits(sv_engine* e, hipStream_t st, const char* who, int 
         fprintf(stderr, "[sv] rowln_cattn give-up: block %lld wave %lld ks0 %lld waited %lld ticks, x0 %016llx, layer %lld, rows %lld; device step %d\n",
                 d[0], d[1], d[2], d[3], (unsigned long long)d[4], d[5], d[6], stepv);
     }
+    if (what == 3 || what == 4) {
+        e->last_giveup = what;
+        if (e->cfg.exclusive_device == 2 && !e->fused_off) {
+            // optimistic ownership (sv_config.exclusive_device = 2) did not hold: from here on this engine decodes without the launches that need
+            // every block resident.  sv_generate runs the failed call again (below); the step-wise entry points report this one failure.
+            e->fused_off = true;
+            e->xpa_armed = false;
+            fprintf(stderr, "[starvector_amd] a fused decode launch gave up waiting (code %d): this GPU is shared -- the engine continues WITHOUT the all-blocks-resident "
+                            "launches (same tokens, ~8 %% more time per step); create it with exclusive_device = 0 to start that way\n", what);
+        }
+    }
     if (what == 3 || what == 4)
         return fail(SV_EHIP, "%s: a block of a fused decode launch (code %d: 3 = MLP pair, 4 = row update + c_attn) gave up waiting for its producers (its blocks were not all resident at "
                              "once?  another process or engine on this GPU?); the tokens of this call are void -- create the engine with "
@@ -210,8 +221,28 @@ int sveng::report_bad_logits(sv_engine* e, hipStream_t st, const char* who, int 
     }
 }
 
+static int generate_attempt(sv_engine* e, const void* dev_embeds, int32_t B, int32_t S0, const sv_sampling* sp,
+                            int64_t* dev_out_tokens, int32_t* n_generated, sv_stream stream);
+
+// sv_config.exclusive_device = 2: OPTIMISTIC ownership.  The fused launches run as if the engine owned its GPU; if one gives up (another process
+// holds CUs: the bounded wait of rowops.hip / gemm.hip, never a hang, never tokens) the engine switches them off for good (report_bad_logits) and
+// THIS call is run again from its prompt pass.  The kernels with and without the fused launches are bit-identical (tests/test_gpu_e2e.py), the
+// sampler's random stream is a function of (seed, step, row): the second attempt re-derives exactly the columns the first one had already handed
+// to a streaming callback, and skips them.
 extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int32_t S0, const sv_sampling* sp,
                            int64_t* dev_out_tokens, int32_t* n_generated, sv_stream stream) {
+    if (e) { e->last_giveup = 0; e->stream_skip = 0; }
+    int rc = generate_attempt(e, dev_embeds, B, S0, sp, dev_out_tokens, n_generated, stream);
+    if (rc != 0 && e && e->cfg.exclusive_device == 2 && e->last_giveup && e->fused_off) {
+        e->last_giveup = 0;
+        rc = generate_attempt(e, dev_embeds, B, S0, sp, dev_out_tokens, n_generated, stream);
+    }
+    if (e) e->stream_skip = 0;
+    return rc;
+}
+
+static int generate_attempt(sv_engine* e, const void* dev_embeds, int32_t B, int32_t S0, const sv_sampling* sp,
+                            int64_t* dev_out_tokens, int32_t* n_generated, sv_stream stream) {
     SVCHECK(check_ready(e));
     if (!sp || !dev_out_tokens || !n_generated) return fail(SV_EINVAL, "sv_generate: null argument");
     const int max_new = sp->max_length - S0;     // HF: with inputs_embeds, max_length includes the prompt
@@ -268,7 +299,8 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
     int steps = 0;
     const int chunk = sp->sync_every > 0 ? sp->sync_every : 32;
     // streaming: columns [0, steps] are final after every poll (a finished batch may have fewer: n_emitted caps it)
-    int streamed = 0;
+    int streamed = e->stream_skip;             // (an optimistic call's second attempt: the columns its first attempt delivered)
+    struct SkipSave { sv_engine* e; int* s; ~SkipSave() { e->stream_skip = *s; } } skip_save{e, &streamed};
     std::vector<int32_t> stream_buf;
     auto stream_upto = [&](int n_cols_final) -> int {
         if (!sp->on_tokens || n_cols_final <= streamed) return 0;
@@ -295,9 +327,9 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
         // stream, the benchmark), so a short request does not pay a 172-node capture + instantiate; a call with other
         // parameters replaces it.  Owned by the engine: no early return below can leak it.
         char key[256];
-        snprintf(key, sizeof(key), "B%d|n%d|ds%d|T%a|p%a|k%d|seed%llu|eos%d|pad%d|ns%d|rp%a|mn%d|x%d", B, max_new, sp->do_sample,
+        snprintf(key, sizeof(key), "B%d|n%d|ds%d|T%a|p%a|k%d|seed%llu|eos%d|pad%d|ns%d|rp%a|mn%d|x%d|fo%d", B, max_new, sp->do_sample,
                  sp->temperature, sp->top_p, sp->top_k, (unsigned long long)sp->seed, sp->eos_token_id, sp->pad_token_id, sp->n_stop,
-                 sp->repetition_penalty, sp->min_new_tokens, e->exp);
+                 sp->repetition_penalty, sp->min_new_tokens, e->exp, e->fused_off ? 1 : 0);
         if (e->gen_gexec && e->gen_graph_key == key) {
             gexec = e->gen_gexec;
         } else {
@@ -388,8 +420,10 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
         }
         steps += n;
         if (!poll) continue;                     // nothing can end this call before its budget: the next chunk follows without a host round trip
-        HIPCHECK(hipMemcpyAsync(&e->h_flags[0], e->d_done, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHECK(hipMemcpyAsync(&e->h_flags[8], e->d_step, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));      // {step, done, n_emitted, bad}
         HIPCHECK(hipStreamSynchronize(st));
+        e->h_flags[0] = e->h_flags[9];
+        if (e->h_flags[11]) break;               // a void step (give-up, non-finite row): nothing of this chunk is handed on; the error is raised below
         if (!e->h_flags[0]) SVCHECK(stream_upto(steps + 1));      // still running: every column so far is final
     }
     const double gexec_used = gexec_multi ? (double)U : gexec ? 1.0 : 0.0;       // steps per graph launch
@@ -398,8 +432,8 @@ extern "C" int sv_generate(sv_engine* e, const void* dev_embeds, int32_t B, int3
         HIPCHECK(hipStreamSynchronize(st));
     }
     e->h_flags[1] = e->h_flags[10];
+    SVCHECK(report_bad_logits(e, st, "sv_generate", e->h_flags[11]));          // (before the last columns go out: a void call streams nothing more)
     if (e->h_flags[1] >= 1 && e->h_flags[1] <= max_new) SVCHECK(stream_upto(e->h_flags[1]));
-    SVCHECK(report_bad_logits(e, st, "sv_generate", e->h_flags[11]));
     const int n_emit = e->h_flags[1];
     if (n_emit < 1 || n_emit > max_new) return fail(SV_EHIP, "generation bookkeeping failed (n_emitted=%d)", n_emit);
     tokens_to_i64(e->out_tok, e->out_ld, dev_out_tokens, B, n_emit, max_new, st);

@@ -109,6 +109,11 @@ struct sv_engine {
     int MT = 0, ldws = 0, Vpad = 0;
     bf16_t *h_dec = nullptr, *hl = nullptr, *xp_a = nullptr, *xp_attn = nullptr, *xp_mlp = nullptr;
     bf16_t* h_xp = nullptr;         // residual stream of the decode step in fragment order (6-launch layer)
+    // sv_config.exclusive_device == 2 ("optimistic"): the fused launches are on until one of them gives up (another tenant holds CUs); then they are off for the
+    // rest of the engine's life and the failed sv_generate call is run again without them (engine_generate.hip)
+    bool fused_off = false;
+    int last_giveup = 0;            // code (3 / 4) of the give-up the last report_bad_logits saw, 0: none
+    int stream_skip = 0;            // columns the failed attempt of an optimistic call already handed to the streaming callback
     bool fold6 = false;             // 6 launches per layer: slab-free attention output projection + ln_2 folded into c_fc
     bool fold_ready = false;
     bf16_t* xp_f = nullptr;         // ln_f output of the last row update (the lm_head's operand) when xp_a belongs to the fused row-update + c_attn launch

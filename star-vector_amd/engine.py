@@ -38,7 +38,8 @@ class EngineConfig:
     vit_eps: float = 1e-6
     sliding_window: int = 0          # v2: keys visible to a query (4096 for bigcode/starcoder2-7b); 0 = all
     weight_dtype: str = "bf16"       # "fp8_e4m3": decoder weights + lm_head quantised at load (per-row scales), BASELINE config 5
-    exclusive_device: bool = False   # this engine alone launches kernels on its GPU while decoding (one process per GPU): enables the
+    exclusive_device: object = False # False / True / "auto" (2: on until a fused launch gives up, then off for good and the call re-run: sv_config.exclusive_device).
+                                     # True: this engine alone launches kernels on its GPU while decoding (one process per GPU): enables the
                                      # all-blocks-resident fused launches (include/starvector_hip.h sv_config.exclusive_device); same tokens
 
     @property
@@ -70,6 +71,17 @@ def _need(t: torch.Tensor, dtype, what: str) -> torch.Tensor:
     return t.contiguous()
 
 
+def _exclusive_code(v) -> int:
+    """sv_config.exclusive_device: 0 (shared GPU), 1 (this engine owns it), 2 ("auto": optimistic, falls back for good at the first give-up)."""
+    if isinstance(v, str):
+        if v.lower() in ("auto", "optimistic", "2"):
+            return 2
+        return 1 if v.lower() in ("1", "true", "yes") else 0
+    if v is True or v is False or v is None:
+        return int(bool(v))
+    return 2 if int(v) == 2 else int(bool(v))
+
+
 class HipEngine:
     """Owns one ``sv_engine`` (weights repacked into library memory, paged KV pool, workspaces)."""
 
@@ -86,7 +98,7 @@ class HipEngine:
                      _lib.SV_ARCH_V2 if cfg.arch == "v2" else _lib.SV_ARCH_V1, cfg.n_kv_head, cfg.rope_theta,
                      cfg.vit_mlp, cfg.vit_eps if cfg.arch == "v2" else cfg.ln_eps,
                      int(cfg.sliding_window) if cfg.arch == "v2" else 0,
-                     {"bf16": 0, "fp8_e4m3": 1}[cfg.weight_dtype], int(bool(getattr(cfg, "exclusive_device", False))))
+                     {"bf16": 0, "fp8_e4m3": 1}[cfg.weight_dtype], _exclusive_code(getattr(cfg, "exclusive_device", False)))
         h = C.c_void_p()
         check(self.lib.sv_create(C.byref(c), C.byref(h)), "sv_create")
         self._h = h

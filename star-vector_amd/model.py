@@ -77,7 +77,10 @@ class StarVectorConfig:
         self.max_batch = max_batch
         # one process per GPU and nothing else decoding on it (the deployment the engine is built for): allows the launches whose blocks
         # wait for each other (INTEGRATION.md "Deployment knob").  None = the environment decides (SV_EXCLUSIVE_DEVICE=1), default off
-        self.exclusive_device = (os.environ.get("SV_EXCLUSIVE_DEVICE", "0") == "1") if exclusive_device is None else bool(exclusive_device)
+        # None: SV_EXCLUSIVE_DEVICE (0 / 1 / auto), default "auto" = the fused decode launches on until one of them finds the GPU shared, then off for good
+        # with the failed call re-run (include/starvector_hip.h, sv_config.exclusive_device = 2): same tokens either way
+        env = os.environ.get("SV_EXCLUSIVE_DEVICE", "auto")
+        self.exclusive_device = ({"0": False, "1": True}.get(env, "auto")) if exclusive_device is None else exclusive_device
         for k, v in kwargs.items():
             setattr(self, k, v)
 
@@ -124,7 +127,7 @@ class StarVectorConfig:
                                 # everywhere) show W.  `window_semantics` picks which one the engine's window (= number of visible
                                 # keys) mirrors: "flash_attention_2" (default: what the reference runs) or "sdpa".
                                 sliding_window=self._visible_keys(g("sliding_window", 4096), g("window_semantics", "flash_attention_2")),
-                                exclusive_device=bool(self.exclusive_device))
+                                exclusive_device=self.exclusive_device)
         if self.image_encoder_type != "clip":
             raise NotImplementedError(f"image_encoder_type={self.image_encoder_type!r}: v1 is built for the clip branch")
         return EngineConfig(image_size=self.image_size, patch_size=self.patch_size, vit_width=self.vit_width,
@@ -132,7 +135,7 @@ class StarVectorConfig:
                             hidden=self.hidden_size, n_layer=self.num_hidden_layers, n_head=self.num_attention_heads,
                             n_inner=self.n_inner, vocab=self.vocab_size + self.added_tokens,
                             n_positions=self.n_positions, max_batch=self.max_batch,
-                            max_seq_len=min(self.max_length, self.n_positions), exclusive_device=bool(self.exclusive_device))
+                            max_seq_len=min(self.max_length, self.n_positions), exclusive_device=self.exclusive_device)
 
 
 def config_from_checkpoint(cfg_json: Dict, shapes: Dict[str, tuple]) -> StarVectorConfig:

@@ -79,6 +79,42 @@ def test_foreign_tenant_on_half_the_cus_ends_the_call_with_an_error_and_the_engi
     eng.close()
 
 
+def test_optimistic_ownership_falls_back_for_good_and_reruns_the_call():
+    """sv_config.exclusive_device = 2 (EngineConfig(exclusive_device="auto"), what the drop-in model wrapper passes by default): the fused launches are on
+    until one gives up; the engine then switches them off for the rest of its life and sv_generate runs the failed call AGAIN -- the caller gets the
+    tokens (the kernels are bit-identical with and without the fused launches), late by the failed attempt; a streaming callback sees every column
+    exactly once; later calls run unfused without an error even while the tenant is still there."""
+    B = 32
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    eng = sva.HipEngine(sva.EngineConfig(max_batch=B, max_seq_len=259 + 64, exclusive_device="auto"))
+    eng.load_random_weights(seed=13)
+    emb = _inputs(eng, B)
+    S0 = emb.shape[1]
+    kw = dict(max_length=S0 + 24, eos_token_id=-1, pad_token_id=49152)
+    ref = eng.generate(emb, **kw).cpu()
+    plan = eng.step_plan()
+    assert plan["mlp_fused"] and plan["rowln_cattn_fused"], "the optimistic engine did not start with the fused launches"
+    seen = []
+    torch.cuda.synchronize()
+    eng.debug_occupy_cus(cus // 2, 144 * 1024, 400)
+    time.sleep(0.02)
+    t0 = time.time()
+    got = eng.generate(emb, sync_every=4, on_tokens=lambda t, first: seen.append((first, t.clone())), **kw).cpu()      # no exception
+    dt = time.time() - t0
+    assert torch.equal(got, ref), "the re-run of an optimistic call did not reproduce the tokens"
+    plan = eng.step_plan()
+    assert not plan["mlp_fused"] and not plan["rowln_cattn_fused"], "the engine kept the fused launches after a give-up"
+    cols = torch.cat([t for _, t in sorted(seen, key=lambda x: x[0])], 1)
+    firsts = sorted(f for f, _ in seen)
+    assert firsts == sorted(set(firsts)) and cols.shape[1] == ref.shape[1] and torch.equal(cols.to(ref.dtype), ref), "a column was streamed twice, never, or wrong"
+    # the tenant is still there (400 ms): the engine now decodes beside it
+    assert torch.equal(eng.generate(emb, **kw).cpu(), ref)
+    torch.cuda.synchronize()
+    assert torch.equal(eng.generate(emb, **kw).cpu(), ref) and not eng.step_plan()["mlp_fused"]
+    print(f"[safety] optimistic engine: the call that met the tenant took {dt * 1e3:.0f} ms (failed attempt + re-run), tokens identical, every column streamed once")
+    eng.close()
+
+
 def test_tenant_that_leaves_room_changes_nothing():
     """Control: a tenant on EVERY CU that pins only 16 KiB leaves room for every block of the engine (the fused launches take 37 / 2 x 32 KiB, the
     256-row-tile prompt-pass GEMM 128 KiB of a CU's 160) -- concurrent work as such is not what fails: same tokens, no error."""

@@ -33,11 +33,16 @@ def test_config_maps_to_engine_shapes():
 
 
 def test_exclusive_device_reaches_the_engine_config(monkeypatch):
-    """The deployment knob: off by default, on by the config field or -- for callers that only change their import line --
-    by SV_EXCLUSIVE_DEVICE=1 in the environment; an explicit field wins over the environment; both model families carry it."""
+    """The deployment knob: "auto" by default since round 6 (sv_config.exclusive_device = 2: the fused decode launches on until one of
+    them finds the GPU shared, then off for good with the failed call re-run), on / off by the config field or -- for callers that only change their
+    import line -- by SV_EXCLUSIVE_DEVICE=1 / 0 in the environment; an explicit field wins over the environment; both model families carry it."""
+    from starvector_amd.engine import _exclusive_code
     monkeypatch.delenv("SV_EXCLUSIVE_DEVICE", raising=False)
-    assert StarVectorConfig().engine_config().exclusive_device is False
+    assert StarVectorConfig().engine_config().exclusive_device == "auto"
+    assert [_exclusive_code(v) for v in (False, True, "auto", 2, 0, 1, "0", "1", None)] == [0, 1, 2, 2, 0, 1, 0, 1, 0]
     assert StarVectorConfig(exclusive_device=True).engine_config().exclusive_device is True
+    monkeypatch.setenv("SV_EXCLUSIVE_DEVICE", "0")
+    assert StarVectorConfig().engine_config().exclusive_device is False
     monkeypatch.setenv("SV_EXCLUSIVE_DEVICE", "1")
     assert StarVectorConfig().engine_config().exclusive_device is True
     assert StarVectorConfig(exclusive_device=False).engine_config().exclusive_device is False

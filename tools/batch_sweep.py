@@ -21,12 +21,13 @@ ap.add_argument("--batches", type=int, nargs="*", default=[1, 2, 4, 8, 16, 32, 6
 ap.add_argument("--new-tokens", type=int, default=256)
 ap.add_argument("--beams", type=int, default=1, help="num_beams (the reference's default decode: 2 with --sample)")
 ap.add_argument("--sample", action="store_true")
+ap.add_argument("--shared", action="store_true", help="exclusive_device = False (the library's default: no all-blocks-resident fused launches)")
 ap.add_argument("--max-seq-len", type=int, default=0, help="engine max_seq_len (default: prompt + new tokens); the reference's eval configs generate up to max_length 8192")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 for B in a.batches:
     ec = sva.EngineConfig(max_batch=B * a.beams, max_seq_len=a.max_seq_len if a.max_seq_len > 0 else 259 + a.new_tokens)
-    ec.exclusive_device = True
+    ec.exclusive_device = not a.shared
     eng = sva.HipEngine(ec)
     eng.load_random_weights(seed=1234)
     img = synthetic_images(torch, B, 224, seed=0).to(dev)
@@ -53,7 +54,7 @@ for B in a.batches:
     plan = eng.step_plan()
     print(json.dumps({"batch": B, "beams": a.beams, "sample": bool(a.sample), "decode_us_per_step": round(statistics.median(d[0] for d in dec), 1), "tokens_per_s": round(statistics.median(d[1] for d in dec), 1),
                       "tokens_per_s_per_sequence": round(statistics.median(d[1] for d in dec) / B, 1), "ttft_ms_p50": round(statistics.median(ttft), 2),
-                      "launches_per_step": plan["graph_kernel_nodes"], "max_seq_len": ec.max_seq_len, "new_tokens": a.new_tokens}), flush=True)
+                      "launches_per_step": plan["graph_kernel_nodes"], "max_seq_len": ec.max_seq_len, "exclusive_device": bool(ec.exclusive_device), "new_tokens": a.new_tokens}), flush=True)
     eng.close()
     del eng
     torch.cuda.empty_cache()
