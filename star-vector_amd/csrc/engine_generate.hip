@@ -206,6 +206,11 @@ int sveng::report_bad_logits(sv_engine* e, hipStream_t st, const char* who, int 
             // every block resident.  sv_generate runs the failed call again (below); the step-wise entry points report this one failure.
             e->fused_off = true;
             e->xpa_armed = false;
+            for (auto& kv : e->cb_graphs) {      // the continuous-batching step graphs were captured with the fused launches (sv_generate's carry the flag in their key)
+                if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
+                if (kv.second.first) (void)hipGraphDestroy(kv.second.first);
+            }
+            e->cb_graphs.clear();
             fprintf(stderr, "[starvector_amd] a fused decode launch gave up waiting (code %d): this GPU is shared -- the engine continues WITHOUT the all-blocks-resident "
                             "launches (same tokens, ~8 %% more time per step); create it with exclusive_device = 0 to start that way\n", what);
         }

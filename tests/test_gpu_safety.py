@@ -113,6 +113,32 @@ def test_optimistic_ownership_falls_back_for_good_and_reruns_the_call():
     assert torch.equal(eng.generate(emb, **kw).cpu(), ref) and not eng.step_plan()["mlp_fused"]
     print(f"[safety] optimistic engine: the call that met the tenant took {dt * 1e3:.0f} ms (failed attempt + re-run), tokens identical, every column streamed once")
     eng.close()
+    # continuous batching on an optimistic engine: the batch that meets the tenant fails ONCE (its step graphs carried the fused launches and are dropped
+    # with them), the next batch -- the tenant still there -- decodes
+    eng = sva.HipEngine(sva.EngineConfig(max_batch=8, max_seq_len=259 + 64, exclusive_device="auto"))
+    eng.load_random_weights(seed=13)
+    emb4 = _inputs(eng, 4)
+    req = dict(max_new_tokens=16, eos_token_id=-1, pad_token_id=49152)
+    slots = eng.cb_admit(emb4, [req] * 4)
+    while eng.cb_step(8) > 0:
+        pass
+    want = [eng.cb_read(s, 0, 16) for s in slots]
+    eng.cb_reset()
+    torch.cuda.synchronize()
+    eng.debug_occupy_cus(cus // 2, 144 * 1024, 400)
+    time.sleep(0.02)
+    slots = eng.cb_admit(emb4, [req] * 4)
+    with pytest.raises(sva.StarVectorHipError, match="gave up waiting"):
+        while eng.cb_step(8) > 0:
+            pass
+    eng.cb_reset()
+    slots = eng.cb_admit(emb4, [req] * 4)                      # the tenant holds its CUs for 400 ms: still there
+    while eng.cb_step(8) > 0:
+        pass
+    assert all(torch.equal(eng.cb_read(s, 0, 16), w) for s, w in zip(slots, want)), "continuous batching after the fall-back"
+    eng.cb_reset()
+    torch.cuda.synchronize()
+    eng.close()
 
 
 def test_tenant_that_leaves_room_changes_nothing():
