@@ -63,6 +63,9 @@ def parse():
                     help="num_beams of the decode (1: BASELINE's greedy line).  2 with --sample = the reference's DEFAULT generate_im2svg call "
                          "(starvector_base.py:231-239: beam-sample, num_beams 2, top-p 0.9): batch x beams rows per decode step -- a secondary line")
     ap.add_argument("--sample", action="store_true", help="with --beams > 1: HF beam-sample (do_sample, top-p 0.9, temperature 1.0)")
+    ap.add_argument("--top-k", type=int, default=50,
+                    help="with --sample: TopKLogitsWarper in front of top-p.  50 = what the reference's call really runs (it never passes top_k, and its pinned "
+                         "transformers 4.49 defaults GenerationConfig.top_k to 50); 0 = top-p over the whole vocabulary (the line filed before this flag existed)")
     ap.add_argument("--batch", type=int, default=0, help="requests per GPU (default: the BASELINE configuration's: 32 / 16 / 64); other values are sweep points, not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ttft-requests", type=int, default=20)
@@ -217,7 +220,8 @@ def main():
             emb = eng.prepare_inputs(enc, prompt)              # a6 + a1 / a7: adapter rows and prompt rows written into one buffer
         if NB > 1:     # the reference's default decode (starvector_base.py:231-239): beam search / beam-sample over B x num_beams rows
             new = eng.generate(emb, max_length=S0 + max_new, eos_token_id=-1, pad_token_id=PAD_ID, num_beams=NB,
-                               do_sample=bool(args.sample), temperature=1.0, top_p=0.9 if args.sample else 1.0, seed=1)
+                               do_sample=bool(args.sample), temperature=1.0, top_p=0.9 if args.sample else 1.0,
+                               top_k=int(args.top_k) if args.sample else 0, seed=1)
         else:
             new = eng.generate(emb, max_length=S0 + max_new, eos_token_id=-1,      # EOS disabled:
                                pad_token_id=PAD_ID,                                # fixed-length workload
@@ -377,7 +381,7 @@ def main():
                                    (f"StarVector-8B im2svg, batch {B_PER_GPU}/GPU, bf16, top-k 50 + top-p 0.95, 384x384, prompt rows "
                                     f"{S0} (576 visual + {len(PROMPT_IDS)}), {n_new} new tokens/seq, EOS disabled") if is8b else
                                    (f"StarVector-1B im2svg, batch {B_PER_GPU}/GPU, bf16, " +
-                                    (f"{'beam-sample (top-p 0.9)' if args.sample else 'beam search'} num_beams {NB} = {ROWS} rows per decode step "
+                                    (f"{('beam-sample (top-k ' + str(int(args.top_k)) + ' + top-p 0.9)' if int(args.top_k) > 0 else 'beam-sample (top-p 0.9, no top-k)') if args.sample else 'beam search'} num_beams {NB} = {ROWS} rows per decode step "
                                      "(the reference's default generate_im2svg call), " if NB > 1 else "greedy, ") +
                                     f"224x224, prompt rows {S0} (257 visual + {len(PROMPT_IDS)}), {n_new} new tokens/seq, EOS disabled"),
                        "global_batch": B_PER_GPU * world, "new_tokens": n_new,

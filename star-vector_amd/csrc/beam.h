@@ -76,8 +76,8 @@ struct BeamScorer {
 };
 
 // KV-cache side of a beam step (engine only).  Full pages are immutable and shared through the block table; only
-// the partially filled tail page of a beam whose parent changed is copied (through a staging buffer, because the
-// beams of a request permute among themselves).
+// the partially filled tail page of a beam whose parent changed is copied (the beams of a request permute among
+// themselves: one thread moves the same pieces of all of them, loads before stores -- beam.hip::beam_tail_copy_kernel).
 struct BeamKvArgs {
     int32_t* block_table; int max_pages;      // [rows][max_pages]
     int need;                                  // pages owned by each row: own page (r, i) = r * need + i
@@ -86,9 +86,8 @@ struct BeamKvArgs {
     int S0, L_fixed;                           // cached length L = L_fixed >= 0 ? L_fixed : S0 + *step - 1
     int B, nb;
     char* kv_pool; size_t layer_stride, kv_head_stride; int n_layer, n_kv, page_bytes;
-    char* staging;                             // [R][n_layer * n_kv][page_bytes]
 };
 void launch_beam_table_reorder(const BeamKvArgs& a, hipStream_t st);
-void launch_beam_tail_copy(const BeamKvArgs& a, hipStream_t st);     // stage + commit
+void launch_beam_tail_copy(const BeamKvArgs& a, hipStream_t st);
 
 }  // namespace sv

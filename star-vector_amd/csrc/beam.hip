@@ -17,6 +17,7 @@
 #include "warp.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 namespace sv {
@@ -75,6 +76,7 @@ __device__ __forceinline__ float bm_logprob(const BeamDev& p, const float* x, co
 }
 
 // beam-sample: HF applies the warpers to the (penalised) log-probs of every running beam
+template <bool SELECT>
 __global__ __launch_bounds__(WP_THREADS) void beam_row_warp_kernel(BeamDev p) {
     __shared__ float red[WP_THREADS / 64];
     if (*p.done) return;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(WP_THREADS) void beam_row_warp_kernel(BeamDev p) {
         return lp * inv_temp;
     };
     (void)inv_pen;
-    const WarpStats w = row_warp_stats<false>(sc, p.V, p.top_k, p.top_p, 2, red);   // min_tokens_to_keep = 2 under beams
+    const WarpStats w = row_warp_stats<false, SELECT>(sc, p.V, p.top_k, p.top_p, 2, red);   // min_tokens_to_keep = 2 under beams
     if (threadIdx.x == 0) {
         float* o = p.warp + (size_t)row * 8;
         o[0] = w.kth; o[1] = w.mx; o[2] = w.invZ; o[3] = w.v0; o[4] = w.smin;
@@ -448,7 +450,12 @@ void BeamScorer::enqueue_step(const float* logits, int ld, int logit_div, hipStr
     if (!pen) a.seen = nullptr;
     const int per = (((c.V + BM_SPLIT - 1) / BM_SPLIT) + 3) & ~3;
     beam_row_stats_kernel<<<dim3(R, BM_SPLIT), 256, 0, st>>>(a);
-    if (c.do_sample) beam_row_warp_kernel<<<R, WP_THREADS, 0, st>>>(a);
+    if (c.do_sample) {
+        // SV_BEAM_WARP_SELECT=0: the bisection form at every top_k (A/B switch of warp.h's selection path; read per call, a captured graph keeps its choice)
+        const bool sel = !(getenv("SV_BEAM_WARP_SELECT") && atoi(getenv("SV_BEAM_WARP_SELECT")) == 0);
+        if (sel) beam_row_warp_kernel<true><<<R, WP_THREADS, 0, st>>>(a);
+        else beam_row_warp_kernel<false><<<R, WP_THREADS, 0, st>>>(a);
+    }
     beam_row_topk_kernel<<<dim3(R, BM_SPLIT), 256, (size_t)per * sizeof(float), st>>>(a);
     beam_merge_kernel<<<c.B, 64, 0, st>>>(a);
     beam_update_kernel<<<1, ((c.B + 63) / 64) * 64, 0, st>>>(a);
@@ -519,30 +526,48 @@ __global__ __launch_bounds__(256) void beam_table_reorder_kernel(BeamKvArgs a) {
     }
 }
 
-// grid (R, n_layer * n_kv): phase 0 parent's tail page -> staging, phase 1 staging -> the row's own tail page
-__global__ __launch_bounds__(256) void beam_tail_copy_kernel(BeamKvArgs a, int phase) {
+// grid (B, n_layer * n_kv, BM_TAIL_Z): the tail pages of ONE request's beams for one (layer, KV head), a slice of the page per z.  The beams of a
+// request permute among themselves, so a page may be both a source and a destination; a THREAD moves the same 16-byte pieces of every beam -- all its
+// loads, then all its stores -- and no other thread touches those pieces: one launch, no staging copy (rounds 1-5 ran two launches over a staging
+// buffer: stage, then commit; 2 x 11.8 us per decode step at 64 rows).
+#define BM_TAIL_Z 4
+__global__ __launch_bounds__(256) void beam_tail_copy_kernel(BeamKvArgs a) {
     if (*a.done) return;
     const int L = bm_cached_len(a);
     if (L % SV_PAGE_TOKENS == 0) return;           // the tail page is empty
-    const int r = blockIdx.x, src_row = a.parent[r];
-    if (src_row == r) return;
+    const int b = blockIdx.x, nb = a.nb;
+    int src[BM_MAXNB];
+    bool any = false;
+#pragma unroll
+    for (int j = 0; j < BM_MAXNB; ++j) {
+        src[j] = -1;
+        if (j < nb) {
+            const int r = b * nb + j, sr = a.parent[r];
+            if (sr != r) { src[j] = sr; any = true; }
+        }
+    }
+    if (!any) return;
     const int pi = L / SV_PAGE_TOKENS;
     const int layer = blockIdx.y / a.n_kv, kvh = blockIdx.y % a.n_kv;
     char* pool = a.kv_pool + (size_t)layer * a.layer_stride + (size_t)kvh * a.kv_head_stride;
-    char* stage = a.staging + ((size_t)r * gridDim.y + blockIdx.y) * a.page_bytes;
-    const size_t own_src = (size_t)src_row * a.need + pi, own_dst = (size_t)r * a.need + pi;
-    const uint4* s = reinterpret_cast<const uint4*>(phase == 0 ? pool + own_src * a.page_bytes : stage);
-    uint4* dst = reinterpret_cast<uint4*>(phase == 0 ? stage : pool + own_dst * a.page_bytes);
-    for (int i = threadIdx.x; i < a.page_bytes / 16; i += 256) dst[i] = s[i];
+    const int n16 = (int)(a.page_bytes / 16), per = (n16 + BM_TAIL_Z - 1) / BM_TAIL_Z;
+    const int beg = blockIdx.z * per, end = min(beg + per, n16);
+    for (int i = beg + threadIdx.x; i < end; i += 256) {
+        uint4 v[BM_MAXNB];
+#pragma unroll
+        for (int j = 0; j < BM_MAXNB; ++j)
+            if (src[j] >= 0) v[j] = reinterpret_cast<const uint4*>(pool + ((size_t)src[j] * a.need + pi) * a.page_bytes)[i];
+#pragma unroll
+        for (int j = 0; j < BM_MAXNB; ++j)
+            if (src[j] >= 0) reinterpret_cast<uint4*>(pool + ((size_t)(b * nb + j) * a.need + pi) * a.page_bytes)[i] = v[j];
+    }
 }
 
 void launch_beam_table_reorder(const BeamKvArgs& a, hipStream_t st) {
     beam_table_reorder_kernel<<<a.B, 256, (size_t)a.nb * a.max_pages * sizeof(int32_t), st>>>(a);
 }
 void launch_beam_tail_copy(const BeamKvArgs& a, hipStream_t st) {
-    const dim3 grid(a.B * a.nb, a.n_layer * a.n_kv);
-    beam_tail_copy_kernel<<<grid, 256, 0, st>>>(a, 0);
-    beam_tail_copy_kernel<<<grid, 256, 0, st>>>(a, 1);
+    beam_tail_copy_kernel<<<dim3(a.B, a.n_layer * a.n_kv, BM_TAIL_Z), 256, 0, st>>>(a);
 }
 
 }  // namespace sv

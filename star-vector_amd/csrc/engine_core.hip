@@ -327,7 +327,6 @@ extern "C" int sv_destroy(sv_engine* e) {
     if (e->gen_graph) (void)hipGraphDestroy(e->gen_graph);
     if (e->gen_gexec_multi) (void)hipGraphExecDestroy(e->gen_gexec_multi);
     if (e->gen_graph_multi) (void)hipGraphDestroy(e->gen_graph_multi);
-    if (e->beam_staging) (void)hipFree(e->beam_staging);
     if (e->score_ws) (void)hipFree(e->score_ws);
     if (e->h_flags) (void)hipHostFree(e->h_flags);
     if (e->h_table) (void)hipHostFree(e->h_table);

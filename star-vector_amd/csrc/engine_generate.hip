@@ -86,13 +86,6 @@ static int generate_beam(sv_engine* e, const void* dev_embeds, int B, int S0, co
         if (r) return fail(SV_ENOMEM, "beam scorer allocation failed (hip error %d)", r);
     }
     e->beam.c = bc;
-    const size_t stage_bytes = (size_t)R * c.n_layer * e->nkv * e->page_bytes;
-    if (stage_bytes > e->beam_staging_bytes) {
-        if (e->beam_staging) (void)hipFree(e->beam_staging);
-        e->beam_staging = nullptr; e->beam_staging_bytes = 0;
-        HIPCHECK(hipMalloc(reinterpret_cast<void**>(&e->beam_staging), stage_bytes));
-        e->beam_staging_bytes = stage_bytes;
-    }
     // prompt pass over the B requests, written into the pages of each request's first beam row
     SVCHECK(upload_beam_table(e, B, nb, need, 0, true, st));
     SVCHECK(prefill_forward(e, (const bf16_t*)dev_embeds, B, S0, st));
@@ -107,7 +100,7 @@ static int generate_beam(sv_engine* e, const void* dev_embeds, int B, int S0, co
     kv.block_table = e->block_table; kv.max_pages = e->pages_per_seq; kv.need = need; kv.parent = e->beam.d.parent;
     kv.step = e->d_step; kv.done = e->d_done; kv.S0 = S0; kv.L_fixed = S0; kv.B = B; kv.nb = nb;
     kv.kv_pool = e->kv_pool; kv.layer_stride = e->layer_stride; kv.kv_head_stride = e->kv_head_stride;
-    kv.n_layer = c.n_layer; kv.n_kv = e->nkv; kv.page_bytes = e->page_bytes; kv.staging = e->beam_staging;
+    kv.n_layer = c.n_layer; kv.n_kv = e->nkv; kv.page_bytes = e->page_bytes;
     launch_beam_tail_copy(kv, st);              // the prompt's tail page fans out to beams 1.. (parent = first beam row)
     kv.L_fixed = -1;
     beam_step(e, kv, nb, st);                   // first token: every beam of a request reads the request's logits row

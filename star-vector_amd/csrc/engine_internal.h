@@ -159,10 +159,8 @@ struct sv_engine {
     int pages_per_seq = 0, num_pages = 0, page_bytes = 0;
     int32_t* block_table = nullptr;
     std::vector<int> free_pages;
-    // beam search (num_beams > 1): device scorer + staging for the tail-page copies
+    // beam search (num_beams > 1): device scorer
     BeamScorer beam;
-    char* beam_staging = nullptr;
-    size_t beam_staging_bytes = 0;
     bf16_t* score_ws = nullptr;      // scoring forward: kept hidden rows, their ln_f, bf16 logits [rows][Vpad]
     size_t score_elems = 0;
     int cached_B = 0;

@@ -175,6 +175,178 @@ __device__ WarpStats row_warp_stats_regs(F sc, int V, int top_k, float top_p, in
     return w;
 }
 
+// ------------------------------------------------------------------------------------------------
+// TopK by SELECTION for the register form (0 < top_k <= 256: HF's effective default is top_k = 50, so the reference's default
+// generate_im2svg call -- beam-sample, num_beams 2, top-p 0.9 -- runs TopK 50 THEN TopP on every beam row of every step).  The two bisections above
+// are 32 + 30 sweeps of NPT register values per thread, each with a block reduction: ~140 us per decode step at 64 rows x 49157 columns.  After
+// TopK only ~k scores are alive, so (the sampler's scheme, sampling.hip::sample_row_topk, on the values already in registers):
+//   1. T0 = the k-th largest of the 1024 THREAD maxima (8-bit MSB-first radix select, one key per thread): k distinct elements are >= T0, so
+//      the row's k-th largest is too -- everything >= T0 is a candidate, ~k of them
+//   2. the candidates' keys go to LDS in thread order; kth = the key with #(greater) < k <= #(greater or equal)  (= what the bisection finds:
+//      the largest threshold that still keeps k scores; ties at the k-th value all survive)
+//   3. Z: the SAME register sweep and block sum as above (invZ bit-identical); the candidates' e = exp(s - mx) ride to LDS with it
+//   4. TopP on the candidates: F(c) = mass of candidates with p <= p_c (summed in LDS order), v0 = the smallest p_c with F(c) > 1 - top_p,
+//      1.0 when there is none -- the bisection's fixed point, with another (fixed) summation order inside F
+// Returns false, block-uniformly, when the row is outside its scope (no finite maximum, more than WS_CAP candidates: ties across T0): the
+// caller takes the bisections.
+// ------------------------------------------------------------------------------------------------
+#define WS_CAP 1024
+struct WarpSelSmem {
+    uint32_t key[WS_CAP];
+    float p[WS_CAP];
+    int hist[256];
+    int wtot[WP_THREADS / 64];
+    uint32_t sel_key;
+    int sel_need;
+};
+__device__ __forceinline__ WarpSelSmem& warp_sel_smem() {
+    __shared__ WarpSelSmem s;
+    return s;
+}
+
+template <int NPT, class F>
+__device__ bool row_warp_stats_select(F sc, int V, int top_k, float top_p, int min_keep, float* red, WarpStats& w) {
+    WarpSelSmem& sm = warp_sel_smem();
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k = top_k > min_keep ? top_k : min_keep;                 // the caller checked 0 < top_k, k <= 256, k < V
+    float v[NPT];
+    float t1 = -INFINITY, t2 = -INFINITY;                              // this thread's largest and second largest score
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int i = tid + j * WP_THREADS;
+        v[j] = i < V ? sc(i) : -INFINITY;
+        if (i < V) {
+            if (v[j] > t1) { t2 = t1; t1 = v[j]; } else if (v[j] > t2) t2 = v[j];
+        }
+        if ((j & 7) == 7) __builtin_amdgcn_sched_barrier(0);
+    }
+    const float mx = wp_block_max(t1, red);
+    if (!(mx > -INFINITY) || !(mx < INFINITY)) return false;
+    w.mx = mx;
+    w.smin = mx;
+    if (min_keep >= 2) {
+        float cnt2 = t1 == mx ? (t2 == mx ? 2.f : 1.f) : 0.f;
+        float below = t1 == mx ? (t2 == mx ? -INFINITY : t2) : t1;
+        cnt2 = wp_block_sum(cnt2, red);
+        below = wp_block_max(below, red);
+        if (cnt2 < 2.f) w.smin = below;
+    }
+
+    // ---- 1. T0 = the k-th largest thread maximum ----
+    const uint32_t mkey = wp_key(t1);
+    uint32_t prefix = 0u;
+    int need = k;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) sm.hist[tid] = 0;
+        __syncthreads();
+        if (pass == 0 || (mkey >> (shift + 8)) == prefix) atomicAdd(&sm.hist[(mkey >> shift) & 255u], 1);
+        __syncthreads();
+        if (tid < 64) {                                                // lane l owns bins 255 - 4l .. 252 - 4l (descending keys)
+            const int b0 = 255 - 4 * tid;
+            const int h0 = sm.hist[b0], h1 = sm.hist[b0 - 1], h2 = sm.hist[b0 - 2], h3 = sm.hist[b0 - 3];
+            const int sum4 = h0 + h1 + h2 + h3;
+            int inc = sum4;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(inc, o, 64);
+                if (tid >= o) inc += t;
+            }
+            int above = inc - sum4;
+            if (above < need && need <= inc) {
+                int d = b0;
+                if (need > above + h0) {
+                    above += h0; d = b0 - 1;
+                    if (need > above + h1) {
+                        above += h1; d = b0 - 2;
+                        if (need > above + h2) { above += h2; d = b0 - 3; }
+                    }
+                }
+                sm.sel_key = (prefix << 8) | (uint32_t)d;
+                sm.sel_need = need - above;
+            }
+        }
+        __syncthreads();
+        prefix = sm.sel_key;
+        need = sm.sel_need;
+    }
+    const float T0 = wp_unkey(prefix);                                 // a thread maximum: finite or -inf, never NaN
+
+    // ---- 2. candidates (>= T0, float compare: a NaN is none) into LDS, thread order ----
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) cnt += v[j] >= T0 ? 1 : 0;
+    int inc = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += t;
+    }
+    __syncthreads();
+    if (lane == 63) sm.wtot[wave] = inc;
+    __syncthreads();
+    int off = inc - cnt, n = 0;
+#pragma unroll
+    for (int w2 = 0; w2 < WP_THREADS / 64; ++w2) {
+        const int t = sm.wtot[w2];
+        off += w2 < wave ? t : 0;
+        n += t;
+    }
+    if (n > WS_CAP || n < k) return false;                             // block-uniform
+    {
+        int q = off;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j)
+            if (v[j] >= T0) sm.key[q++] = wp_key(v[j]);
+    }
+    __syncthreads();
+    if (tid < n) {
+        const uint32_t kc = sm.key[tid];
+        int gt = 0, ge = 0;
+        for (int j = 0; j < n; ++j) {
+            const uint32_t kj = sm.key[j];
+            gt += kj > kc ? 1 : 0;
+            ge += kj >= kc ? 1 : 0;
+        }
+        if (gt < k && k <= ge) sm.sel_key = kc;                        // every writer writes the same key
+    }
+    __syncthreads();
+    w.kth = wp_unkey(sm.sel_key);
+
+    // ---- 3. Z exactly as the bisection form sums it; the candidates' e to LDS ----
+    float z = 0.f;
+    {
+        int q = off;
+#pragma unroll
+        for (int j = 0; j < NPT; ++j) {
+            const bool cand = v[j] >= T0;
+            const float e = (v[j] >= w.kth && v[j] > -INFINITY) ? __expf(v[j] - mx) : (v[j] == mx ? 1.f : 0.f);
+            z += e;
+            if (cand) sm.p[q++] = e;
+        }
+    }
+    z = wp_block_sum(z, red);
+    w.invZ = 1.0f / z;
+
+    // ---- 4. TopP on the candidates ----
+    w.v0 = 0.f;
+    if (top_p < 1.0f) {
+        const float cut = 1.0f - top_p;
+        const float pc = tid < n ? sm.p[tid] * w.invZ : 0.f;
+        __syncthreads();
+        if (tid < n) sm.p[tid] = pc;
+        __syncthreads();
+        float v0c = 1.0f;                                              // the bisection's upper end: nothing exceeds the cut -> 1.0
+        if (pc > 0.f) {
+            float f = 0.f;
+            for (int j = 0; j < n; ++j) { const float pj = sm.p[j]; f += pj <= pc ? pj : 0.f; }
+            if (f > cut) v0c = pc;
+        }
+        w.v0 = -wp_block_max(-v0c, red);
+    }
+    return true;
+}
+
 template <class F>
 __device__ WarpStats row_warp_stats_global(F sc, int V, int top_k, float top_p, int min_keep, float* red) {
     const int tid = threadIdx.x;
@@ -237,12 +409,19 @@ __device__ WarpStats row_warp_stats_global(F sc, int V, int top_k, float top_p, 
 }
 
 // REGS = false keeps every pass on `sc` (beam-sample: its score functor is heavier and the register copy spills)
-template <bool REGS = true, class F>
+template <bool REGS = true, bool SELECT = true, class F>
 __device__ WarpStats row_warp_stats(F sc, int V, int top_k, float top_p, int min_keep, float* red) {
     if (!REGS) {
         // beam-sample: one evaluation of the (heavy) score functor per element, everything else on registers -- the all-passes-on-`sc` form took
         // 317 us per decode step at 64 rows x 49157 columns (rocprof, BASELINE config 2 with num_beams 2: 17 % of the step)
-        if (V <= 49 * WP_THREADS) return row_warp_stats_regs<49, true>(sc, V, top_k, top_p, min_keep, red);       // StarVector: 49156 / 49157 columns
+        if (V <= 49 * WP_THREADS) {                                                                                 // StarVector: 49156 / 49157 columns
+            const int k = top_k > min_keep ? top_k : min_keep;
+            if (SELECT && top_k > 0 && k <= 256 && k < V) {
+                WarpStats w;
+                if (row_warp_stats_select<49>(sc, V, top_k, top_p, min_keep, red, w)) return w;
+            }
+            return row_warp_stats_regs<49, true>(sc, V, top_k, top_p, min_keep, red);
+        }
         return row_warp_stats_global(sc, V, top_k, top_p, min_keep, red);
     }
     if (V <= 16 * WP_THREADS) return row_warp_stats_regs<16>(sc, V, top_k, top_p, min_keep, red);

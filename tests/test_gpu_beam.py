@@ -399,3 +399,54 @@ def test_generate_beam_sample_end_to_end():
     print(f"[beam-sample e2e] {outside} of {total} kept continuations outside the oracle's (slightly widened) support")
     assert outside <= max(1, total // 50)
     eng.close()
+
+
+def test_beam_sample_warper_selection_path_at_full_vocabulary():
+    """beam_row_warp_kernel at StarVector's vocabulary with HF's effective default top_k = 50 (warp.h::row_warp_stats_select:
+    TopK by selection among the thread maxima, TopP on the ~k survivors) against (a) the bisection form it replaces
+    (SV_BEAM_WARP_SELECT=0: same kept beams, tokens and scores on the same seeds) and (b) the oracle's warped support
+    (HF's warper classes, min_tokens_to_keep = 2).  Rows: random scores at three scales, scores quantised so that ties straddle
+    the k-th value, a row whose top scores are all equal (more candidates than the selection's scope: it falls back)."""
+    V, nb, B = 49157, 2, 8
+    R = B * nb
+    g = torch.Generator().manual_seed(41)
+    rows = torch.randn(R, V, generator=g)
+    rows[0:4] *= 0.5
+    rows[4:8] *= 3.0
+    rows[8:12] = torch.round(rows[8:12] * 4.0) / 4.0                  # ~20 distinct levels: ties across the 50th value
+    rows[12:14] = 0.0                                                 # flat: every score ties
+    rows[14:16] *= 8.0                                                # peaked: top-p keeps a handful
+    logits = rows.contiguous().to(dev())
+    lp = torch.log_softmax(rows, -1)
+    for T, tp, tk in ((1.0, 0.9, 50), (0.7, 0.5, 50), (1.0, 0.95, 200), (1.3, 0.9, 2)):
+        # HF's TopP sorts and cuts inside a group of TIED probabilities wherever its sort put them; the device keeps a tie group whole
+        # (p >= v0), so the support is closed over equal scores -- and taken a hair wider in top-p / top-k for the boundary token
+        sup = O.warp_scores(lp, T, tp + 0.01, tk, 2)
+        if tk > 2:
+            sup = torch.maximum(sup, O.warp_scores(lp, T, tp + 0.01, tk + 1, 2))
+        floor = torch.where(sup > float("-inf"), sup, torch.full_like(sup, float("inf"))).min(-1, keepdim=True).values
+        support = (lp / T) >= floor - 1e-6
+        outs = {}
+        for mode in ("1", "0"):
+            os.environ["SV_BEAM_WARP_SELECT"] = mode
+            try:
+                got = []
+                for seed in range(6):
+                    sc = HipBeamScorer(B, nb, V, 4, -1, 0, early_stopping=False, do_sample=True, temperature=T, top_p=tp,
+                                       top_k=tk, seed=seed)
+                    done, par, tok, run = sc.step(logits)
+                    sc.close()
+                    assert not done
+                    got.append((par, tok, run))
+                outs[mode] = got
+            finally:
+                del os.environ["SV_BEAM_WARP_SELECT"]
+        n_out = n_tot = 0
+        for (p1, t1, r1), (p0, t0, r0) in zip(outs["1"], outs["0"]):
+            assert torch.equal(p1, p0) and torch.equal(t1, t0) and torch.equal(r1, r0), (T, tp, tk)
+            # first step: only beam 0 of a request is live, so every continuation descends from row b * nb
+            inside = support[p1.long(), t1.long()]
+            n_out += int((~inside).sum()); n_tot += inside.numel()
+        print(f"[beam-sample warper] T {T} top_p {tp} top_k {tk}: selection == bisection on 6 seeds x {R} rows; "
+              f"{n_out} of {n_tot} kept continuations outside the oracle's support")
+        assert n_out == 0
