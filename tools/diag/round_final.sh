@@ -1,5 +1,6 @@
-bash tools/gpu_round_start.sh r06j pytest smoke bench bench8b rocprof pmc ctx 2>&1 | tail -30
-OUT=gpurun_out/r06j
+TAG="${1:-r06k}"
+bash tools/gpu_round_start.sh ${TAG} pytest smoke bench bench8b rocprof pmc ctx 2>&1 | tail -30
+OUT=gpurun_out/${TAG}
 timeout 400 python bench.py --beams 2 --sample --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_beam2_n1.json 2> $OUT/beam2.err
 timeout 300 python bench.py --no-cpu-baseline --new-tokens 256 > $OUT/bench_n1_256tok.json 2> $OUT/b256.err
 timeout 400 python bench.py --no-cpu-baseline --new-tokens 4096 --steps 2 > $OUT/bench_n1_4096tok.json 2> $OUT/b4096.err
