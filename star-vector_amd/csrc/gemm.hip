@@ -1606,6 +1606,141 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
 }
 
 // ------------------------------------------------------------------------------------------------
+// gemm_head_persist_kernel (round 6, fourth session): the lm_head of a <= 32-row decode step as ONE round of blocks that each walk several
+// column tiles.  gemm_skinny_kernel<8, false, true> runs 1537 blocks of one 32-column tile (StarVector-1B: K = 2048, 16 k-steps per wave) --
+// six rounds on 256 CUs, and in every block a wave's whole life is 16 weight loads between a ramp (its 16 KiB of the activations out of L2
+// again: as many bytes as the weights) and a drain (LDS reduction, epilogue): 42.6 us for 201 MB = 4.7 TB/s.  Here
+//   * a wave's share of the ACTIVATIONS (16 k-steps x 16 B per lane = 64 VGPRs) is loaded once per block and stays in registers: the L2 -> CU side
+//     carries weights only;
+//   * the weights roll through 16 registers per lane: the load of k-step u of the block's NEXT tile is issued right behind the MFMA that consumed
+//     k-step u of this one -- 16 KiB per wave, 128 KiB per CU always in flight, across the tile boundaries (reduction and epilogue of tile i run
+//     under the stream of tile i + 1);
+//   * the ragged last tile (V = 49156: 4 valid columns) reads only those columns' pieces (the other lanes' addresses fold onto them, their
+//     registers are zeroed behind the load: what the zero-padded image holds);
+//   * the greedy selection's per-row key is kept in registers across the block's tiles: one atomic max per row and BLOCK.
+// Same per-wave k ranges, same MFMA order, same cross-wave sum (wave order), same rounding and stores as the one-tile kernel: bit-identical logits
+// and selection (tests/test_gpu_ops.py).  Scope (launcher): F32 mode, one row tile, bf16 weights, K / 16 == 128, split-K 1.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void gemm_head_persist_kernel(const bf16_t* Wp_, const bf16_t* xp_, int KS_, int ks_per_split_, int n_tiles_, SkinnyArgs p_unused) {
+    constexpr int WAVES = 8, RPW = 2, KSW = 16;            // k-steps per wave: KS_ == WAVES * KSW (launcher)
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(sk_smem);          // [WAVES][16][64]
+    unsigned long long* key_s = reinterpret_cast<unsigned long long*>(sk_smem + (size_t)WAVES * 16 * 64 * 4);      // [WAVES][32]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, half = lane >> 5;
+    const int KS = KS_, ks0 = wave * KSW, G = gridDim.x, n_tiles = n_tiles_;
+    (void)ks_per_split_;
+
+    u32x4 x[KSW], w[KSW];
+    {
+        const u32x4* xptr = reinterpret_cast<const u32x4*>(xp_) + (size_t)ks0 * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < KSW; ++u) x[u] = xptr[(size_t)u * 64];
+    }
+    const u32x4* wbase = reinterpret_cast<const u32x4*>(Wp_) + (size_t)ks0 * 64;
+    int nt = blockIdx.x;
+#pragma unroll
+    for (int u = 0; u < KSW; ++u) w[u] = __builtin_nontemporal_load(wbase + ((size_t)nt * KS + u) * 64 + lane);
+
+    SkinnyArgs p = sv_late_args<SkinnyArgs>(offsetof(SkinnyKernarg, p));
+    if (p.poison) {                                          // SkinnyArgs::poison: fire and forget (gemm_skinny_kernel<.., HEAD>)
+        const unsigned off = (blockIdx.x * (unsigned)(WAVES * 64) + (unsigned)tid) * 16u;
+        if (off < p.poison_bytes) {
+            const __amdgpu_buffer_rsrc_t rsp = __builtin_amdgcn_make_buffer_rsrc(p.poison, 0, p.poison_bytes, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu}, rsp, (int)off, 0, 16);      // sc1: write-through
+        }
+    }
+    const int ragged_cols = p.N - (n_tiles - 1) * 32;        // valid columns of the last tile (32: none missing)
+    unsigned long long key = 0ull;
+    const float bias0[RPW] = {0.f, 0.f};
+
+    // one tile: 16 MFMAs; REFILL: each consumed register is re-requested for tile `nn` (lane address `ln`: folded for the ragged tile)
+    auto tile = [&](auto refill_tag, int nn, int ln) {
+        constexpr bool REFILL = decltype(refill_tag)::value;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const u32x4* nsrc = wbase + (size_t)nn * KS * 64 + ln;
+#pragma unroll
+        for (int u = 0; u < KSW; ++u) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(w[u]), as_frag4(x[u]), acc, 0, 0, 0);
+            if constexpr (REFILL) w[u] = __builtin_nontemporal_load(nsrc + (size_t)u * 64);
+        }
+        // K reduction across the waves (wave order), every wave finishes RPW accumulator rows; epilogue = sk_store's F32 mode
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+        __syncthreads();
+        float v[RPW];
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            const int r = wave * RPW + i;
+            float t = red[0][r][lane];
+#pragma unroll
+            for (int q = 1; q < WAVES; ++q) t += red[q][r][lane];
+            v[i] = t;
+        }
+        sk_store<RPW>(p, v, bias0, wave * RPW, nt, 0, 0, m, half);
+        if (p.amax) {
+#pragma unroll
+            for (int i = 0; i < RPW; ++i) {
+                const int r = wave * RPW + i;
+                const int n = nt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                if (n < p.N) { const unsigned long long k = sv_amax_key(v[i], (unsigned)n); key = k > key ? k : key; }
+            }
+        }
+        __syncthreads();                                     // red is free for the next tile
+    };
+    for (; nt + G < n_tiles; nt += G) {
+        const int nn = nt + G;
+        const bool rag = nn == n_tiles - 1 && ragged_cols < 32;          // block-uniform
+        const int ln = rag ? ((half << 5) | (m % ragged_cols)) : lane;
+        tile(std::true_type{}, nn, ln);
+        if (rag) {                                           // the lanes of the missing columns: zero, as the padded image has it (the loads land here)
+            if (m >= ragged_cols) {
+#pragma unroll
+                for (int u = 0; u < KSW; ++u) w[u] = u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    }
+    tile(std::false_type{}, 0, 0);
+
+    if (p.amax) {
+        { const unsigned long long o = __shfl_xor(key, 32, 64); key = o > key ? o : key; }
+        if (half == 0) key_s[wave * 32 + m] = key;
+        __syncthreads();
+        if (wave == 0 && half == 0 && m < p.amax_rows) {
+#pragma unroll
+            for (int q = 1; q < WAVES; ++q) { const unsigned long long o = key_s[q * 32 + m]; key = o > key ? o : key; }
+            (void)__hip_atomic_fetch_max(p.amax + (size_t)m * SV_AMAX_STRIDE, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+std::atomic<int> g_head_persist{1};     // 1: the lm_head of a one-row-tile step through gemm_head_persist_kernel where it applies; 0: the one-tile kernel (A/B)
+void set_head_persist(int on) { g_head_persist = on; }
+// false: outside the kernel's scope
+static bool launch_head_persist(const SkinnyArgs& a, hipStream_t st) {
+    const char* ev = getenv("SV_HEAD_PERSIST");             // read per call (A/B in one process; a captured graph keeps its choice)
+    const int env = ev ? atoi(ev) : -1;
+    const int on = env >= 0 ? env : g_head_persist.load(std::memory_order_relaxed);
+    if (!on) return false;
+    const int n_tiles = a.Npad / 32;
+    if (a.out_mode != SK_OUT_F32 || a.MT != 1 || a.Wq || a.splitk != 1 || a.K / 16 != 128 || n_tiles < 512 || a.fold_c1) return false;
+    if (a.N <= (n_tiles - 1) * 32 || a.N > n_tiles * 32) return false;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return false;
+        cus = pr.multiProcessorCount;
+    }
+    const int G = cus < n_tiles ? cus : n_tiles;
+    if (a.poison && (size_t)G * 512 * 16 < a.poison_bytes) return false;      // the pattern stores are 16 bytes per thread of the grid
+    gemm_head_persist_kernel<<<G, 512, 8 * 16 * 64 * 4 + 8 * 32 * 8, st>>>(a.Wp, a.xp, a.K / 16, a.K / 16, n_tiles, a);
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------
 // mlp_fused_kernel: the MLP half of a decode layer (gpt_bigcode/modeling_gpt_bigcode.py:645-660: c_fc -> GELU-tanh -> c_proj) as ONE
 // launch of F/32 co-resident blocks (256 for StarVector-1B, one 8-wave block per CU), instead of gemm_skinny_kernel<8, true> (folded
 // c_fc) and gemm_skinny_kernel<8, false> (down projection, split-K slabs) with a kernel boundary between them.  Round 4; on for an
@@ -2488,6 +2623,7 @@ void skinny_plan(int Npad, int K, int splitk, int fp8, int MT, int* waves, int* 
 }
 
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st) {
+    if (launch_head_persist(a, st)) return;                      // the lm_head of a <= 32-row step: one round of blocks over several column tiles each
     if (launch_gemm_skinny_mt2(a, st)) return;                  // 33..64 rows: two row tiles per block, weights streamed once
     if (a.Wq && launch_gemm_skinny_fp8(a, st)) return;       // fp8 weights: its own kernel (falls through if unsupported)
     dim3 grid(a.Npad / 32, a.splitk, a.MT);

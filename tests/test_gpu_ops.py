@@ -422,6 +422,38 @@ def test_lm_head_with_folded_greedy_selection(V):
     assert torch.equal(idx3, lg3.cpu().argmax(-1))
 
 
+@pytest.mark.parametrize("V,M", [(49156, 32), (49157, 32), (49156, 13), (49152, 1)])
+def test_lm_head_persistent_blocks_bit_identical_to_one_tile_blocks(V, M):
+    """Round 6 (fourth session): the lm_head of a <= 32-row step as one round of blocks that each walk several column tiles
+    (gemm.hip gemm_head_persist_kernel: the wave's activation share in registers, the weights rolling through 16 registers per lane,
+    the ragged last tile read column by column, one atomic max per row and BLOCK) against the 1537 one-tile blocks it replaces
+    (SV_HEAD_PERSIST=0): logits and folded arg-max bit for bit, with ties, a NaN row and the vocabulary's ragged tile."""
+    g = torch.Generator().manual_seed(90 + V + M)
+    K = 2048
+    x = torch.randn(M, K, generator=g).bfloat16()
+    W = (torch.randn(V, K, generator=g) / K ** 0.5).bfloat16()
+    W[V - 1] = W[7]                                   # a tie between column 7 and the last column (the ragged tile when V = 49156 / 49157)
+    W[V - 3] = 0.5 * W[V - 3]
+    if M > 6:
+        x[6] = float("nan")
+    outs = {}
+    for mode in ("1", "0"):
+        os.environ["SV_HEAD_PERSIST"] = mode
+        try:
+            lg, idx = E.op_lm_head_argmax(bf(x), bf(W))
+            plain = E.op_linear_skinny_epi(bf(x), bf(W), out_f32=True)
+            outs[mode] = (lg.cpu(), idx, plain.cpu())
+        finally:
+            del os.environ["SV_HEAD_PERSIST"]
+    a, b = outs["1"], outs["0"]
+    ok = [m for m in range(M) if m != 6]
+    assert torch.equal(a[0][ok], b[0][ok]) and torch.equal(a[2][ok], b[2][ok]) and torch.equal(a[1], b[1])
+    assert torch.equal(a[0][ok], a[2][ok])
+    assert torch.equal(a[1][ok], a[0][ok].argmax(-1))
+    if M > 6:
+        assert bool(torch.isnan(a[0][6]).all()) and int(a[1][6]) == 0x7fffffff
+
+
 def test_top_p_sampler_distribution():
     """Distributional parity with HF's temperature -> top-p -> multinomial (torch's RNG stream itself is
     not reproducible in a custom kernel)."""

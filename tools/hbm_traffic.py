@@ -8,7 +8,7 @@ streaming read (16 B per lane) -> doubled; WRITE_SIZE taken as is; separate pass
 import json
 import sys
 
-FAMILY = ("gemm_skinny_kernel", "gemm_cols_resid_kernel", "mlp_fused_kernel", "rowln_cattn_kernel")
+FAMILY = ("gemm_skinny_kernel", "gemm_head_persist_kernel", "gemm_cols_resid_kernel", "mlp_fused_kernel", "rowln_cattn_kernel")
 
 
 def family(path, counter):

@@ -8,11 +8,11 @@ import csv
 import json
 import sys
 
-FAMILY = ("gemm_skinny_kernel", "gemm_cols_resid_kernel", "mlp_fused_kernel", "rowln_cattn_kernel")
+FAMILY = ("gemm_skinny_kernel", "gemm_head_persist_kernel", "gemm_cols_resid_kernel", "mlp_fused_kernel", "rowln_cattn_kernel")
 rows = [r for r in csv.DictReader(open(sys.argv[1])) if any(f in r["kernel"] for f in FAMILY)]
 calls = sum(int(r["calls"]) for r in rows)
 total = sum(float(r["total_us"]) for r in rows)
-steps = max(int(r["calls"]) for r in rows if "mlp_fused_kernel" in r["kernel"] or "gemm_skinny" in r["kernel"]) if rows else 0
+steps = max(int(r["calls"]) for r in rows if "mlp_fused_kernel" in r["kernel"] or "gemm_skinny" in r["kernel"] or "gemm_head_persist" in r["kernel"]) if rows else 0
 out = {"family": list(FAMILY), "launches": calls, "total_us": round(total, 1), "avg_launch_us": round(total / max(calls, 1), 3),
        "by_kernel": {f'{r["kernel"]} grid {r["grid_x"]}x{r["grid_y"]}': {"calls": int(r["calls"]), "avg_us": float(r["avg_us"])} for r in rows},
        "source": sys.argv[1], "measured": sys.argv[2] if len(sys.argv) > 2 else ""}
