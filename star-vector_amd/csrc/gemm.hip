@@ -1621,11 +1621,14 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
 // Same per-wave k ranges, same MFMA order, same cross-wave sum (wave order), same rounding and stores as the one-tile kernel: bit-identical logits
 // and selection (tests/test_gpu_ops.py).  Scope (launcher): F32 mode, one row tile, bf16 weights, K / 16 == 128, split-K 1.
 // ------------------------------------------------------------------------------------------------
+//   MT = row tiles (1: <= 32 rows; 2: 33..64 rows -- both tiles' activation shares in registers, 128 VGPRs, every weight register feeds two MFMAs; the
+//        two-row-tile kernels' order: bit-identical to gemm_skinny_mt2x_kernel)
+template <int MT>
 __global__ __launch_bounds__(512) void gemm_head_persist_kernel(const bf16_t* Wp_, const bf16_t* xp_, int KS_, int ks_per_split_, int n_tiles_, SkinnyArgs p_unused) {
     constexpr int WAVES = 8, RPW = 2, KSW = 16;            // k-steps per wave: KS_ == WAVES * KSW (launcher)
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
-    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(sk_smem);          // [WAVES][16][64]
-    unsigned long long* key_s = reinterpret_cast<unsigned long long*>(sk_smem + (size_t)WAVES * 16 * 64 * 4);      // [WAVES][32]
+    float (*red)[WAVES][16][64] = reinterpret_cast<float (*)[WAVES][16][64]>(sk_smem);          // [MT][WAVES][16][64]
+    unsigned long long* key_s = reinterpret_cast<unsigned long long*>(sk_smem + (size_t)MT * WAVES * 16 * 64 * 4);      // [WAVES][32]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1633,11 +1636,12 @@ __global__ __launch_bounds__(512) void gemm_head_persist_kernel(const bf16_t* Wp
     const int KS = KS_, ks0 = wave * KSW, G = gridDim.x, n_tiles = n_tiles_;
     (void)ks_per_split_;
 
-    u32x4 x[KSW], w[KSW];
-    {
-        const u32x4* xptr = reinterpret_cast<const u32x4*>(xp_) + (size_t)ks0 * 64 + lane;
+    u32x4 x[MT][KSW], w[KSW];
 #pragma unroll
-        for (int u = 0; u < KSW; ++u) x[u] = xptr[(size_t)u * 64];
+    for (int mi = 0; mi < MT; ++mi) {
+        const u32x4* xptr = reinterpret_cast<const u32x4*>(xp_) + ((size_t)mi * KS + ks0) * 64 + lane;
+#pragma unroll
+        for (int u = 0; u < KSW; ++u) x[mi][u] = xptr[(size_t)u * 64];
     }
     const u32x4* wbase = reinterpret_cast<const u32x4*>(Wp_) + (size_t)ks0 * 64;
     int nt = blockIdx.x;
@@ -1659,35 +1663,44 @@ __global__ __launch_bounds__(512) void gemm_head_persist_kernel(const bf16_t* Wp
     // one tile: 16 MFMAs; REFILL: each consumed register is re-requested for tile `nn` (lane address `ln`: folded for the ragged tile)
     auto tile = [&](auto refill_tag, int nn, int ln) {
         constexpr bool REFILL = decltype(refill_tag)::value;
-        f32x16 acc;
+        f32x16 acc[MT];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
         const u32x4* nsrc = wbase + (size_t)nn * KS * 64 + ln;
 #pragma unroll
         for (int u = 0; u < KSW; ++u) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(w[u]), as_frag4(x[u]), acc, 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+                acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(w[u]), as_frag4(x[mi][u]), acc[mi], 0, 0, 0);
             if constexpr (REFILL) w[u] = __builtin_nontemporal_load(nsrc + (size_t)u * 64);
         }
         // K reduction across the waves (wave order), every wave finishes RPW accumulator rows; epilogue = sk_store's F32 mode
 #pragma unroll
-        for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[mi][wave][r][lane] = acc[mi][r];
         __syncthreads();
-        float v[RPW];
 #pragma unroll
-        for (int i = 0; i < RPW; ++i) {
-            const int r = wave * RPW + i;
-            float t = red[0][r][lane];
-#pragma unroll
-            for (int q = 1; q < WAVES; ++q) t += red[q][r][lane];
-            v[i] = t;
-        }
-        sk_store<RPW>(p, v, bias0, wave * RPW, nt, 0, 0, m, half);
-        if (p.amax) {
+        for (int mi = 0; mi < MT; ++mi) {
+            float v[RPW];
 #pragma unroll
             for (int i = 0; i < RPW; ++i) {
                 const int r = wave * RPW + i;
-                const int n = nt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
-                if (n < p.N) { const unsigned long long k = sv_amax_key(v[i], (unsigned)n); key = k > key ? k : key; }
+                float t = red[mi][0][r][lane];
+#pragma unroll
+                for (int q = 1; q < WAVES; ++q) t += red[mi][q][r][lane];
+                v[i] = t;
+            }
+            sk_store<RPW>(p, v, bias0, wave * RPW, nt, mi, 0, m, half);
+            if (MT == 1 && p.amax) {
+#pragma unroll
+                for (int i = 0; i < RPW; ++i) {
+                    const int r = wave * RPW + i;
+                    const int n = nt * 32 + 8 * (r >> 2) + 4 * half + (r & 3);
+                    if (n < p.N) { const unsigned long long k = sv_amax_key(v[i], (unsigned)n); key = k > key ? k : key; }
+                }
             }
         }
         __syncthreads();                                     // red is free for the next tile
@@ -1706,7 +1719,7 @@ __global__ __launch_bounds__(512) void gemm_head_persist_kernel(const bf16_t* Wp
     }
     tile(std::false_type{}, 0, 0);
 
-    if (p.amax) {
+    if (MT == 1 && p.amax) {
         { const unsigned long long o = __shfl_xor(key, 32, 64); key = o > key ? o : key; }
         if (half == 0) key_s[wave * 32 + m] = key;
         __syncthreads();
@@ -1726,7 +1739,8 @@ static bool launch_head_persist(const SkinnyArgs& a, hipStream_t st) {
     const int on = env >= 0 ? env : g_head_persist.load(std::memory_order_relaxed);
     if (!on) return false;
     const int n_tiles = a.Npad / 32;
-    if (a.out_mode != SK_OUT_F32 || a.MT != 1 || a.Wq || a.splitk != 1 || a.K / 16 != 128 || n_tiles < 512 || a.fold_c1) return false;
+    if (a.out_mode != SK_OUT_F32 || a.MT < 1 || a.MT > 2 || a.Wq || a.splitk != 1 || a.K / 16 != 128 || n_tiles < 512 || a.fold_c1) return false;
+    if (a.MT == 2 && (a.amax || a.poison)) return false;      // (the folded selection and the pattern stores belong to one-row-tile steps)
     if (a.N <= (n_tiles - 1) * 32 || a.N > n_tiles * 32) return false;
     static int cus = 0;
     if (!cus) {
@@ -1736,7 +1750,8 @@ static bool launch_head_persist(const SkinnyArgs& a, hipStream_t st) {
     }
     const int G = cus < n_tiles ? cus : n_tiles;
     if (a.poison && (size_t)G * 512 * 16 < a.poison_bytes) return false;      // the pattern stores are 16 bytes per thread of the grid
-    gemm_head_persist_kernel<<<G, 512, 8 * 16 * 64 * 4 + 8 * 32 * 8, st>>>(a.Wp, a.xp, a.K / 16, a.K / 16, n_tiles, a);
+    if (a.MT == 2) gemm_head_persist_kernel<2><<<G, 512, 2 * 8 * 16 * 64 * 4 + 8 * 32 * 8, st>>>(a.Wp, a.xp, a.K / 16, a.K / 16, n_tiles, a);
+    else gemm_head_persist_kernel<1><<<G, 512, 8 * 16 * 64 * 4 + 8 * 32 * 8, st>>>(a.Wp, a.xp, a.K / 16, a.K / 16, n_tiles, a);
     return true;
 }
 
@@ -1998,6 +2013,7 @@ int init_gemm_kernels() {
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<16, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
     if (!r) r = init_mt2_attrs();
+    if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_head_persist_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 8 * 16 * 64 * 4 + 8 * 32 * 8);
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<bf16_t>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 2 * G2_BUF);
     if (!r) r = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm256_kernel<float>),

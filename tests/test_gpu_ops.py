@@ -454,6 +454,29 @@ def test_lm_head_persistent_blocks_bit_identical_to_one_tile_blocks(V, M):
         assert bool(torch.isnan(a[0][6]).all()) and int(a[1][6]) == 0x7fffffff
 
 
+@pytest.mark.parametrize("V,M", [(49156, 64), (49157, 40)])
+def test_lm_head_persistent_blocks_two_row_tiles(V, M):
+    """The same launch at 33..64 rows (the reference's default decode: 64 rows; gemm_head_persist_kernel<2>: both row tiles' activation shares in
+    registers, every weight register feeds two MFMAs) against the two-row-tile LDS-ring kernel it replaces (SV_HEAD_PERSIST=0), bit for bit --
+    and each row equal to what a one-row-tile launch gives it."""
+    g = torch.Generator().manual_seed(95 + V + M)
+    K = 2048
+    x = torch.randn(M, K, generator=g).bfloat16()
+    W = (torch.randn(V, K, generator=g) / K ** 0.5).bfloat16()
+    outs = {}
+    for mode in ("1", "0"):
+        os.environ["SV_HEAD_PERSIST"] = mode
+        try:
+            outs[mode] = E.op_linear_skinny_epi(bf(x), bf(W), out_f32=True).cpu()
+            if mode == "1":
+                solo = torch.cat([E.op_linear_skinny_epi(bf(x[:32]), bf(W), out_f32=True).cpu(),
+                                  E.op_linear_skinny_epi(bf(x[32:]), bf(W), out_f32=True).cpu()])
+        finally:
+            del os.environ["SV_HEAD_PERSIST"]
+    assert outs["1"].shape == (M, V) and torch.isfinite(outs["1"]).all()
+    assert torch.equal(outs["1"], outs["0"]) and torch.equal(outs["1"], solo)
+
+
 def test_top_p_sampler_distribution():
     """Distributional parity with HF's temperature -> top-p -> multinomial (torch's RNG stream itself is
     not reproducible in a custom kernel)."""
