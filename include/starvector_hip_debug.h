@@ -61,6 +61,10 @@ int  sv_debug_attn_plan(int32_t max_batch, int32_t n_kv_head, int32_t num_cus, i
  *                             the launch = 32 row blocks + (N / 32) * splitk} -- narrow rows (D <= 2048) need every block resident at once
  *                             (two per CU), wide rows rely on the row blocks being dispatched first.  Host arithmetic, pinned by the CPU tests */
 int  sv_debug_rowln_plan(int32_t D, int32_t N, int32_t splitk, int32_t splitk_ru, int32_t num_cus, int32_t* out3);
+/*   sv_debug_rowln_occupancy  blocks of that launch a CU of the current device holds at once (hipOccupancyMaxActiveBlocksPerMultiprocessor of
+ *                             rowln_cattn_kernel<4, false> / <9, true> for wide != 0): sv_create turns the fused launch off below 2 / 3;
+ *                             needs a GPU */
+int  sv_debug_rowln_occupancy(int32_t wide, int32_t* blocks_per_cu);
 /*   sv_debug_step_plan        what the LAST sv_generate call's decode step actually was, from the engine itself (bench.py's `launches_per_step`
  *                             and roofline captions; ADVICE r05: not re-derived from the configuration): out4 = {kernel nodes of the captured
  *                             decode-step graph (0: no graph, plain launches), 1 if the layers' row update + c_attn ran as one launch,

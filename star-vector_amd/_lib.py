@@ -123,6 +123,7 @@ DEBUG_PROTOTYPES = {
     "sv_debug_gemm_seq_form": (_I, [_I, _I, _I, _I]),
     "sv_debug_attn_plan": (_I, [_I, _I, _I, C.POINTER(_I)]),
     "sv_debug_rowln_plan": (_I, [_I, _I, _I, _I, _I, C.POINTER(_I)]),
+    "sv_debug_rowln_occupancy": (_I, [_I, C.POINTER(_I)]),
     "sv_debug_step_plan": (_I, [_P, C.POINTER(_I)]),
     "sv_debug_attn_trace": (_I, [_P, C.POINTER(C.c_int64), _I]),
     "sv_debug_mlp_trace": (_I, [_P, C.POINTER(C.c_int64), _I]),

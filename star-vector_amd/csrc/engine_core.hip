@@ -597,7 +597,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
         // StarVector-1B, 9 at StarVector-8B: round 5 carried the launch to the 7-launch layer of the wide model), bf16 weights, one row tile
         const Linear& ca = e->dec[0].c_attn; const Linear& dn = e->dec[0].c_proj2;
         e->rc_fused_ok = c.weight_dtype == SV_WEIGHT_BF16 && e->MT == 1 && !ca.fp8 &&
-                         rowln_cattn_fits(D, ca.Npad, ca.Kpad, ca.splitk, dn.splitk, e->num_cus);
+                         rowln_cattn_fits(D, ca.Npad, ca.Kpad, ca.splitk, dn.splitk, e->num_cus) && rowln_cattn_resident(D > 2048);
         // narrow rows (StarVector-1B): the first poll 3.9 us after block start; wide rows (StarVector-8B): the weight stream is the timer and the
         // GEMM blocks' hold-back in front of it measured best at 0 (profiles/rowln_cattn_r05_ab.log, section 8)
         e->rc_delay = D > 2048 ? 0 : 390;

@@ -70,6 +70,12 @@ extern "C" int sv_debug_decode_plan(int32_t rows, int32_t N, int32_t K, int32_t 
     return 0;
 }
 
+extern "C" int sv_debug_rowln_occupancy(int32_t wide, int32_t* blocks_per_cu) {
+    if (!blocks_per_cu) return fail(SV_EINVAL, "sv_debug_rowln_occupancy: null argument");
+    *blocks_per_cu = rowln_cattn_blocks_per_cu(wide != 0);
+    return 0;
+}
+
 extern "C" int sv_debug_attn_plan(int32_t max_batch, int32_t n_kv_head, int32_t num_cus, int32_t* out2) {
     if (!out2 || max_batch < 1 || n_kv_head < 1 || num_cus < 1) return fail(SV_EINVAL, "sv_debug_attn_plan: bad argument");
     out2[0] = attn_max_splits_of(max_batch, n_kv_head, num_cus);

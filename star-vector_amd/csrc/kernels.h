@@ -183,6 +183,8 @@ struct RowCattnArgs {
 int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, int spin_ticks, hipStream_t st, int delay = 390, long long* dbg = nullptr, int layer = 0,
                        int num_cus = 256);
 bool rowln_cattn_fits(int D, int Npad, int K, int splitk, int splitk_ru, int num_cus);
+int rowln_cattn_blocks_per_cu(bool wide);       // hipOccupancyMaxActiveBlocksPerMultiprocessor of the form on the current device
+bool rowln_cattn_resident(bool wide);           // >= 2 (narrow) / 3 (wide) of them: what the launch's waits assume (logs when not)
 
 // ---- embeddings ---------------------------------------------------------------------------------
 void launch_im2col(const bf16_t* img, bf16_t* out, int B, int img_size, int patch, int Kpad, hipStream_t st);

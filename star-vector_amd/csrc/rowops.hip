@@ -1,6 +1,7 @@
 // Row-wise (HBM/L2-bound) kernels of the path: LayerNorm flavours, embeddings, im2col, adapter norms.
 // All loads/stores are 16-byte bf16x8 vectors; statistics in fp32 with wave64 shuffle reductions.
 #include <cstddef>
+#include <cstdio>
 #include <cstring>
 #include "kernels.h"
 
@@ -677,6 +678,28 @@ bool rowln_cattn_fits(int D, int Npad, int K, int splitk, int splitk_ru, int num
     if (D > 8128 || (D & 15) || K != D || !rowln_kpw(K, splitk)) return false;
     if ((NT * splitk) % 8 || NT % (8 / splitk) || splitk_ru < 1 || splitk_ru > 4) return false;
     return D > 2048 || 32 + NT * splitk <= 2 * num_cus;
+}
+// Blocks of the launch a CU really holds at once: the narrow form needs ALL its blocks resident (two per CU), the wide form's first round is
+// three per CU -- both are what __launch_bounds__ asks of the compiler, not something the host arithmetic above can see.  Asked of the runtime once per
+// form on the engine's device (sv_create); a compiler that spills or drops occupancy turns the fused launch off instead of leaving it to the 5 ms give-up.
+int rowln_cattn_blocks_per_cu(bool wide) {
+    static int occ[2] = {-1, -1};
+    int& o = occ[wide ? 1 : 0];
+    if (o < 0) {
+        int n = 0;
+        const size_t smem = (size_t)8 * 16 * 64 * 4 + 64;
+        const hipError_t r = wide ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rowln_cattn_kernel<9, true>, 512, smem)
+                                  : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, rowln_cattn_kernel<4, false>, 512, smem);
+        o = r == hipSuccess ? n : 0;
+    }
+    return o;
+}
+bool rowln_cattn_resident(bool wide) {
+    const int have = rowln_cattn_blocks_per_cu(wide), want = wide ? 3 : 2;
+    if (have >= want) return true;
+    fprintf(stderr, "[starvector_amd] rowln_cattn_kernel<%s>: %d block(s) per CU resident, the fused row update + c_attn launch needs %d -- off for this engine\n",
+            wide ? "9, true" : "4, false", have, want);
+    return false;
 }
 int launch_rowln_cattn(const RowUpdateArgs& ru, const SkinnyArgs& sk, int* err, int spin_ticks, hipStream_t st, int delay, long long* dbg, int layer, int num_cus) {
     const int KS = sk.K / 16, NT = sk.Npad / 32;

@@ -194,6 +194,8 @@ __device__ WarpStats row_warp_stats_regs(F sc, int V, int top_k, float top_p, in
 struct WarpSelSmem {
     uint32_t key[WS_CAP];
     float p[WS_CAP];
+    int idx[WS_CAP];                 // column of candidate c (beam-sample folds its top-K selection onto the candidates: beam.hip)
+    int n_cand;
     int hist[256];
     int wtot[WP_THREADS / 64];
     uint32_t sel_key;
@@ -297,7 +299,8 @@ __device__ bool row_warp_stats_select(F sc, int V, int top_k, float top_p, int m
         int q = off;
 #pragma unroll
         for (int j = 0; j < NPT; ++j)
-            if (v[j] >= T0) sm.key[q++] = wp_key(v[j]);
+            if (v[j] >= T0) { sm.key[q] = wp_key(v[j]); sm.idx[q] = tid + j * WP_THREADS; ++q; }
+        if (tid == 0) sm.n_cand = n;
     }
     __syncthreads();
     if (tid < n) {

@@ -1084,6 +1084,22 @@ def test_folded_greedy_selection_equals_the_argmax_launch_token_for_token():
     eng.close()
 
 
+def test_fused_row_update_launch_blocks_resident_per_cu():
+    """the fused row update + c_attn launch waits on blocks of its own grid -- the narrow form (StarVector-1B) needs two blocks per CU
+    resident, the wide form's (StarVector-8B) first round is three per CU.  That is the compiler's register allocation, not host arithmetic:
+    sv_create asks the runtime (hipOccupancyMaxActiveBlocksPerMultiprocessor) and turns the launch off below that; here the numbers are pinned."""
+    import ctypes as C
+    from starvector_amd import _lib
+    lib = _lib.load()
+    got = {}
+    for wide in (0, 1):
+        n = C.c_int32(0)
+        assert lib.sv_debug_rowln_occupancy(wide, C.byref(n)) == 0
+        got[wide] = n.value
+    print(f"[rowln_cattn occupancy] blocks per CU: narrow {got[0]}, wide {got[1]}")
+    assert got[0] >= 2 and got[1] >= 3
+
+
 def test_row_update_and_c_attn_as_one_launch_bit_for_bit():
     """Round 5 (rowops.hip rowln_cattn_kernel, SV_EXP bit 16384 on a non-exclusive engine): the row update and the c_attn projection
     behind it as ONE launch -- 32 row blocks publish the LayerNorm output with write-through stores, the 288 GEMM blocks hold their
