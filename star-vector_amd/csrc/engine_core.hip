@@ -519,6 +519,8 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     e->d_nemit = e->d_step + 2;
     e->d_bad = e->d_step + 3;         // raised by the selection kernels when a row has no finite logit
     A(dalloc(e, &e->d_stop, 64));
+    A(dalloc(e, &e->tail_ws, (size_t)SV_TAIL_TILES * 4 * 16 * 64));
+    A(dalloc(e, &e->tail_cnt, (size_t)SV_TAIL_TILES));          // zeroed: the tickets re-arm themselves
 
     e->page_bytes = kv_page_bytes(dh);
     e->pages_per_seq = (c.max_seq_len + SV_PAGE_TOKENS - 1) / SV_PAGE_TOKENS;

@@ -351,7 +351,8 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
             a.xcd_remap = (!(e->exp & 16) && MT == 1 && l.splitk > 1 && 8 % l.splitk == 0 && (NT * l.splitk) % 8 == 0 &&
                            NT % (8 / l.splitk) == 0) ? 1 : 0;
         }
-        else if (out_mode == SK_OUT_PACKED_ACT) { a.splitk = 1; a.bias = l.bias; a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16; }
+        else if (out_mode == SK_OUT_PACKED_ACT) { a.splitk = 1; a.bias = l.bias; a.act = ACT_GELU_TANH; a.out_xp = e->xp_mlp; a.out_KS = F / 16;
+                                                  a.tail_ws = e->tail_ws; a.tail_cnt = e->tail_cnt; }
         else {
             a.splitk = 1; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1;
             if (e->greedy_fused) { a.amax = e->amax; a.amax_rows = B; }      // greedy selection inside the lm_head launch (sv_generate)

@@ -589,7 +589,15 @@ extern "C" int sv_op_linear_skinny_epi(const void* x, const void* W, const void*
     memset(&a, 0, sizeof(a));
     a.xp = xp; a.Wp = Wp; a.MT = MT; a.Npad = Npad; a.K = K; a.splitk = 1; a.N = N;
     if (out_f32) { a.out_mode = SK_OUT_F32; a.out_f32 = of; a.ldo = Npad; a.round_bf16 = 1; }
-    else { a.out_mode = SK_OUT_PACKED_ACT; a.bias = (const bf16_t*)bias; a.act = act; a.out_xp = oxp; a.out_KS = Npad / 16; }
+    else {
+        a.out_mode = SK_OUT_PACKED_ACT; a.bias = (const bf16_t*)bias; a.act = act; a.out_xp = oxp; a.out_KS = Npad / 16;
+        // the engine's scratch for the tiles beyond the first round of blocks (gemm_skinny_tailsplit_kernel; taken only where launch_gemm_skinny's rule says so)
+        float* tws; unsigned* tcnt;
+        SVCHECK(tmp.get(&tws, (size_t)SV_TAIL_TILES * 4 * 16 * 64));
+        SVCHECK(tmp.get(&tcnt, (size_t)SV_TAIL_TILES));
+        HIPCHECK(hipMemsetAsync(tcnt, 0, (size_t)SV_TAIL_TILES * sizeof(unsigned), st));
+        a.tail_ws = tws; a.tail_cnt = tcnt;
+    }
     launch_gemm_skinny(a, st);
     if (out_f32) HIPCHECK(hipMemcpy2DAsync(y, (size_t)N * 4, of, (size_t)Npad * 4, (size_t)N * 4, M, hipMemcpyDeviceToDevice, st));
     else unpack_rows(oxp, (bf16_t*)y, N, M, N, st);

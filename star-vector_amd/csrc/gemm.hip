@@ -1730,6 +1730,90 @@ __global__ __launch_bounds__(512) void gemm_head_persist_kernel(const bf16_t* Wp
         }
     }
 }
+// ------------------------------------------------------------------------------------------------
+// gemm_skinny_tailsplit_kernel (round 6, fourth session): the column tiles of a whole-K skinny GEMM that do not fit the first round of blocks.
+// StarVector-8B's c_fc at <= 32 rows is 576 one-tile blocks on 512 block slots (two 8-wave blocks per CU): the second "round" is 64 blocks that each stream
+// 288 KiB alone (~30 GB/s per lone CU): ~10 of the launch's 36 us for 11 % of its bytes (rocprof by grid, profiles/rocprof_r06_8b_im2svg_by_grid.csv).
+// Here the first 512 tiles stay one launch of the ordinary kernel and the T left-over tiles go to 4 T blocks of this one: block (tile, q) takes the q-th
+// quarter of K (8 waves x KS / 32 k-steps, all requested up front), reduces across its waves as the ordinary kernel does, leaves its 32 x 32 fp32 partial in
+// the engine's scratch through write-through stores and draws an arrival ticket; the last of the four sums the partials in q order and runs the epilogue
+// (bias + activation -> packed activations).  The hand-off is the decode attention's (sc1 stores, every wave drains, one relaxed agent-scope ticket, sc1 loads
+// in the last arriver, ticket re-armed): no fences, nobody waits.  The sum order of those tiles' columns is (quarter, wave) instead of wave: other roundings
+// than the one-tile kernel for T / n_tiles of the columns, the same for every batch <= 32 (one kernel, one order: batch-independent).
+// ------------------------------------------------------------------------------------------------
+template <int KPW>                                           // k-steps per wave (KS / 32): 9 for StarVector-8B
+__global__ __launch_bounds__(512) void gemm_skinny_tailsplit_kernel(const bf16_t* Wp_, const bf16_t* xp_, int KS_, int tile0_, int flags_, SkinnyArgs p_unused) {
+    constexpr int WAVES = 8, RPW = 2;
+    extern __shared__ __attribute__((aligned(16))) char sk_smem[];
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(sk_smem);          // [WAVES][16][64]
+    __shared__ int last_s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int m = lane & 31, half = lane >> 5;
+    const int tt = blockIdx.x >> 2, q = blockIdx.x & 3;        // left-over tile, K quarter
+    const int nt = tile0_ + tt, KS = KS_;
+    const int ks0 = q * (KS >> 2) + wave * KPW;
+    (void)flags_;
+    const u32x4* wptr = reinterpret_cast<const u32x4*>(Wp_) + ((size_t)nt * KS + ks0) * 64 + lane;
+    const u32x4* xptr = reinterpret_cast<const u32x4*>(xp_) + (size_t)ks0 * 64 + lane;
+    u32x4 w[KPW], x[KPW];
+#pragma unroll
+    for (int u = 0; u < KPW; ++u) w[u] = __builtin_nontemporal_load(wptr + (size_t)u * 64);
+#pragma unroll
+    for (int u = 0; u < KPW; ++u) x[u] = xptr[(size_t)u * 64];
+    SkinnyArgs p = sv_late_args<SkinnyArgs>(offsetof(SkinnyKernarg, p));
+    float bias_d[RPW];
+    sk_bias<RPW>(p, bias_d, wave * RPW, nt, half);
+    sk_settle<RPW>(bias_d);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int u = 0; u < KPW; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(as_frag4(w[u]), as_frag4(x[u]), acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][r][lane] = acc[r];
+    __syncthreads();
+    float v[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = wave * RPW + i;
+        float t = red[0][r][lane];
+#pragma unroll
+        for (int g = 1; g < WAVES; ++g) t += red[g][r][lane];
+        v[i] = t;
+    }
+    // partial of (tile, quarter): [16 accumulator rows][64 lanes] floats, write-through; every wave drains, then one ticket per block
+    const unsigned bytes = (unsigned)SV_TAIL_TILES * 4u * 16u * 64u * 4u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.tail_ws, 0, bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = wave * RPW + i;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[i]), rs, (int)(((((unsigned)tt * 4u + (unsigned)q) * 16u + (unsigned)r) * 64u + (unsigned)lane) * 4u), 0, 16);     // sc1
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(p.tail_cnt + tt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_s = t == 3u ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last_s) return;
+    float part[RPW][4];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int r = wave * RPW + i;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            part[i][g] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)(((((unsigned)tt * 4u + (unsigned)g) * 16u + (unsigned)r) * 64u + (unsigned)lane) * 4u), 0, 16));   // sc1: L1 bypass
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) v[i] = ((part[i][0] + part[i][1]) + part[i][2]) + part[i][3];          // quarter order
+    if (tid == 0) __hip_atomic_store(p.tail_cnt + tt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // re-arm
+    sk_store<RPW>(p, v, bias_d, wave * RPW, nt, 0, 0, m, half);
+}
+std::atomic<int> g_tailsplit{1};
+void set_tailsplit(int on) { g_tailsplit = on; }
+
 std::atomic<int> g_head_persist{1};     // 1: the lm_head of a one-row-tile step through gemm_head_persist_kernel where it applies; 0: the one-tile kernel (A/B)
 void set_head_persist(int on) { g_head_persist = on; }
 // false: outside the kernel's scope
@@ -2638,10 +2722,32 @@ void skinny_plan(int Npad, int K, int splitk, int fp8, int MT, int* waves, int* 
     *two_row_tiles = (MT >= 2 && !(MT & 1) && (w == 8 || w == 4) && KS % splitk == 0) ? 1 : 0;
 }
 
+// false: outside the scope of the tail split (see gemm_skinny_tailsplit_kernel)
+static bool launch_skinny_tailsplit(const SkinnyArgs& a, hipStream_t st) {
+    const char* ev = getenv("SV_TAILSPLIT");                 // read per call (A/B in one process; a captured graph keeps its choice)
+    const int on = ev ? atoi(ev) : g_tailsplit.load(std::memory_order_relaxed);
+    if (!on || !a.tail_ws || !a.tail_cnt) return false;
+    if (a.out_mode != SK_OUT_PACKED_ACT || a.MT != 1 || a.Wq || a.fold_c1 || a.splitk != 1) return false;
+    const int KS = a.K / 16, n_tiles = a.Npad / 32;
+    if (KS % 32 || KS / 32 != 9 || skinny_waves(a.Npad, KS, 1) != 8) return false;      // the one instantiation: 9 k-steps per wave and quarter (K = 4608)
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return false;
+        cus = pr.multiProcessorCount;
+    }
+    const int slots = 2 * cus, T = n_tiles - slots;           // two 8-wave blocks of the ordinary kernel per CU
+    if (T <= 0 || T > SV_TAIL_TILES || 4 * T > slots) return false;
+    gemm_skinny_kernel<8, false><<<dim3(slots, 1, 1), 512, skinny_smem(8), st>>>(a.Wp, a.xp, KS, KS, 0, a);
+    gemm_skinny_tailsplit_kernel<9><<<4 * T, 512, 8 * 16 * 64 * 4, st>>>(a.Wp, a.xp, KS, slots, 0, a);
+    return true;
+}
+
 void launch_gemm_skinny(const SkinnyArgs& a, hipStream_t st) {
     if (launch_head_persist(a, st)) return;                      // the lm_head of a <= 32-row step: one round of blocks over several column tiles each
     if (launch_gemm_skinny_mt2(a, st)) return;                  // 33..64 rows: two row tiles per block, weights streamed once
     if (a.Wq && launch_gemm_skinny_fp8(a, st)) return;       // fp8 weights: its own kernel (falls through if unsupported)
+    if (launch_skinny_tailsplit(a, st)) return;                 // whole-K tiles beyond the first round of blocks: split four ways along K (StarVector-8B's c_fc)
     dim3 grid(a.Npad / 32, a.splitk, a.MT);
     switch (skinny_waves(a.Npad, a.K / 16, a.splitk)) {
         case 16: launch_sk<16>(a, grid, st); break;

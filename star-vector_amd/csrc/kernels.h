@@ -88,7 +88,12 @@ struct SkinnyArgs {
     // F32 mode (lm_head), one-row-tile bf16 kernel only: a buffer the launch fills with the 0xFFFF'FFFF pattern through write-through
     // stores, 16 bytes per thread (the LayerNorm output buffer of the fused row-update + c_attn launch of the NEXT decode step)
     void* poison; unsigned poison_bytes;
+    // PACKED_ACT, one row tile, whole K (StarVector-8B's c_fc: 576 column tiles on 512 block slots): the tiles beyond the first round of blocks are split four
+    // ways along K by a second launch whose blocks leave fp32 partials here and elect a last arriver through `tail_cnt` (gemm_skinny_tailsplit_kernel).
+    // Per-engine scratch: [SV_TAIL_TILES][4][16][64] floats + [SV_TAIL_TILES] zeroed counters; nullptr: off.
+    float* tail_ws; unsigned* tail_cnt;
 };
+#define SV_TAIL_TILES 128
 #define SV_AMAX_STRIDE 16          // one 128-byte line per row: the rows' atomics do not share an L2 line
 // key = (order-preserving image of the float) << 32 | (0xFFFFFFFF - column): larger value wins, equal values -> LOWER column wins
 // (torch.argmax / HF _sample's tie-break, sampling.hip argmax_pair); 0 = "no finite-or-infinite score seen" (NaN never wins).

@@ -298,6 +298,34 @@ def test_linear_skinny_fused_activation_epilogue(M, N, K, act):
     assert torch.equal(got, E.op_linear_skinny_epi(bf(x), bf(W), bf(b), act=act))
 
 
+def test_linear_skinny_tail_tiles_split_along_k(monkeypatch):
+    """StarVector-8B's c_fc at <= 32 rows is 576 column tiles on 512 block slots: the 64 tiles beyond the first round go to
+    gemm_skinny_tailsplit_kernel (four K quarters per tile, fp32 partials, last arriver runs the epilogue).  The first 512 tiles are
+    the one-tile kernel's bits; the split tiles sum in (quarter, wave) order: inside the same tolerance against the fp32 reference,
+    the same bits at every batch <= 32, and the arrival tickets re-arm themselves (a second call gives the same bits).
+    Reference op: /root/reference/starvector/model/llm/starcoder2.py:12-61 (the HF Starcoder2 MLP's c_fc + gelu_pytorch_tanh)."""
+    M, N, K = 32, 18432, 4608
+    if torch.cuda.get_device_properties(0).multi_processor_count != 256:
+        pytest.skip("the split is sized on 2 x 256 block slots")
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).bfloat16().float()
+    W = (torch.randn(N, K, generator=g) / K ** 0.5).bfloat16().float()
+    b = (0.1 * torch.randn(N, generator=g)).bfloat16().float()
+    y = torch.nn.functional.gelu((x @ W.T + b).bfloat16().float(), approximate="tanh")
+    monkeypatch.setenv("SV_TAILSPLIT", "0")
+    one = E.op_linear_skinny_epi(bf(x), bf(W), bf(b), act="gelu_tanh")
+    monkeypatch.setenv("SV_TAILSPLIT", "1")
+    got = E.op_linear_skinny_epi(bf(x), bf(W), bf(b), act="gelu_tanh")
+    first = 512 * 32
+    assert torch.equal(got[:, :first], one[:, :first])
+    assert not torch.equal(got[:, first:], one[:, first:]), "the split launch did not run (same bits as the one-tile kernel on 64 tiles)"
+    assert rel_err(got, y) <= 2.2 * BF16_1ULP and mean_err(got, y) <= 1.5e-3
+    assert rel_err(got[:, first:], one[:, first:].float()) <= 2.2 * BF16_1ULP
+    assert torch.equal(got, E.op_linear_skinny_epi(bf(x), bf(W), bf(b), act="gelu_tanh"))
+    for m in (1, 7):
+        assert torch.equal(E.op_linear_skinny_epi(bf(x[:m]), bf(W), bf(b), act="gelu_tanh"), got[:m])
+
+
 @pytest.mark.parametrize("M,V,K", [(32, 49156, 2048), (3, 1000, 256), (64, 49157, 4608)])
 def test_linear_skinny_logits_epilogue(M, V, K):
     """The lm_head form: fp32 rows holding bf16-rounded values (HF casts the bf16 logits to float before the argmax)."""
