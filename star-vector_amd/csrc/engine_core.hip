@@ -521,6 +521,7 @@ extern "C" int sv_create(const sv_config* cfg, sv_engine** out) {
     A(dalloc(e, &e->d_stop, 64));
     A(dalloc(e, &e->tail_ws, (size_t)SV_TAIL_TILES * 4 * 16 * 64));
     A(dalloc(e, &e->tail_cnt, (size_t)SV_TAIL_TILES));          // zeroed: the tickets re-arm themselves
+    A(dalloc(e, &e->fin_cnt, 64));                               // zeroed: SkinnyArgs::fin_cnt
 
     e->page_bytes = kv_page_bytes(dh);
     e->pages_per_seq = (c.max_seq_len + SV_PAGE_TOKENS - 1) / SV_PAGE_TOKENS;

@@ -356,10 +356,12 @@ void sveng::decode_forward(sv_engine* e, int B, hipStream_t st) {
         else {
             a.splitk = 1; a.out_f32 = e->logits; a.ldo = e->Vpad; a.round_bf16 = 1;
             if (e->greedy_fused) { a.amax = e->amax; a.amax_rows = B; }      // greedy selection inside the lm_head launch (sv_generate)
+            if (e->greedy_fused && e->fin_fold) { a.finish = &e->fin_args; a.fin_cnt = e->fin_cnt; }     // ... and the step's bookkeeping behind it
                     if (rc_enabled(e) && MT == 1 && xp != e->xp_a) { a.poison = e->xp_a; a.poison_bytes = xpa_bytes; }      // the next step's layer 0
             if (!e->skip_skinny) e->xpa_armed = a.poison != nullptr && lm_head_covers(e, xpa_bytes);
         }
         if (e->skip_skinny) return;
+        if (out_mode == SK_OUT_F32) e->fin_folded = skinny_head_folds_finish(a);
         prof_mark(e, PK_SKINNY, st);
         launch_gemm_skinny(a, st);
     };

@@ -5,7 +5,21 @@
 // sample from e->logits into next_tok, then the bookkeeping kernel
 // fused: the lm_head launch in front has already left every row's best (value, lowest index) in e->amax (gemm.hip, SkinnyArgs::amax):
 // no argmax launch, finish_step_kernel decodes the keys
+static FinishArgs make_finish_args(sv_engine* e, int B, const sv_sampling& sp, int max_new, bool fused) {
+    const bool pen = sp.repetition_penalty > 0.f && sp.repetition_penalty != 1.0f;
+    FinishArgs f;
+    f.pval = sp.do_sample ? nullptr : e->am_val; f.pidx = sp.do_sample ? nullptr : e->am_idx;
+    f.amax = fused ? e->amax : nullptr;
+    f.next = e->next_tok; f.cur_tok = e->cur_tok; f.unfinished = e->unfinished; f.positions = e->positions;
+    f.out_tokens = e->out_tok; f.ld_out = e->out_ld; f.step = e->d_step; f.done = e->d_done; f.n_emitted = e->d_nemit;
+    f.stop_ids = e->d_stop; f.n_stop = sp.n_stop; f.eos = sp.eos_token_id; f.pad = sp.pad_token_id; f.B = B;
+    f.max_new = max_new;
+    f.seen = pen ? e->seen : nullptr; f.seen_words = e->seen_words;
+    f.V = e->cfg.vocab; f.bad = e->d_bad;
+    return f;
+}
 static void sample_and_finish(sv_engine* e, int B, const sv_sampling& sp, int max_new, hipStream_t st, bool fused = false) {
+    if (fused && e->fin_folded) { e->fin_folded = false; return; }      // the lm_head launch in front did the selection AND the bookkeeping (SkinnyArgs::finish)
     const bool pen = sp.repetition_penalty > 0.f && sp.repetition_penalty != 1.0f;
     const uint32_t* seen = pen ? e->seen : nullptr;
     if (sp.min_new_tokens > 0 && sp.eos_token_id >= 0 && sp.eos_token_id < e->cfg.vocab)
@@ -20,15 +34,7 @@ static void sample_and_finish(sv_engine* e, int B, const sv_sampling& sp, int ma
         launch_argmax_partial(e->logits, e->Vpad, e->cfg.vocab, e->am_val, e->am_idx, B, seen, e->seen_words,
                               sp.repetition_penalty, st);
     }
-    FinishArgs f;
-    f.pval = sp.do_sample ? nullptr : e->am_val; f.pidx = sp.do_sample ? nullptr : e->am_idx;
-    f.amax = fused ? e->amax : nullptr;
-    f.next = e->next_tok; f.cur_tok = e->cur_tok; f.unfinished = e->unfinished; f.positions = e->positions;
-    f.out_tokens = e->out_tok; f.ld_out = e->out_ld; f.step = e->d_step; f.done = e->d_done; f.n_emitted = e->d_nemit;
-    f.stop_ids = e->d_stop; f.n_stop = sp.n_stop; f.eos = sp.eos_token_id; f.pad = sp.pad_token_id; f.B = B;
-    f.max_new = max_new;
-    f.seen = pen ? e->seen : nullptr; f.seen_words = e->seen_words;
-    f.V = e->cfg.vocab; f.bad = e->d_bad;
+    const FinishArgs f = make_finish_args(e, B, sp, max_new, fused);
     launch_finish_step(f, st);
 }
 
@@ -285,8 +291,13 @@ static int generate_attempt(sv_engine* e, const void* dev_embeds, int32_t B, int
         HIPCHECK(hipMemcpyAsync(e->d_stop, sp->stop_ids, sp->n_stop * sizeof(int32_t), hipMemcpyHostToDevice, st));
     }
     sample_and_finish(e, B, *sp, max_new, st);       // first token from the prefill logits
-    struct FusedSel { sv_engine* e; ~FusedSel() { e->greedy_fused = false; } } fused_guard{e};
-    if (fused_sel) e->greedy_fused = true;           // read by decode_forward (capture and eager launches below); cleared on every exit
+    struct FusedSel { sv_engine* e; ~FusedSel() { e->greedy_fused = false; e->fin_fold = false; e->fin_folded = false; } } fused_guard{e};
+    if (fused_sel) {
+        e->greedy_fused = true;                      // read by decode_forward (capture and eager launches below); cleared on every exit
+        const char* ff = getenv("SV_FINISH_FOLD");   // 0 = the bookkeeping as its own launch (A/B)
+        e->fin_fold = !(ff && atoi(ff) == 0);
+        e->fin_args = make_finish_args(e, B, *sp, max_new, true);
+    }
     // ONE copy of the device's {step, done, n_emitted, bad} block: a call that is over after its first token (budget 1, EOS) has everything
     // it needs from this round trip and takes no other before the tokens go out
     HIPCHECK(hipMemcpyAsync(&e->h_flags[8], e->d_step, 4 * sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -325,9 +336,9 @@ static int generate_attempt(sv_engine* e, const void* dev_embeds, int32_t B, int
         // stream, the benchmark), so a short request does not pay a 172-node capture + instantiate; a call with other
         // parameters replaces it.  Owned by the engine: no early return below can leak it.
         char key[256];
-        snprintf(key, sizeof(key), "B%d|n%d|ds%d|T%a|p%a|k%d|seed%llu|eos%d|pad%d|ns%d|rp%a|mn%d|x%d|fo%d", B, max_new, sp->do_sample,
+        snprintf(key, sizeof(key), "B%d|n%d|ds%d|T%a|p%a|k%d|seed%llu|eos%d|pad%d|ns%d|rp%a|mn%d|x%d|fo%d|ff%d", B, max_new, sp->do_sample,
                  sp->temperature, sp->top_p, sp->top_k, (unsigned long long)sp->seed, sp->eos_token_id, sp->pad_token_id, sp->n_stop,
-                 sp->repetition_penalty, sp->min_new_tokens, e->exp, e->fused_off ? 1 : 0);
+                 sp->repetition_penalty, sp->min_new_tokens, e->exp, e->fused_off ? 1 : 0, e->fin_fold ? 1 : 0);
         if (e->gen_gexec && e->gen_graph_key == key) {
             gexec = e->gen_gexec;
         } else {

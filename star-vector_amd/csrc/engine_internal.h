@@ -143,6 +143,9 @@ struct sv_engine {
     float *ws = nullptr, *ws2 = nullptr, *logits = nullptr, *sample_scratch = nullptr, *attn_part = nullptr;
     unsigned* attn_cnt = nullptr;
     float* am_val = nullptr; int32_t* am_idx = nullptr;
+    // the step's bookkeeping folded into the lm_head launch (SkinnyArgs::finish): set by sv_generate for the decode steps of a call whose selection is folded
+    // (greedy_fused), read by decode_forward; fin_folded = the lm_head launch just issued took the bookkeeping (sample_and_finish launches no finish_step_kernel)
+    FinishArgs fin_args; bool fin_fold = false, fin_folded = false; unsigned* fin_cnt = nullptr;
     float* tail_ws = nullptr; unsigned* tail_cnt = nullptr;      // SkinnyArgs::tail_ws / ::tail_cnt (gemm_skinny_tailsplit_kernel): partials + zeroed arrival tickets
     unsigned long long* amax = nullptr;   // greedy selection folded into the lm_head launch: one 64-bit key per row, [64 * SV_AMAX_STRIDE]
     bool greedy_fused = false;            //   on for the decode steps of the current sv_generate call (set and cleared by it)

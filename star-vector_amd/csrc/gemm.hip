@@ -1623,8 +1623,10 @@ __global__ __launch_bounds__(WAVES * 64) void gemm_skinny_kernel(const bf16_t* W
 // ------------------------------------------------------------------------------------------------
 //   MT = row tiles (1: <= 32 rows; 2: 33..64 rows -- both tiles' activation shares in registers, 128 VGPRs, every weight register feeds two MFMAs; the
 //        two-row-tile kernels' order: bit-identical to gemm_skinny_mt2x_kernel)
+struct HeadKernarg { const void* W; const bf16_t* x; int KS; int ks_per_split; int n_tiles; SkinnyArgs p; FinishArgs f; };      // the kernarg segment of gemm_head_persist_kernel
 template <int MT>
-__global__ __launch_bounds__(512) void gemm_head_persist_kernel(const bf16_t* Wp_, const bf16_t* xp_, int KS_, int ks_per_split_, int n_tiles_, SkinnyArgs p_unused) {
+__global__ __launch_bounds__(512) void gemm_head_persist_kernel(const bf16_t* Wp_, const bf16_t* xp_, int KS_, int ks_per_split_, int n_tiles_, SkinnyArgs p_unused,
+                                                                 FinishArgs f_unused) {
     constexpr int WAVES = 8, RPW = 2, KSW = 16;            // k-steps per wave: KS_ == WAVES * KSW (launcher)
     extern __shared__ __attribute__((aligned(16))) char sk_smem[];
     float (*red)[WAVES][16][64] = reinterpret_cast<float (*)[WAVES][16][64]>(sk_smem);          // [MT][WAVES][16][64]
@@ -1728,6 +1730,32 @@ __global__ __launch_bounds__(512) void gemm_head_persist_kernel(const bf16_t* Wp
             for (int q = 1; q < WAVES; ++q) { const unsigned long long o = key_s[q * 32 + m]; key = o > key ? o : key; }
             (void)__hip_atomic_fetch_max(p.amax + (size_t)m * SV_AMAX_STRIDE, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        if (p.fin_cnt) {
+            // The step's bookkeeping in this launch (SkinnyArgs::finish; fifth session of round 6): the key atomics of this block are acknowledged (vmcnt counts
+            // them on gfx9), the block draws a ticket, and the last of the grid -- every row's key is final -- decodes the keys and does what finish_step_kernel does,
+            // in its first wave (<= 32 rows).  The hand-off is the decode attention's: agent-scope atomics both ways, no fence, nobody waits.
+            __shared__ int fin_last;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) fin_last = __hip_atomic_fetch_add(p.fin_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1 : 0;
+            __syncthreads();
+            if (fin_last && wave == 0) {
+                if (lane == 0) __hip_atomic_store(p.fin_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // re-arm
+                const FinishArgs f = sv_late_args<FinishArgs>(offsetof(HeadKernarg, f));
+                if (!*f.done) {
+                    const int t = *f.step;
+                    int still = 0;
+                    if (lane < f.B) {
+                        unsigned long long* slot = f.amax + (size_t)lane * SV_AMAX_STRIDE;
+                        const int nxt = sv_amax_index(__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                        __hip_atomic_store(slot, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        still = finish_step_row(f, lane, t, nxt);
+                    }
+                    const int any_unf = __ballot(still) != 0ull;
+                    if (lane == 0) finish_step_call(f, t, any_unf);
+                }
+            }
+        }
     }
 }
 // ------------------------------------------------------------------------------------------------
@@ -1817,25 +1845,42 @@ void set_tailsplit(int on) { g_tailsplit = on; }
 std::atomic<int> g_head_persist{1};     // 1: the lm_head of a one-row-tile step through gemm_head_persist_kernel where it applies; 0: the one-tile kernel (A/B)
 void set_head_persist(int on) { g_head_persist = on; }
 // false: outside the kernel's scope
-static bool launch_head_persist(const SkinnyArgs& a, hipStream_t st) {
+// G = blocks of the persistent lm_head launch for `a`; 0: outside the kernel's scope
+static int head_persist_grid(const SkinnyArgs& a) {
     const char* ev = getenv("SV_HEAD_PERSIST");             // read per call (A/B in one process; a captured graph keeps its choice)
     const int env = ev ? atoi(ev) : -1;
     const int on = env >= 0 ? env : g_head_persist.load(std::memory_order_relaxed);
-    if (!on) return false;
+    if (!on) return 0;
     const int n_tiles = a.Npad / 32;
-    if (a.out_mode != SK_OUT_F32 || a.MT < 1 || a.MT > 2 || a.Wq || a.splitk != 1 || a.K / 16 != 128 || n_tiles < 512 || a.fold_c1) return false;
-    if (a.MT == 2 && (a.amax || a.poison)) return false;      // (the folded selection and the pattern stores belong to one-row-tile steps)
-    if (a.N <= (n_tiles - 1) * 32 || a.N > n_tiles * 32) return false;
+    if (a.out_mode != SK_OUT_F32 || a.MT < 1 || a.MT > 2 || a.Wq || a.splitk != 1 || a.K / 16 != 128 || n_tiles < 512 || a.fold_c1) return 0;
+    if (a.MT == 2 && (a.amax || a.poison)) return 0;      // (the folded selection and the pattern stores belong to one-row-tile steps)
+    if (a.N <= (n_tiles - 1) * 32 || a.N > n_tiles * 32) return 0;
     static int cus = 0;
     if (!cus) {
         int dev = 0; hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return false;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return 0;
         cus = pr.multiProcessorCount;
     }
     const int G = cus < n_tiles ? cus : n_tiles;
-    if (a.poison && (size_t)G * 512 * 16 < a.poison_bytes) return false;      // the pattern stores are 16 bytes per thread of the grid
-    if (a.MT == 2) gemm_head_persist_kernel<2><<<G, 512, 2 * 8 * 16 * 64 * 4 + 8 * 32 * 8, st>>>(a.Wp, a.xp, a.K / 16, a.K / 16, n_tiles, a);
-    else gemm_head_persist_kernel<1><<<G, 512, 8 * 16 * 64 * 4 + 8 * 32 * 8, st>>>(a.Wp, a.xp, a.K / 16, a.K / 16, n_tiles, a);
+    if (a.poison && (size_t)G * 512 * 16 < a.poison_bytes) return 0;      // the pattern stores are 16 bytes per thread of the grid
+    return G;
+}
+// true: the lm_head launch of `a` runs the step's bookkeeping itself (SkinnyArgs::finish) -- the caller launches no finish_step_kernel
+bool skinny_head_folds_finish(const SkinnyArgs& a) {
+    return a.finish && a.fin_cnt && a.amax && a.MT == 1 && a.finish->B <= 32 && a.finish->amax == a.amax && head_persist_grid(a) > 0;
+}
+// false: outside the kernel's scope
+static bool launch_head_persist(const SkinnyArgs& a_, hipStream_t st) {
+    const int G = head_persist_grid(a_);
+    if (!G) return false;
+    SkinnyArgs a = a_;
+    FinishArgs f;
+    memset(&f, 0, sizeof(f));
+    if (skinny_head_folds_finish(a)) f = *a.finish; else a.fin_cnt = nullptr;
+    a.finish = nullptr;                                         // (a host address: nothing for the device)
+    const int n_tiles = a.Npad / 32;
+    if (a.MT == 2) gemm_head_persist_kernel<2><<<G, 512, 2 * 8 * 16 * 64 * 4 + 8 * 32 * 8, st>>>(a.Wp, a.xp, a.K / 16, a.K / 16, n_tiles, a, f);
+    else gemm_head_persist_kernel<1><<<G, 512, 8 * 16 * 64 * 4 + 8 * 32 * 8, st>>>(a.Wp, a.xp, a.K / 16, a.K / 16, n_tiles, a, f);
     return true;
 }
 

@@ -92,7 +92,13 @@ struct SkinnyArgs {
     // ways along K by a second launch whose blocks leave fp32 partials here and elect a last arriver through `tail_cnt` (gemm_skinny_tailsplit_kernel).
     // Per-engine scratch: [SV_TAIL_TILES][4][16][64] floats + [SV_TAIL_TILES] zeroed counters; nullptr: off.
     float* tail_ws; unsigned* tail_cnt;
+    // The step's bookkeeping (finish_step_kernel) folded into the lm_head launch of a greedy step whose selection is folded already (`amax`; persistent-block
+    // kernel only): every block drains its key atomics and draws a ticket from `fin_cnt` (zeroed, re-armed by the last arriver); the last block's first wave
+    // decodes the keys and runs the bookkeeping.  `finish` is a HOST pointer read by the launcher (the struct rides behind SkinnyArgs in that kernel's
+    // arguments); nullptr: off.  skinny_head_folds_finish(a) tells the caller whether the launch takes the bookkeeping with it.
+    const struct FinishArgs* finish; unsigned* fin_cnt;
 };
+bool skinny_head_folds_finish(const SkinnyArgs& a);
 #define SV_TAIL_TILES 128
 #define SV_AMAX_STRIDE 16          // one 128-byte line per row: the rows' atomics do not share an L2 line
 // key = (order-preserving image of the float) << 32 | (0xFFFFFFFF - column): larger value wins, equal values -> LOWER column wins
@@ -301,6 +307,38 @@ struct FinishArgs {
                                   // fed to the next step is then 0, never an out-of-range row of the embedding table
 };
 void launch_finish_step(const FinishArgs& a, hipStream_t st);
+#ifdef __HIPCC__
+// the per-row part of the bookkeeping (row b takes token `nxt` at step t): returns whether the row is still generating
+__device__ __forceinline__ int finish_step_row(const FinishArgs& p, int b, int t, int nxt) {
+    const int unf = p.unfinished[b];
+    if (unf && (unsigned)nxt >= (unsigned)p.V) {     // no finite logit in this row: never index the embedding table with it
+        nxt = 0;
+        if (p.bad) atomicCAS(p.bad, 0, 1);          // 0 -> 1 only: a code already there (3 = the fused MLP launch gave up) survives
+    }
+    const int tok = unf ? nxt : p.pad;
+    p.out_tokens[(size_t)b * p.ld_out + t] = tok;
+    p.cur_tok[b] = tok;
+    if (p.seen && tok >= 0) atomicOr(p.seen + (size_t)b * p.seen_words + (tok >> 5), 1u << (tok & 31));
+    const int still = unf && tok != p.eos;
+    p.unfinished[b] = still;
+    p.positions[b] += 1;
+    return still;
+}
+// the call's part (one thread, after every row's): stop sequence on row 0, step counter, end of generation
+__device__ __forceinline__ void finish_step_call(const FinishArgs& p, int t, int any_unf) {
+    bool fired = false;
+    if (p.n_stop > 0 && t + 1 >= p.n_stop) {
+        fired = true;
+        for (int i = 0; i < p.n_stop; ++i)
+            if (p.out_tokens[t + 1 - p.n_stop + i] != p.stop_ids[i]) { fired = false; break; }
+    }
+    *p.step = t + 1;
+    if (fired || !any_unf || t + 1 >= p.max_new) {
+        *p.done = 1;
+        *p.n_emitted = t + 1;
+    }
+}
+#endif
 
 // ---- continuous batching: one request per row ("slot"), everything per row (sampling.hip) ---------------------------
 #define SV_CB_MAXSTOP 16

@@ -370,7 +370,6 @@ __global__ void finish_step_kernel(FinishArgs p) {
     if (b == 0) any_unf = 0;
     __syncthreads();
     if (b < p.B) {
-        const int unf = p.unfinished[b];
         int nxt;
         if (p.amax) {                       // greedy, selection folded into the lm_head launch: decode the row's key, re-arm the slot
             unsigned long long* slot = p.amax + (size_t)b * SV_AMAX_STRIDE;
@@ -383,33 +382,10 @@ __global__ void finish_step_kernel(FinishArgs p) {
         } else {
             nxt = p.next[b];
         }
-        if (unf && (unsigned)nxt >= (unsigned)p.V) {     // no finite logit in this row: never index the embedding table with it
-            nxt = 0;
-            if (p.bad) atomicCAS(p.bad, 0, 1);          // 0 -> 1 only: a code already there (3 = the fused MLP launch gave up) survives
-        }
-        const int tok = unf ? nxt : p.pad;
-        p.out_tokens[(size_t)b * p.ld_out + t] = tok;
-        p.cur_tok[b] = tok;
-        if (p.seen && tok >= 0) atomicOr(p.seen + (size_t)b * p.seen_words + (tok >> 5), 1u << (tok & 31));
-        const int still = unf && tok != p.eos;
-        p.unfinished[b] = still;
-        p.positions[b] += 1;
-        if (still) atomicOr(&any_unf, 1);
+        if (finish_step_row(p, b, t, nxt)) atomicOr(&any_unf, 1);
     }
     __syncthreads();
-    if (b == 0) {
-        bool fired = false;
-        if (p.n_stop > 0 && t + 1 >= p.n_stop) {
-            fired = true;
-            for (int i = 0; i < p.n_stop; ++i)
-                if (p.out_tokens[t + 1 - p.n_stop + i] != p.stop_ids[i]) { fired = false; break; }
-        }
-        *p.step = t + 1;
-        if (fired || !any_unf || t + 1 >= p.max_new) {
-            *p.done = 1;
-            *p.n_emitted = t + 1;
-        }
-    }
+    if (b == 0) finish_step_call(p, t, any_unf);
 }
 void launch_finish_step(const FinishArgs& a, hipStream_t st) {
     int threads = ((a.B + 63) / 64) * 64;

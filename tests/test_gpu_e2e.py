@@ -1084,6 +1084,54 @@ def test_folded_greedy_selection_equals_the_argmax_launch_token_for_token():
     eng.close()
 
 
+def test_step_bookkeeping_inside_the_lm_head_launch_equals_the_finish_launch(monkeypatch):
+    """Round 6, fifth session: a greedy step whose selection rides in the persistent lm_head launch also does its bookkeeping there (the
+    last block of the grid, elected by a ticket, decodes the keys and runs what finish_step_kernel runs: tokens out, EOS / pad, the stop
+    sequence on row 0, the step counter, the end of the call) -- one launch less per step.  SV_FINISH_FOLD=0 puts the launch back: the
+    streams must be IDENTICAL, with rows ending at different steps, with a stop sequence that fires inside a multi-step graph, at batches
+    1 / 5 / 32, over repeated calls (the ticket and the key slots re-arm).  The reference semantics: HF generate's _sample bookkeeping
+    (transformers generation/utils.py) under /root/reference/starvector/model/models/starvector_base.py:223-241."""
+    import starvector_amd as sva
+    B = 32
+    eng = sva.HipEngine(sva.EngineConfig(max_batch=B, max_seq_len=259 + 200))
+    eng.load_random_weights(seed=13)
+    g = torch.Generator().manual_seed(9)
+    img = torch.randn(B, 3, 224, 224, generator=g).to(torch.bfloat16).to(dev())
+    prompt = torch.tensor([[7, 11]] * B, dtype=torch.long, device=dev())
+    emb = torch.cat([eng.adapter(eng.encode_image(img)), eng.embed_tokens(prompt)], 1)
+    S0 = emb.shape[1]
+    kw = dict(max_length=S0 + 170, pad_token_id=49152)
+    monkeypatch.setenv("SV_FINISH_FOLD", "0")
+    ref = eng.generate(emb, eos_token_id=-1, **kw).cpu()
+    n_unfolded = eng.step_plan()["graph_kernel_nodes"]
+    t_eos = next(t for t in range(20, 160) if int(ref[3, t]) not in ref[3, :t].tolist())
+    eos = int(ref[3, t_eos])
+    r0 = ref[0].tolist()                                        # a pair row 0 emits for the first time at some step >= 60 (random-init rows repeat tokens)
+    t_stop = next(t for t in range(60, 160) if all((r0[u], r0[u + 1]) != (r0[t], r0[t + 1]) for u in range(t)))
+    stop = [r0[t_stop], r0[t_stop + 1]]
+    ref_eos = eng.generate(emb, eos_token_id=eos, **kw).cpu()
+    ref_stop = eng.generate(emb, eos_token_id=-1, stop_ids=stop, **kw).cpu()
+    ref5 = eng.generate(emb[:5].contiguous(), eos_token_id=eos, **kw).cpu()
+    ref1 = eng.generate(emb[:1].contiguous(), eos_token_id=-1, **kw).cpu()
+    monkeypatch.setenv("SV_FINISH_FOLD", "1")
+    for rep in range(2):
+        got = eng.generate(emb, eos_token_id=-1, **kw).cpu()
+        assert eng.last_timing()["graph"] and eng.step_plan()["greedy_in_lm_head"]
+        assert eng.step_plan()["graph_kernel_nodes"] == n_unfolded - 1, "the bookkeeping launch is still in the captured step"
+        assert torch.equal(got, ref)
+        assert torch.equal(eng.generate(emb, eos_token_id=eos, **kw).cpu(), ref_eos)
+        assert torch.equal(eng.generate(emb, eos_token_id=-1, stop_ids=stop, **kw).cpu(), ref_stop)
+        assert torch.equal(eng.generate(emb[:5].contiguous(), eos_token_id=eos, **kw).cpu(), ref5)
+        assert torch.equal(eng.generate(emb[:1].contiguous(), eos_token_id=-1, **kw).cpu(), ref1)
+    assert ref_stop.shape[1] == t_stop + 2, "the stop sequence did not end the call where row 0 completes it"
+    monkeypatch.setenv("SV_NO_GRAPH", "1")
+    assert torch.equal(eng.generate(emb, eos_token_id=eos, **kw).cpu(), ref_eos)
+    assert not eng.last_timing()["graph"]
+    print(f"[finish fold] {n_unfolded} -> {n_unfolded - 1} kernel nodes per captured step; streams identical (EOS at step {t_eos} of row 3, stop sequence "
+          f"ends the call after {ref_stop.shape[1]} of {ref.shape[1]} tokens)")
+    eng.close()
+
+
 def test_fused_row_update_launch_blocks_resident_per_cu():
     """the fused row update + c_attn launch waits on blocks of its own grid -- the narrow form (StarVector-1B) needs two blocks per CU
     resident, the wide form's (StarVector-8B) first round is three per CU.  That is the compiler's register allocation, not host arithmetic:
