@@ -400,7 +400,7 @@ def main():
                              "rowln_cattn_kernel<9, true> (ln_1 row update + c_attn in one launch) + gemm_skinny_kernel" if (is8b and rc_on) else
                              "gemm_skinny_kernel" if (is8b or args.weights != "bf16") else
                              "rowln_cattn_kernel (row update + c_attn in one launch) + gemm_cols_resid_kernel (attention output projection) + mlp_fused_kernel "
-                             "(c_fc and down projection in one launch) + gemm_head_persist_kernel (lm_head: one round of blocks over six column tiles each)"
+                             "(c_fc and down projection in one launch) + gemm_head_persist_kernel (lm_head: one round of blocks over six column tiles each; its last block also runs the greedy step's bookkeeping)"
                              if ec.exclusive_device else
                              "gemm_skinny_kernel (+ gemm_cols_resid_kernel for the attention output projection)") + f", {int(launches)} launches/step",
                          "achieved": round(achieved, 1) if achieved else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
